@@ -1,0 +1,236 @@
+/*
+ * t2d.h -- C ABI of libt2d_hip.so: the MI355X-native batched env.step() hot path
+ * for tactics2d (physics integrators + collision / out-of-bound / off-lane events).
+ *
+ * This is the drop-in boundary.  Every entry point is `extern "C"`, takes plain
+ * pointers / ints / sizes, returns an int status (0 = T2D_OK) and never throws.
+ * No torch types appear here; PyTorch only ever sees the raw device pointers
+ * returned by t2d_get_field().
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * the tactics2d repository root, v0.1.9rc3):
+ *
+ *   t2d_set_param_table   <- SingleTrackKinematics.__init__  physics/single_track_kinematics.py:62-124
+ *                            SingleTrackDynamics.__init__    physics/single_track_dynamics.py:58-138
+ *                            PointMass.__init__              physics/point_mass.py:33-81
+ *                            Vehicle/Cyclist/Pedestrian templates participant/element/participant_template.py:42-257
+ *   t2d_reset             <- ParticipantBase.reset / Trajectory.add_state   participant/trajectory/trajectory.py:115-149
+ *                            _ParkingScenarioManager.reset   envs/parking.py:397-441
+ *   t2d_integrate         <- PhysicsModelBase.step           physics/physics_model_base.py:28
+ *                            SingleTrackKinematics.step/_step physics/single_track_kinematics.py:126-198
+ *                            SingleTrackDynamics.step/_step  physics/single_track_dynamics.py:140-251
+ *                            PointMass.step/_step_newton     physics/point_mass.py:83-175,209-232
+ *   t2d_set_static_geometry <- StaticCollision.reset         traffic/event_detection/collision.py:45-46
+ *                            OutBound.reset                  traffic/event_detection/out_bound.py:50-65
+ *   t2d_set_lane_geometry <- OffLane.reset                   traffic/event_detection/off_lane.py:19-20
+ *   t2d_collide           <- Vehicle.get_pose                participant/element/vehicle.py:263-281
+ *                            StaticCollision.update          traffic/event_detection/collision.py:37-43
+ *                            DynamicCollision.update         traffic/event_detection/collision.py:18-25 (intended semantics)
+ *                            OutBound.update                 traffic/event_detection/out_bound.py:37-48
+ *                            OffLane.update                  traffic/event_detection/off_lane.py:16-17 (stub; build-defined)
+ *   t2d_step              <- _ParkingScenarioManager.update + check_status  envs/parking.py:352-392
+ *                            ParkingEnv.step terminated/truncated/reward    envs/parking.py:219-256,148-161
+ *                            TimeExceed.update               traffic/event_detection/time_exceed.py:26-33
+ *
+ * Threading: one host thread per pool.  t2d_integrate / t2d_collide / t2d_step are
+ * asynchronous on the supplied hipStream_t (passed as void*; NULL = the null stream).
+ * Nothing synchronises implicitly except t2d_download / t2d_upload / t2d_reset /
+ * t2d_sync / the t2d_set_* calls (which copy from host memory).
+ *
+ * Ownership: the pool owns every device buffer.  Host pointers passed in are read
+ * during the call and never retained.  Device pointers handed out by t2d_get_field
+ * stay valid until t2d_destroy.
+ */
+#ifndef T2D_H_
+#define T2D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2D_ABI_VERSION 1
+
+/* ---- status codes --------------------------------------------------------------- */
+#define T2D_OK            0
+#define T2D_ERR_INVALID   1   /* bad argument (null, out of range, inconsistent sizes)   */
+#define T2D_ERR_HIP       2   /* a HIP runtime call failed; see t2d_last_error           */
+#define T2D_ERR_NOMEM     3
+#define T2D_ERR_STATE     4   /* call order violated (e.g. step before param table)      */
+#define T2D_ERR_GEOMETRY  5   /* polygon not convex / degenerate / too many vertices     */
+
+/* ---- physics model ids (column T2D_P_MODEL of a parameter row) --------------------- */
+#define T2D_MODEL_KINEMATICS 0   /* SingleTrackKinematics */
+#define T2D_MODEL_DYNAMICS   1   /* SingleTrackDynamics   */
+#define T2D_MODEL_POINTMASS  2   /* PointMass, newton back-end */
+
+/* ---- shape kinds (column T2D_P_SHAPE) ---------------------------------------------- */
+#define T2D_SHAPE_OBB    0   /* Vehicle / Cyclist / Other: length x width box             */
+#define T2D_SHAPE_CIRCLE 1   /* Pedestrian: (centre, radius = width / 2)                  */
+
+/* ---- parameter-table row: T2D_PARAM_COLS doubles per participant type ---------------
+ * Ranges are ALREADY normalised by the host exactly like the reference constructors
+ * (A.1 in SURVEY.md); an unbounded range has its bit cleared in T2D_P_RANGE_FLAGS.  */
+enum {
+    T2D_P_MODEL = 0,       /* T2D_MODEL_*                                   */
+    T2D_P_LF = 1,
+    T2D_P_LR = 2,
+    T2D_P_WB = 3,          /* lf + lr, summed on the host like the reference */
+    T2D_P_STEER_LO = 4,
+    T2D_P_STEER_HI = 5,
+    T2D_P_SPEED_LO = 6,
+    T2D_P_SPEED_HI = 7,
+    T2D_P_ACCEL_LO = 8,
+    T2D_P_ACCEL_HI = 9,
+    T2D_P_RANGE_FLAGS = 10, /* bit0 steer bounded, bit1 speed bounded, bit2 accel bounded */
+    T2D_P_MASS = 11,
+    T2D_P_MASS_HEIGHT = 12,
+    T2D_P_MU = 13,
+    T2D_P_IZ = 14,
+    T2D_P_CF = 15,
+    T2D_P_CR = 16,
+    T2D_P_DELTA_T_MS = 17,  /* integer-valued: sub-step in ms (reference _DELTA_T = 5)  */
+    T2D_P_SHAPE = 18,       /* T2D_SHAPE_*                                              */
+    T2D_P_LENGTH = 19,      /* OBB length (m)                                           */
+    T2D_P_WIDTH = 20,       /* OBB width (m); circle radius = width / 2                 */
+    T2D_P_RESERVED0 = 21,
+    T2D_P_RESERVED1 = 22,
+    T2D_P_RESERVED2 = 23,
+    T2D_PARAM_COLS = 24
+};
+#define T2D_RANGE_STEER 1
+#define T2D_RANGE_SPEED 2
+#define T2D_RANGE_ACCEL 4
+#define T2D_MAX_TYPES 32
+
+/* ---- pool fields (t2d_get_field / t2d_download / t2d_upload) ------------------------
+ * Per-participant fields hold N = n_env * max_agents elements, env-major
+ * (index = env * max_agents + agent).  Per-env fields hold n_env elements.         */
+enum {
+    T2D_F_X = 0,        /* f32[N]  env-local x (m)                                   */
+    T2D_F_Y = 1,        /* f32[N]                                                    */
+    T2D_F_HEADING = 2,  /* f32[N]  stored heading, np.mod(phi, 2*pi)                 */
+    T2D_F_SPEED = 3,    /* f32[N]  signed scalar speed                               */
+    T2D_F_VX = 4,       /* f32[N]  written by kinematics / point-mass only           */
+    T2D_F_VY = 5,       /* f32[N]                                                    */
+    T2D_F_ACT0 = 6,     /* f32[N]  accel (vehicles) | ax (point mass)                */
+    T2D_F_ACT1 = 7,     /* f32[N]  steer (vehicles) | ay (point mass)                */
+    T2D_F_IDS = 8,      /* u32[N]  model_id | type_id<<8 | active<<16                */
+    T2D_F_FLAGS = 9,    /* u32[N]  event bits, see T2D_FLAG_*                        */
+    T2D_F_APPLIED0 = 10,/* f32[N]  clipped accel actually applied (State.accel)      */
+    T2D_F_APPLIED1 = 11,/* f32[N]  clipped steer actually applied                    */
+    T2D_F_ENV_FLAGS = 12,  /* u32[E]  OR of the participants' flags                  */
+    T2D_F_CNT_STEP = 13,   /* i32[E]  ScenarioManager.cnt_step                       */
+    T2D_F_FRAME_MS = 14,   /* i32[E]  State.frame of the env (ms)                    */
+    T2D_F_STATUS = 15,     /* u8[E*4] scenario_status, traffic_status, terminated, truncated */
+    T2D_F_REWARD = 16,     /* f32[E]                                                  */
+    T2D_F_COUNT = 17
+};
+
+/* ---- per-participant / per-env event bits ------------------------------------------- */
+#define T2D_FLAG_COLLISION_DYNAMIC 1u   /* OBB/circle intersects another active participant */
+#define T2D_FLAG_COLLISION_STATIC  2u   /* intersects a static polygon (StaticCollision)    */
+#define T2D_FLAG_OUT_BOUND         4u   /* not boundary.contains(pose)  (OutBound)          */
+#define T2D_FLAG_OFF_LANE          8u   /* build-defined, see DESIGN.md                      */
+
+/* ---- ScenarioStatus / TrafficStatus values: traffic/status.py:10-61 ----------------- */
+#define T2D_SCENARIO_NORMAL        1
+#define T2D_SCENARIO_COMPLETED     2
+#define T2D_SCENARIO_TIME_EXCEEDED 3
+#define T2D_SCENARIO_OUT_BOUND     4
+#define T2D_SCENARIO_NO_ACTION     5
+#define T2D_SCENARIO_FAILED        6
+#define T2D_TRAFFIC_NORMAL            1
+#define T2D_TRAFFIC_COLLISION_STATIC  3
+#define T2D_TRAFFIC_COLLISION_DYNAMIC 4
+#define T2D_TRAFFIC_OFF_LANE          6
+
+/* ---- geometry limits ----------------------------------------------------------------- */
+#define T2D_MAX_POLY_VERTS 8      /* static / lane polygons: convex, 3..8 vertices        */
+#define T2D_MAX_AGENTS 256        /* participants per env                                 */
+
+/* ---- status / reward configuration (t2d_set_status_config) --------------------------- */
+typedef struct t2d_status_config {
+    int32_t max_step;            /* TimeExceed.max_step; <= 0 disables (time_exceed.py:20) */
+    int32_t ego_index;           /* agent whose flags drive the env status (0)            */
+    int32_t check_dynamic;       /* include participant-participant collision in status   */
+    int32_t check_off_lane;      /* include build-defined off-lane in status              */
+    float reward_collision;      /* -5  envs/parking.py:151-152                           */
+    float reward_time_exceed;    /* -1  envs/parking.py:153-157                           */
+    float reward_out_bound;      /* -5  envs/parking.py:158-159                           */
+    float reward_completed;      /* +5  envs/parking.py:160-161                           */
+    float time_penalty_scale;    /* 0.001: -tanh(cnt_step / max_step) * scale  :163       */
+} t2d_status_config;
+
+typedef struct t2d_pool t2d_pool;
+
+/* Error text of the most recent failing call on this pool (owned by the pool), or of the
+ * most recent failing t2d_create when pool == NULL (thread-local).                      */
+const char* t2d_last_error(const t2d_pool* pool);
+int t2d_abi_version(void);
+
+/* Create a pool of n_env environments x max_agents participants on HIP device device_id.
+ * All state starts zeroed and inactive.                                                  */
+int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** out_pool);
+int t2d_destroy(t2d_pool* pool);
+
+/* rows: n_types rows of row_stride doubles (row_stride >= T2D_PARAM_COLS), host memory.  */
+int t2d_set_param_table(t2d_pool* pool, const double* rows, int32_t n_types, int32_t row_stride);
+
+/* Static obstacle polygons + map boundary, CSR, host memory, env-local fp32 coordinates.
+ *   env_poly_offsets  [n_env + 1]  polygons of env e are [off[e], off[e+1])
+ *   poly_vert_offsets [n_poly + 1] vertices of polygon p are [off[p], off[p+1])
+ *   verts_xy          [2 * n_vert] interleaved x,y
+ *   boundary          [4 * n_env]  xmin, xmax, ymin, ymax (OutBound tuple order) or NULL
+ *   boundary_valid    [n_env]      0 = "boundary is None" -> never out of bound; NULL = all valid
+ * Polygons must be convex with 3..T2D_MAX_POLY_VERTS vertices; either winding accepted.  */
+int t2d_set_static_geometry(t2d_pool* pool, const int32_t* env_poly_offsets,
+                            const int32_t* poly_vert_offsets, const float* verts_xy,
+                            const float* boundary, const uint8_t* boundary_valid);
+
+/* Lane polygons for the build-defined off-lane flag; same CSR convention.  Envs with no
+ * lane polygons never raise T2D_FLAG_OFF_LANE (== the reference stub).                  */
+int t2d_set_lane_geometry(t2d_pool* pool, const int32_t* env_lane_offsets,
+                          const int32_t* lane_vert_offsets, const float* verts_xy);
+
+int t2d_set_status_config(t2d_pool* pool, const t2d_status_config* cfg);
+
+/* (Re)initialise participants.  All arrays are host memory with N = n_env*max_agents
+ * elements; env_mask (n_env bytes, NULL = every env) selects which envs are written.
+ * vx / vy may be NULL (then vx = speed*cos(heading), vy = speed*sin(heading) in fp64,
+ * rounded to fp32 -- State.velocity, participant/trajectory/state.py:152-169).
+ * Resets cnt_step, frame, status, reward and flags of the selected envs.                */
+int t2d_reset(t2d_pool* pool, const uint8_t* env_mask, const float* x, const float* y,
+              const float* heading, const float* speed, const float* vx, const float* vy,
+              const uint8_t* type_id, const uint8_t* active);
+
+/* Physics only: one PhysicsModelBase.step(interval_ms) for every active participant,
+ * actions taken from fields ACT0/ACT1.                                                  */
+int t2d_integrate(t2d_pool* pool, int32_t interval_ms, void* hip_stream);
+/* Events only: recompute FLAGS / ENV_FLAGS from the current poses.                      */
+int t2d_collide(t2d_pool* pool, void* hip_stream);
+/* ScenarioManager.update + check_status: integrate, collide, status/reward epilogue.    */
+int t2d_step(t2d_pool* pool, int32_t interval_ms, void* hip_stream);
+
+/* Zero-copy device pointer of a field (for wrapping as a torch tensor).                 */
+int t2d_get_field(t2d_pool* pool, int32_t field_id, void** dev_ptr, size_t* nbytes);
+/* Synchronous host<->device copies of a whole field (parity tests, small envs).         */
+int t2d_download(t2d_pool* pool, int32_t field_id, void* host_dst, size_t nbytes);
+int t2d_upload(t2d_pool* pool, int32_t field_id, const void* host_src, size_t nbytes);
+int t2d_sync(t2d_pool* pool);
+
+/* Kernel variants: 0 = exact (library-grade fp64 trig every sub-step), 1 = fast
+ * (rotation recurrence, default).  Both satisfy the 1e-5 contract; see DESIGN.md.       */
+int t2d_set_integrator_variant(t2d_pool* pool, int32_t variant);
+
+/* Per-kernel timing with HIP events recorded on the launch stream around each kernel.
+ * kernel_id: 0 = integrate, 1 = collide(+status).                                       */
+int t2d_profile_enable(t2d_pool* pool, int32_t on);
+int t2d_profile_read(t2d_pool* pool, int32_t kernel_id, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2D_H_ */

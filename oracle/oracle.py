@@ -1,0 +1,177 @@
+"""ctypes front-end of oracle/libt2d_oracle.so (see t2d_oracle.c for the parity status).
+
+TEST INFRASTRUCTURE ONLY -- the checker, never the thing measured or shipped.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libt2d_oracle.so")
+_lib = None
+
+NCOL = 24
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+
+
+class StatusConfig(C.Structure):
+    """Mirror of t2d_status_config (include/t2d.h)."""
+    _fields_ = [("max_step", C.c_int32), ("ego_index", C.c_int32), ("check_dynamic", C.c_int32),
+                ("check_off_lane", C.c_int32), ("reward_collision", C.c_float),
+                ("reward_time_exceed", C.c_float), ("reward_out_bound", C.c_float),
+                ("reward_completed", C.c_float), ("time_penalty_scale", C.c_float)]
+
+
+def build(force=False):
+    """Compile the oracle with the committed Makefile (gcc only)."""
+    src = os.path.join(_HERE, "t2d_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libt2d_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.t2do_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        _lib.t2do_integrate.argtypes = [_f64p, C.c_int, C.c_int] + [C.c_void_p] * 8 + \
+            [_u8p, C.c_void_p, C.c_int, _f64p]
+        _lib.t2do_pose_obb.argtypes = [C.c_double] * 5 + [C.c_int, _f64p]
+        _lib.t2do_convex_intersects.argtypes = [_f64p, C.c_int, _f64p, C.c_int]
+        _lib.t2do_point_in_convex.argtypes = [_f64p, C.c_int, _f64p]
+        _lib.t2do_circle_convex_intersects.argtypes = [_f64p, C.c_double, _f64p, C.c_int]
+        _lib.t2do_circle_circle_intersects.argtypes = [_f64p, C.c_double, _f64p, C.c_double]
+        _lib.t2do_polygon_is_convex.argtypes = [_f32p, C.c_int]
+        _lib.t2do_collide.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _u8p,
+                                      _u8p] + [C.c_void_p] * 8 + [C.c_int, _u32p, _u32p]
+        _lib.t2do_status.argtypes = [C.POINTER(StatusConfig), C.c_int, C.c_int, _u32p, C.c_int,
+                                     _i32p, _i32p, _u8p, _f32p]
+        _lib.t2do_pointmass_euler.argtypes = [_f64p] + [C.POINTER(C.c_double)] * 5 + \
+            [C.c_double, C.c_double, C.c_int]
+    return _lib
+
+
+def _ptr(a, dtype):
+    if a is None:
+        return None, None
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def sincos(x):
+    s, c = C.c_double(), C.c_double()
+    lib().t2do_sincos(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def integrate(rows, x, y, heading, speed, vx, vy, act0, act1, type_id, active, interval_ms):
+    """fp64 results (n, 8): x, y, heading, speed, vx, vy, applied0, applied1."""
+    rows = np.ascontiguousarray(rows, np.float64)
+    n = len(x)
+    keep, ptrs = [], []
+    for a in (x, y, heading, speed, vx, vy, act0, act1):
+        if a is None:
+            a = np.zeros(n, np.float32)
+        arr, p = _ptr(a, np.float32)
+        keep.append(arr); ptrs.append(p)
+    tid = np.ascontiguousarray(type_id, np.uint8)
+    act, actp = _ptr(active, np.uint8)
+    out = np.empty((n, 8), np.float64)
+    lib().t2do_integrate(rows, rows.shape[1], n, *ptrs, tid, actp, int(interval_ms), out)
+    return out
+
+
+def pose_obb(x, y, h, L, W, trig=0):
+    v = np.empty(8, np.float64)
+    lib().t2do_pose_obb(float(x), float(y), float(h), float(L), float(W), int(trig), v)
+    return v.reshape(4, 2)
+
+
+def convex_intersects(A, B):
+    A = np.ascontiguousarray(A, np.float64); B = np.ascontiguousarray(B, np.float64)
+    return bool(lib().t2do_convex_intersects(A, len(A), B, len(B)))
+
+
+def point_in_convex(P, pt):
+    P = np.ascontiguousarray(P, np.float64)
+    return bool(lib().t2do_point_in_convex(P, len(P), np.ascontiguousarray(pt, np.float64)))
+
+
+def circle_convex_intersects(c, R, P):
+    P = np.ascontiguousarray(P, np.float64)
+    return bool(lib().t2do_circle_convex_intersects(np.ascontiguousarray(c, np.float64), float(R), P, len(P)))
+
+
+def circle_circle_intersects(c1, R1, c2, R2):
+    return bool(lib().t2do_circle_circle_intersects(np.ascontiguousarray(c1, np.float64), float(R1),
+                                                    np.ascontiguousarray(c2, np.float64), float(R2)))
+
+
+def polygon_is_convex(verts):
+    v = np.ascontiguousarray(verts, np.float32)
+    return bool(lib().t2do_polygon_is_convex(v, len(v)))
+
+
+def collide(rows, n_env, A, x, y, heading, type_id, active, static=None, boundary=None,
+            boundary_valid=None, lanes=None, trig=0):
+    """static / lanes: (env_off[E+1], vert_off[P+1], verts_xy[V,2]) CSR tuples or None.
+    Returns (flags[N], env_flags[E])."""
+    rows = np.ascontiguousarray(rows, np.float64)
+    keep = []
+
+    def csr(t):
+        if t is None:
+            return [None, None, None]
+        eo, vo, xy = t
+        out = []
+        for a, dt in ((eo, np.int32), (vo, np.int32), (xy, np.float32)):
+            arr, p = _ptr(a, dt); keep.append(arr); out.append(p)
+        return out
+
+    sp = csr(static)
+    b, bp = _ptr(boundary, np.float32)
+    bv, bvp = _ptr(boundary_valid, np.uint8)
+    lp = csr(lanes)
+    N = n_env * A
+    flags = np.zeros(N, np.uint32); env_flags = np.zeros(n_env, np.uint32)
+    lib().t2do_collide(rows, rows.shape[1], n_env, A, np.ascontiguousarray(x, np.float32),
+                       np.ascontiguousarray(y, np.float32), np.ascontiguousarray(heading, np.float32),
+                       np.ascontiguousarray(type_id, np.uint8), np.ascontiguousarray(active, np.uint8),
+                       sp[0], sp[1], sp[2], bp, bvp, lp[0], lp[1], lp[2], int(trig), flags, env_flags)
+    return flags, env_flags
+
+
+def status(cfg, n_env, A, flags, interval_ms, cnt_step, frame_ms):
+    """Advance cnt_step / frame_ms in place; returns (status[E,4] u8, reward[E] f32)."""
+    st = np.zeros((n_env, 4), np.uint8); rw = np.zeros(n_env, np.float32)
+    lib().t2do_status(C.byref(cfg), n_env, A, np.ascontiguousarray(flags, np.uint32),
+                      int(interval_ms), cnt_step, frame_ms, st.reshape(-1), rw)
+    return st, rw
+
+
+def pointmass_euler(row, x, y, heading, vx, vy, ax, ay, interval):
+    vals = [C.c_double(v) for v in (x, y, heading, vx, vy)]
+    lib().t2do_pointmass_euler(np.ascontiguousarray(row, np.float64), *[C.byref(v) for v in vals],
+                               float(ax), float(ay), int(interval))
+    return [v.value for v in vals]
+
+
+def set_trig(mode):
+    """0 = libm (reference-faithful, default), 1 = deterministic t2d trig (bit-reproducible)."""
+    lib().t2do_set_trig(int(mode))
+
+
+def atan_det(x):
+    f = lib().t2do_atan
+    f.restype = C.c_double; f.argtypes = [C.c_double]
+    return f(float(x))

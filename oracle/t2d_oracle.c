@@ -1,0 +1,619 @@
+/*
+ * t2d_oracle.c -- CPU restatement (fp64, scalar) of the tactics2d hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (tactics2d_amd/, libt2d_hip.so)
+ * may import, link or call this file; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it, and only as the checker / the timed CPU baseline.
+ *
+ * Parity status
+ *   physics  : PINNED.  Checked against golden vectors produced by importing the
+ *              reference (`oracle/gen_golden.py` -> tests/golden/ npz + physics_kats.json);
+ *              see tests/test_oracle_physics.py.
+ *   geometry : PARITY UNPINNED against the reference's engine.  The reference delegates
+ *              collision / boundary predicates to shapely>=2.0.7,<2.1.0 (GEOS), which is not
+ *              in /root/reference, not installed, and whose results no reference test pins.
+ *              The predicates below restate shapely's documented *semantics* (closed-set
+ *              `intersects`, `contains`) on the reference's own vertex construction, and are
+ *              pinned by hand-built KATs (tests/golden/geometry_kats.json) plus an independent
+ *              cross-check against matplotlib.path (tests/test_oracle_geometry.py).
+ *
+ * Every function cites the reference file:line it follows (paths relative to the
+ * tactics2d repo root).  Arithmetic is IEEE fp64, evaluated left-to-right exactly as the
+ * cited Python expression associates; compile with -ffp-contract=off.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/t2d.h"
+
+#define TWO_PI (2.0 * 3.141592653589793)
+#define G_ACC 9.81 /* PhysicsModelBase._G, physics/physics_model_base.py */
+
+/* ====================================================================================
+ * Deterministic sin/cos ("t2d_sincos", DESIGN.md section "Deterministic trig").
+ * Used for pose construction so that event flags are reproducible bit-for-bit on any
+ * IEEE-754 machine; agrees with libm to <= 2 ulp (tests/test_oracle_geometry.py).
+ * Independent restatement of the spec: Cody-Waite 3-term reduction by pi/2 with fused
+ * multiply-adds, then the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4].
+ * ================================================================================== */
+static const double PIO2_HI = 1.5707963267948966;      /* fl(pi/2)                 */
+static const double PIO2_MID = 6.123233995736766e-17;  /* fl(pi/2 - PIO2_HI)       */
+static const double PIO2_LO = -1.4973849048591698e-33; /* fl(pi/2 - hi - mid)      */
+static const double TWO_OVER_PI = 0.6366197723675814;
+
+void t2do_sincos(double x, double* s_out, double* c_out) {
+    double k = rint(x * TWO_OVER_PI);
+    double r = fma(-k, PIO2_HI, x);
+    r = fma(-k, PIO2_MID, r);
+    r = fma(-k, PIO2_LO, r);
+    double z = r * r;
+    /* sin kernel */
+    double ps = 1.58969099521155010221e-10;
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    double sr = fma(r * z, ps, r);
+    /* cos kernel */
+    double pc = -1.13596475577881948265e-11;
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+    long long q = (long long)k;
+    switch (q & 3) {
+        case 0: *s_out = sr; *c_out = cr; break;
+        case 1: *s_out = cr; *c_out = -sr; break;
+        case 2: *s_out = -sr; *c_out = -cr; break;
+        default: *s_out = -cr; *c_out = sr; break;
+    }
+}
+
+
+/* Deterministic atan ("t2d_atan"): classic 4-breakpoint argument reduction
+ * (7/16, 11/16, 19/16, 39/16) + odd degree-23 polynomial split into even / odd halves.
+ * IEEE +,-,*,/ only (no fma), so any conforming machine reproduces it bit-for-bit.      */
+double t2do_atan(double x) {
+    static const double hi[4] = {4.63647609000806093515e-01, 7.85398163397448278999e-01,
+                                 9.82793723247329054082e-01, 1.57079632679489655800e+00};
+    static const double lo[4] = {2.26987774529616870924e-17, 3.06161699786838301793e-17,
+                                 1.39033110312309984516e-17, 6.12323399573676603587e-17};
+    static const double aT[11] = {3.33333333333329318027e-01, -1.99999999998764832476e-01,
+                                  1.42857142725034663711e-01, -1.11111104054623557880e-01,
+                                  9.09088713343650656196e-02, -7.69187620504482999495e-02,
+                                  6.66107313738753120669e-02, -5.83357013379057348645e-02,
+                                  4.97687799461593236017e-02, -3.65315727442169155270e-02,
+                                  1.62858201153657823623e-02};
+    int neg = x < 0.0;
+    double ax = fabs(x);
+    int id;
+    if (ax != ax) return x;
+    if (ax >= 1.8014398509481984e16) return neg ? -(hi[3] + lo[3]) : (hi[3] + lo[3]);
+    if (ax < 0.4375) {
+        if (ax < 7.450580596923828e-09) return x; /* 2^-27 */
+        id = -1;
+    } else if (ax < 1.1875) {
+        if (ax < 0.6875) { id = 0; ax = (2.0 * ax - 1.0) / (2.0 + ax); }
+        else { id = 1; ax = (ax - 1.0) / (ax + 1.0); }
+    } else {
+        if (ax < 2.4375) { id = 2; ax = (ax - 1.5) / (1.0 + 1.5 * ax); }
+        else { id = 3; ax = -1.0 / ax; }
+    }
+    double z = ax * ax;
+    double w = z * z;
+    double s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    double s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    double r;
+    if (id < 0) r = ax - ax * (s1 + s2);
+    else r = hi[id] - ((ax * (s1 + s2) - lo[id]) - ax);
+    return neg ? -r : r;
+}
+
+/* trig dispatch: mode 0 = libm (what the reference's numpy calls resolve to, up to the
+ * last ulp), mode 1 = deterministic (bit-reproducible; the GPU "exact" variant uses it). */
+static int g_trig = 0;
+void t2do_set_trig(int mode) { g_trig = mode; }
+static double T_sin(double x) { if (!g_trig) return sin(x); double s, c; t2do_sincos(x, &s, &c); return s; }
+static double T_cos(double x) { if (!g_trig) return cos(x); double s, c; t2do_sincos(x, &s, &c); return c; }
+static double T_tan(double x) { if (!g_trig) return tan(x); double s, c; t2do_sincos(x, &s, &c); return s / c; }
+static double T_atan(double x) { return g_trig ? t2do_atan(x) : atan(x); }
+
+/* ====================================================================================
+ * Physics
+ * ================================================================================== */
+static double clip(double v, double lo, double hi) { /* np.clip = min(max(v, lo), hi) */
+    double t = v < lo ? lo : v;
+    return t > hi ? hi : t;
+}
+
+/* np.mod(a, b) for b > 0: fmod, then shift negatives up (numpy npy_divmod semantics).
+ * np.mod(-1e-17, 2*pi) == 2*pi exactly (SURVEY.md finding 10).                         */
+static double np_mod(double a, double b) {
+    double m = fmod(a, b);
+    if (m != 0.0) {
+        if ((b < 0) != (m < 0)) m += b;
+    } else {
+        m = copysign(0.0, b);
+    }
+    return m;
+}
+
+/* SingleTrackKinematics.step + _step: physics/single_track_kinematics.py:126-198.
+ * out: x, y, heading, speed, vx, vy, applied_accel, applied_steer                      */
+void t2do_kinematics(const double* p, double x, double y, double phi, double v, double accel,
+                     double delta, int interval, double* out) {
+    int flags = (int)p[T2D_P_RANGE_FLAGS];
+    if (flags & T2D_RANGE_ACCEL) accel = clip(accel, p[T2D_P_ACCEL_LO], p[T2D_P_ACCEL_HI]); /* :192 */
+    if (flags & T2D_RANGE_STEER) delta = clip(delta, p[T2D_P_STEER_LO], p[T2D_P_STEER_HI]); /* :193 */
+    double lr = p[T2D_P_LR], wb = p[T2D_P_WB];
+    int delta_t = (int)p[T2D_P_DELTA_T_MS];
+    double beta = T_atan(lr / wb * T_tan(delta)); /* :127 */
+    double dt = (double)delta_t / 1000;       /* :128 */
+    int n_steps = interval / delta_t;         /* :129 */
+    int remainder = interval % delta_t;       /* :130 */
+    for (int i = 0; i <= n_steps; ++i) {
+        double h = dt;
+        if (i == n_steps) { /* :151-163 remainder step */
+            if (remainder <= 0) break;
+            h = (double)remainder / 1000;
+        }
+        double dx = v * T_cos(phi + beta);                  /* :138 */
+        double dy = v * T_sin(phi + beta);                  /* :139 */
+        double dphi = v / wb * T_tan(delta) * T_cos(beta);    /* :141 */
+        x += dx * h;                                      /* :143 */
+        y += dy * h;
+        phi += dphi * h;
+        v += accel * h;
+        if (flags & T2D_RANGE_SPEED) v = clip(v, p[T2D_P_SPEED_LO], p[T2D_P_SPEED_HI]); /* :148 */
+    }
+    out[0] = x;
+    out[1] = y;
+    out[2] = np_mod(phi, TWO_PI); /* :169 */
+    out[3] = v;
+    out[4] = v * T_cos(phi);        /* :170  un-wrapped phi */
+    out[5] = v * T_sin(phi);
+    out[6] = accel;
+    out[7] = delta;
+}
+
+/* SingleTrackDynamics.step + _step: physics/single_track_dynamics.py:140-251.
+ * vx, vy are not produced by the reference (State(..., speed=v), :220-227) -> NaN.      */
+void t2do_dynamics(const double* p, double x, double y, double phi, double v, double accel,
+                   double delta, int interval, double* out) {
+    int flags = (int)p[T2D_P_RANGE_FLAGS];
+    if (flags & T2D_RANGE_ACCEL) accel = clip(accel, p[T2D_P_ACCEL_LO], p[T2D_P_ACCEL_HI]); /* :245 */
+    if (flags & T2D_RANGE_STEER) delta = clip(delta, p[T2D_P_STEER_LO], p[T2D_P_STEER_HI]); /* :246 */
+    double lf = p[T2D_P_LF], lr = p[T2D_P_LR], wb = p[T2D_P_WB];
+    double mass = p[T2D_P_MASS], hcg = p[T2D_P_MASS_HEIGHT], mu = p[T2D_P_MU];
+    double Iz = p[T2D_P_IZ], cf = p[T2D_P_CF], cr = p[T2D_P_CR];
+    int delta_t = (int)p[T2D_P_DELTA_T_MS];
+    double dt = (double)delta_t / 1000; /* :141 */
+    int n_steps = interval / delta_t;   /* :142 ; remainder (:143) is never integrated */
+
+    double factor_f = (G_ACC * lr - accel * hcg) / wb; /* :145 */
+    double factor_r = (G_ACC * lf + accel * hcg) / wb; /* :146 */
+    double lf_cf_ff = lf * cf * factor_f;              /* :149 */
+    double lr_cr_fr = lr * cr * factor_r;
+    double lf2_cf_ff = lf * lf * cf * factor_f;        /* lf**2 * cf * factor_f */
+    double lr2_cr_fr = lr * lr * cr * factor_r;
+    double cf_ff = cf * factor_f;
+    double cr_fr = cr * factor_r;
+
+    double d_phi = v / wb * T_tan(delta);        /* :159 */
+    double beta = T_atan(lr / lf * T_tan(delta));  /* :160 */
+
+    for (int i = 0; i < n_steps; ++i) {
+        double dx = v * T_cos(phi + beta); /* :164 */
+        double dy = v * T_sin(phi + beta);
+        double v_safe = fabs(v) > 1e-6 ? v : (v >= 0 ? 1e-6 : -1e-6); /* :169 */
+        double d_beta;
+        if (fabs(v) >= 0.1) { /* :171 */
+            double dd_phi = mu * mass / Iz *
+                            (lf_cf_ff * delta + (lr_cr_fr - lf_cf_ff) * beta -
+                             (lf2_cf_ff + lr2_cr_fr) * d_phi / v_safe); /* :172-181 */
+            d_beta = mu / v_safe *
+                         (cf_ff * delta - (cr_fr + cf_ff) * beta +
+                          (lr_cr_fr - lf_cf_ff) * d_phi / v_safe) -
+                     d_phi; /* :182-191 */
+            d_phi += dd_phi * dt; /* :192 */
+        } else {
+            double tb = 1 + T_tan(delta) * lr / wb;
+            double cd = T_cos(delta);
+            d_beta = lr / (tb * tb) / wb / (cd * cd) * delta;            /* :194-200 */
+            d_phi += v * T_cos(beta) / wb * T_tan(delta) * dt;               /* :210 */
+        }
+        x += dx * dt; /* :212-216 */
+        y += dy * dt;
+        v += accel * dt;
+        phi += d_phi * dt;
+        beta += d_beta * dt;
+        if (flags & T2D_RANGE_SPEED) v = clip(v, p[T2D_P_SPEED_LO], p[T2D_P_SPEED_HI]); /* :218 */
+    }
+    out[0] = x;
+    out[1] = y;
+    out[2] = np_mod(phi, TWO_PI);
+    out[3] = v;
+    out[4] = NAN;
+    out[5] = NAN;
+    out[6] = accel;
+    out[7] = delta;
+}
+
+/* PointMass.step + _step_newton: physics/point_mass.py:83-175, 209-232.
+ * The accel clip at :222-225 is dead code (its result is unused) and is not restated.
+ * out: x, y, heading, speed (= ||(vx,vy)||, State.speed lazily), vx, vy, ax, ay         */
+void t2do_pointmass(const double* p, double x, double y, double vx, double vy, double ax,
+                    double ay, int interval, double* out) {
+    int flags = (int)p[T2D_P_RANGE_FLAGS];
+    double lo = p[T2D_P_SPEED_LO], hi = p[T2D_P_SPEED_HI];
+    double dt = (double)interval / 1000; /* :86 */
+    double nvx = vx + ax * dt;           /* :88 */
+    double nvy = vy + ay * dt;
+    double ns = sqrt(nvx * nvx + nvy * nvy); /* np.linalg.norm :90 */
+    double ox, oy, ovx, ovy;
+    if (!(flags & T2D_RANGE_SPEED) || (lo <= ns && ns <= hi)) { /* :93 */
+        ox = x + vx * dt + 0.5 * ax * (dt * dt);                 /* :96  dt**2 */
+        oy = y + vy * dt + 0.5 * ay * (dt * dt);
+        ovx = nvx;
+        ovy = nvy;
+    } else {
+        int lower = ns < lo;                         /* :105 vs :139 */
+        double bound = lower ? lo : hi;
+        double a_ = ax * ax + ay * ay;               /* :106  ax**2 + ay**2 */
+        double b_ = 2 * (ax * vx + ay * vy);         /* :107 */
+        double c_ = vx * vx + vy * vy - bound * bound; /* :108 */
+        double t1;
+        if (fabs(a_) < 1e-12) {                      /* :111 */
+            if (fabs(b_) < 1e-12) t1 = 0.0;
+            else t1 = -c_ / b_;                      /* :118 */
+        } else {
+            double disc = b_ * b_ - 4 * a_ * c_;     /* :121 */
+            if (!(disc > 0.0)) disc = 0.0;           /* max(0.0, disc) :123 */
+            t1 = lower ? (-b_ - sqrt(disc)) / (2 * a_)   /* :124 */
+                       : (-b_ + sqrt(disc)) / (2 * a_);  /* :158 */
+        }
+        t1 = clip(t1, 0.0, dt); /* :127 */
+        double t2 = dt - t1;
+        ovx = vx + ax * t1; /* :129 */
+        ovy = vy + ay * t1;
+        ox = x + vx * t1 + 0.5 * ax * (t1 * t1) + ovx * t2; /* :134 */
+        oy = y + vy * t1 + 0.5 * ay * (t1 * t1) + ovy * t2;
+    }
+    out[0] = ox;
+    out[1] = oy;
+    out[2] = atan2(ovy, ovx); /* :98 / :136 / :170 */
+    out[3] = sqrt(ovx * ovx + ovy * ovy);
+    out[4] = ovx;
+    out[5] = ovy;
+    out[6] = ax;
+    out[7] = ay;
+}
+
+/* PointMass._step_euler: physics/point_mass.py:177-207 (cross-check only; the reference
+ * test asserts Hausdorff(newton, euler) < 0.01, tests/test_physics.py:248-249).
+ * io: x, y, heading, vx, vy updated in place.                                           */
+void t2do_pointmass_euler(const double* p, double* x, double* y, double* heading, double* vx,
+                          double* vy, double ax, double ay, int interval) {
+    int flags = (int)p[T2D_P_RANGE_FLAGS];
+    int delta_t = (int)p[T2D_P_DELTA_T_MS];
+    int n = interval / delta_t, rem = interval % delta_t;
+    for (int i = 0; i <= n; ++i) {
+        double dt = (double)delta_t / 1000;
+        if (i == n) {
+            if (rem <= 0) break;
+            dt = (double)rem / 1000;
+        }
+        *vx += ax * dt; /* :188 */
+        *vy += ay * dt;
+        double speed = sqrt(*vx * *vx + *vy * *vy);
+        double sc = (flags & T2D_RANGE_SPEED) ? clip(speed, p[T2D_P_SPEED_LO], p[T2D_P_SPEED_HI]) : speed;
+        if (fabs(speed - sc) > 1e-12) { /* :195 */
+            *vx = sc * cos(*heading);
+            *vy = sc * sin(*heading);
+        }
+        *x += *vx * dt; /* :199 */
+        *y += *vy * dt;
+        *heading = atan2(*vy, *vx);
+    }
+}
+
+/* Batched driver over an SoA pool slice (what t2d_integrate does on the GPU).
+ * Inputs are the pool's fp32 columns; out is n x 8 doubles (un-rounded fp64 results):
+ * x, y, heading, speed, vx, vy, applied0, applied1.  Inactive participants copy their
+ * state through unchanged (applied = NaN).                                              */
+void t2do_integrate(const double* rows, int row_stride, int n, const float* x, const float* y,
+                    const float* heading, const float* speed, const float* vx, const float* vy,
+                    const float* act0, const float* act1, const uint8_t* type_id,
+                    const uint8_t* active, int interval_ms, double* out) {
+    for (int i = 0; i < n; ++i) {
+        double* o = out + 8 * (size_t)i;
+        if (active && !active[i]) {
+            o[0] = x[i]; o[1] = y[i]; o[2] = heading[i]; o[3] = speed[i];
+            o[4] = vx ? vx[i] : NAN; o[5] = vy ? vy[i] : NAN; o[6] = NAN; o[7] = NAN;
+            continue;
+        }
+        const double* p = rows + (size_t)type_id[i] * row_stride;
+        int model = (int)p[T2D_P_MODEL];
+        if (model == T2D_MODEL_KINEMATICS)
+            t2do_kinematics(p, x[i], y[i], heading[i], speed[i], act0[i], act1[i], interval_ms, o);
+        else if (model == T2D_MODEL_DYNAMICS)
+            t2do_dynamics(p, x[i], y[i], heading[i], speed[i], act0[i], act1[i], interval_ms, o);
+        else
+            t2do_pointmass(p, x[i], y[i], vx[i], vy[i], act0[i], act1[i], interval_ms, o);
+    }
+}
+
+/* ====================================================================================
+ * Geometry / events
+ * ================================================================================== */
+
+/* Vehicle.get_pose: participant/element/vehicle.py:263-281 with the bbox vertex order of
+ * vehicle.py:132-142: (+L/2,-W/2), (+L/2,+W/2), (-L/2,+W/2), (-L/2,-W/2)  (counter-clockwise).
+ * shapely affine_transform matrix [cos h, -sin h, sin h, cos h, x, y]:
+ *     X = cos*lx - sin*ly + x ;  Y = sin*lx + cos*ly + y        (left-to-right)
+ * trig: 0 = deterministic t2do_sincos (the definition used for flags), 1 = libm.        */
+void t2do_pose_obb(double x, double y, double h, double L, double W, int trig, double* v8) {
+    double s, c;
+    if (trig == 0) t2do_sincos(h, &s, &c);
+    else { s = sin(h); c = cos(h); }
+    const double lx[4] = {0.5 * L, 0.5 * L, -0.5 * L, -0.5 * L};
+    const double ly[4] = {-0.5 * W, 0.5 * W, 0.5 * W, -0.5 * W};
+    for (int k = 0; k < 4; ++k) {
+        v8[2 * k] = c * lx[k] - s * ly[k] + x;
+        v8[2 * k + 1] = s * lx[k] + c * ly[k] + y;
+    }
+}
+
+/* orientation of r relative to the directed line p->q: > 0 left, < 0 right, 0 on it */
+static double orient(const double* p, const double* q, const double* r) {
+    double a = q[0] - p[0], b = r[1] - p[1];
+    double c = q[1] - p[1], d = r[0] - p[0];
+    return a * b - c * d;
+}
+
+/* an edge of the CCW polygon A separates when every vertex of B is strictly to its right */
+static int has_separating_edge(const double* A, int nA, const double* B, int nB) {
+    for (int i = 0; i < nA; ++i) {
+        const double* p = A + 2 * i;
+        const double* q = A + 2 * ((i + 1) % nA);
+        int all_out = 1;
+        for (int j = 0; j < nB; ++j)
+            if (!(orient(p, q, B + 2 * j) < 0.0)) { all_out = 0; break; }
+        if (all_out) return 1;
+    }
+    return 0;
+}
+
+/* shapely `A.intersects(B)` for convex polygons (collision.py:22,40): closed sets share at
+ * least one point -- touching edges / corners and containment all count.  Separating-axis
+ * theorem with strict separation.  Both polygons counter-clockwise.                      */
+int t2do_convex_intersects(const double* A, int nA, const double* B, int nB) {
+    if (has_separating_edge(A, nA, B, nB)) return 0;
+    if (has_separating_edge(B, nB, A, nA)) return 0;
+    return 1;
+}
+
+/* closed point-in-convex-polygon (CCW) */
+int t2do_point_in_convex(const double* P, int n, const double* pt) {
+    for (int i = 0; i < n; ++i)
+        if (orient(P + 2 * i, P + 2 * ((i + 1) % n), pt) < 0.0) return 0;
+    return 1;
+}
+
+static double seg_dist2(const double* p, const double* q, const double* c) {
+    double dx = q[0] - p[0], dy = q[1] - p[1];
+    double wx = c[0] - p[0], wy = c[1] - p[1];
+    double dd = dx * dx + dy * dy;
+    double t = 0.0;
+    if (dd > 0.0) {
+        t = (wx * dx + wy * dy) / dd;
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+    }
+    double ex = wx - t * dx, ey = wy - t * dy;
+    return ex * ex + ey * ey;
+}
+
+/* Pedestrian pose = (centre, radius) (pedestrian.py:138-149) vs convex polygon, closed */
+int t2do_circle_convex_intersects(const double* c, double R, const double* P, int n) {
+    if (t2do_point_in_convex(P, n, c)) return 1;
+    double R2 = R * R;
+    for (int i = 0; i < n; ++i)
+        if (seg_dist2(P + 2 * i, P + 2 * ((i + 1) % n), c) <= R2) return 1;
+    return 0;
+}
+
+int t2do_circle_circle_intersects(const double* c1, double R1, const double* c2, double R2) {
+    double dx = c1[0] - c2[0], dy = c1[1] - c2[1];
+    double rr = R1 + R2;
+    return dx * dx + dy * dy <= rr * rr;
+}
+
+/* signed area * 2 (shoelace) -- used to normalise winding to CCW */
+static double area2(const double* P, int n) {
+    double a = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double* p = P + 2 * i;
+        const double* q = P + 2 * ((i + 1) % n);
+        a += p[0] * q[1] - q[0] * p[1];
+    }
+    return a;
+}
+
+/* load fp32 polygon -> fp64 CCW; returns n */
+static int load_poly(const float* verts_xy, int v0, int v1, double* P) {
+    int n = v1 - v0;
+    for (int k = 0; k < n; ++k) {
+        P[2 * k] = verts_xy[2 * (v0 + k)];
+        P[2 * k + 1] = verts_xy[2 * (v0 + k) + 1];
+    }
+    if (area2(P, n) < 0.0) {
+        for (int a = 0, b = n - 1; a < b; ++a, --b) {
+            double tx = P[2 * a], ty = P[2 * a + 1];
+            P[2 * a] = P[2 * b]; P[2 * a + 1] = P[2 * b + 1];
+            P[2 * b] = tx; P[2 * b + 1] = ty;
+        }
+    }
+    return n;
+}
+
+/* 1 if convex (after CCW normalisation, collinear runs allowed), 0 otherwise */
+int t2do_polygon_is_convex(const float* verts_xy, int n) {
+    double P[2 * 64];
+    if (n < 3 || n > 64) return 0;
+    load_poly(verts_xy, 0, n, P);
+    if (!(area2(P, n) > 0.0)) return 0;
+    for (int i = 0; i < n; ++i)
+        if (orient(P + 2 * i, P + 2 * ((i + 1) % n), P + 2 * ((i + 2) % n)) < 0.0) return 0;
+    return 1;
+}
+
+/* Event flags of every participant (what t2d_collide does on the GPU), brute force:
+ *   COLLISION_DYNAMIC  intended DynamicCollision (collision.py:18-25): pose intersects the
+ *                      pose of any other ACTIVE participant of the same env, all pairs
+ *   COLLISION_STATIC   StaticCollision.update (collision.py:37-43): any static polygon
+ *   OUT_BOUND          OutBound.update (out_bound.py:37-48): not boundary.contains(pose);
+ *                      touching the boundary from inside is still contained -> strict tests
+ *   OFF_LANE           build-defined (reference stub off_lane.py:16-17 returns False): some
+ *                      pose vertex (circle: the centre) lies in no lane polygon (closed);
+ *                      never raised for an env without lane polygons
+ * CSR arrays as in t2d_set_static_geometry / t2d_set_lane_geometry (may be NULL = none).   */
+void t2do_collide(const double* rows, int row_stride, int n_env, int A, const float* x,
+                  const float* y, const float* heading, const uint8_t* type_id,
+                  const uint8_t* active, const int32_t* env_poly_off, const int32_t* poly_vert_off,
+                  const float* poly_xy, const float* boundary, const uint8_t* boundary_valid,
+                  const int32_t* env_lane_off, const int32_t* lane_vert_off, const float* lane_xy,
+                  int trig, uint32_t* flags, uint32_t* env_flags) {
+    double* V = (double*)malloc(sizeof(double) * 8 * (size_t)A);
+    double* C = (double*)malloc(sizeof(double) * 3 * (size_t)A);
+    int* kind = (int*)malloc(sizeof(int) * (size_t)A);
+    for (int e = 0; e < n_env; ++e) {
+        size_t base = (size_t)e * A;
+        for (int i = 0; i < A; ++i) {
+            flags[base + i] = 0;
+            if (!active[base + i]) continue;
+            const double* p = rows + (size_t)type_id[base + i] * row_stride;
+            kind[i] = (int)p[T2D_P_SHAPE];
+            C[3 * i] = x[base + i];
+            C[3 * i + 1] = y[base + i];
+            C[3 * i + 2] = 0.5 * p[T2D_P_WIDTH]; /* pedestrian radius = width / 2 */
+            if (kind[i] == T2D_SHAPE_OBB)
+                t2do_pose_obb(x[base + i], y[base + i], heading[base + i], p[T2D_P_LENGTH],
+                              p[T2D_P_WIDTH], trig, V + 8 * i);
+        }
+        for (int i = 0; i < A; ++i) {
+            if (!active[base + i]) continue;
+            uint32_t f = 0;
+            /* participant vs participant */
+            for (int j = 0; j < A && !(f & T2D_FLAG_COLLISION_DYNAMIC); ++j) {
+                if (j == i || !active[base + j]) continue;
+                int hit;
+                if (kind[i] == T2D_SHAPE_OBB && kind[j] == T2D_SHAPE_OBB)
+                    hit = t2do_convex_intersects(V + 8 * i, 4, V + 8 * j, 4);
+                else if (kind[i] == T2D_SHAPE_OBB)
+                    hit = t2do_circle_convex_intersects(C + 3 * j, C[3 * j + 2], V + 8 * i, 4);
+                else if (kind[j] == T2D_SHAPE_OBB)
+                    hit = t2do_circle_convex_intersects(C + 3 * i, C[3 * i + 2], V + 8 * j, 4);
+                else
+                    hit = t2do_circle_circle_intersects(C + 3 * i, C[3 * i + 2], C + 3 * j, C[3 * j + 2]);
+                if (hit) f |= T2D_FLAG_COLLISION_DYNAMIC;
+            }
+            /* participant vs static polygons */
+            if (env_poly_off) {
+                for (int pi = env_poly_off[e]; pi < env_poly_off[e + 1]; ++pi) {
+                    double P[2 * T2D_MAX_POLY_VERTS];
+                    int n = load_poly(poly_xy, poly_vert_off[pi], poly_vert_off[pi + 1], P);
+                    int hit = kind[i] == T2D_SHAPE_OBB
+                                  ? t2do_convex_intersects(V + 8 * i, 4, P, n)
+                                  : t2do_circle_convex_intersects(C + 3 * i, C[3 * i + 2], P, n);
+                    if (hit) { f |= T2D_FLAG_COLLISION_STATIC; break; }
+                }
+            }
+            /* map boundary */
+            if (boundary && (!boundary_valid || boundary_valid[e])) {
+                double xmin = boundary[4 * e], xmax = boundary[4 * e + 1];
+                double ymin = boundary[4 * e + 2], ymax = boundary[4 * e + 3];
+                int out = 0;
+                if (kind[i] == T2D_SHAPE_OBB) {
+                    for (int k = 0; k < 4; ++k) {
+                        double vx_ = V[8 * i + 2 * k], vy_ = V[8 * i + 2 * k + 1];
+                        if (vx_ < xmin || vx_ > xmax || vy_ < ymin || vy_ > ymax) out = 1;
+                    }
+                } else {
+                    double cx = C[3 * i], cy = C[3 * i + 1], R = C[3 * i + 2];
+                    if (cx - R < xmin || cx + R > xmax || cy - R < ymin || cy + R > ymax) out = 1;
+                }
+                if (out) f |= T2D_FLAG_OUT_BOUND;
+            }
+            /* lanes (build-defined) */
+            if (env_lane_off && env_lane_off[e + 1] > env_lane_off[e]) {
+                int nv = kind[i] == T2D_SHAPE_OBB ? 4 : 1;
+                for (int k = 0; k < nv; ++k) {
+                    const double* pt = kind[i] == T2D_SHAPE_OBB ? V + 8 * i + 2 * k : C + 3 * i;
+                    int inside = 0;
+                    for (int li = env_lane_off[e]; li < env_lane_off[e + 1] && !inside; ++li) {
+                        double P[2 * T2D_MAX_POLY_VERTS];
+                        int n = load_poly(lane_xy, lane_vert_off[li], lane_vert_off[li + 1], P);
+                        inside = t2do_point_in_convex(P, n, pt);
+                    }
+                    if (!inside) { f |= T2D_FLAG_OFF_LANE; break; }
+                }
+            }
+            flags[base + i] = f;
+        }
+        uint32_t ef = 0;
+        for (int i = 0; i < A; ++i) ef |= flags[base + i];
+        env_flags[e] = ef;
+    }
+    free(V); free(C); free(kind);
+}
+
+/* _ParkingScenarioManager.update/check_status (envs/parking.py:352-392) and
+ * ParkingEnv.step/_get_reward (envs/parking.py:219-256,148-166) for the events this build
+ * evaluates, in the reference's early-return order:
+ *   time exceed (cnt_step > max_step, time_exceed.py:32-33)  -> TIME_EXCEEDED, reward -1
+ *   [no-action: IoU based, "next" row, not evaluated]
+ *   out of bound                                             -> OUT_BOUND, reward -5
+ *   collision (static; dynamic / off-lane when enabled)      -> FAILED + COLLISION_*, reward -5
+ *   otherwise NORMAL, reward = -tanh(cnt_step / max_step) * scale (the IoU / distance
+ *   shaping terms of :164-188 belong to the "next" rows).
+ * status: 4 bytes per env = scenario, traffic, terminated, truncated.                    */
+void t2do_status(const t2d_status_config* cfg, int n_env, int A, const uint32_t* flags,
+                 int interval_ms, int32_t* cnt_step, int32_t* frame_ms, uint8_t* status,
+                 float* reward) {
+    for (int e = 0; e < n_env; ++e) {
+        cnt_step[e] += 1; /* parking.py:353 */
+        frame_ms[e] += interval_ms;
+        uint32_t f = flags[(size_t)e * A + cfg->ego_index];
+        int scen = T2D_SCENARIO_NORMAL, traf = T2D_TRAFFIC_NORMAL;
+        float r;
+        if (cfg->max_step > 0 && cnt_step[e] > cfg->max_step) {
+            scen = T2D_SCENARIO_TIME_EXCEEDED; r = cfg->reward_time_exceed;
+        } else if (f & T2D_FLAG_OUT_BOUND) {
+            scen = T2D_SCENARIO_OUT_BOUND; r = cfg->reward_out_bound;
+        } else if (f & T2D_FLAG_COLLISION_STATIC) {
+            scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_COLLISION_STATIC; r = cfg->reward_collision;
+        } else if (cfg->check_dynamic && (f & T2D_FLAG_COLLISION_DYNAMIC)) {
+            scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_COLLISION_DYNAMIC; r = cfg->reward_collision;
+        } else if (cfg->check_off_lane && (f & T2D_FLAG_OFF_LANE)) {
+            scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_OFF_LANE; r = cfg->reward_collision;
+        } else {
+            double tp = cfg->max_step > 0 ? -tanh((double)cnt_step[e] / (double)cfg->max_step) *
+                                                (double)cfg->time_penalty_scale
+                                          : 0.0;
+            r = (float)tp;
+        }
+        status[4 * e] = (uint8_t)scen;
+        status[4 * e + 1] = (uint8_t)traf;
+        status[4 * e + 2] = scen == T2D_SCENARIO_COMPLETED;                       /* :245-246 */
+        status[4 * e + 3] = scen != T2D_SCENARIO_COMPLETED &&
+                            (scen != T2D_SCENARIO_NORMAL || traf != T2D_TRAFFIC_NORMAL); /* :247-248 */
+        reward[e] = r;
+    }
+}
+
+int t2do_abi_version(void) { return T2D_ABI_VERSION; }
