@@ -114,6 +114,21 @@ double t2do_atan(double x) {
     return neg ? -r : r;
 }
 
+
+/* atan2 on top of t2do_atan (deterministic spec; atan2(0, 0) = 0 like numpy) */
+double t2do_atan2(double y, double x) {
+    const double pi = 3.141592653589793, pio2 = 1.5707963267948966;
+    if (x != x || y != y) return x + y;
+    if (y == 0.0) {
+        if (x > 0.0 || (x == 0.0 && !signbit(x))) return y;
+        return signbit(y) ? -pi : pi;
+    }
+    if (x == 0.0) return y > 0.0 ? pio2 : -pio2;
+    double a = t2do_atan(y / x);
+    if (x > 0.0) return a;
+    return y > 0.0 ? a + pi : a - pi;
+}
+
 /* trig dispatch: mode 0 = libm (what the reference's numpy calls resolve to, up to the
  * last ulp), mode 1 = deterministic (bit-reproducible; the GPU "exact" variant uses it). */
 static int g_trig = 0;
@@ -122,6 +137,7 @@ static double T_sin(double x) { if (!g_trig) return sin(x); double s, c; t2do_si
 static double T_cos(double x) { if (!g_trig) return cos(x); double s, c; t2do_sincos(x, &s, &c); return c; }
 static double T_tan(double x) { if (!g_trig) return tan(x); double s, c; t2do_sincos(x, &s, &c); return s / c; }
 static double T_atan(double x) { return g_trig ? t2do_atan(x) : atan(x); }
+static double T_atan2(double y, double x) { return g_trig ? t2do_atan2(y, x) : atan2(y, x); }
 
 /* ====================================================================================
  * Physics
@@ -286,7 +302,7 @@ void t2do_pointmass(const double* p, double x, double y, double vx, double vy, d
     }
     out[0] = ox;
     out[1] = oy;
-    out[2] = atan2(ovy, ovx); /* :98 / :136 / :170 */
+    out[2] = T_atan2(ovy, ovx); /* :98 / :136 / :170 */
     out[3] = sqrt(ovx * ovx + ovy * ovy);
     out[4] = ovx;
     out[5] = ovy;

@@ -1,0 +1,84 @@
+"""ctypes binding of libt2d_hip.so -- the ONLY compute path of this package.
+
+There is no CPU fallback: if the shared library (built in-tree by `python -m
+tactics2d_amd.build`) is missing, or no HIP device is usable, the calls raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libt2d_hip.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_GEOMETRY = 0, 1, 2, 3, 4, 5
+
+
+class T2DError(RuntimeError):
+    """A libt2d_hip.so call returned a non-zero status."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"libt2d_hip error {code}: {msg}")
+        self.code = code
+
+
+class GeometryError(T2DError, ValueError):
+    pass
+
+
+class StatusConfig(C.Structure):
+    """t2d_status_config (include/t2d.h)."""
+    _fields_ = [("max_step", C.c_int32), ("ego_index", C.c_int32), ("check_dynamic", C.c_int32),
+                ("check_off_lane", C.c_int32), ("reward_collision", C.c_float),
+                ("reward_time_exceed", C.c_float), ("reward_out_bound", C.c_float),
+                ("reward_completed", C.c_float), ("time_penalty_scale", C.c_float)]
+
+
+# every symbol include/t2d.h declares: name -> (restype, argtypes)
+_vp = C.c_void_p
+SYMBOLS = {
+    "t2d_last_error": (C.c_char_p, [_vp]),
+    "t2d_abi_version": (C.c_int, []),
+    "t2d_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "t2d_destroy": (C.c_int, [_vp]),
+    "t2d_set_param_table": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32]),
+    "t2d_set_static_geometry": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "t2d_set_lane_geometry": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "t2d_set_status_config": (C.c_int, [_vp, C.POINTER(StatusConfig)]),
+    "t2d_reset": (C.c_int, [_vp] * 10),
+    "t2d_integrate": (C.c_int, [_vp, C.c_int32, _vp]),
+    "t2d_collide": (C.c_int, [_vp, _vp]),
+    "t2d_step": (C.c_int, [_vp, C.c_int32, _vp]),
+    "t2d_get_field": (C.c_int, [_vp, C.c_int32, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
+    "t2d_download": (C.c_int, [_vp, C.c_int32, _vp, C.c_size_t]),
+    "t2d_upload": (C.c_int, [_vp, C.c_int32, _vp, C.c_size_t]),
+    "t2d_sync": (C.c_int, [_vp]),
+    "t2d_set_integrator_variant": (C.c_int, [_vp, C.c_int32]),
+    "t2d_profile_enable": (C.c_int, [_vp, C.c_int32]),
+    "t2d_profile_read": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libt2d_hip.so (raises if it has not been built -- no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -m tactics2d_amd.build` "
+                "(hipcc, gfx950). tactics2d_amd has no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, pool=None):
+    if rc == OK:
+        return
+    msg = lib().t2d_last_error(pool)
+    msg = msg.decode() if msg else ""
+    raise (GeometryError if rc == ERR_GEOMETRY else T2DError)(rc, msg)

@@ -1,0 +1,41 @@
+"""Build libt2d_hip.so (HIP kernels + C ABI) in-tree for gfx950.
+
+    python -m tactics2d_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the numerical contract
+(DESIGN.md "Precision"): every product and sum rounds separately unless the source says fma.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libt2d_hip.so")
+SOURCES = ["t2d_api.hip", "t2d_integrate.hip", "t2d_collide.hip"]
+HEADERS = ["t2d_math.h", "t2d_pool.h", os.path.join("..", "..", "include", "t2d.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,508 @@
+// t2d_api.hip -- host side of libt2d_hip.so: pool lifetime, uploads, launches (C ABI of
+// include/t2d.h).  No CPU compute fallback exists: every entry point that needs the GPU
+// returns T2D_ERR_HIP with the HIP error text when the device / runtime is unavailable.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "t2d_pool.h"
+
+namespace {
+
+thread_local std::string g_create_err;
+
+int fail(t2d_pool* p, int code, const std::string& msg) {
+    if (p) p->err = msg;
+    else g_create_err = msg;
+    return code;
+}
+
+#define T2D_HIP(p, call)                                                                  \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(p, T2D_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+size_t field_elem_bytes(int f) {
+    switch (f) {
+        case T2D_F_STATUS: return 4;  // 4 x u8 per env
+        default: return 4;
+    }
+}
+bool field_per_env(int f) { return f >= T2D_F_ENV_FLAGS; }
+
+template <class T>
+int dev_replace(t2d_pool* p, T** dst, const T* src, size_t n) {
+    if (*dst) {
+        T2D_HIP(p, hipFree(*dst));
+        *dst = nullptr;
+    }
+    if (n == 0) return T2D_OK;
+    T2D_HIP(p, hipMalloc((void**)dst, n * sizeof(T)));
+    T2D_HIP(p, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return T2D_OK;
+}
+
+double area2(const std::vector<double>& P) {
+    const int n = (int)P.size() / 2;
+    double a = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int j = (i + 1) % n;
+        a += P[2 * i] * P[2 * j + 1] - P[2 * j] * P[2 * i + 1];
+    }
+    return a;
+}
+double orient_h(const double* p, const double* q, const double* r) {
+    double a = q[0] - p[0], b = r[1] - p[1];
+    double c = q[1] - p[1], d = r[0] - p[0];
+    return a * b - c * d;
+}
+
+// fp32 CSR polygons -> fp64 CCW vertices + per-polygon AABB.  Validates convexity.
+int prepare_polys(t2d_pool* p, const int32_t* env_off, const int32_t* vert_off, const float* xy,
+                  std::vector<double>& out_xy, std::vector<double>& out_aabb, int* max_polys,
+                  int* max_verts) {
+    const int E = p->v.n_env;
+    if (env_off[0] != 0) return fail(p, T2D_ERR_INVALID, "env offsets must start at 0");
+    for (int e = 0; e < E; ++e)
+        if (env_off[e + 1] < env_off[e]) return fail(p, T2D_ERR_INVALID, "env offsets not monotone");
+    const int P = env_off[E];
+    if (P > 0 && vert_off[0] != 0) return fail(p, T2D_ERR_INVALID, "vertex offsets must start at 0");
+    const int V = P > 0 ? vert_off[P] : 0;
+    out_xy.assign(2 * (size_t)V, 0.0);
+    out_aabb.assign(4 * (size_t)P, 0.0);
+    for (int q = 0; q < P; ++q) {
+        const int v0 = vert_off[q], n = vert_off[q + 1] - v0;
+        if (n < 3 || n > T2D_MAX_POLY_VERTS)
+            return fail(p, T2D_ERR_GEOMETRY, "polygon " + std::to_string(q) + " has " +
+                                                 std::to_string(n) + " vertices (3..8 supported)");
+        std::vector<double> poly(2 * n);
+        for (int k = 0; k < 2 * n; ++k) poly[k] = (double)xy[2 * v0 + k];
+        double a = area2(poly);
+        if (a < 0.0) {  // clockwise -> reverse
+            for (int i = 0, j = n - 1; i < j; ++i, --j) {
+                std::swap(poly[2 * i], poly[2 * j]);
+                std::swap(poly[2 * i + 1], poly[2 * j + 1]);
+            }
+            a = -a;
+        }
+        if (!(a > 0.0)) return fail(p, T2D_ERR_GEOMETRY, "polygon " + std::to_string(q) + " is degenerate");
+        for (int i = 0; i < n; ++i)
+            if (orient_h(&poly[2 * i], &poly[2 * ((i + 1) % n)], &poly[2 * ((i + 2) % n)]) < 0.0)
+                return fail(p, T2D_ERR_GEOMETRY,
+                            "polygon " + std::to_string(q) + " is not convex (decompose on the host)");
+        double xmin = poly[0], xmax = poly[0], ymin = poly[1], ymax = poly[1];
+        for (int i = 0; i < n; ++i) {
+            xmin = std::min(xmin, poly[2 * i]); xmax = std::max(xmax, poly[2 * i]);
+            ymin = std::min(ymin, poly[2 * i + 1]); ymax = std::max(ymax, poly[2 * i + 1]);
+        }
+        memcpy(&out_xy[2 * (size_t)v0], poly.data(), sizeof(double) * 2 * n);
+        out_aabb[4 * (size_t)q] = xmin; out_aabb[4 * (size_t)q + 1] = xmax;
+        out_aabb[4 * (size_t)q + 2] = ymin; out_aabb[4 * (size_t)q + 3] = ymax;
+    }
+    *max_polys = 0; *max_verts = 0;
+    for (int e = 0; e < E; ++e) {
+        const int np = env_off[e + 1] - env_off[e];
+        const int nv = np > 0 ? vert_off[env_off[e + 1]] - vert_off[env_off[e]] : 0;
+        *max_polys = std::max(*max_polys, np);
+        *max_verts = std::max(*max_verts, nv);
+    }
+    return T2D_OK;
+}
+
+int record_event(t2d_pool* p, int kernel_id, hipStream_t s, bool begin) {
+    if (!p->profiling) return T2D_OK;
+    if (begin) {
+        if (p->prof_count + 2 > 2 * t2d_pool::kMaxProfSteps) return T2D_OK;  // buffer full
+    } else if (!(p->prof_count & 1)) {
+        return T2D_OK;  // the matching begin was skipped
+    }
+    T2D_HIP(p, hipEventRecord(p->prof_events[p->prof_count], s));
+    p->prof_kernel[p->prof_count] = kernel_id;
+    p->prof_count++;
+    return T2D_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* t2d_last_error(const t2d_pool* pool) {
+    return pool ? pool->err.c_str() : g_create_err.c_str();
+}
+int t2d_abi_version(void) { return T2D_ABI_VERSION; }
+
+int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** out_pool) {
+    if (!out_pool) return fail(nullptr, T2D_ERR_INVALID, "out_pool is null");
+    *out_pool = nullptr;
+    if (n_env <= 0 || max_agents <= 0 || max_agents > T2D_MAX_AGENTS)
+        return fail(nullptr, T2D_ERR_INVALID, "n_env must be > 0 and 1 <= max_agents <= 256");
+    if ((int64_t)n_env * max_agents > (int64_t)1 << 30)
+        return fail(nullptr, T2D_ERR_INVALID, "pool too large");
+    int n_dev = 0;
+    T2D_HIP(nullptr, hipGetDeviceCount(&n_dev));
+    if (device_id < 0 || device_id >= n_dev)
+        return fail(nullptr, T2D_ERR_HIP, "HIP device " + std::to_string(device_id) + " not available (" +
+                                              std::to_string(n_dev) + " devices visible)");
+    T2D_HIP(nullptr, hipSetDevice(device_id));
+    t2d_pool* p = new (std::nothrow) t2d_pool();
+    if (!p) return fail(nullptr, T2D_ERR_NOMEM, "host allocation failed");
+    p->device = device_id;
+    p->v.n_env = n_env;
+    p->v.A = max_agents;
+    p->v.N = n_env * max_agents;
+    for (int f = 0; f < T2D_F_COUNT; ++f) {
+        const size_t n = field_per_env(f) ? (size_t)n_env : (size_t)p->v.N;
+        p->field_bytes[f] = n * field_elem_bytes(f);
+        hipError_t e = hipMalloc(&p->field_ptr[f], p->field_bytes[f]);
+        if (e == hipSuccess) e = hipMemset(p->field_ptr[f], 0, p->field_bytes[f]);
+        if (e != hipSuccess) {
+            std::string msg = std::string("hipMalloc/hipMemset: ") + hipGetErrorString(e);
+            t2d_destroy(p);
+            return fail(nullptr, e == hipErrorOutOfMemory ? T2D_ERR_NOMEM : T2D_ERR_HIP, msg);
+        }
+    }
+    hipError_t e = hipMalloc((void**)&p->d_params, sizeof(double) * T2D_PARAM_COLS * T2D_MAX_TYPES);
+    if (e != hipSuccess) {
+        t2d_destroy(p);
+        return fail(nullptr, T2D_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
+    t2d::PoolView& v = p->v;
+    v.x = (float*)p->field_ptr[T2D_F_X];
+    v.y = (float*)p->field_ptr[T2D_F_Y];
+    v.heading = (float*)p->field_ptr[T2D_F_HEADING];
+    v.speed = (float*)p->field_ptr[T2D_F_SPEED];
+    v.vx = (float*)p->field_ptr[T2D_F_VX];
+    v.vy = (float*)p->field_ptr[T2D_F_VY];
+    v.act0 = (float*)p->field_ptr[T2D_F_ACT0];
+    v.act1 = (float*)p->field_ptr[T2D_F_ACT1];
+    v.applied0 = (float*)p->field_ptr[T2D_F_APPLIED0];
+    v.applied1 = (float*)p->field_ptr[T2D_F_APPLIED1];
+    v.ids = (uint32_t*)p->field_ptr[T2D_F_IDS];
+    v.flags = (uint32_t*)p->field_ptr[T2D_F_FLAGS];
+    v.env_flags = (uint32_t*)p->field_ptr[T2D_F_ENV_FLAGS];
+    v.cnt_step = (int32_t*)p->field_ptr[T2D_F_CNT_STEP];
+    v.frame_ms = (int32_t*)p->field_ptr[T2D_F_FRAME_MS];
+    v.status = (uint8_t*)p->field_ptr[T2D_F_STATUS];
+    v.reward = (float*)p->field_ptr[T2D_F_REWARD];
+    v.params = p->d_params;
+    v.cell = 1.0;
+    v.inv_cell = 1.0;
+    // ParkingEnv defaults: envs/parking.py:106 (max_step 2e4), :151-163 (reward table)
+    p->status_cfg = t2d_status_config{20000, 0, 0, 0, -5.0f, -1.0f, -5.0f, 5.0f, 0.001f};
+    *out_pool = p;
+    return T2D_OK;
+}
+
+int t2d_destroy(t2d_pool* p) {
+    if (!p) return T2D_OK;
+    (void)hipSetDevice(p->device);
+    for (int f = 0; f < T2D_F_COUNT; ++f)
+        if (p->field_ptr[f]) (void)hipFree(p->field_ptr[f]);
+    void* bufs[] = {p->d_params, p->d_env_poly_off, p->d_poly_vert_off, p->d_poly_xy, p->d_poly_aabb,
+                    p->d_boundary, p->d_boundary_valid, p->d_env_lane_off, p->d_lane_vert_off,
+                    p->d_lane_xy, p->d_lane_aabb};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (p->prof_events) {
+        for (int i = 0; i < 2 * t2d_pool::kMaxProfSteps; ++i) (void)hipEventDestroy(p->prof_events[i]);
+        delete[] p->prof_events;
+    }
+    delete p;
+    return T2D_OK;
+}
+
+int t2d_set_param_table(t2d_pool* p, const double* rows, int32_t n_types, int32_t row_stride) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!rows || n_types <= 0 || n_types > T2D_MAX_TYPES || row_stride < T2D_PARAM_COLS)
+        return fail(p, T2D_ERR_INVALID, "need 1..32 types and row_stride >= 24");
+    T2D_HIP(p, hipSetDevice(p->device));
+    std::vector<double> t(T2D_PARAM_COLS * T2D_MAX_TYPES, 0.0);
+    double dmax = 0.0;
+    for (int ty = 0; ty < n_types; ++ty) {
+        const double* r = rows + (size_t)ty * row_stride;
+        const int model = (int)r[T2D_P_MODEL];
+        if (model < 0 || model > T2D_MODEL_POINTMASS)
+            return fail(p, T2D_ERR_INVALID, "row " + std::to_string(ty) + ": unknown model id");
+        const int dt = (int)r[T2D_P_DELTA_T_MS];
+        if (dt < 1) return fail(p, T2D_ERR_INVALID, "row " + std::to_string(ty) + ": delta_t must be >= 1 ms");
+        if (model != T2D_MODEL_POINTMASS && !(r[T2D_P_WB] != 0.0))
+            return fail(p, T2D_ERR_INVALID, "row " + std::to_string(ty) + ": zero wheel base");
+        for (int c = 0; c < T2D_PARAM_COLS; ++c) {
+            p->host_params[ty][c] = r[c];
+            t[(size_t)c * T2D_MAX_TYPES + ty] = r[c];
+        }
+        const double L = r[T2D_P_LENGTH], W = r[T2D_P_WIDTH];
+        const double br = (int)r[T2D_P_SHAPE] == T2D_SHAPE_CIRCLE ? 0.5 * W : 0.5 * sqrt(L * L + W * W);
+        t[(size_t)T2D_P_RESERVED0 * T2D_MAX_TYPES + ty] = br;  // bounding radius for the reject test
+        dmax = std::max(dmax, 2.0 * br);
+    }
+    p->v.n_types = n_types;
+    p->v.cell = dmax * 1.001 + 1e-3;  // 3x3 cell neighbourhood is then provably sufficient
+    p->v.inv_cell = 1.0 / p->v.cell;
+    T2D_HIP(p, hipMemcpy(p->d_params, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+    p->have_params = true;
+    return T2D_OK;
+}
+
+int t2d_set_static_geometry(t2d_pool* p, const int32_t* env_poly_offsets,
+                            const int32_t* poly_vert_offsets, const float* verts_xy,
+                            const float* boundary, const uint8_t* boundary_valid) {
+    if (!p) return T2D_ERR_INVALID;
+    T2D_HIP(p, hipSetDevice(p->device));
+    const int E = p->v.n_env;
+    int rc;
+    if (env_poly_offsets) {
+        if (!poly_vert_offsets || (!verts_xy && env_poly_offsets[E] > 0))
+            return fail(p, T2D_ERR_INVALID, "polygon CSR arrays missing");
+        std::vector<double> xy, bb;
+        if ((rc = prepare_polys(p, env_poly_offsets, poly_vert_offsets, verts_xy, xy, bb,
+                                &p->geo_max[0], &p->geo_max[1])) != T2D_OK)
+            return rc;
+        const int P = env_poly_offsets[E];
+        if ((rc = dev_replace(p, &p->d_env_poly_off, env_poly_offsets, (size_t)E + 1))) return rc;
+        if ((rc = dev_replace(p, &p->d_poly_vert_off, poly_vert_offsets, (size_t)P + 1))) return rc;
+        if ((rc = dev_replace(p, &p->d_poly_xy, xy.data(), xy.size()))) return rc;
+        if ((rc = dev_replace(p, &p->d_poly_aabb, bb.data(), bb.size()))) return rc;
+    } else {
+        if ((rc = dev_replace<int32_t>(p, &p->d_env_poly_off, nullptr, 0))) return rc;
+        p->geo_max[0] = p->geo_max[1] = 0;
+    }
+    if (boundary) {
+        if ((rc = dev_replace(p, &p->d_boundary, boundary, (size_t)4 * E))) return rc;
+        if ((rc = dev_replace(p, &p->d_boundary_valid, boundary_valid, boundary_valid ? (size_t)E : 0)))
+            return rc;
+    } else {
+        if ((rc = dev_replace<float>(p, &p->d_boundary, nullptr, 0))) return rc;
+        if ((rc = dev_replace<uint8_t>(p, &p->d_boundary_valid, nullptr, 0))) return rc;
+    }
+    p->v.env_poly_off = p->d_env_poly_off;
+    p->v.poly_vert_off = p->d_poly_vert_off;
+    p->v.poly_xy = p->d_poly_xy;
+    p->v.poly_aabb = p->d_poly_aabb;
+    p->v.boundary = p->d_boundary;
+    p->v.boundary_valid = p->d_boundary_valid;
+    return T2D_OK;
+}
+
+int t2d_set_lane_geometry(t2d_pool* p, const int32_t* env_lane_offsets,
+                          const int32_t* lane_vert_offsets, const float* verts_xy) {
+    if (!p) return T2D_ERR_INVALID;
+    T2D_HIP(p, hipSetDevice(p->device));
+    const int E = p->v.n_env;
+    int rc;
+    if (env_lane_offsets) {
+        if (!lane_vert_offsets || (!verts_xy && env_lane_offsets[E] > 0))
+            return fail(p, T2D_ERR_INVALID, "lane CSR arrays missing");
+        std::vector<double> xy, bb;
+        if ((rc = prepare_polys(p, env_lane_offsets, lane_vert_offsets, verts_xy, xy, bb,
+                                &p->geo_max[2], &p->geo_max[3])) != T2D_OK)
+            return rc;
+        const int P = env_lane_offsets[E];
+        if ((rc = dev_replace(p, &p->d_env_lane_off, env_lane_offsets, (size_t)E + 1))) return rc;
+        if ((rc = dev_replace(p, &p->d_lane_vert_off, lane_vert_offsets, (size_t)P + 1))) return rc;
+        if ((rc = dev_replace(p, &p->d_lane_xy, xy.data(), xy.size()))) return rc;
+        if ((rc = dev_replace(p, &p->d_lane_aabb, bb.data(), bb.size()))) return rc;
+    } else {
+        if ((rc = dev_replace<int32_t>(p, &p->d_env_lane_off, nullptr, 0))) return rc;
+        p->geo_max[2] = p->geo_max[3] = 0;
+    }
+    p->v.env_lane_off = p->d_env_lane_off;
+    p->v.lane_vert_off = p->d_lane_vert_off;
+    p->v.lane_xy = p->d_lane_xy;
+    p->v.lane_aabb = p->d_lane_aabb;
+    return T2D_OK;
+}
+
+int t2d_set_status_config(t2d_pool* p, const t2d_status_config* cfg) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!cfg) return fail(p, T2D_ERR_INVALID, "cfg is null");
+    if (cfg->ego_index < 0 || cfg->ego_index >= p->v.A)
+        return fail(p, T2D_ERR_INVALID, "ego_index out of range");
+    p->status_cfg = *cfg;
+    return T2D_OK;
+}
+
+int t2d_reset(t2d_pool* p, const uint8_t* env_mask, const float* x, const float* y,
+              const float* heading, const float* speed, const float* vx, const float* vy,
+              const uint8_t* type_id, const uint8_t* active) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!p->have_params) return fail(p, T2D_ERR_STATE, "t2d_set_param_table must precede t2d_reset");
+    if (!x || !y || !heading || !speed || !type_id || !active)
+        return fail(p, T2D_ERR_INVALID, "x, y, heading, speed, type_id, active are required");
+    T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, hipDeviceSynchronize());
+    const int E = p->v.n_env, A = p->v.A, N = p->v.N;
+    std::vector<float> hx(N), hy(N), hh(N), hs(N), hvx(N), hvy(N);
+    std::vector<uint32_t> hids(N), hflags(N);
+    std::vector<uint32_t> henv(E);
+    std::vector<int32_t> hcnt(E), hframe(E);
+    std::vector<uint8_t> hstat(4 * (size_t)E);
+    std::vector<float> hrew(E);
+    const bool partial = env_mask != nullptr;
+    if (partial) {  // read-modify-write of the unselected envs
+        T2D_HIP(p, hipMemcpy(hx.data(), p->v.x, 4 * (size_t)N, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(hy.data(), p->v.y, 4 * (size_t)N, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(hh.data(), p->v.heading, 4 * (size_t)N, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(hs.data(), p->v.speed, 4 * (size_t)N, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(hvx.data(), p->v.vx, 4 * (size_t)N, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(hvy.data(), p->v.vy, 4 * (size_t)N, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(hids.data(), p->v.ids, 4 * (size_t)N, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(hflags.data(), p->v.flags, 4 * (size_t)N, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(henv.data(), p->v.env_flags, 4 * (size_t)E, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(hcnt.data(), p->v.cnt_step, 4 * (size_t)E, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(hframe.data(), p->v.frame_ms, 4 * (size_t)E, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(hstat.data(), p->v.status, 4 * (size_t)E, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(hrew.data(), p->v.reward, 4 * (size_t)E, hipMemcpyDeviceToHost));
+    }
+    for (int e = 0; e < E; ++e) {
+        if (partial && !env_mask[e]) continue;
+        for (int a = 0; a < A; ++a) {
+            const size_t i = (size_t)e * A + a;
+            const int ty = type_id[i];
+            if (active[i] && ty >= p->v.n_types)
+                return fail(p, T2D_ERR_INVALID, "type_id " + std::to_string(ty) + " not in the parameter table");
+            hx[i] = x[i]; hy[i] = y[i]; hh[i] = heading[i]; hs[i] = speed[i];
+            if (vx && vy) {
+                hvx[i] = vx[i]; hvy[i] = vy[i];
+            } else {  // State.velocity: (speed*cos(heading), speed*sin(heading))  state.py:161-166
+                hvx[i] = (float)((double)speed[i] * cos((double)heading[i]));
+                hvy[i] = (float)((double)speed[i] * sin((double)heading[i]));
+            }
+            const int model = active[i] ? (int)p->host_params[ty][T2D_P_MODEL] : 0;
+            hids[i] = ((uint32_t)model << t2d::kIdsModelShift) | ((uint32_t)ty << t2d::kIdsTypeShift) |
+                      ((uint32_t)(active[i] ? 1 : 0) << t2d::kIdsActiveShift);
+            hflags[i] = 0;
+        }
+        henv[e] = 0; hcnt[e] = 0; hframe[e] = 0; hrew[e] = 0.0f;
+        hstat[4 * (size_t)e] = T2D_SCENARIO_NORMAL; hstat[4 * (size_t)e + 1] = T2D_TRAFFIC_NORMAL;
+        hstat[4 * (size_t)e + 2] = 0; hstat[4 * (size_t)e + 3] = 0;
+    }
+    T2D_HIP(p, hipMemcpy(p->v.x, hx.data(), 4 * (size_t)N, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->v.y, hy.data(), 4 * (size_t)N, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->v.heading, hh.data(), 4 * (size_t)N, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->v.speed, hs.data(), 4 * (size_t)N, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->v.vx, hvx.data(), 4 * (size_t)N, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->v.vy, hvy.data(), 4 * (size_t)N, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->v.ids, hids.data(), 4 * (size_t)N, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->v.flags, hflags.data(), 4 * (size_t)N, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->v.env_flags, henv.data(), 4 * (size_t)E, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->v.cnt_step, hcnt.data(), 4 * (size_t)E, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->v.frame_ms, hframe.data(), 4 * (size_t)E, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->v.status, hstat.data(), 4 * (size_t)E, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->v.reward, hrew.data(), 4 * (size_t)E, hipMemcpyHostToDevice));
+    p->have_reset = true;
+    return T2D_OK;
+}
+
+int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!p->have_params || !p->have_reset)
+        return fail(p, T2D_ERR_STATE, "t2d_set_param_table and t2d_reset must precede t2d_integrate");
+    if (interval_ms <= 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be positive");
+    hipStream_t s = (hipStream_t)hip_stream;
+    int rc;
+    if ((rc = record_event(p, 0, s, true))) return rc;
+    T2D_HIP(p, t2d::launch_integrate(p->v, interval_ms, p->integrator_variant, s));
+    return record_event(p, 0, s, false);
+}
+
+static int collide_impl(t2d_pool* p, bool with_status, int interval_ms, hipStream_t s) {
+    int rc;
+    if ((rc = record_event(p, 1, s, true))) return rc;
+    T2D_HIP(p, t2d::launch_collide(p->v, p->status_cfg, with_status, interval_ms, p->geo_max, s));
+    return record_event(p, 1, s, false);
+}
+
+int t2d_collide(t2d_pool* p, void* hip_stream) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!p->have_params || !p->have_reset)
+        return fail(p, T2D_ERR_STATE, "t2d_set_param_table and t2d_reset must precede t2d_collide");
+    return collide_impl(p, false, 0, (hipStream_t)hip_stream);
+}
+
+int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
+    int rc = t2d_integrate(p, interval_ms, hip_stream);
+    if (rc != T2D_OK) return rc;
+    return collide_impl(p, true, interval_ms, (hipStream_t)hip_stream);
+}
+
+int t2d_get_field(t2d_pool* p, int32_t f, void** dev_ptr, size_t* nbytes) {
+    if (!p) return T2D_ERR_INVALID;
+    if (f < 0 || f >= T2D_F_COUNT || !dev_ptr) return fail(p, T2D_ERR_INVALID, "bad field id");
+    *dev_ptr = p->field_ptr[f];
+    if (nbytes) *nbytes = p->field_bytes[f];
+    return T2D_OK;
+}
+
+int t2d_download(t2d_pool* p, int32_t f, void* host_dst, size_t nbytes) {
+    if (!p) return T2D_ERR_INVALID;
+    if (f < 0 || f >= T2D_F_COUNT || !host_dst || nbytes != p->field_bytes[f])
+        return fail(p, T2D_ERR_INVALID, "bad field id / size (expected " +
+                                            std::to_string(f >= 0 && f < T2D_F_COUNT ? p->field_bytes[f] : 0) + " bytes)");
+    T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, hipMemcpy(host_dst, p->field_ptr[f], nbytes, hipMemcpyDeviceToHost));
+    return T2D_OK;
+}
+
+int t2d_upload(t2d_pool* p, int32_t f, const void* host_src, size_t nbytes) {
+    if (!p) return T2D_ERR_INVALID;
+    if (f < 0 || f >= T2D_F_COUNT || !host_src || nbytes != p->field_bytes[f])
+        return fail(p, T2D_ERR_INVALID, "bad field id / size");
+    T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, hipMemcpy(p->field_ptr[f], host_src, nbytes, hipMemcpyHostToDevice));
+    return T2D_OK;
+}
+
+int t2d_sync(t2d_pool* p) {
+    if (!p) return T2D_ERR_INVALID;
+    T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, hipDeviceSynchronize());
+    return T2D_OK;
+}
+
+int t2d_set_integrator_variant(t2d_pool* p, int32_t variant) {
+    if (!p) return T2D_ERR_INVALID;
+    if (variant != 0 && variant != 1) return fail(p, T2D_ERR_INVALID, "variant must be 0 (exact) or 1 (fast)");
+    p->integrator_variant = variant;
+    return T2D_OK;
+}
+
+int t2d_profile_enable(t2d_pool* p, int32_t on) {
+    if (!p) return T2D_ERR_INVALID;
+    T2D_HIP(p, hipSetDevice(p->device));
+    if (on && !p->prof_events) {
+        p->prof_events = new hipEvent_t[2 * t2d_pool::kMaxProfSteps];
+        for (int i = 0; i < 2 * t2d_pool::kMaxProfSteps; ++i) T2D_HIP(p, hipEventCreate(&p->prof_events[i]));
+    }
+    p->profiling = on != 0;
+    p->prof_count = 0;
+    return T2D_OK;
+}
+
+int t2d_profile_read(t2d_pool* p, int32_t kernel_id, double* total_ms, int64_t* launches) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!total_ms || !launches) return fail(p, T2D_ERR_INVALID, "null output");
+    T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, hipDeviceSynchronize());
+    double tot = 0.0;
+    int64_t n = 0;
+    for (int i = 0; i + 1 < p->prof_count; i += 2) {
+        if (p->prof_kernel[i] != kernel_id) continue;
+        float ms = 0.f;
+        T2D_HIP(p, hipEventElapsedTime(&ms, p->prof_events[i], p->prof_events[i + 1]));
+        tot += ms;
+        ++n;
+    }
+    *total_ms = tot;
+    *launches = n;
+    return T2D_OK;
+}
+
+}  // extern "C"

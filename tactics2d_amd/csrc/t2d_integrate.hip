@@ -1,0 +1,331 @@
+// t2d_integrate.hip -- wavefront-parallel physics integrator for gfx950 (MI355X).
+//
+// One lane = one participant; a wave64 = 64 consecutive pool slots (one env's 64 agents,
+// 2 x 32-agent envs, or 64 single-agent envs), so every SoA field load/store is one
+// coalesced 256-B transaction.  The per-type parameter table is staged once per workgroup
+// into LDS in the transposed [column][type] layout (conflict-free: lanes read one column at
+// consecutive type slots; equal types broadcast).
+//
+// Replaces (reference, tactics2d v0.1.9rc3):
+//   SingleTrackKinematics.step/_step   physics/single_track_kinematics.py:126-198
+//   SingleTrackDynamics.step/_step     physics/single_track_dynamics.py:140-251
+//   PointMass.step/_step_newton        physics/point_mass.py:83-175,209-232
+//
+// Arithmetic contract (DESIGN.md "Precision"): state is stored fp32, every accumulator is
+// fp64 in registers, one rounding on store.  All recurrences that feed back (phi, v, beta,
+// d_phi) are evaluated with the reference's association and no contraction
+// (-ffp-contract=off), so they equal the CPU oracle bit for bit given equal trig inputs.
+//   VARIANT 0 "exact": deterministic sin/cos of (phi + beta) every sub-step -- bit-identical
+//                      to oracle/t2d_oracle.c in deterministic-trig mode.
+//   VARIANT 1 "fast" : cos/sin(phi + beta) advanced by an fp64 rotation recurrence (9th/10th
+//                      order Taylor in the sub-step angle, |eps| <= 0.25, else re-seeded);
+//                      only x, y, vx, vy (pure outputs) see it; error << 1e-9.
+//
+// Roofline: nominally HBM-streaming (44-60 B per participant-step), but 20 explicit-Euler
+// sub-steps of fp64 math per participant make it VALU-bound; see DESIGN.md.
+#include "t2d_math.h"
+#include "t2d_pool.h"
+
+namespace t2d {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr double kG = 9.81;  // PhysicsModelBase._G
+
+struct StepOut {
+    double x, y, heading, speed, vx, vy, app0, app1;
+    bool has_velocity;
+};
+
+// rotate (c, s) by angle eps, |eps| <= 0.25
+T2D_DEV void rotate_small(double eps, double& c, double& s) {
+    double e2 = eps * eps;
+    double ps = __builtin_fma(e2, 1.0 / 362880.0, -1.0 / 5040.0);
+    ps = __builtin_fma(e2, ps, 1.0 / 120.0);
+    ps = __builtin_fma(e2, ps, -1.0 / 6.0);
+    ps = __builtin_fma(e2, ps, 1.0);
+    double se = eps * ps;
+    double pc = __builtin_fma(e2, -1.0 / 3628800.0, 1.0 / 40320.0);
+    pc = __builtin_fma(e2, pc, -1.0 / 720.0);
+    pc = __builtin_fma(e2, pc, 1.0 / 24.0);
+    pc = __builtin_fma(e2, pc, -0.5);
+    double ce = __builtin_fma(e2, pc, 1.0);
+    double cn = __builtin_fma(c, ce, -(s * se));
+    double sn = __builtin_fma(s, ce, c * se);
+    c = cn;
+    s = sn;
+}
+
+template <int VARIANT, typename PF>
+T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, double accel,
+                                double delta, int interval) {
+    int flags = (int)P(T2D_P_RANGE_FLAGS);
+    if (flags & T2D_RANGE_ACCEL) accel = clipd(accel, P(T2D_P_ACCEL_LO), P(T2D_P_ACCEL_HI));
+    if (flags & T2D_RANGE_STEER) delta = clipd(delta, P(T2D_P_STEER_LO), P(T2D_P_STEER_HI));
+    const bool clip_v = flags & T2D_RANGE_SPEED;
+    const double vlo = P(T2D_P_SPEED_LO), vhi = P(T2D_P_SPEED_HI);
+    const double lr = P(T2D_P_LR), wb = P(T2D_P_WB);
+    const int delta_t = (int)P(T2D_P_DELTA_T_MS);
+    const double dt = (double)delta_t / 1000;
+    const int n_steps = interval / delta_t;
+    const int rem = interval - n_steps * delta_t;
+    const double tand = tan_det(delta);
+    const double t = lr / wb * tand;
+    const int total = n_steps + (rem > 0 ? 1 : 0);
+    StepOut o;
+    if (VARIANT == 0) {
+        const double beta = atan_det(t);
+        double sb, cb;
+        sincos_det(beta, sb, cb);
+        for (int k = 0; k < total; ++k) {
+            double h = k < n_steps ? dt : (double)rem / 1000;
+            double sn, cs;
+            sincos_det(phi + beta, sn, cs);
+            double dx = v * cs;
+            double dy = v * sn;
+            double dphi = v / wb * tand * cb;
+            x += dx * h;
+            y += dy * h;
+            phi += dphi * h;
+            v += accel * h;
+            if (clip_v) v = clipd(v, vlo, vhi);
+        }
+        double sp, cp;
+        sincos_det(phi, sp, cp);
+        o.vx = v * cp;
+        o.vy = v * sp;
+    } else {
+        // cos(beta) = 1/sqrt(1+t^2), sin(beta) = t*cos(beta): no atan needed
+        const double cb = 1.0 / __builtin_sqrt(__builtin_fma(t, t, 1.0));
+        const double sb = t * cb;
+        double sp, cp;
+        sincos_det(phi, sp, cp);
+        double c = cp * cb - sp * sb;  // cos(phi + beta)
+        double s = sp * cb + cp * sb;
+        const double kk = tand * cb / wb;
+        for (int k = 0; k < total; ++k) {
+            double h = k < n_steps ? dt : (double)rem / 1000;
+            double eps = (v * kk) * h;
+            x += (v * c) * h;
+            y += (v * s) * h;
+            phi += eps;
+            v += accel * h;
+            if (clip_v) v = clipd(v, vlo, vhi);
+            if (__builtin_fabs(eps) <= 0.25) {
+                rotate_small(eps, c, s);
+            } else {  // absurd yaw rates (unbounded speed): re-seed from phi
+                double s2, c2;
+                sincos_det(phi, s2, c2);
+                c = c2 * cb - s2 * sb;
+                s = s2 * cb + c2 * sb;
+            }
+        }
+        // cos(phi) = cos((phi+beta) - beta)
+        o.vx = v * (c * cb + s * sb);
+        o.vy = v * (s * cb - c * sb);
+    }
+    o.x = x;
+    o.y = y;
+    o.heading = mod_two_pi(phi);
+    o.speed = v;
+    o.app0 = accel;
+    o.app1 = delta;
+    o.has_velocity = true;
+    return o;
+}
+
+template <int VARIANT, typename PF>
+T2D_DEV StepOut step_dynamics(PF P, double x, double y, double phi, double v, double accel,
+                              double delta, int interval) {
+    int flags = (int)P(T2D_P_RANGE_FLAGS);
+    if (flags & T2D_RANGE_ACCEL) accel = clipd(accel, P(T2D_P_ACCEL_LO), P(T2D_P_ACCEL_HI));
+    if (flags & T2D_RANGE_STEER) delta = clipd(delta, P(T2D_P_STEER_LO), P(T2D_P_STEER_HI));
+    const bool clip_v = flags & T2D_RANGE_SPEED;
+    const double vlo = P(T2D_P_SPEED_LO), vhi = P(T2D_P_SPEED_HI);
+    const double lf = P(T2D_P_LF), lr = P(T2D_P_LR), wb = P(T2D_P_WB);
+    const double mass = P(T2D_P_MASS), hcg = P(T2D_P_MASS_HEIGHT), mu = P(T2D_P_MU);
+    const double Iz = P(T2D_P_IZ), cf = P(T2D_P_CF), cr = P(T2D_P_CR);
+    const int delta_t = (int)P(T2D_P_DELTA_T_MS);
+    const double dt = (double)delta_t / 1000;
+    const int n_steps = interval / delta_t;  // the remainder is never integrated (:143)
+
+    const double factor_f = (kG * lr - accel * hcg) / wb;
+    const double factor_r = (kG * lf + accel * hcg) / wb;
+    const double lf_cf_ff = lf * cf * factor_f;
+    const double lr_cr_fr = lr * cr * factor_r;
+    const double lf2_cf_ff = lf * lf * cf * factor_f;
+    const double lr2_cr_fr = lr * lr * cr * factor_r;
+    const double cf_ff = cf * factor_f;
+    const double cr_fr = cr * factor_r;
+    const double mmi = mu * mass / Iz;
+    const double k21 = lr_cr_fr - lf_cf_ff;
+    const double k34 = lf2_cf_ff + lr2_cr_fr;
+    const double k65 = cr_fr + cf_ff;
+
+    const double tand = tan_det(delta);
+    double d_phi = v / wb * tand;
+    double beta = atan_det(lr / lf * tand);
+
+    // low-speed branch constants (only evaluated when some sub-step has |v| < 0.1)
+    double c, s;
+    if (VARIANT == 1) sincos_det(phi + beta, s, c);
+
+    for (int k = 0; k < n_steps; ++k) {
+        if (VARIANT == 0) sincos_det(phi + beta, s, c);
+        double dx = v * c;
+        double dy = v * s;
+        double av = __builtin_fabs(v);
+        double v_safe = av > 1e-6 ? v : (v >= 0 ? 1e-6 : -1e-6);
+        double d_beta;
+        if (av >= 0.1) {
+            double dd_phi = mmi * (lf_cf_ff * delta + k21 * beta - k34 * d_phi / v_safe);
+            d_beta = mu / v_safe * (cf_ff * delta - k65 * beta + k21 * d_phi / v_safe) - d_phi;
+            d_phi += dd_phi * dt;
+        } else {
+            double tb = 1 + tand * lr / wb;
+            double sd, cd;
+            sincos_det(delta, sd, cd);
+            d_beta = lr / (tb * tb) / wb / (cd * cd) * delta;
+            double sbt, cbt;
+            sincos_det(beta, sbt, cbt);
+            d_phi += v * cbt / wb * tand * dt;
+        }
+        x += dx * dt;
+        y += dy * dt;
+        v += accel * dt;
+        double e1 = d_phi * dt;
+        double e2 = d_beta * dt;
+        phi += e1;
+        beta += e2;
+        if (clip_v) v = clipd(v, vlo, vhi);
+        if (VARIANT == 1) {
+            double eps = e1 + e2;
+            if (__builtin_fabs(eps) <= 0.25) rotate_small(eps, c, s);
+            else sincos_det(phi + beta, s, c);
+        }
+    }
+    StepOut o;
+    o.x = x;
+    o.y = y;
+    o.heading = mod_two_pi(phi);
+    o.speed = v;
+    o.vx = 0.0;
+    o.vy = 0.0;
+    o.app0 = accel;
+    o.app1 = delta;
+    o.has_velocity = false;  // reference State has vx = vy = None (:220-227)
+    return o;
+}
+
+template <typename PF>
+T2D_DEV StepOut step_pointmass(PF P, double x, double y, double vx, double vy, double ax,
+                               double ay, int interval) {
+    int flags = (int)P(T2D_P_RANGE_FLAGS);
+    const double lo = P(T2D_P_SPEED_LO), hi = P(T2D_P_SPEED_HI);
+    const double dt = (double)interval / 1000;
+    double nvx = vx + ax * dt;
+    double nvy = vy + ay * dt;
+    double ns = __builtin_sqrt(nvx * nvx + nvy * nvy);
+    StepOut o;
+    double ovx, ovy;
+    if (!(flags & T2D_RANGE_SPEED) || (lo <= ns && ns <= hi)) {
+        o.x = x + vx * dt + 0.5 * ax * (dt * dt);
+        o.y = y + vy * dt + 0.5 * ay * (dt * dt);
+        ovx = nvx;
+        ovy = nvy;
+    } else {
+        bool lower = ns < lo;
+        double bound = lower ? lo : hi;
+        double a_ = ax * ax + ay * ay;
+        double b_ = 2 * (ax * vx + ay * vy);
+        double c_ = vx * vx + vy * vy - bound * bound;
+        double t1;
+        if (__builtin_fabs(a_) < 1e-12) {
+            t1 = __builtin_fabs(b_) < 1e-12 ? 0.0 : -c_ / b_;
+        } else {
+            double disc = b_ * b_ - 4 * a_ * c_;
+            if (!(disc > 0.0)) disc = 0.0;
+            double sq = __builtin_sqrt(disc);
+            t1 = lower ? (-b_ - sq) / (2 * a_) : (-b_ + sq) / (2 * a_);
+        }
+        t1 = clipd(t1, 0.0, dt);
+        double t2 = dt - t1;
+        ovx = vx + ax * t1;
+        ovy = vy + ay * t1;
+        o.x = x + vx * t1 + 0.5 * ax * (t1 * t1) + ovx * t2;
+        o.y = y + vy * t1 + 0.5 * ay * (t1 * t1) + ovy * t2;
+    }
+    o.heading = atan2_det(ovy, ovx);
+    o.speed = __builtin_sqrt(ovx * ovx + ovy * ovy);
+    o.vx = ovx;
+    o.vy = ovy;
+    o.app0 = ax;
+    o.app1 = ay;
+    o.has_velocity = true;
+    return o;
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(kBlock) void integrate_kernel(PoolView pv, int interval_ms) {
+    __shared__ double s_par[T2D_PARAM_COLS * T2D_MAX_TYPES];  // 6 KiB
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kBlock + tid;
+    const bool in_range = i < pv.N;
+
+    // issue the coalesced state loads before the table staging so their latency overlaps it
+    uint32_t ids = 0;
+    float fx = 0, fy = 0, fh = 0, fv = 0, fa0 = 0, fa1 = 0;
+    if (in_range) {
+        ids = pv.ids[i];
+        fx = pv.x[i];
+        fy = pv.y[i];
+        fh = pv.heading[i];
+        fv = pv.speed[i];
+        fa0 = pv.act0[i];
+        fa1 = pv.act1[i];
+    }
+    for (int k = tid; k < T2D_PARAM_COLS * T2D_MAX_TYPES; k += kBlock) s_par[k] = pv.params[k];
+    __syncthreads();
+
+    const bool active = in_range && ((ids >> kIdsActiveShift) & 0xffu);
+    if (!active) return;
+    const int type = (ids >> kIdsTypeShift) & 0xff;
+    const int model = (ids >> kIdsModelShift) & 0xff;
+    auto P = [&](int col) -> double { return s_par[col * T2D_MAX_TYPES + type]; };
+
+    StepOut o;
+    if (model == T2D_MODEL_KINEMATICS) {
+        o = step_kinematics<VARIANT>(P, (double)fx, (double)fy, (double)fh, (double)fv, (double)fa0,
+                                     (double)fa1, interval_ms);
+    } else if (model == T2D_MODEL_DYNAMICS) {
+        o = step_dynamics<VARIANT>(P, (double)fx, (double)fy, (double)fh, (double)fv, (double)fa0,
+                                   (double)fa1, interval_ms);
+    } else {
+        o = step_pointmass(P, (double)fx, (double)fy, (double)pv.vx[i], (double)pv.vy[i],
+                           (double)fa0, (double)fa1, interval_ms);
+    }
+    pv.x[i] = (float)o.x;
+    pv.y[i] = (float)o.y;
+    pv.heading[i] = (float)o.heading;
+    pv.speed[i] = (float)o.speed;
+    if (o.has_velocity) {
+        pv.vx[i] = (float)o.vx;
+        pv.vy[i] = (float)o.vy;
+    }
+    pv.applied0[i] = (float)o.app0;
+    pv.applied1[i] = (float)o.app1;
+}
+
+}  // namespace
+
+hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hipStream_t s) {
+    const int grid = (v.N + kBlock - 1) / kBlock;
+    if (variant == 0)
+        hipLaunchKernelGGL(integrate_kernel<0>, dim3(grid), dim3(kBlock), 0, s, v, interval_ms);
+    else
+        hipLaunchKernelGGL(integrate_kernel<1>, dim3(grid), dim3(kBlock), 0, s, v, interval_ms);
+    return hipGetLastError();
+}
+
+}  // namespace t2d

@@ -1,0 +1,87 @@
+// t2d_pool.h -- internal layout of a participant pool (host + device views).
+//
+// Data layout in HBM (all allocations hipMalloc'ed once in t2d_create, 256-B aligned):
+//   per participant, N = n_env * max_agents, env-major (idx = env * A + agent), one
+//   contiguous array per field (Struct-of-Arrays) so a wave64 touching 64 consecutive
+//   participants issues one 256-B coalesced transaction per field:
+//     x, y, heading, speed, vx, vy, act0, act1, applied0, applied1 : f32[N]
+//     ids, flags                                                   : u32[N]
+//   per env: env_flags u32[E], cnt_step i32[E], frame_ms i32[E], status u8[4E], reward f32[E]
+//   parameter table: fp64, TRANSPOSED [T2D_PARAM_COLS][T2D_MAX_TYPES] so that lanes reading
+//     column c for different type ids hit consecutive LDS banks after staging
+//   static / lane geometry: CSR offsets + fp64 CCW vertices + per-polygon AABB (fp64)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/t2d.h"
+
+namespace t2d {
+
+// What kernels receive by value.
+struct PoolView {
+    int32_t n_env, A, N;
+    float *x, *y, *heading, *speed, *vx, *vy, *act0, *act1, *applied0, *applied1;
+    uint32_t *ids, *flags, *env_flags;
+    int32_t *cnt_step, *frame_ms;
+    uint8_t* status;
+    float* reward;
+    const double* params;  // [T2D_PARAM_COLS][T2D_MAX_TYPES]
+    int32_t n_types;
+    // static geometry
+    const int32_t* env_poly_off;   // [E+1] or null
+    const int32_t* poly_vert_off;  // [P+1]
+    const double* poly_xy;         // [2*V] CCW
+    const double* poly_aabb;       // [4*P] xmin, xmax, ymin, ymax
+    const float* boundary;         // [4*E] or null
+    const uint8_t* boundary_valid; // [E] or null
+    const int32_t* env_lane_off;   // [E+1] or null
+    const int32_t* lane_vert_off;
+    const double* lane_xy;
+    const double* lane_aabb;
+    double cell;      // spatial-hash cell edge (m) >= max circum-diameter * 1.001
+    double inv_cell;
+};
+
+constexpr int kIdsModelShift = 0;
+constexpr int kIdsTypeShift = 8;
+constexpr int kIdsActiveShift = 16;
+
+}  // namespace t2d
+
+struct t2d_pool {
+    t2d::PoolView v{};
+    int device = 0;
+    bool have_params = false;
+    bool have_reset = false;
+    int integrator_variant = 1;
+    t2d_status_config status_cfg{};
+    std::string err;
+    double host_params[T2D_MAX_TYPES][T2D_PARAM_COLS]{};
+    // owned device buffers (freed in t2d_destroy)
+    void* field_ptr[T2D_F_COUNT]{};
+    size_t field_bytes[T2D_F_COUNT]{};
+    double* d_params = nullptr;
+    int32_t *d_env_poly_off = nullptr, *d_poly_vert_off = nullptr;
+    double *d_poly_xy = nullptr, *d_poly_aabb = nullptr;
+    float* d_boundary = nullptr;
+    uint8_t* d_boundary_valid = nullptr;
+    int32_t *d_env_lane_off = nullptr, *d_lane_vert_off = nullptr;
+    double *d_lane_xy = nullptr, *d_lane_aabb = nullptr;
+    int geo_max[4]{};  // max polys/env, max poly verts/env, max lanes/env, max lane verts/env
+    // profiling
+    bool profiling = false;
+    static constexpr int kMaxProfSteps = 4096;
+    hipEvent_t* prof_events = nullptr;  // 2 events per recorded launch
+    int prof_kernel[2 * kMaxProfSteps]{};
+    int prof_count = 0;
+};
+
+// kernel launchers (defined in t2d_integrate.hip / t2d_collide.hip)
+namespace t2d {
+hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hipStream_t s);
+hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
+                          int interval_ms, const int* geo_max, hipStream_t s);
+}  // namespace t2d

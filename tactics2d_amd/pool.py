@@ -1,0 +1,170 @@
+"""ParticipantPool -- thin, typed Python face of one t2d_pool handle (include/t2d.h).
+
+Host logic only: argument marshalling and error translation.  All compute happens in the
+HIP kernels behind libt2d_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi, layout as L
+
+
+def _arr(a, dtype, n=None, name="array"):
+    if a is None:
+        return None
+    out = np.ascontiguousarray(a, dtype=dtype)
+    if n is not None and out.size != n:
+        raise ValueError(f"{name}: expected {n} elements, got {out.size}")
+    return out
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class _DevArray:
+    """Zero-copy view of a pool field for `torch.as_tensor(..., device='cuda')`."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False),
+                                         "version": 2, "strides": None}
+        self._owner = owner
+
+
+class ParticipantPool:
+    """n_env environments x max_agents participants resident on one MI355X."""
+
+    def __init__(self, n_env, max_agents=1, device_id=0):
+        self._lib = _ffi.lib()
+        self._h = C.c_void_p()
+        self.n_env, self.max_agents = int(n_env), int(max_agents)
+        self.n = self.n_env * self.max_agents
+        self.device_id = int(device_id)
+        _ffi.check(self._lib.t2d_create(self.n_env, self.max_agents, self.device_id, C.byref(self._h)))
+
+    # ---------------------------------------------------------------- lifetime
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.t2d_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        _ffi.check(rc, self._h)
+
+    # ---------------------------------------------------------------- configuration
+    def set_param_table(self, rows):
+        rows = np.ascontiguousarray(rows, np.float64)
+        if rows.ndim != 2 or rows.shape[1] < L.PARAM_COLS:
+            raise ValueError("rows must be (n_types, >=24) float64")
+        self._ck(self._lib.t2d_set_param_table(self._h, _p(rows), rows.shape[0], rows.shape[1]))
+        self.n_types = rows.shape[0]
+
+    @staticmethod
+    def _csr(t, n_env):
+        if t is None:
+            return None, None, None
+        eo, vo, xy = t
+        eo = _arr(eo, np.int32, n_env + 1, "env offsets")
+        vo = _arr(vo, np.int32, None, "vertex offsets")
+        xy = _arr(xy, np.float32, None, "verts_xy")
+        if vo.size != eo[-1] + 1:
+            raise ValueError("vertex offsets must have n_poly + 1 entries")
+        if xy.size != 2 * (vo[-1] if vo.size else 0):
+            raise ValueError("verts_xy must have 2 * n_vert entries")
+        return eo, vo, xy
+
+    def set_static_geometry(self, static=None, boundary=None, boundary_valid=None):
+        """static: (env_poly_offsets[E+1], poly_vert_offsets[P+1], verts_xy[V,2]) or None;
+        boundary: (E,4) xmin,xmax,ymin,ymax or None."""
+        eo, vo, xy = self._csr(static, self.n_env)
+        b = _arr(boundary, np.float32, 4 * self.n_env, "boundary")
+        bv = _arr(boundary_valid, np.uint8, self.n_env, "boundary_valid")
+        self._ck(self._lib.t2d_set_static_geometry(self._h, _p(eo), _p(vo), _p(xy), _p(b), _p(bv)))
+
+    def set_lane_geometry(self, lanes=None):
+        eo, vo, xy = self._csr(lanes, self.n_env)
+        self._ck(self._lib.t2d_set_lane_geometry(self._h, _p(eo), _p(vo), _p(xy)))
+
+    def set_status_config(self, **kw):
+        cfg = _ffi.StatusConfig(20000, 0, 0, 0, -5.0, -1.0, -5.0, 5.0, 0.001)
+        for k, v in kw.items():
+            if not hasattr(cfg, k):
+                raise TypeError(f"unknown status option {k}")
+            setattr(cfg, k, v)
+        self._ck(self._lib.t2d_set_status_config(self._h, C.byref(cfg)))
+        self.status_config = cfg
+
+    def set_integrator_variant(self, variant):
+        v = {"exact": 0, "fast": 1}.get(variant, variant)
+        self._ck(self._lib.t2d_set_integrator_variant(self._h, int(v)))
+
+    # ---------------------------------------------------------------- state
+    def reset(self, x, y, heading, speed, type_id, active=None, vx=None, vy=None, env_mask=None):
+        n = self.n
+        a = [_arr(v, np.float32, n, k) for k, v in (("x", x), ("y", y), ("heading", heading), ("speed", speed))]
+        vx_ = _arr(vx, np.float32, n, "vx"); vy_ = _arr(vy, np.float32, n, "vy")
+        tid = _arr(type_id, np.uint8, n, "type_id")
+        act = _arr(np.ones(n, np.uint8) if active is None else active, np.uint8, n, "active")
+        mask = _arr(env_mask, np.uint8, self.n_env, "env_mask")
+        self._ck(self._lib.t2d_reset(self._h, _p(mask), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]),
+                                     _p(vx_), _p(vy_), _p(tid), _p(act)))
+
+    def upload(self, field, values):
+        dt = np.dtype(L.FIELD_DTYPES[field])
+        v = np.ascontiguousarray(values, dt)
+        self._ck(self._lib.t2d_upload(self._h, field, _p(v), v.nbytes))
+
+    def download(self, field):
+        dt = np.dtype(L.FIELD_DTYPES[field])
+        n = self.n_env if field in L.PER_ENV_FIELDS else self.n
+        if field == L.F_STATUS:
+            out = np.empty((n, 4), dt)
+        else:
+            out = np.empty(n, dt)
+        self._ck(self._lib.t2d_download(self._h, field, _p(out), out.nbytes))
+        return out
+
+    def set_actions(self, act0, act1):
+        self.upload(L.F_ACT0, act0)
+        self.upload(L.F_ACT1, act1)
+
+    def field_ptr(self, field):
+        ptr, nb = C.c_void_p(), C.c_size_t()
+        self._ck(self._lib.t2d_get_field(self._h, field, C.byref(ptr), C.byref(nb)))
+        return ptr.value, nb.value
+
+    def device_array(self, field):
+        """Object exposing __cuda_array_interface__ (zero-copy) for torch.as_tensor."""
+        ptr, nb = self.field_ptr(field)
+        dt = np.dtype(L.FIELD_DTYPES[field])
+        shape = (nb // 4, 4) if field == L.F_STATUS else (nb // dt.itemsize,)
+        return _DevArray(ptr, shape, dt.str, self)
+
+    # ---------------------------------------------------------------- the hot path
+    def integrate(self, interval_ms=100, stream=None):
+        self._ck(self._lib.t2d_integrate(self._h, int(interval_ms), stream))
+
+    def collide(self, stream=None):
+        self._ck(self._lib.t2d_collide(self._h, stream))
+
+    def step(self, interval_ms=100, stream=None):
+        self._ck(self._lib.t2d_step(self._h, int(interval_ms), stream))
+
+    def sync(self):
+        self._ck(self._lib.t2d_sync(self._h))
+
+    # ---------------------------------------------------------------- profiling
+    def profile_enable(self, on=True):
+        self._ck(self._lib.t2d_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self, kernel_id):
+        ms, n = C.c_double(), C.c_int64()
+        self._ck(self._lib.t2d_profile_read(self._h, kernel_id, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,200 @@
+"""Shared test helpers: golden loading, scene synthesis, GPU drivers (through the C ABI)."""
+import json
+import os
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TWO_PI = 2 * np.pi
+
+
+def load_npz(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+def load_json(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def ang_err(a, b):
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    return np.minimum(d, np.abs(TWO_PI - d))
+
+
+def state_err(got, want, cols=4):
+    """max abs error per column (x, y, heading (wrapped), speed[, vx, vy])."""
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    e = np.abs(got[:, :cols] - want[:, :cols])
+    e[:, 2] = ang_err(got[:, 2], want[:, 2])
+    return e
+
+
+def dyn_is_stiff(rows, type_id, state, action, timing, vmax_stiff=1.5):
+    """A SingleTrackDynamics step is 'stiff' when some sub-step runs the tyre-force branch
+    (|v| >= 0.1) below ~1.5 m/s: explicit Euler at 5 ms is unstable there in the reference
+    itself (DESIGN.md 'Dynamics conditioning'), so 1-ulp trig differences are amplified."""
+    rows = np.asarray(rows)
+    v0 = state[:, 3].astype(np.float64)
+    a = action[:, 0].astype(np.float64)
+    r = rows[type_id]
+    flags = r[:, 10].astype(int)
+    a = np.where(flags & 4, np.clip(a, r[:, 8], r[:, 9]), a)
+    T = (timing[:, 0] // timing[:, 1]) * timing[:, 1] / 1000.0
+    v1 = v0 + a * T
+    v1 = np.where(flags & 2, np.clip(v1, r[:, 6], r[:, 7]), v1)
+    lo = np.minimum(v0, v1); hi = np.maximum(v0, v1)
+    crosses_zero = (lo <= 0) & (hi >= 0)
+    vmin_abs = np.where(crosses_zero, 0.0, np.minimum(np.abs(v0), np.abs(v1)))
+    vmax_abs = np.maximum(np.abs(v0), np.abs(v1))
+    return (vmin_abs < vmax_stiff) & (vmax_abs >= 0.1 - 1e-9)
+
+
+# --------------------------------------------------------------------------- GPU drivers
+def gpu_physics(rows, type_id, state, action, interval, variant="exact", model="kin"):
+    """Run every case as its own 1-agent env through t2d_integrate; chunk by <= 32 types.
+    state: (n,4) fp32 = x,y,heading,speed (kin/dyn) or x,y,vx,vy (pm).
+    Returns fp32 (n, 8): x, y, heading, speed, vx, vy, applied0, applied1."""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    rows = np.asarray(rows, np.float64)
+    type_id = np.asarray(type_id)
+    n = len(type_id)
+    out = np.full((n, 8), np.nan, np.float32)
+    utypes = np.unique(type_id)
+    for c0 in range(0, len(utypes), 32):
+        chunk = utypes[c0:c0 + 32]
+        sel = np.nonzero(np.isin(type_id, chunk))[0]
+        remap = {int(t): i for i, t in enumerate(chunk)}
+        tid = np.array([remap[int(t)] for t in type_id[sel]], np.uint8)
+        m = len(sel)
+        pool = ParticipantPool(m, 1)
+        try:
+            pool.set_param_table(rows[chunk])
+            pool.set_integrator_variant(variant)
+            st = np.asarray(state[sel], np.float32)
+            if model == "pm":
+                z = np.zeros(m, np.float32)
+                pool.reset(st[:, 0], st[:, 1], z, z, tid, vx=st[:, 2], vy=st[:, 3])
+            else:
+                pool.reset(st[:, 0], st[:, 1], st[:, 2], st[:, 3], tid)
+            pool.set_actions(action[sel, 0], action[sel, 1])
+            pool.integrate(int(interval))
+            cols = [pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_VX, L.F_VY,
+                                               L.F_APPLIED0, L.F_APPLIED1)]
+            out[sel] = np.stack(cols, 1)
+        finally:
+            pool.close()
+    return out
+
+
+def oracle_physics(O, rows, type_id, state, action, interval, model="kin", trig=0):
+    O.set_trig(trig)
+    try:
+        st = np.asarray(state, np.float32)
+        if model == "pm":
+            r = O.integrate(rows, st[:, 0], st[:, 1], None, None, st[:, 2], st[:, 3],
+                            action[:, 0], action[:, 1], type_id, None, interval)
+        else:
+            r = O.integrate(rows, st[:, 0], st[:, 1], st[:, 2], st[:, 3], None, None,
+                            action[:, 0], action[:, 1], type_id, None, interval)
+    finally:
+        O.set_trig(0)
+    return r
+
+
+# --------------------------------------------------------------------------- scenes
+VEHICLE_DIMS = [(3.540, 1.641), (4.053, 1.751), (4.284, 1.799), (4.866, 1.832), (5.050, 1.886),
+                (5.302, 1.945), (4.788, 1.916), (5.155, 1.995), (4.828, 1.943)]
+PED_DIMS = [(0.24, 0.40), (0.22, 0.37), (0.18, 0.25), (0.20, 0.35)]
+
+
+def shape_rows(with_peds=True):
+    """Parameter rows that only matter for their shape columns (collision tests)."""
+    rows = []
+    for (Ln, W) in VEHICLE_DIMS:
+        r = np.zeros(24); r[0] = 0; r[1] = 1.2; r[2] = 1.3; r[3] = 2.5; r[17] = 5
+        r[18] = 0; r[19] = Ln; r[20] = W
+        rows.append(r)
+    if with_peds:
+        for (Ln, W) in PED_DIMS:
+            r = np.zeros(24); r[0] = 2; r[17] = 5; r[18] = 1; r[19] = Ln; r[20] = W
+            rows.append(r)
+    return np.array(rows)
+
+
+def random_quads(rng, n, cx_range, cy_range, size=(2.0, 6.0)):
+    """n random convex quads (perturbed rotated boxes), random winding."""
+    polys = []
+    for _ in range(n):
+        cx = rng.uniform(*cx_range); cy = rng.uniform(*cy_range)
+        L_, W_ = rng.uniform(*size), rng.uniform(size[0] / 2, size[1] / 2)
+        h = rng.uniform(0, TWO_PI)
+        base = np.array([[L_ / 2, -W_ / 2], [L_ / 2, W_ / 2], [-L_ / 2, W_ / 2], [-L_ / 2, -W_ / 2]])
+        base += rng.uniform(0, 0.2, base.shape) * min(L_, W_)
+        R = np.array([[np.cos(h), -np.sin(h)], [np.sin(h), np.cos(h)]])
+        q = base @ R.T + [cx, cy]
+        if rng.uniform() < 0.5:
+            q = q[::-1]
+        polys.append(q.astype(np.float32))
+    return polys
+
+
+def to_csr(per_env_polys):
+    eo = [0]; vo = [0]; xy = []
+    for polys in per_env_polys:
+        for q in polys:
+            xy.append(np.asarray(q, np.float32)); vo.append(vo[-1] + len(q))
+        eo.append(eo[-1] + len(polys))
+    xy = np.concatenate(xy) if xy else np.zeros((0, 2), np.float32)
+    return np.array(eo, np.int32), np.array(vo, np.int32), xy
+
+
+def random_scene(rng, n_env, A, extent=(60.0, 20.0), n_static=6, n_lanes=0, with_peds=True,
+                 inactive_frac=0.1, bounded=True):
+    rows = shape_rows(with_peds)
+    N = n_env * A
+    x = rng.uniform(-extent[0] / 2, extent[0] / 2, N).astype(np.float32)
+    y = rng.uniform(-extent[1] / 2, extent[1] / 2, N).astype(np.float32)
+    h = rng.uniform(-0.5, TWO_PI + 0.5, N).astype(np.float32)
+    tid = rng.integers(0, len(rows), N).astype(np.uint8)
+    active = (rng.uniform(size=N) >= inactive_frac).astype(np.uint8)
+    static = to_csr([random_quads(rng, int(rng.integers(0, n_static + 1)),
+                                  (-extent[0] / 2, extent[0] / 2), (-extent[1] / 2, extent[1] / 2))
+                     for _ in range(n_env)]) if n_static else None
+    lanes = None
+    if n_lanes:
+        per = []
+        for _ in range(n_env):
+            k = int(rng.integers(0, n_lanes + 1))
+            per.append(random_quads(rng, k, (-extent[0] / 3, extent[0] / 3), (-extent[1] / 3, extent[1] / 3),
+                                    size=(10.0, 40.0)))
+        lanes = to_csr(per)
+    boundary = bvalid = None
+    if bounded:
+        bx = rng.uniform(0.35, 0.6, n_env) * extent[0]; by = rng.uniform(0.35, 0.6, n_env) * extent[1]
+        boundary = np.stack([-bx, bx, -by, by], 1).astype(np.float32)
+        bvalid = (rng.uniform(size=n_env) > 0.1).astype(np.uint8)
+    return dict(rows=rows, n_env=n_env, A=A, x=x, y=y, heading=h, type_id=tid, active=active,
+                static=static, lanes=lanes, boundary=boundary, boundary_valid=bvalid)
+
+
+def gpu_collide(sc):
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    pool = ParticipantPool(sc["n_env"], sc["A"])
+    try:
+        pool.set_param_table(sc["rows"])
+        pool.set_static_geometry(sc["static"], sc["boundary"], sc["boundary_valid"])
+        pool.set_lane_geometry(sc["lanes"])
+        z = np.zeros(sc["n_env"] * sc["A"], np.float32)
+        pool.reset(sc["x"], sc["y"], sc["heading"], z, sc["type_id"], sc["active"])
+        pool.collide()
+        return pool.download(L.F_FLAGS), pool.download(L.F_ENV_FLAGS)
+    finally:
+        pool.close()
+
+
+def oracle_collide(O, sc, trig=0):
+    return O.collide(sc["rows"], sc["n_env"], sc["A"], sc["x"], sc["y"], sc["heading"], sc["type_id"],
+                     sc["active"], sc["static"], sc["boundary"], sc["boundary_valid"], sc["lanes"], trig)

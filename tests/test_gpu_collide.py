@@ -1,0 +1,111 @@
+"""GPU parity of t2d_collide / t2d_step (through the C ABI): event flags bit-exact against the
+oracle's brute-force fp64 evaluation on identical fp32 inputs.  Run with -m gpu."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_env,A,extent,kw", [
+    (64, 64, (60.0, 16.0), dict(n_static=6, n_lanes=3)),        # wave == env, grid + LDS staging
+    (64, 64, (400.0, 15.0), dict(n_static=0, n_lanes=4)),       # highway-like, sparse
+    (96, 32, (40.0, 40.0), dict(n_static=8, n_lanes=2)),        # two envs per wave
+    (33, 48, (40.0, 30.0), dict(n_static=4, n_lanes=0)),        # A not a power of two, ragged grid
+    (200, 8, (20.0, 12.0), dict(n_static=5, n_lanes=2)),        # grid, geometry read from global
+    (300, 4, (12.0, 8.0), dict(n_static=5, n_lanes=1)),         # brute-force pairs
+    (1000, 1, (30.0, 20.0), dict(n_static=12, n_lanes=0)),      # parking-like: ego vs static only
+    (5, 200, (120.0, 60.0), dict(n_static=16, n_lanes=0)),      # A_pad = 256, one env per workgroup
+    (40, 64, (30.0, 10.0), dict(n_static=3, n_lanes=2, with_peds=False, inactive_frac=0.5)),
+])
+def test_flags_bit_exact(oracle, n_env, A, extent, kw):
+    rng = np.random.default_rng(n_env * 1000 + A)
+    sc = H.random_scene(rng, n_env, A, extent, **kw)
+    want_f, want_e = H.oracle_collide(oracle, sc)
+    got_f, got_e = H.gpu_collide(sc)
+    bad = np.nonzero(got_f != want_f)[0]
+    assert bad.size == 0, f"{bad.size} participants differ, first {bad[:8]}: got {got_f[bad[:8]]} want {want_f[bad[:8]]}"
+    assert (got_e == want_e).all()
+    # the scene must actually exercise the predicates
+    frac = [(want_f & b).astype(bool).mean() for b in (1, 2, 4, 8)]
+    print(f"E={n_env} A={A}: flag rates dyn/static/out/lane = {np.round(frac, 3)}")
+    if A > 1:
+        assert 0.01 < frac[0] < 0.99
+    if kw.get("n_static"):
+        assert 0.005 < frac[1] < 0.99
+
+
+def test_geometry_kats(oracle):
+    """Hand-built touching / nesting / near-miss cases (tests/golden/geometry_kats.json)."""
+    kats = H.load_json("geometry_kats.json")
+    for k in kats["scenes"]:
+        sc = dict(rows=np.array(k["rows"]), n_env=1, A=len(k["x"]), x=np.float32(k["x"]),
+                  y=np.float32(k["y"]), heading=np.float32(k["heading"]),
+                  type_id=np.array(k["type_id"], np.uint8), active=np.ones(len(k["x"]), np.uint8),
+                  static=H.to_csr([[np.float32(q) for q in k["static"]]]) if k["static"] else None,
+                  lanes=H.to_csr([[np.float32(q) for q in k["lanes"]]]) if k["lanes"] else None,
+                  boundary=np.float32([k["boundary"]]) if k["boundary"] else None, boundary_valid=None)
+        got_f, _ = H.gpu_collide(sc)
+        assert got_f.tolist() == k["flags"], (k["name"], got_f.tolist(), k["flags"])
+
+
+def test_non_convex_polygon_is_rejected():
+    from tactics2d_amd import _ffi
+    from tactics2d_amd.pool import ParticipantPool
+    pool = ParticipantPool(1, 1)
+    dart = np.float32([[0, 0], [4, 0], [1, 1], [0, 4]])
+    with pytest.raises(_ffi.GeometryError):
+        pool.set_static_geometry(H.to_csr([[dart]]))
+    pool.close()
+
+
+def test_step_status_reward_matches_oracle(oracle):
+    """t2d_step = integrate + collide + status epilogue, against oracle integrate->collide->status
+    chained on the same fp32 pool state (teacher-forced on the GPU's own fp32 state)."""
+    from oracle.oracle import StatusConfig
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    rng = np.random.default_rng(7)
+    n_env, A = 128, 8
+    sc = H.random_scene(rng, n_env, A, (30.0, 20.0), n_static=4, n_lanes=2, with_peds=False, inactive_frac=0.0)
+    kin = H.load_npz("kin_random.npz")["rows"][0].copy()
+    rows = sc["rows"].copy()
+    rows[:, :18] = kin[:18]  # every type drives like the medium_car rig, keeps its own shape
+    sc["rows"] = rows
+    N = n_env * A
+    speed = rng.uniform(-2, 10, N).astype(np.float32)
+    pool = ParticipantPool(n_env, A)
+    pool.set_param_table(rows)
+    pool.set_static_geometry(sc["static"], sc["boundary"], sc["boundary_valid"])
+    pool.set_lane_geometry(sc["lanes"])
+    pool.set_status_config(max_step=6, check_dynamic=1, check_off_lane=1)
+    pool.set_integrator_variant("exact")
+    pool.reset(sc["x"], sc["y"], sc["heading"], speed, sc["type_id"], sc["active"])
+    cfg = StatusConfig(6, 0, 1, 1, -5.0, -1.0, -5.0, 5.0, 0.001)
+    cnt = np.zeros(n_env, np.int32); frame = np.zeros(n_env, np.int32)
+    seen = set()
+    for step in range(9):
+        a0 = rng.uniform(-3, 3, N).astype(np.float32); a1 = rng.uniform(-0.5, 0.5, N).astype(np.float32)
+        st = [pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED)]
+        pool.set_actions(a0, a1)
+        pool.step(100)
+        gx, gy, gh = (pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING))
+        oracle.set_trig(1)
+        o = oracle.integrate(rows, st[0], st[1], st[2], st[3], None, None, a0, a1, sc["type_id"], sc["active"], 100)
+        oracle.set_trig(0)
+        assert (np.float32(o[:, 0]) == gx).all() and (np.float32(o[:, 2]) == gh).all()
+        wf, we = oracle.collide(rows, n_env, A, gx, gy, gh, sc["type_id"], sc["active"], sc["static"],
+                                sc["boundary"], sc["boundary_valid"], sc["lanes"], 0)
+        wst, wrw = oracle.status(cfg, n_env, A, wf, 100, cnt, frame)
+        assert (pool.download(L.F_FLAGS) == wf).all()
+        assert (pool.download(L.F_ENV_FLAGS) == we).all()
+        assert (pool.download(L.F_CNT_STEP) == cnt).all() and (pool.download(L.F_FRAME_MS) == frame).all()
+        gst = pool.download(L.F_STATUS)
+        assert (gst == wst).all(), np.nonzero((gst != wst).any(1))[0][:5]
+        grw = pool.download(L.F_REWARD)
+        assert np.allclose(grw, wrw, rtol=0, atol=1e-9), np.abs(grw - wrw).max()
+        seen |= set(map(tuple, gst[:, :2].tolist()))
+    pool.close()
+    # NORMAL, TIME_EXCEEDED, OUT_BOUND, FAILED/static, FAILED/dynamic must all have occurred
+    assert {(1, 1), (3, 1), (4, 1), (6, 3)} <= seen, seen

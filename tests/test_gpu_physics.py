@@ -1,0 +1,165 @@
+"""GPU parity of t2d_integrate (through the C ABI) -- run on the MI355X with -m gpu.
+
+Bars (BASELINE.json north_star): fp32 pose within 1e-5 abs of the reference's fp64 result.
+On top of that, the "exact" kernel variant must equal the deterministic-trig oracle bit for bit
+after the fp32 store -- including the stiff SingleTrackDynamics cases no tolerance can cover.
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # north_star tolerance, abs, on fp32 pose state
+
+
+def _groups(d):
+    for iv in np.unique(d["timing"][:, 0]):
+        yield int(iv), np.nonzero(d["timing"][:, 0] == iv)[0]
+
+
+@pytest.mark.parametrize("name,model", [("kin_random.npz", "kin"), ("dyn_random.npz", "dyn"),
+                                        ("pm_random.npz", "pm")])
+def test_exact_variant_is_bit_identical_to_oracle(oracle, name, model):
+    d = H.load_npz(name)
+    mism = 0
+    for iv, m in _groups(d):
+        want = oracle_f32 = np.float32(H.oracle_physics(oracle, d["rows"], d["type_id"][m], d["state"][m],
+                                                        d["action"][m], iv, model, trig=1))
+        got = H.gpu_physics(d["rows"], d["type_id"][m], d["state"][m], d["action"][m], iv, "exact", model)
+        cols = [0, 1, 2, 3, 6, 7] + ([4, 5] if model != "dyn" else [])
+        for c in cols:
+            bad = got[:, c].view(np.uint32) != want[:, c].view(np.uint32)
+            # +0.0 / -0.0 are the same value
+            bad &= ~((got[:, c] == 0) & (want[:, c] == 0))
+            mism += int(bad.sum())
+            assert not bad.any(), (f"{name} interval {iv} col {c}: {bad.sum()} of {len(bad)} differ, "
+                                   f"first idx {np.nonzero(bad)[0][:5]} got {got[bad, c][:3]} want {want[bad, c][:3]}")
+    assert mism == 0
+
+
+@pytest.mark.parametrize("variant", ["fast", "exact"])
+def test_kinematics_within_1e5_of_reference(variant):
+    d = H.load_npz("kin_random.npz")
+    worst = np.zeros(6)
+    for iv, m in _groups(d):
+        got = H.gpu_physics(d["rows"], d["type_id"][m], d["state"][m], d["action"][m], iv, variant, "kin")
+        e = H.state_err(got, d["out"][m], cols=6)
+        worst = np.maximum(worst, e.max(0))
+        assert np.allclose(got[:, 6:8], np.float32(d["applied"][m]), rtol=0, atol=0)
+    print("kinematics", variant, "max abs err x,y,h,v,vx,vy:", worst)
+    assert worst.max() <= TOL, worst
+
+
+@pytest.mark.parametrize("variant", ["fast", "exact"])
+def test_pointmass_within_1e5_of_reference(variant):
+    d = H.load_npz("pm_random.npz")
+    worst = np.zeros(6)
+    for iv, m in _groups(d):
+        got = H.gpu_physics(d["rows"], d["type_id"][m], d["state"][m], d["action"][m], iv, variant, "pm")
+        e = H.state_err(got, d["out"][m], cols=6)
+        worst = np.maximum(worst, e.max(0))
+    print("pointmass", variant, "max abs err:", worst)
+    assert worst.max() <= TOL, worst
+
+
+@pytest.mark.parametrize("variant", ["fast", "exact"])
+def test_dynamics_within_1e5_of_reference_outside_stiff_regime(variant):
+    d = H.load_npz("dyn_random.npz")
+    stiff = H.dyn_is_stiff(d["rows"], d["type_id"], d["state"], d["action"], d["timing"])
+    worst = np.zeros(4); worst_stiff = np.zeros(4)
+    for iv, m in _groups(d):
+        got = H.gpu_physics(d["rows"], d["type_id"][m], d["state"][m], d["action"][m], iv, variant, "dyn")
+        e = H.state_err(got, d["out"][m], cols=4)
+        s = stiff[m]
+        if (~s).any():
+            worst = np.maximum(worst, e[~s].max(0))
+        if s.any():
+            worst_stiff = np.maximum(worst_stiff, e[s].max(0))
+    print(f"dynamics {variant}: non-stiff {int((~stiff).sum())} cases max err {worst}; "
+          f"stiff {int(stiff.sum())} cases max err {worst_stiff} (reported, not asserted)")
+    assert (~stiff).sum() > 4000
+    assert worst.max() <= TOL, worst
+
+
+def test_known_answers():
+    kats = H.load_json("physics_kats.json")
+    for k in kats:
+        model = {"kinematics": "kin", "dynamics": "dyn", "pointmass": "pm"}[k["model"]]
+        st = np.array([k["state"]], np.float32)
+        act = np.array([k["action"]], np.float32)
+        if not (np.float64(st) == np.array([k["state"]])).all():
+            continue  # KAT input is not fp32-representable (e.g. speed -1e-15 is) -> skip
+        row = np.array([k["row"]])
+        stiff = model == "dyn" and H.dyn_is_stiff(row, np.array([0]), st, act,
+                                                  np.array([[k["interval"], int(k["row"][17])]]))[0]
+        for variant in ("fast", "exact"):
+            got = H.gpu_physics(row, np.array([0]), st, act, k["interval"], variant, model)
+            want = np.array([k["out"]])
+            cols = 4 if model == "dyn" else 6
+            e = H.state_err(got, want, cols=cols)
+            if stiff:  # reference integrator unstable here: covered by the bit-exact test instead
+                print("stiff KAT", k["state"], k["action"], variant, "err vs reference", e.max(0))
+                continue
+            assert e.max() <= TOL, (k["model"], k["ctor"], variant, got, want)
+            if k["applied"] is not None:
+                assert np.allclose(got[0, 6:8], np.float32(k["applied"]), atol=0)
+
+
+def test_mod_two_pi_quirk_matches_numpy():
+    # np.mod(-tiny, 2*pi) == 2*pi: the stored heading may equal fp32(2*pi)
+    k = [q for q in H.load_json("physics_kats.json") if q["ctor"] == "unconstrained"][0]
+    st = np.array([k["state"]], np.float32); act = np.array([k["action"]], np.float32)
+    got = H.gpu_physics(np.array([k["row"]]), np.array([0]), st, act, 100, "exact", "kin")
+    assert got[0, 2] == np.float32(k["out"][2]) == np.float32(2 * np.pi)
+
+
+@pytest.mark.parametrize("tag", ["kin_100_5", "kin_50_3", "kin_9_5", "dyn_100_5", "dyn_50_3"])
+def test_rollout_teacher_forced_and_free_running(oracle, tag):
+    """Per-step parity from shared fp32 inputs (teacher forcing on the reference trajectory) and
+    the drift of a free-running fp32 pool over the reference's VEHICLE_ACTION_LIST roll-out."""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    r = H.load_npz("rollouts.npz")
+    traj, acts, row = r[f"{tag}_traj"], r[f"{tag}_act"], r[f"{tag}_row"]
+    interval = int(tag.split("_")[1])
+    model = tag[:3]
+    n = len(acts)
+    # teacher forced: every step of the reference trajectory is one independent case
+    st = np.float32(traj[:-1]); act = np.float32(acts)
+    ref = H.oracle_physics(oracle, row[None], np.zeros(n, np.uint8), st, act, interval, model, trig=0)
+    got = H.gpu_physics(row[None], np.zeros(n, np.uint8), st, act, interval, "fast", model)
+    e = H.state_err(got, ref, cols=4)
+    stiff = H.dyn_is_stiff(row[None], np.zeros(n, int), st, act, np.tile([interval, int(row[17])], (n, 1))) \
+        if model == "dyn" else np.zeros(n, bool)
+    assert e[~stiff].max() <= TOL, e[~stiff].max(0)
+    # free running on the device, state re-rounded to fp32 every step
+    pool = ParticipantPool(1, 1)
+    pool.set_param_table(row[None])
+    pool.reset([traj[0, 0]], [traj[0, 1]], [traj[0, 2]], [traj[0, 3]], [0])
+    drift = 0.0
+    for k in range(n):
+        pool.set_actions([acts[k, 0]], [acts[k, 1]])
+        pool.integrate(interval)
+    fin = np.array([pool.download(f)[0] for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED)], np.float64)
+    pool.close()
+    drift = np.abs(fin - traj[-1]); drift[2] = H.ang_err(fin[2], traj[-1, 2])
+    print(f"{tag}: {n} steps, teacher-forced max err {e[~stiff].max(0)}, free-running fp32 drift {drift}")
+    if model == "kin":
+        assert drift.max() < 5e-3  # fp32 re-rounding over hundreds of steps; reported in DESIGN.md
+
+
+def test_inactive_participants_are_untouched():
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    d = H.load_npz("kin_random.npz")
+    pool = ParticipantPool(2, 4)
+    pool.set_param_table(d["rows"][:4])
+    x = np.arange(8, dtype=np.float32); act = np.array([1, 0, 1, 0, 0, 1, 1, 1], np.uint8)
+    pool.reset(x, x + 1, x * 0.1, x * 0 + 3, np.zeros(8, np.uint8), act)
+    pool.set_actions(np.ones(8), np.ones(8) * 0.1)
+    pool.integrate(100)
+    gx = pool.download(L.F_X)
+    pool.close()
+    assert (gx[act == 0] == x[act == 0]).all() and (gx[act == 1] != x[act == 1]).all()
