@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- participant-steps/s (physics + collision + status) of the batched env.step().
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one t2d_step (integrate + collide + status epilogue) over every participant of the
+rank's pool, followed by the device-side auto-reset of finished envs (t2d_restore mode 1) and,
+for N > 1, the asynchronous RCCL all-gather of the 8-byte per-env result records.  Inputs
+(state, actions, geometry) are resident in HBM before the timed region starts.  Weak scaling:
+every rank owns --envs environments (default 4096 x 64 participants, the metric workload).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (per-kernel HIP
+event timing recorded on the launch stream inside the timed region) and `cpu_baseline` (the C
+oracle -- a port of the reference's algorithm -- timed on 1 host core on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+INTEGRATOR_BYTES = 44          # algorithmic bytes per participant-step
+COLLIDE_BYTES = 20             # + per-env geometry (computed from the scene)
+
+
+def build_scene(name, n_env, agents, seed):
+    from tactics2d_amd import scenarios as S
+    if name == "metric" or name == "cfg5":
+        return S.mixed(n_env, agents, seed=3 + 1000 * seed)
+    if name == "cfg2":
+        return S.parking(n_env, seed0=seed * n_env)
+    if name == "cfg3":
+        return S.highway(n_env, agents, seed=1 + 1000 * seed)
+    if name == "cfg4":
+        return S.intersection(n_env, agents, seed=2 + 1000 * seed)
+    raise SystemExit(f"unknown config {name}")
+
+
+def cpu_baseline(scene, target_seconds=12.0):
+    """The oracle (C port of the reference algorithm, fp64 scalar, 1 thread) stepping a bounded
+    sample of the SAME scene: integrate -> fp32 store -> collide -> status, per step."""
+    from oracle import oracle as O
+    from oracle.oracle import StatusConfig
+    O.build()
+    n_env = min(scene.n_env, 96)
+    A = scene.A
+    n = n_env * A
+    sl = slice(0, n)
+    eo, vo, xy = scene.static if scene.static is not None else (None, None, None)
+
+    def cut(csr):
+        if csr is None:
+            return None
+        eo, vo, xy = csr
+        p1 = eo[n_env]
+        return eo[:n_env + 1].copy(), vo[:p1 + 1].copy(), xy[:vo[p1]].copy()
+
+    static, lanes = cut(scene.static), cut(scene.lanes)
+    boundary = None if scene.boundary is None else scene.boundary[:n_env]
+    x, y, h, v = (a[sl].copy() for a in (scene.x, scene.y, scene.heading, scene.speed))
+    vx = (v.astype(np.float64) * np.cos(h.astype(np.float64))).astype(np.float32)
+    vy = (v.astype(np.float64) * np.sin(h.astype(np.float64))).astype(np.float32)
+    tid, act = scene.type_id[sl], scene.active[sl]
+    st = scene.status
+    cfg = StatusConfig(st.get("max_step", 20000), 0, st.get("check_dynamic", 0), st.get("check_off_lane", 0),
+                       -5.0, -1.0, -5.0, 5.0, 0.001)
+    cnt = np.zeros(n_env, np.int32); frame = np.zeros(n_env, np.int32)
+    rng = np.random.default_rng(123)
+    full_a0, full_a1 = scene.sample_actions(rng)
+    a0, a1 = full_a0[sl], full_a1[sl]
+    is_dyn = scene.rows[tid, 0] == 1
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        o = O.integrate(scene.rows, x, y, h, v, vx, vy, a0, a1, tid, act, scene.interval_ms)
+        x, y, h, v = (np.float32(o[:, k]) for k in range(4))
+        vx = np.where(is_dyn, vx, np.float32(o[:, 4])); vy = np.where(is_dyn, vy, np.float32(o[:, 5]))
+        f, _ = O.collide(scene.rows, n_env, A, x, y, h, tid, act, static, boundary, None, lanes, 0)
+        O.status(cfg, n_env, A, f, scene.interval_ms, cnt, frame)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= target_seconds or steps >= 2000:
+            break
+    return dict(value=n * steps / el, unit="participant-steps/s", cores=1, kind="port",
+                sample=f"first {n_env} envs x {A} participants of the same scene, {steps} steps, "
+                       f"{el:.1f} s on 1 core ({os.cpu_count()} host cores present); C oracle "
+                       f"oracle/t2d_oracle.c (fp64 scalar restatement of the reference)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--config", default="metric", help="metric | cfg2 | cfg3 | cfg4 | cfg5")
+    ap.add_argument("--envs", type=int, default=None, help="environments PER GPU")
+    ap.add_argument("--agents", type=int, default=None)
+    ap.add_argument("--variant", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events")
+    ap.add_argument("--no-reset", action="store_true", help="skip the device-side auto-reset")
+    args = ap.parse_args()
+
+    import torch
+    from tactics2d_amd import dist as D, layout as L
+    from tactics2d_amd.pool import ParticipantPool
+
+    rank, local_rank, world = D.init_process_group("nccl")
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); "
+                         "there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    defaults = {"metric": (4096, 64), "cfg5": (1024, 64), "cfg2": (4096, 1), "cfg3": (1024, 64),
+                "cfg4": (512, 32)}
+    n_env, agents = defaults[args.config]
+    n_env = args.envs or n_env
+    agents = args.agents or agents
+    scene = build_scene(args.config, n_env, agents, seed=rank)
+    pool = ParticipantPool(n_env, agents, device_id=local_rank)
+    scene.load(pool)
+    pool.set_integrator_variant(args.variant)
+    N = scene.n
+
+    # actions: a ring of pre-generated batches resident in HBM, bound zero-copy each step
+    rng = np.random.default_rng(1000 + rank)
+    ring = []
+    for _ in range(4):
+        a0, a1 = scene.sample_actions(rng)
+        ring.append((torch.from_numpy(a0).to(dev), torch.from_numpy(a1).to(dev)))
+    reward_t = torch.as_tensor(pool.device_array(L.F_REWARD), device=dev)
+    status_t = torch.as_tensor(pool.device_array(L.F_STATUS), device=dev)
+    gather = D.ResultGather(n_env, world, dev) if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def one_step(k):
+        a0, a1 = ring[k & 3]
+        pool.bind_actions(a0.data_ptr(), a1.data_ptr())
+        pool.step(scene.interval_ms, stream)
+        if gather is not None:
+            gather.launch(reward_t, status_t)
+        if not args.no_reset:
+            pool.restore(done_only=True, stream=stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        one_step(k)
+    barrier()
+    profile = not args.no_profile and args.steps <= 4096 // 2
+    if profile:
+        pool.profile_enable(True)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(k)
+    if gather is not None:
+        gather.wait()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern = {}
+    if profile:
+        for kid, name in ((0, "integrate_kernel"), (1, "collide_kernel")):
+            ms, launches = pool.profile_read(kid)
+            kern[name] = dict(avg_us=1e3 * ms / max(launches, 1), launches=launches)
+        pool.profile_enable(False)
+
+    # state sanity after the run (not timed): flags/status distribution
+    flags = pool.download(L.F_FLAGS)
+    status = pool.download(L.F_STATUS)
+    x_end = pool.download(L.F_X)
+    finite = bool(np.isfinite(x_end).all())
+
+    if rank == 0:
+        value = world * N * args.steps / elapsed
+        geo_bytes = 0
+        for csr in (scene.static, scene.lanes):
+            if csr is not None:
+                geo_bytes += 8 * int(csr[1][-1])
+        geo_bytes += 16 * n_env
+        roof = None
+        if kern:
+            per_launch = {"integrate_kernel": INTEGRATOR_BYTES * N, "collide_kernel": COLLIDE_BYTES * N + geo_bytes}
+            dom = max(kern, key=lambda k_: kern[k_]["avg_us"])
+            ach = per_launch[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=ach / HBM_PEAK_GBS, traffic=None,
+                        algorithmic_bytes_per_launch=per_launch[dom], avg_kernel_us=kern[dom]["avg_us"],
+                        kernels={k_: dict(avg_us=v["avg_us"], launches=v["launches"],
+                                          algorithmic_bytes=per_launch[k_],
+                                          achieved_GBs=per_launch[k_] / (v["avg_us"] * 1e-6) / 1e9)
+                                 for k_, v in kern.items()})
+        out = dict(metric="participant-steps/sec (physics+collision)", value=value,
+                   unit="participant-steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak",
+                   vs_baseline=None, dtype="f64", data="synthetic",
+                   config=dict(workload=f"{scene.name}: {n_env} envs x {agents} participants per GPU, "
+                                        f"interval 100 ms / delta_t 5 ms (20 Euler sub-steps), "
+                                        f"integrator variant {args.variant}, auto-reset "
+                                        f"{'off' if args.no_reset else 'on'}",
+                               config=args.config, envs_per_gpu=n_env, participants_per_env=agents,
+                               parallelism=f"env-sharded x{world}, RCCL all-gather of 8 B/env records"
+                               if world > 1 else "single GPU"),
+                   roofline=roof,
+                   check=dict(state_finite=finite,
+                              flag_rates=[float((flags & b).astype(bool).mean()) for b in (1, 2, 4, 8)],
+                              truncated_frac=float(status[:, 3].mean())))
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene)
+        print(json.dumps(out))
+    pool.close()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

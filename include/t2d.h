@@ -28,6 +28,7 @@
  *                            DynamicCollision.update         traffic/event_detection/collision.py:18-25 (intended semantics)
  *                            OutBound.update                 traffic/event_detection/out_bound.py:37-48
  *                            OffLane.update                  traffic/event_detection/off_lane.py:16-17 (stub; build-defined)
+ *   t2d_snapshot/restore  <- ParkingEnv.reset / _ParkingScenarioManager.reset       envs/parking.py:262-298,397-441
  *   t2d_step              <- _ParkingScenarioManager.update + check_status  envs/parking.py:352-392
  *                            ParkingEnv.step terminated/truncated/reward    envs/parking.py:219-256,148-161
  *                            TimeExceed.update               traffic/event_detection/time_exceed.py:26-33
@@ -206,6 +207,11 @@ int t2d_reset(t2d_pool* pool, const uint8_t* env_mask, const float* x, const flo
               const float* heading, const float* speed, const float* vx, const float* vy,
               const uint8_t* type_id, const uint8_t* active);
 
+/* Zero-copy actions: make the integrator read ACT0/ACT1 from caller-owned DEVICE memory (e.g. a
+ * policy's output tensor, N floats each) instead of the pool's own buffers.  NULL, NULL rebinds
+ * the pool's buffers.  The caller keeps the memory alive and orders its writes on the stream.  */
+int t2d_bind_actions(t2d_pool* pool, const float* act0_dev, const float* act1_dev);
+
 /* Physics only: one PhysicsModelBase.step(interval_ms) for every active participant,
  * actions taken from fields ACT0/ACT1.                                                  */
 int t2d_integrate(t2d_pool* pool, int32_t interval_ms, void* hip_stream);
@@ -220,6 +226,15 @@ int t2d_get_field(t2d_pool* pool, int32_t field_id, void** dev_ptr, size_t* nbyt
 int t2d_download(t2d_pool* pool, int32_t field_id, void* host_dst, size_t nbytes);
 int t2d_upload(t2d_pool* pool, int32_t field_id, const void* host_src, size_t nbytes);
 int t2d_sync(t2d_pool* pool);
+
+/* Episode-start snapshot for device-side (auto-)reset -- the vector-env counterpart of
+ * ParkingEnv.reset (envs/parking.py:262-298) without a host round trip.
+ * t2d_snapshot copies the current participant state (x, y, heading, speed, vx, vy, ids) into a
+ * pool-owned device snapshot.  t2d_restore (asynchronous on the stream) writes it back and
+ * clears cnt_step / frame / status / reward / flags:
+ *   mode 0: every env;  mode 1: only envs whose status says terminated or truncated.       */
+int t2d_snapshot(t2d_pool* pool);
+int t2d_restore(t2d_pool* pool, int32_t mode, void* hip_stream);
 
 /* Kernel variants: 0 = exact (library-grade fp64 trig every sub-step), 1 = fast
  * (rotation recurrence, default).  Both satisfy the 1e-5 contract; see DESIGN.md.       */

@@ -44,6 +44,7 @@ SYMBOLS = {
     "t2d_set_lane_geometry": (C.c_int, [_vp, _vp, _vp, _vp]),
     "t2d_set_status_config": (C.c_int, [_vp, C.POINTER(StatusConfig)]),
     "t2d_reset": (C.c_int, [_vp] * 10),
+    "t2d_bind_actions": (C.c_int, [_vp, _vp, _vp]),
     "t2d_integrate": (C.c_int, [_vp, C.c_int32, _vp]),
     "t2d_collide": (C.c_int, [_vp, _vp]),
     "t2d_step": (C.c_int, [_vp, C.c_int32, _vp]),
@@ -51,6 +52,8 @@ SYMBOLS = {
     "t2d_download": (C.c_int, [_vp, C.c_int32, _vp, C.c_size_t]),
     "t2d_upload": (C.c_int, [_vp, C.c_int32, _vp, C.c_size_t]),
     "t2d_sync": (C.c_int, [_vp]),
+    "t2d_snapshot": (C.c_int, [_vp]),
+    "t2d_restore": (C.c_int, [_vp, C.c_int32, _vp]),
     "t2d_set_integrator_variant": (C.c_int, [_vp, C.c_int32]),
     "t2d_profile_enable": (C.c_int, [_vp, C.c_int32]),
     "t2d_profile_read": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

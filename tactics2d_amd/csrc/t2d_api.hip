@@ -129,6 +129,48 @@ int record_event(t2d_pool* p, int kernel_id, hipStream_t s, bool begin) {
 
 }  // namespace
 
+
+namespace t2d {
+namespace {
+struct SnapPtrs { const float* f[6]; const uint32_t* ids; };
+__global__ __launch_bounds__(256) void restore_kernel(PoolView pv, SnapPtrs sp, int mode) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= pv.N) return;
+    const int env = i / pv.A;
+    if (mode == 1) {
+        const uchar4 st = reinterpret_cast<const uchar4*>(pv.status)[env];
+        if (!(st.z | st.w)) return;
+    }
+    pv.x[i] = sp.f[0][i]; pv.y[i] = sp.f[1][i]; pv.heading[i] = sp.f[2][i];
+    pv.speed[i] = sp.f[3][i]; pv.vx[i] = sp.f[4][i]; pv.vy[i] = sp.f[5][i];
+    pv.ids[i] = sp.ids[i];
+    pv.flags[i] = 0;
+    // the env record (status, counters) is cleared by restore_env_kernel, launched after this
+    // kernel on the same stream, so every participant has read `status` before it changes
+}
+__global__ __launch_bounds__(256) void restore_env_kernel(PoolView pv, int mode) {
+    const int env = blockIdx.x * 256 + threadIdx.x;
+    if (env >= pv.n_env) return;
+    if (mode == 1) {
+        const uchar4 st = reinterpret_cast<const uchar4*>(pv.status)[env];
+        if (!(st.z | st.w)) return;
+    }
+    pv.env_flags[env] = 0; pv.cnt_step[env] = 0; pv.frame_ms[env] = 0; pv.reward[env] = 0.f;
+    uchar4 st; st.x = T2D_SCENARIO_NORMAL; st.y = T2D_TRAFFIC_NORMAL; st.z = 0; st.w = 0;
+    reinterpret_cast<uchar4*>(pv.status)[env] = st;
+}
+}  // namespace
+hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
+                          hipStream_t s) {
+    SnapPtrs sp;
+    for (int k = 0; k < 6; ++k) sp.f[k] = snap[k];
+    sp.ids = snap_ids;
+    hipLaunchKernelGGL(restore_kernel, dim3((v.N + 255) / 256), dim3(256), 0, s, v, sp, mode);
+    hipLaunchKernelGGL(restore_env_kernel, dim3((v.n_env + 255) / 256), dim3(256), 0, s, v, mode);
+    return hipGetLastError();
+}
+}  // namespace t2d
+
 extern "C" {
 
 const char* t2d_last_error(const t2d_pool* pool) {
@@ -205,7 +247,8 @@ int t2d_destroy(t2d_pool* p) {
         if (p->field_ptr[f]) (void)hipFree(p->field_ptr[f]);
     void* bufs[] = {p->d_params, p->d_env_poly_off, p->d_poly_vert_off, p->d_poly_xy, p->d_poly_aabb,
                     p->d_boundary, p->d_boundary_valid, p->d_env_lane_off, p->d_lane_vert_off,
-                    p->d_lane_xy, p->d_lane_aabb};
+                    p->d_lane_xy, p->d_lane_aabb, p->d_snap[0], p->d_snap[1], p->d_snap[2],
+                    p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->prof_events) {
@@ -399,6 +442,15 @@ int t2d_reset(t2d_pool* p, const uint8_t* env_mask, const float* x, const float*
     return T2D_OK;
 }
 
+int t2d_bind_actions(t2d_pool* p, const float* act0_dev, const float* act1_dev) {
+    if (!p) return T2D_ERR_INVALID;
+    if ((act0_dev == nullptr) != (act1_dev == nullptr))
+        return fail(p, T2D_ERR_INVALID, "bind both action arrays or neither");
+    p->v.act0 = act0_dev ? const_cast<float*>(act0_dev) : (float*)p->field_ptr[T2D_F_ACT0];
+    p->v.act1 = act1_dev ? const_cast<float*>(act1_dev) : (float*)p->field_ptr[T2D_F_ACT1];
+    return T2D_OK;
+}
+
 int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     if (!p) return T2D_ERR_INVALID;
     if (!p->have_params || !p->have_reset)
@@ -429,6 +481,31 @@ int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     int rc = t2d_integrate(p, interval_ms, hip_stream);
     if (rc != T2D_OK) return rc;
     return collide_impl(p, true, interval_ms, (hipStream_t)hip_stream);
+}
+
+int t2d_snapshot(t2d_pool* p) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!p->have_reset) return fail(p, T2D_ERR_STATE, "t2d_reset must precede t2d_snapshot");
+    T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, hipDeviceSynchronize());
+    const size_t nb = 4 * (size_t)p->v.N;
+    float* src[6] = {p->v.x, p->v.y, p->v.heading, p->v.speed, p->v.vx, p->v.vy};
+    for (int k = 0; k < 6; ++k) {
+        if (!p->d_snap[k]) T2D_HIP(p, hipMalloc((void**)&p->d_snap[k], nb));
+        T2D_HIP(p, hipMemcpy(p->d_snap[k], src[k], nb, hipMemcpyDeviceToDevice));
+    }
+    if (!p->d_snap_ids) T2D_HIP(p, hipMalloc((void**)&p->d_snap_ids, nb));
+    T2D_HIP(p, hipMemcpy(p->d_snap_ids, p->v.ids, nb, hipMemcpyDeviceToDevice));
+    p->have_snapshot = true;
+    return T2D_OK;
+}
+
+int t2d_restore(t2d_pool* p, int32_t mode, void* hip_stream) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!p->have_snapshot) return fail(p, T2D_ERR_STATE, "t2d_snapshot must precede t2d_restore");
+    if (mode != 0 && mode != 1) return fail(p, T2D_ERR_INVALID, "mode must be 0 (all) or 1 (done envs)");
+    T2D_HIP(p, t2d::launch_restore(p->v, p->d_snap, p->d_snap_ids, mode, (hipStream_t)hip_stream));
+    return T2D_OK;
 }
 
 int t2d_get_field(t2d_pool* p, int32_t f, void** dev_ptr, size_t* nbytes) {

@@ -70,6 +70,9 @@ struct t2d_pool {
     uint8_t* d_boundary_valid = nullptr;
     int32_t *d_env_lane_off = nullptr, *d_lane_vert_off = nullptr;
     double *d_lane_xy = nullptr, *d_lane_aabb = nullptr;
+    float* d_snap[6]{};      // x, y, heading, speed, vx, vy at episode start
+    uint32_t* d_snap_ids = nullptr;
+    bool have_snapshot = false;
     int geo_max[4]{};  // max polys/env, max poly verts/env, max lanes/env, max lane verts/env
     // profiling
     bool profiling = false;
@@ -84,4 +87,6 @@ namespace t2d {
 hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hipStream_t s);
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
                           int interval_ms, const int* geo_max, hipStream_t s);
+hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
+                          hipStream_t s);
 }  // namespace t2d

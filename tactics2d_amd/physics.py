@@ -1,0 +1,234 @@
+"""Batched counterparts of tactics2d.physics with the reference's constructor semantics.
+
+Mirrors (tactics2d v0.1.9rc3):
+    SingleTrackKinematics   physics/single_track_kinematics.py:62-124 (ctor), :178-198 (step)
+    SingleTrackDynamics     physics/single_track_dynamics.py:58-138 (ctor), :231-251 (step)
+    PointMass               physics/point_mass.py:33-81 (ctor), :209-232 (step)
+
+The constructors normalise ranges / delta_t exactly like the reference (including its quirks: an
+`int` range means "unbounded" for the vehicle models, PointMass clamps negative bounds to 0) and
+produce one row of the kernels' parameter table.  `step()` takes a BatchedState and arrays of
+actions and runs ONE HIP launch for all of them (t2d_integrate); there is no per-participant
+Python loop and no CPU fallback.
+"""
+import logging
+
+import numpy as np
+
+from . import layout as L
+
+_DELTA_T = 5       # PhysicsModelBase._DELTA_T   physics/physics_model_base.py:23
+_MIN_DELTA_T = 1   # PhysicsModelBase._MIN_DELTA_T
+
+
+def _vehicle_range(r):
+    """single_track_kinematics.py:87-115: float r -> [-r, r] (None if r < 0); 2-sequence kept if
+    lo < hi; anything else (including an int) -> None."""
+    if isinstance(r, float):
+        return None if r < 0 else [-r, r]
+    if hasattr(r, "__len__") and len(r) == 2:
+        return None if r[0] >= r[1] else r
+    return None
+
+
+def _pointmass_range(r):
+    """point_mass.py:50-66: float r -> [0, r]; 2-sequence -> [max(0, lo), max(0, hi)], None if lo >= hi."""
+    if isinstance(r, float):
+        return None if r < 0 else [0, r]
+    if hasattr(r, "__len__") and len(r) == 2:
+        out = [max(0, r[0]), max(0, r[1])]
+        return None if out[0] >= out[1] else out
+    return None
+
+
+def _resolve_delta_t(delta_t, interval):
+    """single_track_kinematics.py:119-124."""
+    if delta_t is None:
+        return _DELTA_T
+    dt = max(delta_t, _MIN_DELTA_T)
+    if interval is not None:
+        dt = min(dt, interval)
+    return dt
+
+
+class BatchedState:
+    """SoA stand-in for a batch of `State` objects (participant/trajectory/state.py:12-223).
+
+    Columns are float32 numpy arrays of equal length; `frame` is an int (ms).  Derived fields
+    follow State: `velocity` = (vx, vy) when set, else (speed*cos(heading), speed*sin(heading))
+    (state.py:152-169); `speed` = ||(vx, vy)|| when only the velocity is set (state.py:135-150).
+    """
+
+    def __init__(self, frame, x, y, heading=None, vx=None, vy=None, speed=None, accel=None):
+        self.frame = int(frame)
+        self.x = np.ascontiguousarray(x, np.float32)
+        self.y = np.ascontiguousarray(y, np.float32)
+        n = self.x.size
+        self.heading = np.zeros(n, np.float32) if heading is None else np.ascontiguousarray(heading, np.float32)
+        self.vx = None if vx is None else np.ascontiguousarray(vx, np.float32)
+        self.vy = None if vy is None else np.ascontiguousarray(vy, np.float32)
+        self._speed = None if speed is None else np.ascontiguousarray(speed, np.float32)
+        self.accel = None if accel is None else np.ascontiguousarray(accel, np.float32)
+
+    def __len__(self):
+        return self.x.size
+
+    @property
+    def location(self):
+        return self.x, self.y
+
+    @property
+    def speed(self):
+        if self._speed is not None:
+            return self._speed
+        if self.vx is not None and self.vy is not None:
+            return np.sqrt(self.vx.astype(np.float64) ** 2 + self.vy.astype(np.float64) ** 2).astype(np.float32)
+        return None
+
+    @property
+    def velocity(self):
+        if self.vx is not None and self.vy is not None:
+            return self.vx, self.vy
+        if self._speed is not None:
+            h = self.heading.astype(np.float64)
+            s = self._speed.astype(np.float64)
+            return (s * np.cos(h)).astype(np.float32), (s * np.sin(h)).astype(np.float32)
+        return None
+
+
+class _BatchedModel:
+    model_id = None
+
+    def _pool(self, n):
+        from .pool import ParticipantPool
+        pool = getattr(self, "_cached_pool", None)
+        if pool is None or pool.n_env != n:
+            if pool is not None:
+                pool.close()
+            pool = ParticipantPool(n, 1)
+            pool.set_param_table(self.param_row()[None])
+            self._cached_pool = pool
+        return pool
+
+    def param_row(self, shape=L.SHAPE_OBB, length=0.0, width=0.0):
+        raise NotImplementedError
+
+    def close(self):
+        pool = getattr(self, "_cached_pool", None)
+        if pool is not None:
+            pool.close()
+            self._cached_pool = None
+
+
+class SingleTrackKinematics(_BatchedModel):
+    model_id = L.MODEL_KINEMATICS
+
+    def __init__(self, lf, lr, steer_range=None, speed_range=None, accel_range=None, interval=100,
+                 delta_t=None):
+        self.lf = lf
+        self.lr = lr
+        self.wheel_base = lf + lr
+        self.steer_range = _vehicle_range(steer_range)
+        self.speed_range = _vehicle_range(speed_range)
+        self.accel_range = _vehicle_range(accel_range)
+        self.interval = interval
+        self.delta_t = _resolve_delta_t(delta_t, interval)
+
+    def param_row(self, shape=L.SHAPE_OBB, length=0.0, width=0.0):
+        r = np.zeros(L.PARAM_COLS)
+        r[L.P_MODEL] = self.model_id
+        r[L.P_LF], r[L.P_LR], r[L.P_WB] = self.lf, self.lr, self.wheel_base
+        flags = 0
+        if self.steer_range is not None:
+            r[L.P_STEER_LO], r[L.P_STEER_HI] = self.steer_range
+            flags |= L.RANGE_STEER
+        if self.speed_range is not None:
+            r[L.P_SPEED_LO], r[L.P_SPEED_HI] = self.speed_range
+            flags |= L.RANGE_SPEED
+        if self.accel_range is not None:
+            r[L.P_ACCEL_LO], r[L.P_ACCEL_HI] = self.accel_range
+            flags |= L.RANGE_ACCEL
+        r[L.P_RANGE_FLAGS] = flags
+        r[L.P_DELTA_T_MS] = self.delta_t
+        r[L.P_SHAPE], r[L.P_LENGTH], r[L.P_WIDTH] = shape, length, width
+        return r
+
+    def step(self, state, accel, delta, interval=None):
+        """Batched `step`: returns (next_state, applied_accel, applied_delta) like the reference."""
+        interval = interval if interval is not None else self.interval
+        n = len(state)
+        pool = self._pool(n)
+        z = np.zeros(n, np.uint8)
+        pool.reset(state.x, state.y, state.heading, state.speed, z)
+        pool.set_actions(np.broadcast_to(np.asarray(accel, np.float32), (n,)),
+                         np.broadcast_to(np.asarray(delta, np.float32), (n,)))
+        pool.integrate(interval)
+        d = pool.download
+        app0, app1 = d(L.F_APPLIED0), d(L.F_APPLIED1)
+        has_v = self.model_id != L.MODEL_DYNAMICS  # dynamics State has vx = vy = None
+        nxt = BatchedState(state.frame + interval, d(L.F_X), d(L.F_Y), d(L.F_HEADING),
+                           d(L.F_VX) if has_v else None, d(L.F_VY) if has_v else None,
+                           speed=d(L.F_SPEED), accel=app0)
+        return nxt, app0, app1
+
+
+class SingleTrackDynamics(SingleTrackKinematics):
+    model_id = L.MODEL_DYNAMICS
+
+    def __init__(self, lf, lr, mass, mass_height, mu=0.7, I_z=1500, cf=20.89, cr=20.89,
+                 steer_range=None, speed_range=None, accel_range=None, interval=100, delta_t=None):
+        super().__init__(lf, lr, steer_range, speed_range, accel_range, interval, delta_t)
+        self.mass, self.mass_height = mass, mass_height
+        self.mu, self.I_z, self.cf, self.cr = mu, I_z, cf, cr
+
+    def param_row(self, shape=L.SHAPE_OBB, length=0.0, width=0.0):
+        r = super().param_row(shape, length, width)
+        r[L.P_MASS], r[L.P_MASS_HEIGHT] = self.mass, self.mass_height
+        r[L.P_MU], r[L.P_IZ], r[L.P_CF], r[L.P_CR] = self.mu, self.I_z, self.cf, self.cr
+        return r
+
+
+class PointMass(_BatchedModel):
+    model_id = L.MODEL_POINTMASS
+    backends = ["newton", "euler"]
+
+    def __init__(self, speed_range=None, accel_range=None, interval=100, delta_t=None, backend="newton"):
+        self.speed_range = _pointmass_range(speed_range)
+        self.accel_range = _pointmass_range(accel_range)
+        self.interval = interval
+        self.delta_t = _resolve_delta_t(delta_t, interval)
+        if backend != "newton":
+            # the euler back-end only exists as a test cross-check in the reference
+            # (point_mass.py:18-19, tests/test_physics.py:224); the kernels implement newton.
+            logging.warning(f"Backend {backend} is not accelerated. Using `newton` instead.")
+        self.backend = "newton"
+
+    def param_row(self, shape=L.SHAPE_CIRCLE, length=0.0, width=0.0):
+        r = np.zeros(L.PARAM_COLS)
+        r[L.P_MODEL] = self.model_id
+        flags = 0
+        if self.speed_range is not None:
+            r[L.P_SPEED_LO], r[L.P_SPEED_HI] = self.speed_range
+            flags |= L.RANGE_SPEED
+        if self.accel_range is not None:
+            r[L.P_ACCEL_LO], r[L.P_ACCEL_HI] = self.accel_range
+            flags |= L.RANGE_ACCEL
+        r[L.P_RANGE_FLAGS] = flags
+        r[L.P_DELTA_T_MS] = self.delta_t
+        r[L.P_SHAPE], r[L.P_LENGTH], r[L.P_WIDTH] = shape, length, width
+        return r
+
+    def step(self, state, accel, interval=None):
+        """Batched `step(state, (ax, ay), interval)` -> next_state (point_mass.py:209-232)."""
+        interval = interval if interval is not None else self.interval
+        n = len(state)
+        pool = self._pool(n)
+        vx, vy = state.velocity
+        z = np.zeros(n, np.float32)
+        pool.reset(state.x, state.y, z, z, np.zeros(n, np.uint8), vx=vx, vy=vy)
+        ax, ay = accel
+        pool.set_actions(np.broadcast_to(np.asarray(ax, np.float32), (n,)),
+                         np.broadcast_to(np.asarray(ay, np.float32), (n,)))
+        pool.integrate(interval)
+        d = pool.download
+        return BatchedState(state.frame + interval, d(L.F_X), d(L.F_Y), d(L.F_HEADING), d(L.F_VX), d(L.F_VY))

@@ -135,6 +135,10 @@ class ParticipantPool:
         self.upload(L.F_ACT0, act0)
         self.upload(L.F_ACT1, act1)
 
+    def bind_actions(self, act0_ptr=None, act1_ptr=None):
+        """Zero-copy actions from caller-owned device memory (raw pointers, e.g. tensor.data_ptr())."""
+        self._ck(self._lib.t2d_bind_actions(self._h, act0_ptr, act1_ptr))
+
     def field_ptr(self, field):
         ptr, nb = C.c_void_p(), C.c_size_t()
         self._ck(self._lib.t2d_get_field(self._h, field, C.byref(ptr), C.byref(nb)))
@@ -156,6 +160,14 @@ class ParticipantPool:
 
     def step(self, interval_ms=100, stream=None):
         self._ck(self._lib.t2d_step(self._h, int(interval_ms), stream))
+
+    def snapshot(self):
+        """Record the current state as the episode start for device-side resets."""
+        self._ck(self._lib.t2d_snapshot(self._h))
+
+    def restore(self, done_only=False, stream=None):
+        """Device-side reset to the snapshot: all envs, or only terminated/truncated ones."""
+        self._ck(self._lib.t2d_restore(self._h, 1 if done_only else 0, stream))
 
     def sync(self):
         self._ck(self._lib.t2d_sync(self._h))

@@ -1,0 +1,268 @@
+"""Synthetic scenario builders for BASELINE.json's configs.
+
+The reference ships only ParkingEnv / RacingEnv (envs/__init__.py:7-10); its highway /
+intersection / roundabout scenarios do not exist in code.  Config 2 follows the bay-mode layout
+of ParkingLotGenerator (map/generator/generate_parking_lot.py:239-444); configs 3-5 are
+BUILD-DEFINED scenes composed from reference primitives (vehicle templates, physics models,
+convex lane polygons) and documented in DESIGN.md.  Everything is seeded numpy, env-local fp32
+coordinates with |x|, |y| < 256 m.
+
+Every builder returns a Scene; `Scene.load(pool)` pushes it through the C ABI.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import layout as L
+from .participant import (CYCLIST_TEMPLATE, PEDESTRIAN_TEMPLATE, VEHICLE_TEMPLATE, full_type_table,
+                          vehicle_model)
+
+TWO_PI = 2 * np.pi
+
+
+def _box(cx, cy, h, length, width):
+    """ParkingLotGenerator._get_bbox vertex order (generate_parking_lot.py:67-87)."""
+    base = np.array([[0.5 * length, -0.5 * width], [0.5 * length, 0.5 * width],
+                     [-0.5 * length, 0.5 * width], [-0.5 * length, -0.5 * width]])
+    c, s = np.cos(h), np.sin(h)
+    R = np.array([[c, -s], [s, c]])
+    return (base @ R.T + [cx, cy]).astype(np.float32)
+
+
+def _csr(per_env):
+    eo, vo, xy = [0], [0], []
+    for polys in per_env:
+        for q in polys:
+            xy.append(np.asarray(q, np.float32)); vo.append(vo[-1] + len(q))
+        eo.append(eo[-1] + len(polys))
+    xy = np.concatenate(xy) if xy else np.zeros((0, 2), np.float32)
+    return np.array(eo, np.int32), np.array(vo, np.int32), xy
+
+
+@dataclass
+class Scene:
+    name: str
+    n_env: int
+    A: int
+    rows: np.ndarray
+    type_names: list
+    x: np.ndarray
+    y: np.ndarray
+    heading: np.ndarray
+    speed: np.ndarray
+    type_id: np.ndarray
+    active: np.ndarray
+    static: tuple = None
+    lanes: tuple = None
+    boundary: np.ndarray = None
+    boundary_valid: np.ndarray = None
+    status: dict = field(default_factory=dict)
+    interval_ms: int = 100
+
+    @property
+    def n(self):
+        return self.n_env * self.A
+
+    def load(self, pool):
+        pool.set_param_table(self.rows)
+        pool.set_static_geometry(self.static, self.boundary, self.boundary_valid)
+        pool.set_lane_geometry(self.lanes)
+        pool.set_status_config(**self.status)
+        pool.reset(self.x, self.y, self.heading, self.speed, self.type_id, self.active)
+        pool.snapshot()
+
+    def sample_actions(self, rng):
+        """One batch of random actions in the reference's action conventions:
+        vehicles (accel U(-3, 2), steer N(0, 0.02) -- parking: the ParkingEnv action box
+        envs/parking.py:132-136), point masses (ax, ay) U(-1, 1)."""
+        model = self.rows[self.type_id, L.P_MODEL].astype(int)
+        n = self.n
+        if self.name.startswith("parking"):
+            a0 = rng.uniform(-2.0, 2.0, n); a1 = rng.uniform(-0.524, 0.524, n)
+        else:
+            a0 = rng.uniform(-3.0, 2.0, n); a1 = rng.normal(0.0, 0.02, n)
+        pm = model == L.MODEL_POINTMASS
+        a0 = np.where(pm, rng.uniform(-1, 1, n), a0); a1 = np.where(pm, rng.uniform(-1, 1, n), a1)
+        return a0.astype(np.float32), a1.astype(np.float32)
+
+
+# ------------------------------------------------------------------------------- config 1 / 2
+def parking(n_env, seed0=0):
+    """cfg1 (n_env = 1) / cfg2 (n_env = 4096): one ego (medium_car, SingleTrackKinematics with
+    the ParkingEnv ranges, envs/parking.py:318-327) + 8 static quads in the bay layout of
+    generate_parking_lot.py; boundary = floor/ceil(start/target -+ 13 m) (:434-438)."""
+    ego = vehicle_model("medium_car", "kinematics", speed_range=(-0.5, 0.5), accel_range=(-2.0, 2.0),
+                        steer_range=(-0.524, 0.524))
+    Ln, W = VEHICLE_TEMPLATE["medium_car"][:2]
+    rows = ego.param_row(L.SHAPE_OBB, Ln, W)[None]
+    xs, ys, hs, statics, bounds = [], [], [], [], []
+    for e in range(n_env):
+        rng = np.random.default_rng(seed0 + e)
+        car = (5.3, 2.5)
+        th = np.clip(rng.normal(np.pi / 2, np.pi / 54), np.pi * 4 / 9, np.pi * 5 / 9)
+        ty = 0.8 + 2.65 + np.clip(rng.normal(0.4, 0.2), 0.0, 0.8)
+        polys = []
+        ww = rng.uniform(0.5, 1.5)
+        polys.append(_box(0.0, -ww / 2, 0.0, 30.0, ww))                       # back wall :135-141
+        ymax = 0.0
+        for side in (-1, 1):
+            off = car[1] + rng.uniform(0.9, 1.6)
+            for k in range(3):                                                # 1 neighbour + 2 further
+                hh = np.clip(rng.normal(np.pi / 2, np.pi / 54), np.pi * 4 / 9, np.pi * 5 / 9)
+                yy = 0.8 + 2.65 + np.clip(rng.normal(0.4, 0.2), 0.0, 0.8)
+                q = _box(side * off, yy, hh, *car)
+                polys.append(q); ymax = max(ymax, float(q[:, 1].max()))
+                off += car[1] + 0.8 + rng.uniform(0.1, 0.8)
+        ymax = max(ymax, ty + 2.7) + 0.8
+        polys.append(_box(0.0, ymax + 7.0 + 4.0, 0.0, 30.0, rng.uniform(0.05, 0.2)))  # far wall
+        sx = rng.uniform(-7.5, 7.5); sy = rng.uniform(ymax + 1.8, ymax + 6.0)
+        sh = np.clip(rng.normal(0.0, np.pi / 54), -np.pi / 18, np.pi / 18)
+        if rng.uniform() > 0.5:
+            sh += np.pi
+        xs.append(sx); ys.append(sy); hs.append(np.mod(sh, TWO_PI)); statics.append(polys)
+        bounds.append([np.floor(min(sx, 0.0) - 13), np.ceil(max(sx, 0.0) + 13),
+                       np.floor(min(sy, ty) - 13), np.ceil(max(sy, ty) + 13)])
+        _ = th
+    n = n_env
+    return Scene("parking", n_env, 1, rows, ["medium_car:parking"], np.float32(xs), np.float32(ys),
+                 np.float32(hs), np.zeros(n, np.float32), np.zeros(n, np.uint8), np.ones(n, np.uint8),
+                 static=_csr(statics), boundary=np.float32(bounds),
+                 status=dict(max_step=20000, check_dynamic=0, check_off_lane=0))
+
+
+# ------------------------------------------------------------------------------- config 3
+def _highway_env(rng, A, rows_by_name, dyn=True):
+    names = list(VEHICLE_TEMPLATE)
+    lanes_y = [-5.625, -1.875, 1.875, 5.625]
+    per_lane = A // 4
+    x, y, h, v, t = [], [], [], [], []
+    for li, ly in enumerate(lanes_y):
+        n_l = per_lane + (1 if li < A - 4 * per_lane else 0)
+        spacing = 400.0 / max(n_l, 1)
+        for k in range(n_l):
+            name = names[int(rng.integers(0, 9))]
+            Ln = VEHICLE_TEMPLATE[name][0]
+            jit = max(0.0, (spacing - Ln - 2.0) / 2)
+            x.append(-200.0 + (k + 0.5) * spacing + rng.uniform(-jit, jit))
+            y.append(ly + rng.normal(0, 0.2)); h.append(np.mod(rng.normal(0, 0.02), TWO_PI))
+            v.append(rng.uniform(20, 35)); t.append(rows_by_name[name + (":dyn" if dyn else ":kin")])
+    lanes = [np.float32([[-210, ly - 1.875], [210, ly - 1.875], [210, ly + 1.875], [-210, ly + 1.875]])
+             for ly in lanes_y]
+    return x, y, h, v, t, [], lanes, [-215.0, 215.0, -9.0, 9.0]
+
+
+def _intersection_env(rng, A, rows_by_name, ped_frac=0.0):
+    names = list(VEHICLE_TEMPLATE)
+    peds = list(PEDESTRIAN_TEMPLATE)
+    x, y, h, v, t = [], [], [], [], []
+    n_ped = int(round(A * ped_frac))
+    n_veh = A - n_ped
+    arms = [(1, 0), (-1, 0), (0, 1), (0, -1)]     # direction of travel towards the centre is -arm
+    half = max(60.0, 8.0 + ((n_veh + 3) // 4) * 7.0 + 6.0)       # road half-length (m)
+    for k in range(n_veh):
+        ax_, ay_ = arms[k % 4]
+        slot = k // 4
+        d = 8.0 + slot * 7.0 + rng.uniform(-0.8, 0.8)              # distance from the centre
+        lane_off = 1.875                                           # right-hand traffic
+        name = names[int(rng.integers(0, 9))]
+        if ax_ != 0:
+            px, py = ax_ * d, -ax_ * lane_off + rng.normal(0, 0.15)
+            hd = np.pi if ax_ > 0 else 0.0
+        else:
+            px, py = ay_ * lane_off + rng.normal(0, 0.15), ay_ * d
+            hd = -np.pi / 2 if ay_ > 0 else np.pi / 2
+        x.append(px); y.append(py); h.append(np.mod(hd + rng.normal(0, 0.02), TWO_PI))
+        v.append(rng.uniform(0, 12)); t.append(rows_by_name[name + ":kin"])
+    for k in range(n_ped):                                         # pedestrians on the corners
+        cx = rng.choice([-1, 1]) * rng.uniform(4.5, 7.5); cy = rng.choice([-1, 1]) * rng.uniform(4.5, 7.5)
+        x.append(cx); y.append(cy); h.append(rng.uniform(0, TWO_PI)); v.append(rng.uniform(0, 1.5))
+        t.append(rows_by_name[peds[int(rng.integers(0, 4))]])
+    lanes = [np.float32([[-half, -3.75], [half, -3.75], [half, 3.75], [-half, 3.75]]),
+             np.float32([[-3.75, -half], [3.75, -half], [3.75, half], [-3.75, half]])]
+    for sx in (-1, 1):                                             # 4 corner fillets (triangles)
+        for sy in (-1, 1):
+            lanes.append(np.float32([[sx * 3.75, sy * 3.75], [sx * 7.75, sy * 3.75], [sx * 3.75, sy * 7.75]]))
+    static = [_box(sx * 14.0, sy * 14.0, 0.0, 12.0, 12.0) for sx in (-1, 1) for sy in (-1, 1)]  # buildings
+    return x, y, h, v, t, static, lanes, [-half - 4.0, half + 4.0, -half - 4.0, half + 4.0]
+
+
+def _roundabout_env(rng, A, rows_by_name):
+    names = list(VEHICLE_TEMPLATE)
+    cyc = list(CYCLIST_TEMPLATE)
+    r_in, r_out, nseg = 12.0, 20.0, 12
+    n_ring = max(1, A // 4)
+    arm_len = 26.0 + ((A - n_ring + 3) // 4) * 7.5 + 6.0
+    lanes = []
+    for k in range(nseg):                                          # annulus as 12 convex trapezoids
+        a0, a1 = TWO_PI * k / nseg, TWO_PI * (k + 1) / nseg
+        lanes.append(np.float32([[r_in * np.cos(a0), r_in * np.sin(a0)], [r_out * np.cos(a0), r_out * np.sin(a0)],
+                                 [r_out * np.cos(a1), r_out * np.sin(a1)], [r_in * np.cos(a1), r_in * np.sin(a1)]]))
+    for ax_, ay_ in ((1, 0), (-1, 0), (0, 1), (0, -1)):            # 4 arms
+        if ax_:
+            lanes.append(np.float32([[ax_ * 19, -3.75], [ax_ * arm_len, -3.75], [ax_ * arm_len, 3.75], [ax_ * 19, 3.75]]))
+        else:
+            lanes.append(np.float32([[-3.75, ay_ * 19], [3.75, ay_ * 19], [3.75, ay_ * arm_len], [-3.75, ay_ * arm_len]]))
+    x, y, h, v, t = [], [], [], [], []
+    for k in range(A):
+        if k < n_ring:                                             # circulating, counter-clockwise
+            ang = TWO_PI * k / n_ring + rng.uniform(-0.05, 0.05)
+            rr = 14.0 if k % 2 == 0 else 18.0
+            x.append(rr * np.cos(ang)); y.append(rr * np.sin(ang)); h.append(np.mod(ang + np.pi / 2, TWO_PI))
+            v.append(rng.uniform(4, 9))
+        else:                                                      # approaching on the arms
+            j = k - n_ring
+            ax_, ay_ = ((1, 0), (-1, 0), (0, 1), (0, -1))[j % 4]
+            d = 26.0 + (j // 4) * 7.5 + rng.uniform(-0.8, 0.8)
+            if ax_:
+                x.append(ax_ * d); y.append(-ax_ * 1.875); h.append(np.pi if ax_ > 0 else 0.0)
+            else:
+                x.append(ay_ * 1.875); y.append(ay_ * d); h.append(np.mod(-np.pi / 2 if ay_ > 0 else np.pi / 2, TWO_PI))
+            v.append(rng.uniform(3, 10))
+        if rng.uniform() < 0.15:
+            t.append(rows_by_name[cyc[int(rng.integers(0, 3))]])
+        else:
+            t.append(rows_by_name[names[int(rng.integers(0, 9))] + ":kin"])
+    island = np.float32([[11.0 * np.cos(TWO_PI * k / 8), 11.0 * np.sin(TWO_PI * k / 8)] for k in range(8)])
+    bb = arm_len + 3.0
+    return x, y, h, v, t, [island], lanes, [-bb, bb, -bb, bb]
+
+
+def _assemble(name, n_env, A, seed, env_fn):
+    rows, names = full_type_table()
+    by = {n: i for i, n in enumerate(names)}
+    X, Y, Hh, V, T, ST, LN, B = [], [], [], [], [], [], [], []
+    for e in range(n_env):
+        rng = np.random.default_rng([seed, e])
+        x, y, h, v, t, static, lanes, b = env_fn(e, rng, A, by)
+        assert len(x) == A
+        X += x; Y += y; Hh += h; V += v; T += t; ST.append(static); LN.append(lanes); B.append(b)
+    n = n_env * A
+    return Scene(name, n_env, A, rows, names, np.float32(X), np.float32(Y), np.float32(Hh), np.float32(V),
+                 np.array(T, np.uint8), np.ones(n, np.uint8), static=_csr(ST), lanes=_csr(LN),
+                 boundary=np.float32(B), status=dict(max_step=2000, check_dynamic=1, check_off_lane=1))
+
+
+def highway(n_env=1024, A=64, seed=1):
+    """cfg3: straight 420 m x 4-lane highway, SingleTrackDynamics, 9 vehicle templates."""
+    return _assemble("highway", n_env, A, seed, lambda e, rng, A_, by: _highway_env(rng, A_, by, True))
+
+
+def intersection(n_env=2048, A=32, seed=2):
+    """cfg4: 4-way unsignalised intersection (two 7.5 m x 120 m roads + corner fillets as lane
+    polygons, 4 buildings as static obstacles), SingleTrackKinematics, off-lane flag on."""
+    return _assemble("intersection", n_env, A, seed, lambda e, rng, A_, by: _intersection_env(rng, A_, by, 0.0))
+
+
+def mixed(n_env=8192, A=64, seed=3):
+    """cfg5 / the metric run (n_env = 4096): env type = e mod 3 in {highway (dynamics), roundabout
+    (kinematics + cyclists), intersection (kinematics + 10 % point-mass pedestrians)}."""
+    def fn(e, rng, A_, by):
+        k = e % 3
+        if k == 0:
+            return _highway_env(rng, A_, by, True)
+        if k == 1:
+            return _roundabout_env(rng, A_, by)
+        x, y, h, v, t, st, ln, b = _intersection_env(rng, A_, by, 0.10)
+        # keep vehicles first, pedestrians last inside the env (already so) -> fewer mixed waves
+        return x, y, h, v, t, st, ln, b
+    return _assemble("mixed", n_env, A, seed, fn)
