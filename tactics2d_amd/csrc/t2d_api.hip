@@ -62,10 +62,10 @@ double orient_h(const double* p, const double* q, const double* r) {
     return a * b - c * d;
 }
 
-// fp32 CSR polygons -> fp64 CCW vertices + per-polygon AABB.  Validates convexity.
+// fp32 CSR polygons -> CCW-normalised fp32 copy + per-polygon AABB.  Validates convexity with the
+// same fp64 orientation arithmetic the kernels use.
 int prepare_polys(t2d_pool* p, const int32_t* env_off, const int32_t* vert_off, const float* xy,
-                  std::vector<double>& out_xy, std::vector<double>& out_aabb, int* max_polys,
-                  int* max_verts) {
+                  t2d_pool::HostGeo& out) {
     const int E = p->v.n_env;
     if (env_off[0] != 0) return fail(p, T2D_ERR_INVALID, "env offsets must start at 0");
     for (int e = 0; e < E; ++e)
@@ -73,8 +73,13 @@ int prepare_polys(t2d_pool* p, const int32_t* env_off, const int32_t* vert_off, 
     const int P = env_off[E];
     if (P > 0 && vert_off[0] != 0) return fail(p, T2D_ERR_INVALID, "vertex offsets must start at 0");
     const int V = P > 0 ? vert_off[P] : 0;
-    out_xy.assign(2 * (size_t)V, 0.0);
-    out_aabb.assign(4 * (size_t)P, 0.0);
+    t2d_pool::HostGeo g;
+    g.present = true;
+    g.env_off.assign(env_off, env_off + E + 1);
+    g.vert_off.assign(vert_off, vert_off + P + 1);
+    if (P == 0) g.vert_off.assign(1, 0);
+    g.xy.assign(2 * (size_t)V, 0.f);
+    g.aabb.assign(4 * (size_t)P, 0.f);
     for (int q = 0; q < P; ++q) {
         const int v0 = vert_off[q], n = vert_off[q + 1] - v0;
         if (n < 3 || n > T2D_MAX_POLY_VERTS)
@@ -95,22 +100,94 @@ int prepare_polys(t2d_pool* p, const int32_t* env_off, const int32_t* vert_off, 
             if (orient_h(&poly[2 * i], &poly[2 * ((i + 1) % n)], &poly[2 * ((i + 2) % n)]) < 0.0)
                 return fail(p, T2D_ERR_GEOMETRY,
                             "polygon " + std::to_string(q) + " is not convex (decompose on the host)");
-        double xmin = poly[0], xmax = poly[0], ymin = poly[1], ymax = poly[1];
+        float xmin = (float)poly[0], xmax = xmin, ymin = (float)poly[1], ymax = ymin;
         for (int i = 0; i < n; ++i) {
-            xmin = std::min(xmin, poly[2 * i]); xmax = std::max(xmax, poly[2 * i]);
-            ymin = std::min(ymin, poly[2 * i + 1]); ymax = std::max(ymax, poly[2 * i + 1]);
+            const float fx = (float)poly[2 * i], fy = (float)poly[2 * i + 1];  // exact: inputs are fp32
+            g.xy[2 * (size_t)(v0 + i)] = fx;
+            g.xy[2 * (size_t)(v0 + i) + 1] = fy;
+            xmin = std::min(xmin, fx); xmax = std::max(xmax, fx);
+            ymin = std::min(ymin, fy); ymax = std::max(ymax, fy);
         }
-        memcpy(&out_xy[2 * (size_t)v0], poly.data(), sizeof(double) * 2 * n);
-        out_aabb[4 * (size_t)q] = xmin; out_aabb[4 * (size_t)q + 1] = xmax;
-        out_aabb[4 * (size_t)q + 2] = ymin; out_aabb[4 * (size_t)q + 3] = ymax;
+        g.aabb[4 * (size_t)q] = xmin; g.aabb[4 * (size_t)q + 1] = xmax;
+        g.aabb[4 * (size_t)q + 2] = ymin; g.aabb[4 * (size_t)q + 3] = ymax;
     }
-    *max_polys = 0; *max_verts = 0;
-    for (int e = 0; e < E; ++e) {
-        const int np = env_off[e + 1] - env_off[e];
-        const int nv = np > 0 ? vert_off[env_off[e + 1]] - vert_off[env_off[e]] : 0;
-        *max_polys = std::max(*max_polys, np);
-        *max_verts = std::max(*max_verts, nv);
+    out = std::move(g);
+    return T2D_OK;
+}
+
+int log2_pad(int A) {
+    int l = 0;
+    while ((1 << l) < A) ++l;
+    return l;
+}
+
+// (Re)build the packed per-workgroup geometry records from the host CSR copies and upload them.
+int rebuild_geo(t2d_pool* p) {
+    const int E = p->v.n_env;
+    const int log2A = log2_pad(p->v.A);
+    const int epb_max = 256 >> log2A;
+    constexpr int kBudgetDwords = 8192;  // 32 KiB of dynamic LDS for the record
+    t2d::GeoLayout gl{};
+    gl.epb = epb_max;
+    if (!p->hgeo[0].present && !p->hgeo[1].present) {
+        int rc = dev_replace<uint32_t>(p, &p->d_geo, nullptr, 0);
+        p->v.geo = nullptr;
+        p->v.geo_layout = gl;
+        return rc;
     }
+    int epb = epb_max;
+    int mp[2], mv[2];
+    for (;; epb >>= 1) {
+        const int nb = (E + epb - 1) / epb;
+        for (int k = 0; k < 2; ++k) {
+            mp[k] = mv[k] = 0;
+            const auto& g = p->hgeo[k];
+            if (!g.present) continue;
+            for (int b = 0; b < nb; ++b) {
+                const int e0 = b * epb, e1 = std::min(E, e0 + epb);
+                const int p0 = g.env_off[e0], p1 = g.env_off[e1];
+                mp[k] = std::max(mp[k], p1 - p0);
+                mv[k] = std::max(mv[k], g.vert_off[p1] - g.vert_off[p0]);
+            }
+        }
+        int off = 0;
+        for (int k = 0; k < 2; ++k) { gl.off_pstart[k] = off; off += epb + 1; }
+        for (int k = 0; k < 2; ++k) { gl.off_vstart[k] = off; off += mp[k] + 1; }
+        off = (off + 3) & ~3;  // 16-B align the float4 AABBs
+        for (int k = 0; k < 2; ++k) { gl.off_aabb[k] = off; off += 4 * mp[k]; }
+        for (int k = 0; k < 2; ++k) { gl.off_xy[k] = off; off += 2 * mv[k]; }  // even -> 8-B aligned
+        gl.stride = (off + 3) & ~3;
+        gl.epb = epb;
+        if (gl.stride <= kBudgetDwords) break;
+        if ((epb << log2A) <= 64 || epb == 1)
+            return fail(p, T2D_ERR_GEOMETRY, "static + lane geometry of one workgroup exceeds the 32 KiB LDS record");
+    }
+    for (int k = 0; k < 2; ++k) gl.has[k] = p->hgeo[k].present && mp[k] > 0;
+    const int nb = (E + epb - 1) / epb;
+    std::vector<uint32_t> rec((size_t)nb * gl.stride, 0u);
+    for (int b = 0; b < nb; ++b) {
+        uint32_t* r = rec.data() + (size_t)b * gl.stride;
+        const int e0 = b * epb;
+        for (int k = 0; k < 2; ++k) {
+            const auto& g = p->hgeo[k];
+            int32_t* pstart = reinterpret_cast<int32_t*>(r) + gl.off_pstart[k];
+            int32_t* vstart = reinterpret_cast<int32_t*>(r) + gl.off_vstart[k];
+            if (!g.present) continue;  // zeros: every env has an empty range
+            const int pb = g.env_off[std::min(E, e0)];
+            for (int el = 0; el <= epb; ++el) pstart[el] = g.env_off[std::min(E, e0 + el)] - pb;
+            const int np = pstart[epb];
+            const int vb = g.vert_off[pb];
+            for (int q = 0; q <= np; ++q) vstart[q] = g.vert_off[pb + q] - vb;
+            float* bb = reinterpret_cast<float*>(r) + gl.off_aabb[k];
+            float* xy = reinterpret_cast<float*>(r) + gl.off_xy[k];
+            memcpy(bb, g.aabb.data() + 4 * (size_t)pb, sizeof(float) * 4 * np);
+            memcpy(xy, g.xy.data() + 2 * (size_t)vb, sizeof(float) * 2 * vstart[np]);
+        }
+    }
+    int rc = dev_replace(p, &p->d_geo, rec.data(), rec.size());
+    if (rc != T2D_OK) return rc;
+    p->v.geo = p->d_geo;
+    p->v.geo_layout = gl;
     return T2D_OK;
 }
 
@@ -234,6 +311,9 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
     v.params = p->d_params;
     v.cell = 1.0;
     v.inv_cell = 1.0;
+    v.geo = nullptr;
+    v.geo_layout = t2d::GeoLayout{};
+    v.geo_layout.epb = 256 >> log2_pad(max_agents);
     // ParkingEnv defaults: envs/parking.py:106 (max_step 2e4), :151-163 (reward table)
     p->status_cfg = t2d_status_config{20000, 0, 0, 0, -5.0f, -1.0f, -5.0f, 5.0f, 0.001f};
     *out_pool = p;
@@ -245,9 +325,8 @@ int t2d_destroy(t2d_pool* p) {
     (void)hipSetDevice(p->device);
     for (int f = 0; f < T2D_F_COUNT; ++f)
         if (p->field_ptr[f]) (void)hipFree(p->field_ptr[f]);
-    void* bufs[] = {p->d_params, p->d_env_poly_off, p->d_poly_vert_off, p->d_poly_xy, p->d_poly_aabb,
-                    p->d_boundary, p->d_boundary_valid, p->d_env_lane_off, p->d_lane_vert_off,
-                    p->d_lane_xy, p->d_lane_aabb, p->d_snap[0], p->d_snap[1], p->d_snap[2],
+    void* bufs[] = {p->d_params, p->d_geo, p->d_boundary, p->d_boundary_valid,
+                    p->d_snap[0], p->d_snap[1], p->d_snap[2],
                     p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -297,24 +376,18 @@ int t2d_set_static_geometry(t2d_pool* p, const int32_t* env_poly_offsets,
                             const float* boundary, const uint8_t* boundary_valid) {
     if (!p) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, hipDeviceSynchronize());
     const int E = p->v.n_env;
     int rc;
     if (env_poly_offsets) {
         if (!poly_vert_offsets || (!verts_xy && env_poly_offsets[E] > 0))
             return fail(p, T2D_ERR_INVALID, "polygon CSR arrays missing");
-        std::vector<double> xy, bb;
-        if ((rc = prepare_polys(p, env_poly_offsets, poly_vert_offsets, verts_xy, xy, bb,
-                                &p->geo_max[0], &p->geo_max[1])) != T2D_OK)
+        if ((rc = prepare_polys(p, env_poly_offsets, poly_vert_offsets, verts_xy, p->hgeo[0])) != T2D_OK)
             return rc;
-        const int P = env_poly_offsets[E];
-        if ((rc = dev_replace(p, &p->d_env_poly_off, env_poly_offsets, (size_t)E + 1))) return rc;
-        if ((rc = dev_replace(p, &p->d_poly_vert_off, poly_vert_offsets, (size_t)P + 1))) return rc;
-        if ((rc = dev_replace(p, &p->d_poly_xy, xy.data(), xy.size()))) return rc;
-        if ((rc = dev_replace(p, &p->d_poly_aabb, bb.data(), bb.size()))) return rc;
     } else {
-        if ((rc = dev_replace<int32_t>(p, &p->d_env_poly_off, nullptr, 0))) return rc;
-        p->geo_max[0] = p->geo_max[1] = 0;
+        p->hgeo[0] = t2d_pool::HostGeo{};
     }
+    if ((rc = rebuild_geo(p)) != T2D_OK) return rc;
     if (boundary) {
         if ((rc = dev_replace(p, &p->d_boundary, boundary, (size_t)4 * E))) return rc;
         if ((rc = dev_replace(p, &p->d_boundary_valid, boundary_valid, boundary_valid ? (size_t)E : 0)))
@@ -323,10 +396,6 @@ int t2d_set_static_geometry(t2d_pool* p, const int32_t* env_poly_offsets,
         if ((rc = dev_replace<float>(p, &p->d_boundary, nullptr, 0))) return rc;
         if ((rc = dev_replace<uint8_t>(p, &p->d_boundary_valid, nullptr, 0))) return rc;
     }
-    p->v.env_poly_off = p->d_env_poly_off;
-    p->v.poly_vert_off = p->d_poly_vert_off;
-    p->v.poly_xy = p->d_poly_xy;
-    p->v.poly_aabb = p->d_poly_aabb;
     p->v.boundary = p->d_boundary;
     p->v.boundary_valid = p->d_boundary_valid;
     return T2D_OK;
@@ -336,29 +405,18 @@ int t2d_set_lane_geometry(t2d_pool* p, const int32_t* env_lane_offsets,
                           const int32_t* lane_vert_offsets, const float* verts_xy) {
     if (!p) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, hipDeviceSynchronize());
     const int E = p->v.n_env;
     int rc;
     if (env_lane_offsets) {
         if (!lane_vert_offsets || (!verts_xy && env_lane_offsets[E] > 0))
             return fail(p, T2D_ERR_INVALID, "lane CSR arrays missing");
-        std::vector<double> xy, bb;
-        if ((rc = prepare_polys(p, env_lane_offsets, lane_vert_offsets, verts_xy, xy, bb,
-                                &p->geo_max[2], &p->geo_max[3])) != T2D_OK)
+        if ((rc = prepare_polys(p, env_lane_offsets, lane_vert_offsets, verts_xy, p->hgeo[1])) != T2D_OK)
             return rc;
-        const int P = env_lane_offsets[E];
-        if ((rc = dev_replace(p, &p->d_env_lane_off, env_lane_offsets, (size_t)E + 1))) return rc;
-        if ((rc = dev_replace(p, &p->d_lane_vert_off, lane_vert_offsets, (size_t)P + 1))) return rc;
-        if ((rc = dev_replace(p, &p->d_lane_xy, xy.data(), xy.size()))) return rc;
-        if ((rc = dev_replace(p, &p->d_lane_aabb, bb.data(), bb.size()))) return rc;
     } else {
-        if ((rc = dev_replace<int32_t>(p, &p->d_env_lane_off, nullptr, 0))) return rc;
-        p->geo_max[2] = p->geo_max[3] = 0;
+        p->hgeo[1] = t2d_pool::HostGeo{};
     }
-    p->v.env_lane_off = p->d_env_lane_off;
-    p->v.lane_vert_off = p->d_lane_vert_off;
-    p->v.lane_xy = p->d_lane_xy;
-    p->v.lane_aabb = p->d_lane_aabb;
-    return T2D_OK;
+    return rebuild_geo(p);
 }
 
 int t2d_set_status_config(t2d_pool* p, const t2d_status_config* cfg) {
@@ -466,7 +524,7 @@ int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
 static int collide_impl(t2d_pool* p, bool with_status, int interval_ms, hipStream_t s) {
     int rc;
     if ((rc = record_event(p, 1, s, true))) return rc;
-    T2D_HIP(p, t2d::launch_collide(p->v, p->status_cfg, with_status, interval_ms, p->geo_max, s));
+    T2D_HIP(p, t2d::launch_collide(p->v, p->status_cfg, with_status, interval_ms, s));
     return record_event(p, 1, s, false);
 }
 

@@ -285,7 +285,12 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(PoolView pv, int inte
         fa0 = pv.act0[i];
         fa1 = pv.act1[i];
     }
-    for (int k = tid; k < T2D_PARAM_COLS * T2D_MAX_TYPES; k += kBlock) s_par[k] = pv.params[k];
+    // table staging: all three 8-B loads per thread in flight together (one exposed latency)
+    static_assert(T2D_PARAM_COLS * T2D_MAX_TYPES == 3 * kBlock, "staging assumes 3 loads per thread");
+    const double t0 = pv.params[tid], t1 = pv.params[tid + kBlock], t2 = pv.params[tid + 2 * kBlock];
+    s_par[tid] = t0;
+    s_par[tid + kBlock] = t1;
+    s_par[tid + 2 * kBlock] = t2;
     __syncthreads();
 
     const bool active = in_range && ((ids >> kIdsActiveShift) & 0xffu);

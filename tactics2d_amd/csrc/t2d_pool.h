@@ -15,10 +15,26 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/t2d.h"
 
 namespace t2d {
+
+// Packed geometry record of one collide workgroup (EPB consecutive envs), all dwords, kind k =
+// 0 static obstacles / 1 lanes:
+//   pstart[k][EPB+1]   first polygon of each env inside the record (int)
+//   vstart[k][MP_k+1]  first vertex of each polygon inside the record (int)
+//   aabb[k][MP_k]      xmin, xmax, ymin, ymax (fp32, exact: vertices are fp32)
+//   xy[k][MV_k]        CCW vertices x, y (fp32)
+// MP_k / MV_k = largest polygon / vertex count of any workgroup; stride is a multiple of 4
+// dwords so records are copied to LDS with 16-B loads.
+struct GeoLayout {
+    int32_t stride;          // dwords per record (0 when there is no geometry)
+    int32_t epb;             // environments per collide workgroup
+    int32_t has[2];
+    int32_t off_pstart[2], off_vstart[2], off_aabb[2], off_xy[2];  // dword offsets
+};
 
 // What kernels receive by value.
 struct PoolView {
@@ -30,17 +46,11 @@ struct PoolView {
     float* reward;
     const double* params;  // [T2D_PARAM_COLS][T2D_MAX_TYPES]
     int32_t n_types;
-    // static geometry
-    const int32_t* env_poly_off;   // [E+1] or null
-    const int32_t* poly_vert_off;  // [P+1]
-    const double* poly_xy;         // [2*V] CCW
-    const double* poly_aabb;       // [4*P] xmin, xmax, ymin, ymax
+    // static + lane geometry: one fixed-stride packed record per collide workgroup (see GeoLayout)
+    const uint32_t* geo;           // [n_blocks * stride] dwords or null
+    GeoLayout geo_layout;
     const float* boundary;         // [4*E] or null
     const uint8_t* boundary_valid; // [E] or null
-    const int32_t* env_lane_off;   // [E+1] or null
-    const int32_t* lane_vert_off;
-    const double* lane_xy;
-    const double* lane_aabb;
     double cell;      // spatial-hash cell edge (m) >= max circum-diameter * 1.001
     double inv_cell;
 };
@@ -64,16 +74,18 @@ struct t2d_pool {
     void* field_ptr[T2D_F_COUNT]{};
     size_t field_bytes[T2D_F_COUNT]{};
     double* d_params = nullptr;
-    int32_t *d_env_poly_off = nullptr, *d_poly_vert_off = nullptr;
-    double *d_poly_xy = nullptr, *d_poly_aabb = nullptr;
+    uint32_t* d_geo = nullptr;
     float* d_boundary = nullptr;
     uint8_t* d_boundary_valid = nullptr;
-    int32_t *d_env_lane_off = nullptr, *d_lane_vert_off = nullptr;
-    double *d_lane_xy = nullptr, *d_lane_aabb = nullptr;
+    // host copies of the CCW-normalised CSR geometry, kind 0 static / 1 lanes
+    struct HostGeo {
+        bool present = false;
+        std::vector<int32_t> env_off, vert_off;
+        std::vector<float> xy, aabb;
+    } hgeo[2];
     float* d_snap[6]{};      // x, y, heading, speed, vx, vy at episode start
     uint32_t* d_snap_ids = nullptr;
     bool have_snapshot = false;
-    int geo_max[4]{};  // max polys/env, max poly verts/env, max lanes/env, max lane verts/env
     // profiling
     bool profiling = false;
     static constexpr int kMaxProfSteps = 4096;
@@ -86,7 +98,7 @@ struct t2d_pool {
 namespace t2d {
 hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hipStream_t s);
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
-                          int interval_ms, const int* geo_max, hipStream_t s);
+                          int interval_ms, hipStream_t s);
 hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
                           hipStream_t s);
 }  // namespace t2d
