@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libt2d_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("T2D_LIB_NAME", "libt2d_hip.so"))
 
 OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_GEOMETRY = 0, 1, 2, 3, 4, 5
 

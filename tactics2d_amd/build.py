@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libt2d_hip.so")
+LIB = os.path.join(HERE, os.environ.get("T2D_LIB_NAME", "libt2d_hip.so"))
 SOURCES = ["t2d_api.hip", "t2d_integrate.hip", "t2d_collide.hip"]
 HEADERS = ["t2d_math.h", "t2d_pool.h", os.path.join("..", "..", "include", "t2d.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -30,7 +30,8 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+    extra = os.environ.get("T2D_EXTRA_FLAGS", "").split()
+    cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

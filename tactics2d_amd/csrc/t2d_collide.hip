@@ -39,6 +39,12 @@ namespace t2d {
 
 namespace {
 
+#ifndef T2D_ABLATE
+#define T2D_ABLATE 0  // profiling builds: 1 no lanes, 2 no narrow phase, 4 no broad phase, 8 no static
+#endif
+#ifndef T2D_COLLIDE_WAVES
+#define T2D_COLLIDE_WAVES 4  // min waves / SIMD the register allocator must allow
+#endif
 constexpr int kBlock = 256;
 constexpr int kMaxHeads = 512;  // EPB * H for A_pad >= 8
 constexpr double kRejectMargin = 1e-6;
@@ -142,12 +148,80 @@ T2D_DEV bool circle_vs_convex(double cx, double cy, double R, const RegPoly<MAXN
     return hit;
 }
 
+// ---- streaming variants for the rare 5..8-vertex polygons: vertices are re-read from LDS instead
+// of being held in 32 VGPRs, which keeps the kernel at 4 waves / SIMD.  Same predicates.
+struct PolyLds {
+    const float2* q;
+    int n;
+    T2D_DEV void get(int j, double& x, double& y) const {
+        const float2 v = q[j];
+        x = (double)v.x;
+        y = (double)v.y;
+    }
+};
+
+T2D_DEV bool sat_obb_stream(const double (&ax)[4], const double (&ay)[4], const PolyLds& B) {
+    // pass 1: every B vertex against the 4 edges of A (one LDS read per vertex, branch-free)
+    bool out0 = true, out1 = true, out2 = true, out3 = true;
+    for (int j = 0; j < B.n; ++j) {
+        double rx, ry;
+        B.get(j, rx, ry);
+        out0 &= orient(ax[0], ay[0], ax[1], ay[1], rx, ry) < 0.0;
+        out1 &= orient(ax[1], ay[1], ax[2], ay[2], rx, ry) < 0.0;
+        out2 &= orient(ax[2], ay[2], ax[3], ay[3], rx, ry) < 0.0;
+        out3 &= orient(ax[3], ay[3], ax[0], ay[0], rx, ry) < 0.0;
+    }
+    if (out0 | out1 | out2 | out3) return false;
+    // pass 2: every edge of B against the 4 vertices of A (vertex carried between iterations)
+    double px, py;
+    B.get(B.n - 1, px, py);
+    bool sep = false;
+    for (int j = 0; j < B.n; ++j) {
+        double qx, qy;
+        B.get(j, qx, qy);
+        bool all_out = true;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) all_out &= orient(px, py, qx, qy, ax[i], ay[i]) < 0.0;
+        sep |= all_out;
+        px = qx;
+        py = qy;
+    }
+    return !sep;
+}
+
+T2D_DEV bool point_in_convex_stream(const PolyLds& B, double x, double y) {
+    bool in = true;
+    double px, py;
+    B.get(B.n - 1, px, py);
+    for (int j = 0; j < B.n; ++j) {
+        double qx, qy;
+        B.get(j, qx, qy);
+        in &= !(orient(px, py, qx, qy, x, y) < 0.0);
+        px = qx;
+        py = qy;
+    }
+    return in;
+}
+
+T2D_DEV bool circle_vs_convex_stream(double cx, double cy, double R, const PolyLds& B) {
+    if (point_in_convex_stream(B, cx, cy)) return true;
+    const double R2 = R * R;
+    bool hit = false;
+    for (int j = 0; j < B.n; ++j) {
+        double px, py, qx, qy;
+        B.get(j, px, py);
+        B.get(j + 1 == B.n ? 0 : j + 1, qx, qy);
+        hit |= seg_dist2(px, py, qx, qy, cx, cy) <= R2;
+    }
+    return hit;
+}
+
 T2D_DEV uint32_t cell_hash(int cx, int cy) {
     return ((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u);
 }
 
 template <bool WITH_STATUS>
-__global__ __launch_bounds__(kBlock) void collide_kernel(PoolView pv, t2d_status_config cfg,
+__global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv, t2d_status_config cfg,
                                                          int interval_ms, int log2A) {
     __shared__ double s_v[8][kBlock];   // OBB vertex coordinate planes x0,y0,...,x3,y3
     __shared__ double s_c[3][kBlock];   // centre x, centre y, bounding radius
@@ -285,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void collide_kernel(PoolView pv, t2d_status
     // (inactive ones publish a negative radius) because shuffles read from executing lanes only.
     unsigned long long cand = 0ull;
     const float R32 = active ? (float)R + 5e-3f : -1.0f;
-    if (!use_hash_grid) {
+    if (!use_hash_grid && !(T2D_ABLATE & 4)) {
         const int seg0 = (tid & 63) & ~(A_pad - 1);  // first lane of my env inside the wave
         for (int a = 0; a < A_pad; ++a) {
             const float ox = __shfl(fx, seg0 + a), oy = __shfl(fy, seg0 + a), oR = __shfl(R32, seg0 + a);
@@ -315,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void collide_kernel(PoolView pv, t2d_status
             while (cand != 0ull && !hit) {
                 const int a = __ffsll((long long)cand) - 1;
                 cand &= cand - 1ull;
-                hit = test_shapes(j0 + a);
+                hit = (T2D_ABLATE & 2) ? false : test_shapes(j0 + a);
             }
         } else {
             for (int oy_ = -1; oy_ <= 1 && !hit; ++oy_)
@@ -340,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void collide_kernel(PoolView pv, t2d_status
         // ---- participant vs static polygons ----------------------------------------------
         // pass 1 (branch-free, loads pipeline): bit mask of polygons whose box is within reach
         // of the bounding circle; pass 2: exact test on the survivors only.
-        if (gl.has[0]) {
+        if (gl.has[0] && !(T2D_ABLATE & 8)) {
             const int* vstart = reinterpret_cast<const int*>(s_geo) + gl.off_vstart[0];
             const float4* bb = reinterpret_cast<const float4*>(s_geo + gl.off_aabb[0]);
             const float* xy = reinterpret_cast<const float*>(s_geo + gl.off_xy[0]);
@@ -362,8 +436,8 @@ __global__ __launch_bounds__(kBlock) void collide_kernel(PoolView pv, t2d_status
                         const RegPoly<4> B = load_poly_f32<4>(xy + 2 * v0, n);
                         shit = kind == T2D_SHAPE_OBB ? sat_obb(ax, ay, B) : circle_vs_convex(cx, cy, rad, B, n);
                     } else {
-                        const RegPoly<8> B = load_poly_f32<8>(xy + 2 * v0, n);
-                        shit = kind == T2D_SHAPE_OBB ? sat_obb(ax, ay, B) : circle_vs_convex(cx, cy, rad, B, n);
+                        const PolyLds B{reinterpret_cast<const float2*>(xy + 2 * v0), n};
+                        shit = kind == T2D_SHAPE_OBB ? sat_obb_stream(ax, ay, B) : circle_vs_convex_stream(cx, cy, rad, B);
                     }
                 }
             }
@@ -385,7 +459,7 @@ __global__ __launch_bounds__(kBlock) void collide_kernel(PoolView pv, t2d_status
         }
 
         // ---- lanes (build-defined): some pose vertex lies in no lane polygon -------------
-        if (gl.has[1]) {
+        if (gl.has[1] && !(T2D_ABLATE & 1)) {
             const int p0 = pstart1[env_local], p1 = pstart1[env_local + 1];
             if (p1 > p0) {
                 const int* vstart = reinterpret_cast<const int*>(s_geo) + gl.off_vstart[1];
@@ -426,10 +500,10 @@ __global__ __launch_bounds__(kBlock) void collide_kernel(PoolView pv, t2d_status
                             for (int k = 0; k < 4; ++k)
                                 if (k < nv && !(inside >> k & 1u) && point_in_convex(B, qx[k], qy[k])) inside |= 1u << k;
                         } else {
-                            const RegPoly<8> B = load_poly_f32<8>(xy + 2 * v0, n);
+                            const PolyLds B{reinterpret_cast<const float2*>(xy + 2 * v0), n};
 #pragma unroll
                             for (int k = 0; k < 4; ++k)
-                                if (k < nv && !(inside >> k & 1u) && point_in_convex(B, qx[k], qy[k])) inside |= 1u << k;
+                                if (k < nv && !(inside >> k & 1u) && point_in_convex_stream(B, qx[k], qy[k])) inside |= 1u << k;
                         }
                     }
                 }

@@ -38,16 +38,16 @@ struct StepOut {
     bool has_velocity;
 };
 
-// rotate (c, s) by angle eps, |eps| <= 0.25
+constexpr double kEpsMax = 0.1;  // largest sub-step angle the Taylor rotation accepts
+
+// rotate (c, s) by angle eps, |eps| <= kEpsMax: sin to e^7, cos to e^8 (truncation < 3e-15)
 T2D_DEV void rotate_small(double eps, double& c, double& s) {
     double e2 = eps * eps;
-    double ps = __builtin_fma(e2, 1.0 / 362880.0, -1.0 / 5040.0);
-    ps = __builtin_fma(e2, ps, 1.0 / 120.0);
+    double ps = __builtin_fma(e2, -1.0 / 5040.0, 1.0 / 120.0);
     ps = __builtin_fma(e2, ps, -1.0 / 6.0);
     ps = __builtin_fma(e2, ps, 1.0);
     double se = eps * ps;
-    double pc = __builtin_fma(e2, -1.0 / 3628800.0, 1.0 / 40320.0);
-    pc = __builtin_fma(e2, pc, -1.0 / 720.0);
+    double pc = __builtin_fma(e2, 1.0 / 40320.0, -1.0 / 720.0);
     pc = __builtin_fma(e2, pc, 1.0 / 24.0);
     pc = __builtin_fma(e2, pc, -0.5);
     double ce = __builtin_fma(e2, pc, 1.0);
@@ -55,6 +55,30 @@ T2D_DEV void rotate_small(double eps, double& c, double& s) {
     double sn = __builtin_fma(s, ce, c * se);
     c = cn;
     s = sn;
+}
+
+// 1/x to ~1 ulp: hardware estimate + two Newton steps (fast variant only; the exact variant
+// uses IEEE division).  x must be normal and finite.
+T2D_DEV double rcp_nr(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+// 1/sqrt(x) to ~1 ulp, x > 0 normal
+T2D_DEV double rsq_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double h = 0.5 * x;
+    y = y * __builtin_fma(-h, y * y, 1.5);
+    return y * __builtin_fma(-h, y * y, 1.5);
+}
+// a / b given r ~ 1/b: one residual correction makes the quotient correctly rounded except in
+// vanishingly rare cases (Markstein); b normal, quotient finite
+T2D_DEV double div_r(double a, double b, double r) {
+    double q = a * r;
+    double rem = __builtin_fma(-q, b, a);
+    return __builtin_fma(rem, r, q);
 }
 
 template <int VARIANT, typename PF>
@@ -70,11 +94,11 @@ T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, 
     const double dt = (double)delta_t / 1000;
     const int n_steps = interval / delta_t;
     const int rem = interval - n_steps * delta_t;
-    const double tand = tan_det(delta);
-    const double t = lr / wb * tand;
     const int total = n_steps + (rem > 0 ? 1 : 0);
     StepOut o;
     if (VARIANT == 0) {
+        const double tand = tan_det(delta);
+        const double t = lr / wb * tand;
         const double beta = atan_det(t);
         double sb, cb;
         sincos_det(beta, sb, cb);
@@ -96,23 +120,27 @@ T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, 
         o.vx = v * cp;
         o.vy = v * sp;
     } else {
+        double sd, cd;
+        sincos_det(delta, sd, cd);
+        const double tw = sd * rcp_nr(cd * wb);  // tan(delta) / wb
+        const double t = lr * tw;                // tan(beta)
         // cos(beta) = 1/sqrt(1+t^2), sin(beta) = t*cos(beta): no atan needed
-        const double cb = 1.0 / __builtin_sqrt(__builtin_fma(t, t, 1.0));
+        const double cb = rsq_nr(__builtin_fma(t, t, 1.0));
         const double sb = t * cb;
         double sp, cp;
         sincos_det(phi, sp, cp);
         double c = cp * cb - sp * sb;  // cos(phi + beta)
         double s = sp * cb + cp * sb;
-        const double kk = tand * cb / wb;
-        for (int k = 0; k < total; ++k) {
-            double h = k < n_steps ? dt : (double)rem / 1000;
-            double eps = (v * kk) * h;
-            x += (v * c) * h;
-            y += (v * s) * h;
+        const double kk = tw * cb;  // d(phi)/dt = v * kk
+        auto sub_step = [&](double h, double ah, double kh) {
+            const double eps = v * kh;  // d(phi) of this sub-step
+            const double vh = v * h;
+            x = __builtin_fma(vh, c, x);
+            y = __builtin_fma(vh, s, y);
             phi += eps;
-            v += accel * h;
-            if (clip_v) v = clipd(v, vlo, vhi);
-            if (__builtin_fabs(eps) <= 0.25) {
+            v += ah;
+            if (clip_v) v = __builtin_fmin(__builtin_fmax(v, vlo), vhi);
+            if (__builtin_fabs(eps) <= kEpsMax) {
                 rotate_small(eps, c, s);
             } else {  // absurd yaw rates (unbounded speed): re-seed from phi
                 double s2, c2;
@@ -120,6 +148,12 @@ T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, 
                 c = c2 * cb - s2 * sb;
                 s = s2 * cb + c2 * sb;
             }
+        };
+        const double ah = accel * dt, kh = kk * dt;
+        for (int k = 0; k < n_steps; ++k) sub_step(dt, ah, kh);
+        if (rem > 0) {
+            const double hr = (double)rem / 1000;
+            sub_step(hr, accel * hr, kk * hr);
         }
         // cos(phi) = cos((phi+beta) - beta)
         o.vx = v * (c * cb + s * sb);
@@ -167,41 +201,73 @@ T2D_DEV StepOut step_dynamics(PF P, double x, double y, double phi, double v, do
     double d_phi = v / wb * tand;
     double beta = atan_det(lr / lf * tand);
 
-    // low-speed branch constants (only evaluated when some sub-step has |v| < 0.1)
-    double c, s;
-    if (VARIANT == 1) sincos_det(phi + beta, s, c);
-
-    for (int k = 0; k < n_steps; ++k) {
-        if (VARIANT == 0) sincos_det(phi + beta, s, c);
-        double dx = v * c;
-        double dy = v * s;
-        double av = __builtin_fabs(v);
-        double v_safe = av > 1e-6 ? v : (v >= 0 ? 1e-6 : -1e-6);
-        double d_beta;
-        if (av >= 0.1) {
-            double dd_phi = mmi * (lf_cf_ff * delta + k21 * beta - k34 * d_phi / v_safe);
-            d_beta = mu / v_safe * (cf_ff * delta - k65 * beta + k21 * d_phi / v_safe) - d_phi;
-            d_phi += dd_phi * dt;
-        } else {
-            double tb = 1 + tand * lr / wb;
-            double sd, cd;
-            sincos_det(delta, sd, cd);
-            d_beta = lr / (tb * tb) / wb / (cd * cd) * delta;
-            double sbt, cbt;
-            sincos_det(beta, sbt, cbt);
-            d_phi += v * cbt / wb * tand * dt;
+    if (VARIANT == 0) {
+        for (int k = 0; k < n_steps; ++k) {
+            double s, c;
+            sincos_det(phi + beta, s, c);
+            double dx = v * c;
+            double dy = v * s;
+            double av = __builtin_fabs(v);
+            double v_safe = av > 1e-6 ? v : (v >= 0 ? 1e-6 : -1e-6);
+            double d_beta;
+            if (av >= 0.1) {
+                double dd_phi = mmi * (lf_cf_ff * delta + k21 * beta - k34 * d_phi / v_safe);
+                d_beta = mu / v_safe * (cf_ff * delta - k65 * beta + k21 * d_phi / v_safe) - d_phi;
+                d_phi += dd_phi * dt;
+            } else {
+                double tb = 1 + tand * lr / wb;
+                double sd, cd;
+                sincos_det(delta, sd, cd);
+                d_beta = lr / (tb * tb) / wb / (cd * cd) * delta;
+                double sbt, cbt;
+                sincos_det(beta, sbt, cbt);
+                d_phi += v * cbt / wb * tand * dt;
+            }
+            x += dx * dt;
+            y += dy * dt;
+            v += accel * dt;
+            phi += d_phi * dt;
+            beta += d_beta * dt;
+            if (clip_v) v = clipd(v, vlo, vhi);
         }
-        x += dx * dt;
-        y += dy * dt;
-        v += accel * dt;
-        double e1 = d_phi * dt;
-        double e2 = d_beta * dt;
-        phi += e1;
-        beta += e2;
-        if (clip_v) v = clipd(v, vlo, vhi);
-        if (VARIANT == 1) {
-            double eps = e1 + e2;
-            if (__builtin_fabs(eps) <= 0.25) rotate_small(eps, c, s);
+    } else {
+        // Same recurrences; the three divisions by v_safe share one Newton reciprocal with a
+        // residual-corrected quotient, x / y use fma, cos/sin(phi + beta) a rotation recurrence.
+        double s, c;
+        sincos_det(phi + beta, s, c);
+        const double c1 = lf_cf_ff * delta, c2 = cf_ff * delta, ah = accel * dt;
+        for (int k = 0; k < n_steps; ++k) {
+            const double vh = v * dt;
+            x = __builtin_fma(vh, c, x);
+            y = __builtin_fma(vh, s, y);
+            const double av = __builtin_fabs(v);
+            const double v_safe = av > 1e-6 ? v : (v >= 0 ? 1e-6 : -1e-6);
+            double d_beta;
+            if (av >= 0.1) {
+                const double r = rcp_nr(v_safe);
+                const double q1 = div_r(k34 * d_phi, v_safe, r);
+                const double q2 = div_r(mu, v_safe, r);
+                const double q3 = div_r(k21 * d_phi, v_safe, r);
+                const double dd_phi = mmi * (c1 + k21 * beta - q1);
+                d_beta = q2 * (c2 - k65 * beta + q3) - d_phi;
+                d_phi += dd_phi * dt;
+            } else {
+                double tb = 1 + tand * lr / wb;
+                double sd, cd;
+                sincos_det(delta, sd, cd);
+                d_beta = lr / (tb * tb) / wb / (cd * cd) * delta;
+                double sbt, cbt;
+                sincos_det(beta, sbt, cbt);
+                d_phi += v * cbt / wb * tand * dt;
+            }
+            v += ah;
+            const double e1 = d_phi * dt;
+            const double e2 = d_beta * dt;
+            phi += e1;
+            beta += e2;
+            if (clip_v) v = __builtin_fmin(__builtin_fmax(v, vlo), vhi);
+            const double eps = e1 + e2;
+            if (__builtin_fabs(eps) <= kEpsMax) rotate_small(eps, c, s);
             else sincos_det(phi + beta, s, c);
         }
     }

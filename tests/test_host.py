@@ -1,0 +1,113 @@
+"""Host-side logic that mirrors the reference's Python API (no GPU needed)."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+def test_constructor_normalisation_matches_reference():
+    """Ranges / delta_t are normalised exactly like the reference constructors
+    (single_track_kinematics.py:87-124, single_track_dynamics.py:101-138, point_mass.py:50-75):
+    rows built from reference objects by oracle/gen_golden.py vs rows built by our classes."""
+    from tactics2d_amd.physics import PointMass, SingleTrackDynamics, SingleTrackKinematics
+    cases = H.load_json("ctor_rows.json")
+    assert len(cases) >= 60
+    for c in cases:
+        ra = tuple(c["range"]) if isinstance(c["range"], list) else c["range"]
+        k = SingleTrackKinematics(1.2, 1.3, ra, ra, ra, c["interval"], c["delta_t"]).param_row()
+        d = SingleTrackDynamics(1.2, 1.3, 1500.0, 0.7, steer_range=ra, speed_range=ra, accel_range=ra,
+                                interval=c["interval"], delta_t=c["delta_t"]).param_row()
+        p = PointMass(ra, ra, c["interval"], c["delta_t"]).param_row(0, 0.0, 0.0)
+        assert np.array_equal(k, np.array(c["kin"])), (c["range"], c["delta_t"])
+        assert np.array_equal(d, np.array(c["dyn"])), (c["range"], c["delta_t"])
+        assert np.array_equal(p, np.array(c["pm"])), (c["range"], c["delta_t"])
+
+
+def test_int_range_means_unbounded_for_vehicle_models():
+    """Reference quirk: isinstance(5, float) is False -> speed_range=5 silently means 'no limit'."""
+    from tactics2d_amd.physics import PointMass, SingleTrackKinematics
+    assert SingleTrackKinematics(1.0, 1.0, speed_range=5).speed_range is None
+    assert SingleTrackKinematics(1.0, 1.0, speed_range=5.0).speed_range == [-5.0, 5.0]
+    assert PointMass(speed_range=(-7, 7)).speed_range == [0, 7]
+
+
+def test_template_rows_reproduce_survey_appendix_b():
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.participant import full_type_table, vehicle_row
+    r = vehicle_row("medium_car", "kinematics")
+    assert r[L.P_LF] == 4.284 / 2 - 0.880 and r[L.P_LR] == 4.284 / 2 - 0.767
+    assert abs(r[L.P_WB] - 2.637) < 1e-12
+    assert (r[L.P_STEER_LO], r[L.P_STEER_HI]) == (-0.524, 0.524)
+    assert (r[L.P_SPEED_LO], r[L.P_SPEED_HI]) == (-16.67, 69.44)
+    assert (r[L.P_ACCEL_LO], r[L.P_ACCEL_HI]) == (-11.0, 3.121)
+    rows, names = full_type_table()
+    assert rows.shape == (25, 24) and len(set(names)) == 25
+    want_amax = dict(mini_car=1.929, small_car=2.480, medium_car=3.121, large_car=3.307, executive_car=3.429,
+                     luxury_car=4.146, sports_coupe=5.241, multi_purpose_car=2.955, sports_utility_car=7.310)
+    for n, a in want_amax.items():
+        assert rows[names.index(n + ":kin"), L.P_ACCEL_HI] == a
+        d = rows[names.index(n + ":dyn")]
+        assert d[L.P_MODEL] == L.MODEL_DYNAMICS and d[L.P_MU] == 0.7 and d[L.P_IZ] == 1500 and d[L.P_CF] == 20.89
+    ped = rows[names.index("adult_male")]
+    assert ped[L.P_MODEL] == L.MODEL_POINTMASS and ped[L.P_SHAPE] == L.SHAPE_CIRCLE
+    assert (ped[L.P_SPEED_LO], ped[L.P_SPEED_HI]) == (0, 7.0) and ped[L.P_WIDTH] == 0.40
+    cyc = rows[names.index("cyclist")]
+    assert cyc[L.P_LF] == cyc[L.P_LR] == 0.9 and (cyc[L.P_SPEED_LO], cyc[L.P_SPEED_HI]) == (0, 22.78)
+
+
+def test_batched_state_derived_fields_follow_state_semantics():
+    """State.velocity / State.speed laziness (participant/trajectory/state.py:135-169)."""
+    from tactics2d_amd.physics import BatchedState
+    s = BatchedState(0, [1.0, 2.0], [0.0, 0.0], heading=[0.0, np.pi / 2], speed=[2.0, 3.0])
+    vx, vy = s.velocity
+    assert np.allclose(vx, [2.0, 0.0], atol=1e-6) and np.allclose(vy, [0.0, 3.0], atol=1e-6)
+    s2 = BatchedState(0, [0.0], [0.0], vx=[3.0], vy=[4.0])
+    assert s2.speed[0] == 5.0 and s2.velocity[0][0] == 3.0
+    assert BatchedState(0, [0.0], [0.0]).velocity is None
+
+
+@pytest.mark.parametrize("builder,kw", [("parking", dict(n_env=32)), ("highway", dict(n_env=6, A=64)),
+                                        ("intersection", dict(n_env=6, A=32)), ("mixed", dict(n_env=9, A=64))])
+def test_scenes_are_deterministic_valid_and_start_clean(oracle, builder, kw):
+    from tactics2d_amd import layout as L, scenarios as S
+    a = getattr(S, builder)(**kw); b = getattr(S, builder)(**kw)
+    for f in ("x", "y", "heading", "speed", "type_id"):
+        assert np.array_equal(getattr(a, f), getattr(b, f))
+    assert np.abs(a.x).max() < 256 and np.abs(a.y).max() < 256           # env-local coordinate contract
+    assert a.rows.shape[0] <= L.MAX_TYPES
+    for csr in (a.static, a.lanes):
+        if csr is None:
+            continue
+        eo, vo, xy = csr
+        for p in range(len(vo) - 1):
+            assert 3 <= vo[p + 1] - vo[p] <= L.MAX_POLY_VERTS
+            assert oracle.polygon_is_convex(xy[vo[p]:vo[p + 1]])
+    f, _ = oracle.collide(a.rows, a.n_env, a.A, a.x, a.y, a.heading, a.type_id, a.active, a.static,
+                          a.boundary, a.boundary_valid, a.lanes, 0)
+    veh = a.rows[a.type_id, L.P_SHAPE] == L.SHAPE_OBB
+    assert (f[veh] & (L.FLAG_COLLISION_DYNAMIC | L.FLAG_COLLISION_STATIC | L.FLAG_OUT_BOUND)).sum() == 0
+    assert (f[veh] & L.FLAG_OFF_LANE).mean() < 0.02
+
+
+def test_parking_scene_follows_the_reference_layout():
+    """cfg1/cfg2: 1 ego + 8 static quads, ParkingEnv ranges (envs/parking.py:318-327), boundary = start /
+    target -+ 13 m rounded outwards (generate_parking_lot.py:434-438)."""
+    from tactics2d_amd import layout as L, scenarios as S
+    sc = S.parking(16)
+    assert sc.A == 1 and (np.diff(sc.static[0]) == 8).all()
+    r = sc.rows[0]
+    assert (r[L.P_SPEED_LO], r[L.P_SPEED_HI], r[L.P_ACCEL_LO], r[L.P_ACCEL_HI]) == (-0.5, 0.5, -2.0, 2.0)
+    b = sc.boundary
+    assert (b == np.round(b)).all() and ((b[:, 1] - b[:, 0]) >= 26).all()
+    a0, a1 = sc.sample_actions(np.random.default_rng(0))
+    assert np.abs(a0).max() <= 2.0 and np.abs(a1).max() <= 0.524      # ParkingEnv action box
+
+
+def test_shard_ranges_cover_every_env_once():
+    from tactics2d_amd.dist import shard_range
+    for total, world in ((8192, 8), (4096, 3), (10, 4), (5, 8)):
+        got = [shard_range(total, r, world) for r in range(world)]
+        assert got[0][0] == 0 and got[-1][1] == total
+        assert all(got[i][1] == got[i + 1][0] for i in range(world - 1))
+        sizes = [hi - lo for lo, hi in got]
+        assert max(sizes) - min(sizes) <= 1

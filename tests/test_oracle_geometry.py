@@ -1,0 +1,121 @@
+"""The oracle's geometry / event predicates.  PARITY UNPINNED against the reference's engine
+(shapely/GEOS is not available and the reference's tests pin no predicate result); pinned instead
+by hand-derived KATs and an independent cross-check against matplotlib.path.  CPU only."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+def _scene_from_kat(k):
+    return dict(rows=np.array(k["rows"]), n_env=1, A=len(k["x"]), x=np.float32(k["x"]), y=np.float32(k["y"]),
+                heading=np.float32(k["heading"]), type_id=np.array(k["type_id"], np.uint8),
+                active=np.ones(len(k["x"]), np.uint8),
+                static=H.to_csr([[np.float32(q) for q in k["static"]]]) if k["static"] else None,
+                lanes=H.to_csr([[np.float32(q) for q in k["lanes"]]]) if k["lanes"] else None,
+                boundary=np.float32([k["boundary"]]) if k["boundary"] else None, boundary_valid=None)
+
+
+@pytest.mark.parametrize("trig", [0, 1])
+def test_hand_built_scene_kats(oracle, trig):
+    for k in H.load_json("geometry_kats.json")["scenes"]:
+        f, e = H.oracle_collide(oracle, _scene_from_kat(k), trig)
+        assert f.tolist() == k["flags"], (k["name"], f.tolist(), k["flags"])
+        assert e[0] == np.bitwise_or.reduce(np.array(k["flags"], np.uint32))
+
+
+def test_pairwise_kats_and_symmetry(oracle):
+    for p in H.load_json("geometry_kats.json")["pairs"]:
+        assert oracle.convex_intersects(p["A"], p["B"]) == p["intersects"], p["name"]
+        assert oracle.convex_intersects(p["B"], p["A"]) == p["intersects"], p["name"]
+
+
+def test_deterministic_sincos_is_within_one_ulp_of_numpy(oracle):
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.uniform(-7, 7, 4000), rng.uniform(-2000, 2000, 2000),
+                         np.float64(np.float32(rng.uniform(0, 2 * np.pi, 2000))), [0.0, np.pi / 2, np.pi, 2 * np.pi]])
+    worst = 0.0
+    for x in xs:
+        s, c = oracle.sincos(x)
+        worst = max(worst, abs(s - np.sin(x)) / np.spacing(abs(np.sin(x))), abs(c - np.cos(x)) / np.spacing(abs(np.cos(x))))
+    assert worst <= 1.0 + 1e-9, worst
+    assert oracle.sincos(0.0) == (0.0, 1.0)
+
+
+def test_pose_follows_the_reference_vertex_order_and_transform(oracle):
+    """vehicle.py:132-142 / :263-281: (+L/2,-W/2), (+L/2,+W/2), (-L/2,+W/2), (-L/2,-W/2), matrix
+    [cos, -sin, sin, cos, x, y]."""
+    x, y, h, L_, W_ = 3.0, -2.0, 0.7, 4.284, 1.799
+    v = oracle.pose_obb(x, y, h, L_, W_, trig=1)
+    base = np.array([[L_ / 2, -W_ / 2], [L_ / 2, W_ / 2], [-L_ / 2, W_ / 2], [-L_ / 2, -W_ / 2]])
+    want = np.stack([np.cos(h) * base[:, 0] - np.sin(h) * base[:, 1] + x,
+                     np.sin(h) * base[:, 0] + np.cos(h) * base[:, 1] + y], 1)
+    assert np.abs(v - want).max() < 1e-15
+    assert np.abs(oracle.pose_obb(x, y, h, L_, W_, trig=0) - want).max() < 1e-14
+    # counter-clockwise
+    area2 = sum(v[i, 0] * v[(i + 1) % 4, 1] - v[(i + 1) % 4, 0] * v[i, 1] for i in range(4))
+    assert area2 > 0
+
+
+def test_intersects_agrees_with_matplotlib_path(oracle):
+    """Independent, non-reference cross-check: matplotlib.path.Path.intersects_path(filled=True) has
+    closed-set overlap/containment semantics like shapely `intersects`.  Random
+    convex quads; pairs within 1e-9 of touching are excluded (different arithmetic there)."""
+    mpath = pytest.importorskip("matplotlib.path")
+    rng = np.random.default_rng(11)
+    n_checked = n_true = 0
+    for _ in range(1500):
+        A, B = H.random_quads(rng, 2, (-4, 4), (-4, 4), size=(1.5, 5.0))
+        A = np.float64(A); B = np.float64(B)
+        if not (oracle.polygon_is_convex(np.float32(A)) and oracle.polygon_is_convex(np.float32(B))):
+            continue
+
+        def ccw(P):
+            a2 = sum(P[i, 0] * P[(i + 1) % 4, 1] - P[(i + 1) % 4, 0] * P[i, 1] for i in range(4))
+            return P if a2 > 0 else P[::-1].copy()
+        A, B = ccw(A), ccw(B)
+        got = oracle.convex_intersects(A, B)
+        pa = mpath.Path(np.vstack([A, A[:1]]), closed=True); pb = mpath.Path(np.vstack([B, B[:1]]), closed=True)
+        want = bool(pa.intersects_path(pb, filled=True))
+        # robustness margin: shrink/grow B by 1e-7 must not flip the answer, else skip (near touching)
+        cB = B.mean(0)
+        g1 = oracle.convex_intersects(A, cB + (B - cB) * (1 + 1e-7)); g2 = oracle.convex_intersects(A, cB + (B - cB) * (1 - 1e-7))
+        if g1 != g2:
+            continue
+        n_checked += 1; n_true += got
+        assert got == want
+    assert n_checked > 1000 and 0.2 < n_true / n_checked < 0.9
+
+
+def test_flags_do_not_depend_on_libm_vs_deterministic_trig(oracle):
+    """The bit-exact flag definition uses the deterministic sin/cos; the reference would use numpy's.
+    Their vertices differ by <= 1 ulp, so flags agree on every random scene here."""
+    rng = np.random.default_rng(3)
+    diff = tot = 0
+    for (n_env, A, extent) in ((40, 64, (60.0, 16.0)), (60, 8, (20.0, 12.0)), (300, 1, (30.0, 20.0))):
+        sc = H.random_scene(rng, n_env, A, extent, n_static=6, n_lanes=3)
+        f0, _ = H.oracle_collide(oracle, sc, 0); f1, _ = H.oracle_collide(oracle, sc, 1)
+        diff += int((f0 != f1).sum()); tot += f0.size
+    assert diff == 0 and tot > 3000
+
+
+def test_convexity_check(oracle):
+    assert oracle.polygon_is_convex(np.float32([[0, 0], [2, 0], [2, 2], [0, 2]]))
+    assert oracle.polygon_is_convex(np.float32([[0, 2], [2, 2], [2, 0], [0, 0]]))        # clockwise is fine
+    assert not oracle.polygon_is_convex(np.float32([[0, 0], [4, 0], [1, 1], [0, 4]]))    # dart
+    assert not oracle.polygon_is_convex(np.float32([[0, 0], [1, 1], [2, 2]]))            # degenerate
+
+
+def test_status_priority_order(oracle):
+    """Early-return order of _ParkingScenarioManager.check_status (envs/parking.py:361-392)."""
+    from oracle.oracle import StatusConfig
+    cfg = StatusConfig(3, 0, 1, 1, -5.0, -1.0, -5.0, 5.0, 0.001)
+    flags = np.array([0, 4, 2, 1, 8, 4 | 2 | 1, 2 | 1], np.uint32)
+    cnt = np.zeros(7, np.int32); frame = np.zeros(7, np.int32)
+    st, rw = oracle.status(cfg, 7, 1, flags, 100, cnt, frame)
+    assert st[:, :2].tolist() == [[1, 1], [4, 1], [6, 3], [6, 4], [6, 6], [4, 1], [6, 3]]
+    assert st[:, 2].tolist() == [0] * 7 and st[:, 3].tolist() == [0, 1, 1, 1, 1, 1, 1]
+    assert rw[1] == -5 and rw[2] == -5 and abs(rw[0] + np.tanh(1 / 3) * 0.001) < 1e-9
+    cnt[:] = 3
+    st, rw = oracle.status(cfg, 7, 1, flags, 100, cnt, frame)   # cnt 4 > max_step 3: time exceed wins
+    assert (st[:, 0] == 3).all() and (rw == -1).all() and (cnt == 4).all() and (frame == 200).all()
