@@ -1,0 +1,27 @@
+"""Per-phase cycle breakdown of the collide kernel (profiling build with -DT2D_TIMING)."""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tactics2d_amd import _ffi, scenarios as S
+from tactics2d_amd.pool import ParticipantPool
+cfg = sys.argv[1] if len(sys.argv) > 1 else "metric"
+sc = {"metric": lambda: S.mixed(4096, 64, 3), "cfg3": lambda: S.highway(1024, 64), "cfg2": lambda: S.parking(4096)}[cfg]()
+pool = ParticipantPool(sc.n_env, sc.A); sc.load(pool)
+rng = np.random.default_rng(0)
+lib = _ffi.lib(); lib.t2d_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+log2A = int(np.ceil(np.log2(sc.A))); epb = 256 >> log2A
+n_blocks = (sc.n_env + epb - 1) // epb
+n_waves = n_blocks * 4
+buf = np.zeros(n_waves * 16, np.uint64)
+for k in range(60):
+    a0, a1 = sc.sample_actions(rng); pool.set_actions(a0, a1); pool.step(100); pool.restore(done_only=True)
+lib.t2d_debug_read(pool._h, buf.ctypes.data_as(C.c_void_p), buf.size)
+v = buf.reshape(n_waves, 16).astype(np.float64)
+names = ["0 load+stage+barrier(a)", "1 pose", "2 barrier(b)", "3 broad phase", "4 pair compaction+narrow", "5 static AABB pass",
+         "6 static narrow", "7 lane AABB pass", "8 lane narrow", "9 (loop exit)", "10 barrier(c)", "11 reduce+barrier(d)", "12 epilogue"]
+tot = v[:, :13].sum(1)
+print(cfg, "waves", n_waves, "mean ticks/wave", tot.mean(), "max", tot.max())
+for t in range(3 if cfg == "metric" else 1):
+    sel = (np.arange(n_waves) % 3 == t) if cfg == "metric" else np.ones(n_waves, bool)
+    print(" env type", t, "mean total", tot[sel].mean())
+    for k, n in enumerate(names): print(f"  {n:32s} {v[sel, k].mean():10.1f}  {100 * v[sel, k].mean() / tot[sel].mean():5.1f}%")

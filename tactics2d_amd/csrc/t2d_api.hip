@@ -311,6 +311,11 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
     v.params = p->d_params;
     v.cell = 1.0;
     v.inv_cell = 1.0;
+    v.dbg = nullptr;
+#ifdef T2D_TIMING
+    (void)hipMalloc((void**)&v.dbg, (size_t)(n_env + 64) * 16 * 4 * sizeof(unsigned long long));
+    (void)hipMemset(v.dbg, 0, (size_t)(n_env + 64) * 16 * 4 * sizeof(unsigned long long));
+#endif
     v.geo = nullptr;
     v.geo_layout = t2d::GeoLayout{};
     v.geo_layout.epb = 256 >> log2_pad(max_agents);
@@ -565,6 +570,16 @@ int t2d_restore(t2d_pool* p, int32_t mode, void* hip_stream) {
     T2D_HIP(p, t2d::launch_restore(p->v, p->d_snap, p->d_snap_ids, mode, (hipStream_t)hip_stream));
     return T2D_OK;
 }
+
+#ifdef T2D_TIMING
+// profiling builds only (not part of the ABI): read and clear the phase cycle accumulators
+int t2d_debug_read(t2d_pool* p, unsigned long long* out, size_t n_words) {
+    if (!p || !p->v.dbg) return T2D_ERR_INVALID;
+    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, hipMemcpy(out, p->v.dbg, n_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return T2D_OK;
+}
+#endif
 
 int t2d_get_field(t2d_pool* p, int32_t f, void** dev_ptr, size_t* nbytes) {
     if (!p) return T2D_ERR_INVALID;

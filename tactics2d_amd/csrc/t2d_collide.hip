@@ -17,21 +17,28 @@
 //   0. every global load of the workgroup is issued up front so only ONE memory latency is
 //      exposed: participant state, map boundary, the 4 shape columns of the type table, and the
 //      workgroup's packed static+lane geometry record (fixed stride, built once on the host at
-//      t2d_set_*_geometry: per-env polygon ranges, per-polygon vertex ranges, fp32 AABBs and
-//      CCW vertices) copied with 16-B loads straight into dynamic LDS.
+//      t2d_set_*_geometry) copied with 16-B loads straight into dynamic LDS.
 //   1. pose: deterministic fp64 sin/cos of the stored heading -> 4 OBB vertices (or circle),
-//      written to LDS as coordinate planes s_v[k][lane] (SoA: conflict-free gathers); each
-//      lane links itself into its env's uniform spatial-hash grid (cell >= largest
-//      circum-diameter, per-env bucket heads in LDS, atomicExch-built linked lists).
-//   2. each lane walks the 3x3 neighbouring cells, circle-rejects candidates with a 1e-6 m
-//      safety margin (never changes a result: intersecting shapes always pass) and runs the
-//      separating-axis test in fp64 on register-resident vertices -- strict separation, so
-//      touching counts, like shapely.  Static / lane polygons come from the LDS record.
-//   3. wave ballot -> LDS OR -> per-env flags; one lane per env runs the status epilogue.
+//      written to LDS as coordinate planes s_v[k][lane]; out-of-bound test; conservative fp32
+//      box of the pose.
+//   2. broad phase -> compacted work queues -> dense narrow phase, three times (participant
+//      pairs, static polygons, lane polygons):
+//        * pairs: envs that fit a wave (A_pad <= 64) compare bounding circles with cross-lane
+//          shuffles (fp32, 1 cm margin, no LDS traffic) and keep only partners j > i, so each
+//          unordered pair is tested once; larger envs walk an LDS spatial-hash grid (cell >=
+//          largest circum-diameter, atomicExch-built linked lists).
+//        * polygons: a branch-free AABB pass over the env's polygons in the LDS record.
+//      Survivors are compacted with a wave prefix sum into a per-wave LDS queue and processed
+//      one entry per lane -- dense lanes instead of per-lane divergent loops, and no register-
+//      resident per-participant state, which keeps the kernel at 4 waves / SIMD without spills.
+//      The narrow phase is the oracle's arithmetic: fp64 separating-axis test with strict
+//      separation (touching counts, like shapely), results OR-ed into LDS with atomics.
+//   3. per-env OR of the flags; one lane per env runs the status epilogue.
 //
 // Every predicate is the exact arithmetic of oracle/t2d_oracle.c (same operation order,
-// -ffp-contract=off, deterministic trig), so flags are bit-exact against the oracle.
-// Bound: LDS/latency + fp64 VALU (about 20 B of HBM per participant); see DESIGN.md.
+// -ffp-contract=off, deterministic trig); broad phases are strictly conservative, so flags are
+// bit-exact against the oracle's brute force.
+// Bound: fp64 VALU issue + LDS latency (about 20 B of HBM per participant); see DESIGN.md.
 #include "t2d_math.h"
 #include "t2d_pool.h"
 
@@ -39,14 +46,13 @@ namespace t2d {
 
 namespace {
 
-#ifndef T2D_ABLATE
-#define T2D_ABLATE 0  // profiling builds: 1 no lanes, 2 no narrow phase, 4 no broad phase, 8 no static
-#endif
 #ifndef T2D_COLLIDE_WAVES
 #define T2D_COLLIDE_WAVES 4  // min waves / SIMD the register allocator must allow
 #endif
 constexpr int kBlock = 256;
-constexpr int kMaxHeads = 512;  // EPB * H for A_pad >= 8
+constexpr int kWaves = kBlock / 64;
+constexpr int kQueueCap = 256;  // queue entries per wave per round
+constexpr int kMaxHeads = 512;  // EPB * H when the hash grid is in use (A_pad = 128 or 256)
 constexpr double kRejectMargin = 1e-6;
 
 T2D_DEV double orient(double px, double py, double qx, double qy, double rx, double ry) {
@@ -55,20 +61,18 @@ T2D_DEV double orient(double px, double py, double qx, double qy, double rx, dou
     return a * b - c * d;
 }
 
-// A convex polygon held in registers, padded to MAXN vertices by repeating vertex 0.  Padding
-// never changes a predicate: duplicate vertices repeat an existing test, and the padded edges
-// are zero-length (orientation 0: never separating, never "outside").
-template <int MAXN>
-struct RegPoly {
-    double x[MAXN], y[MAXN];
+// A convex quadrilateral (or triangle padded by repeating vertex 0) in registers.  Padding never
+// changes a predicate: duplicate vertices repeat an existing test, padded edges are zero-length
+// (orientation exactly 0: never separating, never "outside").
+struct Quad {
+    double x[4], y[4];
 };
 
-template <int MAXN>
-T2D_DEV RegPoly<MAXN> load_poly_f32(const float* p, int n) {  // interleaved x,y fp32 (LDS)
-    RegPoly<MAXN> r;
+T2D_DEV Quad load_quad_f32(const float* p, int n) {  // interleaved x,y fp32 in LDS, n = 3 or 4
+    Quad r;
     const float2* q = reinterpret_cast<const float2*>(p);
 #pragma unroll
-    for (int j = 0; j < MAXN; ++j) {
+    for (int j = 0; j < 4; ++j) {
         const float2 v = q[j < n ? j : 0];
         r.x[j] = (double)v.x;
         r.y[j] = (double)v.y;
@@ -76,8 +80,8 @@ T2D_DEV RegPoly<MAXN> load_poly_f32(const float* p, int n) {  // interleaved x,y
     return r;
 }
 
-T2D_DEV RegPoly<4> load_obb_lds(const double* base) {  // &s_v[0][lane_j], planes kBlock apart
-    RegPoly<4> r;
+T2D_DEV Quad load_obb_lds(const double* base) {  // &s_v[0][lane], planes kBlock apart
+    Quad r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         r.x[j] = base[(2 * j) * kBlock];
@@ -86,37 +90,89 @@ T2D_DEV RegPoly<4> load_obb_lds(const double* base) {  // &s_v[0][lane_j], plane
     return r;
 }
 
-// closed-set convex `intersects`, A = own OBB.  Same orientation evaluations (plus harmless
-// padded ones) as oracle t2do_convex_intersects(A, 4, B, n).
-template <int MAXN>
-T2D_DEV bool sat_obb(const double (&ax)[4], const double (&ay)[4], const RegPoly<MAXN>& B) {
+// closed-set convex `intersects` of two quads: the orientation evaluations of oracle
+// t2do_convex_intersects(A, 4, B, n) (plus harmless padded ones).
+T2D_DEV bool sat_quads(const Quad& A, const Quad& B) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const double px = ax[i], py = ay[i], qx = ax[(i + 1) & 3], qy = ay[(i + 1) & 3];
+        const int k = (i + 1) & 3;
         bool all_out = true;
 #pragma unroll
-        for (int j = 0; j < MAXN; ++j) all_out &= orient(px, py, qx, qy, B.x[j], B.y[j]) < 0.0;
+        for (int j = 0; j < 4; ++j) all_out &= orient(A.x[i], A.y[i], A.x[k], A.y[k], B.x[j], B.y[j]) < 0.0;
         if (all_out) return false;
     }
 #pragma unroll
-    for (int j = 0; j < MAXN; ++j) {
-        const double px = B.x[j], py = B.y[j];
-        const double qx = B.x[j + 1 < MAXN ? j + 1 : 0], qy = B.y[j + 1 < MAXN ? j + 1 : 0];
+    for (int j = 0; j < 4; ++j) {
+        const int k = (j + 1) & 3;
         bool all_out = true;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) all_out &= orient(px, py, qx, qy, ax[i], ay[i]) < 0.0;
+        for (int i = 0; i < 4; ++i) all_out &= orient(B.x[j], B.y[j], B.x[k], B.y[k], A.x[i], A.y[i]) < 0.0;
         if (all_out) return false;
     }
     return true;
 }
 
-template <int MAXN>
-T2D_DEV bool point_in_convex(const RegPoly<MAXN>& B, double x, double y) {
+T2D_DEV bool point_in_quad(const Quad& B, double x, double y) {
     bool in = true;
 #pragma unroll
-    for (int j = 0; j < MAXN; ++j) {
-        const int k = j + 1 < MAXN ? j + 1 : 0;
+    for (int j = 0; j < 4; ++j) {
+        const int k = (j + 1) & 3;
         in &= !(orient(B.x[j], B.y[j], B.x[k], B.y[k], x, y) < 0.0);
+    }
+    return in;
+}
+
+// ---- generic (slow, rare) paths: circles and 5..8-vertex polygons, streamed from LDS ----------
+// Kept out of line so their registers do not count against the hot quad-vs-quad code.
+struct PolyRef {           // a polygon in LDS: either fp32 interleaved x,y or an OBB in s_v planes
+    const float2* f32;     // non-null: fp32 vertices
+    const double* planes;  // else: &s_v[0][lane]
+    int n;
+    T2D_DEV void get(int j, double& x, double& y) const {
+        if (f32) {
+            const float2 v = f32[j];
+            x = (double)v.x;
+            y = (double)v.y;
+        } else {
+            x = planes[(2 * j) * kBlock];
+            y = planes[(2 * j + 1) * kBlock];
+        }
+    }
+};
+
+__device__ __noinline__ bool sat_generic(const PolyRef A, const PolyRef B) {
+    for (int pass = 0; pass < 2; ++pass) {
+        const PolyRef& P = pass == 0 ? A : B;  // edges of P against vertices of Q
+        const PolyRef& Q = pass == 0 ? B : A;
+        double px, py;
+        P.get(P.n - 1, px, py);
+        for (int i = 0; i < P.n; ++i) {
+            double qx, qy;
+            P.get(i, qx, qy);
+            bool all_out = true;
+            for (int j = 0; j < Q.n; ++j) {
+                double rx, ry;
+                Q.get(j, rx, ry);
+                all_out &= orient(px, py, qx, qy, rx, ry) < 0.0;
+            }
+            if (all_out) return false;
+            px = qx;
+            py = qy;
+        }
+    }
+    return true;
+}
+
+__device__ __noinline__ bool point_in_generic(const PolyRef B, double x, double y) {
+    bool in = true;
+    double px, py;
+    B.get(B.n - 1, px, py);
+    for (int j = 0; j < B.n; ++j) {
+        double qx, qy;
+        B.get(j, qx, qy);
+        in &= !(orient(px, py, qx, qy, x, y) < 0.0);
+        px = qx;
+        py = qy;
     }
     return in;
 }
@@ -135,83 +191,18 @@ T2D_DEV double seg_dist2(double px, double py, double qx, double qy, double cx, 
 }
 
 // oracle t2do_circle_convex_intersects
-template <int MAXN>
-T2D_DEV bool circle_vs_convex(double cx, double cy, double R, const RegPoly<MAXN>& B, int n) {
-    if (point_in_convex(B, cx, cy)) return true;
+__device__ __noinline__ bool circle_vs_generic(double cx, double cy, double R, const PolyRef B) {
+    if (point_in_generic(B, cx, cy)) return true;
     const double R2 = R * R;
     bool hit = false;
-#pragma unroll
-    for (int j = 0; j < MAXN; ++j) {  // real edges only (j < n): padded ones are skipped
-        const int k = j + 1 < MAXN ? j + 1 : 0;
-        hit |= j < n && seg_dist2(B.x[j], B.y[j], B.x[k], B.y[k], cx, cy) <= R2;
-    }
-    return hit;
-}
-
-// ---- streaming variants for the rare 5..8-vertex polygons: vertices are re-read from LDS instead
-// of being held in 32 VGPRs, which keeps the kernel at 4 waves / SIMD.  Same predicates.
-struct PolyLds {
-    const float2* q;
-    int n;
-    T2D_DEV void get(int j, double& x, double& y) const {
-        const float2 v = q[j];
-        x = (double)v.x;
-        y = (double)v.y;
-    }
-};
-
-T2D_DEV bool sat_obb_stream(const double (&ax)[4], const double (&ay)[4], const PolyLds& B) {
-    // pass 1: every B vertex against the 4 edges of A (one LDS read per vertex, branch-free)
-    bool out0 = true, out1 = true, out2 = true, out3 = true;
-    for (int j = 0; j < B.n; ++j) {
-        double rx, ry;
-        B.get(j, rx, ry);
-        out0 &= orient(ax[0], ay[0], ax[1], ay[1], rx, ry) < 0.0;
-        out1 &= orient(ax[1], ay[1], ax[2], ay[2], rx, ry) < 0.0;
-        out2 &= orient(ax[2], ay[2], ax[3], ay[3], rx, ry) < 0.0;
-        out3 &= orient(ax[3], ay[3], ax[0], ay[0], rx, ry) < 0.0;
-    }
-    if (out0 | out1 | out2 | out3) return false;
-    // pass 2: every edge of B against the 4 vertices of A (vertex carried between iterations)
-    double px, py;
-    B.get(B.n - 1, px, py);
-    bool sep = false;
-    for (int j = 0; j < B.n; ++j) {
-        double qx, qy;
-        B.get(j, qx, qy);
-        bool all_out = true;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) all_out &= orient(px, py, qx, qy, ax[i], ay[i]) < 0.0;
-        sep |= all_out;
-        px = qx;
-        py = qy;
-    }
-    return !sep;
-}
-
-T2D_DEV bool point_in_convex_stream(const PolyLds& B, double x, double y) {
-    bool in = true;
     double px, py;
     B.get(B.n - 1, px, py);
     for (int j = 0; j < B.n; ++j) {
         double qx, qy;
         B.get(j, qx, qy);
-        in &= !(orient(px, py, qx, qy, x, y) < 0.0);
-        px = qx;
-        py = qy;
-    }
-    return in;
-}
-
-T2D_DEV bool circle_vs_convex_stream(double cx, double cy, double R, const PolyLds& B) {
-    if (point_in_convex_stream(B, cx, cy)) return true;
-    const double R2 = R * R;
-    bool hit = false;
-    for (int j = 0; j < B.n; ++j) {
-        double px, py, qx, qy;
-        B.get(j, px, py);
-        B.get(j + 1 == B.n ? 0 : j + 1, qx, qy);
         hit |= seg_dist2(px, py, qx, qy, cx, cy) <= R2;
+        px = qx;
+        py = qy;
     }
     return hit;
 }
@@ -220,21 +211,76 @@ T2D_DEV uint32_t cell_hash(int cx, int cy) {
     return ((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u);
 }
 
+// LDS writes of this wave -> visible to the other lanes of this wave
+T2D_DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// Compact the set bits of every lane's `mask` into the wave's LDS queue (entry = tid | id << 8,
+// id = id_base + bit index) and run `process(entry)` densely, one entry per lane; repeats in
+// rounds of kQueueCap entries.  Slots are handed out by one LDS atomic per lane on the wave's
+// counter (cheaper than a 6-step shuffle scan; the order of entries is irrelevant).  Must be
+// called by all 64 lanes of the wave (mask 0 for idle lanes).
+template <bool SWAP, class F>
+T2D_DEV void compact_and_process(unsigned long long mask, int id_base, int own_id, uint32_t* queue, int* qcount,
+                                 int lane, F process) {
+    // entry = participant | other << 8.  SWAP = false: this lane is the participant (own_id = tid)
+    // and the bits name the other object (id_base + bit); SWAP = true: this lane owns the other
+    // object (own_id = polygon index) and the bits name participants (id_base + bit).
+    for (;;) {
+        const int cnt = __popcll(mask);
+        if (__ballot(cnt > 0) == 0ull) break;
+        if (lane == 0) *qcount = 0;
+        wave_sync();
+        const int off = cnt > 0 ? atomicAdd(qcount, cnt) : kQueueCap;
+        const int room = kQueueCap - off;
+        const int n_emit = room <= 0 ? 0 : (cnt < room ? cnt : room);
+        for (int e = 0; e < n_emit; ++e) {
+            const int a = __ffsll((long long)mask) - 1;
+            mask &= mask - 1ull;
+            queue[off + e] = SWAP ? (uint32_t)(id_base + a) | ((uint32_t)own_id << 8)
+                                  : (uint32_t)own_id | ((uint32_t)(id_base + a) << 8);
+        }
+        wave_sync();
+        const int total = *qcount;
+        const int n_round = total < kQueueCap ? total : kQueueCap;
+        for (int k = lane; k < n_round; k += 64) process(queue[k]);
+        wave_sync();
+    }
+}
+
+#ifdef T2D_TIMING
+#define T2D_MARK(k)                                                                     \
+    do {                                                                                \
+        const unsigned long long now_ = __builtin_readcyclecounter();                   \
+        if (lane == 0) pv.dbg[wave_slot_ + k] = now_ - t_prev_;                         \
+        t_prev_ = now_;                                                                 \
+    } while (0)
+#else
+#define T2D_MARK(k)
+#endif
+
 template <bool WITH_STATUS>
 __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv, t2d_status_config cfg,
-                                                         int interval_ms, int log2A) {
+                                                                            int interval_ms, int log2A) {
     __shared__ double s_v[8][kBlock];   // OBB vertex coordinate planes x0,y0,...,x3,y3
-    __shared__ double s_c[3][kBlock];   // centre x, centre y, bounding radius
+    __shared__ double s_c[3][kBlock];   // centre x, centre y, radius (circle) / bounding radius (OBB)
     __shared__ double s_par[4][T2D_MAX_TYPES];  // length, width, shape, bounding radius per type
     __shared__ int s_kind[kBlock];      // T2D_SHAPE_* or -1 = inactive
     __shared__ int s_head[kMaxHeads];
     __shared__ int s_next[kBlock];
-    __shared__ uint32_t s_flags[kBlock];
+    __shared__ uint32_t s_flags[kBlock];   // event bits, OR-ed by the narrow phase
+    __shared__ uint32_t s_inside[kBlock];  // bit k: pose vertex k lies in some lane polygon
     __shared__ uint32_t s_env_or[kBlock];
+    __shared__ uint32_t s_queue[kWaves][kQueueCap];
+    __shared__ int s_qcount[kWaves];
     extern __shared__ __attribute__((aligned(16))) uint32_t s_geo[];  // packed geometry record
 
     const GeoLayout& gl = pv.geo_layout;
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int A_pad = 1 << log2A;
     const int EPB = gl.epb;
     const int nthreads = EPB << log2A;
@@ -244,9 +290,14 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     const bool valid = env < pv.n_env && agent < pv.A;
     const int idx = valid ? env * pv.A + agent : 0;
     const bool use_hash_grid = log2A > 6;  // envs larger than a wave use the LDS spatial hash
-    const bool use_grid = use_hash_grid;
-    const int H = 2 * A_pad;  // buckets per env (power of two)
+    const int H = 2 * A_pad;               // buckets per env (power of two)
+    uint32_t* const queue = s_queue[tid >> 6];
+    int* const qcount = &s_qcount[tid >> 6];
 
+#ifdef T2D_TIMING
+    unsigned long long t_prev_ = __builtin_readcyclecounter();
+    const size_t wave_slot_ = ((size_t)blockIdx.x * kWaves + (tid >> 6)) * 16;
+#endif
     // ---------------- phase 0: issue every global load, clear LDS tables ------------------
     uint32_t ids = 0;
     float fx = 0, fy = 0, fh = 0;
@@ -278,24 +329,28 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     const int n_vec = pv.geo ? gl.stride >> 2 : 0;
     constexpr int kBatch = 8;
     const uint4* gsrc = reinterpret_cast<const uint4*>(pv.geo + (size_t)blockIdx.x * gl.stride);
-    uint4 geo_stage[kBatch];
+    {
+        uint4 geo_stage[kBatch];
 #pragma unroll
-    for (int k = 0; k < kBatch; ++k) {
-        geo_stage[k] = make_uint4(0, 0, 0, 0);
-        if (tid + k * nthreads < n_vec) geo_stage[k] = gsrc[tid + k * nthreads];
+        for (int k = 0; k < kBatch; ++k) {
+            geo_stage[k] = make_uint4(0, 0, 0, 0);
+            if (tid + k * nthreads < n_vec) geo_stage[k] = gsrc[tid + k * nthreads];
+        }
+        if (use_hash_grid)
+            for (int k = tid; k < EPB * H; k += nthreads) s_head[k] = -1;
+        s_env_or[tid] = 0;
+        s_flags[tid] = 0;
+        s_inside[tid] = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int q = tid + k * nthreads;
+            if (q < 4 * T2D_MAX_TYPES && (k == 0 || nthreads < 4 * T2D_MAX_TYPES))
+                s_par[q / T2D_MAX_TYPES][q % T2D_MAX_TYPES] = par_stage[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k)
+            if (tid + k * nthreads < n_vec) reinterpret_cast<uint4*>(s_geo)[tid + k * nthreads] = geo_stage[k];
     }
-    if (use_grid)
-        for (int k = tid; k < EPB * H; k += nthreads) s_head[k] = -1;
-    s_env_or[tid] = 0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int q = tid + k * nthreads;
-        if (q < 4 * T2D_MAX_TYPES && (k == 0 || nthreads < 4 * T2D_MAX_TYPES))
-            s_par[q / T2D_MAX_TYPES][q % T2D_MAX_TYPES] = par_stage[k];
-    }
-#pragma unroll
-    for (int k = 0; k < kBatch; ++k)
-        if (tid + k * nthreads < n_vec) reinterpret_cast<uint4*>(s_geo)[tid + k * nthreads] = geo_stage[k];
     for (int base = kBatch * nthreads; base < n_vec; base += kBatch * nthreads) {  // big records only
         uint4 g2[kBatch];
 #pragma unroll
@@ -309,26 +364,33 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                 reinterpret_cast<uint4*>(s_geo)[base + tid + k * nthreads] = g2[k];
     }
     __syncthreads();  // (a) tables cleared, type columns + geometry record staged
+    T2D_MARK(0);
 
-    // ---------------- phase 1: pose + grid insert -----------------------------------------
+    // ---------------- phase 1: pose, out-of-bound, conservative fp32 box ------------------------
     const bool active = valid && ((ids >> kIdsActiveShift) & 0xffu);
     const int type = (ids >> kIdsTypeShift) & 0xff;
-    double ax[4], ay[4];
-    double cx = (double)fx, cy = (double)fy, R = 0.0, rad = 0.0;
     int kind = -1;
+    float R32 = -1.0f;                                  // bounding radius + 5 mm; < 0 = inactive
+    float box_lo_x = 0, box_hi_x = 0, box_lo_y = 0, box_hi_y = 0;  // encloses the pose (outward rounded)
+    uint32_t f_own = 0;                                 // flags this lane decides alone
     int gcx = 0, gcy = 0;
     if (active) {
+        const double cx = (double)fx, cy = (double)fy;
         const double L = s_par[0][type];
         const double W = s_par[1][type];
         kind = (int)s_par[2][type];
-        R = s_par[3][type];  // bounding radius (host-computed)
-        rad = 0.5 * W;
+        const double R = s_par[3][type];  // bounding radius (host-computed)
+        const double rad = 0.5 * W;
+        R32 = (float)R + 5e-3f;
+        double lo_x, hi_x, lo_y, hi_y;
+        bool out = false;
         if (kind == T2D_SHAPE_OBB) {
             double s, c;
             sincos_det((double)fh, s, c);
             const double hl = 0.5 * L, hw = 0.5 * W;
             const double lx[4] = {hl, hl, -hl, -hl};
             const double ly[4] = {-hw, hw, hw, -hw};
+            double ax[4], ay[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 ax[k] = c * lx[k] - s * ly[k] + cx;
@@ -336,11 +398,33 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                 s_v[2 * k][tid] = ax[k];
                 s_v[2 * k + 1][tid] = ay[k];
             }
+            lo_x = hi_x = ax[0];
+            lo_y = hi_y = ay[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                lo_x = ax[k] < lo_x ? ax[k] : lo_x; hi_x = ax[k] > hi_x ? ax[k] : hi_x;
+                lo_y = ay[k] < lo_y ? ay[k] : lo_y; hi_y = ay[k] > hi_y ? ay[k] : hi_y;
+            }
+            s_c[2][tid] = R;
+            // OutBound.update: not boundary.contains(pose); touching from inside is contained
+            if (has_boundary)
+                out = lo_x < (double)bxmin || hi_x > (double)bxmax || lo_y < (double)bymin || hi_y > (double)bymax;
+        } else {
+            lo_x = cx - rad; hi_x = cx + rad; lo_y = cy - rad; hi_y = cy + rad;
+            s_c[2][tid] = rad;
+            if (has_boundary)
+                out = cx - rad < (double)bxmin || cx + rad > (double)bxmax || cy - rad < (double)bymin ||
+                      cy + rad > (double)bymax;
         }
+        if (out) f_own |= T2D_FLAG_OUT_BOUND;
         s_c[0][tid] = cx;
         s_c[1][tid] = cy;
-        s_c[2][tid] = R;
-        if (use_grid) {
+        // fp32 box rounded outwards (relative 2^-23 + 1e-6 m): conservative for the AABB passes
+        box_lo_x = (float)lo_x; box_lo_x -= __builtin_fabsf(box_lo_x) * 1.2e-7f + 1e-6f;
+        box_hi_x = (float)hi_x; box_hi_x += __builtin_fabsf(box_hi_x) * 1.2e-7f + 1e-6f;
+        box_lo_y = (float)lo_y; box_lo_y -= __builtin_fabsf(box_lo_y) * 1.2e-7f + 1e-6f;
+        box_hi_y = (float)hi_y; box_hi_y += __builtin_fabsf(box_hi_y) * 1.2e-7f + 1e-6f;
+        if (use_hash_grid) {
             gcx = (int)__builtin_floor(cx * pv.inv_cell);
             gcy = (int)__builtin_floor(cy * pv.inv_cell);
             const int b = env_local * H + (int)(cell_hash(gcx, gcy) & (uint32_t)(H - 1));
@@ -348,175 +432,206 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         }
     }
     s_kind[tid] = kind;
-    __syncthreads();  // (b) poses and grid lists visible
+    T2D_MARK(1);
+    // an env that fits in a wave only ever reads its own wave's poses: no workgroup barrier needed
+    if (log2A <= 6) wave_sync(); else __syncthreads();  // (b) poses (and grid lists) visible
+    T2D_MARK(2);
 
-    // ---------------- phase 2: tests --------------------------------------------------------
-    // Broad phase for envs that fit in one wave (A_pad <= 64): every lane compares its bounding
-    // circle against all agents of its env with cross-lane shuffles -- no LDS traffic, no
-    // dependent chain, fp32 with a 1 cm safety margin (strictly conservative for |x|,|y| < 4 km:
-    // fp32 rounding moves the test by < 1e-4 m there) -- and keeps a 64-bit candidate mask.
-    // Larger envs (A_pad > 64) walk the LDS spatial-hash grid instead.  Executed by ALL lanes
-    // (inactive ones publish a negative radius) because shuffles read from executing lanes only.
-    unsigned long long cand = 0ull;
-    const float R32 = active ? (float)R + 5e-3f : -1.0f;
-    if (!use_hash_grid && !(T2D_ABLATE & 4)) {
-        const int seg0 = (tid & 63) & ~(A_pad - 1);  // first lane of my env inside the wave
-        for (int a = 0; a < A_pad; ++a) {
-            const float ox = __shfl(fx, seg0 + a), oy = __shfl(fy, seg0 + a), oR = __shfl(R32, seg0 + a);
-            const float dx = fx - ox, dy = fy - oy, rr = R32 + oR;
-            const bool near = oR >= 0.0f && dx * dx + dy * dy <= rr * rr;
-            cand |= (unsigned long long)near << a;
+    // ---------------- phase 2a: participant pairs ----------------------------------------------
+    // narrow phase of one unordered pair (i < j by construction); flags both participants
+    auto process_pair = [&](uint32_t e) {
+        const int i = (int)(e & 255u), j = (int)(e >> 8);
+        const int ki = s_kind[i], kj = s_kind[j];
+        bool hit;
+        if (ki == T2D_SHAPE_OBB && kj == T2D_SHAPE_OBB) {
+            hit = sat_quads(load_obb_lds(&s_v[0][i]), load_obb_lds(&s_v[0][j]));
+        } else if (ki == T2D_SHAPE_OBB) {   // circle j against box i
+            hit = circle_vs_generic(s_c[0][j], s_c[1][j], s_c[2][j], PolyRef{nullptr, &s_v[0][i], 4});
+        } else if (kj == T2D_SHAPE_OBB) {   // circle i against box j
+            hit = circle_vs_generic(s_c[0][i], s_c[1][i], s_c[2][i], PolyRef{nullptr, &s_v[0][j], 4});
+        } else {                            // circle - circle (oracle: c1 = i, c2 = j)
+            const double dx = s_c[0][i] - s_c[0][j], dy = s_c[1][i] - s_c[1][j];
+            const double rr = s_c[2][i] + s_c[2][j];
+            hit = dx * dx + dy * dy <= rr * rr;
         }
-        cand &= ~(1ull << agent);
+        if (hit) {
+            atomicOr(&s_flags[i], T2D_FLAG_COLLISION_DYNAMIC);
+            atomicOr(&s_flags[j], T2D_FLAG_COLLISION_DYNAMIC);
+        }
+    };
+    if (!use_hash_grid) {
+        // every lane against all agents of its env: fp32 circles, 1 cm margin (strictly
+        // conservative for |x|,|y| < 4 km); executed by ALL lanes (shuffles read executing lanes)
+        unsigned long long cand = 0ull;
+        if (log2A == 6) {
+            // env == wave: agent a's circle arrives in SGPRs (v_readlane, wave-uniform lane index)
+            // and every lane tests itself against it -- fully unrolled so the bit deposit is one
+            // select + one or on a 32-bit half; no LDS, no 64-bit shifts, ~11 instructions / agent.
+            // Inactive lanes are parked at x = 1e30 (distance^2 = inf: never near).
+            const float px = active ? fx : 1e30f;
+            const int ifx = __float_as_int(px), ify = __float_as_int(fy), iR = __float_as_int(R32);
+            uint32_t half[2] = {0u, 0u};
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+                for (int a = 0; a < 32; ++a) {
+                    const float ox = __int_as_float(__builtin_amdgcn_readlane(ifx, hb * 32 + a));
+                    const float oy = __int_as_float(__builtin_amdgcn_readlane(ify, hb * 32 + a));
+                    const float oR = __int_as_float(__builtin_amdgcn_readlane(iR, hb * 32 + a));
+                    const float dx = px - ox, dy = fy - oy, rr = R32 + oR;
+                    half[hb] |= dx * dx + dy * dy <= rr * rr ? 1u << a : 0u;
+                }
+            }
+            cand = (unsigned long long)half[0] | ((unsigned long long)half[1] << 32);
+        } else {
+            const int seg0 = lane & ~(A_pad - 1);  // first lane of my env inside the wave
+#pragma unroll 4
+            for (int a = 0; a < A_pad; ++a) {
+                const float ox = __shfl(fx, seg0 + a), oy = __shfl(fy, seg0 + a), oR = __shfl(R32, seg0 + a);
+                const float dx = fx - ox, dy = fy - oy, rr = R32 + oR;
+                const bool near = oR >= 0.0f && dx * dx + dy * dy <= rr * rr;
+                cand |= (unsigned long long)near << a;
+            }
+        }
+        T2D_MARK(3);
+        cand &= ~((2ull << agent) - 1ull);  // partners with a higher index only: each pair once
+        if (!active) cand = 0ull;
+        compact_and_process<false>(cand, (env_local << log2A), tid, queue, qcount, lane, process_pair);
+    } else {
+        // spatial-hash walk; pairs go straight to the narrow phase (i < j de-duplicates)
+        if (active) {
+            const double cx = s_c[0][tid], cy = s_c[1][tid];
+            for (int oy_ = -1; oy_ <= 1; ++oy_)
+                for (int ox_ = -1; ox_ <= 1; ++ox_) {
+                    const int b = env_local * H + (int)(cell_hash(gcx + ox_, gcy + oy_) & (uint32_t)(H - 1));
+                    for (int j = s_head[b]; j >= 0; j = s_next[j]) {
+                        if (j <= tid) continue;
+                        const int jx = (int)__builtin_floor(s_c[0][j] * pv.inv_cell);
+                        const int jy = (int)__builtin_floor(s_c[1][j] * pv.inv_cell);
+                        if (jx != gcx + ox_ || jy != gcy + oy_) continue;  // hash alias of another cell
+                        const double dx = cx - s_c[0][j], dy = cy - s_c[1][j];
+                        const double rr = s_c[2][tid] + s_c[2][j] + kRejectMargin;
+                        if (dx * dx + dy * dy > rr * rr) continue;  // cannot touch
+                        process_pair((uint32_t)tid | ((uint32_t)j << 8));
+                    }
+                }
+        }
     }
 
-    uint32_t f = 0;
-    if (active) {
-        // ---- participant vs participant (narrow phase, fp64, oracle arithmetic) ------------
-        auto test_shapes = [&](int j) -> bool {  // j = workgroup-local lane of the other participant
-            const int kj = s_kind[j];
-            if (kind == T2D_SHAPE_OBB && kj == T2D_SHAPE_OBB) return sat_obb(ax, ay, load_obb_lds(&s_v[0][j]));
-            const double ox = s_c[0][j], oy = s_c[1][j], oR = s_c[2][j];
-            if (kind == T2D_SHAPE_OBB) return circle_vs_convex(ox, oy, oR, load_obb_lds(&s_v[0][tid]), 4);
-            if (kj == T2D_SHAPE_OBB) return circle_vs_convex(cx, cy, rad, load_obb_lds(&s_v[0][j]), 4);
-            const double dx = cx - ox, dy = cy - oy;
-            const double r2 = rad + oR;  // circle-circle: bounding radius == radius
-            return dx * dx + dy * dy <= r2 * r2;
-        };
-        bool hit = false;
-        if (!use_hash_grid) {
-            const int j0 = env_local << log2A;
-            while (cand != 0ull && !hit) {
-                const int a = __ffsll((long long)cand) - 1;
-                cand &= cand - 1ull;
-                hit = (T2D_ABLATE & 2) ? false : test_shapes(j0 + a);
+    T2D_MARK(4);
+    // ---------------- phase 2b / 2c: static polygons and lane polygons -------------------------
+    const int* geo_i = reinterpret_cast<const int*>(s_geo);
+    auto process_static = [&](uint32_t e) {
+        const int i = (int)(e & 255u), p = (int)(e >> 8);
+        const int* vstart = geo_i + gl.off_vstart[0];
+        const float* xy = reinterpret_cast<const float*>(s_geo + gl.off_xy[0]);
+        const int v0 = vstart[p], n = vstart[p + 1] - v0;
+        bool hit;
+        if (s_kind[i] == T2D_SHAPE_OBB) {
+            if (n <= 4) hit = sat_quads(load_obb_lds(&s_v[0][i]), load_quad_f32(xy + 2 * v0, n));
+            else hit = sat_generic(PolyRef{nullptr, &s_v[0][i], 4}, PolyRef{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n});
+        } else {
+            hit = circle_vs_generic(s_c[0][i], s_c[1][i], s_c[2][i],
+                                    PolyRef{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n});
+        }
+        if (hit) atomicOr(&s_flags[i], T2D_FLAG_COLLISION_STATIC);
+    };
+    auto process_lane = [&](uint32_t e) {
+        const int i = (int)(e & 255u), p = (int)(e >> 8);
+        const int* vstart = geo_i + gl.off_vstart[1];
+        const float* xy = reinterpret_cast<const float*>(s_geo + gl.off_xy[1]);
+        const int v0 = vstart[p], n = vstart[p + 1] - v0;
+        uint32_t bits = 0;
+        if (s_kind[i] == T2D_SHAPE_OBB) {
+            if (n <= 4) {
+                const Quad A = load_obb_lds(&s_v[0][i]);
+                const Quad B = load_quad_f32(xy + 2 * v0, n);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bits |= (uint32_t)point_in_quad(B, A.x[k], A.y[k]) << k;
+            } else {
+                const PolyRef B{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n};
+                for (int k = 0; k < 4; ++k)
+                    bits |= (uint32_t)point_in_generic(B, s_v[2 * k][i], s_v[2 * k + 1][i]) << k;
             }
         } else {
-            for (int oy_ = -1; oy_ <= 1 && !hit; ++oy_)
-                for (int ox_ = -1; ox_ <= 1 && !hit; ++ox_) {
-                    const int b = env_local * H +
-                                  (int)(cell_hash(gcx + ox_, gcy + oy_) & (uint32_t)(H - 1));
-                    for (int j = s_head[b]; j >= 0 && !hit; j = s_next[j]) {
-                        if (j == tid || s_kind[j] < 0) continue;
-                        const double dx = cx - s_c[0][j], dy = cy - s_c[1][j];
-                        const double rr = R + s_c[2][j] + kRejectMargin;
-                        if (dx * dx + dy * dy > rr * rr) continue;  // cannot touch
-                        hit = test_shapes(j);
-                    }
-                }
+            bits = point_in_generic(PolyRef{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n}, s_c[0][i], s_c[1][i]);
         }
-        if (hit) f |= T2D_FLAG_COLLISION_DYNAMIC;
-
-        // ---- geometry record accessors -------------------------------------------------------
-        const int* pstart0 = reinterpret_cast<const int*>(s_geo) + gl.off_pstart[0];
-        const int* pstart1 = reinterpret_cast<const int*>(s_geo) + gl.off_pstart[1];
-
-        // ---- participant vs static polygons ----------------------------------------------
-        // pass 1 (branch-free, loads pipeline): bit mask of polygons whose box is within reach
-        // of the bounding circle; pass 2: exact test on the survivors only.
-        if (gl.has[0] && !(T2D_ABLATE & 8)) {
-            const int* vstart = reinterpret_cast<const int*>(s_geo) + gl.off_vstart[0];
-            const float4* bb = reinterpret_cast<const float4*>(s_geo + gl.off_aabb[0]);
-            const float* xy = reinterpret_cast<const float*>(s_geo + gl.off_xy[0]);
-            const int pend = pstart0[env_local + 1];
-            bool shit = false;
-            for (int c0 = pstart0[env_local]; c0 < pend && !shit; c0 += 32) {
-                const int cn = pend - c0 < 32 ? pend - c0 : 32;
-                uint32_t m = 0;
+        if (bits) atomicOr(&s_inside[i], bits);
+    };
+    int n_lane_polys = 0;
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd) {
+        if (!gl.has[kd]) continue;
+        const int* pstart = geo_i + gl.off_pstart[kd];
+        const float4* bb = reinterpret_cast<const float4*>(s_geo + gl.off_aabb[kd]);
+        const int p0 = pstart[env_local], p1 = pstart[env_local + 1];
+        if (kd == 1) n_lane_polys = p1 - p0;
+        // pass 1: which (participant, polygon) boxes meet; pass 2: survivors of the whole wave,
+        // compacted, one narrow test per lane.
+        if (log2A == 6) {
+            // env == wave: lane q fetches polygon q's box (one parallel LDS read); the boxes are
+            // then broadcast one by one through SGPRs and every participant compares its pose box.
+            const int np = p1 - p0;  // wave-uniform
+            for (int c0 = 0; c0 < np; c0 += 64) {
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 + lane < np) b = bb[p0 + c0 + lane];
+                const int ib0 = __float_as_int(b.x), ib1 = __float_as_int(b.y), ib2 = __float_as_int(b.z),
+                          ib3 = __float_as_int(b.w);
+                uint32_t mlo = 0, mhi = 0;
+                const int cn = np - c0 < 64 ? np - c0 : 64;
+                for (int a = 0; a < cn; ++a) {
+                    const float xmin = __int_as_float(__builtin_amdgcn_readlane(ib0, a));
+                    const float xmax = __int_as_float(__builtin_amdgcn_readlane(ib1, a));
+                    const float ymin = __int_as_float(__builtin_amdgcn_readlane(ib2, a));
+                    const float ymax = __int_as_float(__builtin_amdgcn_readlane(ib3, a));
+                    const bool ov = !(box_hi_x < xmin || box_lo_x > xmax || box_hi_y < ymin || box_lo_y > ymax);
+                    const uint32_t bit = 1u << (a & 31);
+                    if (a < 32) mlo |= ov ? bit : 0u;
+                    else mhi |= ov ? bit : 0u;
+                }
+                unsigned long long m = (unsigned long long)mlo | ((unsigned long long)mhi << 32);
+                if (!active) m = 0ull;
+                T2D_MARK(5 + 2 * kd);
+                if (kd == 0) compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_static);
+                else compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_lane);
+                T2D_MARK(6 + 2 * kd);
+            }
+        } else {
+            for (int c0 = 0;; c0 += 64) {
+                const int left = active ? p1 - p0 - c0 : 0;
+                if (__ballot(left > 0) == 0ull) break;
+                unsigned long long m = 0ull;
+                const int cn = left < 64 ? left : 64;
                 for (int q = 0; q < cn; ++q) {
-                    const float4 b = bb[c0 + q];  // xmin, xmax, ymin, ymax
-                    const bool ov = !(fx + R32 < b.x || fx - R32 > b.y || fy + R32 < b.z || fy - R32 > b.w);
-                    m |= (uint32_t)ov << q;
+                    const float4 b = bb[p0 + c0 + q];  // xmin, xmax, ymin, ymax
+                    const bool ov = !(box_hi_x < b.x || box_lo_x > b.y || box_hi_y < b.z || box_lo_y > b.w);
+                    m |= (unsigned long long)ov << q;
                 }
-                while (m != 0u && !shit) {
-                    const int p = c0 + __ffs((int)m) - 1;
-                    m &= m - 1u;
-                    const int v0 = vstart[p], n = vstart[p + 1] - v0;
-                    if (n <= 4) {
-                        const RegPoly<4> B = load_poly_f32<4>(xy + 2 * v0, n);
-                        shit = kind == T2D_SHAPE_OBB ? sat_obb(ax, ay, B) : circle_vs_convex(cx, cy, rad, B, n);
-                    } else {
-                        const PolyLds B{reinterpret_cast<const float2*>(xy + 2 * v0), n};
-                        shit = kind == T2D_SHAPE_OBB ? sat_obb_stream(ax, ay, B) : circle_vs_convex_stream(cx, cy, rad, B);
-                    }
-                }
-            }
-            if (shit) f |= T2D_FLAG_COLLISION_STATIC;
-        }
-
-        // ---- map boundary: not boundary.contains(pose) ---------------------------------
-        if (has_boundary) {
-            const double xmin = bxmin, xmax = bxmax, ymin = bymin, ymax = bymax;
-            bool out = false;
-            if (kind == T2D_SHAPE_OBB) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (ax[k] < xmin || ax[k] > xmax || ay[k] < ymin || ay[k] > ymax) out = true;
-            } else {
-                if (cx - rad < xmin || cx + rad > xmax || cy - rad < ymin || cy + rad > ymax) out = true;
-            }
-            if (out) f |= T2D_FLAG_OUT_BOUND;
-        }
-
-        // ---- lanes (build-defined): some pose vertex lies in no lane polygon -------------
-        if (gl.has[1] && !(T2D_ABLATE & 1)) {
-            const int p0 = pstart1[env_local], p1 = pstart1[env_local + 1];
-            if (p1 > p0) {
-                const int* vstart = reinterpret_cast<const int*>(s_geo) + gl.off_vstart[1];
-                const float4* bb = reinterpret_cast<const float4*>(s_geo + gl.off_aabb[1]);
-                const float* xy = reinterpret_cast<const float*>(s_geo + gl.off_xy[1]);
-                const int nv = kind == T2D_SHAPE_OBB ? 4 : 1;
-                double qx[4], qy[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    qx[k] = kind == T2D_SHAPE_OBB ? ax[k] : cx;
-                    qy[k] = kind == T2D_SHAPE_OBB ? ay[k] : cy;
-                }
-                // box of the pose vertices: lanes farther than the margin from it contain none
-                double lo_x = qx[0], hi_x = qx[0], lo_y = qy[0], hi_y = qy[0];
-#pragma unroll
-                for (int k = 1; k < 4; ++k) {
-                    lo_x = qx[k] < lo_x ? qx[k] : lo_x; hi_x = qx[k] > hi_x ? qx[k] : hi_x;
-                    lo_y = qy[k] < lo_y ? qy[k] : lo_y; hi_y = qy[k] > hi_y ? qy[k] : hi_y;
-                }
-                unsigned inside = 0;  // bit k: vertex k lies in some lane polygon
-                const unsigned all = (1u << nv) - 1u;
-                for (int c0 = p0; c0 < p1 && inside != all; c0 += 32) {
-                    const int cn = p1 - c0 < 32 ? p1 - c0 : 32;
-                    uint32_t m = 0;  // pass 1: lanes whose box is within 1e-6 m of the pose's box
-                    for (int q = 0; q < cn; ++q) {
-                        const float4 b = bb[c0 + q];
-                        const bool ov = !(hi_x + kRejectMargin < (double)b.x || lo_x - kRejectMargin > (double)b.y ||
-                                          hi_y + kRejectMargin < (double)b.z || lo_y - kRejectMargin > (double)b.w);
-                        m |= (uint32_t)ov << q;
-                    }
-                    while (m != 0u && inside != all) {  // pass 2: exact containment per vertex
-                        const int p = c0 + __ffs((int)m) - 1;
-                        m &= m - 1u;
-                        const int v0 = vstart[p], n = vstart[p + 1] - v0;
-                        if (n <= 4) {
-                            const RegPoly<4> B = load_poly_f32<4>(xy + 2 * v0, n);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                if (k < nv && !(inside >> k & 1u) && point_in_convex(B, qx[k], qy[k])) inside |= 1u << k;
-                        } else {
-                            const PolyLds B{reinterpret_cast<const float2*>(xy + 2 * v0), n};
-#pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                if (k < nv && !(inside >> k & 1u) && point_in_convex_stream(B, qx[k], qy[k])) inside |= 1u << k;
-                        }
-                    }
-                }
-                if (inside != all) f |= T2D_FLAG_OFF_LANE;
+                T2D_MARK(5 + 2 * kd);
+                if (kd == 0) compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_static);
+                else compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_lane);
+                T2D_MARK(6 + 2 * kd);
             }
         }
     }
 
     // ---------------- phase 3: reduce + status epilogue ------------------------------------
+    T2D_MARK(9);
+    if (log2A <= 6) wave_sync(); else __syncthreads();  // (c) every queue drained: s_flags / s_inside complete
+    T2D_MARK(10);
+    uint32_t f = 0;
+    if (active) {
+        f = f_own | s_flags[tid];
+        if (n_lane_polys > 0) {  // build-defined off-lane: some pose vertex (circle: the centre) in no lane
+            const uint32_t all = kind == T2D_SHAPE_OBB ? 15u : 1u;
+            if ((s_inside[tid] & all) != all) f |= T2D_FLAG_OFF_LANE;
+        }
+    }
     if (valid) pv.flags[idx] = f;
     s_flags[tid] = f;
     if (__ballot(f != 0) != 0ull && f != 0) atomicOr(&s_env_or[env_local], f);
-    __syncthreads();  // (c)
+    if (log2A <= 6) wave_sync(); else __syncthreads();  // (d)
+    T2D_MARK(11);
 
     if (valid && agent == 0) {
         pv.env_flags[env] = s_env_or[env_local];
@@ -552,6 +667,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             pv.reward[env] = r;
         }
     }
+    T2D_MARK(12);
 }
 
 }  // namespace

@@ -51,6 +51,7 @@ struct PoolView {
     GeoLayout geo_layout;
     const float* boundary;         // [4*E] or null
     const uint8_t* boundary_valid; // [E] or null
+    unsigned long long* dbg;  // phase cycle accumulators (profiling builds with -DT2D_TIMING only)
     double cell;      // spatial-hash cell edge (m) >= max circum-diameter * 1.001
     double inv_cell;
 };
