@@ -127,7 +127,10 @@ enum {
     T2D_F_FRAME_MS = 14,   /* i32[E]  State.frame of the env (ms)                    */
     T2D_F_STATUS = 15,     /* u8[E*4] scenario_status, traffic_status, terminated, truncated */
     T2D_F_REWARD = 16,     /* f32[E]                                                  */
-    T2D_F_COUNT = 17
+    T2D_F_RECORD = 17,     /* u32[2][E][2] packed per-env result records {reward bits, status word},
+                              double buffered: t2d_step number k (0-based since create) writes half
+                              k & 1, so a collective may still read step k while step k+1 runs    */
+    T2D_F_COUNT = 18
 };
 
 /* ---- per-participant / per-env event bits ------------------------------------------- */
@@ -235,6 +238,11 @@ int t2d_sync(t2d_pool* pool);
  *   mode 0: every env;  mode 1: only envs whose status says terminated or truncated.       */
 int t2d_snapshot(t2d_pool* pool);
 int t2d_restore(t2d_pool* pool, int32_t mode, void* hip_stream);
+/* Vector-env auto-reset fused into t2d_step: an env whose status comes out terminated or truncated
+ * is put back to the snapshot at the end of the same launch (state, ids, cnt_step, frame).  Its
+ * status / reward / flags keep the terminal step's values until the next step overwrites them, as
+ * Gym vector envs report them.  Needs a snapshot.                                                */
+int t2d_set_auto_reset(t2d_pool* pool, int32_t on);
 
 /* Kernel variants: 0 = exact (library-grade fp64 trig every sub-step), 1 = fast
  * (rotation recurrence, default).  Both satisfy the 1e-5 contract; see DESIGN.md.       */

@@ -29,6 +29,7 @@ int fail(t2d_pool* p, int code, const std::string& msg) {
 
 size_t field_elem_bytes(int f) {
     switch (f) {
+        case T2D_F_RECORD: return 16;  // 2 halves x {u32 reward bits, u32 status word} per env
         case T2D_F_STATUS: return 4;  // 4 x u8 per env
         default: return 4;
     }
@@ -308,10 +309,14 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
     v.frame_ms = (int32_t*)p->field_ptr[T2D_F_FRAME_MS];
     v.status = (uint8_t*)p->field_ptr[T2D_F_STATUS];
     v.reward = (float*)p->field_ptr[T2D_F_REWARD];
+    v.record = (uint2*)p->field_ptr[T2D_F_RECORD];
     v.params = p->d_params;
     v.cell = 1.0;
     v.inv_cell = 1.0;
     v.dbg = nullptr;
+    for (int k = 0; k < 6; ++k) v.snap[k] = nullptr;
+    v.snap_ids = nullptr;
+    v.auto_reset = 0;
 #ifdef T2D_TIMING
     (void)hipMalloc((void**)&v.dbg, (size_t)(n_env + 64) * 16 * 4 * sizeof(unsigned long long));
     (void)hipMemset(v.dbg, 0, (size_t)(n_env + 64) * 16 * 4 * sizeof(unsigned long long));
@@ -543,7 +548,10 @@ int t2d_collide(t2d_pool* p, void* hip_stream) {
 int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     int rc = t2d_integrate(p, interval_ms, hip_stream);
     if (rc != T2D_OK) return rc;
-    return collide_impl(p, true, interval_ms, (hipStream_t)hip_stream);
+    p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)(p->step_count & 1) * p->v.n_env;
+    rc = collide_impl(p, true, interval_ms, (hipStream_t)hip_stream);
+    if (rc == T2D_OK) p->step_count++;
+    return rc;
 }
 
 int t2d_snapshot(t2d_pool* p) {
@@ -560,6 +568,17 @@ int t2d_snapshot(t2d_pool* p) {
     if (!p->d_snap_ids) T2D_HIP(p, hipMalloc((void**)&p->d_snap_ids, nb));
     T2D_HIP(p, hipMemcpy(p->d_snap_ids, p->v.ids, nb, hipMemcpyDeviceToDevice));
     p->have_snapshot = true;
+    for (int k = 0; k < 6; ++k) p->v.snap[k] = p->d_snap[k];
+    p->v.snap_ids = p->d_snap_ids;
+    p->v.auto_reset = p->auto_reset ? 1 : 0;
+    return T2D_OK;
+}
+
+int t2d_set_auto_reset(t2d_pool* p, int32_t on) {
+    if (!p) return T2D_ERR_INVALID;
+    if (on && !p->have_snapshot) return fail(p, T2D_ERR_STATE, "t2d_snapshot must precede t2d_set_auto_reset");
+    p->auto_reset = on != 0;
+    p->v.auto_reset = p->auto_reset ? 1 : 0;
     return T2D_OK;
 }
 

@@ -276,6 +276,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     __shared__ uint32_t s_env_or[kBlock];
     __shared__ uint32_t s_queue[kWaves][kQueueCap];
     __shared__ int s_qcount[kWaves];
+    __shared__ int s_done[kBlock];  // per env_local: episode finished this step (auto-reset)
     extern __shared__ __attribute__((aligned(16))) uint32_t s_geo[];  // packed geometry record
 
     const GeoLayout& gl = pv.geo_layout;
@@ -665,6 +666,28 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             st.z = terminated; st.w = truncated;
             reinterpret_cast<uchar4*>(pv.status)[env] = st;
             pv.reward[env] = r;
+            pv.record[env] = make_uint2(__float_as_uint(r), (uint32_t)scen | (uint32_t)traf << 8 |
+                                                                (uint32_t)terminated << 16 | (uint32_t)truncated << 24);
+            if (pv.auto_reset) {
+                const bool done = terminated || truncated;
+                s_done[env_local] = done;
+                if (done) {  // ParkingEnv.reset: counters back to the episode start
+                    pv.cnt_step[env] = 0;
+                    pv.frame_ms[env] = 0;
+                }
+            }
+        }
+    }
+    if (WITH_STATUS && pv.auto_reset) {  // fused vector-env auto-reset: finished envs go back to the snapshot
+        if (log2A <= 6) wave_sync(); else __syncthreads();
+        if (valid && s_done[env_local]) {
+            pv.x[idx] = pv.snap[0][idx];
+            pv.y[idx] = pv.snap[1][idx];
+            pv.heading[idx] = pv.snap[2][idx];
+            pv.speed[idx] = pv.snap[3][idx];
+            pv.vx[idx] = pv.snap[4][idx];
+            pv.vy[idx] = pv.snap[5][idx];
+            pv.ids[idx] = pv.snap_ids[idx];
         }
     }
     T2D_MARK(12);

@@ -44,6 +44,7 @@ struct PoolView {
     int32_t *cnt_step, *frame_ms;
     uint8_t* status;
     float* reward;
+    uint2* record;  // this step's half of the double-buffered {reward bits, status word} records
     const double* params;  // [T2D_PARAM_COLS][T2D_MAX_TYPES]
     int32_t n_types;
     // static + lane geometry: one fixed-stride packed record per collide workgroup (see GeoLayout)
@@ -51,6 +52,9 @@ struct PoolView {
     GeoLayout geo_layout;
     const float* boundary;         // [4*E] or null
     const uint8_t* boundary_valid; // [E] or null
+    const float* snap[6];      // episode-start snapshot (x, y, heading, speed, vx, vy) or null
+    const uint32_t* snap_ids;
+    int32_t auto_reset;        // t2d_step restores finished envs in its epilogue
     unsigned long long* dbg;  // phase cycle accumulators (profiling builds with -DT2D_TIMING only)
     double cell;      // spatial-hash cell edge (m) >= max circum-diameter * 1.001
     double inv_cell;
@@ -87,6 +91,8 @@ struct t2d_pool {
     float* d_snap[6]{};      // x, y, heading, speed, vx, vy at episode start
     uint32_t* d_snap_ids = nullptr;
     bool have_snapshot = false;
+    bool auto_reset = false;
+    long long step_count = 0;  // t2d_step calls so far (selects the record half)
     // profiling
     bool profiling = false;
     static constexpr int kMaxProfSteps = 4096;

@@ -52,29 +52,32 @@ def unpack_record(rec):
 
 
 class ResultGather:
-    """Asynchronous all-gather of the per-env result records, double buffered so the next step
-    may overwrite the pool's reward/status while the collective is still in flight."""
+    """Asynchronous all-gather of the per-env result records.
 
-    def __init__(self, n_env_local, world, device):
+    The step kernel itself writes the 8-byte records into a double-buffered pool field
+    (T2D_F_RECORD, half = step parity), so the collective reads them in place: no packing kernels,
+    and step k+1 may run while the gather of step k is still in flight.  `records` is an int32
+    tensor view [2, E, 2] of that field (a CPU tensor in the gloo tests)."""
+
+    def __init__(self, records, world):
         import torch
         self.world = world
-        self.n = n_env_local
-        self.stage = [torch.empty((n_env_local, 2), dtype=torch.int32, device=device) for _ in range(2)]
-        self.out = [torch.empty((world * n_env_local, 2), dtype=torch.int32, device=device) for _ in range(2)]
+        self.records = records
+        n = records.shape[1]
+        self.out = [torch.empty((world * n, 2), dtype=torch.int32, device=records.device) for _ in range(2)]
         self.work = [None, None]
-        self.k = 0
 
-    def launch(self, reward, status):
+    def launch(self, step):
+        """Start gathering the records of (0-based) step `step`; returns the buffer index."""
         import torch.distributed as dist
-        k = self.k
+        k = step & 1
         if self.work[k] is not None:
             self.work[k].wait()
-        self.stage[k].copy_(pack_record(reward, status))
+            self.work[k] = None
         if self.world > 1:
-            self.work[k] = dist.all_gather_into_tensor(self.out[k], self.stage[k], async_op=True)
+            self.work[k] = dist.all_gather_into_tensor(self.out[k], self.records[k], async_op=True)
         else:
-            self.out[k].copy_(self.stage[k])
-        self.k ^= 1
+            self.out[k].copy_(self.records[k])
         return k
 
     def wait(self, k=None):
@@ -84,6 +87,6 @@ class ResultGather:
                 self.work[i] = None
 
     def result(self, k):
-        """(reward f32[world*E], status u8[world*E,4]) of launch k, rank-major env order."""
+        """(reward f32[world*E], status u8[world*E,4]) of buffer k, rank-major env order."""
         self.wait(k)
         return unpack_record(self.out[k])

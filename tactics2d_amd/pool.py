@@ -126,6 +126,8 @@ class ParticipantPool:
         n = self.n_env if field in L.PER_ENV_FIELDS else self.n
         if field == L.F_STATUS:
             out = np.empty((n, 4), dt)
+        elif field == L.F_RECORD:
+            out = np.empty((2, n, 2), dt)
         else:
             out = np.empty(n, dt)
         self._ck(self._lib.t2d_download(self._h, field, _p(out), out.nbytes))
@@ -148,7 +150,7 @@ class ParticipantPool:
         """Object exposing __cuda_array_interface__ (zero-copy) for torch.as_tensor."""
         ptr, nb = self.field_ptr(field)
         dt = np.dtype(L.FIELD_DTYPES[field])
-        shape = (nb // 4, 4) if field == L.F_STATUS else (nb // dt.itemsize,)
+        shape = (nb // 4, 4) if field == L.F_STATUS else (2, nb // 16, 2) if field == L.F_RECORD else (nb // dt.itemsize,)
         return _DevArray(ptr, shape, dt.str, self)
 
     # ---------------------------------------------------------------- the hot path
@@ -168,6 +170,10 @@ class ParticipantPool:
     def restore(self, done_only=False, stream=None):
         """Device-side reset to the snapshot: all envs, or only terminated/truncated ones."""
         self._ck(self._lib.t2d_restore(self._h, 1 if done_only else 0, stream))
+
+    def set_auto_reset(self, on=True):
+        """Fuse the reset of finished envs (to the snapshot) into every step()."""
+        self._ck(self._lib.t2d_set_auto_reset(self._h, int(bool(on))))
 
     def sync(self):
         self._ck(self._lib.t2d_sync(self._h))

@@ -23,19 +23,19 @@ def _worker(rank, world, port, n_env_total, out_dir):
     assert (r, w) == (rank, world)
     lo, hi = D.shard_range(n_env_total, rank, world)
     n = hi - lo
-    g = D.ResultGather(n, world, torch.device("cpu"))
-    results = []
+    records = torch.zeros((2, n, 2), dtype=torch.int32)   # stands in for the pool's T2D_F_RECORD field
+    g = D.ResultGather(records, world)
     for step in range(3):
-        # what the pool would hold after a step: reward and status of the local envs
+        # what the step kernel writes: reward bits + status word of the local envs, half = step & 1
         env = torch.arange(lo, hi, dtype=torch.float32)
         reward = -0.001 * (step + 1) - env
         status = torch.stack([(torch.arange(lo, hi) % 6 + 1).to(torch.uint8),
                               torch.full((n,), 1 + step, dtype=torch.uint8),
                               torch.zeros(n, dtype=torch.uint8),
                               (torch.arange(lo, hi) % 2).to(torch.uint8)], 1)
-        k = g.launch(reward, status)
-        reward.fill_(99.0)  # the next step overwrites the pool buffers while the gather is in flight
-        results.append(k)
+        records[step & 1].copy_(D.pack_record(reward, status))
+        k = g.launch(step)
+        records[(step + 1) & 1].fill_(-1)  # the next step overwrites the OTHER half while this gather flies
         rw, st = g.result(k)
         np.save(os.path.join(out_dir, f"r{rank}_s{step}_rw.npy"), rw.numpy())
         np.save(os.path.join(out_dir, f"r{rank}_s{step}_st.npy"), st.numpy())

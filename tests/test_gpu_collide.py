@@ -105,7 +105,44 @@ def test_step_status_reward_matches_oracle(oracle):
         assert (gst == wst).all(), np.nonzero((gst != wst).any(1))[0][:5]
         grw = pool.download(L.F_REWARD)
         assert np.allclose(grw, wrw, rtol=0, atol=1e-9), np.abs(grw - wrw).max()
+        rec = pool.download(L.F_RECORD)[step & 1]          # packed 8-byte records, half = step parity
+        assert np.array_equal(rec[:, 0].view(np.float32), grw)
+        assert np.array_equal(rec[:, 1].copy().view(np.uint8).reshape(-1, 4), gst)
         seen |= set(map(tuple, gst[:, :2].tolist()))
     pool.close()
     # NORMAL, TIME_EXCEEDED, OUT_BOUND, FAILED/static, FAILED/dynamic must all have occurred
     assert {(1, 1), (3, 1), (4, 1), (6, 3)} <= seen, seen
+
+
+def test_fused_auto_reset_matches_explicit_restore():
+    """t2d_set_auto_reset: finished envs return to the snapshot inside the step launch; the result must
+    equal step + t2d_restore(mode 1), except that status / reward keep the terminal values."""
+    from tactics2d_amd import layout as L, scenarios as S
+    from tactics2d_amd.pool import ParticipantPool
+    sc = S.mixed(48, 64, seed=5)
+    sc.status = dict(max_step=7, check_dynamic=1, check_off_lane=1)
+    rng = np.random.default_rng(1)
+    acts = [sc.sample_actions(rng) for _ in range(12)]
+    pools = []
+    for fused in (False, True):
+        pool = ParticipantPool(sc.n_env, sc.A)
+        sc.load(pool)
+        if fused:
+            pool.set_auto_reset(True)
+        pools.append(pool)
+    n_done = 0
+    for a0, a1 in acts:
+        for fused, pool in zip((False, True), pools):
+            pool.set_actions(a0, a1)
+            pool.step(100)
+        st_terminal = pools[0].download(L.F_STATUS)
+        rw_terminal = pools[0].download(L.F_REWARD)
+        pools[0].restore(done_only=True)
+        for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_VX, L.F_VY, L.F_IDS, L.F_CNT_STEP, L.F_FRAME_MS):
+            assert np.array_equal(pools[0].download(f), pools[1].download(f), equal_nan=True), f
+        assert np.array_equal(pools[1].download(L.F_STATUS), st_terminal)      # terminal status stays visible
+        assert np.array_equal(pools[1].download(L.F_REWARD), rw_terminal)
+        n_done += int((st_terminal[:, 2] | st_terminal[:, 3]).sum())
+    assert n_done > 20
+    for p in pools:
+        p.close()
