@@ -210,8 +210,16 @@ def main():
             per_launch = {"integrate_kernel": INTEGRATOR_BYTES * N, "collide_kernel": COLLIDE_BYTES * N + geo_bytes}
             dom = max(kern, key=lambda k_: kern[k_]["avg_us"])
             ach = per_launch[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            traffic, traffic_src = None, None
+            tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tf):   # PMC counters cannot be read from inside the process: taken from the
+                tj = json.load(open(tf))  # committed rocprofv3 pass of the same workload (scripts/profile_round.sh)
+                if (tj.get("config"), tj.get("envs_per_gpu"), tj.get("participants_per_env")) == (args.config, n_env, agents):
+                    traffic = tj["hbm_bytes_per_launch"].get(dom)
+                    traffic_src = f"profiles/traffic_latest.json ({tj.get('tag')}): " + tj.get("source", "")
             roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=ach / HBM_PEAK_GBS, traffic=None,
+                        frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                        timed_over="second pass of the same steps with HIP events on the launch stream around each kernel",
                         algorithmic_bytes_per_launch=per_launch[dom], avg_kernel_us=kern[dom]["avg_us"],
                         kernels={k_: dict(avg_us=v["avg_us"], launches=v["launches"],
                                           algorithmic_bytes=per_launch[k_],
