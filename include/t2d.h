@@ -29,6 +29,7 @@
  *                            OutBound.update                 traffic/event_detection/out_bound.py:37-48
  *                            OffLane.update                  traffic/event_detection/off_lane.py:16-17 (stub; build-defined)
  *   t2d_snapshot/restore  <- ParkingEnv.reset / _ParkingScenarioManager.reset       envs/parking.py:262-298,397-441
+ *   t2d_check_status      <- _ParkingScenarioManager.check_status           envs/parking.py:361-392
  *   t2d_step              <- _ParkingScenarioManager.update + check_status  envs/parking.py:352-392
  *                            ParkingEnv.step terminated/truncated/reward    envs/parking.py:219-256,148-161
  *                            TimeExceed.update               traffic/event_detection/time_exceed.py:26-33
@@ -220,6 +221,9 @@ int t2d_bind_actions(t2d_pool* pool, const float* act0_dev, const float* act1_de
 int t2d_integrate(t2d_pool* pool, int32_t interval_ms, void* hip_stream);
 /* Events only: recompute FLAGS / ENV_FLAGS from the current poses.                      */
 int t2d_collide(t2d_pool* pool, void* hip_stream);
+/* ScenarioManager.check_status alone (envs/parking.py:361-392): events + the status / reward /
+ * counter epilogue on the current poses (what t2d_step runs after the integrator).         */
+int t2d_check_status(t2d_pool* pool, int32_t interval_ms, void* hip_stream);
 /* ScenarioManager.update + check_status: integrate, collide, status/reward epilogue.    */
 int t2d_step(t2d_pool* pool, int32_t interval_ms, void* hip_stream);
 

@@ -47,6 +47,7 @@ SYMBOLS = {
     "t2d_bind_actions": (C.c_int, [_vp, _vp, _vp]),
     "t2d_integrate": (C.c_int, [_vp, C.c_int32, _vp]),
     "t2d_collide": (C.c_int, [_vp, _vp]),
+    "t2d_check_status": (C.c_int, [_vp, C.c_int32, _vp]),
     "t2d_step": (C.c_int, [_vp, C.c_int32, _vp]),
     "t2d_get_field": (C.c_int, [_vp, C.c_int32, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "t2d_download": (C.c_int, [_vp, C.c_int32, _vp, C.c_size_t]),

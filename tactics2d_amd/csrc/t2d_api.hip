@@ -545,13 +545,21 @@ int t2d_collide(t2d_pool* p, void* hip_stream) {
     return collide_impl(p, false, 0, (hipStream_t)hip_stream);
 }
 
+int t2d_check_status(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!p->have_params || !p->have_reset)
+        return fail(p, T2D_ERR_STATE, "t2d_set_param_table and t2d_reset must precede t2d_check_status");
+    if (interval_ms <= 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be positive");
+    p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)(p->step_count & 1) * p->v.n_env;
+    int rc = collide_impl(p, true, interval_ms, (hipStream_t)hip_stream);
+    if (rc == T2D_OK) p->step_count++;
+    return rc;
+}
+
 int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     int rc = t2d_integrate(p, interval_ms, hip_stream);
     if (rc != T2D_OK) return rc;
-    p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)(p->step_count & 1) * p->v.n_env;
-    rc = collide_impl(p, true, interval_ms, (hipStream_t)hip_stream);
-    if (rc == T2D_OK) p->step_count++;
-    return rc;
+    return t2d_check_status(p, interval_ms, hip_stream);
 }
 
 int t2d_snapshot(t2d_pool* p) {

@@ -1,0 +1,163 @@
+"""Gym-style environments on top of the batched hot path.
+
+Mirrors (tactics2d v0.1.9rc3) `ParkingEnv` -- envs/parking.py:44-444 -- for the part that is on
+the accelerated path: `step()` = physics update of the ego (`_ParkingScenarioManager.update`, :352-359)
++ ordered status checks (`check_status`, :361-392) + terminated / truncated / reward (:243-250,
+:148-166).  The rendered camera observation, the lidar and the IoU-based events (`Arrival`,
+`NoAction`) are "next" rows of the scope table: observations here are the ego
+state vector, `COMPLETED` / `NO_ACTION` never occur, and the reward is the reference's table value
+for terminal events plus its time penalty (no IoU / distance shaping).
+
+gymnasium is not a dependency: `Box` below is the minimal stand-in for `spaces.Box`.
+"""
+import numpy as np
+
+from . import layout as L, scenarios
+from .traffic import BatchedScenarioManager, ScenarioStatus, TrafficStatus
+
+MAX_STEER = 0.524  # envs/parking.py:30
+MAX_ACCEL = 2.0    # envs/parking.py:31
+
+
+class InvalidAction(Exception):
+    """Same role as gymnasium.error.InvalidAction in envs/parking.py:235-236."""
+
+
+class Box:
+    def __init__(self, low, high, dtype=np.float32):
+        self.low = np.asarray(low, dtype)
+        self.high = np.asarray(high, dtype)
+        self.shape = self.low.shape
+        self.dtype = np.dtype(dtype)
+
+    def contains(self, a):
+        a = np.asarray(a)
+        return a.shape[-len(self.shape):] == self.shape and bool(np.all(a >= self.low) and np.all(a <= self.high))
+
+    def sample(self, rng, n=None):
+        size = self.shape if n is None else (n,) + self.shape
+        return rng.uniform(self.low, self.high, size).astype(self.dtype)
+
+
+class VecParkingEnv:
+    """n_envs independent ParkingEnv scenes stepped by one t2d_step per call.
+
+    step(actions[n_envs, 2]) -> (obs[n_envs, 6], reward[n_envs], terminated[n_envs], truncated[n_envs], infos)
+    The action layout is the reference's: (steering, accel) (envs/parking.py:239)."""
+
+    _max_steer = MAX_STEER
+    _max_accel = MAX_ACCEL
+    _discrete_actions = {1: (0, 0), 2: (-0.5, 0), 3: (0.5, 0), 4: (0, 1), 5: (0, -1)}  # parking.py:95
+
+    def __init__(self, n_envs, max_step=int(2e4), continuous=True, auto_reset=False, seed=0, device_id=0):
+        self.n_envs = int(n_envs)
+        self.max_step = max_step
+        self.continuous = continuous
+        self.auto_reset = auto_reset
+        self.observation_space = Box(np.full(6, -np.inf), np.full(6, np.inf))
+        self.action_space = Box([-self._max_steer, -self._max_accel], [self._max_steer, self._max_accel])
+        # ScenarioManager(max_step, step_size=100, ...)  envs/parking.py:144-146
+        self.scenario_manager = BatchedScenarioManager(self.n_envs, 1, max_step, 100, device_id=device_id)
+        self._seed = seed
+        self._scene = None
+
+    # ------------------------------------------------------------------ reset
+    def reset(self, seed=None, options=None):
+        """New scenes for every env (ParkingLotGenerator-like bay layouts, scenarios.parking)."""
+        if seed is not None:
+            self._seed = int(seed)
+        sc = scenarios.parking(self.n_envs, seed0=self._seed * self.n_envs)
+        self._scene = sc
+        m = self.scenario_manager
+        m.configure(sc.rows, check_dynamic=False, check_off_lane=False)
+        m.status_checklist["collision"].reset(_csr_to_lists(sc.static))
+        m.status_checklist["out_bound"].reset(sc.boundary)
+        m.reset(sc.x, sc.y, sc.heading, sc.speed, sc.type_id, sc.active)
+        m.pool.set_auto_reset(self.auto_reset)
+        obs = m.get_observation()
+        n = self.n_envs
+        return obs, self._infos(obs, np.full(n, ScenarioStatus.NORMAL, np.uint8), np.full(n, TrafficStatus.NORMAL, np.uint8))
+
+    # ------------------------------------------------------------------ step
+    def _to_continuous(self, actions):
+        if self.continuous:
+            a = np.asarray(actions, np.float32).reshape(self.n_envs, 2)
+            if not (np.all(a >= self.action_space.low) and np.all(a <= self.action_space.high)):
+                raise InvalidAction(f"Action {actions} is not in the action space.")
+            return a
+        idx = np.asarray(actions).reshape(self.n_envs)
+        if not np.all(np.isin(idx, list(self._discrete_actions))):
+            raise InvalidAction(f"Action {actions} is not in the action space.")
+        return np.array([self._discrete_actions[int(i)] for i in idx], np.float32)
+
+    def step(self, actions):
+        if self._scene is None:
+            raise RuntimeError("call reset() first")
+        a = self._to_continuous(actions)
+        m = self.scenario_manager
+        m.step(a[:, 1], a[:, 0])  # physics_model.step(state, accel, steering)  parking.py:355
+        pool = m.pool
+        status = pool.download(L.F_STATUS)
+        reward = pool.download(L.F_REWARD)
+        obs = m.get_observation()
+        terminated = status[:, 2].astype(bool)
+        truncated = status[:, 3].astype(bool)
+        return obs, reward, terminated, truncated, self._infos(obs, status[:, 0], status[:, 1])
+
+    def _infos(self, obs, scenario_status, traffic_status):
+        return dict(state=dict(x=obs[:, 0], y=obs[:, 1], heading=obs[:, 2], speed=obs[:, 3], vx=obs[:, 4],
+                               vy=obs[:, 5], frame=self.scenario_manager.pool.download(L.F_FRAME_MS)),
+                    scenario_status=scenario_status, traffic_status=traffic_status,
+                    target_area=None, target_heading=None, lidar=None)
+
+    def render(self):
+        raise NotImplementedError("rendering is outside the accelerated path")
+
+    def close(self):
+        self.scenario_manager.close()
+
+
+class ParkingEnv:
+    """Single-scene adapter with the reference's 5-tuple (envs/parking.py:256)."""
+
+    def __init__(self, type_proportion=0.5, render_mode="rgb_array", render_fps=60, max_step=int(2e4),
+                 continuous=True, seed=0):
+        if render_mode not in ("human", "rgb_array"):
+            raise NotImplementedError(f"Render mode {render_mode} is not supported.")  # parking.py:119-120
+        self.max_step = max_step
+        self.continuous = continuous
+        self._vec = VecParkingEnv(1, max_step, continuous, seed=seed)
+        self.observation_space = self._vec.observation_space
+        self.action_space = self._vec.action_space
+        self.scenario_manager = self._vec.scenario_manager
+
+    def reset(self, seed=None, options=None):
+        obs, infos = self._vec.reset(seed, options)
+        return obs[0], _first(infos)
+
+    def step(self, action):
+        if self.continuous and not self.action_space.contains(np.asarray(action, np.float32)):
+            raise InvalidAction(f"Action {action} is not in the action space.")
+        obs, reward, terminated, truncated, infos = self._vec.step([action])
+        infos = _first(infos)
+        infos["scenario_status"] = ScenarioStatus(int(infos["scenario_status"]))
+        infos["traffic_status"] = TrafficStatus(int(infos["traffic_status"]))
+        return obs[0], float(reward[0]), bool(terminated[0]), bool(truncated[0]), infos
+
+    def close(self):
+        self._vec.close()
+
+
+def _first(infos):
+    out = {}
+    for k, v in infos.items():
+        if isinstance(v, dict):
+            out[k] = {kk: (vv[0] if vv is not None else None) for kk, vv in v.items()}
+        else:
+            out[k] = v[0] if isinstance(v, np.ndarray) else v
+    return out
+
+
+def _csr_to_lists(csr):
+    eo, vo, xy = csr
+    return [[xy[vo[p]:vo[p + 1]] for p in range(eo[e], eo[e + 1])] for e in range(len(eo) - 1)]

@@ -160,6 +160,9 @@ class ParticipantPool:
     def collide(self, stream=None):
         self._ck(self._lib.t2d_collide(self._h, stream))
 
+    def check_status(self, interval_ms=100, stream=None):
+        self._ck(self._lib.t2d_check_status(self._h, int(interval_ms), stream))
+
     def step(self, interval_ms=100, stream=None):
         self._ck(self._lib.t2d_step(self._h, int(interval_ms), stream))
 

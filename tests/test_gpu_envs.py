@@ -1,0 +1,89 @@
+"""The Gym-style / ScenarioManager mirrors running on the MI355X (through the C ABI)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_vec_parking_env_step_contract(oracle):
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.envs import InvalidAction, VecParkingEnv
+    from tactics2d_amd.traffic import ScenarioStatus, TrafficStatus
+    env = VecParkingEnv(256, max_step=50, seed=3)
+    obs, infos = env.reset()
+    assert obs.shape == (256, 6) and obs.dtype == np.float32
+    assert (infos["scenario_status"] == ScenarioStatus.NORMAL).all()
+    with pytest.raises(InvalidAction):
+        env.step(np.tile([0.6, 0.0], (256, 1)))              # steering outside +-0.524 (parking.py:235-236)
+    rng = np.random.default_rng(0)
+    seen = set()
+    sc = env._scene
+    x, y, h, v = sc.x.copy(), sc.y.copy(), sc.heading.copy(), sc.speed.copy()
+    for t in range(60):
+        act = env.action_space.sample(rng, 256)
+        act[:, 1] = np.abs(act[:, 1])                         # keep accelerating: reach walls / boundary
+        obs, reward, terminated, truncated, infos = env.step(act)
+        # physics parity of the env step against the oracle (teacher-forced on the pool's fp32 state)
+        o = oracle.integrate(sc.rows, x, y, h, v, None, None, act[:, 1], act[:, 0], sc.type_id, sc.active, 100)
+        assert np.abs(obs[:, :4] - o[:, :4]).max() <= 1e-5
+        x, y, h, v = obs[:, 0].copy(), obs[:, 1].copy(), obs[:, 2].copy(), obs[:, 3].copy()
+        assert reward.shape == (256,) and terminated.dtype == bool and truncated.dtype == bool
+        assert not terminated.any()                           # COMPLETED needs the IoU row (next)
+        st = infos["scenario_status"]; tr = infos["traffic_status"]
+        assert (truncated == ((st != 1) | (tr != 1))).all()   # parking.py:247-248
+        assert (reward[st == ScenarioStatus.TIME_EXCEEDED] == -1).all()
+        assert (reward[st == ScenarioStatus.OUT_BOUND] == -5).all()
+        assert (reward[tr == TrafficStatus.COLLISION_STATIC] == -5).all()
+        normal = (st == 1) & (tr == 1)
+        assert np.allclose(reward[normal], -np.tanh((t + 1) / 50) * 0.001, atol=1e-7)
+        seen |= set(zip(st.tolist(), tr.tolist()))
+    assert (3, 1) in seen and (1, 1) in seen                  # time exceeded after 50 steps
+    assert (infos["state"]["frame"] == 6000).all()
+    env.close()
+
+
+def test_parking_env_adapter_returns_the_reference_5_tuple():
+    from tactics2d_amd.envs import InvalidAction, ParkingEnv
+    from tactics2d_amd.traffic import ScenarioStatus, TrafficStatus
+    env = ParkingEnv(max_step=20000, seed=1)
+    obs, infos = env.reset()
+    assert obs.shape == (6,)
+    out = env.step(np.array([0.1, 1.0], np.float32))
+    assert len(out) == 5
+    obs, reward, terminated, truncated, infos = out
+    assert isinstance(reward, float) and isinstance(terminated, bool) and isinstance(truncated, bool)
+    assert isinstance(infos["scenario_status"], ScenarioStatus) and isinstance(infos["traffic_status"], TrafficStatus)
+    assert infos["state"]["frame"] == 100 and abs(infos["state"]["speed"] - 0.1) < 1e-6   # a = 1 m/s^2 for 0.1 s
+    with pytest.raises(InvalidAction):
+        env.step(np.array([0.0, 2.5], np.float32))
+    env.close()
+
+
+def test_scenario_manager_update_then_check_status_equals_step():
+    from tactics2d_amd import layout as L, scenarios as S
+    from tactics2d_amd.traffic import BatchedScenarioManager
+    sc = S.intersection(24, 32, seed=9)
+    rng = np.random.default_rng(2)
+    res = []
+    for split in (False, True):
+        m = BatchedScenarioManager(sc.n_env, sc.A, max_step=100, step_size=100)
+        m.configure(sc.rows, check_dynamic=True, check_off_lane=True)
+        m._static, m._boundary, m._lanes = sc.static, sc.boundary, sc.lanes
+        m._push_geometry(); m.pool.set_lane_geometry(sc.lanes)
+        m.reset(sc.x, sc.y, sc.heading, sc.speed, sc.type_id, sc.active)
+        r = np.random.default_rng(5)
+        for _ in range(5):
+            a0, a1 = sc.sample_actions(r)
+            if split:
+                m.update(a0, a1)
+                scen, traf = m.check_status()
+            else:
+                m.step(a0, a1)
+        res.append([m.pool.download(f) for f in (L.F_X, L.F_HEADING, L.F_FLAGS, L.F_STATUS, L.F_REWARD, L.F_CNT_STEP)])
+        assert len(m.get_active_participants()) == sc.n_env and m.get_observation().shape == (sc.n_env, 6)
+        assert m.status_checklist["out_bound"].update().shape == (sc.n_env,)
+        assert m.status_checklist["dynamic_collision"].update(ego_only=False).shape == (sc.n_env, sc.A)
+        m.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+    assert (res[0][5] == 5).all()

@@ -111,3 +111,25 @@ def test_shard_ranges_cover_every_env_once():
         assert all(got[i][1] == got[i + 1][0] for i in range(world - 1))
         sizes = [hi - lo for lo, hi in got]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_status_enums_match_the_reference_values():
+    """traffic/status.py:10-61 and the C ABI's T2D_SCENARIO_* / T2D_TRAFFIC_* constants."""
+    from tactics2d_amd.traffic import ScenarioStatus, TrafficStatus
+    assert [s.value for s in ScenarioStatus] == [1, 2, 3, 4, 5, 6]
+    assert (ScenarioStatus.TIME_EXCEEDED, ScenarioStatus.OUT_BOUND, ScenarioStatus.FAILED) == (3, 4, 6)
+    assert (TrafficStatus.COLLISION_STATIC, TrafficStatus.COLLISION_DYNAMIC, TrafficStatus.OFF_LANE) == (3, 4, 6)
+    import re, os
+    h = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "t2d.h")).read()
+    for name, val in re.findall(r"#define\s+T2D_SCENARIO_(\w+)\s+(\d+)", h):
+        assert ScenarioStatus[name] == int(val)
+    for name, val in re.findall(r"#define\s+T2D_TRAFFIC_(\w+)\s+(\d+)", h):
+        assert TrafficStatus[name] == int(val)
+
+
+def test_action_space_and_discrete_table():
+    """ParkingEnv action box (envs/parking.py:130-139) and discrete table (:95)."""
+    from tactics2d_amd.envs import MAX_ACCEL, MAX_STEER, Box, VecParkingEnv
+    b = Box([-MAX_STEER, -MAX_ACCEL], [MAX_STEER, MAX_ACCEL])
+    assert b.contains(np.float32([0.524, -2.0])) and not b.contains(np.float32([0.53, 0.0]))
+    assert VecParkingEnv._discrete_actions == {1: (0, 0), 2: (-0.5, 0), 3: (0.5, 0), 4: (0, 1), 5: (0, -1)}
