@@ -71,6 +71,23 @@ class Scene:
         pool.reset(self.x, self.y, self.heading, self.speed, self.type_id, self.active)
         pool.snapshot()
 
+    def shard(self, lo, hi):
+        """The scenes [lo, hi) as a Scene of their own (what one rank of an env-sharded job owns)."""
+        def cut(csr):
+            if csr is None:
+                return None
+            eo, vo, xy = csr
+            p0, p1 = eo[lo], eo[hi]
+            return (eo[lo:hi + 1] - p0).astype(np.int32), (vo[p0:p1 + 1] - vo[p0]).astype(np.int32), \
+                xy[vo[p0]:vo[p1]].copy()
+        sl = slice(lo * self.A, hi * self.A)
+        return Scene(self.name, hi - lo, self.A, self.rows, self.type_names, self.x[sl].copy(), self.y[sl].copy(),
+                     self.heading[sl].copy(), self.speed[sl].copy(), self.type_id[sl].copy(), self.active[sl].copy(),
+                     static=cut(self.static), lanes=cut(self.lanes),
+                     boundary=None if self.boundary is None else self.boundary[lo:hi].copy(),
+                     boundary_valid=None if self.boundary_valid is None else self.boundary_valid[lo:hi].copy(),
+                     status=dict(self.status), interval_ms=self.interval_ms)
+
     def sample_actions(self, rng):
         """One batch of random actions in the reference's action conventions:
         vehicles (accel U(-3, 2), steer N(0, 0.02) -- parking: the ParkingEnv action box

@@ -1,0 +1,160 @@
+"""BASELINE.json's configs at FULL size on one MI355X, checked through size-independent properties
+(the oracle cannot step half a million participants in seconds):
+  * oracle spot check: a random sample of envs of the full run, bit-exact (state via the exact variant,
+    flags, status) against the oracle;
+  * shard consistency: a pool holding only envs [lo, hi) reproduces the big pool's slice bit for bit
+    (what env-sharding across GPUs relies on);
+  * permutation: re-ordering the agents inside every env permutes states and flags and changes nothing else;
+  * idempotence: a second t2d_collide on the same poses returns the same flags;
+  * fast vs exact integrator variants agree to 1e-6 on the stored fp32 state.
+"""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+STATE = None
+
+
+def _fields():
+    from tactics2d_amd import layout as L
+    return (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_VX, L.F_VY)
+
+
+def _run(sc, acts, variant="exact", collect_pre=False):
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    pool = ParticipantPool(sc.n_env, sc.A)
+    sc.load(pool)
+    pool.set_integrator_variant(variant)
+    pre = None
+    for k, (a0, a1) in enumerate(acts):
+        if collect_pre and k == len(acts) - 1:
+            pre = [pool.download(f) for f in _fields()] + [pool.download(L.F_CNT_STEP), pool.download(L.F_FRAME_MS)]
+        pool.set_actions(a0, a1)
+        pool.step(100)
+    out = dict(state=[pool.download(f) for f in _fields()], flags=pool.download(L.F_FLAGS),
+               env_flags=pool.download(L.F_ENV_FLAGS), status=pool.download(L.F_STATUS),
+               reward=pool.download(L.F_REWARD), cnt=pool.download(L.F_CNT_STEP), pre=pre)
+    pool.collide()
+    out["flags_again"] = pool.download(L.F_FLAGS)
+    pool.close()
+    return out
+
+
+def _scene(name):
+    from tactics2d_amd import scenarios as S
+    return {"cfg2": lambda: S.parking(4096), "cfg3": lambda: S.highway(1024, 64),
+            "cfg4": lambda: S.intersection(2048, 32), "cfg5": lambda: S.mixed(8192, 64),
+            "metric": lambda: S.mixed(4096, 64)}[name]()
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5", "metric"])
+def test_full_size_config(oracle, name):
+    from oracle.oracle import StatusConfig
+    sc = _scene(name)
+    rng = np.random.default_rng(17)
+    acts = [sc.sample_actions(rng) for _ in range(3)]
+    # stress jitter (test only): scatter the start poses so that every predicate fires within 3 steps
+    jx, jy = {"cfg2": (4.0, 5.0), "cfg3": (3.0, 2.5), "cfg4": (3.0, 3.0)}.get(name, (3.0, 3.0))
+    sc.x = (sc.x + rng.normal(0, jx, sc.n)).astype(np.float32)
+    sc.y = (sc.y + rng.normal(0, jy, sc.n)).astype(np.float32)
+    sc.heading = np.mod(sc.heading + rng.normal(0, 0.3, sc.n), 2 * np.pi).astype(np.float32)
+    if name == "cfg2":
+        sc.speed[:] = np.where(np.arange(sc.n) % 2 == 0, 0.5, -0.5)
+        sc.boundary[::3, 1] = sc.boundary[::3, 0] + 20.0      # shrink every third map: out-of-bound fires
+    big = _run(sc, acts, "exact", collect_pre=True)
+
+    # idempotence of the event kernel
+    assert np.array_equal(big["flags"], big["flags_again"])
+    assert np.isfinite(np.stack(big["state"][:4])).all()
+
+    # ---- oracle spot check on a sample of envs (last step, teacher-forced on the pool's fp32 state)
+    E, A = sc.n_env, sc.A
+    envs = np.sort(rng.choice(E, size=min(E, 40), replace=False))
+    idx = (envs[:, None] * A + np.arange(A)[None]).reshape(-1)
+    pre = big["pre"]
+    a0, a1 = acts[-1]
+    oracle.set_trig(1)
+    o = oracle.integrate(sc.rows, pre[0][idx], pre[1][idx], pre[2][idx], pre[3][idx], pre[4][idx], pre[5][idx],
+                         a0[idx], a1[idx], sc.type_id[idx], sc.active[idx], 100)
+    oracle.set_trig(0)
+    for c in range(4):
+        assert np.array_equal(np.float32(o[:, c]), big["state"][c][idx]), f"{name}: state column {c}"
+    sub = sc.shard(0, E)  # full CSR; pick the sampled envs one by one for the oracle
+    wf_all = []
+    for e in envs:
+        one = sc.shard(int(e), int(e) + 1)
+        sl = slice(e * A, (e + 1) * A)
+        wf, we = oracle.collide(sc.rows, 1, A, big["state"][0][sl], big["state"][1][sl], big["state"][2][sl],
+                                one.type_id, one.active, one.static, one.boundary, one.boundary_valid, one.lanes, 0)
+        assert np.array_equal(wf, big["flags"][sl]), f"{name}: flags of env {e}"
+        assert we[0] == big["env_flags"][e]
+        wf_all.append(wf)
+    st = sc.status
+    cfg = StatusConfig(st.get("max_step", 20000), 0, st.get("check_dynamic", 0), st.get("check_off_lane", 0),
+                       -5.0, -1.0, -5.0, 5.0, 0.001)
+    cnt = pre[6][envs].copy(); frame = pre[7][envs].copy()
+    wst, wrw = oracle.status(cfg, len(envs), A, np.concatenate(wf_all), 100, cnt, frame)
+    assert np.array_equal(wst, big["status"][envs]) and np.array_equal(cnt, big["cnt"][envs])
+    assert np.allclose(wrw, big["reward"][envs], rtol=0, atol=1e-9)
+    del sub
+
+    # ---- shard consistency: envs [lo, hi) alone == the slice of the big pool
+    lo, hi = E // 3, E // 3 + min(E // 4, 160)
+    part = sc.shard(lo, hi)
+    pacts = [(a0[lo * A:hi * A], a1[lo * A:hi * A]) for a0, a1 in acts]
+    small = _run(part, pacts, "exact")
+    for c in range(6):
+        assert np.array_equal(small["state"][c], big["state"][c][lo * A:hi * A], equal_nan=True)
+    assert np.array_equal(small["flags"], big["flags"][lo * A:hi * A])
+    assert np.array_equal(small["status"], big["status"][lo:hi]) and np.array_equal(small["reward"], big["reward"][lo:hi])
+
+    # ---- fast vs exact variant
+    fast = _run(sc, acts, "fast")
+    from tactics2d_amd import layout as L
+    dyn = sc.rows[sc.type_id, L.P_MODEL] == L.MODEL_DYNAMICS
+    stiff = dyn & (np.abs(sc.speed) < 3.0)        # initial speed: 3 steps cannot leave/enter the band otherwise
+    ok = sc.active.astype(bool) & ~stiff
+    for c in (0, 1, 3):
+        assert np.abs(fast["state"][c][ok] - big["state"][c][ok]).max() <= 2e-5, c
+    assert H.ang_err(fast["state"][2][ok], big["state"][2][ok]).max() <= 1e-6
+    # flags may only differ where a pose moved by an fp32 ulp across a touching configuration: rare
+    assert (fast["flags"] != big["flags"]).mean() < 1e-4
+
+    # event rates: the scenes must exercise the predicates at full size
+    rates = [(big["flags"] & b).astype(bool).mean() for b in (1, 2, 4, 8)]
+    if A > 1:
+        assert rates[0] > 0.005
+    assert rates[2] > 0.002 or name not in ("cfg2",)
+    if sc.static is not None and sc.static[0][-1] > 0:
+        assert rates[1] > 0.001, rates
+    if sc.lanes is not None:
+        assert rates[3] > 0.005
+    print(f"{name}: E={E} A={A} flag rates dyn/static/out/lane = {np.round(rates, 4)}; "
+          f"status counts = {dict(zip(*np.unique(big['status'][:, 0], return_counts=True)))}")
+
+
+def test_agent_permutation_property():
+    """Re-ordering the agents of every env permutes per-participant results and nothing else."""
+    from tactics2d_amd import scenarios as S
+    sc = S.mixed(96, 64, seed=21)
+    rng = np.random.default_rng(4)
+    acts = [sc.sample_actions(rng) for _ in range(4)]
+    base = _run(sc, acts, "exact")
+    A = sc.A
+    perm = rng.permutation(A)
+    perm = np.concatenate([[0], perm[perm != 0]])      # the ego (agent 0) drives the env status: keep it
+    gidx = (np.arange(sc.n_env)[:, None] * A + perm[None]).reshape(-1)
+    import copy
+    sc2 = copy.copy(sc)
+    for f in ("x", "y", "heading", "speed", "type_id", "active"):
+        setattr(sc2, f, getattr(sc, f)[gidx].copy())
+    acts2 = [(a0[gidx], a1[gidx]) for a0, a1 in acts]
+    out = _run(sc2, acts2, "exact")
+    for c in range(6):
+        assert np.array_equal(out["state"][c], base["state"][c][gidx], equal_nan=True)
+    assert np.array_equal(out["flags"], base["flags"][gidx])
+    assert np.array_equal(out["env_flags"], base["env_flags"]) and np.array_equal(out["status"], base["status"])
