@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events")
     ap.add_argument("--no-reset", action="store_true", help="skip the device-side auto-reset")
+    ap.add_argument("--split", action="store_true", help="two-kernel step (integrate + check_status) instead of the fused launch")
     args = ap.parse_args()
 
     import torch
@@ -131,6 +132,7 @@ def main():
     pool = ParticipantPool(n_env, agents, device_id=local_rank)
     scene.load(pool)
     pool.set_integrator_variant(args.variant)
+    pool.set_fused_step(not args.split)
     if not args.no_reset:
         pool.set_auto_reset(True)   # finished envs restart inside the step launch (no extra kernels)
     N = scene.n
@@ -187,9 +189,21 @@ def main():
         if gather is not None:
             gather.wait()
         barrier()
-        for kid, name in ((0, "integrate_kernel"), (1, "collide_kernel")):
+        for kid, name in ((0, "integrate_kernel"), (1, "collide_kernel"), (2, "step_kernel")):
             ms, launches = pool.profile_read(kid)
-            kern[name] = dict(avg_us=1e3 * ms / max(launches, 1), launches=launches)
+            if launches:
+                kern[name] = dict(avg_us=1e3 * ms / launches, launches=launches)
+        if not args.split:   # also time the two stand-alone kernels (the integrator is north_star's roofline kernel)
+            pool.set_fused_step(False)
+            pool.profile_enable(True)
+            for k in range(min(n_prof, 200)):
+                one_step(k)
+            barrier()
+            for kid, name in ((0, "integrate_kernel"), (1, "collide_kernel")):
+                ms, launches = pool.profile_read(kid)
+                if launches:
+                    kern[name] = dict(avg_us=1e3 * ms / launches, launches=launches)
+            pool.set_fused_step(True)
         pool.profile_enable(False)
 
     # state sanity after the run (not timed): flags/status distribution
@@ -207,8 +221,11 @@ def main():
         geo_bytes += 16 * n_env
         roof = None
         if kern:
-            per_launch = {"integrate_kernel": INTEGRATOR_BYTES * N, "collide_kernel": COLLIDE_BYTES * N + geo_bytes}
-            dom = max(kern, key=lambda k_: kern[k_]["avg_us"])
+            per_launch = {"integrate_kernel": INTEGRATOR_BYTES * N, "collide_kernel": COLLIDE_BYTES * N + geo_bytes,
+                          # fused: the integrator's 44 B + the 4-B flag word (poses never leave registers)
+                          "step_kernel": (INTEGRATOR_BYTES + 4) * N + geo_bytes}
+            in_step = {"step_kernel"} if not args.split else {"integrate_kernel", "collide_kernel"}
+            dom = max(in_step & set(kern), key=lambda k_: kern[k_]["avg_us"])
             ach = per_launch[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
             traffic, traffic_src = None, None
             tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -231,7 +248,7 @@ def main():
                    vs_baseline=None, dtype="f64", data="synthetic",
                    config=dict(workload=f"{scene.name}: {n_env} envs x {agents} participants per GPU, "
                                         f"interval 100 ms / delta_t 5 ms (20 Euler sub-steps), "
-                                        f"integrator variant {args.variant}, auto-reset "
+                                        f"integrator variant {args.variant}, {'two-kernel' if args.split else 'fused single-launch'} step, auto-reset "
                                         f"{'off' if args.no_reset else 'on'}",
                                config=args.config, envs_per_gpu=n_env, participants_per_env=agents,
                                parallelism=f"env-sharded x{world}, RCCL all-gather of 8 B/env records"

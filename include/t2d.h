@@ -224,8 +224,12 @@ int t2d_collide(t2d_pool* pool, void* hip_stream);
 /* ScenarioManager.check_status alone (envs/parking.py:361-392): events + the status / reward /
  * counter epilogue on the current poses (what t2d_step runs after the integrator).         */
 int t2d_check_status(t2d_pool* pool, int32_t interval_ms, void* hip_stream);
-/* ScenarioManager.update + check_status: integrate, collide, status/reward epilogue.    */
+/* ScenarioManager.update + check_status: integrate, collide, status/reward epilogue.  By default
+ * ONE fused launch (the participant is integrated in registers and its new pose feeds the event
+ * phases directly); t2d_set_fused_step(pool, 0) selects the two-kernel form, whose results are
+ * bit-identical.  kernel_id 2 of t2d_profile_read times the fused launch.                   */
 int t2d_step(t2d_pool* pool, int32_t interval_ms, void* hip_stream);
+int t2d_set_fused_step(t2d_pool* pool, int32_t on);
 
 /* Zero-copy device pointer of a field (for wrapping as a torch tensor).                 */
 int t2d_get_field(t2d_pool* pool, int32_t field_id, void** dev_ptr, size_t* nbytes);
@@ -253,7 +257,7 @@ int t2d_set_auto_reset(t2d_pool* pool, int32_t on);
 int t2d_set_integrator_variant(t2d_pool* pool, int32_t variant);
 
 /* Per-kernel timing with HIP events recorded on the launch stream around each kernel.
- * kernel_id: 0 = integrate, 1 = collide(+status).                                       */
+ * kernel_id: 0 = integrate, 1 = collide(+status), 2 = fused step.                                     */
 int t2d_profile_enable(t2d_pool* pool, int32_t on);
 int t2d_profile_read(t2d_pool* pool, int32_t kernel_id, double* total_ms, int64_t* launches);
 

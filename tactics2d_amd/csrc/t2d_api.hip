@@ -531,11 +531,12 @@ int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     return record_event(p, 0, s, false);
 }
 
-static int collide_impl(t2d_pool* p, bool with_status, int interval_ms, hipStream_t s) {
+static int collide_impl(t2d_pool* p, bool with_status, int interval_ms, hipStream_t s, int fuse_variant = -1) {
     int rc;
-    if ((rc = record_event(p, 1, s, true))) return rc;
-    T2D_HIP(p, t2d::launch_collide(p->v, p->status_cfg, with_status, interval_ms, s));
-    return record_event(p, 1, s, false);
+    const int kid = fuse_variant >= 0 ? 2 : 1;
+    if ((rc = record_event(p, kid, s, true))) return rc;
+    T2D_HIP(p, t2d::launch_collide(p->v, p->status_cfg, with_status, interval_ms, fuse_variant, s));
+    return record_event(p, kid, s, false);
 }
 
 int t2d_collide(t2d_pool* p, void* hip_stream) {
@@ -557,9 +558,25 @@ int t2d_check_status(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
 }
 
 int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
-    int rc = t2d_integrate(p, interval_ms, hip_stream);
-    if (rc != T2D_OK) return rc;
-    return t2d_check_status(p, interval_ms, hip_stream);
+    if (!p) return T2D_ERR_INVALID;
+    if (!p->fused_step) {
+        int rc = t2d_integrate(p, interval_ms, hip_stream);
+        if (rc != T2D_OK) return rc;
+        return t2d_check_status(p, interval_ms, hip_stream);
+    }
+    if (!p->have_params || !p->have_reset)
+        return fail(p, T2D_ERR_STATE, "t2d_set_param_table and t2d_reset must precede t2d_step");
+    if (interval_ms <= 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be positive");
+    p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)(p->step_count & 1) * p->v.n_env;
+    int rc = collide_impl(p, true, interval_ms, (hipStream_t)hip_stream, p->integrator_variant);
+    if (rc == T2D_OK) p->step_count++;
+    return rc;
+}
+
+int t2d_set_fused_step(t2d_pool* p, int32_t on) {
+    if (!p) return T2D_ERR_INVALID;
+    p->fused_step = on != 0;
+    return T2D_OK;
 }
 
 int t2d_snapshot(t2d_pool* p) {

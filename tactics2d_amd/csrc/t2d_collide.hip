@@ -39,8 +39,7 @@
 // -ffp-contract=off, deterministic trig); broad phases are strictly conservative, so flags are
 // bit-exact against the oracle's brute force.
 // Bound: fp64 VALU issue + LDS latency (about 20 B of HBM per participant); see DESIGN.md.
-#include "t2d_math.h"
-#include "t2d_pool.h"
+#include "t2d_integrate_dev.h"
 
 namespace t2d {
 
@@ -262,21 +261,33 @@ T2D_DEV void compact_and_process(unsigned long long mask, int id_base, int own_i
 #define T2D_MARK(k)
 #endif
 
-template <bool WITH_STATUS>
+// FUSE = -1: events only (poses read from the pool).  FUSE = 0 / 1: the whole ScenarioManager step in
+// one launch -- the participant is first integrated in registers (exact / fast variant, the same
+// device functions as integrate_kernel), written back, and its new pose goes straight into the event
+// phases: no second launch, no state reload.
+template <bool WITH_STATUS, int FUSE>
 __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv, t2d_status_config cfg,
                                                                             int interval_ms, int log2A) {
     __shared__ double s_v[8][kBlock];   // OBB vertex coordinate planes x0,y0,...,x3,y3
     __shared__ double s_c[3][kBlock];   // centre x, centre y, radius (circle) / bounding radius (OBB)
-    __shared__ double s_par[4][T2D_MAX_TYPES];  // length, width, shape, bounding radius per type
+    // type table in LDS, [column][type]: all columns up to the bounding radius when fused, else only
+    // the 4 shape columns (length, width, shape, bounding radius)
+    constexpr int kTabCols = T2D_P_RESERVED0 + 1;
+    __shared__ double s_partab[FUSE >= 0 ? kTabCols * T2D_MAX_TYPES : 4 * T2D_MAX_TYPES];
     __shared__ int s_kind[kBlock];      // T2D_SHAPE_* or -1 = inactive
-    __shared__ int s_head[kMaxHeads];
-    __shared__ int s_next[kBlock];
     __shared__ uint32_t s_flags[kBlock];   // event bits, OR-ed by the narrow phase
     __shared__ uint32_t s_inside[kBlock];  // bit k: pose vertex k lies in some lane polygon
     __shared__ uint32_t s_env_or[kBlock];
     __shared__ uint32_t s_queue[kWaves][kQueueCap];
     __shared__ int s_qcount[kWaves];
-    __shared__ int s_done[kBlock];  // per env_local: episode finished this step (auto-reset)
+    // the spatial-hash lists (envs wider than a wave only) live in the queue storage: they are dead
+    // before the polygon stages start using the queues (workgroup barrier in between)
+    static_assert(kMaxHeads + kBlock <= kWaves * kQueueCap, "hash grid must fit in the queue storage");
+    int* const s_head = reinterpret_cast<int*>(&s_queue[0][0]);
+    int* const s_next = s_head + kMaxHeads;
+    // per env: episode finished.  Shares s_env_or: slot env_local is only ever touched by that env's own
+    // lanes, and it is consumed (env_flags written) before it is reused
+    int* const s_done = reinterpret_cast<int*>(s_env_or);
     extern __shared__ __attribute__((aligned(16))) uint32_t s_geo[];  // packed geometry record
 
     const GeoLayout& gl = pv.geo_layout;
@@ -302,6 +313,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     // ---------------- phase 0: issue every global load, clear LDS tables ------------------
     uint32_t ids = 0;
     float fx = 0, fy = 0, fh = 0;
+    float fv = 0, fa0 = 0, fa1 = 0;  // fused: speed and actions
     float bxmin = 0, bxmax = 0, bymin = 0, bymax = 0;
     bool has_boundary = false;
     if (valid) {
@@ -309,20 +321,36 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         fx = pv.x[idx];
         fy = pv.y[idx];
         fh = pv.heading[idx];
+        if (FUSE >= 0) {
+            fv = pv.speed[idx];
+            fa0 = pv.act0[idx];
+            fa1 = pv.act1[idx];
+        }
         if (pv.boundary) {
             const float4 b = reinterpret_cast<const float4*>(pv.boundary)[env];
             bxmin = b.x; bxmax = b.y; bymin = b.z; bymax = b.w;
             has_boundary = pv.boundary_valid ? pv.boundary_valid[env] != 0 : true;
         }
     }
-    double par_stage[2] = {0.0, 0.0};  // 4 shape columns x 32 types = 128 doubles, <= 2 per thread
+    if (FUSE >= 0) {  // full parameter table -> LDS (<= 12 x 8 B per thread, loads issued together)
+        constexpr int kTab = kTabCols * T2D_MAX_TYPES;
+        double tstage[12];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int q = tid + k * nthreads;
-        if (q < 4 * T2D_MAX_TYPES && (k == 0 || nthreads < 4 * T2D_MAX_TYPES)) {
-            const int col = q / T2D_MAX_TYPES, ty = q % T2D_MAX_TYPES;
-            const int src = col == 0 ? T2D_P_LENGTH : col == 1 ? T2D_P_WIDTH : col == 2 ? T2D_P_SHAPE : T2D_P_RESERVED0;
-            par_stage[k] = pv.params[src * T2D_MAX_TYPES + ty];
+        for (int k = 0; k < 12; ++k) {
+            tstage[k] = 0.0;
+            if (k * 64 < kTab && tid + k * nthreads < kTab) tstage[k] = pv.params[tid + k * nthreads];
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            if (k * 64 < kTab && tid + k * nthreads < kTab) s_partab[tid + k * nthreads] = tstage[k];
+    }
+    double par_stage[2] = {0.0, 0.0};  // events only: 4 shape columns x 32 types, <= 2 per thread
+    if (FUSE < 0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int q = tid + k * nthreads;
+            if (q < 4 * T2D_MAX_TYPES && (k == 0 || nthreads < 4 * T2D_MAX_TYPES))
+                par_stage[k] = pv.params[(T2D_P_SHAPE + q / T2D_MAX_TYPES) * T2D_MAX_TYPES + q % T2D_MAX_TYPES];
         }
     }
     // geometry record -> LDS in batches of kBatch 16-B loads per thread (one latency per batch;
@@ -342,11 +370,12 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         s_env_or[tid] = 0;
         s_flags[tid] = 0;
         s_inside[tid] = 0;
+        if (FUSE < 0) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int q = tid + k * nthreads;
-            if (q < 4 * T2D_MAX_TYPES && (k == 0 || nthreads < 4 * T2D_MAX_TYPES))
-                s_par[q / T2D_MAX_TYPES][q % T2D_MAX_TYPES] = par_stage[k];
+            for (int k = 0; k < 2; ++k) {
+                const int q = tid + k * nthreads;
+                if (q < 4 * T2D_MAX_TYPES && (k == 0 || nthreads < 4 * T2D_MAX_TYPES)) s_partab[q] = par_stage[k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < kBatch; ++k)
@@ -367,9 +396,35 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     __syncthreads();  // (a) tables cleared, type columns + geometry record staged
     T2D_MARK(0);
 
-    // ---------------- phase 1: pose, out-of-bound, conservative fp32 box ------------------------
     const bool active = valid && ((ids >> kIdsActiveShift) & 0xffu);
     const int type = (ids >> kIdsTypeShift) & 0xff;
+    if (FUSE >= 0 && active) {
+        // ---------------- fused physics: one PhysicsModelBase.step in registers ----------------
+        const int model = (ids >> kIdsModelShift) & 0xff;
+        auto P = [&](int col) -> double { return s_partab[col * T2D_MAX_TYPES + type]; };
+        double pvx = 0.0, pvy = 0.0;
+        if (model == T2D_MODEL_POINTMASS) {
+            pvx = (double)pv.vx[idx];
+            pvy = (double)pv.vy[idx];
+        }
+        const integ::StepOut o = integ::step_participant<(FUSE > 0 ? 1 : 0)>(
+            model, P, (double)fx, (double)fy, (double)fh, (double)fv, pvx, pvy, (double)fa0, (double)fa1, interval_ms);
+        fx = (float)o.x;
+        fy = (float)o.y;
+        fh = (float)o.heading;
+        pv.x[idx] = fx;
+        pv.y[idx] = fy;
+        pv.heading[idx] = fh;
+        pv.speed[idx] = (float)o.speed;
+        if (o.has_velocity) {
+            pv.vx[idx] = (float)o.vx;
+            pv.vy[idx] = (float)o.vy;
+        }
+        pv.applied0[idx] = (float)o.app0;
+        pv.applied1[idx] = (float)o.app1;
+    }
+    T2D_MARK(13);
+    // ---------------- phase 1: pose, out-of-bound, conservative fp32 box ------------------------
     int kind = -1;
     float R32 = -1.0f;                                  // bounding radius + 5 mm; < 0 = inactive
     float box_lo_x = 0, box_hi_x = 0, box_lo_y = 0, box_hi_y = 0;  // encloses the pose (outward rounded)
@@ -377,10 +432,12 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     int gcx = 0, gcy = 0;
     if (active) {
         const double cx = (double)fx, cy = (double)fy;
-        const double L = s_par[0][type];
-        const double W = s_par[1][type];
-        kind = (int)s_par[2][type];
-        const double R = s_par[3][type];  // bounding radius (host-computed)
+        // columns SHAPE, LENGTH, WIDTH, RESERVED0 (bounding radius) are consecutive in the table
+        constexpr int c0 = FUSE >= 0 ? T2D_P_SHAPE : 0;
+        kind = (int)s_partab[(c0 + 0) * T2D_MAX_TYPES + type];
+        const double L = s_partab[(c0 + 1) * T2D_MAX_TYPES + type];
+        const double W = s_partab[(c0 + 2) * T2D_MAX_TYPES + type];
+        const double R = s_partab[(c0 + 3) * T2D_MAX_TYPES + type];  // bounding radius (host-computed)
         const double rad = 0.5 * W;
         R32 = (float)R + 5e-3f;
         double lo_x, hi_x, lo_y, hi_y;
@@ -520,6 +577,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     }
 
     T2D_MARK(4);
+    if (use_hash_grid) __syncthreads();  // the grid lists share LDS with the queues used below
     // ---------------- phase 2b / 2c: static polygons and lane polygons -------------------------
     const int* geo_i = reinterpret_cast<const int*>(s_geo);
     auto process_static = [&](uint32_t e) {
@@ -696,17 +754,22 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
 }  // namespace
 
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
-                          int interval_ms, hipStream_t s) {
+                          int interval_ms, int fuse_variant, hipStream_t s) {
     int log2A = 0;
     while ((1 << log2A) < v.A) ++log2A;
     const int EPB = v.geo_layout.epb;
-    const int grid = (v.n_env + EPB - 1) / EPB;
-    const int threads = EPB << log2A;
+    const dim3 grid((v.n_env + EPB - 1) / EPB), block(EPB << log2A);
     const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
-    if (with_status)
-        hipLaunchKernelGGL(collide_kernel<true>, dim3(grid), dim3(threads), dyn, s, v, cfg, interval_ms, log2A);
-    else
-        hipLaunchKernelGGL(collide_kernel<false>, dim3(grid), dim3(threads), dyn, s, v, cfg, interval_ms, log2A);
+    if (fuse_variant >= 0) {  // the fused step always runs the status epilogue
+        if (fuse_variant == 0)
+            hipLaunchKernelGGL((collide_kernel<true, 0>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        else
+            hipLaunchKernelGGL((collide_kernel<true, 1>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+    } else if (with_status) {
+        hipLaunchKernelGGL((collide_kernel<true, -1>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+    } else {
+        hipLaunchKernelGGL((collide_kernel<false, -1>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+    }
     return hipGetLastError();
 }
 

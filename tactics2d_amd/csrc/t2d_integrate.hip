@@ -23,370 +23,14 @@
 //
 // Roofline: nominally HBM-streaming (44-60 B per participant-step), but 20 explicit-Euler
 // sub-steps of fp64 math per participant make it VALU-bound; see DESIGN.md.
-#include "t2d_math.h"
-#include "t2d_pool.h"
+#include "t2d_integrate_dev.h"
 
 namespace t2d {
 
 namespace {
 
 constexpr int kBlock = 256;
-constexpr double kG = 9.81;  // PhysicsModelBase._G
-
-struct StepOut {
-    double x, y, heading, speed, vx, vy, app0, app1;
-    bool has_velocity;
-};
-
-constexpr double kEpsMax = 0.1;    // largest sub-step angle the Taylor rotation accepts
-constexpr double kEpsTiny = 0.01;  // below this, sin to e^3 / cos to e^4 are exact to < 1e-13
-
-// rotate (c, s) by angle eps, |eps| <= kEpsMax: sin to e^7, cos to e^8 (truncation < 3e-15)
-T2D_DEV void rotate_small(double eps, double& c, double& s) {
-    double e2 = eps * eps;
-    double ps = __builtin_fma(e2, -1.0 / 5040.0, 1.0 / 120.0);
-    ps = __builtin_fma(e2, ps, -1.0 / 6.0);
-    ps = __builtin_fma(e2, ps, 1.0);
-    double se = eps * ps;
-    double pc = __builtin_fma(e2, 1.0 / 40320.0, -1.0 / 720.0);
-    pc = __builtin_fma(e2, pc, 1.0 / 24.0);
-    pc = __builtin_fma(e2, pc, -0.5);
-    double ce = __builtin_fma(e2, pc, 1.0);
-    double cn = __builtin_fma(c, ce, -(s * se));
-    double sn = __builtin_fma(s, ce, c * se);
-    c = cn;
-    s = sn;
-}
-
-// rotate (c, s) by a tiny angle |eps| <= kEpsTiny: sin = e - e^3/6 (err e^5/120 < 1e-12 relative to
-// e), cos = 1 - e^2/2 + e^4/24 (err e^6/720 < 2e-15)
-T2D_DEV void rotate_tiny(double eps, double& c, double& s) {
-    double e2 = eps * eps;
-    double se = eps * __builtin_fma(e2, -1.0 / 6.0, 1.0);
-    double ce = __builtin_fma(e2, __builtin_fma(e2, 1.0 / 24.0, -0.5), 1.0);
-    double cn = __builtin_fma(c, ce, -(s * se));
-    double sn = __builtin_fma(s, ce, c * se);
-    c = cn;
-    s = sn;
-}
-
-// 1/x to ~1 ulp: hardware estimate + two Newton steps (fast variant only; the exact variant
-// uses IEEE division).  x must be normal and finite.
-T2D_DEV double rcp_nr(double x) {
-    double y = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-x, y, 1.0);
-    return __builtin_fma(y, e, y);
-}
-// 1/x with ONE Newton step (~2^-50): enough as the seed of div_r, whose residual correction
-// squares the remaining error
-T2D_DEV double rcp_nr1(double x) {
-    double y = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, y, 1.0);
-    return __builtin_fma(y, e, y);
-}
-// 1/sqrt(x) to ~1 ulp, x > 0 normal
-T2D_DEV double rsq_nr(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    double h = 0.5 * x;
-    y = y * __builtin_fma(-h, y * y, 1.5);
-    return y * __builtin_fma(-h, y * y, 1.5);
-}
-// a / b given r ~ 1/b: one residual correction makes the quotient correctly rounded except in
-// vanishingly rare cases (Markstein); b normal, quotient finite
-T2D_DEV double div_r(double a, double b, double r) {
-    double q = a * r;
-    double rem = __builtin_fma(-q, b, a);
-    return __builtin_fma(rem, r, q);
-}
-
-template <int VARIANT, typename PF>
-T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, double accel,
-                                double delta, int interval) {
-    int flags = (int)P(T2D_P_RANGE_FLAGS);
-    if (flags & T2D_RANGE_ACCEL) accel = clipd(accel, P(T2D_P_ACCEL_LO), P(T2D_P_ACCEL_HI));
-    if (flags & T2D_RANGE_STEER) delta = clipd(delta, P(T2D_P_STEER_LO), P(T2D_P_STEER_HI));
-    const bool clip_v = flags & T2D_RANGE_SPEED;
-    const double vlo = P(T2D_P_SPEED_LO), vhi = P(T2D_P_SPEED_HI);
-    const double lr = P(T2D_P_LR), wb = P(T2D_P_WB);
-    const int delta_t = (int)P(T2D_P_DELTA_T_MS);
-    const double dt = (double)delta_t / 1000;
-    const int n_steps = interval / delta_t;
-    const int rem = interval - n_steps * delta_t;
-    const int total = n_steps + (rem > 0 ? 1 : 0);
-    StepOut o;
-    if (VARIANT == 0) {
-        const double tand = tan_det(delta);
-        const double t = lr / wb * tand;
-        const double beta = atan_det(t);
-        double sb, cb;
-        sincos_det(beta, sb, cb);
-        for (int k = 0; k < total; ++k) {
-            double h = k < n_steps ? dt : (double)rem / 1000;
-            double sn, cs;
-            sincos_det(phi + beta, sn, cs);
-            double dx = v * cs;
-            double dy = v * sn;
-            double dphi = v / wb * tand * cb;
-            x += dx * h;
-            y += dy * h;
-            phi += dphi * h;
-            v += accel * h;
-            if (clip_v) v = clipd(v, vlo, vhi);
-        }
-        double sp, cp;
-        sincos_det(phi, sp, cp);
-        o.vx = v * cp;
-        o.vy = v * sp;
-    } else {
-        double sd, cd;
-        sincos_det(delta, sd, cd);
-        const double tw = sd * rcp_nr(cd * wb);  // tan(delta) / wb
-        const double t = lr * tw;                // tan(beta)
-        // cos(beta) = 1/sqrt(1+t^2), sin(beta) = t*cos(beta): no atan needed
-        const double cb = rsq_nr(__builtin_fma(t, t, 1.0));
-        const double sb = t * cb;
-        double sp, cp;
-        sincos_det(phi, sp, cp);
-        double c = cp * cb - sp * sb;  // cos(phi + beta)
-        double s = sp * cb + cp * sb;
-        const double kk = tw * cb;  // d(phi)/dt = v * kk
-        auto sub_step = [&](double h, double ah, double kh) {
-            const double eps = v * kh;  // d(phi) of this sub-step
-            const double vh = v * h;
-            x = __builtin_fma(vh, c, x);
-            y = __builtin_fma(vh, s, y);
-            phi += eps;
-            v += ah;
-            if (clip_v) v = __builtin_fmin(__builtin_fmax(v, vlo), vhi);
-            if (__builtin_fabs(eps) <= kEpsMax) {
-                rotate_small(eps, c, s);
-            } else {  // absurd yaw rates (unbounded speed): re-seed from phi
-                double s2, c2;
-                sincos_det(phi, s2, c2);
-                c = c2 * cb - s2 * sb;
-                s = s2 * cb + c2 * sb;
-            }
-        };
-        const double ah = accel * dt, kh = kk * dt;
-        // Main loop.  While the speed is not clipped it is linear in the sub-step index, so the
-        // sub-step angle eps_k = v_k * kh grows by the constant dlt = ah * kh and (cos eps, sin eps)
-        // is itself advanced by a fixed rotation (cD, sD) instead of being re-evaluated: 16 fp64
-        // operations per sub-step instead of 21.  Decided once per step and per wave: if any lane
-        // would clip its speed or leave the small-angle range during this step, the whole wave
-        // takes the generic loop.
-        const double v_end = v + (double)n_steps * ah;
-        const double eps0 = v * kh, eps_end = v_end * kh, dlt = ah * kh;
-        const bool lane_linear = (!clip_v || (v >= vlo && v <= vhi && v_end >= vlo && v_end <= vhi)) &&
-                                 __builtin_fabs(eps0) <= kEpsMax && __builtin_fabs(eps_end) <= kEpsMax;
-        if (__ballot(!lane_linear) == 0ull) {
-            double eps = eps0;
-            double ce = 1.0, se = 0.0, cD = 1.0, sD = 0.0;
-            rotate_small(eps, ce, se);   // (cos eps_0, sin eps_0)
-            rotate_small(dlt, cD, sD);   // |dlt| <= |eps_end - eps0| / n <= 2 kEpsMax / n
-            for (int k = 0; k < n_steps; ++k) {
-                const double vh = v * dt;
-                x = __builtin_fma(vh, c, x);
-                y = __builtin_fma(vh, s, y);
-                phi += eps;
-                const double cn = __builtin_fma(c, ce, -(s * se));
-                const double sn = __builtin_fma(s, ce, c * se);
-                c = cn;
-                s = sn;
-                const double cen = __builtin_fma(ce, cD, -(se * sD));
-                const double sen = __builtin_fma(se, cD, ce * sD);
-                ce = cen;
-                se = sen;
-                eps += dlt;
-                v += ah;
-            }
-        } else {
-            for (int k = 0; k < n_steps; ++k) sub_step(dt, ah, kh);
-        }
-        if (rem > 0) {
-            const double hr = (double)rem / 1000;
-            sub_step(hr, accel * hr, kk * hr);
-        }
-        // cos(phi) = cos((phi+beta) - beta)
-        o.vx = v * (c * cb + s * sb);
-        o.vy = v * (s * cb - c * sb);
-    }
-    o.x = x;
-    o.y = y;
-    o.heading = mod_two_pi(phi);
-    o.speed = v;
-    o.app0 = accel;
-    o.app1 = delta;
-    o.has_velocity = true;
-    return o;
-}
-
-template <int VARIANT, typename PF>
-T2D_DEV StepOut step_dynamics(PF P, double x, double y, double phi, double v, double accel,
-                              double delta, int interval) {
-    int flags = (int)P(T2D_P_RANGE_FLAGS);
-    if (flags & T2D_RANGE_ACCEL) accel = clipd(accel, P(T2D_P_ACCEL_LO), P(T2D_P_ACCEL_HI));
-    if (flags & T2D_RANGE_STEER) delta = clipd(delta, P(T2D_P_STEER_LO), P(T2D_P_STEER_HI));
-    const bool clip_v = flags & T2D_RANGE_SPEED;
-    const double vlo = P(T2D_P_SPEED_LO), vhi = P(T2D_P_SPEED_HI);
-    const double lf = P(T2D_P_LF), lr = P(T2D_P_LR), wb = P(T2D_P_WB);
-    const double mass = P(T2D_P_MASS), hcg = P(T2D_P_MASS_HEIGHT), mu = P(T2D_P_MU);
-    const double Iz = P(T2D_P_IZ), cf = P(T2D_P_CF), cr = P(T2D_P_CR);
-    const int delta_t = (int)P(T2D_P_DELTA_T_MS);
-    const double dt = (double)delta_t / 1000;
-    const int n_steps = interval / delta_t;  // the remainder is never integrated (:143)
-
-    const double factor_f = (kG * lr - accel * hcg) / wb;
-    const double factor_r = (kG * lf + accel * hcg) / wb;
-    const double lf_cf_ff = lf * cf * factor_f;
-    const double lr_cr_fr = lr * cr * factor_r;
-    const double lf2_cf_ff = lf * lf * cf * factor_f;
-    const double lr2_cr_fr = lr * lr * cr * factor_r;
-    const double cf_ff = cf * factor_f;
-    const double cr_fr = cr * factor_r;
-    const double mmi = mu * mass / Iz;
-    const double k21 = lr_cr_fr - lf_cf_ff;
-    const double k34 = lf2_cf_ff + lr2_cr_fr;
-    const double k65 = cr_fr + cf_ff;
-
-    const double tand = tan_det(delta);
-    double d_phi = v / wb * tand;
-    double beta = atan_det(lr / lf * tand);
-
-    if (VARIANT == 0) {
-        for (int k = 0; k < n_steps; ++k) {
-            double s, c;
-            sincos_det(phi + beta, s, c);
-            double dx = v * c;
-            double dy = v * s;
-            double av = __builtin_fabs(v);
-            double v_safe = av > 1e-6 ? v : (v >= 0 ? 1e-6 : -1e-6);
-            double d_beta;
-            if (av >= 0.1) {
-                double dd_phi = mmi * (lf_cf_ff * delta + k21 * beta - k34 * d_phi / v_safe);
-                d_beta = mu / v_safe * (cf_ff * delta - k65 * beta + k21 * d_phi / v_safe) - d_phi;
-                d_phi += dd_phi * dt;
-            } else {
-                double tb = 1 + tand * lr / wb;
-                double sd, cd;
-                sincos_det(delta, sd, cd);
-                d_beta = lr / (tb * tb) / wb / (cd * cd) * delta;
-                double sbt, cbt;
-                sincos_det(beta, sbt, cbt);
-                d_phi += v * cbt / wb * tand * dt;
-            }
-            x += dx * dt;
-            y += dy * dt;
-            v += accel * dt;
-            phi += d_phi * dt;
-            beta += d_beta * dt;
-            if (clip_v) v = clipd(v, vlo, vhi);
-        }
-    } else {
-        // Same recurrences; the three divisions by v_safe share one Newton reciprocal with a
-        // residual-corrected quotient, x / y use fma, cos/sin(phi + beta) a rotation recurrence.
-        double s, c;
-        sincos_det(phi + beta, s, c);
-        const double c1 = lf_cf_ff * delta, c2 = cf_ff * delta, ah = accel * dt;
-        for (int k = 0; k < n_steps; ++k) {
-            const double vh = v * dt;
-            x = __builtin_fma(vh, c, x);
-            y = __builtin_fma(vh, s, y);
-            const double av = __builtin_fabs(v);
-            const double v_safe = av > 1e-6 ? v : (v >= 0 ? 1e-6 : -1e-6);
-            double d_beta;
-            if (av >= 0.1) {
-                // one Newton reciprocal (~1e-15) serves all three divisions by v_safe; fma freely:
-                // ~1e-16 relative changes of the feedback terms are far inside the 1e-5 contract
-                // wherever the reference itself is well conditioned (dynamics conditioning)
-                const double r = rcp_nr1(v_safe);
-                const double w = d_phi * r;
-                const double dd_phi = mmi * __builtin_fma(-k34, w, __builtin_fma(k21, beta, c1));
-                d_beta = __builtin_fma(mu * r, __builtin_fma(k21, w, __builtin_fma(-k65, beta, c2)), -d_phi);
-                d_phi = __builtin_fma(dd_phi, dt, d_phi);
-            } else {
-                double tb = 1 + tand * lr / wb;
-                double sd, cd;
-                sincos_det(delta, sd, cd);
-                d_beta = lr / (tb * tb) / wb / (cd * cd) * delta;
-                double sbt, cbt;
-                sincos_det(beta, sbt, cbt);
-                d_phi += v * cbt / wb * tand * dt;
-            }
-            v += ah;
-            const double e1 = d_phi * dt;
-            const double e2 = d_beta * dt;
-            phi += e1;
-            beta += e2;
-            if (clip_v) v = __builtin_fmin(__builtin_fmax(v, vlo), vhi);
-            const double eps = e1 + e2;
-            const double aeps = __builtin_fabs(eps);
-            if (__ballot(aeps > kEpsTiny) == 0ull) rotate_tiny(eps, c, s);   // wave-uniform: usual case
-            else if (aeps <= kEpsMax) rotate_small(eps, c, s);
-            else sincos_det(phi + beta, s, c);
-        }
-    }
-    StepOut o;
-    o.x = x;
-    o.y = y;
-    o.heading = mod_two_pi(phi);
-    o.speed = v;
-    o.vx = 0.0;
-    o.vy = 0.0;
-    o.app0 = accel;
-    o.app1 = delta;
-    o.has_velocity = false;  // reference State has vx = vy = None (:220-227)
-    return o;
-}
-
-template <typename PF>
-T2D_DEV StepOut step_pointmass(PF P, double x, double y, double vx, double vy, double ax,
-                               double ay, int interval) {
-    int flags = (int)P(T2D_P_RANGE_FLAGS);
-    const double lo = P(T2D_P_SPEED_LO), hi = P(T2D_P_SPEED_HI);
-    const double dt = (double)interval / 1000;
-    double nvx = vx + ax * dt;
-    double nvy = vy + ay * dt;
-    double ns = __builtin_sqrt(nvx * nvx + nvy * nvy);
-    StepOut o;
-    double ovx, ovy;
-    if (!(flags & T2D_RANGE_SPEED) || (lo <= ns && ns <= hi)) {
-        o.x = x + vx * dt + 0.5 * ax * (dt * dt);
-        o.y = y + vy * dt + 0.5 * ay * (dt * dt);
-        ovx = nvx;
-        ovy = nvy;
-    } else {
-        bool lower = ns < lo;
-        double bound = lower ? lo : hi;
-        double a_ = ax * ax + ay * ay;
-        double b_ = 2 * (ax * vx + ay * vy);
-        double c_ = vx * vx + vy * vy - bound * bound;
-        double t1;
-        if (__builtin_fabs(a_) < 1e-12) {
-            t1 = __builtin_fabs(b_) < 1e-12 ? 0.0 : -c_ / b_;
-        } else {
-            double disc = b_ * b_ - 4 * a_ * c_;
-            if (!(disc > 0.0)) disc = 0.0;
-            double sq = __builtin_sqrt(disc);
-            t1 = lower ? (-b_ - sq) / (2 * a_) : (-b_ + sq) / (2 * a_);
-        }
-        t1 = clipd(t1, 0.0, dt);
-        double t2 = dt - t1;
-        ovx = vx + ax * t1;
-        ovy = vy + ay * t1;
-        o.x = x + vx * t1 + 0.5 * ax * (t1 * t1) + ovx * t2;
-        o.y = y + vy * t1 + 0.5 * ay * (t1 * t1) + ovy * t2;
-    }
-    o.heading = atan2_det(ovy, ovx);
-    o.speed = __builtin_sqrt(ovx * ovx + ovy * ovy);
-    o.vx = ovx;
-    o.vy = ovy;
-    o.app0 = ax;
-    o.app1 = ay;
-    o.has_velocity = true;
-    return o;
-}
+using namespace integ;
 
 template <int VARIANT>
 __global__ __launch_bounds__(kBlock) void integrate_kernel(PoolView pv, int interval_ms) {

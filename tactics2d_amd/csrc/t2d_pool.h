@@ -72,6 +72,7 @@ struct t2d_pool {
     bool have_params = false;
     bool have_reset = false;
     int integrator_variant = 1;
+    bool fused_step = true;  // t2d_step = one launch (integrate + events + status)
     t2d_status_config status_cfg{};
     std::string err;
     double host_params[T2D_MAX_TYPES][T2D_PARAM_COLS]{};
@@ -105,7 +106,7 @@ struct t2d_pool {
 namespace t2d {
 hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hipStream_t s);
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
-                          int interval_ms, hipStream_t s);
+                          int interval_ms, int fuse_variant, hipStream_t s);
 hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
                           hipStream_t s);
 }  // namespace t2d

@@ -174,6 +174,10 @@ class ParticipantPool:
         """Device-side reset to the snapshot: all envs, or only terminated/truncated ones."""
         self._ck(self._lib.t2d_restore(self._h, 1 if done_only else 0, stream))
 
+    def set_fused_step(self, on=True):
+        """step() as one fused launch (default) or as integrate + check_status (two launches)."""
+        self._ck(self._lib.t2d_set_fused_step(self._h, int(bool(on))))
+
     def set_auto_reset(self, on=True):
         """Fuse the reset of finished envs (to the snapshot) into every step()."""
         self._ck(self._lib.t2d_set_auto_reset(self._h, int(bool(on))))

@@ -146,3 +146,30 @@ def test_fused_auto_reset_matches_explicit_restore():
     assert n_done > 20
     for p in pools:
         p.close()
+
+
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+@pytest.mark.parametrize("n_env,A", [(96, 64), (50, 32), (300, 3), (3, 200)])
+def test_fused_step_equals_two_kernel_step(variant, n_env, A):
+    """t2d_step as ONE launch (integrate in registers -> events -> status) must be bit-identical to
+    t2d_integrate followed by t2d_check_status."""
+    from tactics2d_amd import layout as L, scenarios as S
+    from tactics2d_amd.pool import ParticipantPool
+    sc = S.mixed(n_env, A, seed=31)
+    sc.status = dict(max_step=4, check_dynamic=1, check_off_lane=1)
+    rng = np.random.default_rng(3)
+    acts = [sc.sample_actions(rng) for _ in range(6)]
+    outs = []
+    for fused in (False, True):
+        pool = ParticipantPool(sc.n_env, sc.A)
+        sc.load(pool)
+        pool.set_integrator_variant(variant)
+        pool.set_fused_step(fused)
+        pool.set_auto_reset(True)
+        for a0, a1 in acts:
+            pool.set_actions(a0, a1)
+            pool.step(100)
+        outs.append([pool.download(f) for f in range(L.F_COUNT) if f not in (L.F_ACT0, L.F_ACT1)])
+        pool.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
