@@ -48,7 +48,6 @@ def cpu_baseline(scene, target_seconds=12.0):
     """The oracle (C port of the reference algorithm, fp64 scalar, 1 thread) stepping a bounded
     sample of the SAME scene: integrate -> fp32 store -> collide -> status, per step."""
     from oracle import oracle as O
-    from oracle.oracle import StatusConfig
     O.build()
     n_env = min(scene.n_env, 96)
     A = scene.A
@@ -69,9 +68,9 @@ def cpu_baseline(scene, target_seconds=12.0):
     vx = (v.astype(np.float64) * np.cos(h.astype(np.float64))).astype(np.float32)
     vy = (v.astype(np.float64) * np.sin(h.astype(np.float64))).astype(np.float32)
     tid, act = scene.type_id[sl], scene.active[sl]
-    st = scene.status
-    cfg = StatusConfig(st.get("max_step", 20000), 0, st.get("check_dynamic", 0), st.get("check_off_lane", 0),
-                       -5.0, -1.0, -5.0, 5.0, 0.001)
+    cfg = O.make_config(**scene.status)
+    ep = O.EpisodeState(n_env, None if scene.target is None else scene.target[:n_env], None,
+                        np.stack([scene.x[sl].reshape(n_env, A)[:, 0], scene.y[sl].reshape(n_env, A)[:, 0]], 1))
     cnt = np.zeros(n_env, np.int32); frame = np.zeros(n_env, np.int32)
     rng = np.random.default_rng(123)
     full_a0, full_a1 = scene.sample_actions(rng)
@@ -84,7 +83,7 @@ def cpu_baseline(scene, target_seconds=12.0):
         x, y, h, v = (np.float32(o[:, k]) for k in range(4))
         vx = np.where(is_dyn, vx, np.float32(o[:, 4])); vy = np.where(is_dyn, vy, np.float32(o[:, 5]))
         f, _ = O.collide(scene.rows, n_env, A, x, y, h, tid, act, static, boundary, None, lanes, 0)
-        O.status(cfg, n_env, A, f, scene.interval_ms, cnt, frame)
+        O.status_ex(cfg, A, f, scene.interval_ms, cnt, frame, scene.rows, x, y, h, tid, ep)
         steps += 1
         el = time.perf_counter() - t0
         if el >= target_seconds or steps >= 2000:

@@ -29,6 +29,8 @@
  *                            OutBound.update                 traffic/event_detection/out_bound.py:37-48
  *                            OffLane.update                  traffic/event_detection/off_lane.py:16-17 (stub; build-defined)
  *   t2d_snapshot/restore  <- ParkingEnv.reset / _ParkingScenarioManager.reset       envs/parking.py:262-298,397-441
+ *   t2d_set_target_areas  <- Arrival.reset                traffic/event_detection/arrival.py:49-51
+ *                            Arrival.update / NoAction.update (IoU)   arrival.py:32-47, no_action.py:32-53
  *   t2d_check_status      <- _ParkingScenarioManager.check_status           envs/parking.py:361-392
  *   t2d_step              <- _ParkingScenarioManager.update + check_status  envs/parking.py:352-392
  *                            ParkingEnv.step terminated/truncated/reward    envs/parking.py:219-256,148-161
@@ -53,7 +55,7 @@
 extern "C" {
 #endif
 
-#define T2D_ABI_VERSION 1
+#define T2D_ABI_VERSION 2
 
 /* ---- status codes --------------------------------------------------------------- */
 #define T2D_OK            0
@@ -131,7 +133,9 @@ enum {
     T2D_F_RECORD = 17,     /* u32[2][E][2] packed per-env result records {reward bits, status word},
                               double buffered: t2d_step number k (0-based since create) writes half
                               k & 1, so a collective may still read step k while step k+1 runs    */
-    T2D_F_COUNT = 18
+    T2D_F_IOU = 18,        /* f32[E]  IoU(ego pose, target) of the last step; NaN = not evaluated (None) */
+    T2D_F_CNT_NO_ACTION = 19, /* i32[E] NoAction.cnt_no_action                          */
+    T2D_F_COUNT = 20
 };
 
 /* ---- per-participant / per-env event bits ------------------------------------------- */
@@ -141,6 +145,7 @@ enum {
 #define T2D_FLAG_OFF_LANE          8u   /* build-defined, see DESIGN.md                      */
 
 /* ---- ScenarioStatus / TrafficStatus values: traffic/status.py:10-61 ----------------- */
+#define T2D_TRAFFIC_NO_ACTION_QUIRK 5  /* parking.py:373 stores ScenarioStatus.NO_ACTION (5) in traffic_status */
 #define T2D_SCENARIO_NORMAL        1
 #define T2D_SCENARIO_COMPLETED     2
 #define T2D_SCENARIO_TIME_EXCEEDED 3
@@ -167,6 +172,16 @@ typedef struct t2d_status_config {
     float reward_out_bound;      /* -5  envs/parking.py:158-159                           */
     float reward_completed;      /* +5  envs/parking.py:160-161                           */
     float time_penalty_scale;    /* 0.001: -tanh(cnt_step / max_step) * scale  :163       */
+    /* ---- IoU events of the ego (scope rows f1), all off by default ------------------------- */
+    int32_t check_arrival;       /* Arrival.update arrival.py:32-47: IoU(pose, target) >= threshold
+                                    -> COMPLETED (needs t2d_set_target_areas)               */
+    int32_t check_no_action;     /* NoAction.update no_action.py:32-53: IoU(pose, last pose) >
+                                    no_action_iou on more than no_action_max_step checks    */
+    int32_t no_action_max_step;  /* 100  envs/parking.py:344                                   */
+    int32_t shaped_reward;       /* IoU gain + distance-to-target gain of _get_reward :163-188 */
+    float arrival_threshold;     /* 0.95  arrival.py:22                                        */
+    float no_action_iou;         /* 0.999 no_action.py:47                                      */
+    float dist_reward_scale;     /* 0.1   envs/parking.py:187                                  */
 } t2d_status_config;
 
 typedef struct t2d_pool t2d_pool;
@@ -201,6 +216,13 @@ int t2d_set_lane_geometry(t2d_pool* pool, const int32_t* env_lane_offsets,
                           const int32_t* lane_vert_offsets, const float* verts_xy);
 
 int t2d_set_status_config(t2d_pool* pool, const t2d_status_config* cfg);
+
+/* Target parking areas for Arrival and the reward shaping (Arrival.reset arrival.py:49-51,
+ * _ParkingScenarioManager.target_area envs/parking.py:399-401): one quadrilateral per env,
+ * target_xy[n_env][4][2] fp32 (either winding, convex); centroid[n_env][2] = its area centroid
+ * (`target_area.geometry.centroid`) or NULL to have it computed.  NULL target_xy removes them.
+ * Host memory.  (Re)initialises the per-env min-distance-to-target from the current state.    */
+int t2d_set_target_areas(t2d_pool* pool, const float* target_xy, const float* centroid);
 
 /* (Re)initialise participants.  All arrays are host memory with N = n_env*max_agents
  * elements; env_mask (n_env bytes, NULL = every env) selects which envs are written.

@@ -26,7 +26,11 @@ class StatusConfig(C.Structure):
     _fields_ = [("max_step", C.c_int32), ("ego_index", C.c_int32), ("check_dynamic", C.c_int32),
                 ("check_off_lane", C.c_int32), ("reward_collision", C.c_float),
                 ("reward_time_exceed", C.c_float), ("reward_out_bound", C.c_float),
-                ("reward_completed", C.c_float), ("time_penalty_scale", C.c_float)]
+                ("reward_completed", C.c_float), ("time_penalty_scale", C.c_float),
+                ("check_arrival", C.c_int32), ("check_no_action", C.c_int32),
+                ("no_action_max_step", C.c_int32), ("shaped_reward", C.c_int32),
+                ("arrival_threshold", C.c_float), ("no_action_iou", C.c_float),
+                ("dist_reward_scale", C.c_float)]
 
 
 def build(force=False):
@@ -175,3 +179,87 @@ def atan_det(x):
     f = lib().t2do_atan
     f.restype = C.c_double; f.argtypes = [C.c_double]
     return f(float(x))
+
+
+def make_config(**kw):
+    """t2d_status_config with the ParkingEnv defaults; keyword overrides."""
+    cfg = StatusConfig(20000, 0, 0, 0, -5.0, -1.0, -5.0, 5.0, 0.001, 0, 0, 100, 0, 0.95, 0.999, 0.1)
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise TypeError(f"unknown status option {k}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+def quad_iou(A, B):
+    f = lib().t2do_quad_iou
+    f.restype = C.c_double
+    f.argtypes = [_f64p, _f64p]
+    return f(np.ascontiguousarray(A, np.float64).reshape(-1), np.ascontiguousarray(B, np.float64).reshape(-1))
+
+
+def ccw(q):
+    q = np.asarray(q, np.float64).reshape(4, 2)
+    a2 = sum(q[i, 0] * q[(i + 1) % 4, 1] - q[(i + 1) % 4, 0] * q[i, 1] for i in range(4))
+    return q if a2 > 0 else q[::-1].copy()
+
+
+class EpisodeState:
+    """Per-env detector / shaping state of the status epilogue (NoAction, _max_iou, _min_dist_to_target)."""
+
+    def __init__(self, n_env, target=None, centroid=None, start_xy=None):
+        self.n_env = n_env
+        self.target = None
+        self.target_c = None
+        if target is not None:
+            self.target = np.stack([ccw(np.float32(t)) for t in target]).reshape(n_env, 8)
+            if centroid is None:
+                c = []
+                for t in self.target.reshape(n_env, 4, 2):
+                    w = t[:, 0] * np.roll(t[:, 1], -1) - np.roll(t[:, 0], -1) * t[:, 1]
+                    a2 = w.sum()
+                    c.append([((t[:, 0] + np.roll(t[:, 0], -1)) * w).sum() / (3 * a2),
+                              ((t[:, 1] + np.roll(t[:, 1], -1)) * w).sum() / (3 * a2)])
+                centroid = np.array(c)
+            self.target_c = np.ascontiguousarray(centroid, np.float64)
+        self.last_pose = np.zeros((n_env, 8)); self.last_valid = np.zeros(n_env, np.uint8)
+        self.cnt_na = np.zeros(n_env, np.int32); self.max_iou = np.full(n_env, -np.inf)
+        self.min_dist = np.full(n_env, np.inf)
+        if self.target is not None and start_xy is not None:
+            self.reset_envs(np.ones(n_env, bool), start_xy)
+        self.start_min_dist = self.min_dist.copy()
+
+    def reset_envs(self, mask, start_xy=None):
+        self.last_valid[mask] = 0; self.cnt_na[mask] = 0; self.max_iou[mask] = -np.inf
+        if start_xy is not None and self.target is not None:
+            d = np.float64(np.float32(start_xy)) - self.target_c
+            self.min_dist[mask] = np.sqrt(d[:, 0] ** 2 + d[:, 1] ** 2)[mask]
+        elif hasattr(self, "start_min_dist"):
+            self.min_dist[mask] = self.start_min_dist[mask]
+
+
+def status_ex(cfg, A, flags, interval_ms, cnt_step, frame_ms, rows, x, y, heading, type_id, ep):
+    """Extended status step for the ego of every env (IoU events + shaped reward); mutates cnt_step,
+    frame_ms and `ep` (EpisodeState).  Returns (status[E,4], reward[E], iou[E])."""
+    n_env = ep.n_env
+    ego = cfg.ego_index
+    rows = np.ascontiguousarray(rows, np.float64)
+    xe = np.float32(x).reshape(n_env, A)[:, ego]; ye = np.float32(y).reshape(n_env, A)[:, ego]
+    he = np.float32(heading).reshape(n_env, A)[:, ego]; te = np.asarray(type_id).reshape(n_env, A)[:, ego]
+    pose = np.zeros((n_env, 8)); is_obb = np.zeros(n_env, np.uint8)
+    for e in range(n_env):
+        r = rows[te[e]]
+        if int(r[18]) == 0:
+            pose[e] = pose_obb(xe[e], ye[e], he[e], r[19], r[20], 0).reshape(-1)
+            is_obb[e] = 1
+    xy = np.ascontiguousarray(np.stack([xe, ye], 1), np.float64)
+    st = np.zeros((n_env, 4), np.uint8); rw = np.zeros(n_env, np.float32); iou = np.zeros(n_env, np.float32)
+    f = lib().t2do_status_ex
+    f.argtypes = [C.POINTER(StatusConfig), C.c_int, C.c_int, _u32p, C.c_int, _i32p, _i32p, _u8p, _f32p,
+                  _f64p, _f64p, _u8p, C.c_void_p, C.c_void_p, C.c_int, _f64p, _u8p, _i32p, _f64p, _f64p, _f32p]
+    tgt = ep.target.ctypes.data_as(C.c_void_p) if ep.target is not None else None
+    tc = ep.target_c.ctypes.data_as(C.c_void_p) if ep.target is not None else None
+    f(C.byref(cfg), n_env, A, np.ascontiguousarray(flags, np.uint32), int(interval_ms), cnt_step, frame_ms,
+      st.reshape(-1), rw, pose.reshape(-1), xy.reshape(-1), is_obb, tgt, tc, int(ep.target is not None),
+      ep.last_pose.reshape(-1), ep.last_valid, ep.cnt_na, ep.max_iou, ep.min_dist, iou)
+    return st, rw, iou

@@ -588,48 +588,168 @@ void t2do_collide(const double* rows, int row_stride, int n_env, int A, const fl
     free(V); free(C); free(kind);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * IoU of two convex quadrilaterals (Arrival.update arrival.py:42-44, NoAction.update
+ * no_action.py:44-46: iou = intersection.area / union.area).  The reference delegates to GEOS
+ * overlay (parity unpinned); this restatement integrates the boundary of A n B directly:
+ * every edge of A is clipped to the closed polygon B, every edge of B to the OPEN side of A's
+ * edge lines where they are parallel (so coincident boundary pieces count once), and
+ * 2*area = sum of cross(a - O, b - O) over the kept oriented pieces (Green's theorem), O = A[0].
+ * Partial sums are combined in the fixed tree order the GPU uses.  Both quads CCW.
+ * ---------------------------------------------------------------------------------------- */
+static double clipped_edge_term(const double* p0, const double* p1, const double* Q, int strict,
+                                const double* O) {
+    const double dx = p1[0] - p0[0], dy = p1[1] - p0[1];
+    double t0 = 0.0, t1 = 1.0;
+    int ok = 1;
+    for (int j = 0; j < 4; ++j) {
+        const double* q0 = Q + 2 * j;
+        const double* q1 = Q + 2 * ((j + 1) & 3);
+        const double ex = q1[0] - q0[0], ey = q1[1] - q0[1];
+        const double num = ex * (p0[1] - q0[1]) - ey * (p0[0] - q0[0]); /* inside <=> num + t*den >= 0 */
+        const double den = ex * dy - ey * dx;
+        if (den == 0.0) {
+            if (num < 0.0 || (strict && num == 0.0)) ok = 0;
+        } else {
+            const double tc = -num / den;
+            if (den > 0.0) t0 = tc > t0 ? tc : t0;
+            else t1 = tc < t1 ? tc : t1;
+        }
+    }
+    if (!ok || !(t0 < t1)) return 0.0;
+    const double ax = p0[0] + t0 * dx - O[0], ay = p0[1] + t0 * dy - O[1];
+    const double bx = p0[0] + t1 * dx - O[0], by = p0[1] + t1 * dy - O[1];
+    return ax * by - bx * ay;
+}
+
+static double quad_area2(const double* P) {
+    double a = 0.0;
+    for (int i = 0; i < 4; ++i) {
+        const double* p = P + 2 * i;
+        const double* q = P + 2 * ((i + 1) & 3);
+        a += (p[0] - P[0]) * (q[1] - P[1]) - (q[0] - P[0]) * (p[1] - P[1]);
+    }
+    return a;
+}
+
+/* twice the area of A n B */
+double t2do_quad_intersection_area2(const double* A, const double* B) {
+    double s[8];
+    for (int i = 0; i < 4; ++i) s[i] = clipped_edge_term(A + 2 * i, A + 2 * ((i + 1) & 3), B, 0, A);
+    for (int i = 0; i < 4; ++i) s[4 + i] = clipped_edge_term(B + 2 * i, B + 2 * ((i + 1) & 3), A, 1, A);
+    return ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+double t2do_quad_iou(const double* A, const double* B) {
+    double inter = t2do_quad_intersection_area2(A, B);
+    if (inter < 0.0) inter = 0.0;
+    const double uni = quad_area2(A) + quad_area2(B) - inter;
+    return inter / uni;
+}
+
 /* _ParkingScenarioManager.update/check_status (envs/parking.py:352-392) and
- * ParkingEnv.step/_get_reward (envs/parking.py:219-256,148-166) for the events this build
- * evaluates, in the reference's early-return order:
- *   time exceed (cnt_step > max_step, time_exceed.py:32-33)  -> TIME_EXCEEDED, reward -1
- *   [no-action: IoU based, "next" row, not evaluated]
- *   out of bound                                             -> OUT_BOUND, reward -5
- *   collision (static; dynamic / off-lane when enabled)      -> FAILED + COLLISION_*, reward -5
- *   otherwise NORMAL, reward = -tanh(cnt_step / max_step) * scale (the IoU / distance
- *   shaping terms of :164-188 belong to the "next" rows).
+ * ParkingEnv.step/_get_reward (envs/parking.py:219-256,148-190), in the reference's early-return
+ * order, for the ego of every env:
+ *   time exceed (cnt_step > max_step, time_exceed.py:32-33)   -> TIME_EXCEEDED; later detectors are
+ *                                                                NOT updated this step
+ *   no action   (NoAction.update no_action.py:32-53)          -> traffic_status = 5 (the reference
+ *                 stores ScenarioStatus.NO_ACTION in traffic_status, parking.py:373), scenario NORMAL
+ *   out of bound                                              -> OUT_BOUND
+ *   static collision                                          -> FAILED + COLLISION_STATIC
+ *   [build-defined: dynamic collision / off-lane when enabled -> FAILED + COLLISION_DYNAMIC / OFF_LANE]
+ *   arrival     (Arrival.update arrival.py:32-47)             -> COMPLETED when IoU >= threshold
+ * reward (_get_reward :148-190): -5 static collision, -1 time exceeded, -5 out of bound, +5 completed,
+ * else time penalty -tanh(cnt/max_step)*0.001 + (shaped_reward: IoU gain over the best IoU so far +
+ * 0.1 * improvement of the best distance to the target centroid).  The no-action case falls into
+ * the shaped branch with iou = None exactly like the reference.
+ * Per-env IoU state (NULL when the IoU features are off): ego_pose (8 doubles, CCW, from
+ * t2do_pose_obb), ego_xy, ego_is_obb, target (8 doubles CCW) / target_c (centroid) / has_target,
+ * last_pose / last_valid / cnt_na (NoAction), max_iou / min_dist (reward shaping), iou_out (NaN = None).
  * status: 4 bytes per env = scenario, traffic, terminated, truncated.                    */
-void t2do_status(const t2d_status_config* cfg, int n_env, int A, const uint32_t* flags,
-                 int interval_ms, int32_t* cnt_step, int32_t* frame_ms, uint8_t* status,
-                 float* reward) {
+void t2do_status_ex(const t2d_status_config* cfg, int n_env, int A, const uint32_t* flags,
+                    int interval_ms, int32_t* cnt_step, int32_t* frame_ms, uint8_t* status, float* reward,
+                    const double* ego_pose, const double* ego_xy, const uint8_t* ego_is_obb,
+                    const double* target, const double* target_c, int has_target, double* last_pose,
+                    uint8_t* last_valid, int32_t* cnt_na, double* max_iou, double* min_dist, float* iou_out) {
     for (int e = 0; e < n_env; ++e) {
         cnt_step[e] += 1; /* parking.py:353 */
         frame_ms[e] += interval_ms;
         uint32_t f = flags[(size_t)e * A + cfg->ego_index];
         int scen = T2D_SCENARIO_NORMAL, traf = T2D_TRAFFIC_NORMAL;
-        float r;
+        double iou = 0.0;
+        int has_iou = 0;
+        const int obb = ego_is_obb ? ego_is_obb[e] : 0;
         if (cfg->max_step > 0 && cnt_step[e] > cfg->max_step) {
-            scen = T2D_SCENARIO_TIME_EXCEEDED; r = cfg->reward_time_exceed;
-        } else if (f & T2D_FLAG_OUT_BOUND) {
-            scen = T2D_SCENARIO_OUT_BOUND; r = cfg->reward_out_bound;
-        } else if (f & T2D_FLAG_COLLISION_STATIC) {
-            scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_COLLISION_STATIC; r = cfg->reward_collision;
-        } else if (cfg->check_dynamic && (f & T2D_FLAG_COLLISION_DYNAMIC)) {
-            scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_COLLISION_DYNAMIC; r = cfg->reward_collision;
-        } else if (cfg->check_off_lane && (f & T2D_FLAG_OFF_LANE)) {
-            scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_OFF_LANE; r = cfg->reward_collision;
+            scen = T2D_SCENARIO_TIME_EXCEEDED; /* parking.py:366-369 */
         } else {
-            double tp = cfg->max_step > 0 ? -tanh((double)cnt_step[e] / (double)cfg->max_step) *
-                                                (double)cfg->time_penalty_scale
-                                          : 0.0;
-            r = (float)tp;
+            int na = 0;
+            if (cfg->check_no_action && obb && last_pose) { /* parking.py:371-374, no_action.py:41-53 */
+                const double* pose = ego_pose + 8 * (size_t)e;
+                double* last = last_pose + 8 * (size_t)e;
+                if (!last_valid[e]) {
+                    last_valid[e] = 1;
+                } else {
+                    const double i2 = t2do_quad_iou(pose, last);
+                    cnt_na[e] = i2 > (double)cfg->no_action_iou ? cnt_na[e] + 1 : 0;
+                }
+                memcpy(last, pose, 8 * sizeof(double));
+                na = cnt_na[e] > cfg->no_action_max_step;
+            }
+            if (na) {
+                traf = T2D_TRAFFIC_NO_ACTION_QUIRK;
+            } else if (f & T2D_FLAG_OUT_BOUND) {
+                scen = T2D_SCENARIO_OUT_BOUND;
+            } else if (f & T2D_FLAG_COLLISION_STATIC) {
+                scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_COLLISION_STATIC;
+            } else if (cfg->check_dynamic && (f & T2D_FLAG_COLLISION_DYNAMIC)) {
+                scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_COLLISION_DYNAMIC;
+            } else if (cfg->check_off_lane && (f & T2D_FLAG_OFF_LANE)) {
+                scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_OFF_LANE;
+            } else if (cfg->check_arrival && has_target && obb) { /* parking.py:387-390 */
+                iou = t2do_quad_iou(ego_pose + 8 * (size_t)e, target + 8 * (size_t)e);
+                has_iou = 1;
+                if (iou >= (double)cfg->arrival_threshold) scen = T2D_SCENARIO_COMPLETED;
+            }
+        }
+        double r;
+        if (traf == T2D_TRAFFIC_COLLISION_STATIC) r = cfg->reward_collision;           /* :151-152 */
+        else if (scen == T2D_SCENARIO_TIME_EXCEEDED || scen == T2D_SCENARIO_NO_ACTION) r = cfg->reward_time_exceed;
+        else if (scen == T2D_SCENARIO_OUT_BOUND) r = cfg->reward_out_bound;
+        else if (scen == T2D_SCENARIO_COMPLETED) r = cfg->reward_completed;
+        else if (traf == T2D_TRAFFIC_COLLISION_DYNAMIC || traf == T2D_TRAFFIC_OFF_LANE) r = cfg->reward_collision;
+        else {
+            r = cfg->max_step > 0 ? -tanh((double)cnt_step[e] / (double)cfg->max_step) * (double)cfg->time_penalty_scale
+                                  : 0.0; /* :163 */
+            if (cfg->shaped_reward && max_iou) {
+                double iou_reward = 0.0;                                               /* :164-167 */
+                if (has_iou) iou_reward = max_iou[e] == -INFINITY ? iou : iou - max_iou[e];
+                r = r + iou_reward;                                                    /* :169 */
+                if (has_iou) max_iou[e] = max_iou[e] > iou ? max_iou[e] : iou;         /* :170 */
+                if (has_target) {
+                    const double dx = ego_xy[2 * e] - target_c[2 * e], dy = ego_xy[2 * e + 1] - target_c[2 * e + 1];
+                    const double d = sqrt(dx * dx + dy * dy);                          /* :172-185 */
+                    if (d < min_dist[e]) {
+                        r += (min_dist[e] - d) * (double)cfg->dist_reward_scale;       /* :186-188 */
+                        min_dist[e] = d;
+                    }
+                }
+            }
         }
         status[4 * e] = (uint8_t)scen;
         status[4 * e + 1] = (uint8_t)traf;
         status[4 * e + 2] = scen == T2D_SCENARIO_COMPLETED;                       /* :245-246 */
         status[4 * e + 3] = scen != T2D_SCENARIO_COMPLETED &&
                             (scen != T2D_SCENARIO_NORMAL || traf != T2D_TRAFFIC_NORMAL); /* :247-248 */
-        reward[e] = r;
+        reward[e] = (float)r;
+        if (iou_out) iou_out[e] = has_iou ? (float)iou : NAN;
     }
+}
+
+void t2do_status(const t2d_status_config* cfg, int n_env, int A, const uint32_t* flags,
+                 int interval_ms, int32_t* cnt_step, int32_t* frame_ms, uint8_t* status,
+                 float* reward) {
+    t2do_status_ex(cfg, n_env, A, flags, interval_ms, cnt_step, frame_ms, status, reward, NULL, NULL, NULL,
+                   NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL);
 }
 
 int t2do_abi_version(void) { return T2D_ABI_VERSION; }

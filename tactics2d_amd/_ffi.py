@@ -29,7 +29,11 @@ class StatusConfig(C.Structure):
     _fields_ = [("max_step", C.c_int32), ("ego_index", C.c_int32), ("check_dynamic", C.c_int32),
                 ("check_off_lane", C.c_int32), ("reward_collision", C.c_float),
                 ("reward_time_exceed", C.c_float), ("reward_out_bound", C.c_float),
-                ("reward_completed", C.c_float), ("time_penalty_scale", C.c_float)]
+                ("reward_completed", C.c_float), ("time_penalty_scale", C.c_float),
+                ("check_arrival", C.c_int32), ("check_no_action", C.c_int32),
+                ("no_action_max_step", C.c_int32), ("shaped_reward", C.c_int32),
+                ("arrival_threshold", C.c_float), ("no_action_iou", C.c_float),
+                ("dist_reward_scale", C.c_float)]
 
 
 # every symbol include/t2d.h declares: name -> (restype, argtypes)
@@ -43,6 +47,7 @@ SYMBOLS = {
     "t2d_set_static_geometry": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "t2d_set_lane_geometry": (C.c_int, [_vp, _vp, _vp, _vp]),
     "t2d_set_status_config": (C.c_int, [_vp, C.POINTER(StatusConfig)]),
+    "t2d_set_target_areas": (C.c_int, [_vp, _vp, _vp]),
     "t2d_reset": (C.c_int, [_vp] * 10),
     "t2d_bind_actions": (C.c_int, [_vp, _vp, _vp]),
     "t2d_integrate": (C.c_int, [_vp, C.c_int32, _vp]),

@@ -192,6 +192,48 @@ int rebuild_geo(t2d_pool* p) {
     return T2D_OK;
 }
 
+// (Re)initialise the per-env IoU / shaping state: NoAction forgets its pose, _max_iou = -inf,
+// _min_dist_to_target = ||start - target centroid|| (envs/parking.py:280-296), inf without targets.
+int init_iou_state(t2d_pool* p, const uint8_t* env_mask, const float* hx, const float* hy) {
+    const int E = p->v.n_env, A = p->v.A, ego = p->status_cfg.ego_index;
+    std::vector<double> maxi(E), mind(E), tc;
+    std::vector<uint8_t> lv(E);
+    std::vector<int32_t> cna(E);
+    std::vector<float> iou(E);
+    const bool partial = env_mask != nullptr;
+    if (partial) {
+        T2D_HIP(p, hipMemcpy(maxi.data(), p->d_max_iou, sizeof(double) * E, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(mind.data(), p->d_min_dist, sizeof(double) * E, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(lv.data(), p->d_last_valid, E, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(cna.data(), p->v.cnt_na, 4 * (size_t)E, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(iou.data(), p->v.iou, 4 * (size_t)E, hipMemcpyDeviceToHost));
+    }
+    if (p->have_target) {
+        tc.resize(2 * (size_t)E);
+        T2D_HIP(p, hipMemcpy(tc.data(), p->d_target_c, sizeof(double) * 2 * E, hipMemcpyDeviceToHost));
+    }
+    for (int e = 0; e < E; ++e) {
+        if (partial && !env_mask[e]) continue;
+        maxi[e] = -INFINITY;
+        lv[e] = 0;
+        cna[e] = 0;
+        iou[e] = NAN;
+        if (p->have_target) {
+            const double dx = (double)hx[(size_t)e * A + ego] - tc[2 * (size_t)e];
+            const double dy = (double)hy[(size_t)e * A + ego] - tc[2 * (size_t)e + 1];
+            mind[e] = sqrt(dx * dx + dy * dy);
+        } else {
+            mind[e] = INFINITY;
+        }
+    }
+    T2D_HIP(p, hipMemcpy(p->d_max_iou, maxi.data(), sizeof(double) * E, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->d_min_dist, mind.data(), sizeof(double) * E, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->d_last_valid, lv.data(), E, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->v.cnt_na, cna.data(), 4 * (size_t)E, hipMemcpyHostToDevice));
+    T2D_HIP(p, hipMemcpy(p->v.iou, iou.data(), 4 * (size_t)E, hipMemcpyHostToDevice));
+    return T2D_OK;
+}
+
 int record_event(t2d_pool* p, int kernel_id, hipStream_t s, bool begin) {
     if (!p->profiling) return T2D_OK;
     if (begin) {
@@ -234,6 +276,8 @@ __global__ __launch_bounds__(256) void restore_env_kernel(PoolView pv, int mode)
         if (!(st.z | st.w)) return;
     }
     pv.env_flags[env] = 0; pv.cnt_step[env] = 0; pv.frame_ms[env] = 0; pv.reward[env] = 0.f;
+    pv.last_valid[env] = 0; pv.cnt_na[env] = 0; pv.max_iou[env] = -INFINITY;
+    pv.min_dist[env] = pv.snap_min_dist[env]; pv.iou[env] = NAN;
     uchar4 st; st.x = T2D_SCENARIO_NORMAL; st.y = T2D_TRAFFIC_NORMAL; st.z = 0; st.w = 0;
     reinterpret_cast<uchar4*>(pv.status)[env] = st;
 }
@@ -291,6 +335,23 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
         t2d_destroy(p);
         return fail(nullptr, T2D_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
     }
+    {
+        const size_t E = (size_t)n_env;
+        hipError_t e2 = hipSuccess;
+        auto alloc = [&](void** ptr, size_t bytes) {
+            if (e2 == hipSuccess) e2 = hipMalloc(ptr, bytes);
+            if (e2 == hipSuccess) e2 = hipMemset(*ptr, 0, bytes);
+        };
+        alloc((void**)&p->d_last_pose, E * 8 * sizeof(double));
+        alloc((void**)&p->d_max_iou, E * sizeof(double));
+        alloc((void**)&p->d_min_dist, E * sizeof(double));
+        alloc((void**)&p->d_snap_min_dist, E * sizeof(double));
+        alloc((void**)&p->d_last_valid, E);
+        if (e2 != hipSuccess) {
+            t2d_destroy(p);
+            return fail(nullptr, T2D_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e2));
+        }
+    }
     t2d::PoolView& v = p->v;
     v.x = (float*)p->field_ptr[T2D_F_X];
     v.y = (float*)p->field_ptr[T2D_F_Y];
@@ -310,6 +371,15 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
     v.status = (uint8_t*)p->field_ptr[T2D_F_STATUS];
     v.reward = (float*)p->field_ptr[T2D_F_REWARD];
     v.record = (uint2*)p->field_ptr[T2D_F_RECORD];
+    v.iou = (float*)p->field_ptr[T2D_F_IOU];
+    v.cnt_na = (int32_t*)p->field_ptr[T2D_F_CNT_NO_ACTION];
+    v.target_xy = nullptr;
+    v.target_c = nullptr;
+    v.last_pose = p->d_last_pose;
+    v.last_valid = p->d_last_valid;
+    v.max_iou = p->d_max_iou;
+    v.min_dist = p->d_min_dist;
+    v.snap_min_dist = p->d_snap_min_dist;
     v.params = p->d_params;
     v.cell = 1.0;
     v.inv_cell = 1.0;
@@ -325,7 +395,8 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
     v.geo_layout = t2d::GeoLayout{};
     v.geo_layout.epb = 256 >> log2_pad(max_agents);
     // ParkingEnv defaults: envs/parking.py:106 (max_step 2e4), :151-163 (reward table)
-    p->status_cfg = t2d_status_config{20000, 0, 0, 0, -5.0f, -1.0f, -5.0f, 5.0f, 0.001f};
+    p->status_cfg = t2d_status_config{20000, 0, 0, 0, -5.0f, -1.0f, -5.0f, 5.0f, 0.001f,
+                                      0, 0, 100, 0, 0.95f, 0.999f, 0.1f};
     *out_pool = p;
     return T2D_OK;
 }
@@ -335,7 +406,8 @@ int t2d_destroy(t2d_pool* p) {
     (void)hipSetDevice(p->device);
     for (int f = 0; f < T2D_F_COUNT; ++f)
         if (p->field_ptr[f]) (void)hipFree(p->field_ptr[f]);
-    void* bufs[] = {p->d_params, p->d_geo, p->d_boundary, p->d_boundary_valid,
+    void* bufs[] = {p->d_params, p->d_geo, p->d_boundary, p->d_boundary_valid, p->d_target_xy, p->d_target_c,
+                    p->d_last_pose, p->d_max_iou, p->d_min_dist, p->d_snap_min_dist, p->d_last_valid,
                     p->d_snap[0], p->d_snap[1], p->d_snap[2],
                     p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids};
     for (void* b : bufs)
@@ -429,6 +501,65 @@ int t2d_set_lane_geometry(t2d_pool* p, const int32_t* env_lane_offsets,
     return rebuild_geo(p);
 }
 
+int t2d_set_target_areas(t2d_pool* p, const float* target_xy, const float* centroid) {
+    if (!p) return T2D_ERR_INVALID;
+    T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, hipDeviceSynchronize());
+    const int E = p->v.n_env;
+    int rc;
+    if (!target_xy) {
+        if ((rc = dev_replace<double>(p, &p->d_target_xy, nullptr, 0))) return rc;
+        if ((rc = dev_replace<double>(p, &p->d_target_c, nullptr, 0))) return rc;
+        p->have_target = false;
+    } else {
+        std::vector<double> xy(8 * (size_t)E), c(2 * (size_t)E);
+        for (int e = 0; e < E; ++e) {
+            std::vector<double> q(8);
+            for (int k = 0; k < 8; ++k) q[k] = (double)target_xy[8 * (size_t)e + k];
+            double a = area2(q);
+            if (a < 0.0) {  // clockwise -> reverse
+                for (int i = 0, j = 3; i < j; ++i, --j) {
+                    std::swap(q[2 * i], q[2 * j]);
+                    std::swap(q[2 * i + 1], q[2 * j + 1]);
+                }
+                a = -a;
+            }
+            if (!(a > 0.0)) return fail(p, T2D_ERR_GEOMETRY, "target area " + std::to_string(e) + " is degenerate");
+            for (int i = 0; i < 4; ++i)
+                if (orient_h(&q[2 * i], &q[2 * ((i + 1) & 3)], &q[2 * ((i + 2) & 3)]) < 0.0)
+                    return fail(p, T2D_ERR_GEOMETRY, "target area " + std::to_string(e) + " is not convex");
+            memcpy(&xy[8 * (size_t)e], q.data(), 8 * sizeof(double));
+            if (centroid) {
+                c[2 * (size_t)e] = centroid[2 * (size_t)e];
+                c[2 * (size_t)e + 1] = centroid[2 * (size_t)e + 1];
+            } else {  // area centroid of the polygon (shapely Polygon.centroid)
+                double cx = 0.0, cy = 0.0;
+                for (int i = 0; i < 4; ++i) {
+                    const int j = (i + 1) & 3;
+                    const double w = q[2 * i] * q[2 * j + 1] - q[2 * j] * q[2 * i + 1];
+                    cx += (q[2 * i] + q[2 * j]) * w;
+                    cy += (q[2 * i + 1] + q[2 * j + 1]) * w;
+                }
+                c[2 * (size_t)e] = cx / (3.0 * a);
+                c[2 * (size_t)e + 1] = cy / (3.0 * a);
+            }
+        }
+        if ((rc = dev_replace(p, &p->d_target_xy, xy.data(), xy.size()))) return rc;
+        if ((rc = dev_replace(p, &p->d_target_c, c.data(), c.size()))) return rc;
+        p->have_target = true;
+    }
+    p->v.target_xy = p->d_target_xy;
+    p->v.target_c = p->d_target_c;
+    if (p->have_reset) {  // distance-to-target of the shaping restarts from the current state
+        const size_t N = (size_t)p->v.N;
+        std::vector<float> hx(N), hy(N);
+        T2D_HIP(p, hipMemcpy(hx.data(), p->v.x, 4 * N, hipMemcpyDeviceToHost));
+        T2D_HIP(p, hipMemcpy(hy.data(), p->v.y, 4 * N, hipMemcpyDeviceToHost));
+        if ((rc = init_iou_state(p, nullptr, hx.data(), hy.data()))) return rc;
+    }
+    return T2D_OK;
+}
+
 int t2d_set_status_config(t2d_pool* p, const t2d_status_config* cfg) {
     if (!p) return T2D_ERR_INVALID;
     if (!cfg) return fail(p, T2D_ERR_INVALID, "cfg is null");
@@ -506,6 +637,10 @@ int t2d_reset(t2d_pool* p, const uint8_t* env_mask, const float* x, const float*
     T2D_HIP(p, hipMemcpy(p->v.frame_ms, hframe.data(), 4 * (size_t)E, hipMemcpyHostToDevice));
     T2D_HIP(p, hipMemcpy(p->v.status, hstat.data(), 4 * (size_t)E, hipMemcpyHostToDevice));
     T2D_HIP(p, hipMemcpy(p->v.reward, hrew.data(), 4 * (size_t)E, hipMemcpyHostToDevice));
+    {
+        int rc2 = init_iou_state(p, env_mask, hx.data(), hy.data());
+        if (rc2 != T2D_OK) return rc2;
+    }
     p->have_reset = true;
     return T2D_OK;
 }
@@ -592,6 +727,7 @@ int t2d_snapshot(t2d_pool* p) {
     }
     if (!p->d_snap_ids) T2D_HIP(p, hipMalloc((void**)&p->d_snap_ids, nb));
     T2D_HIP(p, hipMemcpy(p->d_snap_ids, p->v.ids, nb, hipMemcpyDeviceToDevice));
+    T2D_HIP(p, hipMemcpy(p->d_snap_min_dist, p->d_min_dist, sizeof(double) * p->v.n_env, hipMemcpyDeviceToDevice));
     p->have_snapshot = true;
     for (int k = 0; k < 6; ++k) p->v.snap[k] = p->d_snap[k];
     p->v.snap_ids = p->d_snap_ids;

@@ -206,6 +206,59 @@ __device__ __noinline__ bool circle_vs_generic(double cx, double cy, double R, c
     return hit;
 }
 
+// ---- IoU of two convex quads (Arrival / NoAction), oracle t2do_quad_iou: the boundary of A n B is
+// integrated directly -- every edge of A clipped to closed B, every edge of B clipped to A with
+// coincident (parallel, on-the-line) pieces dropped -- and the 8 partial sums are combined in a
+// fixed tree order.  Out of line: only the ego lane of an env runs it.
+T2D_DEV double clipped_edge_term(double p0x, double p0y, double p1x, double p1y, const Quad& Q, bool strict,
+                                 double Ox, double Oy) {
+    const double dx = p1x - p0x, dy = p1y - p0y;
+    double t0 = 0.0, t1 = 1.0;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = (j + 1) & 3;
+        const double ex = Q.x[k] - Q.x[j], ey = Q.y[k] - Q.y[j];
+        const double num = ex * (p0y - Q.y[j]) - ey * (p0x - Q.x[j]);
+        const double den = ex * dy - ey * dx;
+        if (den == 0.0) {
+            if (num < 0.0 || (strict && num == 0.0)) ok = false;
+        } else {
+            const double tc = -num / den;
+            if (den > 0.0) t0 = tc > t0 ? tc : t0;
+            else t1 = tc < t1 ? tc : t1;
+        }
+    }
+    if (!ok || !(t0 < t1)) return 0.0;
+    const double ax = p0x + t0 * dx - Ox, ay = p0y + t0 * dy - Oy;
+    const double bx = p0x + t1 * dx - Ox, by = p0y + t1 * dy - Oy;
+    return ax * by - bx * ay;
+}
+
+T2D_DEV double quad_area2(const Quad& P) {
+    double a = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = (i + 1) & 3;
+        a += (P.x[i] - P.x[0]) * (P.y[k] - P.y[0]) - (P.x[k] - P.x[0]) * (P.y[i] - P.y[0]);
+    }
+    return a;
+}
+
+__device__ __noinline__ double quad_iou(const Quad A, const Quad B) {
+    double s[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = (i + 1) & 3;
+        s[i] = clipped_edge_term(A.x[i], A.y[i], A.x[k], A.y[k], B, false, A.x[0], A.y[0]);
+        s[4 + i] = clipped_edge_term(B.x[i], B.y[i], B.x[k], B.y[k], A, true, A.x[0], A.y[0]);
+    }
+    double inter = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    if (inter < 0.0) inter = 0.0;
+    const double uni = quad_area2(A) + quad_area2(B) - inter;
+    return inter / uni;
+}
+
 T2D_DEV uint32_t cell_hash(int cx, int cy) {
     return ((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u);
 }
@@ -698,25 +751,81 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             const int cnt = pv.cnt_step[env] + 1;  // parking.py:353
             pv.cnt_step[env] = cnt;
             pv.frame_ms[env] += interval_ms;
-            const uint32_t ef = s_flags[(env_local << log2A) + cfg.ego_index];
+            const int ego = (env_local << log2A) + cfg.ego_index;  // workgroup-local lane of the ego
+            const uint32_t ef = s_flags[ego];
             int scen = T2D_SCENARIO_NORMAL, traf = T2D_TRAFFIC_NORMAL;
-            float r;
+            double iou = 0.0;
+            bool has_iou = false;
+            const bool ego_obb = s_kind[ego] == T2D_SHAPE_OBB;
             if (cfg.max_step > 0 && cnt > cfg.max_step) {
-                scen = T2D_SCENARIO_TIME_EXCEEDED; r = cfg.reward_time_exceed;
-            } else if (ef & T2D_FLAG_OUT_BOUND) {
-                scen = T2D_SCENARIO_OUT_BOUND; r = cfg.reward_out_bound;
-            } else if (ef & T2D_FLAG_COLLISION_STATIC) {
-                scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_COLLISION_STATIC; r = cfg.reward_collision;
-            } else if (cfg.check_dynamic && (ef & T2D_FLAG_COLLISION_DYNAMIC)) {
-                scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_COLLISION_DYNAMIC; r = cfg.reward_collision;
-            } else if (cfg.check_off_lane && (ef & T2D_FLAG_OFF_LANE)) {
-                scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_OFF_LANE; r = cfg.reward_collision;
+                scen = T2D_SCENARIO_TIME_EXCEEDED;  // later detectors are not updated (parking.py:366-369)
             } else {
-                const double tp = cfg.max_step > 0
-                                      ? -tanh((double)cnt / (double)cfg.max_step) * (double)cfg.time_penalty_scale
-                                      : 0.0;
-                r = (float)tp;
+                bool na = false;
+                if (cfg.check_no_action && ego_obb) {  // NoAction.update (no_action.py:41-53)
+                    const Quad pose = load_obb_lds(&s_v[0][ego]);
+                    double* last = pv.last_pose + 8 * (size_t)env;
+                    int cna = pv.cnt_na[env];
+                    if (!pv.last_valid[env]) {
+                        pv.last_valid[env] = 1;
+                    } else {
+                        Quad lq;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { lq.x[k] = last[2 * k]; lq.y[k] = last[2 * k + 1]; }
+                        cna = quad_iou(pose, lq) > (double)cfg.no_action_iou ? cna + 1 : 0;
+                        pv.cnt_na[env] = cna;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { last[2 * k] = pose.x[k]; last[2 * k + 1] = pose.y[k]; }
+                    na = cna > cfg.no_action_max_step;
+                }
+                if (na) {
+                    traf = T2D_TRAFFIC_NO_ACTION_QUIRK;  // parking.py:373 writes ScenarioStatus.NO_ACTION here
+                } else if (ef & T2D_FLAG_OUT_BOUND) {
+                    scen = T2D_SCENARIO_OUT_BOUND;
+                } else if (ef & T2D_FLAG_COLLISION_STATIC) {
+                    scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_COLLISION_STATIC;
+                } else if (cfg.check_dynamic && (ef & T2D_FLAG_COLLISION_DYNAMIC)) {
+                    scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_COLLISION_DYNAMIC;
+                } else if (cfg.check_off_lane && (ef & T2D_FLAG_OFF_LANE)) {
+                    scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_OFF_LANE;
+                } else if (cfg.check_arrival && pv.target_xy && ego_obb) {  // Arrival.update (arrival.py:42-47)
+                    Quad tq;
+                    const double* t = pv.target_xy + 8 * (size_t)env;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { tq.x[k] = t[2 * k]; tq.y[k] = t[2 * k + 1]; }
+                    iou = quad_iou(load_obb_lds(&s_v[0][ego]), tq);
+                    has_iou = true;
+                    if (iou >= (double)cfg.arrival_threshold) scen = T2D_SCENARIO_COMPLETED;
+                }
             }
+            double rd;  // ParkingEnv._get_reward (envs/parking.py:148-190)
+            if (traf == T2D_TRAFFIC_COLLISION_STATIC) rd = cfg.reward_collision;
+            else if (scen == T2D_SCENARIO_TIME_EXCEEDED || scen == T2D_SCENARIO_NO_ACTION) rd = cfg.reward_time_exceed;
+            else if (scen == T2D_SCENARIO_OUT_BOUND) rd = cfg.reward_out_bound;
+            else if (scen == T2D_SCENARIO_COMPLETED) rd = cfg.reward_completed;
+            else if (traf == T2D_TRAFFIC_COLLISION_DYNAMIC || traf == T2D_TRAFFIC_OFF_LANE) rd = cfg.reward_collision;
+            else {
+                rd = cfg.max_step > 0 ? -tanh((double)cnt / (double)cfg.max_step) * (double)cfg.time_penalty_scale : 0.0;
+                if (cfg.shaped_reward) {
+                    double mi = pv.max_iou[env];
+                    double iou_reward = 0.0;
+                    if (has_iou) iou_reward = mi == -INFINITY ? iou : iou - mi;
+                    rd = rd + iou_reward;
+                    if (has_iou) pv.max_iou[env] = mi > iou ? mi : iou;
+                    if (pv.target_c) {
+                        const double dx = s_c[0][ego] - pv.target_c[2 * (size_t)env];
+                        const double dy = s_c[1][ego] - pv.target_c[2 * (size_t)env + 1];
+                        const double d = __builtin_sqrt(dx * dx + dy * dy);
+                        const double md = pv.min_dist[env];
+                        if (d < md) {
+                            rd += (md - d) * (double)cfg.dist_reward_scale;
+                            pv.min_dist[env] = d;
+                        }
+                    }
+                }
+            }
+            const float r = (float)rd;
+            pv.iou[env] = has_iou ? (float)iou : __builtin_nanf("");
             const bool terminated = scen == T2D_SCENARIO_COMPLETED;
             const bool truncated = !terminated && (scen != T2D_SCENARIO_NORMAL || traf != T2D_TRAFFIC_NORMAL);
             uchar4 st;
@@ -729,9 +838,13 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             if (pv.auto_reset) {
                 const bool done = terminated || truncated;
                 s_done[env_local] = done;
-                if (done) {  // ParkingEnv.reset: counters back to the episode start
+                if (done) {  // ParkingEnv.reset: counters and detector state back to the episode start
                     pv.cnt_step[env] = 0;
                     pv.frame_ms[env] = 0;
+                    pv.last_valid[env] = 0;
+                    pv.cnt_na[env] = 0;
+                    pv.max_iou[env] = -INFINITY;
+                    pv.min_dist[env] = pv.snap_min_dist[env];
                 }
             }
         }

@@ -52,6 +52,16 @@ struct PoolView {
     GeoLayout geo_layout;
     const float* boundary;         // [4*E] or null
     const uint8_t* boundary_valid; // [E] or null
+    // IoU events of the ego (Arrival / NoAction) and reward shaping state, per env
+    const double* target_xy;   // [E][8] CCW target quad, or null
+    const double* target_c;    // [E][2] its area centroid
+    double* last_pose;         // [E][8] pose seen by the previous NoAction.update
+    uint8_t* last_valid;       // [E]
+    int32_t* cnt_na;           // [E] NoAction.cnt_no_action
+    double* max_iou;           // [E] ParkingEnv._max_iou
+    double* min_dist;          // [E] ParkingEnv._min_dist_to_target
+    const double* snap_min_dist;  // [E] value at the snapshot (episode start)
+    float* iou;                // [E] last IoU(pose, target), NaN = None
     const float* snap[6];      // episode-start snapshot (x, y, heading, speed, vx, vy) or null
     const uint32_t* snap_ids;
     int32_t auto_reset;        // t2d_step restores finished envs in its epilogue
@@ -89,6 +99,10 @@ struct t2d_pool {
         std::vector<int32_t> env_off, vert_off;
         std::vector<float> xy, aabb;
     } hgeo[2];
+    double *d_target_xy = nullptr, *d_target_c = nullptr, *d_last_pose = nullptr, *d_max_iou = nullptr,
+           *d_min_dist = nullptr, *d_snap_min_dist = nullptr;
+    uint8_t* d_last_valid = nullptr;
+    bool have_target = false;
     float* d_snap[6]{};      // x, y, heading, speed, vx, vy at episode start
     uint32_t* d_snap_ids = nullptr;
     bool have_snapshot = false;

@@ -3,10 +3,11 @@
 Mirrors (tactics2d v0.1.9rc3) `ParkingEnv` -- envs/parking.py:44-444 -- for the part that is on
 the accelerated path: `step()` = physics update of the ego (`_ParkingScenarioManager.update`, :352-359)
 + ordered status checks (`check_status`, :361-392) + terminated / truncated / reward (:243-250,
-:148-166).  The rendered camera observation, the lidar and the IoU-based events (`Arrival`,
-`NoAction`) are "next" rows of the scope table: observations here are the ego
-state vector, `COMPLETED` / `NO_ACTION` never occur, and the reward is the reference's table value
-for terminal events plus its time penalty (no IoU / distance shaping).
+:148-166).  `Arrival` (IoU >= 0.95 with the target bay -> COMPLETED, +5, terminated), `NoAction` (IoU with the
+previous pose > 0.999 on more than 100 checks, including the reference's quirk of reporting it in
+`traffic_status`) and the IoU / distance reward shaping are evaluated in the same launch.  The rendered
+camera observation and the lidar are "next" rows of the scope table: observations
+here are the ego state vector.
 
 gymnasium is not a dependency: `Box` below is the minimal stand-in for `spaces.Box`.
 """
@@ -69,7 +70,9 @@ class VecParkingEnv:
         sc = scenarios.parking(self.n_envs, seed0=self._seed * self.n_envs)
         self._scene = sc
         m = self.scenario_manager
-        m.configure(sc.rows, check_dynamic=False, check_off_lane=False)
+        m.pool.set_target_areas(sc.target)
+        m.configure(sc.rows, check_dynamic=False, check_off_lane=False, check_arrival=1, check_no_action=1,
+                    no_action_max_step=100, shaped_reward=1)
         m.status_checklist["collision"].reset(_csr_to_lists(sc.static))
         m.status_checklist["out_bound"].reset(sc.boundary)
         m.reset(sc.x, sc.y, sc.heading, sc.speed, sc.type_id, sc.active)
@@ -108,7 +111,9 @@ class VecParkingEnv:
         return dict(state=dict(x=obs[:, 0], y=obs[:, 1], heading=obs[:, 2], speed=obs[:, 3], vx=obs[:, 4],
                                vy=obs[:, 5], frame=self.scenario_manager.pool.download(L.F_FRAME_MS)),
                     scenario_status=scenario_status, traffic_status=traffic_status,
-                    target_area=None, target_heading=None, lidar=None)
+                    target_area=None if self._scene is None else self._scene.target,
+                    target_heading=None if self._scene is None else self._scene.target_heading,
+                    iou=self.scenario_manager.pool.download(L.F_IOU), lidar=None)
 
     def render(self):
         raise NotImplementedError("rendering is outside the accelerated path")

@@ -93,13 +93,19 @@ class ParticipantPool:
         self._ck(self._lib.t2d_set_lane_geometry(self._h, _p(eo), _p(vo), _p(xy)))
 
     def set_status_config(self, **kw):
-        cfg = _ffi.StatusConfig(20000, 0, 0, 0, -5.0, -1.0, -5.0, 5.0, 0.001)
+        cfg = _ffi.StatusConfig(20000, 0, 0, 0, -5.0, -1.0, -5.0, 5.0, 0.001, 0, 0, 100, 0, 0.95, 0.999, 0.1)
         for k, v in kw.items():
             if not hasattr(cfg, k):
                 raise TypeError(f"unknown status option {k}")
             setattr(cfg, k, v)
         self._ck(self._lib.t2d_set_status_config(self._h, C.byref(cfg)))
         self.status_config = cfg
+
+    def set_target_areas(self, target_xy=None, centroid=None):
+        """target_xy: (n_env, 4, 2) quads or None; centroid: (n_env, 2) or None (computed)."""
+        t = _arr(target_xy, np.float32, 8 * self.n_env, "target_xy")
+        c = _arr(centroid, np.float32, 2 * self.n_env, "centroid")
+        self._ck(self._lib.t2d_set_target_areas(self._h, _p(t), _p(c)))
 
     def set_integrator_variant(self, variant):
         v = {"exact": 0, "fast": 1}.get(variant, variant)

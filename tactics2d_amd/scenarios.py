@@ -58,6 +58,8 @@ class Scene:
     boundary_valid: np.ndarray = None
     status: dict = field(default_factory=dict)
     interval_ms: int = 100
+    target: np.ndarray = None          # (n_env, 4, 2) target parking areas (Arrival), or None
+    target_heading: np.ndarray = None  # (n_env,)
 
     @property
     def n(self):
@@ -67,6 +69,7 @@ class Scene:
         pool.set_param_table(self.rows)
         pool.set_static_geometry(self.static, self.boundary, self.boundary_valid)
         pool.set_lane_geometry(self.lanes)
+        pool.set_target_areas(self.target)
         pool.set_status_config(**self.status)
         pool.reset(self.x, self.y, self.heading, self.speed, self.type_id, self.active)
         pool.snapshot()
@@ -86,7 +89,9 @@ class Scene:
                      static=cut(self.static), lanes=cut(self.lanes),
                      boundary=None if self.boundary is None else self.boundary[lo:hi].copy(),
                      boundary_valid=None if self.boundary_valid is None else self.boundary_valid[lo:hi].copy(),
-                     status=dict(self.status), interval_ms=self.interval_ms)
+                     status=dict(self.status), interval_ms=self.interval_ms,
+                     target=None if self.target is None else self.target[lo:hi].copy(),
+                     target_heading=None if self.target_heading is None else self.target_heading[lo:hi].copy())
 
     def sample_actions(self, rng):
         """One batch of random actions in the reference's action conventions:
@@ -112,7 +117,7 @@ def parking(n_env, seed0=0):
                         steer_range=(-0.524, 0.524))
     Ln, W = VEHICLE_TEMPLATE["medium_car"][:2]
     rows = ego.param_row(L.SHAPE_OBB, Ln, W)[None]
-    xs, ys, hs, statics, bounds = [], [], [], [], []
+    xs, ys, hs, statics, bounds, targets, theads = [], [], [], [], [], [], []
     for e in range(n_env):
         rng = np.random.default_rng(seed0 + e)
         car = (5.3, 2.5)
@@ -137,14 +142,18 @@ def parking(n_env, seed0=0):
         if rng.uniform() > 0.5:
             sh += np.pi
         xs.append(sx); ys.append(sy); hs.append(np.mod(sh, TWO_PI)); statics.append(polys)
+        # target bay = the agent's own footprint at the bay pose (ParkingLotGenerator(vehicle_size=(L, W)),
+        # envs/parking.py:331-333, generate_parking_lot.py:116-133)
+        targets.append(_box(0.0, ty, th, Ln, W)); theads.append(th)
         bounds.append([np.floor(min(sx, 0.0) - 13), np.ceil(max(sx, 0.0) + 13),
                        np.floor(min(sy, ty) - 13), np.ceil(max(sy, ty) + 13)])
-        _ = th
     n = n_env
     return Scene("parking", n_env, 1, rows, ["medium_car:parking"], np.float32(xs), np.float32(ys),
                  np.float32(hs), np.zeros(n, np.float32), np.zeros(n, np.uint8), np.ones(n, np.uint8),
                  static=_csr(statics), boundary=np.float32(bounds),
-                 status=dict(max_step=20000, check_dynamic=0, check_off_lane=0))
+                 status=dict(max_step=20000, check_dynamic=0, check_off_lane=0, check_arrival=1, check_no_action=1,
+                             no_action_max_step=100, shaped_reward=1),
+                 target=np.float32(targets), target_heading=np.float32(theads))
 
 
 # ------------------------------------------------------------------------------- config 3

@@ -192,11 +192,11 @@ class BatchedScenarioManager:
         self.pool.set_static_geometry(self._static, self._boundary)
 
     # -- ScenarioManager interface -----------------------------------------------------------------
-    def configure(self, rows, check_dynamic=False, check_off_lane=False, **reward):
+    def configure(self, rows, check_dynamic=False, check_off_lane=False, **options):
         self.pool.set_param_table(rows)
         self.pool.set_status_config(max_step=self.max_step if self.max_step is not None else 0,
                                     ego_index=self.ego_index, check_dynamic=int(check_dynamic),
-                                    check_off_lane=int(check_off_lane), **reward)
+                                    check_off_lane=int(check_off_lane), **options)
 
     def reset(self, x, y, heading, speed, type_id, active=None, env_mask=None):
         """Load the start states (Trajectory reset + detector resets, envs/parking.py:397-441)."""

@@ -63,7 +63,6 @@ def test_non_convex_polygon_is_rejected():
 def test_step_status_reward_matches_oracle(oracle):
     """t2d_step = integrate + collide + status epilogue, against oracle integrate->collide->status
     chained on the same fp32 pool state (teacher-forced on the GPU's own fp32 state)."""
-    from oracle.oracle import StatusConfig
     from tactics2d_amd import layout as L
     from tactics2d_amd.pool import ParticipantPool
     rng = np.random.default_rng(7)
@@ -82,7 +81,7 @@ def test_step_status_reward_matches_oracle(oracle):
     pool.set_status_config(max_step=6, check_dynamic=1, check_off_lane=1)
     pool.set_integrator_variant("exact")
     pool.reset(sc["x"], sc["y"], sc["heading"], speed, sc["type_id"], sc["active"])
-    cfg = StatusConfig(6, 0, 1, 1, -5.0, -1.0, -5.0, 5.0, 0.001)
+    cfg = oracle.make_config(max_step=6, check_dynamic=1, check_off_lane=1)
     cnt = np.zeros(n_env, np.int32); frame = np.zeros(n_env, np.int32)
     seen = set()
     for step in range(9):

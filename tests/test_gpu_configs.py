@@ -53,8 +53,9 @@ def _scene(name):
 
 @pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5", "metric"])
 def test_full_size_config(oracle, name):
-    from oracle.oracle import StatusConfig
     sc = _scene(name)
+    # the IoU events keep per-env history and are covered step by step in tests/test_iou_events.py
+    sc.status.update(check_arrival=0, check_no_action=0, shaped_reward=0)
     rng = np.random.default_rng(17)
     acts = [sc.sample_actions(rng) for _ in range(3)]
     # stress jitter (test only): scatter the start poses so that every predicate fires within 3 steps
@@ -93,9 +94,7 @@ def test_full_size_config(oracle, name):
         assert np.array_equal(wf, big["flags"][sl]), f"{name}: flags of env {e}"
         assert we[0] == big["env_flags"][e]
         wf_all.append(wf)
-    st = sc.status
-    cfg = StatusConfig(st.get("max_step", 20000), 0, st.get("check_dynamic", 0), st.get("check_off_lane", 0),
-                       -5.0, -1.0, -5.0, 5.0, 0.001)
+    cfg = oracle.make_config(**sc.status)
     cnt = pre[6][envs].copy(); frame = pre[7][envs].copy()
     wst, wrw = oracle.status(cfg, len(envs), A, np.concatenate(wf_all), 100, cnt, frame)
     assert np.array_equal(wst, big["status"][envs]) and np.array_equal(cnt, big["cnt"][envs])

@@ -28,17 +28,17 @@ def test_vec_parking_env_step_contract(oracle):
         assert np.abs(obs[:, :4] - o[:, :4]).max() <= 1e-5
         x, y, h, v = obs[:, 0].copy(), obs[:, 1].copy(), obs[:, 2].copy(), obs[:, 3].copy()
         assert reward.shape == (256,) and terminated.dtype == bool and truncated.dtype == bool
-        assert not terminated.any()                           # COMPLETED needs the IoU row (next)
         st = infos["scenario_status"]; tr = infos["traffic_status"]
         assert (truncated == ((st != 1) | (tr != 1))).all()   # parking.py:247-248
         assert (reward[st == ScenarioStatus.TIME_EXCEEDED] == -1).all()
         assert (reward[st == ScenarioStatus.OUT_BOUND] == -5).all()
         assert (reward[tr == TrafficStatus.COLLISION_STATIC] == -5).all()
+        assert (terminated == (st == ScenarioStatus.COMPLETED)).all()
+        assert (reward[terminated] == 5).all()
         normal = (st == 1) & (tr == 1)
-        assert np.allclose(reward[normal], -np.tanh((t + 1) / 50) * 0.001, atol=1e-7)
+        assert (reward[normal] > -0.002).all() and (reward[normal] < 0.2).all()   # time penalty + shaping
         seen |= set(zip(st.tolist(), tr.tolist()))
     assert (3, 1) in seen and (1, 1) in seen                  # time exceeded after 50 steps
-    assert (infos["state"]["frame"] == 6000).all()
     env.close()
 
 
@@ -87,3 +87,20 @@ def test_scenario_manager_update_then_check_status_equals_step():
     for a, b in zip(*res):
         assert np.array_equal(a, b)
     assert (res[0][5] == 5).all()
+
+
+def test_parking_env_reaches_completed_when_parked_on_the_target():
+    """Arrival: an ego standing on the target bay -> COMPLETED, terminated, reward +5 (arrival.py, parking.py:387-390)."""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.envs import VecParkingEnv
+    from tactics2d_amd.traffic import ScenarioStatus
+    env = VecParkingEnv(64, seed=5)
+    env.reset()
+    sc = env._scene
+    tc = sc.target.mean(1)
+    pool = env.scenario_manager.pool
+    pool.reset(tc[:, 0], tc[:, 1], sc.target_heading, np.zeros(64, np.float32), sc.type_id, sc.active)
+    obs, reward, terminated, truncated, infos = env.step(np.zeros((64, 2), np.float32))
+    assert terminated.all() and not truncated.any() and (reward == 5).all()
+    assert (infos["scenario_status"] == ScenarioStatus.COMPLETED).all() and (infos["iou"] > 0.999).all()
+    env.close()

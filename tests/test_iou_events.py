@@ -1,0 +1,193 @@
+"""Scope row f1: Arrival / NoAction (IoU) events and ParkingEnv's shaped reward.
+
+The reference computes IoU with shapely/GEOS overlay (arrival.py:42-44, no_action.py:44-46), which is
+not available here: PARITY UNPINNED against that engine.  The oracle's boundary-integral IoU is pinned by
+exact hand KATs and an independent Sutherland-Hodgman clipper; the status / reward logic is pinned by
+hand-derived sequences following envs/parking.py:361-392 and :148-190 line by line."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+def box(cx, cy, h, L_, W_):
+    b = np.array([[L_ / 2, -W_ / 2], [L_ / 2, W_ / 2], [-L_ / 2, W_ / 2], [-L_ / 2, -W_ / 2]])
+    c, s = np.cos(h), np.sin(h)
+    return np.ascontiguousarray(b @ np.array([[c, -s], [s, c]]).T + [cx, cy])
+
+
+def sh_area(A, B):
+    """Independent Sutherland-Hodgman clip of A by convex B (both CCW) -> area."""
+    poly = [tuple(p) for p in A]
+    for j in range(4):
+        q0, q1 = B[j], B[(j + 1) % 4]
+        e = q1 - q0
+        out = []
+        if not poly:
+            break
+        for i in range(len(poly)):
+            S, E = np.array(poly[i - 1]), np.array(poly[i])
+            fs = e[0] * (S[1] - q0[1]) - e[1] * (S[0] - q0[0]); fe = e[0] * (E[1] - q0[1]) - e[1] * (E[0] - q0[0])
+            if fe >= 0:
+                if fs < 0:
+                    out.append(tuple(S + (E - S) * (fs / (fs - fe))))
+                out.append(tuple(E))
+            elif fs >= 0:
+                out.append(tuple(S + (E - S) * (fs / (fs - fe))))
+        poly = out
+    if len(poly) < 3:
+        return 0.0
+    P = np.array(poly)
+    return 0.5 * abs(np.sum(P[:, 0] * np.roll(P[:, 1], -1) - np.roll(P[:, 0], -1) * P[:, 1]))
+
+
+def test_iou_known_answers(oracle):
+    A = box(0, 0, 0, 4, 2)
+    assert oracle.quad_iou(A, A.copy()) == 1.0                       # identical: coincident edges count once
+    assert abs(oracle.quad_iou(A, box(2, 0, 0, 4, 2)) - 1 / 3) < 1e-15
+    assert oracle.quad_iou(A, box(10, 0, 0, 4, 2)) == 0.0
+    assert oracle.quad_iou(A, box(4, 0, 0, 4, 2)) == 0.0             # shared edge only: zero area
+    assert oracle.quad_iou(A, box(0, 0, 0, 2, 1)) == 0.25            # nested
+    assert abs(oracle.quad_iou(A, box(0.5, 0, 0, 4, 2)) - 7 / 9) < 1e-15   # collinear sides, shifted
+    assert abs(oracle.quad_iou(A, box(0, 0, np.pi / 2, 4, 2)) - 4 / 12) < 1e-12   # cross: 2x2 overlap
+    assert oracle.quad_iou(A, box(1, 0.5, 0.3, 3, 1.5)) == oracle.quad_iou(box(1, 0.5, 0.3, 3, 1.5), A) or \
+        abs(oracle.quad_iou(A, box(1, 0.5, 0.3, 3, 1.5)) - oracle.quad_iou(box(1, 0.5, 0.3, 3, 1.5), A)) < 1e-14
+
+
+def test_iou_against_independent_clipper(oracle):
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    n_overlap = 0
+    for k in range(6000):
+        if k % 3 == 0:   # NoAction regime: nearly identical poses
+            h = rng.uniform(0, 6.3); d = rng.uniform(-1e-3, 1e-3, 3)
+            A = box(1, 2, h, 4.284, 1.799); B = box(1 + d[0], 2 + d[1], h + 0.1 * d[2], 4.284, 1.799)
+        else:
+            A = box(*rng.uniform(-3, 3, 2), rng.uniform(0, 6.3), rng.uniform(1, 6), rng.uniform(0.5, 3))
+            B = box(*rng.uniform(-3, 3, 2), rng.uniform(0, 6.3), rng.uniform(1, 6), rng.uniform(0.5, 3))
+        inter = sh_area(A, B)
+        aA = 0.5 * abs(np.sum(A[:, 0] * np.roll(A[:, 1], -1) - np.roll(A[:, 0], -1) * A[:, 1]))
+        aB = 0.5 * abs(np.sum(B[:, 0] * np.roll(B[:, 1], -1) - np.roll(B[:, 0], -1) * B[:, 1]))
+        want = inter / (aA + aB - inter)
+        worst = max(worst, abs(oracle.quad_iou(A, B) - want))
+        n_overlap += inter > 0
+    assert worst < 1e-12 and n_overlap > 3000, (worst, n_overlap)
+
+
+def _rows():
+    r = np.zeros((1, 24)); r[0, 0] = 0; r[0, 1] = 1.262; r[0, 2] = 1.375; r[0, 3] = 2.637; r[0, 17] = 5
+    r[0, 18] = 0; r[0, 19] = 4.0; r[0, 20] = 2.0
+    return r
+
+
+def test_status_sequence_follows_parking_check_status(oracle):
+    """One env, hand-driven: the order of parking.py:361-392 and the reward of :148-190."""
+    rows = _rows()
+    target = np.float32([box(10, 0, 0, 4.0, 2.0)])
+    cfg = oracle.make_config(max_step=1000, check_arrival=1, check_no_action=1, no_action_max_step=2, shaped_reward=1)
+    ep = oracle.EpisodeState(1, target, None, np.float32([[0.0, 0.0]]))
+    assert ep.min_dist[0] == 10.0 and ep.max_iou[0] == -np.inf
+    cnt = np.zeros(1, np.int32); frame = np.zeros(1, np.int32)
+    tid = np.zeros(1, np.uint8); f0 = np.zeros(1, np.uint32)
+
+    def step(x, flags=f0):
+        return oracle.status_ex(cfg, 1, flags, 100, cnt, frame, rows, np.float32([x]), np.float32([0.0]),
+                                np.float32([0.0]), tid, ep)
+    # step 1: far from the target: iou 0 -> iou_reward = iou (first) = 0; distance 10 -> 9: +0.1
+    st, rw, iou = step(1.0)
+    assert st[0].tolist() == [1, 1, 0, 0] and iou[0] == 0.0
+    assert abs(rw[0] - (-np.tanh(1 / 1000) * 0.001 + 0.0 + 1.0 * 0.1)) < 1e-7
+    assert ep.max_iou[0] == 0.0 and ep.min_dist[0] == 9.0 and ep.cnt_na[0] == 0 and ep.last_valid[0] == 1
+    # steps 2-4: not moving -> IoU(pose, last) = 1 > 0.999: counter 1, 2, 3; 3 > 2 -> no action on step 4
+    for k, want_cnt in ((2, 1), (3, 2)):
+        st, rw, iou = step(1.0)
+        assert st[0].tolist() == [1, 1, 0, 0] and ep.cnt_na[0] == want_cnt
+        assert abs(rw[0] - (-np.tanh(k / 1000) * 0.001)) < 1e-9      # iou - max_iou = 0, no distance gain
+    st, rw, iou = step(1.0)
+    # reference quirk (parking.py:373): traffic_status = ScenarioStatus.NO_ACTION (5), scenario stays NORMAL,
+    # truncated, iou None, and the reward is the SHAPED branch (not -1)
+    assert st[0].tolist() == [1, 5, 0, 1] and np.isnan(iou[0]) and ep.cnt_na[0] == 3
+    assert abs(rw[0] - (-np.tanh(4 / 1000) * 0.001)) < 1e-9
+    # moving resets the counter; half way onto the target: IoU = 1/3 -> reward gains the IoU
+    st, rw, iou = step(8.0)
+    assert ep.cnt_na[0] == 0 and abs(iou[0] - 1 / 3) < 1e-6 and st[0].tolist() == [1, 1, 0, 0]
+    assert abs(rw[0] - (-np.tanh(5 / 1000) * 0.001 + (1 / 3 - 0.0) + (9.0 - 2.0) * 0.1)) < 1e-6
+    # out of bound wins over arrival and leaves iou None; NoAction was still updated before it
+    st, rw, iou = step(10.0, np.uint32([4]))
+    assert st[0].tolist() == [4, 1, 0, 1] and rw[0] == -5 and np.isnan(iou[0]) and ep.max_iou[0] == pytest.approx(1 / 3)
+    # exactly on the target: completed, +5, terminated
+    st, rw, iou = step(10.0)
+    assert st[0].tolist() == [2, 1, 1, 0] and rw[0] == 5 and iou[0] == 1.0
+    # time exceed: nothing else is updated that step (last pose keeps the previous one)
+    cnt[0] = 1000
+    last = ep.last_pose.copy()
+    st, rw, iou = step(3.0)
+    assert st[0].tolist() == [3, 1, 0, 1] and rw[0] == -1 and np.array_equal(last, ep.last_pose)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("A", [1, 8])
+def test_gpu_iou_events_match_oracle(oracle, A):
+    """t2d_step's epilogue (IoU(pose, target), NoAction counter, shaped reward, auto-reset of the detector
+    state) against the oracle chain on the pool's own fp32 states, many steps, crawling egos."""
+    from tactics2d_amd import layout as L, scenarios as S
+    from tactics2d_amd.pool import ParticipantPool
+    n_env = 512
+    sc = S.parking(n_env, seed0=77)
+    rng = np.random.default_rng(8)
+    if A > 1:   # parking egos + passive clones as extra participants (never collide: check_dynamic off)
+        def rep(a):
+            return np.repeat(a.reshape(n_env, 1), A, 1).reshape(-1).copy()
+        sc.x, sc.y, sc.heading, sc.speed = rep(sc.x), rep(sc.y), rep(sc.heading), rep(sc.speed)
+        sc.type_id, sc.active = rep(sc.type_id), rep(sc.active)
+        sc.A = A
+    # a third of the egos start ON the target (arrival), a third never moves (no action), rest drive
+    ego = np.arange(n_env) * A
+    tc = sc.target.mean(1)
+    on = np.arange(n_env) % 3 == 0
+    sc.x[ego[on]] = tc[on, 0] + rng.normal(0, 0.02, on.sum()).astype(np.float32)
+    sc.y[ego[on]] = tc[on, 1] + rng.normal(0, 0.02, on.sum()).astype(np.float32)
+    sc.heading[ego[on]] = sc.target_heading[on]
+    sc.status.update(max_step=40, no_action_max_step=5)
+    pool = ParticipantPool(n_env, A)
+    sc.load(pool)
+    pool.set_integrator_variant("exact")
+    pool.set_auto_reset(True)
+    cfg = oracle.make_config(**sc.status)
+    ep = oracle.EpisodeState(n_env, sc.target, None, np.stack([sc.x[ego], sc.y[ego]], 1))
+    cnt = np.zeros(n_env, np.int32); frame = np.zeros(n_env, np.int32)
+    still = np.arange(n_env) % 3 == 1
+    seen = set()
+    for t in range(48):
+        a0, a1 = sc.sample_actions(rng)
+        a0[ego[still]] = 0.0                                  # never accelerate: stay at speed 0
+        a0[ego[on]] = 0.0
+        pool.set_actions(a0, a1)
+        pool.step(100)
+        # the pool auto-reset finished envs; rebuild the post-integration poses with the oracle instead
+        gx, gy, gh = (pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING))
+        if t == 0:
+            x, y, h, v = sc.x.copy(), sc.y.copy(), sc.heading.copy(), sc.speed.copy()
+        oracle.set_trig(1)
+        o = oracle.integrate(sc.rows, x, y, h, v, None, None, a0, a1, sc.type_id, sc.active, 100)
+        oracle.set_trig(0)
+        x, y, h, v = (np.float32(o[:, k]) for k in range(4))
+        wf, _ = oracle.collide(sc.rows, n_env, A, x, y, h, sc.type_id, sc.active, sc.static, sc.boundary,
+                               sc.boundary_valid, sc.lanes, 0)
+        wst, wrw, wiou = oracle.status_ex(cfg, A, wf, 100, cnt, frame, sc.rows, x, y, h, sc.type_id, ep)
+        gst, grw, giou = pool.download(L.F_STATUS), pool.download(L.F_REWARD), pool.download(L.F_IOU)
+        assert np.array_equal(gst, wst), (t, np.nonzero((gst != wst).any(1))[0][:5])
+        assert np.array_equal(np.isnan(giou), np.isnan(wiou)) and np.allclose(giou, wiou, rtol=0, atol=1e-7, equal_nan=True)
+        assert np.allclose(grw, wrw, rtol=0, atol=2e-6), np.abs(grw - wrw).max()
+        seen |= set(map(tuple, gst[:, :2].tolist()))
+        # emulate the auto-reset on the oracle side
+        done = (wst[:, 2] | wst[:, 3]).astype(bool)
+        if done.any():
+            idx = (np.nonzero(done)[0][:, None] * A + np.arange(A)[None]).reshape(-1)
+            x[idx], y[idx], h[idx], v[idx] = sc.x[idx], sc.y[idx], sc.heading[idx], sc.speed[idx]
+            cnt[done] = 0; frame[done] = 0
+            ep.reset_envs(done)
+        assert np.array_equal(pool.download(L.F_CNT_NO_ACTION), ep.cnt_na)
+        assert np.array_equal(gx, x) and np.array_equal(gh, h)
+    pool.close()
+    assert {(1, 1), (2, 1), (1, 5), (3, 1)} <= seen, seen     # normal, completed, no-action quirk, time exceeded

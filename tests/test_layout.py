@@ -83,7 +83,7 @@ def test_status_config_struct_matches_oracle_mirror():
     from oracle.oracle import StatusConfig as O
     from tactics2d_amd._ffi import StatusConfig as P
     assert [(n, t) for n, t in O._fields_] == [(n, t) for n, t in P._fields_]
-    assert ctypes.sizeof(P) == 36
+    assert ctypes.sizeof(P) == 64
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

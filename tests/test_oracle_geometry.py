@@ -108,8 +108,7 @@ def test_convexity_check(oracle):
 
 def test_status_priority_order(oracle):
     """Early-return order of _ParkingScenarioManager.check_status (envs/parking.py:361-392)."""
-    from oracle.oracle import StatusConfig
-    cfg = StatusConfig(3, 0, 1, 1, -5.0, -1.0, -5.0, 5.0, 0.001)
+    cfg = oracle.make_config(max_step=3, check_dynamic=1, check_off_lane=1)
     flags = np.array([0, 4, 2, 1, 8, 4 | 2 | 1, 2 | 1], np.uint32)
     cnt = np.zeros(7, np.int32); frame = np.zeros(7, np.int32)
     st, rw = oracle.status(cfg, 7, 1, flags, 100, cnt, frame)
