@@ -4,7 +4,9 @@ There is no CPU fallback: if the shared library (built in-tree by `python -m
 tactics2d_amd.build`) is missing, or no HIP device is usable, the calls raise.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("T2D_LIB_NAME", "libt2d_hip.so"))
@@ -70,10 +72,29 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7; if this
+    library pulled in /opt/rocm's copy first, a later `import torch` would bring a second runtime
+    that finds no GPU ("No HIP GPUs are available").  So when torch is installed but not imported
+    yet, load ITS runtime first: libt2d_hip.so's DT_NEEDED libamdhip64.so.7 then resolves to it."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load libt2d_hip.so (raises if it has not been built -- no fallback)."""
     global _lib
     if _lib is None:
+        _share_torch_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -m tactics2d_amd.build` "

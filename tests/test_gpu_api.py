@@ -1,0 +1,155 @@
+"""Error behaviour and call-order rules of the C ABI (include/t2d.h), plus partial reset and the
+zero-copy paths.  The reference raises Python exceptions on its path (ValueError / KeyError /
+RuntimeError / InvalidAction); the ABI returns status codes that tactics2d_amd._ffi turns into T2DError."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _pool(n_env=4, A=2):
+    from tactics2d_amd.pool import ParticipantPool
+    return ParticipantPool(n_env, A)
+
+
+def test_call_order_is_enforced():
+    from tactics2d_amd import _ffi
+    p = _pool()
+    z = np.zeros(8, np.float32)
+    with pytest.raises(_ffi.T2DError) as e:
+        p.reset(z, z, z, z, np.zeros(8, np.uint8))
+    assert e.value.code == _ffi.ERR_STATE and "t2d_set_param_table" in str(e.value)
+    p.set_param_table(H.shape_rows())
+    for fn in (p.integrate, p.collide, p.step, p.check_status):
+        with pytest.raises(_ffi.T2DError) as e:
+            fn()
+        assert e.value.code == _ffi.ERR_STATE
+    with pytest.raises(_ffi.T2DError) as e:
+        p.set_auto_reset(True)
+    assert e.value.code == _ffi.ERR_STATE and "t2d_snapshot" in str(e.value)
+    with pytest.raises(_ffi.T2DError):
+        p.restore()
+    p.reset(z, z, z, z, np.zeros(8, np.uint8))
+    p.step(100)
+    p.close()
+
+
+def test_invalid_arguments_are_rejected_with_messages():
+    from tactics2d_amd import _ffi
+    from tactics2d_amd.pool import ParticipantPool
+    for bad in ((0, 1), (4, 0), (4, 257), (-1, 1)):
+        with pytest.raises(_ffi.T2DError) as e:
+            ParticipantPool(*bad)
+        assert e.value.code == _ffi.ERR_INVALID
+    p = _pool()
+    rows = H.shape_rows()
+    with pytest.raises(_ffi.T2DError):
+        p.set_param_table(np.zeros((33, 24)))                 # more than T2D_MAX_TYPES
+    bad_rows = rows.copy(); bad_rows[0, 17] = 0               # delta_t < 1 ms
+    with pytest.raises(_ffi.T2DError):
+        p.set_param_table(bad_rows)
+    bad_rows = rows.copy(); bad_rows[0, 0] = 7                # unknown model id
+    with pytest.raises(_ffi.T2DError):
+        p.set_param_table(bad_rows)
+    p.set_param_table(rows)
+    z = np.zeros(8, np.float32)
+    with pytest.raises(_ffi.T2DError) as e:                   # type id outside the table
+        p.reset(z, z, z, z, np.full(8, 31, np.uint8))
+    assert e.value.code == _ffi.ERR_INVALID
+    p.reset(z, z, z, z, np.zeros(8, np.uint8))
+    with pytest.raises(_ffi.T2DError):
+        p.integrate(0)                                        # interval must be positive
+    with pytest.raises(_ffi.T2DError):
+        p.set_status_config(ego_index=2)                      # >= max_agents
+    with pytest.raises(_ffi.T2DError):
+        p.set_integrator_variant(3)
+    lib = _ffi.lib()
+    buf = np.zeros(3, np.float32)                             # wrong size for a field
+    assert lib.t2d_download(p._h, 0, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == _ffi.ERR_INVALID
+    assert lib.t2d_download(p._h, 99, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == _ffi.ERR_INVALID
+    assert b"bytes" in lib.t2d_last_error(p._h)
+    assert lib.t2d_bind_actions(p._h, C.c_void_p(16), None) == _ffi.ERR_INVALID
+    assert lib.t2d_get_field(p._h, -1, None, None) == _ffi.ERR_INVALID
+    assert lib.t2d_destroy(None) == 0 and lib.t2d_sync(None) == _ffi.ERR_INVALID
+    p.close()
+
+
+def test_geometry_validation():
+    from tactics2d_amd import _ffi
+    p = _pool(2, 1)
+    quad = np.float32([[0, 0], [2, 0], [2, 2], [0, 2]])
+    nine = np.float32([[np.cos(a), np.sin(a)] for a in np.linspace(0, 2 * np.pi, 9, endpoint=False)])
+    for polys, code in (([[nine], []], _ffi.ERR_GEOMETRY),                                   # > 8 vertices
+                        ([[np.float32([[0, 0], [1, 1]])], []], _ffi.ERR_GEOMETRY),           # < 3 vertices
+                        ([[np.float32([[0, 0], [1, 1], [2, 2]])], []], _ffi.ERR_GEOMETRY),   # zero area
+                        ([[np.float32([[0, 0], [4, 0], [1, 1], [0, 4]])], []], _ffi.ERR_GEOMETRY)):  # not convex
+        with pytest.raises(_ffi.T2DError) as e:
+            p.set_static_geometry(H.to_csr(polys))
+        assert e.value.code == code, polys
+    eo, vo, xy = H.to_csr([[quad], [quad]])
+    with pytest.raises(_ffi.T2DError):                        # CSR offsets must start at 0 and be monotone
+        p._ck(p._lib.t2d_set_static_geometry(p._h, (eo + 1).ctypes.data_as(C.c_void_p), vo.ctypes.data_as(C.c_void_p),
+                                             xy.ctypes.data_as(C.c_void_p), None, None))
+    with pytest.raises(ValueError):
+        p.set_static_geometry((eo, vo[:-1], xy))              # host-side shape check
+    with pytest.raises(_ffi.T2DError):
+        p.set_target_areas(np.float32([[[0, 0], [4, 0], [1, 1], [0, 4]]] * 2))   # dart target
+    p.set_static_geometry(H.to_csr([[quad[::-1]], [quad]]))   # clockwise input is accepted
+    p.close()
+
+
+def test_partial_reset_only_touches_masked_envs():
+    from tactics2d_amd import layout as L
+    p = _pool(6, 4)
+    rows = H.load_npz("kin_random.npz")["rows"][:2]
+    p.set_param_table(rows)
+    n = 24
+    x = np.arange(n, dtype=np.float32); tid = (np.arange(n) % 2).astype(np.uint8)
+    p.reset(x, x + 1, x * 0.1, x * 0 + 2, tid)
+    p.set_actions(np.ones(n, np.float32), np.zeros(n, np.float32))
+    for _ in range(3):
+        p.step(100)
+    before = {f: p.download(f) for f in (L.F_X, L.F_SPEED, L.F_CNT_STEP, L.F_FRAME_MS, L.F_IDS)}
+    mask = np.array([0, 1, 0, 0, 1, 0], np.uint8)
+    p.reset(x * 0 - 5, x * 0, x * 0, x * 0 + 9, tid[::-1].copy(), env_mask=mask)
+    after = {f: p.download(f) for f in before}
+    sel = np.repeat(mask.astype(bool), 4)
+    assert np.array_equal(after[L.F_X][~sel], before[L.F_X][~sel]) and (after[L.F_X][sel] == -5).all()
+    assert (after[L.F_SPEED][sel] == 9).all() and np.array_equal(after[L.F_SPEED][~sel], before[L.F_SPEED][~sel])
+    assert after[L.F_CNT_STEP].tolist() == [3, 0, 3, 3, 0, 3] and after[L.F_FRAME_MS].tolist() == [300, 0, 300, 300, 0, 300]
+    assert np.array_equal(after[L.F_IDS][~sel], before[L.F_IDS][~sel])
+    p.close()
+
+
+def test_zero_copy_views_and_bound_actions():
+    """t2d_get_field pointers as torch tensors (the only PyTorch touch point) and t2d_bind_actions reading the
+    actions straight from a caller-owned device tensor."""
+    import torch
+    from tactics2d_amd import layout as L
+    d = H.load_npz("kin_random.npz")
+    m = d["timing"][:, 0] == 100
+    st, act, tid = d["state"][m][:512], d["action"][m][:512], d["type_id"][m][:512]
+    ut = np.unique(tid); remap = {int(t): i for i, t in enumerate(ut)}
+    tid2 = np.array([remap[int(t)] for t in tid], np.uint8)
+    p = _pool(512, 1)
+    p.set_param_table(d["rows"][ut])
+    p.reset(st[:, 0], st[:, 1], st[:, 2], st[:, 3], tid2)
+    a0 = torch.from_numpy(act[:, 0].copy()).cuda(); a1 = torch.from_numpy(act[:, 1].copy()).cuda()
+    p.bind_actions(a0.data_ptr(), a1.data_ptr())
+    s = torch.cuda.current_stream().cuda_stream
+    p.integrate(100, s)
+    xt = torch.as_tensor(p.device_array(L.F_X), device="cuda")
+    torch.cuda.synchronize()
+    assert xt.dtype == torch.float32 and xt.shape == (512,)
+    assert np.array_equal(xt.cpu().numpy(), p.download(L.F_X))
+    want = H.gpu_physics(d["rows"], tid, st, act, 100, "fast", "kin")
+    assert np.array_equal(xt.cpu().numpy(), want[:, 0])
+    xt += 1.0                                                  # writes through to the pool
+    torch.cuda.synchronize()
+    assert np.array_equal(p.download(L.F_X), want[:, 0] + np.float32(1.0))
+    p.bind_actions(None, None)                                 # back to the pool's own buffers
+    p.close()
