@@ -245,7 +245,15 @@ T2D_DEV double quad_area2(const Quad& P) {
     return a;
 }
 
-__device__ __noinline__ double quad_iou(const Quad A, const Quad B) {
+// a_planes: the pose in the LDS coordinate planes (&s_v[0][lane]); b_aos: 4 x (x, y) doubles in global memory
+__device__ __noinline__ double quad_iou(const double* a_planes, const double* b_aos) {
+    const Quad A = load_obb_lds(a_planes);
+    Quad B;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        B.x[k] = b_aos[2 * k];
+        B.y[k] = b_aos[2 * k + 1];
+    }
     double s[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             fa0 = pv.act0[idx];
             fa1 = pv.act1[idx];
         }
-        if (pv.boundary) {
+        if (FUSE < 0 && pv.boundary) {  // fused: fetched after the integrator (register pressure)
             const float4 b = reinterpret_cast<const float4*>(pv.boundary)[env];
             bxmin = b.x; bxmax = b.y; bymin = b.z; bymax = b.w;
             has_boundary = pv.boundary_valid ? pv.boundary_valid[env] != 0 : true;
@@ -477,6 +485,11 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         pv.applied1[idx] = (float)o.app1;
     }
     T2D_MARK(13);
+    if (FUSE >= 0 && valid && pv.boundary) {  // L2-resident by now (16 B per env)
+        const float4 b = reinterpret_cast<const float4*>(pv.boundary)[env];
+        bxmin = b.x; bxmax = b.y; bymin = b.z; bymax = b.w;
+        has_boundary = pv.boundary_valid ? pv.boundary_valid[env] != 0 : true;
+    }
     // ---------------- phase 1: pose, out-of-bound, conservative fp32 box ------------------------
     int kind = -1;
     float R32 = -1.0f;                                  // bounding radius + 5 mm; < 0 = inactive
@@ -762,20 +775,19 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             } else {
                 bool na = false;
                 if (cfg.check_no_action && ego_obb) {  // NoAction.update (no_action.py:41-53)
-                    const Quad pose = load_obb_lds(&s_v[0][ego]);
                     double* last = pv.last_pose + 8 * (size_t)env;
                     int cna = pv.cnt_na[env];
                     if (!pv.last_valid[env]) {
                         pv.last_valid[env] = 1;
                     } else {
-                        Quad lq;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) { lq.x[k] = last[2 * k]; lq.y[k] = last[2 * k + 1]; }
-                        cna = quad_iou(pose, lq) > (double)cfg.no_action_iou ? cna + 1 : 0;
+                        cna = quad_iou(&s_v[0][ego], last) > (double)cfg.no_action_iou ? cna + 1 : 0;
                         pv.cnt_na[env] = cna;
                     }
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { last[2 * k] = pose.x[k]; last[2 * k + 1] = pose.y[k]; }
+                    for (int k = 0; k < 4; ++k) {
+                        last[2 * k] = s_v[2 * k][ego];
+                        last[2 * k + 1] = s_v[2 * k + 1][ego];
+                    }
                     na = cna > cfg.no_action_max_step;
                 }
                 if (na) {
@@ -789,11 +801,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                 } else if (cfg.check_off_lane && (ef & T2D_FLAG_OFF_LANE)) {
                     scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_OFF_LANE;
                 } else if (cfg.check_arrival && pv.target_xy && ego_obb) {  // Arrival.update (arrival.py:42-47)
-                    Quad tq;
-                    const double* t = pv.target_xy + 8 * (size_t)env;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { tq.x[k] = t[2 * k]; tq.y[k] = t[2 * k + 1]; }
-                    iou = quad_iou(load_obb_lds(&s_v[0][ego]), tq);
+                    iou = quad_iou(&s_v[0][ego], pv.target_xy + 8 * (size_t)env);
                     has_iou = true;
                     if (iou >= (double)cfg.arrival_threshold) scen = T2D_SCENARIO_COMPLETED;
                 }
