@@ -31,6 +31,7 @@
  *   t2d_snapshot/restore  <- ParkingEnv.reset / _ParkingScenarioManager.reset       envs/parking.py:262-298,397-441
  *   t2d_set_target_areas  <- Arrival.reset                traffic/event_detection/arrival.py:49-51
  *                            Arrival.update / NoAction.update (IoU)   arrival.py:32-47, no_action.py:32-53
+ *   t2d_lidar_config/scan <- SingleLineLidar.__init__ / _scan_obstacles    sensor/lidar.py:33-57,128-221
  *   t2d_check_status      <- _ParkingScenarioManager.check_status           envs/parking.py:361-392
  *   t2d_step              <- _ParkingScenarioManager.update + check_status  envs/parking.py:352-392
  *                            ParkingEnv.step terminated/truncated/reward    envs/parking.py:219-256,148-161
@@ -135,7 +136,9 @@ enum {
                               k & 1, so a collective may still read step k while step k+1 runs    */
     T2D_F_IOU = 18,        /* f32[E]  IoU(ego pose, target) of the last step; NaN = not evaluated (None) */
     T2D_F_CNT_NO_ACTION = 19, /* i32[E] NoAction.cnt_no_action                          */
-    T2D_F_COUNT = 20
+    T2D_F_LIDAR = 20,      /* f32[E][n_beams] last t2d_lidar_scan into the pool's own buffer (size set by
+                              t2d_lidar_config; +inf = no return)                                 */
+    T2D_F_COUNT = 21
 };
 
 /* ---- per-participant / per-env event bits ------------------------------------------- */
@@ -274,12 +277,24 @@ int t2d_restore(t2d_pool* pool, int32_t mode, void* hip_stream);
  * Gym vector envs report them.  Needs a snapshot.                                                */
 int t2d_set_auto_reset(t2d_pool* pool, int32_t on);
 
+/* Single-line lidar of the ego of every env (SingleLineLidar, sensor/lidar.py:33-221, as configured by
+ * ParkingEnv envs/parking.py:303-304,422-431: 360 beams, 20 m): distance to the nearest obstacle edge
+ * along n_beams rays at angles linspace(0, 2 pi, n_beams, endpoint=False) in the ego frame; +inf = no
+ * return.  Obstacles = the static polygons of t2d_set_static_geometry and, when include_participants,
+ * the boxes of the other active participants.  beam_sin / beam_cos: host arrays [n_beams] with the sin /
+ * cos of those angles (numpy), or NULL to have the library compute them with libm.
+ * t2d_lidar_scan writes fp32 [n_env][n_beams] to out_dev (caller-owned device memory, e.g. the policy's
+ * observation tensor) or, when NULL, to the pool's T2D_F_LIDAR buffer.  kernel_id 3 in t2d_profile_read. */
+int t2d_lidar_config(t2d_pool* pool, int32_t n_beams, float max_range, int32_t include_participants,
+                     const double* beam_sin, const double* beam_cos);
+int t2d_lidar_scan(t2d_pool* pool, float* out_dev, void* hip_stream);
+
 /* Kernel variants: 0 = exact (library-grade fp64 trig every sub-step), 1 = fast
  * (rotation recurrence, default).  Both satisfy the 1e-5 contract; see DESIGN.md.       */
 int t2d_set_integrator_variant(t2d_pool* pool, int32_t variant);
 
 /* Per-kernel timing with HIP events recorded on the launch stream around each kernel.
- * kernel_id: 0 = integrate, 1 = collide(+status), 2 = fused step.                                     */
+ * kernel_id: 0 = integrate, 1 = collide(+status), 2 = fused step, 3 = lidar.                                     */
 int t2d_profile_enable(t2d_pool* pool, int32_t on);
 int t2d_profile_read(t2d_pool* pool, int32_t kernel_id, double* total_ms, int64_t* launches);
 

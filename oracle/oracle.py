@@ -263,3 +263,31 @@ def status_ex(cfg, A, flags, interval_ms, cnt_step, frame_ms, rows, x, y, headin
       st.reshape(-1), rw, pose.reshape(-1), xy.reshape(-1), is_obb, tgt, tc, int(ep.target is not None),
       ep.last_pose.reshape(-1), ep.last_valid, ep.cnt_na, ep.max_iou, ep.min_dist, iou)
     return st, rw, iou
+
+
+def beam_tables(n_beams):
+    th = np.linspace(0, 2 * np.pi, n_beams, endpoint=False)
+    return np.ascontiguousarray(np.sin(th)), np.ascontiguousarray(np.cos(th))
+
+
+def lidar(rows, n_env, A, ego_index, x, y, heading, type_id, active, static, include_participants,
+          n_beams, max_range, trig=0):
+    """SingleLineLidar scan of every env's ego -> float32 [n_env, n_beams] (+inf = no return)."""
+    rows = np.ascontiguousarray(rows, np.float64)
+    keep = []
+    if static is None:
+        sp = [None, None, None]
+    else:
+        sp = []
+        for a, dt in zip(static, (np.int32, np.int32, np.float32)):
+            arr, p = _ptr(a, dt); keep.append(arr); sp.append(p)
+    bs, bc = beam_tables(n_beams)
+    out = np.empty((n_env, n_beams), np.float32)
+    f = lib().t2do_lidar
+    f.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _u8p, _u8p, C.c_void_p,
+                  C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, _f64p, _f64p, C.c_int, _f32p]
+    f(rows, rows.shape[1], n_env, A, ego_index, np.ascontiguousarray(x, np.float32),
+      np.ascontiguousarray(y, np.float32), np.ascontiguousarray(heading, np.float32),
+      np.ascontiguousarray(type_id, np.uint8), np.ascontiguousarray(active, np.uint8), sp[0], sp[1], sp[2],
+      int(include_participants), int(n_beams), float(max_range), bs, bc, int(trig), out.reshape(-1))
+    return out

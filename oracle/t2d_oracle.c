@@ -752,4 +752,99 @@ void t2do_status(const t2d_status_config* cfg, int n_env, int A, const uint32_t*
                    NULL, NULL, 0, NULL, NULL, NULL, NULL, NULL, NULL);
 }
 
+/* ==========================================================================================
+ * Single-line lidar of the ego (scope row f2): SingleLineLidar._scan_obstacles,
+ * sensor/lidar.py:128-221, with the ring transform of _rotate_and_filter_obstacles :98-126.
+ * Obstacles = the env's static polygons (areas of type "obstacle", :137-143) and, when
+ * include_participants, the poses of the other ACTIVE box-shaped participants (:146-153;
+ * pedestrians return (location, radius) from get_pose and are skipped by the isinstance test).
+ * beam_sin / beam_cos: sin / cos of linspace(0, 2 pi, n_beams, endpoint=False) computed by the host
+ * (numpy), so every implementation shares them bit for bit.  The sensor's own rotation uses the
+ * deterministic sincos (trig = 0) or libm (trig = 1).  out: n_env x n_beams fp32, +inf = no return.
+ * ======================================================================================== */
+static double lidar_edge(double a, double b, double lx, double ly, double R, double x1, double y1,
+                         double x2, double y2) {
+    const double tz = 1e-8, tinf = R * 10;            /* :198-199 */
+    const double d = y2 - y1, e = x1 - x2, f = y1 * x2 - x1 * y2;   /* :183-185 */
+    double det = a * e - b * d;                       /* :188 */
+    const int parallel = det == 0.0;
+    if (parallel) det = 1.0;
+    double rx = (b * f) / det;                        /* c = 0: b*f - c*e = b*f, c*d - a*f = -(a*f)  :191-192 */
+    double ry = (-(a * f)) / det;
+    const double mx = tz > lx ? tz : lx, nx = -tz < lx ? -tz : lx;
+    const double my = tz > ly ? tz : ly, ny = -tz < ly ? -tz : ly;
+    if (rx > mx + tz) rx = tinf;                      /* :205-208 */
+    if (rx < nx - tz) rx = tinf;
+    if (ry > my + tz) ry = tinf;
+    if (ry < ny - tz) ry = tinf;
+    if (rx > (x1 > x2 ? x1 : x2) + tz) rx = tinf;     /* :210-213 */
+    if (rx < (x1 < x2 ? x1 : x2) - tz) rx = tinf;
+    if (ry > (y1 > y2 ? y1 : y2) + tz) ry = tinf;
+    if (ry < (y1 < y2 ? y1 : y2) - tz) ry = tinf;
+    if (parallel) rx = tinf;                          /* :215 */
+    return sqrt(rx * rx + ry * ry);                   /* :218 */
+}
+
+void t2do_lidar(const double* rows, int row_stride, int n_env, int A, int ego_index, const float* x,
+                const float* y, const float* heading, const uint8_t* type_id, const uint8_t* active,
+                const int32_t* env_poly_off, const int32_t* poly_vert_off, const float* poly_xy,
+                int include_participants, int n_beams, double max_range, const double* beam_sin,
+                const double* beam_cos, int trig, float* out) {
+    double* ex = (double*)malloc(sizeof(double) * 4 * (size_t)(A * 4 + 16 * T2D_MAX_POLY_VERTS * 64));
+    for (int env = 0; env < n_env; ++env) {
+        const size_t base = (size_t)env * A;
+        const size_t ie = base + ego_index;
+        float* o = out + (size_t)env * n_beams;
+        if (!active[ie]) { for (int k = 0; k < n_beams; ++k) o[k] = INFINITY; continue; }
+        double sn, cs;
+        if (trig == 0) t2do_sincos((double)heading[ie], &sn, &cs);
+        else { sn = sin((double)heading[ie]); cs = cos((double)heading[ie]); }
+        const double px = x[ie], py = y[ie];
+        const double x_off = -px * cs - py * sn;      /* :112-113 */
+        const double y_off = px * sn - py * cs;
+        int ne = 0;
+        double ring[2 * T2D_MAX_POLY_VERTS];
+        /* gather rings -> edges in the sensor frame */
+        #define T2DO_ADD_RING(n_)                                                            \
+            for (int k = 0; k < (n_); ++k) {                                                 \
+                const int k2 = (k + 1) % (n_);                                               \
+                ex[4 * ne + 0] = cs * ring[2 * k] + sn * ring[2 * k + 1] + x_off;            \
+                ex[4 * ne + 1] = -sn * ring[2 * k] + cs * ring[2 * k + 1] + y_off;           \
+                ex[4 * ne + 2] = cs * ring[2 * k2] + sn * ring[2 * k2 + 1] + x_off;          \
+                ex[4 * ne + 3] = -sn * ring[2 * k2] + cs * ring[2 * k2 + 1] + y_off;         \
+                ++ne;                                                                        \
+            }
+        if (env_poly_off) {
+            for (int p = env_poly_off[env]; p < env_poly_off[env + 1]; ++p) {
+                const int v0 = poly_vert_off[p], n = poly_vert_off[p + 1] - v0;
+                for (int k = 0; k < n; ++k) { ring[2 * k] = poly_xy[2 * (v0 + k)]; ring[2 * k + 1] = poly_xy[2 * (v0 + k) + 1]; }
+                T2DO_ADD_RING(n)
+            }
+        }
+        if (include_participants) {
+            for (int j = 0; j < A; ++j) {
+                if (j == ego_index || !active[base + j]) continue;
+                const double* p = rows + (size_t)type_id[base + j] * row_stride;
+                if ((int)p[T2D_P_SHAPE] != T2D_SHAPE_OBB) continue;
+                t2do_pose_obb(x[base + j], y[base + j], heading[base + j], p[T2D_P_LENGTH], p[T2D_P_WIDTH], trig, ring);
+                T2DO_ADD_RING(4)
+            }
+        }
+        #undef T2DO_ADD_RING
+        for (int k = 0; k < n_beams; ++k) {
+            if (ne == 0) { o[k] = INFINITY; continue; }       /* :173-175 */
+            const double a = beam_sin[k], b = -beam_cos[k];   /* :161-162 */
+            const double lx = beam_cos[k] * max_range, ly = beam_sin[k] * max_range;   /* :201-204 */
+            double best = INFINITY;
+            for (int q = 0; q < ne; ++q) {
+                const double dd = lidar_edge(a, b, lx, ly, max_range, ex[4 * q], ex[4 * q + 1], ex[4 * q + 2], ex[4 * q + 3]);
+                best = dd < best ? dd : best;
+            }
+            best = best < 0 ? 0 : (best > max_range ? max_range : best);   /* np.clip :219 */
+            o[k] = best == max_range ? INFINITY : (float)best;              /* :220 */
+        }
+    }
+    free(ex);
+}
+
 int t2do_abi_version(void) { return T2D_ABI_VERSION; }

@@ -234,6 +234,34 @@ int init_iou_state(t2d_pool* p, const uint8_t* env_mask, const float* hx, const 
     return T2D_OK;
 }
 
+// plain per-env CSR of the static obstacle rings for the lidar kernel (from the host copy of the geometry)
+int rebuild_lidar_geo(t2d_pool* p) {
+    if (!p->lidar_on) return T2D_OK;
+    const int E = p->v.n_env;
+    const auto& g = p->hgeo[0];
+    int rc;
+    p->lidar.max_static_verts = 0;
+    if (!g.present || g.env_off[E] == 0) {
+        if ((rc = dev_replace<int32_t>(p, &p->d_lidar_env_off, nullptr, 0))) return rc;
+        if ((rc = dev_replace<int32_t>(p, &p->d_lidar_next, nullptr, 0))) return rc;
+        if ((rc = dev_replace<float>(p, &p->d_lidar_xy, nullptr, 0))) return rc;
+    } else {
+        const int P = g.env_off[E], V = g.vert_off[P];
+        std::vector<int32_t> evo(E + 1), nxt(V);
+        for (int e = 0; e <= E; ++e) evo[e] = g.vert_off[g.env_off[e]];
+        for (int q = 0; q < P; ++q)
+            for (int v = g.vert_off[q]; v < g.vert_off[q + 1]; ++v) nxt[v] = v + 1 < g.vert_off[q + 1] ? v + 1 : g.vert_off[q];
+        for (int e = 0; e < E; ++e) p->lidar.max_static_verts = std::max(p->lidar.max_static_verts, evo[e + 1] - evo[e]);
+        if ((rc = dev_replace(p, &p->d_lidar_env_off, evo.data(), evo.size()))) return rc;
+        if ((rc = dev_replace(p, &p->d_lidar_next, nxt.data(), nxt.size()))) return rc;
+        if ((rc = dev_replace(p, &p->d_lidar_xy, g.xy.data(), g.xy.size()))) return rc;
+    }
+    p->lidar.env_vert_off = p->d_lidar_env_off;
+    p->lidar.next_vert = p->d_lidar_next;
+    p->lidar.xy = p->d_lidar_xy;
+    return T2D_OK;
+}
+
 int record_event(t2d_pool* p, int kernel_id, hipStream_t s, bool begin) {
     if (!p->profiling) return T2D_OK;
     if (begin) {
@@ -322,6 +350,10 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
     for (int f = 0; f < T2D_F_COUNT; ++f) {
         const size_t n = field_per_env(f) ? (size_t)n_env : (size_t)p->v.N;
         p->field_bytes[f] = n * field_elem_bytes(f);
+        if (f == T2D_F_LIDAR) {  // sized by t2d_lidar_config
+            p->field_bytes[f] = 0;
+            continue;
+        }
         hipError_t e = hipMalloc(&p->field_ptr[f], p->field_bytes[f]);
         if (e == hipSuccess) e = hipMemset(p->field_ptr[f], 0, p->field_bytes[f]);
         if (e != hipSuccess) {
@@ -408,6 +440,7 @@ int t2d_destroy(t2d_pool* p) {
         if (p->field_ptr[f]) (void)hipFree(p->field_ptr[f]);
     void* bufs[] = {p->d_params, p->d_geo, p->d_boundary, p->d_boundary_valid, p->d_target_xy, p->d_target_c,
                     p->d_last_pose, p->d_max_iou, p->d_min_dist, p->d_snap_min_dist, p->d_last_valid,
+                    p->d_lidar_env_off, p->d_lidar_next, p->d_lidar_xy, p->d_beam_sin, p->d_beam_cos,
                     p->d_snap[0], p->d_snap[1], p->d_snap[2],
                     p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids};
     for (void* b : bufs)
@@ -470,6 +503,7 @@ int t2d_set_static_geometry(t2d_pool* p, const int32_t* env_poly_offsets,
         p->hgeo[0] = t2d_pool::HostGeo{};
     }
     if ((rc = rebuild_geo(p)) != T2D_OK) return rc;
+    if ((rc = rebuild_lidar_geo(p)) != T2D_OK) return rc;
     if (boundary) {
         if ((rc = dev_replace(p, &p->d_boundary, boundary, (size_t)4 * E))) return rc;
         if ((rc = dev_replace(p, &p->d_boundary_valid, boundary_valid, boundary_valid ? (size_t)E : 0)))
@@ -795,6 +829,60 @@ int t2d_sync(t2d_pool* p) {
     T2D_HIP(p, hipSetDevice(p->device));
     T2D_HIP(p, hipDeviceSynchronize());
     return T2D_OK;
+}
+
+int t2d_lidar_config(t2d_pool* p, int32_t n_beams, float max_range, int32_t include_participants,
+                     const double* beam_sin, const double* beam_cos) {
+    if (!p) return T2D_ERR_INVALID;
+    if (n_beams < 1 || n_beams > 4096 || !(max_range > 0.0f))
+        return fail(p, T2D_ERR_INVALID, "need 1 <= n_beams <= 4096 and max_range > 0");
+    if ((beam_sin == nullptr) != (beam_cos == nullptr)) return fail(p, T2D_ERR_INVALID, "pass both beam tables or neither");
+    T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, hipDeviceSynchronize());
+    std::vector<double> bs(n_beams), bc(n_beams);
+    for (int k = 0; k < n_beams; ++k) {
+        if (beam_sin) {
+            bs[k] = beam_sin[k];
+            bc[k] = beam_cos[k];
+        } else {  // linspace(0, 2 pi, n, endpoint=False) = k * (2 pi / n)
+            const double th = (double)k * ((2.0 * 3.141592653589793) / (double)n_beams);
+            bs[k] = sin(th);
+            bc[k] = cos(th);
+        }
+    }
+    int rc;
+    if ((rc = dev_replace(p, &p->d_beam_sin, bs.data(), bs.size()))) return rc;
+    if ((rc = dev_replace(p, &p->d_beam_cos, bc.data(), bc.size()))) return rc;
+    if (p->field_ptr[T2D_F_LIDAR]) {
+        T2D_HIP(p, hipFree(p->field_ptr[T2D_F_LIDAR]));
+        p->field_ptr[T2D_F_LIDAR] = nullptr;
+    }
+    p->field_bytes[T2D_F_LIDAR] = (size_t)p->v.n_env * n_beams * sizeof(float);
+    T2D_HIP(p, hipMalloc(&p->field_ptr[T2D_F_LIDAR], p->field_bytes[T2D_F_LIDAR]));
+    T2D_HIP(p, hipMemset(p->field_ptr[T2D_F_LIDAR], 0, p->field_bytes[T2D_F_LIDAR]));
+    p->lidar.beam_sin = p->d_beam_sin;
+    p->lidar.beam_cos = p->d_beam_cos;
+    p->lidar.max_range = (double)max_range;
+    p->lidar.n_beams = n_beams;
+    p->lidar.include_participants = include_participants != 0;
+    p->lidar_on = true;
+    rc = rebuild_lidar_geo(p);
+    if (rc != T2D_OK) return rc;
+    const size_t dyn = sizeof(double) * 4 * (size_t)(p->lidar.max_static_verts + (include_participants ? 4 * p->v.A : 0));
+    if (dyn > 60 * 1024) return fail(p, T2D_ERR_GEOMETRY, "too many obstacle edges per env for the lidar's LDS edge list");
+    return T2D_OK;
+}
+
+int t2d_lidar_scan(t2d_pool* p, float* out_dev, void* hip_stream) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!p->lidar_on) return fail(p, T2D_ERR_STATE, "t2d_lidar_config must precede t2d_lidar_scan");
+    if (!p->have_params || !p->have_reset) return fail(p, T2D_ERR_STATE, "t2d_reset must precede t2d_lidar_scan");
+    p->lidar.ego_index = p->status_cfg.ego_index;
+    hipStream_t s = (hipStream_t)hip_stream;
+    int rc;
+    if ((rc = record_event(p, 3, s, true))) return rc;
+    T2D_HIP(p, t2d::launch_lidar(p->v, p->lidar, out_dev ? out_dev : (float*)p->field_ptr[T2D_F_LIDAR], s));
+    return record_event(p, 3, s, false);
 }
 
 int t2d_set_integrator_variant(t2d_pool* p, int32_t variant) {

@@ -37,6 +37,7 @@ struct GeoLayout {
 };
 
 // What kernels receive by value.
+struct LidarView;
 struct PoolView {
     int32_t n_env, A, N;
     float *x, *y, *heading, *speed, *vx, *vy, *act0, *act1, *applied0, *applied1;
@@ -68,6 +69,17 @@ struct PoolView {
     unsigned long long* dbg;  // phase cycle accumulators (profiling builds with -DT2D_TIMING only)
     double cell;      // spatial-hash cell edge (m) >= max circum-diameter * 1.001
     double inv_cell;
+};
+
+// Lidar inputs (t2d_lidar.hip): plain per-env CSR of the static obstacle rings + beam tables.
+struct LidarView {
+    const int32_t* env_vert_off;  // [E+1] vertex range of env e, or null (no static obstacles)
+    const int32_t* next_vert;     // [V] index of the next vertex of the same ring
+    const float* xy;              // [V][2]
+    const double* beam_sin;       // [n_beams] sin / cos of linspace(0, 2pi, n_beams, endpoint=False)
+    const double* beam_cos;
+    double max_range;
+    int32_t n_beams, include_participants, ego_index, max_static_verts;
 };
 
 constexpr int kIdsModelShift = 0;
@@ -103,6 +115,12 @@ struct t2d_pool {
            *d_min_dist = nullptr, *d_snap_min_dist = nullptr;
     uint8_t* d_last_valid = nullptr;
     bool have_target = false;
+    // lidar (row f2)
+    bool lidar_on = false;
+    t2d::LidarView lidar{};
+    int32_t *d_lidar_env_off = nullptr, *d_lidar_next = nullptr;
+    float* d_lidar_xy = nullptr;
+    double *d_beam_sin = nullptr, *d_beam_cos = nullptr;
     float* d_snap[6]{};      // x, y, heading, speed, vx, vy at episode start
     uint32_t* d_snap_ids = nullptr;
     bool have_snapshot = false;
@@ -121,6 +139,7 @@ namespace t2d {
 hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hipStream_t s);
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
                           int interval_ms, int fuse_variant, hipStream_t s);
+hipError_t launch_lidar(const PoolView& v, const LidarView& lv, float* out, hipStream_t s);
 hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
                           hipStream_t s);
 }  // namespace t2d

@@ -5,9 +5,9 @@ the accelerated path: `step()` = physics update of the ego (`_ParkingScenarioMan
 + ordered status checks (`check_status`, :361-392) + terminated / truncated / reward (:243-250,
 :148-166).  `Arrival` (IoU >= 0.95 with the target bay -> COMPLETED, +5, terminated), `NoAction` (IoU with the
 previous pose > 0.999 on more than 100 checks, including the reference's quirk of reporting it in
-`traffic_status`) and the IoU / distance reward shaping are evaluated in the same launch.  The rendered
-camera observation and the lidar are "next" rows of the scope table: observations
-here are the ego state vector.
+`traffic_status`) and the IoU / distance reward shaping are evaluated in the same launch.  `info["lidar"]` is the 360-beam / 20 m
+SingleLineLidar scan of the same poses (t2d_lidar_scan).  The rendered camera image is not on the
+accelerated path: the observation returned here is the ego state vector.
 
 gymnasium is not a dependency: `Box` below is the minimal stand-in for `spaces.Box`.
 """
@@ -77,6 +77,8 @@ class VecParkingEnv:
         m.status_checklist["out_bound"].reset(sc.boundary)
         m.reset(sc.x, sc.y, sc.heading, sc.speed, sc.type_id, sc.active)
         m.pool.set_auto_reset(self.auto_reset)
+        # SingleLineLidar(perception_range=20, freq_detect=360 * 10)  envs/parking.py:303-304,422-431
+        m.pool.lidar_config(360, 20.0, include_participants=False)
         obs = m.get_observation()
         n = self.n_envs
         return obs, self._infos(obs, np.full(n, ScenarioStatus.NORMAL, np.uint8), np.full(n, TrafficStatus.NORMAL, np.uint8))
@@ -113,7 +115,13 @@ class VecParkingEnv:
                     scenario_status=scenario_status, traffic_status=traffic_status,
                     target_area=None if self._scene is None else self._scene.target,
                     target_heading=None if self._scene is None else self._scene.target_heading,
-                    iou=self.scenario_manager.pool.download(L.F_IOU), lidar=None)
+                    iou=self.scenario_manager.pool.download(L.F_IOU), lidar=self._lidar())
+
+    def _lidar(self):
+        """info["lidar"]: 360 ranges per env, +inf = no return (the reference's scan_result)."""
+        pool = self.scenario_manager.pool
+        pool.lidar_scan()
+        return pool.download(L.F_LIDAR)
 
     def render(self):
         raise NotImplementedError("rendering is outside the accelerated path")

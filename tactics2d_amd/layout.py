@@ -16,14 +16,15 @@ F_APPLIED0, F_APPLIED1, F_ENV_FLAGS, F_CNT_STEP, F_FRAME_MS, F_STATUS, F_REWARD 
 F_RECORD = 17
 F_IOU = 18
 F_CNT_NO_ACTION = 19
-F_COUNT = 20
+F_LIDAR = 20
+F_COUNT = 21
 FIELD_DTYPES = {
     F_X: "float32", F_Y: "float32", F_HEADING: "float32", F_SPEED: "float32", F_VX: "float32",
     F_VY: "float32", F_ACT0: "float32", F_ACT1: "float32", F_IDS: "uint32", F_FLAGS: "uint32",
     F_APPLIED0: "float32", F_APPLIED1: "float32", F_ENV_FLAGS: "uint32", F_CNT_STEP: "int32",
-    F_FRAME_MS: "int32", F_STATUS: "uint8", F_REWARD: "float32", F_RECORD: "uint32", F_IOU: "float32", F_CNT_NO_ACTION: "int32",
+    F_FRAME_MS: "int32", F_STATUS: "uint8", F_REWARD: "float32", F_RECORD: "uint32", F_IOU: "float32", F_CNT_NO_ACTION: "int32", F_LIDAR: "float32",
 }
-PER_ENV_FIELDS = (F_ENV_FLAGS, F_CNT_STEP, F_FRAME_MS, F_STATUS, F_REWARD, F_RECORD, F_IOU, F_CNT_NO_ACTION)
+PER_ENV_FIELDS = (F_ENV_FLAGS, F_CNT_STEP, F_FRAME_MS, F_STATUS, F_REWARD, F_RECORD, F_IOU, F_CNT_NO_ACTION, F_LIDAR)
 # event bits
 FLAG_COLLISION_DYNAMIC, FLAG_COLLISION_STATIC, FLAG_OUT_BOUND, FLAG_OFF_LANE = 1, 2, 4, 8
 MAX_POLY_VERTS = 8

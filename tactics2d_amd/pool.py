@@ -107,6 +107,17 @@ class ParticipantPool:
         c = _arr(centroid, np.float32, 2 * self.n_env, "centroid")
         self._ck(self._lib.t2d_set_target_areas(self._h, _p(t), _p(c)))
 
+    def lidar_config(self, n_beams=360, max_range=20.0, include_participants=False):
+        """SingleLineLidar of every ego; beam tables come from numpy like the reference's linspace/sin/cos."""
+        th = np.linspace(0, 2 * np.pi, int(n_beams), endpoint=False)
+        bs, bc = np.ascontiguousarray(np.sin(th)), np.ascontiguousarray(np.cos(th))
+        self._ck(self._lib.t2d_lidar_config(self._h, int(n_beams), float(max_range), int(bool(include_participants)),
+                                            _p(bs), _p(bc)))
+        self.n_beams = int(n_beams)
+
+    def lidar_scan(self, out_ptr=None, stream=None):
+        self._ck(self._lib.t2d_lidar_scan(self._h, out_ptr, stream))
+
     def set_integrator_variant(self, variant):
         v = {"exact": 0, "fast": 1}.get(variant, variant)
         self._ck(self._lib.t2d_set_integrator_variant(self._h, int(v)))
@@ -130,7 +141,10 @@ class ParticipantPool:
     def download(self, field):
         dt = np.dtype(L.FIELD_DTYPES[field])
         n = self.n_env if field in L.PER_ENV_FIELDS else self.n
-        if field == L.F_STATUS:
+        if field == L.F_LIDAR:
+            ptr, nb = self.field_ptr(field)
+            out = np.empty((n, nb // (4 * n)), dt)
+        elif field == L.F_STATUS:
             out = np.empty((n, 4), dt)
         elif field == L.F_RECORD:
             out = np.empty((2, n, 2), dt)
@@ -156,7 +170,8 @@ class ParticipantPool:
         """Object exposing __cuda_array_interface__ (zero-copy) for torch.as_tensor."""
         ptr, nb = self.field_ptr(field)
         dt = np.dtype(L.FIELD_DTYPES[field])
-        shape = (nb // 4, 4) if field == L.F_STATUS else (2, nb // 16, 2) if field == L.F_RECORD else (nb // dt.itemsize,)
+        shape = (nb // 4, 4) if field == L.F_STATUS else (2, nb // 16, 2) if field == L.F_RECORD else \
+            (self.n_env, nb // (4 * self.n_env)) if field == L.F_LIDAR else (nb // dt.itemsize,)
         return _DevArray(ptr, shape, dt.str, self)
 
     # ---------------------------------------------------------------- the hot path

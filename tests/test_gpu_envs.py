@@ -12,6 +12,7 @@ def test_vec_parking_env_step_contract(oracle):
     env = VecParkingEnv(256, max_step=50, seed=3)
     obs, infos = env.reset()
     assert obs.shape == (256, 6) and obs.dtype == np.float32
+    assert infos["lidar"].shape == (256, 360) and np.isfinite(infos["lidar"]).mean() > 0.3
     assert (infos["scenario_status"] == ScenarioStatus.NORMAL).all()
     with pytest.raises(InvalidAction):
         env.step(np.tile([0.6, 0.0], (256, 1)))              # steering outside +-0.524 (parking.py:235-236)
