@@ -259,6 +259,9 @@ int rebuild_lidar_geo(t2d_pool* p) {
     p->lidar.env_vert_off = p->d_lidar_env_off;
     p->lidar.next_vert = p->d_lidar_next;
     p->lidar.xy = p->d_lidar_xy;
+    p->lidar.max_slots = p->lidar.max_static_verts + (p->lidar.include_participants ? 4 * p->v.A : 0);
+    if ((sizeof(double) * 4 + 8) * (size_t)p->lidar.max_slots > 60 * 1024)
+        return fail(p, T2D_ERR_GEOMETRY, "too many obstacle edges per env for the lidar's LDS edge list");
     return T2D_OK;
 }
 
@@ -868,8 +871,6 @@ int t2d_lidar_config(t2d_pool* p, int32_t n_beams, float max_range, int32_t incl
     p->lidar_on = true;
     rc = rebuild_lidar_geo(p);
     if (rc != T2D_OK) return rc;
-    const size_t dyn = sizeof(double) * 4 * (size_t)(p->lidar.max_static_verts + (include_participants ? 4 * p->v.A : 0));
-    if (dyn > 60 * 1024) return fail(p, T2D_ERR_GEOMETRY, "too many obstacle edges per env for the lidar's LDS edge list");
     return T2D_OK;
 }
 

@@ -7,11 +7,13 @@
 //
 // One workgroup per environment.  Phase 1: the env's obstacle rings -- static polygons and, optionally,
 // the poses of the other active box participants -- are turned into edges in the sensor frame (fp64,
-// deterministic sincos of the stored headings) and staged in LDS.  Phase 2: one lane per beam sweeps the
-// edge list from LDS (wave-uniform reads).  A conservative side-of-line pre-test (both end points more
-// than 1e-5 m on the same side of the beam's line) skips the exact intersection arithmetic for the edges
-// a beam cannot reach; it never changes a result because such an edge can only produce intersections the
-// reference's own 1e-8 segment filter rejects.  The accepted (beam, edge) pairs run the reference's
+// deterministic sincos of the stored headings) and staged in LDS together with the range of beam indices
+// each edge can possibly be seen by (the arc between its end points, widened by a beam on each side; all
+// beams if the edge's line passes within 1 mm of the sensor; none if the edge lies beyond the range).
+// Phase 2: one lane per beam sweeps the edge list with an integer span test (wave-uniform LDS reads),
+// collects its candidates in a bit mask and runs the exact arithmetic only on those.  The span is strictly
+// conservative, so it never changes a result: an edge outside it can only produce intersections the
+// reference's own 1e-8 segment / ray filters reject.  The accepted (beam, edge) pairs run the reference's
 // arithmetic operation by operation (IEEE division, no contraction), so the output equals the oracle bit
 // for bit.  Output: fp32 [n_env][n_beams], +inf = no return: written once, coalesced -- the one genuinely
 // HBM-streaming product of the step (5.9 MB at 4096 envs x 360 beams).
@@ -47,8 +49,42 @@ T2D_DEV double lidar_edge(double a, double b, double lx, double ly, double R, do
     return __builtin_sqrt(rx * rx + ry * ry);
 }
 
+// Beam-index span of an edge given in the sensor frame: {first beam, number of further beams} or
+// {0, -1} = invisible.  Beams are at angles k * dbeam.  fp32 is enough: the span is widened by a full
+// beam on each side (dbeam >= 1.5e-3 rad for n_beams <= 4096, fp32 atan2 error ~1e-6).
+T2D_DEV int2 edge_span(double x1, double y1, double x2, double y2, double R, int n_beams) {
+    const float fx1 = (float)x1, fy1 = (float)y1, fx2 = (float)x2, fy2 = (float)y2;
+    const float ex = fx2 - fx1, ey = fy2 - fy1;
+    const float len2 = ex * ex + ey * ey;
+    const float d1 = fx1 * fx1 + fy1 * fy1, d2 = fx2 * fx2 + fy2 * fy2;
+    const float cross = fx1 * fy2 - fx2 * fy1;
+    if (!(len2 > 0.0f) || !(d1 < 1e30f) || !(d2 < 1e30f)) return make_int2(0, -1);  // degenerate / placeholder
+    const float dline2 = cross * cross / len2;                 // squared distance sensor -> edge line
+    const float t = -(fx1 * ex + fy1 * ey) / len2;             // foot point parameter
+    const float dseg2 = t <= 0.0f ? d1 : (t >= 1.0f ? d2 : dline2);
+    const float Rm = (float)R * 1.0001f + 1e-3f;
+    if (dseg2 > Rm * Rm) return make_int2(0, -1);              // entirely beyond the range
+    if (dline2 < 1e-6f) return make_int2(0, n_beams);           // line through the sensor (within 1 mm): every beam
+    const float twopi = 6.2831853f;
+    float a1 = atan2f(fy1, fx1), a2 = atan2f(fy2, fx2);
+    float da = a2 - a1;
+    if (da > 3.14159265f) da -= twopi;
+    if (da < -3.14159265f) da += twopi;
+    float start = da >= 0.0f ? a1 : a2;
+    const float sweep = fabsf(da);
+    if (start < 0.0f) start += twopi;
+    const float inv = (float)n_beams / twopi;
+    int k0 = (int)floorf(start * inv) - 1;
+    const int len = (int)ceilf(sweep * inv) + 3;
+    if (len >= n_beams) return make_int2(0, n_beams);
+    k0 %= n_beams;
+    if (k0 < 0) k0 += n_beams;
+    return make_int2(k0, len);
+}
+
 __global__ __launch_bounds__(kLidarBlock) void lidar_kernel(PoolView pv, LidarView lv, float* out) {
     extern __shared__ __attribute__((aligned(16))) double s_edge[];  // [slots][4] = x1, y1, x2, y2 (sensor frame)
+    int2* const s_span = reinterpret_cast<int2*>(s_edge + 4 * (size_t)lv.max_slots);  // [slots] beam span per edge
     __shared__ double s_ego[4];                                       // cos, sin, x_off, y_off
     __shared__ int s_ego_active;
     const int env = blockIdx.x;
@@ -84,6 +120,8 @@ __global__ __launch_bounds__(kLidarBlock) void lidar_kernel(PoolView pv, LidarVi
             s_edge[4 * q + 1] = -sn * (double)p.x + cs * (double)p.y + y_off;
             s_edge[4 * q + 2] = cs * (double)r.x + sn * (double)r.y + x_off;
             s_edge[4 * q + 3] = -sn * (double)r.x + cs * (double)r.y + y_off;
+            s_span[q] = edge_span(s_edge[4 * q], s_edge[4 * q + 1], s_edge[4 * q + 2], s_edge[4 * q + 3], lv.max_range,
+                                  lv.n_beams);
         }
     }
     // ---- phase 1b: the other participants' boxes (4 edges each; skipped slots get the far edge) -------
@@ -120,6 +158,8 @@ __global__ __launch_bounds__(kLidarBlock) void lidar_kernel(PoolView pv, LidarVi
                 e[1] = use ? vy[k] : kFar;
                 e[2] = use ? vx[(k + 1) & 3] : kFar;
                 e[3] = use ? vy[(k + 1) & 3] : kFar + 1.0;
+                s_span[n_static + 4 * j + k] = use ? edge_span(e[0], e[1], e[2], e[3], lv.max_range, lv.n_beams)
+                                                   : make_int2(0, -1);
             }
         }
     }
@@ -135,12 +175,24 @@ __global__ __launch_bounds__(kLidarBlock) void lidar_kernel(PoolView pv, LidarVi
             const double a = bs, b = -bc;                    // lidar.py:161-162
             const double lx = bc * R, ly = bs * R;           // :201-204
             double best = __builtin_inf();
-            for (int q = 0; q < n_slots; ++q) {
-                const double x1 = s_edge[4 * q], y1 = s_edge[4 * q + 1], x2 = s_edge[4 * q + 2], y2 = s_edge[4 * q + 3];
-                const double s1 = a * x1 + b * y1, s2 = a * x2 + b * y2;   // signed distances to the beam's line
-                if ((s1 > 1e-5 && s2 > 1e-5) || (s1 < -1e-5 && s2 < -1e-5)) continue;   // cannot intersect
-                const double dd = lidar_edge(a, b, lx, ly, R, x1, y1, x2, y2);
-                best = dd < best ? dd : best;
+            for (int c0 = 0; c0 < n_slots; c0 += 64) {
+                // pass 1: integer span test per edge (LDS broadcast reads, branch-free) -> candidate mask
+                unsigned long long m = 0ull;
+                const int cn = n_slots - c0 < 64 ? n_slots - c0 : 64;
+                for (int q = 0; q < cn; ++q) {
+                    const int2 sp = s_span[c0 + q];
+                    int rel = k - sp.x;
+                    rel += rel < 0 ? lv.n_beams : 0;
+                    m |= (unsigned long long)(rel <= sp.y) << q;
+                }
+                // pass 2: the reference's arithmetic on the candidates only
+                while (m != 0ull) {
+                    const int q = c0 + __ffsll((long long)m) - 1;
+                    m &= m - 1ull;
+                    const double dd = lidar_edge(a, b, lx, ly, R, s_edge[4 * q], s_edge[4 * q + 1], s_edge[4 * q + 2],
+                                                 s_edge[4 * q + 3]);
+                    best = dd < best ? dd : best;
+                }
             }
             best = best < 0.0 ? 0.0 : (best > R ? R : best);   // np.clip(0, R)
             res = best == R ? __builtin_inff() : (float)best;
@@ -152,7 +204,7 @@ __global__ __launch_bounds__(kLidarBlock) void lidar_kernel(PoolView pv, LidarVi
 }  // namespace
 
 hipError_t launch_lidar(const PoolView& v, const LidarView& lv, float* out, hipStream_t s) {
-    const size_t dyn = sizeof(double) * 4 * (size_t)(lv.max_static_verts + (lv.include_participants ? 4 * v.A : 0));
+    const size_t dyn = (sizeof(double) * 4 + sizeof(int2)) * (size_t)lv.max_slots;
     hipLaunchKernelGGL(lidar_kernel, dim3(v.n_env), dim3(kLidarBlock), dyn, s, v, lv, out);
     return hipGetLastError();
 }

@@ -80,6 +80,7 @@ struct LidarView {
     const double* beam_cos;
     double max_range;
     int32_t n_beams, include_participants, ego_index, max_static_verts;
+    int32_t max_slots;  // LDS edge slots per env: max_static_verts + 4 * max_agents (when participants are scanned)
 };
 
 constexpr int kIdsModelShift = 0;
