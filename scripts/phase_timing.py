@@ -18,10 +18,16 @@ for k in range(60):
 lib.t2d_debug_read(pool._h, buf.ctypes.data_as(C.c_void_p), buf.size)
 v = buf.reshape(n_waves, 16).astype(np.float64)
 names = ["0 load+stage+barrier(a)", "1 pose", "2 barrier(b)", "3 broad phase", "4 pair compaction+narrow", "5 static AABB pass",
-         "6 static narrow", "7 lane AABB pass", "8 lane narrow", "9 (loop exit)", "10 barrier(c)", "11 reduce+barrier(d)", "12 epilogue"]
-tot = v[:, :13].sum(1)
+         "6 static narrow", "7 lane AABB pass", "8 lane narrow", "9 (loop exit)", "10 barrier(c)", "11 reduce+barrier(d)", "12 epilogue",
+         "13 fused integrate"]
+tot = v[:, :14].sum(1)
 print(cfg, "waves", n_waves, "mean ticks/wave", tot.mean(), "max", tot.max())
 for t in range(3 if cfg == "metric" else 1):
     sel = (np.arange(n_waves) % 3 == t) if cfg == "metric" else np.ones(n_waves, bool)
     print(" env type", t, "mean total", tot[sel].mean())
     for k, n in enumerate(names): print(f"  {n:32s} {v[sel, k].mean():10.1f}  {100 * v[sel, k].mean() / tot[sel].mean():5.1f}%")
+q = np.quantile(tot, [0.5, 0.9, 0.99, 1.0])
+print("quantiles of wave total", q)
+slow = tot >= np.quantile(tot, 0.97)
+print("slowest 3% waves: env types", np.bincount(np.arange(n_waves)[slow] % 3, minlength=3), "mean total", tot[slow].mean())
+for k, n in enumerate(names): print(f"  {n:32s} {v[slow, k].mean():10.1f}   (all waves {v[:, k].mean():10.1f})")
