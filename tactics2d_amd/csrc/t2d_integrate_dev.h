@@ -91,7 +91,8 @@ T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, 
     const int n_steps = interval / delta_t;
     const int rem = interval - n_steps * delta_t;
     const int total = n_steps + (rem > 0 ? 1 : 0);
-    StepOut o;
+    double ovx, ovy;  // (all StepOut fields are assembled in ONE place per model: stores into a
+                      // struct from several branches get sunk into pointer-phis and cost scratch)
     if (VARIANT == 0) {
         const double tand = tan_det(delta);
         const double t = lr / wb * tand;
@@ -113,8 +114,8 @@ T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, 
         }
         double sp, cp;
         sincos_det(phi, sp, cp);
-        o.vx = v * cp;
-        o.vy = v * sp;
+        ovx = v * cp;
+        ovy = v * sp;
     } else {
         double sd, cd;
         sincos_det(delta, sd, cd);
@@ -185,17 +186,10 @@ T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, 
             sub_step(hr, accel * hr, kk * hr);
         }
         // cos(phi) = cos((phi+beta) - beta)
-        o.vx = v * (c * cb + s * sb);
-        o.vy = v * (s * cb - c * sb);
+        ovx = v * (c * cb + s * sb);
+        ovy = v * (s * cb - c * sb);
     }
-    o.x = x;
-    o.y = y;
-    o.heading = mod_two_pi(phi);
-    o.speed = v;
-    o.app0 = accel;
-    o.app1 = delta;
-    o.has_velocity = true;
-    return o;
+    return StepOut{x, y, mod_two_pi(phi), v, ovx, ovy, accel, delta, true};
 }
 
 template <int VARIANT, typename PF>
@@ -303,17 +297,8 @@ T2D_DEV StepOut step_dynamics(PF P, double x, double y, double phi, double v, do
             else sincos_det(phi + beta, s, c);
         }
     }
-    StepOut o;
-    o.x = x;
-    o.y = y;
-    o.heading = mod_two_pi(phi);
-    o.speed = v;
-    o.vx = 0.0;
-    o.vy = 0.0;
-    o.app0 = accel;
-    o.app1 = delta;
-    o.has_velocity = false;  // reference State has vx = vy = None (:220-227)
-    return o;
+    // reference State has vx = vy = None (:220-227)
+    return StepOut{x, y, mod_two_pi(phi), v, 0.0, 0.0, accel, delta, false};
 }
 
 template <typename PF>
@@ -325,11 +310,10 @@ T2D_DEV StepOut step_pointmass(PF P, double x, double y, double vx, double vy, d
     double nvx = vx + ax * dt;
     double nvy = vy + ay * dt;
     double ns = __builtin_sqrt(nvx * nvx + nvy * nvy);
-    StepOut o;
-    double ovx, ovy;
+    double ox, oy, ovx, ovy;
     if (!(flags & T2D_RANGE_SPEED) || (lo <= ns && ns <= hi)) {
-        o.x = x + vx * dt + 0.5 * ax * (dt * dt);
-        o.y = y + vy * dt + 0.5 * ay * (dt * dt);
+        ox = x + vx * dt + 0.5 * ax * (dt * dt);
+        oy = y + vy * dt + 0.5 * ay * (dt * dt);
         ovx = nvx;
         ovy = nvy;
     } else {
@@ -351,17 +335,10 @@ T2D_DEV StepOut step_pointmass(PF P, double x, double y, double vx, double vy, d
         double t2 = dt - t1;
         ovx = vx + ax * t1;
         ovy = vy + ay * t1;
-        o.x = x + vx * t1 + 0.5 * ax * (t1 * t1) + ovx * t2;
-        o.y = y + vy * t1 + 0.5 * ay * (t1 * t1) + ovy * t2;
+        ox = x + vx * t1 + 0.5 * ax * (t1 * t1) + ovx * t2;
+        oy = y + vy * t1 + 0.5 * ay * (t1 * t1) + ovy * t2;
     }
-    o.heading = atan2_det(ovy, ovx);
-    o.speed = __builtin_sqrt(ovx * ovx + ovy * ovy);
-    o.vx = ovx;
-    o.vy = ovy;
-    o.app0 = ax;
-    o.app1 = ay;
-    o.has_velocity = true;
-    return o;
+    return StepOut{ox, oy, atan2_det(ovy, ovx), __builtin_sqrt(ovx * ovx + ovy * ovy), ovx, ovy, ax, ay, true};
 }
 
 
