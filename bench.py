@@ -13,7 +13,8 @@ every rank owns --envs environments (default 4096 x 64 participants, the metric 
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (per-kernel HIP
 event timing recorded on the launch stream inside the timed region) and `cpu_baseline` (the C
-oracle -- a port of the reference's algorithm -- timed on 1 host core on a bounded sample).
+oracle -- a port of the reference's algorithm -- timed on one host core and on all host cores,
+OpenMP over envs, on a bounded sample).
 """
 import argparse
 import json
@@ -44,16 +45,13 @@ def build_scene(name, n_env, agents, seed):
     raise SystemExit(f"unknown config {name}")
 
 
-def cpu_baseline(scene, target_seconds=12.0):
-    """The oracle (C port of the reference algorithm, fp64 scalar, 1 thread) stepping a bounded
-    sample of the SAME scene: integrate -> fp32 store -> collide -> status, per step."""
+def _cpu_leg(scene, n_env, threads, target_seconds):
+    """Step the first n_env envs of the scene with the oracle on `threads` host threads:
+    integrate -> fp32 store -> collide -> status, per step.  Returns (participant-steps/s, steps, s)."""
     from oracle import oracle as O
-    O.build()
-    n_env = min(scene.n_env, 96)
     A = scene.A
     n = n_env * A
     sl = slice(0, n)
-    eo, vo, xy = scene.static if scene.static is not None else (None, None, None)
 
     def cut(csr):
         if csr is None:
@@ -77,21 +75,46 @@ def cpu_baseline(scene, target_seconds=12.0):
     a0, a1 = full_a0[sl], full_a1[sl]
     is_dyn = scene.rows[tid, 0] == 1
     steps = 0
-    t0 = time.perf_counter()
-    while True:
-        o = O.integrate(scene.rows, x, y, h, v, vx, vy, a0, a1, tid, act, scene.interval_ms)
-        x, y, h, v = (np.float32(o[:, k]) for k in range(4))
-        vx = np.where(is_dyn, vx, np.float32(o[:, 4])); vy = np.where(is_dyn, vy, np.float32(o[:, 5]))
-        f, _ = O.collide(scene.rows, n_env, A, x, y, h, tid, act, static, boundary, None, lanes, 0)
-        O.status_ex(cfg, A, f, scene.interval_ms, cnt, frame, scene.rows, x, y, h, tid, ep)
-        steps += 1
-        el = time.perf_counter() - t0
-        if el >= target_seconds or steps >= 2000:
-            break
-    return dict(value=n * steps / el, unit="participant-steps/s", cores=1, kind="port",
-                sample=f"first {n_env} envs x {A} participants of the same scene, {steps} steps, "
-                       f"{el:.1f} s on 1 core ({os.cpu_count()} host cores present); C oracle "
-                       f"oracle/t2d_oracle.c (fp64 scalar restatement of the reference)")
+    O.set_threads(threads)
+    try:
+        t0 = time.perf_counter()
+        while True:
+            o = O.integrate(scene.rows, x, y, h, v, vx, vy, a0, a1, tid, act, scene.interval_ms)
+            x, y, h, v = (np.float32(o[:, k]) for k in range(4))
+            vx = np.where(is_dyn, vx, np.float32(o[:, 4])); vy = np.where(is_dyn, vy, np.float32(o[:, 5]))
+            f, _ = O.collide(scene.rows, n_env, A, x, y, h, tid, act, static, boundary, None, lanes, 0)
+            O.status_ex(cfg, A, f, scene.interval_ms, cnt, frame, scene.rows, x, y, h, tid, ep)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el >= target_seconds or steps >= 2000:
+                break
+    finally:
+        O.set_threads(1)
+    return n * steps / el, steps, el
+
+
+def cpu_baseline(scene, target_seconds=10.0):
+    """The oracle (C port of the reference algorithm, fp64 scalar) on a bounded sample of the SAME
+    scene, SURVEY.md 8(d): (1) one core, first 96 envs; (2) best effort: the same code with its
+    batch loops spread over all host cores (OpenMP), whole scene.  `value` is the all-cores rate."""
+    from oracle import oracle as O
+    O.build()
+    A = scene.A
+    one, steps1, el1 = _cpu_leg(scene, min(scene.n_env, 96), 1, target_seconds)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    out = dict(value=one, unit="participant-steps/s", cores=1, kind="port",
+               sample=f"first {min(scene.n_env, 96)} envs x {A} participants of the same scene, {steps1} steps, "
+                      f"{el1:.1f} s on 1 core; C oracle oracle/t2d_oracle.c (fp64 scalar restatement "
+                      f"of the reference)")
+    if O.has_openmp() and cores > 1:
+        allc, stepsN, elN = _cpu_leg(scene, scene.n_env, cores, target_seconds)
+        out.update(value=allc, cores=cores, one_core_value=one,
+                   sample=f"all {scene.n_env} envs x {A} participants of the same scene, {stepsN} steps, "
+                          f"{elN:.1f} s on {cores} host threads (OpenMP over envs; numpy glue between "
+                          f"the three calls is serial); one_core_value: first {min(scene.n_env, 96)} envs, "
+                          f"{steps1} steps, {el1:.1f} s on 1 core; C oracle oracle/t2d_oracle.c "
+                          f"(fp64 scalar restatement of the reference)")
+    return out
 
 
 def main():

@@ -181,6 +181,15 @@ def atan_det(x):
     return f(float(x))
 
 
+def set_threads(n):
+    """Host threads for the batch loops (integrate / collide / status).  Results are independent of it."""
+    lib().t2do_set_threads(int(n))
+
+
+def has_openmp():
+    return bool(lib().t2do_has_openmp())
+
+
 def make_config(**kw):
     """t2d_status_config with the ParkingEnv defaults; keyword overrides."""
     cfg = StatusConfig(20000, 0, 0, 0, -5.0, -1.0, -5.0, 5.0, 0.001, 0, 0, 100, 0, 0.95, 0.999, 0.1)
@@ -244,15 +253,12 @@ def status_ex(cfg, A, flags, interval_ms, cnt_step, frame_ms, rows, x, y, headin
     n_env = ep.n_env
     ego = cfg.ego_index
     rows = np.ascontiguousarray(rows, np.float64)
-    xe = np.float32(x).reshape(n_env, A)[:, ego]; ye = np.float32(y).reshape(n_env, A)[:, ego]
-    he = np.float32(heading).reshape(n_env, A)[:, ego]; te = np.asarray(type_id).reshape(n_env, A)[:, ego]
-    pose = np.zeros((n_env, 8)); is_obb = np.zeros(n_env, np.uint8)
-    for e in range(n_env):
-        r = rows[te[e]]
-        if int(r[18]) == 0:
-            pose[e] = pose_obb(xe[e], ye[e], he[e], r[19], r[20], 0).reshape(-1)
-            is_obb[e] = 1
-    xy = np.ascontiguousarray(np.stack([xe, ye], 1), np.float64)
+    pose = np.zeros((n_env, 8)); is_obb = np.zeros(n_env, np.uint8); xy = np.zeros((n_env, 2))
+    g = lib().t2do_ego_poses
+    g.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _u8p, C.c_int, _f64p, _f64p, _u8p]
+    g(rows, rows.shape[1], n_env, A, int(ego), np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32),
+      np.ascontiguousarray(heading, np.float32), np.ascontiguousarray(type_id, np.uint8), 0,
+      pose.reshape(-1), xy.reshape(-1), is_obb)
     st = np.zeros((n_env, 4), np.uint8); rw = np.zeros(n_env, np.float32); iou = np.zeros(n_env, np.float32)
     f = lib().t2do_status_ex
     f.argtypes = [C.POINTER(StatusConfig), C.c_int, C.c_int, _u32p, C.c_int, _i32p, _i32p, _u8p, _f32p,

@@ -133,6 +133,20 @@ double t2do_atan2(double y, double x) {
  * last ulp), mode 1 = deterministic (bit-reproducible; the GPU "exact" variant uses it). */
 static int g_trig = 0;
 void t2do_set_trig(int mode) { g_trig = mode; }
+
+/* Batch entry points below loop over independent participants / envs; the all-cores CPU baseline
+ * of bench.py spreads those loops over host threads (OpenMP, when built with -fopenmp).  Results
+ * do not depend on the thread count.  Default 1 thread. */
+static int g_threads = 1;
+void t2do_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int t2do_get_threads(void) { return g_threads; }
+int t2do_has_openmp(void) {
+#ifdef _OPENMP
+    return 1;
+#else
+    return 0;
+#endif
+}
 static double T_sin(double x) { if (!g_trig) return sin(x); double s, c; t2do_sincos(x, &s, &c); return s; }
 static double T_cos(double x) { if (!g_trig) return cos(x); double s, c; t2do_sincos(x, &s, &c); return c; }
 static double T_tan(double x) { if (!g_trig) return tan(x); double s, c; t2do_sincos(x, &s, &c); return s / c; }
@@ -346,6 +360,7 @@ void t2do_integrate(const double* rows, int row_stride, int n, const float* x, c
                     const float* heading, const float* speed, const float* vx, const float* vy,
                     const float* act0, const float* act1, const uint8_t* type_id,
                     const uint8_t* active, int interval_ms, double* out) {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int i = 0; i < n; ++i) {
         double* o = out + 8 * (size_t)i;
         if (active && !active[i]) {
@@ -386,6 +401,26 @@ void t2do_pose_obb(double x, double y, double h, double L, double W, int trig, d
 }
 
 /* orientation of r relative to the directed line p->q: > 0 left, < 0 right, 0 on it */
+/* pose of the ego of every env (input of t2do_status_ex), batched so that the CPU baseline does
+ * not loop in Python: pose8[e] = t2do_pose_obb(ego) for box-shaped egos, is_obb[e] = 0 otherwise */
+void t2do_ego_poses(const double* rows, int row_stride, int n_env, int A, int ego_index,
+                    const float* x, const float* y, const float* heading, const uint8_t* type_id,
+                    int trig, double* pose8, double* xy, uint8_t* is_obb) {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+    for (int e = 0; e < n_env; ++e) {
+        size_t i = (size_t)e * A + ego_index;
+        const double* p = rows + (size_t)type_id[i] * row_stride;
+        xy[2 * e] = x[i];
+        xy[2 * e + 1] = y[i];
+        is_obb[e] = 0;
+        for (int k = 0; k < 8; ++k) pose8[8 * (size_t)e + k] = 0.0;
+        if ((int)p[T2D_P_SHAPE] == T2D_SHAPE_OBB) {
+            t2do_pose_obb(x[i], y[i], heading[i], p[T2D_P_LENGTH], p[T2D_P_WIDTH], trig, pose8 + 8 * (size_t)e);
+            is_obb[e] = 1;
+        }
+    }
+}
+
 static double orient(const double* p, const double* q, const double* r) {
     double a = q[0] - p[0], b = r[1] - p[1];
     double c = q[1] - p[1], d = r[0] - p[0];
@@ -504,9 +539,12 @@ void t2do_collide(const double* rows, int row_stride, int n_env, int A, const fl
                   const float* poly_xy, const float* boundary, const uint8_t* boundary_valid,
                   const int32_t* env_lane_off, const int32_t* lane_vert_off, const float* lane_xy,
                   int trig, uint32_t* flags, uint32_t* env_flags) {
+#pragma omp parallel num_threads(g_threads) if (g_threads > 1)
+    {
     double* V = (double*)malloc(sizeof(double) * 8 * (size_t)A);
     double* C = (double*)malloc(sizeof(double) * 3 * (size_t)A);
     int* kind = (int*)malloc(sizeof(int) * (size_t)A);
+#pragma omp for schedule(dynamic, 4)
     for (int e = 0; e < n_env; ++e) {
         size_t base = (size_t)e * A;
         for (int i = 0; i < A; ++i) {
@@ -586,6 +624,7 @@ void t2do_collide(const double* rows, int row_stride, int n_env, int A, const fl
         env_flags[e] = ef;
     }
     free(V); free(C); free(kind);
+    }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -671,6 +710,7 @@ void t2do_status_ex(const t2d_status_config* cfg, int n_env, int A, const uint32
                     const double* ego_pose, const double* ego_xy, const uint8_t* ego_is_obb,
                     const double* target, const double* target_c, int has_target, double* last_pose,
                     uint8_t* last_valid, int32_t* cnt_na, double* max_iou, double* min_dist, float* iou_out) {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int e = 0; e < n_env; ++e) {
         cnt_step[e] += 1; /* parking.py:353 */
         frame_ms[e] += interval_ms;

@@ -16,7 +16,8 @@ buf = np.zeros(n_waves * 16, np.uint64)
 for k in range(60):
     a0, a1 = sc.sample_actions(rng); pool.set_actions(a0, a1); pool.step(100); pool.restore(done_only=True)
 lib.t2d_debug_read(pool._h, buf.ctypes.data_as(C.c_void_p), buf.size)
-v = buf.reshape(n_waves, 16).astype(np.float64)
+raw = buf.reshape(n_waves, 16)
+v = raw.astype(np.float64)
 names = ["0 load+stage+barrier(a)", "1 pose", "2 barrier(b)", "3 broad phase", "4 pair compaction+narrow", "5 static AABB pass",
          "6 static narrow", "7 lane AABB pass", "8 lane narrow", "9 (loop exit)", "10 barrier(c)", "11 reduce+barrier(d)", "12 epilogue",
          "13 fused integrate"]
@@ -31,3 +32,22 @@ print("quantiles of wave total", q)
 slow = tot >= np.quantile(tot, 0.97)
 print("slowest 3% waves: env types", np.bincount(np.arange(n_waves)[slow] % 3, minlength=3), "mean total", tot[slow].mean())
 for k, n in enumerate(names): print(f"  {n:32s} {v[slow, k].mean():10.1f}   (all waves {v[:, k].mean():10.1f})")
+
+# placement: per-SIMD sums (HW_ID bits: simd [5:4], cu [11:8], sh [12], se [15:13]; XCC_ID low bits)
+hw = raw[:, 14] & 0xffffffff; xcc = (raw[:, 14] >> 32) & 0xf
+simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+uk, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+per = np.bincount(inv, weights=tot)
+start = raw[:, 15].astype(np.float64); end = start + tot
+print("SIMDs used", len(uk), "waves/SIMD min/mean/max", cnt.min(), cnt.mean(), cnt.max())
+print("XCCs", np.unique(xcc), "SEs", np.unique(se), "CUs", np.unique(cu), "SH", np.unique(sh))
+for x in np.unique(xcc):
+    m = xcc == x
+    print(f" xcc {x}: waves {m.sum()}, span {end[m].max() - start[m].min():.0f} ticks, first start {start[m].min():.0f}, last start {start[m].max() - start[m].min():.0f} after, mean wave {tot[m].mean():.0f}")
+span = np.array([end[inv == i].max() - start[inv == i].min() for i in range(len(uk))])
+print("per-SIMD span (first start -> last end): mean", span.mean(), "max", span.max(), "min", span.min())
+print("per-SIMD sum of wave times: mean", per.mean(), "max", per.max())
+wg = np.arange(n_waves) // 4
+print("first 16 WGs -> (xcc,se,sh,cu):", [(int(xcc[4*i]), int(se[4*i]), int(sh[4*i]), int(cu[4*i])) for i in range(16)])
+print("WG 0 waves simd:", simd[:4], " WG 1:", simd[4:8])

@@ -370,6 +370,11 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
 #ifdef T2D_TIMING
     unsigned long long t_prev_ = __builtin_readcyclecounter();
     const size_t wave_slot_ = ((size_t)blockIdx.x * kWaves + (tid >> 6)) * 16;
+    if (lane == 0) {  // where and when this wave ran: HW_ID | XCC_ID << 32, start tick
+        pv.dbg[wave_slot_ + 14] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |
+                                  ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+        pv.dbg[wave_slot_ + 15] = t_prev_;
+    }
 #endif
     // ---------------- phase 0: issue every global load, clear LDS tables ------------------
     uint32_t ids = 0;

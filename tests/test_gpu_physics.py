@@ -163,3 +163,47 @@ def test_inactive_participants_are_untouched():
     gx = pool.download(L.F_X)
     pool.close()
     assert (gx[act == 0] == x[act == 0]).all() and (gx[act == 1] != x[act == 1]).all()
+
+
+@pytest.mark.parametrize("interval,delta_t", [(100, 5), (50, 3), (9, 5), (100, 7)])
+def test_fast_kinematics_speed_clipping_paths(oracle, interval, delta_t):
+    """The fast variant treats the clamped speed as piecewise linear in the sub-step index (linear
+    until the bound is crossed, pinned afterwards).  Cases sitting on a bound, crossing it at every
+    possible sub-step, starting outside the range (plain loop) and never clipping must all stay
+    within 2e-6 m / 1e-6 rad of the plain 20-sub-step loop (the exact variant == oracle)."""
+    from tactics2d_amd import layout as L
+    rng = np.random.default_rng(42 + interval)
+    k = [q for q in H.load_json("physics_kats.json") if q["ctor"] == "parking" and q["model"] == "kinematics"][0]
+    rows = []
+    ranges = [(-0.5, 0.5), (0.0, 1.2), (0.5, 7.0), (-7.0, 7.0), (0.0, 20.0), (2.0, 30.0)]
+    for lo, hi in ranges:
+        r = np.array(k["row"], np.float64)
+        r[L.P_SPEED_LO], r[L.P_SPEED_HI] = lo, hi
+        r[L.P_RANGE_FLAGS] = int(r[L.P_RANGE_FLAGS]) | 2
+        r[L.P_ACCEL_LO], r[L.P_ACCEL_HI] = -6.0, 6.0
+        r[L.P_DELTA_T_MS] = delta_t
+        rows.append(r)
+    rows = np.array(rows)
+    n = 6000
+    tid = rng.integers(0, len(ranges), n).astype(np.uint8)
+    lo = rows[tid, L.P_SPEED_LO]; hi = rows[tid, L.P_SPEED_HI]
+    mode = rng.integers(0, 5, n)
+    u = rng.random(n)
+    v = np.where(mode == 0, lo, np.where(mode == 1, hi, lo + u * (hi - lo)))          # on a bound / inside
+    v = np.where(mode == 3, np.where(u < 0.5, hi - 0.02 * u, lo + 0.02 * u), v)       # about to cross
+    v = np.where(mode == 4, np.where(u < 0.5, hi + 0.3 * u, lo - 0.3 * u), v)         # outside (plain loop)
+    st = np.stack([rng.uniform(-200, 200, n), rng.uniform(-200, 200, n), rng.uniform(-7, 7, n), v], 1).astype(np.float32)
+    act = np.stack([rng.uniform(-6, 6, n), rng.uniform(-0.6, 0.6, n)], 1).astype(np.float32)
+    act[rng.random(n) < 0.1, 0] = 0.0
+    ref = H.oracle_physics(oracle, rows, tid, st, act, interval, "kin", trig=1)
+    exact = H.gpu_physics(rows, tid, st, act, interval, "exact", "kin")
+    fast = H.gpu_physics(rows, tid, st, act, interval, "fast", "kin")
+    assert np.array_equal(exact[:, :4], np.float32(ref[:, :4]))
+    e = H.state_err(fast, exact, cols=4)
+    # one fp32 ulp of the stored coordinate (|x| <= 256 m: 1.5e-5) can flip on a 1e-12 difference
+    ulp = np.spacing(np.abs(exact[:, :2]).astype(np.float32)).max(1)
+    assert (e[:, :2].max(1) <= ulp + 2e-6).all(), e.max(0)
+    assert e[:, 2].max() <= 1e-6, e.max(0)
+    # the closed-form speed v0 + n*ah may round to the neighbouring fp32 of the iterated sum
+    assert (e[:, 3] <= np.spacing(np.abs(exact[:, 3]).astype(np.float32)) + 1e-7).all(), e.max(0)
+    print("clip paths", interval, delta_t, "max err", e.max(0), "flipped-ulp cases", int((e[:, :2].max(1) > 2e-6).sum()))

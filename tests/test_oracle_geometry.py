@@ -118,3 +118,25 @@ def test_status_priority_order(oracle):
     cnt[:] = 3
     st, rw = oracle.status(cfg, 7, 1, flags, 100, cnt, frame)   # cnt 4 > max_step 3: time exceed wins
     assert (st[:, 0] == 3).all() and (rw == -1).all() and (cnt == 4).all() and (frame == 200).all()
+
+
+def test_oracle_batch_loops_do_not_depend_on_thread_count(oracle):
+    """bench.py's all-cores CPU baseline runs the same batch entry points with OpenMP threads."""
+    import helpers as H
+    from tactics2d_amd import scenarios as S
+    sc = S.mixed(24, 16, seed=5)
+    rng = np.random.default_rng(0)
+    a0, a1 = sc.sample_actions(rng)
+    vx = np.float32(sc.speed * np.cos(sc.heading)); vy = np.float32(sc.speed * np.sin(sc.heading))
+    res = []
+    for th in (1, 4):
+        oracle.set_threads(th)
+        try:
+            o = oracle.integrate(sc.rows, sc.x, sc.y, sc.heading, sc.speed, vx, vy, a0, a1, sc.type_id, sc.active, 100)
+            f, ef = oracle.collide(sc.rows, sc.n_env, sc.A, np.float32(o[:, 0]), np.float32(o[:, 1]), np.float32(o[:, 2]),
+                                   sc.type_id, sc.active, sc.static, sc.boundary, None, sc.lanes, 1)
+        finally:
+            oracle.set_threads(1)
+        res.append((o.copy(), f.copy(), ef.copy()))
+    assert np.array_equal(res[0][0], res[1][0], equal_nan=True)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
