@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events")
     ap.add_argument("--no-reset", action="store_true", help="skip the device-side auto-reset")
+    ap.add_argument("--idm", action="store_true", help="non-ego vehicles driven by on-device IDM controllers (row f3); "
+                    "adds the idm kernel to every step (not the metric configuration)")
     ap.add_argument("--split", action="store_true", help="two-kernel step (integrate + check_status) instead of the fused launch")
     args = ap.parse_args()
 
@@ -158,6 +160,12 @@ def main():
     if not args.no_reset:
         pool.set_auto_reset(True)   # finished envs restart inside the step launch (no extra kernels)
     N = scene.n
+    if args.idm:
+        from tactics2d_amd.controller import IDMController, install
+        cid = np.full(N, L.IDM_NONE, np.uint8).reshape(n_env, agents)
+        veh = (scene.rows[scene.type_id, L.P_MODEL] != L.MODEL_POINTMASS).reshape(n_env, agents)
+        cid[:, 1:] = np.where(veh[:, 1:], 0, L.IDM_NONE)
+        install(pool, [IDMController(desired_speed=25.0, horizon=120.0)], cid.reshape(-1))
 
     # actions: a ring of pre-generated batches resident in HBM, bound zero-copy each step
     rng = np.random.default_rng(1000 + rank)
@@ -211,7 +219,7 @@ def main():
         if gather is not None:
             gather.wait()
         barrier()
-        for kid, name in ((0, "integrate_kernel"), (1, "collide_kernel"), (2, "step_kernel")):
+        for kid, name in ((0, "integrate_kernel"), (1, "collide_kernel"), (2, "step_kernel"), (4, "idm_kernel")):
             ms, launches = pool.profile_read(kid)
             if launches:
                 kern[name] = dict(avg_us=1e3 * ms / launches, launches=launches)
@@ -245,7 +253,9 @@ def main():
         if kern:
             per_launch = {"integrate_kernel": INTEGRATOR_BYTES * N, "collide_kernel": COLLIDE_BYTES * N + geo_bytes,
                           # fused: the integrator's 44 B + the 4-B flag word (poses never leave registers)
-                          "step_kernel": (INTEGRATOR_BYTES + 4) * N + geo_bytes}
+                          "step_kernel": (INTEGRATOR_BYTES + 4) * N + geo_bytes,
+                          # idm: x, y, heading, speed, ids, ctrl id in; 2 actions + leader out
+                          "idm_kernel": 33 * N}
             in_step = {"step_kernel"} if not args.split else {"integrate_kernel", "collide_kernel"}
             dom = max(in_step & set(kern), key=lambda k_: kern[k_]["avg_us"])
             ach = per_launch[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
@@ -271,7 +281,7 @@ def main():
                    config=dict(workload=f"{scene.name}: {n_env} envs x {agents} participants per GPU, "
                                         f"interval 100 ms / delta_t 5 ms (20 Euler sub-steps), "
                                         f"integrator variant {args.variant}, {'two-kernel' if args.split else 'fused single-launch'} step, auto-reset "
-                                        f"{'off' if args.no_reset else 'on'}",
+                                        f"{'off' if args.no_reset else 'on'}" + (", IDM agents on" if args.idm else ""),
                                config=args.config, envs_per_gpu=n_env, participants_per_env=agents,
                                parallelism=f"env-sharded x{world}, RCCL all-gather of 8 B/env records"
                                if world > 1 else "single GPU"),

@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define T2D_ABI_VERSION 2
+#define T2D_ABI_VERSION 3
 
 /* ---- status codes --------------------------------------------------------------- */
 #define T2D_OK            0
@@ -138,7 +138,9 @@ enum {
     T2D_F_CNT_NO_ACTION = 19, /* i32[E] NoAction.cnt_no_action                          */
     T2D_F_LIDAR = 20,      /* f32[E][n_beams] last t2d_lidar_scan into the pool's own buffer (size set by
                               t2d_lidar_config; +inf = no return)                                 */
-    T2D_F_COUNT = 21
+    T2D_F_LEADER = 21,     /* i32[N]  agent index (inside the env) of the IDM leader chosen by the last
+                            *         t2d_idm_actions, -1 = none / participant not IDM-controlled   */
+    T2D_F_COUNT = 22
 };
 
 /* ---- per-participant / per-env event bits ------------------------------------------- */
@@ -289,12 +291,47 @@ int t2d_lidar_config(t2d_pool* pool, int32_t n_beams, float max_range, int32_t i
                      const double* beam_sin, const double* beam_cos);
 int t2d_lidar_scan(t2d_pool* pool, float* out_dev, void* hip_stream);
 
+/* On-device scripted agents: IDM car following (IDMController, controller/idm_controller.py:33-157).
+ * ctrl_rows: host array [n_ctrl][row_stride >= T2D_IDM_COLS] of fp64 parameter sets -- the constructor
+ * arguments of idm_controller.py:33-57 (`configure` :143-157 = calling t2d_set_idm again) plus the two
+ * columns of the build-defined leader rule; ctrl_id: host array [n_env * max_agents], index of the
+ * participant's parameter set or T2D_IDM_NONE (its action stays whatever the caller supplied).
+ * n_ctrl = 0 uninstalls.  t2d_idm_actions = IDMController.step :59-93 for every controlled participant:
+ * acceleration (np.clip-ed to [-comfortable_deceleration, max_acceleration]) -> action 0, steering 0.0 ->
+ * action 1 (written into the bound action buffers when t2d_bind_actions is in effect), leader index ->
+ * T2D_F_LEADER.  The reference takes `leading_state` from its caller; here the leader is the nearest active
+ * participant ahead (0 < longitudinal offset <= horizon along the own heading) inside the own corridor
+ * (|lateral offset| <= lane_half_width), lowest index on ties; none -> free-flow branch.  Distance is
+ * centre to centre (np.hypot), as in :111-113.  While installed, t2d_step and t2d_integrate run it first
+ * on the same stream.  kernel_id 4 in t2d_profile_read.                                               */
+enum t2d_idm_col {
+    T2D_IDM_DESIRED_SPEED = 0,
+    T2D_IDM_TIME_HEADWAY = 1,
+    T2D_IDM_MIN_SPACING = 2,
+    T2D_IDM_MAX_ACCEL = 3,
+    T2D_IDM_COMF_DECEL = 4,
+    T2D_IDM_DELTA = 5,
+    T2D_IDM_LANE_HALF_WIDTH = 6, /* build-defined leader rule */
+    T2D_IDM_HORIZON = 7,         /* build-defined: look-ahead (m), may be +inf */
+    T2D_IDM_COLS = 8
+};
+#define T2D_IDM_NONE 255
+/* values of forced_leader_dev[i] (device array [n_env * max_agents], or NULL = search everywhere): the
+ * reference's calling convention `step(ego_state, leading_state)` -- an agent index inside the env (an
+ * inactive or out-of-range index counts as no leader), T2D_IDM_LEADER_FREE = `leading_state=None`,
+ * T2D_IDM_LEADER_SEARCH = apply the leader rule above.                                               */
+#define T2D_IDM_LEADER_FREE (-1)
+#define T2D_IDM_LEADER_SEARCH (-2)
+int t2d_set_idm(t2d_pool* pool, const double* ctrl_rows, int32_t n_ctrl, int32_t row_stride,
+                const uint8_t* ctrl_id);
+int t2d_idm_actions(t2d_pool* pool, const int32_t* forced_leader_dev, void* hip_stream);
+
 /* Kernel variants: 0 = exact (library-grade fp64 trig every sub-step), 1 = fast
  * (rotation recurrence, default).  Both satisfy the 1e-5 contract; see DESIGN.md.       */
 int t2d_set_integrator_variant(t2d_pool* pool, int32_t variant);
 
 /* Per-kernel timing with HIP events recorded on the launch stream around each kernel.
- * kernel_id: 0 = integrate, 1 = collide(+status), 2 = fused step, 3 = lidar.                                     */
+ * kernel_id: 0 = integrate, 1 = collide(+status), 2 = fused step, 3 = lidar, 4 = idm.                                    */
 int t2d_profile_enable(t2d_pool* pool, int32_t on);
 int t2d_profile_read(t2d_pool* pool, int32_t kernel_id, double* total_ms, int64_t* launches);
 

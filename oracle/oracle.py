@@ -271,6 +271,56 @@ def status_ex(cfg, A, flags, interval_ms, cnt_step, frame_ms, rows, x, y, headin
     return st, rw, iou
 
 
+def idm_accel(params, v, has_lead, dx=0.0, dy=0.0, v_lead=0.0, trig=0):
+    """One IDMController.step -> clipped acceleration.  trig=0: libm pow/hypot (pins vs the golden
+    vectors); trig=1: the deterministic spec shared with the GPU."""
+    f = lib().t2do_idm_accel
+    f.restype = C.c_double
+    f.argtypes = [_f64p, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double]
+    lib().t2do_set_trig(trig)
+    try:
+        return f(np.ascontiguousarray(params, np.float64), float(v), int(has_lead), float(dx), float(dy), float(v_lead))
+    finally:
+        lib().t2do_set_trig(0)
+
+
+def det_pow(x, y):
+    f = lib().t2do_pow; f.restype = C.c_double; f.argtypes = [C.c_double, C.c_double]
+    return f(float(x), float(y))
+
+
+def det_exp(x):
+    f = lib().t2do_exp; f.restype = C.c_double; f.argtypes = [C.c_double]
+    return f(float(x))
+
+
+def det_log(x):
+    f = lib().t2do_log; f.restype = C.c_double; f.argtypes = [C.c_double]
+    return f(float(x))
+
+
+def idm(ctrl_rows, ctrl_id, n_env, A, x, y, heading, speed, active, act0, act1, forced_leader=None, trig=1):
+    """Batched IDM with the build-defined leader rule.  Returns (act0, act1, leader) -- act0/act1 are
+    copies of the inputs with the controlled participants' entries replaced."""
+    rows = np.ascontiguousarray(ctrl_rows, np.float64)
+    a0 = np.array(act0, np.float32).reshape(-1).copy(); a1 = np.array(act1, np.float32).reshape(-1).copy()
+    lead = np.full(n_env * A, -1, np.int32)
+    fl = None if forced_leader is None else np.ascontiguousarray(forced_leader, np.int32)
+    f = lib().t2do_idm
+    f.restype = None
+    f.argtypes = [_f64p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, _u8p, C.c_void_p,
+                  _f32p, _f32p, _i32p]
+    lib().t2do_set_trig(trig)
+    try:
+        f(rows, rows.shape[1], rows.shape[0], np.ascontiguousarray(ctrl_id, np.uint8), n_env, A,
+          np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32),
+          np.ascontiguousarray(heading, np.float32), np.ascontiguousarray(speed, np.float32),
+          np.ascontiguousarray(active, np.uint8), None if fl is None else fl.ctypes.data_as(C.c_void_p), a0, a1, lead)
+    finally:
+        lib().t2do_set_trig(0)
+    return a0, a1, lead
+
+
 def beam_tables(n_beams):
     th = np.linspace(0, 2 * np.pi, n_beams, endpoint=False)
     return np.ascontiguousarray(np.sin(th)), np.ascontiguousarray(np.cos(th))

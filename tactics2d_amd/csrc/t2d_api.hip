@@ -34,7 +34,7 @@ size_t field_elem_bytes(int f) {
         default: return 4;
     }
 }
-bool field_per_env(int f) { return f >= T2D_F_ENV_FLAGS; }
+bool field_per_env(int f) { return f >= T2D_F_ENV_FLAGS && f != T2D_F_LEADER; }
 
 template <class T>
 int dev_replace(t2d_pool* p, T** dst, const T* src, size_t n) {
@@ -445,7 +445,7 @@ int t2d_destroy(t2d_pool* p) {
                     p->d_last_pose, p->d_max_iou, p->d_min_dist, p->d_snap_min_dist, p->d_last_valid,
                     p->d_lidar_env_off, p->d_lidar_next, p->d_lidar_xy, p->d_beam_sin, p->d_beam_cos,
                     p->d_snap[0], p->d_snap[1], p->d_snap[2],
-                    p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids};
+                    p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_idm_rows, p->d_idm_ctrl};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->prof_events) {
@@ -691,6 +691,13 @@ int t2d_bind_actions(t2d_pool* p, const float* act0_dev, const float* act1_dev) 
     return T2D_OK;
 }
 
+static int idm_impl(t2d_pool* p, hipStream_t s, const int32_t* forced_leader = nullptr) {
+    int rc;
+    if ((rc = record_event(p, 4, s, true))) return rc;
+    T2D_HIP(p, t2d::launch_idm(p->v, p->idm, forced_leader, s));
+    return record_event(p, 4, s, false);
+}
+
 int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     if (!p) return T2D_ERR_INVALID;
     if (!p->have_params || !p->have_reset)
@@ -698,6 +705,7 @@ int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     if (interval_ms <= 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be positive");
     hipStream_t s = (hipStream_t)hip_stream;
     int rc;
+    if (p->idm_on && (rc = idm_impl(p, s))) return rc;
     if ((rc = record_event(p, 0, s, true))) return rc;
     T2D_HIP(p, t2d::launch_integrate(p->v, interval_ms, p->integrator_variant, s));
     return record_event(p, 0, s, false);
@@ -740,7 +748,9 @@ int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
         return fail(p, T2D_ERR_STATE, "t2d_set_param_table and t2d_reset must precede t2d_step");
     if (interval_ms <= 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be positive");
     p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)(p->step_count & 1) * p->v.n_env;
-    int rc = collide_impl(p, true, interval_ms, (hipStream_t)hip_stream, p->integrator_variant);
+    int rc;
+    if (p->idm_on && (rc = idm_impl(p, (hipStream_t)hip_stream))) return rc;
+    rc = collide_impl(p, true, interval_ms, (hipStream_t)hip_stream, p->integrator_variant);
     if (rc == T2D_OK) p->step_count++;
     return rc;
 }
@@ -884,6 +894,51 @@ int t2d_lidar_scan(t2d_pool* p, float* out_dev, void* hip_stream) {
     if ((rc = record_event(p, 3, s, true))) return rc;
     T2D_HIP(p, t2d::launch_lidar(p->v, p->lidar, out_dev ? out_dev : (float*)p->field_ptr[T2D_F_LIDAR], s));
     return record_event(p, 3, s, false);
+}
+
+int t2d_set_idm(t2d_pool* p, const double* ctrl_rows, int32_t n_ctrl, int32_t row_stride, const uint8_t* ctrl_id) {
+    if (!p) return T2D_ERR_INVALID;
+    T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, hipDeviceSynchronize());
+    if (n_ctrl == 0) {
+        p->idm_on = false;
+        return T2D_OK;
+    }
+    if (!ctrl_rows || !ctrl_id || n_ctrl < 0 || n_ctrl >= T2D_IDM_NONE || row_stride < T2D_IDM_COLS)
+        return fail(p, T2D_ERR_INVALID, "t2d_set_idm: need 1..254 parameter sets of >= 8 columns and a controller id per participant");
+    std::vector<double> rows((size_t)n_ctrl * T2D_IDM_COLS);
+    for (int c = 0; c < n_ctrl; ++c) {
+        const double* r = ctrl_rows + (size_t)c * row_stride;
+        for (int k = 0; k < T2D_IDM_COLS; ++k) rows[(size_t)c * T2D_IDM_COLS + k] = r[k];
+        // idm_controller.py divides by sqrt(max_acceleration * comfortable_deceleration) (:121)
+        if (!(r[T2D_IDM_MAX_ACCEL] * r[T2D_IDM_COMF_DECEL] > 0.0))
+            return fail(p, T2D_ERR_INVALID, "t2d_set_idm: max_acceleration * comfortable_deceleration must be positive (row " +
+                                                std::to_string(c) + ")");
+        if (!(r[T2D_IDM_LANE_HALF_WIDTH] >= 0.0) || !(r[T2D_IDM_HORIZON] > 0.0))
+            return fail(p, T2D_ERR_INVALID, "t2d_set_idm: lane_half_width >= 0 and horizon > 0 required (row " +
+                                                std::to_string(c) + ")");
+    }
+    for (int i = 0; i < p->v.N; ++i)
+        if (ctrl_id[i] != T2D_IDM_NONE && ctrl_id[i] >= n_ctrl)
+            return fail(p, T2D_ERR_INVALID, "t2d_set_idm: ctrl_id[" + std::to_string(i) + "] = " +
+                                                std::to_string((int)ctrl_id[i]) + " out of range");
+    int rc;
+    if ((rc = dev_replace(p, &p->d_idm_rows, rows.data(), rows.size()))) return rc;
+    if ((rc = dev_replace(p, &p->d_idm_ctrl, ctrl_id, (size_t)p->v.N))) return rc;
+    p->idm.rows = p->d_idm_rows;
+    p->idm.ctrl_id = p->d_idm_ctrl;
+    p->idm.leader = (int32_t*)p->field_ptr[T2D_F_LEADER];
+    p->idm.n_ctrl = n_ctrl;
+    T2D_HIP(p, hipMemset(p->field_ptr[T2D_F_LEADER], 0xff, p->field_bytes[T2D_F_LEADER]));
+    p->idm_on = true;
+    return T2D_OK;
+}
+
+int t2d_idm_actions(t2d_pool* p, const int32_t* forced_leader_dev, void* hip_stream) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!p->idm_on) return fail(p, T2D_ERR_STATE, "t2d_set_idm must precede t2d_idm_actions");
+    if (!p->have_reset) return fail(p, T2D_ERR_STATE, "t2d_reset must precede t2d_idm_actions");
+    return idm_impl(p, (hipStream_t)hip_stream, forced_leader_dev);
 }
 
 int t2d_set_integrator_variant(t2d_pool* p, int32_t variant) {

@@ -150,4 +150,68 @@ T2D_DEV double mod_two_pi(double phi) {
     return r;
 }
 
+// ---- exp / log / pow for the IDM controller's (v / v_des) ** delta (oracle: t2do_exp/log/pow) ----
+// Public fdlibm formulations (e_log.c / e_exp.c), written without fma so that the C oracle computes the
+// same bits with -ffp-contract=off.  < 1 ulp each; pow_det = exp(y log x) is good to ~|y log x| ulp,
+// integer-valued exponents up to 64 use a fixed square-and-multiply chain instead.
+T2D_DEV double log_det(double x) {  // x > 0, finite
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    int e;
+    double m = __builtin_frexp(x, &e);  // [0.5, 1)
+    if (m < 0.70710678118654752440) {
+        m = m * 2.0;
+        e -= 1;
+    }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+T2D_DEV double exp_det(double x) {
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 709.782712893384) return __builtin_inf();
+    if (x < -745.1332191019411) return 0.0;
+    const double k = __builtin_rint(x * invln2);
+    const double hi = x - k * ln2HI;
+    const double lo = k * ln2LO;
+    const double r = hi - lo;
+    const double t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    return __builtin_ldexp(y, (int)k);
+}
+
+T2D_DEV double pow_det(double x, double y) {  // float.__pow__ on the IDM path (idm_controller.py:79,129)
+    if (y == 0.0) return 1.0;
+    if (x != x || y != y) return x + y;
+    const double yi = __builtin_rint(y);
+    if (yi == y && __builtin_fabs(y) <= 64.0) {
+        int n = (int)__builtin_fabs(yi);
+        double r = 1.0, b = x;
+        while (n) {
+            if (n & 1) r = r * b;
+            b = b * b;
+            n >>= 1;
+        }
+        return y < 0.0 ? 1.0 / r : r;
+    }
+    if (x < 0.0) return __builtin_nan("");  // Python yields a complex number: outside the contract
+    if (x == 0.0) return y > 0.0 ? 0.0 : __builtin_inf();
+    return exp_det(y * log_det(x));
+}
+
 }  // namespace t2d

@@ -83,6 +83,14 @@ struct LidarView {
     int32_t max_slots;  // LDS edge slots per env: max_static_verts + 4 * max_agents (when participants are scanned)
 };
 
+// IDM controllers (t2d_idm.hip): parameter sets + one controller id per participant.
+struct IdmView {
+    const double* rows;      // [n_ctrl][T2D_IDM_COLS]
+    const uint8_t* ctrl_id;  // [N] index into rows, T2D_IDM_NONE = action left to the caller
+    int32_t* leader;         // [N] out: agent index of the chosen leader inside the env, -1 = none
+    int32_t n_ctrl;
+};
+
 constexpr int kIdsModelShift = 0;
 constexpr int kIdsTypeShift = 8;
 constexpr int kIdsActiveShift = 16;
@@ -122,6 +130,11 @@ struct t2d_pool {
     int32_t *d_lidar_env_off = nullptr, *d_lidar_next = nullptr;
     float* d_lidar_xy = nullptr;
     double *d_beam_sin = nullptr, *d_beam_cos = nullptr;
+    // IDM agents (row f3)
+    bool idm_on = false;
+    t2d::IdmView idm{};
+    double* d_idm_rows = nullptr;
+    uint8_t* d_idm_ctrl = nullptr;
     float* d_snap[6]{};      // x, y, heading, speed, vx, vy at episode start
     uint32_t* d_snap_ids = nullptr;
     bool have_snapshot = false;
@@ -141,6 +154,7 @@ hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hip
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
                           int interval_ms, int fuse_variant, hipStream_t s);
 hipError_t launch_lidar(const PoolView& v, const LidarView& lv, float* out, hipStream_t s);
+hipError_t launch_idm(const PoolView& v, const IdmView& iv, const int32_t* forced_leader, hipStream_t s);
 hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
                           hipStream_t s);
 }  // namespace t2d

@@ -118,6 +118,22 @@ class ParticipantPool:
     def lidar_scan(self, out_ptr=None, stream=None):
         self._ck(self._lib.t2d_lidar_scan(self._h, out_ptr, stream))
 
+    def set_idm(self, ctrl_rows, ctrl_id):
+        """Install IDM controllers: ctrl_rows [n_ctrl, 8] (layout.IDM_*), ctrl_id [n] uint8 (IDM_NONE =
+        action supplied by the caller).  ctrl_rows=None uninstalls."""
+        if ctrl_rows is None:
+            self._ck(self._lib.t2d_set_idm(self._h, None, 0, 0, None))
+            return
+        rows = np.ascontiguousarray(ctrl_rows, np.float64)
+        if rows.ndim != 2:
+            raise ValueError("ctrl_rows must be 2-D [n_ctrl, >= 8]")
+        cid = _arr(ctrl_id, np.uint8, self.n, "ctrl_id")
+        self._ck(self._lib.t2d_set_idm(self._h, _p(rows), rows.shape[0], rows.shape[1], _p(cid)))
+
+    def idm_actions(self, forced_leader_ptr=None, stream=None):
+        """IDMController.step for every controlled participant (also runs inside step()/integrate())."""
+        self._ck(self._lib.t2d_idm_actions(self._h, forced_leader_ptr, stream))
+
     def set_integrator_variant(self, variant):
         v = {"exact": 0, "fast": 1}.get(variant, variant)
         self._ck(self._lib.t2d_set_integrator_variant(self._h, int(v)))

@@ -1,0 +1,194 @@
+"""IDM car-following controller (scope row f3): oracle vs the reference's golden vectors (CPU) and the
+HIP kernel vs the oracle (GPU), through the C ABI.
+
+Reference: controller/idm_controller.py:59-141; golden vectors tests/golden/idm.npz come from running
+the reference (oracle/gen_golden_idm.py)."""
+import math
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+def _golden():
+    return H.load_npz("idm.npz")
+
+
+def test_oracle_matches_reference_golden_vectors(oracle):
+    g = _golden()
+    assert (g["steer"] == 0.0).all()
+    worst = 0.0
+    for k in range(len(g["accel"])):
+        p = np.r_[g["params"][k], 1.875, np.inf]
+        dx, dy = g["lead"][k, 0] - g["ego"][k, 0], g["lead"][k, 1] - g["ego"][k, 1]
+        a = oracle.idm_accel(p, g["ego"][k, 2], g["has_lead"][k], dx, dy, g["lead"][k, 2], trig=0)
+        # same libm pow / hypot as CPython & numpy: identical bits expected; allow 1 ulp of slack
+        assert abs(a - g["accel"][k]) <= 4e-16 * max(1.0, abs(g["accel"][k])), (k, a, g["accel"][k])
+        d = oracle.idm_accel(p, g["ego"][k, 2], g["has_lead"][k], dx, dy, g["lead"][k, 2], trig=1)
+        worst = max(worst, abs(d - g["accel"][k]))
+    # deterministic exp/log/pow + sqrt-hypot vs libm: unclipped values reach ~3e4 * a_max before np.clip
+    assert worst <= 1e-9, worst
+
+
+def test_reference_test_suite_cases(oracle):
+    """tests/test_controllers.py:152-189 of the reference, restated on the oracle."""
+    d = np.array([10.0, 1.5, 2.0, 1.0, 3.0, 4.0, 1.875, np.inf])
+    a = oracle.idm_accel(d, 5.0, 0)
+    assert 0.0 < a <= 1.0
+    assert oracle.idm_accel(d, 10.0, 0) == 0.0
+    a = oracle.idm_accel(d, 5.0, 1, 20.0, 0.0, 6.0)
+    assert -3.0 <= a <= 1.0
+    assert oracle.idm_accel(d, 5.0, 1, 3.0, 0.0, 6.0) < 0.0
+    assert oracle.idm_accel(d, 4.0, 1, 0.0, 0.0, 1.0) == -3.0            # zero distance -> -b
+    z = d.copy(); z[0] = 0.0
+    assert oracle.idm_accel(z, 3.0, 0) == -3.0 and oracle.idm_accel(z, 0.0, 0) == 0.0
+
+
+def test_deterministic_pow_exp_log_against_libm(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(3000):
+        x = float(rng.uniform(1e-3, 30)); y = float(rng.choice([0.5, 2.5, 3.7, -1.3, 7.25, rng.uniform(-6, 6)]))
+        assert abs(oracle.det_pow(x, y) - math.pow(x, y)) <= 4e-15 * math.pow(x, y) * max(1.0, abs(y * math.log(x)))
+        assert abs(oracle.det_log(x) - math.log(x)) <= 2.3e-16 * max(abs(math.log(x)), 1e-3) + 1e-18
+        e = float(rng.uniform(-30, 30))
+        assert abs(oracle.det_exp(e) - math.exp(e)) <= 2.3e-16 * math.exp(e)
+    for n in (1, 2, 3, 4, 6, -2):
+        assert abs(oracle.det_pow(1.37, float(n)) - 1.37 ** n) <= 4e-16 * 1.37 ** n
+    assert oracle.det_pow(-2.0, 4.0) == 16.0 and oracle.det_pow(-2.0, 3.0) == -8.0
+    assert math.isnan(oracle.det_pow(-2.0, 2.5)) and oracle.det_pow(5.0, 0.0) == 1.0 and oracle.det_pow(0.0, 2.5) == 0.0
+
+
+def test_leader_rule_on_hand_built_lane(oracle):
+    from tactics2d_amd import layout as L
+    # ego at origin heading +x; candidates: behind, ahead in lane (12 m), nearer but in the next lane,
+    # ahead in lane and nearer (7 m) but inactive, ahead in lane at 30 m
+    x = np.float32([0, -5, 12, 6, 7, 30]); y = np.float32([0, 0, 0.5, 3.5, 0, -0.2])
+    h = np.zeros(6, np.float32); v = np.float32([8, 8, 6, 9, 0, 3])
+    act = np.uint8([1, 1, 1, 1, 0, 1])
+    rows = np.array([[10.0, 1.5, 2.0, 1.0, 3.0, 4.0, 1.875, np.inf]])
+    cid = np.full(6, L.IDM_NONE, np.uint8); cid[0] = 0
+    a0, a1, lead = oracle.idm(rows, cid, 1, 6, x, y, h, v, act, np.full(6, 9.0), np.full(6, 9.0))
+    assert lead[0] == 2 and (lead[1:] == -1).all()
+    assert a0[0] == np.float32(oracle.idm_accel(rows[0], 8.0, 1, 12.0, 0.5, 6.0, trig=1)) and a1[0] == 0.0
+    assert (a0[1:] == 9.0).all() and (a1[1:] == 9.0).all()                # uncontrolled actions untouched
+    rows[0, L.IDM_HORIZON] = 10.0                                         # leader beyond the horizon -> free flow
+    a0, _, lead = oracle.idm(rows, cid, 1, 6, x, y, h, v, act, np.zeros(6), np.zeros(6))
+    assert lead[0] == -1 and a0[0] == np.float32(oracle.idm_accel(rows[0], 8.0, 0, trig=1))
+    forced = np.full(6, L.IDM_LEADER_SEARCH, np.int32); forced[0] = 5     # the caller's leading_state wins
+    a0, _, lead = oracle.idm(rows, cid, 1, 6, x, y, h, v, act, np.zeros(6), np.zeros(6), forced)
+    assert lead[0] == 5
+    forced[0] = 4                                                         # inactive -> none
+    _, _, lead = oracle.idm(rows, cid, 1, 6, x, y, h, v, act, np.zeros(6), np.zeros(6), forced)
+    assert lead[0] == -1
+
+
+def test_controller_mirror_has_the_reference_interface():
+    from tactics2d_amd.controller import IDMController
+    c = IDMController()
+    assert (c.desired_speed, c.time_headway, c.min_spacing, c.max_acceleration, c.comfortable_deceleration,
+            c.delta) == (10.0, 1.5, 2.0, 1.0, 3.0, 4.0)
+    c.configure(desired_speed=12.0, max_acceleration=1.5)
+    assert c.desired_speed == 12.0 and c.max_acceleration == 1.5
+    with pytest.raises(AttributeError, match="has no parameter"):
+        c.configure(invalid_param=1.0)
+    assert list(c.row()[:6]) == [12.0, 1.5, 2.0, 1.5, 3.0, 4.0]
+
+
+# ------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_gpu_matches_reference_golden_vectors_with_forced_leader(oracle):
+    """Every golden case as a 2-participant env (ego, its leading_state) through t2d_idm_actions."""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    g = _golden()
+    n = len(g["accel"])
+    got = np.zeros(n, np.float32)
+    row = np.zeros((1, L.PARAM_COLS)); row[0, [L.P_LF, L.P_LR, L.P_WB, L.P_DELTA_T_MS, L.P_LENGTH, L.P_WIDTH]] = 1, 1, 2, 5, 4, 2
+    for c0 in range(0, n, 250):
+        sl = slice(c0, min(n, c0 + 250)); m = sl.stop - sl.start
+        pool = ParticipantPool(m, 2)
+        try:
+            pool.set_param_table(row)
+            x = np.stack([g["ego"][sl, 0], g["lead"][sl, 0]], 1).reshape(-1)
+            y = np.stack([g["ego"][sl, 1], g["lead"][sl, 1]], 1).reshape(-1)
+            v = np.stack([g["ego"][sl, 2], g["lead"][sl, 2]], 1).reshape(-1)
+            act = np.stack([np.ones(m), g["has_lead"][sl]], 1).reshape(-1).astype(np.uint8)
+            pool.reset(x, y, np.zeros(2 * m), v, np.zeros(2 * m, np.uint8), active=act)
+            rows = np.c_[g["params"][sl], np.full(m, 1.875), np.full(m, np.inf)]
+            cid = np.full(2 * m, L.IDM_NONE, np.uint8); cid[::2] = np.arange(m)
+            pool.set_idm(rows, cid)
+            forced = np.full(2 * m, L.IDM_LEADER_FREE, np.int32); forced[::2] = np.where(g["has_lead"][sl], 1, -1)
+            pool.upload(L.F_LEADER, forced)
+            pool.idm_actions(pool.field_ptr(L.F_LEADER)[0])
+            got[sl] = pool.download(L.F_ACT0)[::2]
+            assert (pool.download(L.F_ACT1)[::2] == 0.0).all()
+            assert np.array_equal(pool.download(L.F_LEADER)[::2], np.where(g["has_lead"][sl], 1, -1))
+        finally:
+            pool.close()
+    want_det = np.float32([oracle.idm_accel(np.r_[g["params"][k], 1.875, np.inf], g["ego"][k, 2], g["has_lead"][k],
+                                            g["lead"][k, 0] - g["ego"][k, 0], g["lead"][k, 1] - g["ego"][k, 1],
+                                            g["lead"][k, 2], trig=1) for k in range(n)])
+    assert np.array_equal(got.view(np.uint32), want_det.view(np.uint32))            # bit-exact vs the oracle
+    assert np.abs(got.astype(np.float64) - g["accel"]).max() <= 1e-6                # reference, after fp32 rounding
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("A", [1, 7, 64, 100])
+def test_gpu_leader_rule_and_law_match_oracle_on_random_traffic(oracle, A):
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    rng = np.random.default_rng(A)
+    n_env = 37
+    n = n_env * A
+    lane = rng.integers(0, 4, n)
+    x = np.float32(rng.uniform(-200, 200, n)); y = np.float32((lane - 1.5) * 3.75 + rng.normal(0, 0.3, n))
+    h = np.float32(np.where(rng.random(n) < 0.8, rng.normal(0, 0.03, n), rng.uniform(0, 2 * np.pi, n)))
+    v = np.float32(rng.uniform(0, 35, n)); act = (rng.random(n) < 0.9).astype(np.uint8)
+    rows = np.array([[30.0, 1.5, 2.0, 1.0, 3.0, 4.0, 1.875, np.inf], [25.0, 1.2, 3.0, 1.5, 2.0, 2.5, 1.5, 80.0],
+                     [0.0, 1.0, 2.0, 1.0, 3.0, 4.0, 2.0, 50.0]])
+    cid = rng.choice([0, 1, 2, L.IDM_NONE], n, p=[0.4, 0.3, 0.1, 0.2]).astype(np.uint8)
+    a0 = np.float32(rng.uniform(-3, 2, n)); a1 = np.float32(rng.normal(0, 0.02, n))
+    row = np.zeros((1, L.PARAM_COLS)); row[0, [L.P_LF, L.P_LR, L.P_WB, L.P_DELTA_T_MS, L.P_LENGTH, L.P_WIDTH]] = 1.2, 1.3, 2.5, 5, 4.5, 1.8
+    pool = ParticipantPool(n_env, A)
+    try:
+        pool.set_param_table(row)
+        pool.reset(x, y, h, v, np.zeros(n, np.uint8), active=act)
+        pool.set_actions(a0, a1)
+        pool.set_idm(rows, cid)
+        pool.idm_actions()
+        g0, g1, gl = pool.download(L.F_ACT0), pool.download(L.F_ACT1), pool.download(L.F_LEADER)
+        w0, w1, wl = oracle.idm(rows, cid, n_env, A, x, y, h, v, act, a0, a1)
+        assert np.array_equal(gl, wl)
+        assert np.array_equal(g0.view(np.uint32), w0.view(np.uint32)) and np.array_equal(g1.view(np.uint32), w1.view(np.uint32))
+        assert (wl >= 0).sum() > 0 or A == 1
+        # installed controllers run inside integrate(): same as oracle IDM -> oracle integrate
+        pool.set_actions(a0, a1)
+        pool.set_integrator_variant("exact")
+        pool.integrate(100)
+        st = np.stack([pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED)], 1)
+        oracle.set_trig(1)
+        try:
+            ref = oracle.integrate(row, x, y, h, v, None, None, w0, w1, np.zeros(n, np.uint8), act, 100)
+        finally:
+            oracle.set_trig(0)
+        assert np.array_equal(st, np.float32(ref[:, :4]))
+        pool.set_idm(None, None)                                     # uninstall: actions are the caller's again
+        with pytest.raises(Exception):
+            pool.idm_actions()
+    finally:
+        pool.close()
+
+
+@pytest.mark.gpu
+def test_gpu_controller_mirror_step_matches_reference_cases():
+    from tactics2d_amd.controller import IDMController
+    from tactics2d_amd.physics import BatchedState
+    c = IDMController(desired_speed=10.0)
+    ego = BatchedState(frame=0, x=[0.0, 0.0], y=[0.0, 0.0], heading=[0.0, 0.0], speed=[5.0, 10.0])
+    steer, acc = c.step(ego)
+    assert (steer == 0.0).all() and acc[0] > 0.0 and acc[1] == 0.0
+    lead = BatchedState(frame=0, x=[20.0, 3.0], y=[0.0, 0.0], heading=[0.0, 0.0], speed=[6.0, 6.0])
+    ego = BatchedState(frame=0, x=[0.0, 0.0], y=[0.0, 0.0], heading=[0.0, 0.0], speed=[5.0, 5.0])
+    steer, acc = c.step(ego, lead)
+    assert (steer == 0.0).all() and -3.0 <= acc[0] <= 1.0 and acc[1] < 0.0
