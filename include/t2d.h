@@ -326,6 +326,15 @@ int t2d_set_idm(t2d_pool* pool, const double* ctrl_rows, int32_t n_ctrl, int32_t
                 const uint8_t* ctrl_id);
 int t2d_idm_actions(t2d_pool* pool, const int32_t* forced_leader_dev, void* hip_stream);
 
+/* verify_state -- the reference's "very rough check" of a state transition (SingleTrackKinematics.verify_state
+ * physics/single_track_kinematics.py:200-250, SingleTrackDynamics.verify_state single_track_dynamics.py:253-306,
+ * PointMass.verify_state point_mass.py:234-259; called by ParticipantBase._verify_state participant_base.py:107-118).
+ * last_state = the pool's current state, candidate = four device arrays [n_env * max_agents] (x, y, heading, speed);
+ * valid_dev[i] = 1 where the reference returns True (also for inactive participants and interval_ms = 0).
+ * Quirks kept: any unbounded range -> True; x / y are tested with strict inequalities against an unsorted range. */
+int t2d_verify_state(t2d_pool* pool, const float* x_dev, const float* y_dev, const float* heading_dev,
+                     const float* speed_dev, int32_t interval_ms, uint8_t* valid_dev, void* hip_stream);
+
 /* Kernel variants: 0 = exact (library-grade fp64 trig every sub-step), 1 = fast
  * (rotation recurrence, default).  Both satisfy the 1e-5 contract; see DESIGN.md.       */
 int t2d_set_integrator_variant(t2d_pool* pool, int32_t variant);

@@ -321,6 +321,25 @@ def idm(ctrl_rows, ctrl_id, n_env, A, x, y, heading, speed, active, act0, act1, 
     return a0, a1, lead
 
 
+def verify_state(rows, type_id, last, cand, interval_ms, trig=0):
+    """Batched verify_state: last (n, 6) = x, y, heading, speed, vx, vy; cand (n, 4) = x, y, heading, speed
+    (both rounded to fp32, as the pool stores them).  Returns bool[n]."""
+    rows = np.ascontiguousarray(rows, np.float64)
+    n = len(type_id)
+    lc = [np.ascontiguousarray(np.asarray(last)[:, k], np.float32) for k in range(6)]
+    cc = [np.ascontiguousarray(np.asarray(cand)[:, k], np.float32) for k in range(4)]
+    out = np.zeros(n, np.uint8)
+    f = lib().t2do_verify_batch
+    f.restype = None
+    f.argtypes = [_f64p, C.c_int, C.c_int, _u8p] + [_f32p] * 10 + [C.c_int, _u8p]
+    lib().t2do_set_trig(trig)
+    try:
+        f(rows, rows.shape[1], n, np.ascontiguousarray(type_id, np.uint8), *lc, *cc, int(interval_ms), out)
+    finally:
+        lib().t2do_set_trig(0)
+    return out.astype(bool)
+
+
 def beam_tables(n_beams):
     th = np.linspace(0, 2 * np.pi, n_beams, endpoint=False)
     return np.ascontiguousarray(np.sin(th)), np.ascontiguousarray(np.cos(th))

@@ -1030,4 +1030,59 @@ void t2do_idm(const double* ctrl_rows, int row_stride, int n_ctrl, const uint8_t
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * verify_state: "very rough check" of a candidate state against the last one.
+ *   SingleTrackKinematics.verify_state  physics/single_track_kinematics.py:200-250
+ *   SingleTrackDynamics.verify_state    physics/single_track_dynamics.py:253-306 (same check)
+ *   PointMass.verify_state              physics/point_mass.py:234-259
+ * Quirks kept: any unbounded range -> True; x/y use STRICT inequalities against a range whose ends
+ * are not sorted (cos < 0 makes it empty); the heading window wraps.
+ * ---------------------------------------------------------------------------------------- */
+int t2do_verify_state(const double* p, double lx, double ly, double lh, double lv, double lvx, double lvy,
+                      double x, double y, double h, double v, int interval_ms) {
+    if (interval_ms == 0) return 1;
+    const int model = (int)p[T2D_P_MODEL];
+    const int flags = (int)p[T2D_P_RANGE_FLAGS];
+    if (model == T2D_MODEL_POINTMASS) { /* point_mass.py:249-259 */
+        const double dt = (double)interval_ms / 1000;
+        const double den = 2 / (dt * dt);
+        const double ax = (x - lx - lvx * dt) * den;
+        const double ay = (y - ly - lvy * dt) * den;
+        if (flags & T2D_RANGE_ACCEL) {
+            const double a = sqrt(ax * ax + ay * ay);
+            if (!(p[T2D_P_ACCEL_LO] <= a && a <= p[T2D_P_ACCEL_HI])) return 0;
+        }
+        return 1;
+    }
+    const double dt = (double)interval_ms / 1000;
+    if ((flags & 7) != 7) return 1; /* None in [steer_range, speed_range, accel_range] */
+    const double wb = p[T2D_P_WB], k = p[T2D_P_LR] / wb;
+    const double st[2] = {p[T2D_P_STEER_LO], p[T2D_P_STEER_HI]};
+    const double ac[2] = {p[T2D_P_ACCEL_LO], p[T2D_P_ACCEL_HI]};
+    double beta[2], hr[2], sr[2], xr[2], yr[2];
+    for (int i = 0; i < 2; ++i) {
+        beta[i] = T_atan(k * st[i]);
+        hr[i] = np_mod(lh + lv / wb * T_sin(beta[i]) * dt, TWO_PI);
+        sr[i] = clip(lv + ac[i] * dt, p[T2D_P_SPEED_LO], p[T2D_P_SPEED_HI]);
+        xr[i] = lx + sr[i] * T_cos(lh + beta[i]) * dt;
+        yr[i] = ly + sr[i] * T_sin(lh + beta[i]) * dt;
+    }
+    if (hr[0] < hr[1] && !(hr[0] <= h && h <= hr[1])) return 0;
+    if (hr[0] > hr[1] && !(hr[0] <= h || h <= hr[1])) return 0;
+    if (!(sr[0] <= v && v <= sr[1])) return 0;
+    if (!(xr[0] < x && x < xr[1]) || !(yr[0] < y && y < yr[1])) return 0;
+    return 1;
+}
+
+/* batched: last state = (lx, ly, lh, lv, lvx, lvy)[n] fp32 as stored in the pool, candidate = (x, y, h, v)[n] */
+void t2do_verify_batch(const double* rows, int row_stride, int n, const uint8_t* type_id, const float* lx,
+                       const float* ly, const float* lh, const float* lv, const float* lvx, const float* lvy,
+                       const float* x, const float* y, const float* h, const float* v, int interval_ms,
+                       uint8_t* valid) {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+    for (int i = 0; i < n; ++i)
+        valid[i] = (uint8_t)t2do_verify_state(rows + (size_t)type_id[i] * row_stride, lx[i], ly[i], lh[i], lv[i],
+                                              lvx[i], lvy[i], x[i], y[i], h[i], v[i], interval_ms);
+}
+
 int t2do_abi_version(void) { return T2D_ABI_VERSION; }

@@ -941,6 +941,19 @@ int t2d_idm_actions(t2d_pool* p, const int32_t* forced_leader_dev, void* hip_str
     return idm_impl(p, (hipStream_t)hip_stream, forced_leader_dev);
 }
 
+int t2d_verify_state(t2d_pool* p, const float* x_dev, const float* y_dev, const float* heading_dev,
+                     const float* speed_dev, int32_t interval_ms, uint8_t* valid_dev, void* hip_stream) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!p->have_params || !p->have_reset)
+        return fail(p, T2D_ERR_STATE, "t2d_set_param_table and t2d_reset must precede t2d_verify_state");
+    if (!x_dev || !y_dev || !heading_dev || !speed_dev || !valid_dev)
+        return fail(p, T2D_ERR_INVALID, "t2d_verify_state: null device array");
+    if (interval_ms < 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be >= 0");
+    T2D_HIP(p, t2d::launch_verify(p->v, x_dev, y_dev, heading_dev, speed_dev, interval_ms, valid_dev,
+                                  (hipStream_t)hip_stream));
+    return T2D_OK;
+}
+
 int t2d_set_integrator_variant(t2d_pool* p, int32_t variant) {
     if (!p) return T2D_ERR_INVALID;
     if (variant != 0 && variant != 1) return fail(p, T2D_ERR_INVALID, "variant must be 0 (exact) or 1 (fast)");

@@ -88,7 +88,72 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(PoolView pv, int inte
     pv.applied1[i] = (float)o.app1;
 }
 
+// verify_state: the "very rough check" of a candidate state against the pool's current (= last) state.
+//   SingleTrackKinematics.verify_state physics/single_track_kinematics.py:200-250, SingleTrackDynamics
+//   :253-306 (same check), PointMass.verify_state physics/point_mass.py:234-259.  Oracle: t2do_verify_state.
+struct VerifyArgs {
+    const float *x, *y, *heading, *speed;  // candidate state [N], device
+    uint8_t* valid;                        // out [N]: 1 = plausible (inactive participants: 1)
+    int interval_ms;
+};
+
+__global__ __launch_bounds__(kBlock) void verify_kernel(PoolView pv, VerifyArgs a) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= pv.N) return;
+    const uint32_t ids = pv.ids[i];
+    uint8_t ok = 1;
+    if (((ids >> kIdsActiveShift) & 0xffu) && a.interval_ms != 0) {
+        const int type = (ids >> kIdsTypeShift) & 0xff;
+        const int model = (ids >> kIdsModelShift) & 0xff;
+        auto P = [&](int col) -> double { return pv.params[col * T2D_MAX_TYPES + type]; };
+        const int flags = (int)P(T2D_P_RANGE_FLAGS);
+        const double dt = (double)a.interval_ms / 1000;
+        const double lx = (double)pv.x[i], ly = (double)pv.y[i];
+        const double x = (double)a.x[i], y = (double)a.y[i];
+        if (model == T2D_MODEL_POINTMASS) {
+            const double den = 2 / (dt * dt);
+            const double ax = (x - lx - (double)pv.vx[i] * dt) * den;
+            const double ay = (y - ly - (double)pv.vy[i] * dt) * den;
+            if (flags & T2D_RANGE_ACCEL) {
+                const double acc = __builtin_sqrt(ax * ax + ay * ay);
+                if (!(P(T2D_P_ACCEL_LO) <= acc && acc <= P(T2D_P_ACCEL_HI))) ok = 0;
+            }
+        } else if ((flags & 7) == 7) {
+            const double lh = (double)pv.heading[i], lv = (double)pv.speed[i];
+            const double h = (double)a.heading[i], v = (double)a.speed[i];
+            const double wb = P(T2D_P_WB), k = P(T2D_P_LR) / wb;
+            const double st[2] = {P(T2D_P_STEER_LO), P(T2D_P_STEER_HI)};
+            const double ac[2] = {P(T2D_P_ACCEL_LO), P(T2D_P_ACCEL_HI)};
+            const double vlo = P(T2D_P_SPEED_LO), vhi = P(T2D_P_SPEED_HI);
+            double hr[2], sr[2], xr[2], yr[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const double beta = atan_det(k * st[e]);
+                double sb, cb, sh, ch;
+                sincos_det(beta, sb, cb);
+                hr[e] = mod_two_pi(lh + lv / wb * sb * dt);
+                sr[e] = clipd(lv + ac[e] * dt, vlo, vhi);
+                sincos_det(lh + beta, sh, ch);
+                xr[e] = lx + sr[e] * ch * dt;
+                yr[e] = ly + sr[e] * sh * dt;
+            }
+            if (hr[0] < hr[1] && !(hr[0] <= h && h <= hr[1])) ok = 0;
+            if (hr[0] > hr[1] && !(hr[0] <= h || h <= hr[1])) ok = 0;
+            if (!(sr[0] <= v && v <= sr[1])) ok = 0;
+            if (!(xr[0] < x && x < xr[1]) || !(yr[0] < y && y < yr[1])) ok = 0;
+        }
+    }
+    a.valid[i] = ok;
+}
+
 }  // namespace
+
+hipError_t launch_verify(const PoolView& v, const float* x, const float* y, const float* heading, const float* speed,
+                         int interval_ms, uint8_t* valid, hipStream_t s) {
+    VerifyArgs a{x, y, heading, speed, valid, interval_ms};
+    hipLaunchKernelGGL(verify_kernel, dim3((v.N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, v, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hipStream_t s) {
     const int grid = (v.N + kBlock - 1) / kBlock;

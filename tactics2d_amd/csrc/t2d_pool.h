@@ -154,6 +154,8 @@ hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hip
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
                           int interval_ms, int fuse_variant, hipStream_t s);
 hipError_t launch_lidar(const PoolView& v, const LidarView& lv, float* out, hipStream_t s);
+hipError_t launch_verify(const PoolView& v, const float* x, const float* y, const float* heading, const float* speed,
+                         int interval_ms, uint8_t* valid, hipStream_t s);
 hipError_t launch_idm(const PoolView& v, const IdmView& iv, const int32_t* forced_leader, hipStream_t s);
 hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
                           hipStream_t s);

@@ -113,6 +113,20 @@ class _BatchedModel:
     def param_row(self, shape=L.SHAPE_OBB, length=0.0, width=0.0):
         raise NotImplementedError
 
+    def verify_state(self, state, last_state, interval=None):
+        """Batched `verify_state(state, last_state, interval)` -> bool[n] (single_track_kinematics.py:200-250,
+        single_track_dynamics.py:253-306, point_mass.py:234-259), evaluated on the device."""
+        interval = state.frame - last_state.frame if interval is None else interval
+        n = len(state)
+        pool = self._pool(n)
+        z = np.zeros(n, np.float32)
+        if self.model_id == L.MODEL_POINTMASS:
+            vx, vy = last_state.velocity
+            pool.reset(last_state.x, last_state.y, z, z, np.zeros(n, np.uint8), vx=vx, vy=vy)
+            return pool.verify_state(state.x, state.y, z, z, interval)
+        pool.reset(last_state.x, last_state.y, last_state.heading, last_state.speed, np.zeros(n, np.uint8))
+        return pool.verify_state(state.x, state.y, state.heading, state.speed, interval)
+
     def close(self):
         pool = getattr(self, "_cached_pool", None)
         if pool is not None:

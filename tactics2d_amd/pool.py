@@ -134,6 +134,26 @@ class ParticipantPool:
         """IDMController.step for every controlled participant (also runs inside step()/integrate())."""
         self._ck(self._lib.t2d_idm_actions(self._h, forced_leader_ptr, stream))
 
+    def verify_state_ptr(self, x_ptr, y_ptr, heading_ptr, speed_ptr, interval_ms, valid_ptr, stream=None):
+        """verify_state of device-resident candidate columns against the pool's current state."""
+        self._ck(self._lib.t2d_verify_state(self._h, x_ptr, y_ptr, heading_ptr, speed_ptr, int(interval_ms),
+                                            valid_ptr, stream))
+
+    def verify_state(self, x, y, heading, speed, interval_ms):
+        """Host-array convenience: candidate columns are staged in this pool's action / applied-action
+        fields (scratch here: the next integrate overwrites them anyway) and the verdict bytes in FLAGS."""
+        n = self.n
+        saved = [self.download(f) for f in (L.F_ACT0, L.F_ACT1, L.F_APPLIED0, L.F_APPLIED1, L.F_FLAGS)]
+        for f, v in zip((L.F_ACT0, L.F_ACT1, L.F_APPLIED0, L.F_APPLIED1), (x, y, heading, speed)):
+            self.upload(f, _arr(v, np.float32, n, "candidate"))
+        ptr = lambda f: self.field_ptr(f)[0]
+        self.verify_state_ptr(ptr(L.F_ACT0), ptr(L.F_ACT1), ptr(L.F_APPLIED0), ptr(L.F_APPLIED1), interval_ms,
+                              ptr(L.F_FLAGS))
+        out = self.download(L.F_FLAGS).view(np.uint8)[:n].astype(bool)
+        for f, v in zip((L.F_ACT0, L.F_ACT1, L.F_APPLIED0, L.F_APPLIED1, L.F_FLAGS), saved):
+            self.upload(f, v)
+        return out
+
     def set_integrator_variant(self, variant):
         v = {"exact": 0, "fast": 1}.get(variant, variant)
         self._ck(self._lib.t2d_set_integrator_variant(self._h, int(v)))
