@@ -70,6 +70,8 @@ extern "C" {
 #define T2D_MODEL_KINEMATICS 0   /* SingleTrackKinematics */
 #define T2D_MODEL_DYNAMICS   1   /* SingleTrackDynamics   */
 #define T2D_MODEL_POINTMASS  2   /* PointMass, newton back-end */
+#define T2D_MODEL_DRIFT      3   /* SingleTrackDrift (Pacejka tyres, default Tire constants); extra state
+                                  * T2D_F_OMEGA_F / T2D_F_OMEGA_R; integrated by its own kernel */
 
 /* ---- shape kinds (column T2D_P_SHAPE) ---------------------------------------------- */
 #define T2D_SHAPE_OBB    0   /* Vehicle / Cyclist / Other: length x width box             */
@@ -103,7 +105,12 @@ enum {
     T2D_P_RESERVED0 = 21,
     T2D_P_RESERVED1 = 22,
     T2D_P_RESERVED2 = 23,
-    T2D_PARAM_COLS = 24
+    T2D_PARAM_COLS = 24,
+    /* T2D_MODEL_DRIFT rows reuse four columns the other models leave alone: */
+    T2D_P_DRIFT_TSB = 15,    /* T_sb, brake-torque split   (single_track_drift.py:102) */
+    T2D_P_DRIFT_TSE = 16,    /* T_se, engine-torque split  (:103)                      */
+    T2D_P_DRIFT_RADIUS = 22, /* effective wheel radius (m) (:101)                      */
+    T2D_P_DRIFT_IYW = 23     /* wheel inertia I_yw         (:106)                      */
 };
 #define T2D_RANGE_STEER 1
 #define T2D_RANGE_SPEED 2
@@ -140,7 +147,9 @@ enum {
                               t2d_lidar_config; +inf = no return)                                 */
     T2D_F_LEADER = 21,     /* i32[N]  agent index (inside the env) of the IDM leader chosen by the last
                             *         t2d_idm_actions, -1 = none / participant not IDM-controlled   */
-    T2D_F_COUNT = 22
+    T2D_F_OMEGA_F = 22,    /* f32[N]  SingleTrackDrift front wheel angular speed (rad/s); 0 after t2d_reset */
+    T2D_F_OMEGA_R = 23,    /* f32[N]  rear wheel                                                        */
+    T2D_F_COUNT = 24
 };
 
 /* ---- per-participant / per-env event bits ------------------------------------------- */
@@ -340,7 +349,7 @@ int t2d_verify_state(t2d_pool* pool, const float* x_dev, const float* y_dev, con
 int t2d_set_integrator_variant(t2d_pool* pool, int32_t variant);
 
 /* Per-kernel timing with HIP events recorded on the launch stream around each kernel.
- * kernel_id: 0 = integrate, 1 = collide(+status), 2 = fused step, 3 = lidar, 4 = idm.                                    */
+ * kernel_id: 0 = integrate, 1 = collide(+status), 2 = fused step, 3 = lidar, 4 = idm, 5 = drift.                                    */
 int t2d_profile_enable(t2d_pool* pool, int32_t on);
 int t2d_profile_read(t2d_pool* pool, int32_t kernel_id, double* total_ms, int64_t* launches);
 

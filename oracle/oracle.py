@@ -340,6 +340,27 @@ def verify_state(rows, type_id, last, cand, interval_ms, trig=0):
     return out.astype(bool)
 
 
+def drift(rows, type_id, state, action, interval_ms, active=None, trig=0):
+    """Batched SingleTrackDrift.step: state (n, 6) = x, y, heading, speed, omega_wf, omega_wr (fp32-rounded),
+    action (n, 2).  Returns fp64 (n, 8): x, y, heading, speed, omega_wf, omega_wr, applied accel, applied steer."""
+    rows = np.ascontiguousarray(rows, np.float64)
+    n = len(type_id)
+    st = [np.ascontiguousarray(np.asarray(state)[:, k], np.float32) for k in range(6)]
+    ac = [np.ascontiguousarray(np.asarray(action)[:, k], np.float32) for k in range(2)]
+    out = np.zeros((n, 8))
+    f = lib().t2do_drift_batch
+    f.restype = None
+    f.argtypes = [_f64p, C.c_int, C.c_int] + [_f32p] * 8 + [_u8p, C.c_void_p, C.c_int, _f64p]
+    act = None if active is None else np.ascontiguousarray(active, np.uint8)
+    lib().t2do_set_trig(trig)
+    try:
+        f(rows, rows.shape[1], n, *st, *ac, np.ascontiguousarray(type_id, np.uint8),
+          None if act is None else act.ctypes.data_as(C.c_void_p), int(interval_ms), out.reshape(-1))
+    finally:
+        lib().t2do_set_trig(0)
+    return out
+
+
 def beam_tables(n_beams):
     th = np.linspace(0, 2 * np.pi, n_beams, endpoint=False)
     return np.ascontiguousarray(np.sin(th)), np.ascontiguousarray(np.cos(th))

@@ -1085,4 +1085,143 @@ void t2do_verify_batch(const double* rows, int row_stride, int n, const uint8_t*
                                               lvx[i], lvy[i], x[i], y[i], h[i], v[i], interval_ms);
 }
 
+/* ------------------------------------------------------------------------------------------
+ * SingleTrackDrift (scope row f4): dynamic single-track model with Pacejka tyres.
+ *   Tire constants                      physics/single_track_drift.py:16-49
+ *   _pure_slip_longitudinal_tire_forces :183-201      _pure_slip_lateral_tire_forces :203-222
+ *   _combined_slip_longitudinal_...     :224-250      _combined_slip_lateral_...     :252-289
+ *   _tire_forces                        :291-344      _step :346-465      step :467-503
+ * gamma (camber) is the literal 0 at every call site (:326-339), which the restatement folds:
+ * mu_x = p_dx1, mu_y = p_dy1, S_hy = S_vy = 0, r_vy3 * gamma = 0.  Values that the reference
+ * evaluates several times from the same argument (sin(beta), B*kappa_x ...) are computed once.
+ * Quirks kept: d_phi / beta re-initialised per call (:364-365); the remainder sub-step IS
+ * integrated (:356-359, unlike SingleTrackDynamics); dd_phi of the low-speed branch is dead.
+ * ---------------------------------------------------------------------------------------- */
+static const double TP_cx1 = 1.6411, TP_dx1 = 1.1739, TP_ex1 = 0.4640, TP_kx1 = 22.303, TP_hx1 = 1.2297e-3,
+                    TP_vx1 = -8.8098e-6, TR_bx1 = 13.276, TR_bx2 = -13.778, TR_ex1 = 1.2568, TR_cx1 = 0.6522,
+                    TR_hx1 = 5.0722e-3, TP_cy1 = 1.3507, TP_dy1 = 1.0489, TP_ey1 = -7.4722e-3, TP_ky1 = -21.920,
+                    TR_by1 = 7.1433, TR_by2 = 9.1917, TR_by3 = -2.7856e-2, TR_cy1 = 1.0719, TR_ey1 = -0.2757,
+                    TR_hy1 = 5.7448e-6, TR_vy1 = -2.7825e-2, TR_vy4 = 12.120, TR_vy5 = 1.9, TR_vy6 = -10.704;
+
+static double safe_den(double u) { return fabs(u) > 1e-6 ? u : (u >= 0 ? 1e-6 : -1e-6); }
+
+/* D * sin|cos( C * atan(B*s - E*(B*s - atan(B*s))) ): the magic-formula core shared by all four */
+static double mf_angle(double B, double C, double E, double s) {
+    const double bs = B * s;
+    return C * T_atan(bs - E * (bs - T_atan(bs)));
+}
+
+static double pure_long(double kappa, double F_z) { /* :183-201, gamma = 0 */
+    const double S_vx = TP_vx1 * F_z;
+    const double kappa_x = -kappa + TP_hx1;
+    const double D_x = TP_dx1 * F_z;
+    const double B_x = (TP_kx1 * F_z) / (TP_cx1 * D_x + 1e-6);
+    return D_x * T_sin(mf_angle(B_x, TP_cx1, TP_ex1, kappa_x) + S_vx);
+}
+
+static double pure_lat(double alpha, double F_z) { /* :203-222, gamma = 0: S_hy = S_vy = 0, mu_y = p_dy1 */
+    const double alpha_y = alpha + 0.0;
+    const double D_y = TP_dy1 * F_z;
+    const double B_y = (TP_ky1 * F_z) / (TP_cy1 * D_y + 1e-6);
+    return D_y * T_sin(mf_angle(B_y, TP_cy1, TP_ey1, alpha_y) + 0.0);
+}
+
+static double comb_long(double kappa, double alpha, double F0_x) { /* :224-250 */
+    const double alpha_s = alpha + TR_hx1;
+    const double B = TR_bx1 * T_cos(T_atan(TR_bx2 * kappa));
+    const double D = F0_x / T_cos(mf_angle(B, TR_cx1, TR_ex1, TR_hx1));
+    return D * T_cos(mf_angle(B, TR_cx1, TR_ex1, alpha_s));
+}
+
+static double comb_lat(double kappa, double alpha, double F_z, double F0_y) { /* :252-289, gamma = 0 */
+    const double kappa_s = kappa + TR_hy1;
+    const double B = TR_by1 * T_cos(T_atan(TR_by2 * (alpha - TR_by3)));
+    const double D = F0_y / T_cos(mf_angle(B, TR_cy1, TR_ey1, TR_hy1));
+    const double D_vy = TP_dy1 * F_z * TR_vy1 * T_cos(T_atan(TR_vy4 * alpha));
+    const double S_vy = D_vy * T_sin(TR_vy5 * T_atan(TR_vy6 * kappa));
+    return D * T_cos(mf_angle(B, TR_cy1, TR_ey1, kappa_s)) + S_vy;
+}
+
+/* out[8] = x, y, heading, speed, omega_wf, omega_wr, applied accel, applied steer */
+void t2do_drift(const double* p, double x, double y, double phi, double v, double omega_wf, double omega_wr,
+                double accel, double delta, int interval_ms, double* out) {
+    const int flags = (int)p[T2D_P_RANGE_FLAGS];
+    if (flags & T2D_RANGE_ACCEL) accel = clip(accel, p[T2D_P_ACCEL_LO], p[T2D_P_ACCEL_HI]); /* :495 */
+    if (flags & T2D_RANGE_STEER) delta = clip(delta, p[T2D_P_STEER_LO], p[T2D_P_STEER_HI]); /* :496 */
+    const double lf = p[T2D_P_LF], lr = p[T2D_P_LR], wb = p[T2D_P_WB], mass = p[T2D_P_MASS], Iz = p[T2D_P_IZ];
+    const double radius = p[T2D_P_DRIFT_RADIUS], Tsb = p[T2D_P_DRIFT_TSB], Tse = p[T2D_P_DRIFT_TSE],
+                 Iyw = p[T2D_P_DRIFT_IYW];
+    const int delta_t = (int)p[T2D_P_DELTA_T_MS];
+    const int n_steps = interval_ms / delta_t, rem = interval_ms % delta_t;
+    const double tan_d = T_tan(delta), sin_d = T_sin(delta), cos_d = T_cos(delta);
+    double d_phi = v / wb * tan_d;              /* :364 */
+    double beta = T_atan(lr / lf * tan_d);      /* :365 */
+    double T_B, T_E;
+    if (accel > 0) { T_B = 0; T_E = mass * radius * accel; } else { T_B = mass * radius * accel; T_E = 0; }
+    const double F_zf = (mass * 9.81 * lr) / wb, F_zr = (mass * 9.81 * lf) / wb; /* :308-309 */
+    for (int k = 0; k < n_steps + (rem > 0 ? 1 : 0); ++k) {
+        const double dt = k < n_steps ? (double)delta_t / 1000 : (double)rem / 1000;
+        const double v_safe = safe_den(v); /* :376; _tire_forces applies the same guard again: idempotent */
+        const double sin_b = T_sin(beta), cos_b = T_cos(beta);
+        /* ---- _tire_forces :291-344 ---- */
+        const double cos_b_safe = safe_den(cos_b);
+        const double alpha_f = T_atan((v_safe * sin_b + d_phi * lf) / (v_safe * cos_b_safe)) - delta;
+        const double alpha_r = T_atan((v_safe * sin_b - d_phi * lr) / (v_safe * cos_b_safe));
+        const double u_wf = v_safe * cos_b_safe * cos_d + (v_safe * sin_b + lf * d_phi) * sin_d;
+        const double u_wr = v_safe * cos_b_safe;
+        const double s_f = 1 - radius * omega_wf / safe_den(u_wf);
+        const double s_r = 1 - radius * omega_wr / safe_den(u_wr);
+        const double F0_xf = pure_long(s_f, F_zf), F0_xr = pure_long(s_r, F_zr);
+        const double F0_yf = pure_lat(alpha_f, F_zf), F0_yr = pure_lat(alpha_r, F_zr);
+        const double F_lf = comb_long(s_f, alpha_f, F0_xf), F_lr = comb_long(s_r, alpha_r, F0_xr);
+        const double F_sf = comb_lat(s_f, alpha_f, F_zf, F0_yf), F_sr = comb_lat(s_r, alpha_r, F_zr, F0_yr);
+        /* ---- _step body ---- */
+        const double dx = v * T_cos(phi + beta), dy = v * T_sin(phi + beta);
+        double dv, d_beta, d_owf, d_owr;
+        if (fabs(v) >= 0.1) { /* :384-419 */
+            const double sdb = T_sin(delta - beta), cdb = T_cos(delta - beta);
+            dv = 1 / mass * (-F_sf * sdb + F_sr * sin_b + F_lr * cos_b + F_lf * cdb);
+            d_beta = -d_phi + 1 / (mass * v_safe) * (F_sf * cdb + F_sr * cos_b - F_lr * sin_b + F_lf * sdb);
+            const double dd_phi = 1 / Iz * (F_sf * cos_d * lf - F_sr * lr + F_lf * sin_d * lf);
+            d_phi += dd_phi * dt;
+            d_owf = 1 / Iyw * (-radius * F_lf + Tsb * T_B + Tse * T_E);
+            d_owr = 1 / Iyw * (-radius * F_lr + (1 - Tsb) * T_B + (1 - Tse) * T_E);
+        } else { /* :420-451 */
+            const double tb = 1 + tan_d * lr / wb;
+            dv = accel;
+            d_beta = lr / (tb * tb) / wb / (cos_d * cos_d) * delta;
+            d_phi += v * cos_b / wb * tan_d * dt;
+            d_owf = 1 / (cos_d * radius) * (accel * cos_b - v * sin_b * d_beta + v * cos_b * tan_d * delta);
+            d_owr = 1 / radius * (accel * cos_b - v * sin_b * d_beta);
+        }
+        x += dx * dt;
+        y += dy * dt;
+        v += dv * dt;
+        phi += d_phi * dt;
+        beta += d_beta * dt;
+        omega_wf += d_owf * dt;
+        omega_wr += d_owr * dt;
+        if (flags & T2D_RANGE_SPEED) v = clip(v, p[T2D_P_SPEED_LO], p[T2D_P_SPEED_HI]); /* :461 */
+    }
+    out[0] = x; out[1] = y; out[2] = np_mod(phi, TWO_PI); out[3] = v;
+    out[4] = omega_wf; out[5] = omega_wr; out[6] = accel; out[7] = delta;
+}
+
+/* batched over the T2D_MODEL_DRIFT participants (others: state passed through, omegas untouched) */
+void t2do_drift_batch(const double* rows, int row_stride, int n, const float* x, const float* y, const float* heading,
+                      const float* speed, const float* omega_f, const float* omega_r, const float* act0,
+                      const float* act1, const uint8_t* type_id, const uint8_t* active, int interval_ms, double* out) {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+    for (int i = 0; i < n; ++i) {
+        double* o = out + 8 * (size_t)i;
+        const double* p = rows + (size_t)type_id[i] * row_stride;
+        if ((active && !active[i]) || (int)p[T2D_P_MODEL] != T2D_MODEL_DRIFT) {
+            o[0] = x[i]; o[1] = y[i]; o[2] = heading[i]; o[3] = speed[i];
+            o[4] = omega_f[i]; o[5] = omega_r[i]; o[6] = 0.0; o[7] = 0.0;
+            continue;
+        }
+        t2do_drift(p, x[i], y[i], heading[i], speed[i], omega_f[i], omega_r[i], act0[i], act1[i], interval_ms, o);
+    }
+}
+
 int t2do_abi_version(void) { return T2D_ABI_VERSION; }

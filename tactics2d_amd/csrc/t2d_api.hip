@@ -34,7 +34,7 @@ size_t field_elem_bytes(int f) {
         default: return 4;
     }
 }
-bool field_per_env(int f) { return f >= T2D_F_ENV_FLAGS && f != T2D_F_LEADER; }
+bool field_per_env(int f) { return f >= T2D_F_ENV_FLAGS && f < T2D_F_LEADER; }
 
 template <class T>
 int dev_replace(t2d_pool* p, T** dst, const T* src, size_t n) {
@@ -296,6 +296,10 @@ __global__ __launch_bounds__(256) void restore_kernel(PoolView pv, SnapPtrs sp, 
     pv.speed[i] = sp.f[3][i]; pv.vx[i] = sp.f[4][i]; pv.vy[i] = sp.f[5][i];
     pv.ids[i] = sp.ids[i];
     pv.flags[i] = 0;
+    if (pv.snap_omega[0]) {
+        pv.omega_f[i] = pv.snap_omega[0][i];
+        pv.omega_r[i] = pv.snap_omega[1][i];
+    }
     // the env record (status, counters) is cleared by restore_env_kernel, launched after this
     // kernel on the same stream, so every participant has read `status` before it changes
 }
@@ -398,6 +402,8 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
     v.act1 = (float*)p->field_ptr[T2D_F_ACT1];
     v.applied0 = (float*)p->field_ptr[T2D_F_APPLIED0];
     v.applied1 = (float*)p->field_ptr[T2D_F_APPLIED1];
+    v.omega_f = (float*)p->field_ptr[T2D_F_OMEGA_F];
+    v.omega_r = (float*)p->field_ptr[T2D_F_OMEGA_R];
     v.ids = (uint32_t*)p->field_ptr[T2D_F_IDS];
     v.flags = (uint32_t*)p->field_ptr[T2D_F_FLAGS];
     v.env_flags = (uint32_t*)p->field_ptr[T2D_F_ENV_FLAGS];
@@ -445,7 +451,7 @@ int t2d_destroy(t2d_pool* p) {
                     p->d_last_pose, p->d_max_iou, p->d_min_dist, p->d_snap_min_dist, p->d_last_valid,
                     p->d_lidar_env_off, p->d_lidar_next, p->d_lidar_xy, p->d_beam_sin, p->d_beam_cos,
                     p->d_snap[0], p->d_snap[1], p->d_snap[2],
-                    p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_idm_rows, p->d_idm_ctrl};
+                    p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_idm_rows, p->d_idm_ctrl, p->d_snap_omega[0], p->d_snap_omega[1]};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->prof_events) {
@@ -463,11 +469,19 @@ int t2d_set_param_table(t2d_pool* p, const double* rows, int32_t n_types, int32_
     T2D_HIP(p, hipSetDevice(p->device));
     std::vector<double> t(T2D_PARAM_COLS * T2D_MAX_TYPES, 0.0);
     double dmax = 0.0;
+    bool has_drift = false;
     for (int ty = 0; ty < n_types; ++ty) {
         const double* r = rows + (size_t)ty * row_stride;
         const int model = (int)r[T2D_P_MODEL];
-        if (model < 0 || model > T2D_MODEL_POINTMASS)
+        if (model < 0 || model > T2D_MODEL_DRIFT)
             return fail(p, T2D_ERR_INVALID, "row " + std::to_string(ty) + ": unknown model id");
+        if (model == T2D_MODEL_DRIFT) {
+            has_drift = true;
+            if (!(r[T2D_P_MASS] > 0.0) || !(r[T2D_P_IZ] > 0.0) || !(r[T2D_P_DRIFT_RADIUS] > 0.0) ||
+                !(r[T2D_P_DRIFT_IYW] > 0.0) || !(r[T2D_P_LF] != 0.0))
+                return fail(p, T2D_ERR_INVALID, "row " + std::to_string(ty) +
+                                                    ": SingleTrackDrift needs mass, I_z, radius, I_yw > 0 and lf != 0");
+        }
         const int dt = (int)r[T2D_P_DELTA_T_MS];
         if (dt < 1) return fail(p, T2D_ERR_INVALID, "row " + std::to_string(ty) + ": delta_t must be >= 1 ms");
         if (model != T2D_MODEL_POINTMASS && !(r[T2D_P_WB] != 0.0))
@@ -482,6 +496,7 @@ int t2d_set_param_table(t2d_pool* p, const double* rows, int32_t n_types, int32_
         dmax = std::max(dmax, 2.0 * br);
     }
     p->v.n_types = n_types;
+    p->has_drift = has_drift;
     p->v.cell = dmax * 1.001 + 1e-3;  // 3x3 cell neighbourhood is then provably sufficient
     p->v.inv_cell = 1.0 / p->v.cell;
     T2D_HIP(p, hipMemcpy(p->d_params, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
@@ -674,6 +689,17 @@ int t2d_reset(t2d_pool* p, const uint8_t* env_mask, const float* x, const float*
     T2D_HIP(p, hipMemcpy(p->v.frame_ms, hframe.data(), 4 * (size_t)E, hipMemcpyHostToDevice));
     T2D_HIP(p, hipMemcpy(p->v.status, hstat.data(), 4 * (size_t)E, hipMemcpyHostToDevice));
     T2D_HIP(p, hipMemcpy(p->v.reward, hrew.data(), 4 * (size_t)E, hipMemcpyHostToDevice));
+    {  // SingleTrackDrift wheel speeds start at rest (the reference's callers pass omega = 0 for a new episode)
+        std::vector<float> ho(N, 0.0f);
+        for (int f : {T2D_F_OMEGA_F, T2D_F_OMEGA_R}) {
+            if (partial) {
+                T2D_HIP(p, hipMemcpy(ho.data(), p->field_ptr[f], 4 * (size_t)N, hipMemcpyDeviceToHost));
+                for (int e = 0; e < E; ++e)
+                    if (env_mask[e]) std::fill(ho.begin() + (size_t)e * A, ho.begin() + (size_t)(e + 1) * A, 0.0f);
+            }
+            T2D_HIP(p, hipMemcpy(p->field_ptr[f], ho.data(), 4 * (size_t)N, hipMemcpyHostToDevice));
+        }
+    }
     {
         int rc2 = init_iou_state(p, env_mask, hx.data(), hy.data());
         if (rc2 != T2D_OK) return rc2;
@@ -691,6 +717,13 @@ int t2d_bind_actions(t2d_pool* p, const float* act0_dev, const float* act1_dev) 
     return T2D_OK;
 }
 
+static int drift_impl(t2d_pool* p, int interval_ms, hipStream_t s) {
+    int rc;
+    if ((rc = record_event(p, 5, s, true))) return rc;
+    T2D_HIP(p, t2d::launch_drift(p->v, interval_ms, s));
+    return record_event(p, 5, s, false);
+}
+
 static int idm_impl(t2d_pool* p, hipStream_t s, const int32_t* forced_leader = nullptr) {
     int rc;
     if ((rc = record_event(p, 4, s, true))) return rc;
@@ -706,6 +739,7 @@ int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     hipStream_t s = (hipStream_t)hip_stream;
     int rc;
     if (p->idm_on && (rc = idm_impl(p, s))) return rc;
+    if (p->has_drift && (rc = drift_impl(p, interval_ms, s))) return rc;
     if ((rc = record_event(p, 0, s, true))) return rc;
     T2D_HIP(p, t2d::launch_integrate(p->v, interval_ms, p->integrator_variant, s));
     return record_event(p, 0, s, false);
@@ -750,6 +784,7 @@ int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)(p->step_count & 1) * p->v.n_env;
     int rc;
     if (p->idm_on && (rc = idm_impl(p, (hipStream_t)hip_stream))) return rc;
+    if (p->has_drift && (rc = drift_impl(p, interval_ms, (hipStream_t)hip_stream))) return rc;
     rc = collide_impl(p, true, interval_ms, (hipStream_t)hip_stream, p->integrator_variant);
     if (rc == T2D_OK) p->step_count++;
     return rc;
@@ -771,6 +806,11 @@ int t2d_snapshot(t2d_pool* p) {
     for (int k = 0; k < 6; ++k) {
         if (!p->d_snap[k]) T2D_HIP(p, hipMalloc((void**)&p->d_snap[k], nb));
         T2D_HIP(p, hipMemcpy(p->d_snap[k], src[k], nb, hipMemcpyDeviceToDevice));
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (!p->d_snap_omega[k]) T2D_HIP(p, hipMalloc((void**)&p->d_snap_omega[k], nb));
+        T2D_HIP(p, hipMemcpy(p->d_snap_omega[k], k ? p->v.omega_r : p->v.omega_f, nb, hipMemcpyDeviceToDevice));
+        p->v.snap_omega[k] = p->has_drift ? p->d_snap_omega[k] : nullptr;
     }
     if (!p->d_snap_ids) T2D_HIP(p, hipMalloc((void**)&p->d_snap_ids, nb));
     T2D_HIP(p, hipMemcpy(p->d_snap_ids, p->v.ids, nb, hipMemcpyDeviceToDevice));

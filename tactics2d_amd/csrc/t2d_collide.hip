@@ -464,7 +464,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
 
     const bool active = valid && ((ids >> kIdsActiveShift) & 0xffu);
     const int type = (ids >> kIdsTypeShift) & 0xff;
-    if (FUSE >= 0 && active) {
+    // (SingleTrackDrift lanes were integrated by drift_kernel, launched before this one)
+    if (FUSE >= 0 && active && ((ids >> kIdsModelShift) & 0xff) != T2D_MODEL_DRIFT) {
         // ---------------- fused physics: one PhysicsModelBase.step in registers ----------------
         const int model = (ids >> kIdsModelShift) & 0xff;
         auto P = [&](int col) -> double { return s_partab[col * T2D_MAX_TYPES + type]; };
@@ -872,6 +873,10 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             pv.vx[idx] = pv.snap[4][idx];
             pv.vy[idx] = pv.snap[5][idx];
             pv.ids[idx] = pv.snap_ids[idx];
+            if (pv.snap_omega[0]) {  // SingleTrackDrift wheel speeds (only with a drift type in the table)
+                pv.omega_f[idx] = pv.snap_omega[0][idx];
+                pv.omega_r[idx] = pv.snap_omega[1][idx];
+            }
         }
     }
     T2D_MARK(12);

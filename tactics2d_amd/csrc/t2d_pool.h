@@ -41,6 +41,7 @@ struct LidarView;
 struct PoolView {
     int32_t n_env, A, N;
     float *x, *y, *heading, *speed, *vx, *vy, *act0, *act1, *applied0, *applied1;
+    float *omega_f, *omega_r;  // SingleTrackDrift wheel speeds
     uint32_t *ids, *flags, *env_flags;
     int32_t *cnt_step, *frame_ms;
     uint8_t* status;
@@ -65,6 +66,7 @@ struct PoolView {
     float* iou;                // [E] last IoU(pose, target), NaN = None
     const float* snap[6];      // episode-start snapshot (x, y, heading, speed, vx, vy) or null
     const uint32_t* snap_ids;
+    const float* snap_omega[2];  // wheel speeds at the snapshot; null unless a drift type is present
     int32_t auto_reset;        // t2d_step restores finished envs in its epilogue
     unsigned long long* dbg;  // phase cycle accumulators (profiling builds with -DT2D_TIMING only)
     double cell;      // spatial-hash cell edge (m) >= max circum-diameter * 1.001
@@ -130,6 +132,8 @@ struct t2d_pool {
     int32_t *d_lidar_env_off = nullptr, *d_lidar_next = nullptr;
     float* d_lidar_xy = nullptr;
     double *d_beam_sin = nullptr, *d_beam_cos = nullptr;
+    bool has_drift = false;   // a T2D_MODEL_DRIFT row is in the parameter table
+    float* d_snap_omega[2]{};
     // IDM agents (row f3)
     bool idm_on = false;
     t2d::IdmView idm{};
@@ -154,6 +158,7 @@ hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hip
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
                           int interval_ms, int fuse_variant, hipStream_t s);
 hipError_t launch_lidar(const PoolView& v, const LidarView& lv, float* out, hipStream_t s);
+hipError_t launch_drift(const PoolView& v, int interval_ms, hipStream_t s);
 hipError_t launch_verify(const PoolView& v, const float* x, const float* y, const float* heading, const float* speed,
                          int interval_ms, uint8_t* valid, hipStream_t s);
 hipError_t launch_idm(const PoolView& v, const IdmView& iv, const int32_t* forced_leader, hipStream_t s);

@@ -202,6 +202,41 @@ class SingleTrackDynamics(SingleTrackKinematics):
         return r
 
 
+class SingleTrackDrift(SingleTrackKinematics):
+    """Batched `tactics2d.physics.SingleTrackDrift` (single_track_drift.py:52-503): same constructor
+    (the built-in `Tire` constants only) and the five-tuple `step` return."""
+    model_id = L.MODEL_DRIFT
+
+    def __init__(self, lf, lr, mass, mass_height, radius=0.344, T_sb=0.76, T_se=1, tire=None, I_z=1500, I_yw=1.7,
+                 steer_range=None, speed_range=None, accel_range=None, interval=100, delta_t=None):
+        if tire is not None:
+            raise NotImplementedError("only the reference's built-in Tire constants are implemented on the device")
+        super().__init__(lf, lr, steer_range, speed_range, accel_range, interval, delta_t)
+        self.mass, self.mass_height, self.radius = mass, mass_height, radius
+        self.T_sb, self.T_se, self.I_z, self.I_yw = T_sb, T_se, I_z, I_yw
+
+    def param_row(self, shape=L.SHAPE_OBB, length=0.0, width=0.0):
+        r = super().param_row(shape, length, width)
+        r[L.P_MASS], r[L.P_MASS_HEIGHT], r[L.P_IZ] = self.mass, self.mass_height, self.I_z
+        r[L.P_DRIFT_TSB], r[L.P_DRIFT_TSE], r[L.P_DRIFT_RADIUS], r[L.P_DRIFT_IYW] = self.T_sb, self.T_se, self.radius, self.I_yw
+        return r
+
+    def step(self, state, omega_wf, omega_wr, accel, delta, interval=None):
+        """-> (next_state, next_omega_wf, next_omega_wr, applied_accel, applied_delta)  (:467-503)"""
+        interval = interval if interval is not None else self.interval
+        n = len(state)
+        pool = self._pool(n)
+        bc = lambda a: np.broadcast_to(np.asarray(a, np.float32), (n,))
+        pool.reset(state.x, state.y, state.heading, state.speed, np.zeros(n, np.uint8))
+        pool.upload(L.F_OMEGA_F, bc(omega_wf)); pool.upload(L.F_OMEGA_R, bc(omega_wr))
+        pool.set_actions(bc(accel), bc(delta))
+        pool.integrate(interval)
+        d = pool.download
+        app0, app1 = d(L.F_APPLIED0), d(L.F_APPLIED1)
+        nxt = BatchedState(state.frame + interval, d(L.F_X), d(L.F_Y), d(L.F_HEADING), speed=d(L.F_SPEED), accel=app0)
+        return nxt, d(L.F_OMEGA_F), d(L.F_OMEGA_R), app0, app1
+
+
 class PointMass(_BatchedModel):
     model_id = L.MODEL_POINTMASS
     backends = ["newton", "euler"]

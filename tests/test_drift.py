@@ -1,0 +1,145 @@
+"""SingleTrackDrift (scope row f4; physics/single_track_drift.py): oracle vs golden vectors produced by
+running the reference (oracle/gen_golden_drift.py); HIP kernel vs oracle through the C ABI."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+TOL = 1e-5
+
+
+def _err(o, want):
+    e = np.abs(np.asarray(o, np.float64) - want)
+    e[:, 2] = np.minimum(e[:, 2], 2 * np.pi - e[:, 2])
+    return e
+
+
+def test_oracle_matches_reference_single_steps(oracle):
+    g = H.load_npz("drift.npz")
+    for iv in sorted(set(int(i) for i in g["s_interval"])):
+        m = g["s_interval"] == iv
+        o = oracle.drift(g["rows"], g["s_type"][m], g["s_in"][m], g["s_act"][m], iv, trig=0)
+        e = _err(o, g["s_out"][m])
+        # same libm, same operation order: the restatement reproduces the reference to rounding noise,
+        # amplified by the step's own conditioning (s_cond, finite-difference estimate from the generator)
+        assert (e[:, :4].max(1) <= 1e-12 * np.maximum(1.0, g["s_cond"][m])).all(), e.max(0)
+        assert np.array_equal(o[:, 6:], g["s_out"][m][:, 6:])
+        d = _err(oracle.drift(g["rows"], g["s_type"][m], g["s_in"][m], g["s_act"][m], iv, trig=1), g["s_out"][m])
+        assert d[:, :4].max() <= TOL, d.max(0)         # deterministic trig stays inside the 1e-5 contract
+
+
+@pytest.mark.parametrize("tag", ["roll_100_5", "roll_50_3", "roll_9_5"])
+def test_oracle_rollout_of_the_reference_test(oracle, tag):
+    """tests/test_physics.py:385-415: VEHICLE_ACTION_LIST from State(0, 10, 10, 0, 0), omega = 0 -- teacher forced
+    on the reference trajectory in fp64 (each step is one independent case)."""
+    g = H.load_npz("drift.npz")
+    traj, acts, row = g[tag + "_traj"], g[tag + "_act"], g[tag + "_row"]
+    iv = int(tag.split("_")[1])
+    st = np.float32(traj[:-1]); n = len(acts)
+    o = oracle.drift(row[None], np.zeros(n, np.uint8), st, np.float32(acts), iv, trig=0)
+    # inputs were rounded to fp32 for the oracle but not for the reference roll-out: compare loosely here;
+    # the bit-level pin is the single-step test above
+    e = _err(o[:, :4], traj[1:, :4])
+    assert np.median(e.max(1)) < 1e-4 and np.isfinite(o).all()
+
+
+@pytest.mark.gpu
+def test_gpu_bit_identical_to_oracle_and_within_tolerance_of_reference(oracle):
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    g = H.load_npz("drift.npz")
+    for iv in sorted(set(int(i) for i in g["s_interval"])):
+        m = np.nonzero(g["s_interval"] == iv)[0]
+        n = len(m)
+        pool = ParticipantPool(n, 1)
+        try:
+            pool.set_param_table(g["rows"])
+            st = np.float32(g["s_in"][m]); act = np.float32(g["s_act"][m])
+            pool.reset(st[:, 0], st[:, 1], st[:, 2], st[:, 3], g["s_type"][m])
+            pool.upload(L.F_OMEGA_F, st[:, 4]); pool.upload(L.F_OMEGA_R, st[:, 5])
+            pool.set_actions(act[:, 0], act[:, 1])
+            pool.integrate(iv)
+            got = np.stack([pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_OMEGA_F, L.F_OMEGA_R,
+                                                       L.F_APPLIED0, L.F_APPLIED1)], 1)
+        finally:
+            pool.close()
+        want = oracle.drift(g["rows"], g["s_type"][m], g["s_in"][m], g["s_act"][m], iv, trig=1)
+        assert np.array_equal(got.view(np.uint32), np.float32(want).view(np.uint32)), \
+            (iv, np.abs(got - np.float32(want)).max(0))
+        e = _err(got, g["s_out"][m])
+        ulp = np.spacing(np.abs(np.float32(g["s_out"][m][:, :2]))).max(1)
+        assert (e[:, :2].max(1) <= TOL + ulp).all() and e[:, 2].max() <= TOL and e[:, 3].max() <= TOL, e.max(0)
+        assert np.array_equal(got[:, 6:], np.float32(g["s_out"][m][:, 6:]))
+
+
+@pytest.mark.gpu
+def test_gpu_drift_inside_step_with_other_models_and_auto_reset(oracle):
+    """A mixed table (kinematics + drift): t2d_step launches the drift kernel first, the fused kernel passes the
+    drift lanes through and evaluates events on their new pose; fused == two-launch; auto-reset restores omegas."""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    g = H.load_npz("drift.npz")
+    kin = np.zeros(L.PARAM_COLS); kin[[L.P_LF, L.P_LR, L.P_WB, L.P_DELTA_T_MS, L.P_LENGTH, L.P_WIDTH]] = 1.2, 1.3, 2.5, 5, 4.5, 1.8
+    rows = np.stack([kin, g["rows"][0]])
+    n_env, A = 16, 4
+    n = n_env * A
+    rng = np.random.default_rng(5)
+    tid = np.tile([0, 1, 1, 0], n_env).astype(np.uint8)
+    x = np.float32(np.tile([0, 12, 24, 36], n_env) + rng.normal(0, 0.1, n)); y = np.float32(rng.normal(0, 0.1, n))
+    h = np.float32(rng.normal(0, 0.02, n) % (2 * np.pi)); v = np.float32(rng.uniform(5, 15, n))
+    om = np.float32(v / 0.344)
+    a0 = np.float32(rng.uniform(-2, 2, n)); a1 = np.float32(rng.normal(0, 0.05, n))
+    outs = []
+    for fused in (True, False):
+        pool = ParticipantPool(n_env, A)
+        try:
+            pool.set_param_table(rows)
+            pool.set_status_config(max_step=3)
+            pool.reset(x, y, h, v, tid)
+            pool.upload(L.F_OMEGA_F, om); pool.upload(L.F_OMEGA_R, om)
+            pool.snapshot(); pool.set_auto_reset(True)
+            pool.set_integrator_variant("exact"); pool.set_fused_step(fused)
+            pool.set_actions(a0, a1)
+            pool.step(100)
+            s1 = [pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_OMEGA_F, L.F_OMEGA_R, L.F_FLAGS)]
+            for _ in range(8):                          # until the time limit truncates: auto-reset to the snapshot
+                pool.step(100)
+                if pool.download(L.F_STATUS)[:, 3].all():
+                    break
+            assert pool.download(L.F_STATUS)[:, 3].all()
+            s3 = [pool.download(f) for f in (L.F_X, L.F_SPEED, L.F_OMEGA_F, L.F_OMEGA_R)]
+            outs.append((s1, s3))
+        finally:
+            pool.close()
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, b)
+    s1, s3 = outs[0]
+    dr = tid == 1
+    want = oracle.drift(rows, tid, np.stack([x, y, h, v, om, om], 1), np.stack([a0, a1], 1), 100, trig=1)
+    got = np.stack(s1[:6], 1)
+    assert np.array_equal(got[dr], np.float32(want[dr][:, :6]))
+    assert np.array_equal(s1[4][~dr], om[~dr])                      # non-drift lanes: omegas untouched
+    assert np.array_equal(s3[0], x) and np.array_equal(s3[1], v) and np.array_equal(s3[2], om) and np.array_equal(s3[3], om)
+
+
+@pytest.mark.gpu
+def test_gpu_mirror_class_runs_the_reference_rollout():
+    from tactics2d_amd.physics import BatchedState, SingleTrackDrift
+    g = H.load_npz("drift.npz")
+    m = SingleTrackDrift(lf=4.284 / 2 - 0.880, lr=4.284 / 2 - 0.767, mass=1620.0, mass_height=1.449 / 2,
+                         steer_range=(-0.524, 0.524), speed_range=(-16.67, 69.44), accel_range=(-11.0, 3.121),
+                         interval=100, delta_t=5)
+    traj, acts = g["roll_100_5_traj"], g["roll_100_5_act"]
+    s = BatchedState(frame=0, x=[10.0], y=[10.0], heading=[0.0], speed=[0.0])
+    owf = owr = np.float32([0.0])
+    try:
+        for k in range(60):                      # the first 6 s of the reference's own test roll-out, free running in fp32
+            s, owf, owr, a, d = m.step(s, owf, owr, acts[k][0], acts[k][1], 100)
+    finally:
+        m.close()
+    assert s.frame == 6000
+    # free running with the state re-rounded to fp32 every step (speed and wheel speeds feed the tyre slip):
+    # centimetre-level drift after 60 steps; the per-step contract is pinned by the tests above
+    assert abs(float(s.x[0]) - traj[60, 0]) < 5e-2 and abs(float(s.y[0]) - traj[60, 1]) < 5e-2
+    with pytest.raises(NotImplementedError):
+        SingleTrackDrift(1.0, 1.0, 1000.0, 0.5, tire=object())
