@@ -106,6 +106,15 @@ def cpu_baseline(scene, target_seconds=10.0):
                sample=f"first {min(scene.n_env, 96)} envs x {A} participants of the same scene, {steps1} steps, "
                       f"{el1:.1f} s on 1 core; C oracle oracle/t2d_oracle.c (fp64 scalar restatement "
                       f"of the reference)")
+    try:   # the reference's own call pattern: one Python-level step per participant, numpy scalar ufuncs
+        from oracle import py_loop
+        kin = scene.rows[scene.rows[:, 0] == 0]
+        if len(kin):
+            out["python_loop_value"] = py_loop.time_loop(kin[0], 2000)
+            out["python_loop_note"] = ("reference-style per-participant Python loop (SingleTrackKinematics.step restated "
+                                       "with numpy scalar calls, physics only), 2000 steps on 1 core")
+    except Exception as e:  # reported, never fatal for the bench line
+        out["python_loop_note"] = f"not run: {e}"
     if O.has_openmp() and cores > 1:
         allc, stepsN, elN = _cpu_leg(scene, scene.n_env, cores, target_seconds)
         out.update(value=allc, cores=cores, one_core_value=one,

@@ -141,3 +141,18 @@ def test_dynamics_ignores_the_remainder_substep(oracle):
     assert abs(kin["out"][3] - (2.0 + 3.0 * 0.009)) < 1e-12      # 5 ms + 4 ms remainder
     assert abs(dyn["out"][3] - (2.0 + 3.0 * 0.005)) < 1e-12      # remainder dropped
     assert ks
+
+
+def test_python_loop_baseline_is_the_same_algorithm():
+    """oracle/py_loop.py (the reference-call-pattern CPU baseline of bench.py) against the golden vectors."""
+    from oracle import py_loop
+    d = H.load_npz("kin_random.npz")
+    worst = 0.0
+    for k in range(0, len(d["state"]), 37):
+        row = d["rows"][d["type_id"][k]]
+        st, act = np.float64(np.float32(d["state"][k])), np.float64(np.float32(d["action"][k]))
+        iv = int(d["timing"][k][0]) if "timing" in d else 100
+        o = py_loop.kinematics_step(row, st[0], st[1], st[2], st[3], act[0], act[1], iv)
+        e = np.abs(np.array(o[:4]) - d["out"][k][:4]); e[2] = min(e[2], 2 * np.pi - e[2])
+        worst = max(worst, e.max())
+    assert worst <= 1e-12, worst
