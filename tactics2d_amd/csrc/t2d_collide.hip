@@ -589,68 +589,6 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             atomicOr(&s_flags[j], T2D_FLAG_COLLISION_DYNAMIC);
         }
     };
-    if (!use_hash_grid) {
-        // every lane against all agents of its env: fp32 circles, 1 cm margin (strictly
-        // conservative for |x|,|y| < 4 km); executed by ALL lanes (shuffles read executing lanes)
-        unsigned long long cand = 0ull;
-        if (log2A == 6) {
-            // env == wave: agent a's circle arrives in SGPRs (v_readlane, wave-uniform lane index)
-            // and every lane tests itself against it -- fully unrolled so the bit deposit is one
-            // select + one or on a 32-bit half; no LDS, no 64-bit shifts, ~11 instructions / agent.
-            // Inactive lanes are parked at x = 1e30 (distance^2 = inf: never near).
-            const float px = active ? fx : 1e30f;
-            const int ifx = __float_as_int(px), ify = __float_as_int(fy), iR = __float_as_int(R32);
-            uint32_t half[2] = {0u, 0u};
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
-#pragma unroll
-                for (int a = 0; a < 32; ++a) {
-                    const float ox = __int_as_float(__builtin_amdgcn_readlane(ifx, hb * 32 + a));
-                    const float oy = __int_as_float(__builtin_amdgcn_readlane(ify, hb * 32 + a));
-                    const float oR = __int_as_float(__builtin_amdgcn_readlane(iR, hb * 32 + a));
-                    const float dx = px - ox, dy = fy - oy, rr = R32 + oR;
-                    half[hb] |= dx * dx + dy * dy <= rr * rr ? 1u << a : 0u;
-                }
-            }
-            cand = (unsigned long long)half[0] | ((unsigned long long)half[1] << 32);
-        } else {
-            const int seg0 = lane & ~(A_pad - 1);  // first lane of my env inside the wave
-#pragma unroll 4
-            for (int a = 0; a < A_pad; ++a) {
-                const float ox = __shfl(fx, seg0 + a), oy = __shfl(fy, seg0 + a), oR = __shfl(R32, seg0 + a);
-                const float dx = fx - ox, dy = fy - oy, rr = R32 + oR;
-                const bool near = oR >= 0.0f && dx * dx + dy * dy <= rr * rr;
-                cand |= (unsigned long long)near << a;
-            }
-        }
-        T2D_MARK(3);
-        cand &= ~((2ull << agent) - 1ull);  // partners with a higher index only: each pair once
-        if (!active) cand = 0ull;
-        compact_and_process<false>(cand, (env_local << log2A), tid, queue, qcount, lane, process_pair);
-    } else {
-        // spatial-hash walk; pairs go straight to the narrow phase (i < j de-duplicates)
-        if (active) {
-            const double cx = s_c[0][tid], cy = s_c[1][tid];
-            for (int oy_ = -1; oy_ <= 1; ++oy_)
-                for (int ox_ = -1; ox_ <= 1; ++ox_) {
-                    const int b = env_local * H + (int)(cell_hash(gcx + ox_, gcy + oy_) & (uint32_t)(H - 1));
-                    for (int j = s_head[b]; j >= 0; j = s_next[j]) {
-                        if (j <= tid) continue;
-                        const int jx = (int)__builtin_floor(s_c[0][j] * pv.inv_cell);
-                        const int jy = (int)__builtin_floor(s_c[1][j] * pv.inv_cell);
-                        if (jx != gcx + ox_ || jy != gcy + oy_) continue;  // hash alias of another cell
-                        const double dx = cx - s_c[0][j], dy = cy - s_c[1][j];
-                        const double rr = s_c[2][tid] + s_c[2][j] + kRejectMargin;
-                        if (dx * dx + dy * dy > rr * rr) continue;  // cannot touch
-                        process_pair((uint32_t)tid | ((uint32_t)j << 8));
-                    }
-                }
-        }
-    }
-
-    T2D_MARK(4);
-    if (use_hash_grid) __syncthreads();  // the grid lists share LDS with the queues used below
-    // ---------------- phase 2b / 2c: static polygons and lane polygons -------------------------
     const int* geo_i = reinterpret_cast<const int*>(s_geo);
     auto process_static = [&](uint32_t e) {
         const int i = (int)(e & 255u), p = (int)(e >> 8);
@@ -690,6 +628,107 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         if (bits) atomicOr(&s_inside[i], bits);
     };
     int n_lane_polys = 0;
+    // Odd waves visit the polygon stages before the pair stage: the four waves of a SIMD start together
+    // and would otherwise sit in the same latency-bound (LDS compaction) or issue-bound (narrow phase)
+    // stretch at the same time.  The stages are independent (results are OR-ed into s_flags / s_inside).
+    const bool polys_first = log2A <= 6 && ((tid >> 6) & 1);
+    for (int stage_it = 0; stage_it < 2; ++stage_it) {
+    if ((stage_it == 0) != polys_first) {
+    if (!use_hash_grid) {
+        // every lane against all agents of its env: fp32 circles, 1 cm margin (strictly
+        // conservative for |x|,|y| < 4 km); executed by ALL lanes (shuffles read executing lanes)
+        unsigned long long cand = 0ull;
+        if (log2A > 0) {
+            // (x, y, R) of the wave's 64 lanes go through LDS (the wave's queue storage, idle until the
+            // compaction below) and come back two agents at a time as wave-uniform 8-B reads; the
+            // distance test runs on packed fp32 (v_pk_*: 2 agents per instruction) and each verdict is
+            // shifted into the lane's candidate word by v_cmp + v_addc (carry-in = the compare mask):
+            // 5 VALU instructions per agent instead of 11.  Agents are visited in descending order so
+            // that agent a lands on bit a.  Inactive lanes are parked at x = 1e30 (distance^2 = inf).
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            float* const bx = reinterpret_cast<float*>(queue);
+            float* const by = bx + 64;
+            float* const bR = by + 64;
+            static_assert(3 * 64 <= kQueueCap, "broad-phase staging must fit in the wave's queue");
+            const float px = active ? fx : 1e30f;
+            bx[lane] = px;
+            by[lane] = fy;
+            bR[lane] = R32;
+            wave_sync();
+            const f2 px2 = {px, px}, py2 = {fy, fy}, pR2 = {R32, R32};
+            uint32_t half[2] = {0u, 0u};
+            // K pairs per batch: all 3K LDS reads are issued before the first compare, so one LDS latency
+            // is exposed per batch instead of per pair
+            auto batch = [&](uint32_t& h, int top, auto kc) {   // agents top + 2K - 1 ... top
+                constexpr int K = decltype(kc)::value;
+                f2 ox[K], oy[K], oR[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    ox[k] = *reinterpret_cast<const f2*>(&bx[top + 2 * (K - 1 - k)]);
+                    oy[k] = *reinterpret_cast<const f2*>(&by[top + 2 * (K - 1 - k)]);
+                    oR[k] = *reinterpret_cast<const f2*>(&bR[top + 2 * (K - 1 - k)]);
+                }
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const f2 dx = px2 - ox[k], dy = py2 - oy[k], rr = pR2 + oR[k];
+                    const f2 q = __builtin_elementwise_fma(dy, dy, dx * dx), r = rr * rr;
+                    asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                                 : "+v"(h) : "v"(q.y), "v"(r.y) : "vcc");
+                    asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                                 : "+v"(h) : "v"(q.x), "v"(r.x) : "vcc");
+                }
+            };
+            using K1 = std::integral_constant<int, 1>;
+            using K4 = std::integral_constant<int, 4>;
+            if (log2A == 6) {  // env == wave: constant trip counts, fully unrolled
+#pragma unroll
+                for (int hb = 1; hb >= 0; --hb) {
+                    uint32_t h = 0u;
+#pragma unroll
+                    for (int top = 24; top >= 0; top -= 8) batch(h, hb * 32 + top, K4{});
+                    half[hb] = h;
+                }
+            } else {           // several envs per wave: A_pad in {2 .. 32} agents from my env's first lane
+                const int first = lane & ~(A_pad - 1);
+                uint32_t h = 0u;
+                if (A_pad >= 8) {
+                    for (int top = A_pad - 8; top >= 0; top -= 8) batch(h, first + top, K4{});
+                } else {
+                    for (int top = A_pad - 2; top >= 0; top -= 2) batch(h, first + top, K1{});
+                }
+                half[0] = h;
+            }
+            cand = (unsigned long long)half[0] | ((unsigned long long)half[1] << 32);
+        }
+        T2D_MARK(3);
+        cand &= ~((2ull << agent) - 1ull);  // partners with a higher index only: each pair once
+        if (!active) cand = 0ull;
+        compact_and_process<false>(cand, (env_local << log2A), tid, queue, qcount, lane, process_pair);
+    } else {
+        // spatial-hash walk; pairs go straight to the narrow phase (i < j de-duplicates)
+        if (active) {
+            const double cx = s_c[0][tid], cy = s_c[1][tid];
+            for (int oy_ = -1; oy_ <= 1; ++oy_)
+                for (int ox_ = -1; ox_ <= 1; ++ox_) {
+                    const int b = env_local * H + (int)(cell_hash(gcx + ox_, gcy + oy_) & (uint32_t)(H - 1));
+                    for (int j = s_head[b]; j >= 0; j = s_next[j]) {
+                        if (j <= tid) continue;
+                        const int jx = (int)__builtin_floor(s_c[0][j] * pv.inv_cell);
+                        const int jy = (int)__builtin_floor(s_c[1][j] * pv.inv_cell);
+                        if (jx != gcx + ox_ || jy != gcy + oy_) continue;  // hash alias of another cell
+                        const double dx = cx - s_c[0][j], dy = cy - s_c[1][j];
+                        const double rr = s_c[2][tid] + s_c[2][j] + kRejectMargin;
+                        if (dx * dx + dy * dy > rr * rr) continue;  // cannot touch
+                        process_pair((uint32_t)tid | ((uint32_t)j << 8));
+                    }
+                }
+        }
+    }
+
+    T2D_MARK(4);
+    if (use_hash_grid) __syncthreads();  // the grid lists share LDS with the queues used below
+    // ---------------- phase 2b / 2c: static polygons and lane polygons -------------------------
+    } else {
 #pragma unroll
     for (int kd = 0; kd < 2; ++kd) {
         if (!gl.has[kd]) continue;
@@ -746,6 +785,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         }
     }
 
+    }
+    }
     // ---------------- phase 3: reduce + status epilogue ------------------------------------
     T2D_MARK(9);
     if (log2A <= 6) wave_sync(); else __syncthreads();  // (c) every queue drained: s_flags / s_inside complete
