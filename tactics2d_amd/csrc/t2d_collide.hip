@@ -382,6 +382,13 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     float fv = 0, fa0 = 0, fa1 = 0;  // fused: speed and actions
     float bxmin = 0, bxmax = 0, bymin = 0, bymax = 0;
     bool has_boundary = false;
+    // the status epilogue's inputs, fetched now by the lane that will run it (agent 0): their latency
+    // would otherwise sit, unhidden, at the very end of the wave
+    int pre_cnt = 0, pre_frame = 0;
+    if (WITH_STATUS && valid && agent == 0) {
+        pre_cnt = pv.cnt_step[env];
+        pre_frame = pv.frame_ms[env];
+    }
     if (valid) {
         ids = pv.ids[idx];
         fx = pv.x[idx];
@@ -808,9 +815,9 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     if (valid && agent == 0) {
         pv.env_flags[env] = s_env_or[env_local];
         if (WITH_STATUS) {
-            const int cnt = pv.cnt_step[env] + 1;  // parking.py:353
+            const int cnt = pre_cnt + 1;  // parking.py:353
             pv.cnt_step[env] = cnt;
-            pv.frame_ms[env] += interval_ms;
+            pv.frame_ms[env] = pre_frame + interval_ms;
             const int ego = (env_local << log2A) + cfg.ego_index;  // workgroup-local lane of the ego
             const uint32_t ef = s_flags[ego];
             int scen = T2D_SCENARIO_NORMAL, traf = T2D_TRAFFIC_NORMAL;
