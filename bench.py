@@ -289,8 +289,18 @@ def main():
                 if (tj.get("config"), tj.get("envs_per_gpu"), tj.get("participants_per_env")) == (args.config, n_env, agents):
                     traffic = tj["hbm_bytes_per_launch"].get(dom)
                     traffic_src = f"profiles/traffic_latest.json ({tj.get('tag')}): " + tj.get("source", "")
+            valu = None
+            if os.path.exists(tf):   # report VALU busy next to the HBM figure (the kernel is fp64-issue bound)
+                sq = json.load(open(tf)).get("sq_counters_per_dispatch", {}).get(dom)
+                if sq and traffic is not None:
+                    n_simd = 256 * 4
+                    kcyc = sq["SQ_BUSY_CYCLES"] / 32.0          # summed over 8 XCDs x 4 SEs
+                    valu = dict(busy_frac=4.0 * sq["SQ_ACTIVE_INST_VALU"] / (n_simd * kcyc),
+                                valu_insts_per_wave=sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"],
+                                kernel_cycles=kcyc, source="SQ_* counters of the committed rocprofv3 pass "
+                                "(profiles/traffic_latest.json); SQ_ACTIVE_INST_VALU counts quad-cycles")
             roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                        frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, valu=valu,
                         timed_over="second pass of the same steps with HIP events on the launch stream around each kernel",
                         algorithmic_bytes_per_launch=per_launch[dom], avg_kernel_us=kern[dom]["avg_us"],
                         kernels={k_: dict(avg_us=v["avg_us"], launches=v["launches"],

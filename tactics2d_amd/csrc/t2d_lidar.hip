@@ -25,6 +25,7 @@ namespace t2d {
 namespace {
 
 constexpr int kLidarBlock = 128;
+constexpr int kLidarQueue = 256;  // (beam, edge) candidates per wave per round
 
 T2D_DEV double lidar_edge(double a, double b, double lx, double ly, double R, double x1, double y1, double x2,
                           double y2) {
@@ -82,9 +83,18 @@ T2D_DEV int2 edge_span(double x1, double y1, double x2, double y2, double R, int
     return make_int2(k0, len);
 }
 
-__global__ __launch_bounds__(kLidarBlock) void lidar_kernel(PoolView pv, LidarView lv, float* out) {
+// WAVES = waves per SIMD the register allocation is held to: short edge lists (ParkingEnv: ~32 edges) are bound by
+// the chain of dependent latencies per workgroup, so twice the resident workgroups beat the 22 spilled registers
+// (39 vs 47 us at 4096 envs); long lists (participants scanned: 250+ edges) are issue-bound and keep all 98 registers.
+template <int WAVES>
+__global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, LidarView lv, float* out) {
     extern __shared__ __attribute__((aligned(16))) double s_edge[];  // [slots][4] = x1, y1, x2, y2 (sensor frame)
     int2* const s_span = reinterpret_cast<int2*>(s_edge + 4 * (size_t)lv.max_slots);  // [slots] beam span per edge
+    // [n_beams] running minimum per beam as the bit pattern of a non-negative double (monotone), then the wave queues
+    unsigned long long* const s_best = reinterpret_cast<unsigned long long*>(s_span + lv.max_slots);
+    unsigned long long* const s_mask = s_best + lv.n_beams;   // [n_beams] candidate edges (bit q) of the current 64-edge chunk
+    uint32_t* const s_queue = reinterpret_cast<uint32_t*>(s_mask + lv.n_beams);       // [kLidarBlock / 64][kLidarQueue]
+    __shared__ int s_qcount[kLidarBlock / 64];
     __shared__ double s_ego[4];                                       // cos, sin, x_off, y_off
     __shared__ int s_ego_active;
     const int env = blockIdx.x;
@@ -165,35 +175,82 @@ __global__ __launch_bounds__(kLidarBlock) void lidar_kernel(PoolView pv, LidarVi
     }
     __syncthreads();
 
-    // ---- phase 2: one lane per beam ---------------------------------------------------------------------
+    // ---- phase 2: beams x candidate edges ------------------------------------------------------------------
+    // Pass 1 (edge-major scatter of the spans into per-beam candidate masks, see below).  Pass 2: the candidates of the
+    // wave's 64 beams are compacted into an LDS queue and evaluated one per lane (dense lanes: the rounds needed
+    // are total / 64 instead of the largest per-beam count), each result folded into its beam's minimum by a
+    // 64-bit LDS atomic min on the bit pattern (distances are >= 0, so the order of bit patterns is the order of
+    // values).  min over the same set of values: the result does not depend on the evaluation order.
     const double R = lv.max_range;
+    const unsigned long long inf_bits = 0x7ff0000000000000ull;
+    for (int k = tid; k < lv.n_beams; k += kLidarBlock) s_best[k] = inf_bits;
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t* const queue = s_queue + wave * kLidarQueue;
+    int* const qcount = &s_qcount[wave];
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    const bool scan = s_ego_active && n_slots > 0;
+    const int n_iter = (lv.n_beams + kLidarBlock - 1) / kLidarBlock;
+    for (int c0 = 0; c0 < n_slots && scan; c0 += 64) {
+        // pass 1, edge-major: every edge of the chunk ORs its bit into the masks of the beams of its span (two
+        // lanes per edge, alternate beams) -- sum of span lengths instead of beams x edges comparisons
+        for (int k = tid; k < lv.n_beams; k += kLidarBlock) s_mask[k] = 0ull;
+        __syncthreads();
+        {
+            const int q = tid >> 1;
+            if (c0 + q < n_slots) {
+                const int2 sp = s_span[c0 + q];
+                const int last = sp.y < lv.n_beams ? sp.y : lv.n_beams - 1;   // sp.y = -1: invisible
+                for (int i = tid & 1; i <= last; i += 2) {
+                    int kb = sp.x + i;
+                    kb -= kb >= lv.n_beams ? lv.n_beams : 0;
+                    atomicOr(&s_mask[kb], 1ull << q);
+                }
+            }
+        }
+        __syncthreads();
+        for (int it = 0; it < n_iter; ++it) {
+            const int k = tid + it * kLidarBlock;
+            unsigned long long m = k < lv.n_beams ? s_mask[k] : 0ull;
+            for (;;) {  // compaction rounds (all 64 lanes take part)
+                const int cnt = __popcll(m);
+                if (__ballot(cnt > 0) == 0ull) break;
+                if (lane == 0) *qcount = 0;
+                wave_sync();
+                const int off = cnt > 0 ? atomicAdd(qcount, cnt) : kLidarQueue;
+                const int room = kLidarQueue - off;
+                const int n_emit = room <= 0 ? 0 : (cnt < room ? cnt : room);
+                for (int e = 0; e < n_emit; ++e) {
+                    const int q = __ffsll((long long)m) - 1;
+                    m &= m - 1ull;
+                    queue[off + e] = (uint32_t)k | ((uint32_t)(c0 + q) << 16);
+                }
+                wave_sync();
+                const int total = *qcount;
+                const int n_round = total < kLidarQueue ? total : kLidarQueue;
+                for (int j = lane; j < n_round; j += 64) {
+                    const uint32_t en = queue[j];
+                    const int kb = (int)(en & 0xffffu), q = (int)(en >> 16);
+                    const double bs = lv.beam_sin[kb], bc = lv.beam_cos[kb];
+                    // a = sin, b = -cos (lidar.py:161-162); lx = cos R, ly = sin R (:201-204)
+                    const double dd = lidar_edge(bs, -bc, bc * R, bs * R, R, s_edge[4 * q], s_edge[4 * q + 1],
+                                                 s_edge[4 * q + 2], s_edge[4 * q + 3]);
+                    if (dd == dd) atomicMin(&s_best[kb], (unsigned long long)__double_as_longlong(dd));
+                }
+                wave_sync();
+            }
+        }
+        __syncthreads();  // the next chunk clears s_mask
+    }
+    wave_sync();
     float* o = out + (size_t)env * lv.n_beams;
     for (int k = tid; k < lv.n_beams; k += kLidarBlock) {
         float res = __builtin_inff();
-        if (s_ego_active && n_slots > 0) {
-            const double bs = lv.beam_sin[k], bc = lv.beam_cos[k];
-            const double a = bs, b = -bc;                    // lidar.py:161-162
-            const double lx = bc * R, ly = bs * R;           // :201-204
-            double best = __builtin_inf();
-            for (int c0 = 0; c0 < n_slots; c0 += 64) {
-                // pass 1: integer span test per edge (LDS broadcast reads, branch-free) -> candidate mask
-                unsigned long long m = 0ull;
-                const int cn = n_slots - c0 < 64 ? n_slots - c0 : 64;
-                for (int q = 0; q < cn; ++q) {
-                    const int2 sp = s_span[c0 + q];
-                    int rel = k - sp.x;
-                    rel += rel < 0 ? lv.n_beams : 0;
-                    m |= (unsigned long long)(rel <= sp.y) << q;
-                }
-                // pass 2: the reference's arithmetic on the candidates only
-                while (m != 0ull) {
-                    const int q = c0 + __ffsll((long long)m) - 1;
-                    m &= m - 1ull;
-                    const double dd = lidar_edge(a, b, lx, ly, R, s_edge[4 * q], s_edge[4 * q + 1], s_edge[4 * q + 2],
-                                                 s_edge[4 * q + 3]);
-                    best = dd < best ? dd : best;
-                }
-            }
+        if (scan) {
+            double best = __longlong_as_double((long long)s_best[k]);
             best = best < 0.0 ? 0.0 : (best > R ? R : best);   // np.clip(0, R)
             res = best == R ? __builtin_inff() : (float)best;
         }
@@ -204,8 +261,12 @@ __global__ __launch_bounds__(kLidarBlock) void lidar_kernel(PoolView pv, LidarVi
 }  // namespace
 
 hipError_t launch_lidar(const PoolView& v, const LidarView& lv, float* out, hipStream_t s) {
-    const size_t dyn = (sizeof(double) * 4 + sizeof(int2)) * (size_t)lv.max_slots;
-    hipLaunchKernelGGL(lidar_kernel, dim3(v.n_env), dim3(kLidarBlock), dyn, s, v, lv, out);
+    const size_t dyn = (sizeof(double) * 4 + sizeof(int2)) * (size_t)lv.max_slots + 16 * (size_t)lv.n_beams +
+                       4 * (size_t)kLidarQueue * (kLidarBlock / 64);
+    if (lv.max_slots <= 64)
+        hipLaunchKernelGGL(lidar_kernel<8>, dim3(v.n_env), dim3(kLidarBlock), dyn, s, v, lv, out);
+    else
+        hipLaunchKernelGGL(lidar_kernel<4>, dim3(v.n_env), dim3(kLidarBlock), dyn, s, v, lv, out);
     return hipGetLastError();
 }
 
