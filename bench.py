@@ -197,7 +197,9 @@ def main():
         a0, a1 = scene.sample_actions(rng)
         ring.append((torch.from_numpy(a0).to(dev), torch.from_numpy(a1).to(dev)))
     records_t = torch.as_tensor(pool.device_array(L.F_RECORD), device=dev).view(torch.int32)
-    gather = D.ResultGather(records_t, world) if (world > 1 or os.environ.get("T2D_FORCE_GATHER")) else None
+    # N > 1: the per-env result records of 8 consecutive steps travel in one RCCL all-gather (rollout fragment)
+    gather_every = 8
+    gather = D.ResultGather(records_t, world, every=gather_every) if (world > 1 or os.environ.get("T2D_FORCE_GATHER")) else None
     step_no = [0]
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -316,7 +318,7 @@ def main():
                                         f"integrator variant {args.variant}, {'two-kernel' if args.split else 'fused single-launch'} step, auto-reset "
                                         f"{'off' if args.no_reset else 'on'}" + (", IDM agents on" if args.idm else ""),
                                config=args.config, envs_per_gpu=n_env, participants_per_env=agents,
-                               parallelism=f"env-sharded x{world}, RCCL all-gather of 8 B/env records"
+                               parallelism=f"env-sharded x{world}, one async RCCL all-gather of the 8 B/env result records per {gather_every} steps"
                                if world > 1 else "single GPU"),
                    roofline=roof,
                    check=dict(state_finite=finite,

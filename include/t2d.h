@@ -138,9 +138,10 @@ enum {
     T2D_F_FRAME_MS = 14,   /* i32[E]  State.frame of the env (ms)                    */
     T2D_F_STATUS = 15,     /* u8[E*4] scenario_status, traffic_status, terminated, truncated */
     T2D_F_REWARD = 16,     /* f32[E]                                                  */
-    T2D_F_RECORD = 17,     /* u32[2][E][2] packed per-env result records {reward bits, status word},
-                              double buffered: t2d_step number k (0-based since create) writes half
-                              k & 1, so a collective may still read step k while step k+1 runs    */
+    T2D_F_RECORD = 17,     /* u32[T2D_RECORD_RING][E][2] packed per-env result records {reward bits, status
+                              word}, a ring: t2d_step number k (0-based since create) writes slot
+                              k % T2D_RECORD_RING, so a collective can ship the records of the last K
+                              steps in one message while the following steps already run          */
     T2D_F_IOU = 18,        /* f32[E]  IoU(ego pose, target) of the last step; NaN = not evaluated (None) */
     T2D_F_CNT_NO_ACTION = 19, /* i32[E] NoAction.cnt_no_action                          */
     T2D_F_LIDAR = 20,      /* f32[E][n_beams] last t2d_lidar_scan into the pool's own buffer (size set by
@@ -173,6 +174,7 @@ enum {
 
 /* ---- geometry limits ----------------------------------------------------------------- */
 #define T2D_MAX_POLY_VERTS 8      /* static / lane polygons: convex, 3..8 vertices        */
+#define T2D_RECORD_RING 16      /* slots of the per-env result-record ring (T2D_F_RECORD) */
 #define T2D_MAX_AGENTS 256        /* participants per env                                 */
 
 /* ---- status / reward configuration (t2d_set_status_config) --------------------------- */

@@ -29,7 +29,7 @@ int fail(t2d_pool* p, int code, const std::string& msg) {
 
 size_t field_elem_bytes(int f) {
     switch (f) {
-        case T2D_F_RECORD: return 16;  // 2 halves x {u32 reward bits, u32 status word} per env
+        case T2D_F_RECORD: return 8 * T2D_RECORD_RING;  // ring slots x {u32 reward bits, u32 status word} per env
         case T2D_F_STATUS: return 4;  // 4 x u8 per env
         default: return 4;
     }
@@ -765,7 +765,7 @@ int t2d_check_status(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     if (!p->have_params || !p->have_reset)
         return fail(p, T2D_ERR_STATE, "t2d_set_param_table and t2d_reset must precede t2d_check_status");
     if (interval_ms <= 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be positive");
-    p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)(p->step_count & 1) * p->v.n_env;
+    p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)(p->step_count % T2D_RECORD_RING) * p->v.n_env;
     int rc = collide_impl(p, true, interval_ms, (hipStream_t)hip_stream);
     if (rc == T2D_OK) p->step_count++;
     return rc;
@@ -781,7 +781,7 @@ int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     if (!p->have_params || !p->have_reset)
         return fail(p, T2D_ERR_STATE, "t2d_set_param_table and t2d_reset must precede t2d_step");
     if (interval_ms <= 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be positive");
-    p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)(p->step_count & 1) * p->v.n_env;
+    p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)(p->step_count % T2D_RECORD_RING) * p->v.n_env;
     int rc;
     if (p->idm_on && (rc = idm_impl(p, (hipStream_t)hip_stream))) return rc;
     if (p->has_drift && (rc = drift_impl(p, interval_ms, (hipStream_t)hip_stream))) return rc;

@@ -46,7 +46,7 @@ struct PoolView {
     int32_t *cnt_step, *frame_ms;
     uint8_t* status;
     float* reward;
-    uint2* record;  // this step's half of the double-buffered {reward bits, status word} records
+    uint2* record;  // this step's slot of the ring of {reward bits, status word} records
     const double* params;  // [T2D_PARAM_COLS][T2D_MAX_TYPES]
     int32_t n_types;
     // static + lane geometry: one fixed-stride packed record per collide workgroup (see GeoLayout)
@@ -143,7 +143,7 @@ struct t2d_pool {
     uint32_t* d_snap_ids = nullptr;
     bool have_snapshot = false;
     bool auto_reset = false;
-    long long step_count = 0;  // t2d_step calls so far (selects the record half)
+    long long step_count = 0;  // t2d_step calls so far (selects the record ring slot)
     // profiling
     bool profiling = false;
     static constexpr int kMaxProfSteps = 4096;

@@ -54,30 +54,47 @@ def unpack_record(rec):
 class ResultGather:
     """Asynchronous all-gather of the per-env result records.
 
-    The step kernel itself writes the 8-byte records into a double-buffered pool field
-    (T2D_F_RECORD, half = step parity), so the collective reads them in place: no packing kernels,
-    and step k+1 may run while the gather of step k is still in flight.  `records` is an int32
-    tensor view [2, E, 2] of that field (a CPU tensor in the gloo tests)."""
+    The step kernel itself writes the 8-byte records into a ring of slots in the pool (T2D_F_RECORD, slot =
+    step number % ring), so the collective reads them in place: no packing kernels.  `every` = K ships the
+    records of K consecutive steps in ONE message (a rollout fragment): a collective costs ~10 us of launch /
+    stream-event overhead per call however small it is, which per step would be a third of the step itself;
+    K must divide the ring and leave at least two fragments in it (K <= ring / 2), so the next fragment is
+    written while the previous one is in flight.  `records` is an int32 tensor view [ring, E, 2] of that field
+    (a CPU tensor in the gloo tests)."""
 
-    def __init__(self, records, world):
+    def __init__(self, records, world, every=1):
         import torch
+        ring = records.shape[0]
+        if every < 1 or ring % every or ring // every < 2:
+            raise ValueError(f"every={every} must divide the record ring ({ring}) and be <= ring / 2")
         self.world = world
         self.records = records
+        self.every = every
+        self.ring = ring
         n = records.shape[1]
-        self.out = [torch.empty((world * n, 2), dtype=torch.int32, device=records.device) for _ in range(2)]
+        self.n = n
+        self.out = [torch.empty((world, every, n, 2), dtype=torch.int32, device=records.device) for _ in range(2)]
         self.work = [None, None]
+        self._frag = 0
 
     def launch(self, step):
-        """Start gathering the records of (0-based) step `step`; returns the buffer index."""
+        """Call after (0-based) step `step`.  When the step closes a fragment of `every` steps, starts
+        gathering it and returns the output buffer index; otherwise returns None."""
         import torch.distributed as dist
-        k = step & 1
+        if (step + 1) % self.every:
+            return None
+        k = self._frag & 1
+        self._frag += 1
         if self.work[k] is not None:
             self.work[k].wait()
             self.work[k] = None
+        s0 = (step + 1 - self.every) % self.ring
+        src = self.records[s0:s0 + self.every]          # contiguous: `every` whole slots
         if self.world > 1:
-            self.work[k] = dist.all_gather_into_tensor(self.out[k], self.records[k], async_op=True)
+            self.work[k] = dist.all_gather_into_tensor(self.out[k].view(self.world * self.every * self.n, 2),
+                                                       src.reshape(self.every * self.n, 2), async_op=True)
         else:
-            self.out[k].copy_(self.records[k])
+            self.out[k][0].copy_(src)
         return k
 
     def wait(self, k=None):
@@ -86,7 +103,9 @@ class ResultGather:
                 self.work[i].wait()
                 self.work[i] = None
 
-    def result(self, k):
-        """(reward f32[world*E], status u8[world*E,4]) of buffer k, rank-major env order."""
+    def result(self, k, j=None):
+        """Records of buffer k: (reward f32[world*E], status u8[world*E, 4]) of the fragment's j-th step
+        (default: its last), rank-major env order."""
         self.wait(k)
-        return unpack_record(self.out[k])
+        j = self.every - 1 if j is None else j
+        return unpack_record(self.out[k][:, j].reshape(self.world * self.n, 2))

@@ -183,7 +183,7 @@ class ParticipantPool:
         elif field == L.F_STATUS:
             out = np.empty((n, 4), dt)
         elif field == L.F_RECORD:
-            out = np.empty((2, n, 2), dt)
+            out = np.empty((L.RECORD_RING, n, 2), dt)
         else:
             out = np.empty(n, dt)
         self._ck(self._lib.t2d_download(self._h, field, _p(out), out.nbytes))
@@ -206,7 +206,7 @@ class ParticipantPool:
         """Object exposing __cuda_array_interface__ (zero-copy) for torch.as_tensor."""
         ptr, nb = self.field_ptr(field)
         dt = np.dtype(L.FIELD_DTYPES[field])
-        shape = (nb // 4, 4) if field == L.F_STATUS else (2, nb // 16, 2) if field == L.F_RECORD else \
+        shape = (nb // 4, 4) if field == L.F_STATUS else (L.RECORD_RING, nb // (8 * L.RECORD_RING), 2) if field == L.F_RECORD else \
             (self.n_env, nb // (4 * self.n_env)) if field == L.F_LIDAR else (nb // dt.itemsize,)
         return _DevArray(ptr, shape, dt.str, self)
 

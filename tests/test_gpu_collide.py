@@ -104,7 +104,7 @@ def test_step_status_reward_matches_oracle(oracle):
         assert (gst == wst).all(), np.nonzero((gst != wst).any(1))[0][:5]
         grw = pool.download(L.F_REWARD)
         assert np.allclose(grw, wrw, rtol=0, atol=1e-9), np.abs(grw - wrw).max()
-        rec = pool.download(L.F_RECORD)[step & 1]          # packed 8-byte records, half = step parity
+        rec = pool.download(L.F_RECORD)[step % L.RECORD_RING]   # packed 8-byte records, ring slot = step number
         assert np.array_equal(rec[:, 0].view(np.float32), grw)
         assert np.array_equal(rec[:, 1].copy().view(np.uint8).reshape(-1, 4), gst)
         seen |= set(map(tuple, gst[:, :2].tolist()))
