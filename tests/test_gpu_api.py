@@ -153,3 +153,39 @@ def test_zero_copy_views_and_bound_actions():
     assert np.array_equal(p.download(L.F_X), want[:, 0] + np.float32(1.0))
     p.bind_actions(None, None)                                 # back to the pool's own buffers
     p.close()
+
+
+def test_idm_verify_and_drift_argument_checks():
+    from tactics2d_amd import _ffi, layout as L
+    p = _pool()
+    rows = H.shape_rows()
+    p.set_param_table(rows)
+    z = np.zeros(8, np.float32)
+    cid = np.zeros(8, np.uint8)
+    good = np.array([[10.0, 1.5, 2.0, 1.0, 3.0, 4.0, 1.875, np.inf]])
+    with pytest.raises(_ffi.T2DError) as e:                   # nothing installed yet
+        p.idm_actions()
+    assert e.value.code == _ffi.ERR_STATE
+    for bad, why in ((good[:, :6], "8 columns"), (np.r_[good[0, :3], 0.0, good[0, 4:]][None], "positive"),
+                     (np.r_[good[0, :7], -1.0][None], "horizon")):
+        with pytest.raises(_ffi.T2DError) as e:
+            p.set_idm(bad, cid)
+        assert e.value.code == _ffi.ERR_INVALID and why in str(e.value), (why, str(e.value))
+    with pytest.raises(_ffi.T2DError) as e:                   # controller id outside the table
+        p.set_idm(good, np.full(8, 3, np.uint8))
+    assert "out of range" in str(e.value)
+    p.set_idm(good, cid)
+    with pytest.raises(_ffi.T2DError) as e:                   # needs a reset first
+        p.idm_actions()
+    assert e.value.code == _ffi.ERR_STATE
+    p.reset(z, z, z, z, np.zeros(8, np.uint8))
+    p.idm_actions()
+    lib = _ffi.lib()
+    assert lib.t2d_verify_state(p._h, None, None, None, None, 100, None, None) == _ffi.ERR_INVALID
+    ptr = C.c_void_p(p.field_ptr(L.F_X)[0]) if not isinstance(p.field_ptr(L.F_X)[0], C.c_void_p) else p.field_ptr(L.F_X)[0]
+    assert lib.t2d_verify_state(p._h, ptr, ptr, ptr, ptr, -5, ptr, None) == _ffi.ERR_INVALID
+    drift = np.zeros(L.PARAM_COLS); drift[[L.P_MODEL, L.P_LF, L.P_LR, L.P_WB, L.P_DELTA_T_MS]] = L.MODEL_DRIFT, 1.2, 1.3, 2.5, 5
+    with pytest.raises(_ffi.T2DError) as e:                   # mass / I_z / radius / I_yw missing
+        p.set_param_table(drift[None])
+    assert "SingleTrackDrift" in str(e.value)
+    p.close()
