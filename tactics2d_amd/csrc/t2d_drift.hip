@@ -6,8 +6,8 @@
 //   _tire_forces :291-344, _step :346-465, step :467-503.
 //
 // Its own kernel: ~34 arctan + ~30 sin/cos per sub-step make this model ~50x the work of the others
-// (~3.4 k fp64 VALU instructions per sub-step), so it stays out of the fused step kernel's register and
-// code budget.  t2d_step / t2d_integrate launch it first when the parameter table holds a drift type; the
+// (~3.4 k fp64 VALU instructions per sub-step, 195 VGPRs with everything inlined so that the independent
+// front / rear tyre chains interleave), so it stays out of the fused step kernel's register and code budget.  t2d_step / t2d_integrate launch it first when the parameter table holds a drift type; the
 // other kernels pass drift lanes through.  One lane per participant, non-drift lanes exit at once.  All
 // arithmetic is the oracle's (t2do_drift), operation by operation, deterministic trig, no contraction:
 // state bit-identical to the oracle after the fp32 store.  The camber argument is the literal 0 at every
@@ -28,17 +28,17 @@ constexpr double TP_cx1 = 1.6411, TP_dx1 = 1.1739, TP_ex1 = 0.4640, TP_kx1 = 22.
                  TR_by1 = 7.1433, TR_by2 = 9.1917, TR_by3 = -2.7856e-2, TR_cy1 = 1.0719, TR_ey1 = -0.2757,
                  TR_hy1 = 5.7448e-6, TR_vy1 = -2.7825e-2, TR_vy4 = 12.120, TR_vy5 = 1.9, TR_vy6 = -10.704;
 
-__device__ __noinline__ double sin_d(double x) {
+T2D_DEV double sin_d(double x) {
     double s, c;
     sincos_det(x, s, c);
     return s;
 }
-__device__ __noinline__ double cos_d(double x) {
+T2D_DEV double cos_d(double x) {
     double s, c;
     sincos_det(x, s, c);
     return c;
 }
-__device__ __noinline__ double atan_d(double x) { return atan_det(x); }
+T2D_DEV double atan_d(double x) { return atan_det(x); }
 
 T2D_DEV double safe_den(double u) { return __builtin_fabs(u) > 1e-6 ? u : (u >= 0 ? 1e-6 : -1e-6); }
 
