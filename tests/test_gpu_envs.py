@@ -105,3 +105,30 @@ def test_parking_env_reaches_completed_when_parked_on_the_target():
     assert terminated.all() and not truncated.any() and (reward == 5).all()
     assert (infos["scenario_status"] == ScenarioStatus.COMPLETED).all() and (infos["iou"] > 0.999).all()
     env.close()
+
+
+def test_cfg1_single_parking_env_600_random_actions(oracle):
+    """BASELINE.json configs[0] / the reference's own env test (tests/test_env.py:49-52: 600 samples of the action
+    space through one ParkingEnv): every step's state against the oracle, teacher-forced on the fp32 state, the
+    5-tuple contract, and a reset whenever the episode ends."""
+    from tactics2d_amd.envs import ParkingEnv
+    env = ParkingEnv(max_step=200, seed=0)
+    obs, infos = env.reset()
+    sc = env._vec._scene
+    rng = np.random.default_rng(0)
+    n_done = 0
+    prev = np.array([obs[0], obs[1], obs[2], obs[3]], np.float32)
+    for t in range(600):
+        act = env.action_space.sample(rng)
+        obs, reward, terminated, truncated, infos = env.step(act)
+        o = oracle.integrate(sc.rows, prev[0:1], prev[1:2], prev[2:3], prev[3:4], None, None,
+                             np.float32([act[1]]), np.float32([act[0]]), sc.type_id[:1], sc.active[:1], 100)
+        assert np.abs(np.asarray(obs[:4], np.float64) - o[0, :4]).max() <= 1e-5, (t, obs[:4], o[0, :4])
+        assert isinstance(reward, float) and np.isfinite(reward)
+        assert infos["state"]["frame"] % 100 == 0
+        if terminated or truncated:
+            n_done += 1
+            obs, infos = env.reset()
+        prev = np.array([obs[0], obs[1], obs[2], obs[3]], np.float32)
+    env.close()
+    assert n_done >= 1          # time limit (200 steps) at the latest
