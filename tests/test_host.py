@@ -142,7 +142,7 @@ def test_batched_trajectory_follows_the_reference_rules(caplog):
     """participant/trajectory/trajectory.py:97-188 restated for a batch (scope row a7)."""
     import logging
     from tactics2d_amd.physics import BatchedState
-    from tactics2d_amd.trajectory import BatchedTrajectory
+    from tactics2d_amd.history import BatchedTrajectory
     t = BatchedTrajectory(id_=7)
     assert len(t) == 0 and t.initial_state is None and t.last_state is None and t.first_frame is None and t.last_frame is None
     with pytest.raises(ValueError):
