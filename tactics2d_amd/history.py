@@ -74,8 +74,8 @@ class BatchedTrajectory:
             _log.warning("trajectory %s: state at time stamp %s overwritten", self.id_, frame)
         if self._stamps and frame < self._stamps[-1]:
             raise KeyError(f"trajectory {self.id_}: time stamp {frame} lies before the last one ({self._stamps[-1]})")
-        if len(self._by_frame) > 1 and self.stable_freq and \\
-                frame - self._stamps[-1] != self._stamps[-1] - self._stamps[-2]:
+        uneven = len(self._by_frame) > 1 and frame - self._stamps[-1] != self._stamps[-1] - self._stamps[-2]
+        if uneven and self.stable_freq:
             self.stable_freq = False
             _log.warning("trajectory %s: uneven time interval", self.id_)
         self._stamps.append(frame)
