@@ -22,6 +22,10 @@ import os
 import sys
 import time
 
+# HIP maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; streams sharing a queue serialise.  The env
+# groups below need one queue each next to torch's own streams -- must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -154,6 +158,8 @@ def main():
     ap.add_argument("--no-reset", action="store_true", help="skip the device-side auto-reset")
     ap.add_argument("--idm", action="store_true", help="non-ego vehicles driven by on-device IDM controllers (row f3); "
                     "adds the idm kernel to every step (not the metric configuration)")
+    ap.add_argument("--groups", type=int, default=0, help="env groups on separate HIP streams per GPU "
+                    "(0 = auto: 4 when the env count allows, else 1)")
     ap.add_argument("--split", action="store_true", help="two-kernel step (integrate + check_status) instead of the fused launch")
     args = ap.parse_args()
 
@@ -176,40 +182,62 @@ def main():
     n_env = args.envs or n_env
     agents = args.agents or agents
     scene = build_scene(args.config, n_env, agents, seed=rank)
-    pool = ParticipantPool(n_env, agents, device_id=local_rank)
-    scene.load(pool)
-    pool.set_integrator_variant(args.variant)
-    pool.set_fused_step(not args.split)
-    if not args.no_reset:
-        pool.set_auto_reset(True)   # finished envs restart inside the step launch (no extra kernels)
+    # env groups: independent envs cut into G pools on G HIP streams, so that one group's start-up latency and
+    # tail overlap the others' busy middle, and step k+1 of a group starts while step k of the next one still
+    # runs (tactics2d_amd/pipeline.py).  G = 1 is the plain single-launch step.
+    # auto: 4 groups once a group still fills the GPU's wave slots (>= 32 Ki participants per group); smaller
+    # pools are bound by the latency of one launch per step, which splitting does not shorten (measured: no gain)
+    G = args.groups if args.groups else (4 if n_env % 4 == 0 and n_env * agents >= 131072 else 1)
+    from tactics2d_amd.pipeline import EnvGroups
+    eg = EnvGroups(scene, G, device_id=local_rank)
     N = scene.n
+
+    def setup(p):
+        p.set_integrator_variant(args.variant)
+        p.set_fused_step(not args.split)
+        if not args.no_reset:
+            p.set_auto_reset(True)   # finished envs restart inside the step launch (no extra kernels)
+    eg.configure(setup)
     if args.idm:
         from tactics2d_amd.controller import IDMController, install
-        cid = np.full(N, L.IDM_NONE, np.uint8).reshape(n_env, agents)
-        veh = (scene.rows[scene.type_id, L.P_MODEL] != L.MODEL_POINTMASS).reshape(n_env, agents)
-        cid[:, 1:] = np.where(veh[:, 1:], 0, L.IDM_NONE)
-        install(pool, [IDMController(desired_speed=25.0, horizon=120.0)], cid.reshape(-1))
+        for (lo, hi), p in zip(eg.bounds, eg.pools):
+            sub = slice(lo * agents, hi * agents)
+            cid = np.full((hi - lo, agents), L.IDM_NONE, np.uint8)
+            veh = (scene.rows[scene.type_id[sub], L.P_MODEL] != L.MODEL_POINTMASS).reshape(hi - lo, agents)
+            cid[:, 1:] = np.where(veh[:, 1:], 0, L.IDM_NONE)
+            install(p, [IDMController(desired_speed=25.0, horizon=120.0)], cid.reshape(-1))
 
-    # actions: a ring of pre-generated batches resident in HBM, bound zero-copy each step
+    # actions: a ring of pre-generated batches resident in HBM, bound zero-copy (each group its slice)
     rng = np.random.default_rng(1000 + rank)
     ring = []
     for _ in range(4):
         a0, a1 = scene.sample_actions(rng)
         ring.append((torch.from_numpy(a0).to(dev), torch.from_numpy(a1).to(dev)))
-    records_t = torch.as_tensor(pool.device_array(L.F_RECORD), device=dev).view(torch.int32)
-    # N > 1: the per-env result records of 8 consecutive steps travel in one RCCL all-gather (rollout fragment)
+    # N > 1: the per-env result records of 8 consecutive steps travel in one RCCL all-gather per group (rollout
+    # fragment), issued on the group's stream so that it is ordered after that group's step kernels only
     gather_every = 8
-    gather = D.ResultGather(records_t, world, every=gather_every) if (world > 1 or os.environ.get("T2D_FORCE_GATHER")) else None
+    gathers = []
+    if world > 1 or os.environ.get("T2D_FORCE_GATHER"):
+        for p in eg.pools:
+            rec = torch.as_tensor(p.device_array(L.F_RECORD), device=dev).view(torch.int32)
+            gathers.append(D.ResultGather(rec, world, every=gather_every))
     step_no = [0]
-    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()
 
     def one_step(k):
         a0, a1 = ring[k & 3]
-        pool.bind_actions(a0.data_ptr(), a1.data_ptr())
-        pool.step(scene.interval_ms, stream)
-        if gather is not None:
-            gather.launch(step_no[0])
+        eg.bind_actions(a0, a1)
+        eg.step(scene.interval_ms)
+        if gathers:
+            for g, s in zip(gathers, eg.streams):
+                with torch.cuda.stream(s):
+                    g.launch(step_no[0])
         step_no[0] += 1
+
+    def drain():
+        for g, s in zip(gathers, eg.streams):
+            with torch.cuda.stream(s):
+                g.wait()
 
     def barrier():
         torch.cuda.synchronize()
@@ -219,52 +247,66 @@ def main():
 
     for k in range(args.warmup):
         one_step(k)
+    drain()
     barrier()
-    # ---- timed region: EXACTLY --steps steps, nothing but the step launches in it -------------
+    # ---- timed region: EXACTLY --steps steps, nothing but the step launches in it; the HIP events on the
+    # launch streams bracket the same region for the roofline's aggregate figure -------------------------
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    eg.fork()
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(k)
-    if gather is not None:
-        gather.wait()
+    host_enqueue_us = 1e6 * (time.perf_counter() - t0) / args.steps
+    drain()
+    ev_end = []
+    for s in eg.streams:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(s)
+        ev_end.append(e)
     barrier()
     elapsed = time.perf_counter() - t0
+    span_ms = max(ev0.elapsed_time(e) for e in ev_end)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline pass: the same steps again with HIP events recorded on the launch stream
-    # around every kernel (3 events / step cost ~15 us / step, so they stay out of `value`) ----
+    # ---- per-kernel pass: the same steps again with HIP events recorded on the launch streams around every
+    # kernel (event packets cost ~2 us per kernel, so they stay out of `value`) --------------------------
     kern = {}
+
+    def read_kernels(ids):
+        for kid, name in ids:
+            tot, cnt = 0.0, 0
+            for p in eg.pools:
+                ms, launches = p.profile_read(kid)
+                tot += ms; cnt += launches
+            if cnt:
+                kern[name] = dict(avg_us=1e3 * tot / cnt, launches=cnt)
+
     if not args.no_profile:
-        n_prof = min(args.steps, 2000)
-        pool.profile_enable(True)
+        n_prof = min(args.steps, 2000 // G)
+        eg.configure(lambda p: p.profile_enable(True))
         for k in range(n_prof):
             one_step(k)
-        if gather is not None:
-            gather.wait()
+        drain()
         barrier()
-        for kid, name in ((0, "integrate_kernel"), (1, "collide_kernel"), (2, "step_kernel"), (4, "idm_kernel")):
-            ms, launches = pool.profile_read(kid)
-            if launches:
-                kern[name] = dict(avg_us=1e3 * ms / launches, launches=launches)
+        read_kernels(((0, "integrate_kernel"), (1, "collide_kernel"), (2, "step_kernel"), (4, "idm_kernel")))
         if not args.split:   # also time the two stand-alone kernels (the integrator is north_star's roofline kernel)
-            pool.set_fused_step(False)
-            pool.profile_enable(True)
+            eg.configure(lambda p: (p.set_fused_step(False), p.profile_enable(True)))
             for k in range(min(n_prof, 200)):
                 one_step(k)
+            drain()
             barrier()
-            for kid, name in ((0, "integrate_kernel"), (1, "collide_kernel")):
-                ms, launches = pool.profile_read(kid)
-                if launches:
-                    kern[name] = dict(avg_us=1e3 * ms / launches, launches=launches)
-            pool.set_fused_step(True)
-        pool.profile_enable(False)
+            read_kernels(((0, "integrate_kernel"), (1, "collide_kernel")))
+            eg.configure(lambda p: p.set_fused_step(True))
+        eg.configure(lambda p: p.profile_enable(False))
 
     # state sanity after the run (not timed): flags/status distribution
-    flags = pool.download(L.F_FLAGS)
-    status = pool.download(L.F_STATUS)
-    x_end = pool.download(L.F_X)
+    flags = eg.download(L.F_FLAGS)
+    status = eg.download(L.F_STATUS)
+    x_end = eg.download(L.F_X)
     finite = bool(np.isfinite(x_end).all())
 
     if rank == 0:
@@ -276,35 +318,46 @@ def main():
         geo_bytes += 16 * n_env
         roof = None
         if kern:
-            per_launch = {"integrate_kernel": INTEGRATOR_BYTES * N, "collide_kernel": COLLIDE_BYTES * N + geo_bytes,
+            # ALGORITHMIC bytes of ONE launch = one env group of N / G participants
+            Ng, geo_g = N // G, geo_bytes / G
+            per_launch = {"integrate_kernel": INTEGRATOR_BYTES * Ng, "collide_kernel": COLLIDE_BYTES * Ng + geo_g,
                           # fused: the integrator's 44 B + the 4-B flag word (poses never leave registers)
-                          "step_kernel": (INTEGRATOR_BYTES + 4) * N + geo_bytes,
+                          "step_kernel": (INTEGRATOR_BYTES + 4) * Ng + geo_g,
                           # idm: x, y, heading, speed, ids, ctrl id in; 2 actions + leader out
-                          "idm_kernel": 33 * N}
+                          "idm_kernel": 33 * Ng}
             in_step = {"step_kernel"} if not args.split else {"integrate_kernel", "collide_kernel"}
             dom = max(in_step & set(kern), key=lambda k_: kern[k_]["avg_us"])
-            ach = per_launch[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            per_launch_gbs = per_launch[dom] / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            # G launches of the kernel are in flight at any time (one per env group / stream): the bandwidth the
+            # kernel achieves is the bytes of ALL its launches in the timed region over the HIP-event span of
+            # that region (for G = 1: bytes per launch / launch duration, launches being back to back)
+            ach = per_launch[dom] * G * args.steps / (span_ms * 1e-3) / 1e9
             traffic, traffic_src = None, None
             tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
-            if os.path.exists(tf):   # PMC counters cannot be read from inside the process: taken from the
-                tj = json.load(open(tf))  # committed rocprofv3 pass of the same workload (scripts/profile_round.sh)
-                if (tj.get("config"), tj.get("envs_per_gpu"), tj.get("participants_per_env")) == (args.config, n_env, agents):
-                    traffic = tj["hbm_bytes_per_launch"].get(dom)
-                    traffic_src = f"profiles/traffic_latest.json ({tj.get('tag')}): " + tj.get("source", "")
+            tj = json.load(open(tf)) if os.path.exists(tf) else {}
+            same = (tj.get("config"), tj.get("envs_per_gpu"), tj.get("participants_per_env"), tj.get("groups", 1)) == \
+                (args.config, n_env, agents, G)
+            if same:   # PMC counters cannot be read from inside the process: taken from the committed rocprofv3
+                traffic = tj["hbm_bytes_per_launch"].get(dom)       # pass of the same command (scripts/profile_round.sh)
+                traffic_src = f"profiles/traffic_latest.json ({tj.get('tag')}): " + tj.get("source", "")
             valu = None
-            if os.path.exists(tf):   # report VALU busy next to the HBM figure (the kernel is fp64-issue bound)
-                sq = json.load(open(tf)).get("sq_counters_per_dispatch", {}).get(dom)
-                if sq and traffic is not None:
-                    n_simd = 256 * 4
-                    kcyc = sq["SQ_BUSY_CYCLES"] / 32.0          # summed over 8 XCDs x 4 SEs
-                    valu = dict(busy_frac=4.0 * sq["SQ_ACTIVE_INST_VALU"] / (n_simd * kcyc),
-                                valu_insts_per_wave=sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"],
-                                kernel_cycles=kcyc, source="SQ_* counters of the committed rocprofv3 pass "
-                                "(profiles/traffic_latest.json); SQ_ACTIVE_INST_VALU counts quad-cycles")
+            sq = tj.get("sq_counters_per_dispatch", {}).get(dom) if same else None
+            if sq:     # report VALU busy next to the HBM figure (the kernel is fp64-issue bound)
+                n_simd = 256 * 4
+                kcyc = sq["SQ_BUSY_CYCLES"] / 32.0          # summed over 8 XCDs x 4 SEs
+                valu = dict(busy_frac=4.0 * sq["SQ_ACTIVE_INST_VALU"] / (n_simd * kcyc),
+                            valu_insts_per_wave=sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"], kernel_cycles=kcyc,
+                            source="SQ_* counters of the committed rocprofv3 pass (profiles/traffic_latest.json; PMC passes "
+                                   "serialise the launches); SQ_ACTIVE_INST_VALU counts quad-cycles")
             roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, valu=valu,
-                        timed_over="second pass of the same steps with HIP events on the launch stream around each kernel",
+                        concurrent_launches=G, launches_in_timed_region=G * args.steps, timed_region_event_span_ms=span_ms,
                         algorithmic_bytes_per_launch=per_launch[dom], avg_kernel_us=kern[dom]["avg_us"],
+                        per_launch_GBs=per_launch_gbs,
+                        how=(f"achieved = algorithmic_bytes_per_launch x launches_in_timed_region / HIP-event span of the timed "
+                             f"region on the launch streams; {G} launch(es) of the kernel run concurrently (one per env group), "
+                             f"so this is ~ concurrent_launches x per_launch_GBs; avg_kernel_us / per_launch_GBs are per launch, "
+                             f"timed with HIP events around each kernel in a second pass of the same steps"),
                         kernels={k_: dict(avg_us=v["avg_us"], launches=v["launches"],
                                           algorithmic_bytes=per_launch[k_],
                                           achieved_GBs=per_launch[k_] / (v["avg_us"] * 1e-6) / 1e9)
@@ -316,9 +369,11 @@ def main():
                    config=dict(workload=f"{scene.name}: {n_env} envs x {agents} participants per GPU, "
                                         f"interval 100 ms / delta_t 5 ms (20 Euler sub-steps), "
                                         f"integrator variant {args.variant}, {'two-kernel' if args.split else 'fused single-launch'} step, auto-reset "
-                                        f"{'off' if args.no_reset else 'on'}" + (", IDM agents on" if args.idm else ""),
-                               config=args.config, envs_per_gpu=n_env, participants_per_env=agents,
-                               parallelism=f"env-sharded x{world}, one async RCCL all-gather of the 8 B/env result records per {gather_every} steps"
+                                        f"{'off' if args.no_reset else 'on'}" + (", IDM agents on" if args.idm else "") +
+                                        (f", {G} env groups of {n_env // G} envs pipelined on {G} HIP streams" if G > 1 else ""),
+                               config=args.config, envs_per_gpu=n_env, participants_per_env=agents, env_groups=G,
+                               host_enqueue_us_per_step=host_enqueue_us,
+                               parallelism=f"env-sharded x{world}, per env group one async RCCL all-gather of the 8 B/env result records per {gather_every} steps"
                                if world > 1 else "single GPU"),
                    roofline=roof,
                    check=dict(state_finite=finite,
@@ -327,7 +382,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(out))
-    pool.close()
+    eg.close()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -268,6 +268,14 @@ int t2d_check_status(t2d_pool* pool, int32_t interval_ms, void* hip_stream);
  * bit-identical.  kernel_id 2 of t2d_profile_read times the fused launch.                   */
 int t2d_step(t2d_pool* pool, int32_t interval_ms, void* hip_stream);
 int t2d_set_fused_step(t2d_pool* pool, int32_t on);
+/* One step of n pools in a single call -- env groups on separate streams (independent environments cut into
+ * groups whose launches overlap: one group's start-up latency and tail hide behind the others' busy middle,
+ * DESIGN.md "Env groups").  For i in [0, n): if act0 / act1 are non-NULL, t2d_bind_actions(pools[i],
+ * act0[i], act1[i]); then t2d_step(pools[i], interval_ms, hip_streams[i]).  Exists because at ~6 us of GPU
+ * time per group and step, one host call per pool and per step is what limits the rate.  Returns the first
+ * error (its message is on that pool).                                                                  */
+int t2d_step_groups(t2d_pool* const* pools, const float* const* act0_dev, const float* const* act1_dev,
+                    void* const* hip_streams, int32_t n, int32_t interval_ms);
 
 /* Zero-copy device pointer of a field (for wrapping as a torch tensor).                 */
 int t2d_get_field(t2d_pool* pool, int32_t field_id, void** dev_ptr, size_t* nbytes);

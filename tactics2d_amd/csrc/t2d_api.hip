@@ -790,6 +790,17 @@ int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     return rc;
 }
 
+int t2d_step_groups(t2d_pool* const* pools, const float* const* act0_dev, const float* const* act1_dev,
+                    void* const* hip_streams, int32_t n, int32_t interval_ms) {
+    if (!pools || !hip_streams || n <= 0 || (act0_dev == nullptr) != (act1_dev == nullptr)) return T2D_ERR_INVALID;
+    for (int i = 0; i < n; ++i) {
+        int rc;
+        if (act0_dev && (rc = t2d_bind_actions(pools[i], act0_dev[i], act1_dev[i])) != T2D_OK) return rc;
+        if ((rc = t2d_step(pools[i], interval_ms, hip_streams[i])) != T2D_OK) return rc;
+    }
+    return T2D_OK;
+}
+
 int t2d_set_fused_step(t2d_pool* p, int32_t on) {
     if (!p) return T2D_ERR_INVALID;
     p->fused_step = on != 0;
