@@ -207,22 +207,36 @@ T2D_DEV StepOut step_dynamics(PF P, double x, double y, double phi, double v, do
     const double dt = (double)delta_t / 1000;
     const int n_steps = interval / delta_t;  // the remainder is never integrated (:143)
 
-    const double factor_f = (kG * lr - accel * hcg) / wb;
-    const double factor_r = (kG * lf + accel * hcg) / wb;
+    // the exact variant keeps the reference's IEEE divisions; the fast one multiplies by Newton reciprocals of the
+    // per-type constants (wb, lf, Iz) -- ~1e-16 relative, far inside the contract wherever the model is well conditioned
+    double factor_f, factor_r, mmi, tand, d_phi, beta;
+    if (VARIANT == 0) {
+        factor_f = (kG * lr - accel * hcg) / wb;
+        factor_r = (kG * lf + accel * hcg) / wb;
+        mmi = mu * mass / Iz;
+        tand = tan_det(delta);
+        d_phi = v / wb * tand;
+        beta = atan_det(lr / lf * tand);
+    } else {
+        const double inv_wb = rcp_nr(wb);
+        factor_f = (kG * lr - accel * hcg) * inv_wb;
+        factor_r = (kG * lf + accel * hcg) * inv_wb;
+        mmi = mu * mass * rcp_nr(Iz);
+        double sd, cd;
+        sincos_det(delta, sd, cd);
+        tand = sd * rcp_nr(cd);
+        d_phi = v * inv_wb * tand;
+        beta = atan_det(lr * rcp_nr(lf) * tand);
+    }
     const double lf_cf_ff = lf * cf * factor_f;
     const double lr_cr_fr = lr * cr * factor_r;
     const double lf2_cf_ff = lf * lf * cf * factor_f;
     const double lr2_cr_fr = lr * lr * cr * factor_r;
     const double cf_ff = cf * factor_f;
     const double cr_fr = cr * factor_r;
-    const double mmi = mu * mass / Iz;
     const double k21 = lr_cr_fr - lf_cf_ff;
     const double k34 = lf2_cf_ff + lr2_cr_fr;
     const double k65 = cr_fr + cf_ff;
-
-    const double tand = tan_det(delta);
-    double d_phi = v / wb * tand;
-    double beta = atan_det(lr / lf * tand);
 
     if (VARIANT == 0) {
         for (int k = 0; k < n_steps; ++k) {
@@ -259,7 +273,38 @@ T2D_DEV StepOut step_dynamics(PF P, double x, double y, double phi, double v, do
         double s, c;
         sincos_det(phi + beta, s, c);
         const double c1 = lf_cf_ff * delta, c2 = cf_ff * delta, ah = accel * dt;
-        for (int k = 0; k < n_steps; ++k) {
+        // The speed moves monotonically between v0 and clamp(v0 + n*ah): when both ends are at least 0.1 m/s
+        // (plus slack for the accumulated rounding) and of one sign for every lane of the wave, the |v| >= 0.1
+        // branch is taken in every sub-step and the loop below runs without the test, the v_safe guard and the
+        // low-speed code; constants are folded (mmi*dt) and phi / beta advance by fma.
+        const double v_lin = __builtin_fma((double)n_steps, ah, v);
+        const double v_fin = clip_v ? __builtin_fmin(__builtin_fmax(v_lin, vlo), vhi) : v_lin;
+        const bool always_fast = (v >= 0.1000001 && v_fin >= 0.1000001) || (v <= -0.1000001 && v_fin <= -0.1000001);
+        int k_done = 0;
+        if (__ballot(!always_fast) == 0ull) {
+            const double mmidt = mmi * dt;
+            for (int k = 0; k < n_steps; ++k) {
+                const double vh = v * dt;
+                x = __builtin_fma(vh, c, x);
+                y = __builtin_fma(vh, s, y);
+                const double r = rcp_nr1(v);
+                const double w = d_phi * r;
+                const double in1 = __builtin_fma(-k34, w, __builtin_fma(k21, beta, c1));
+                const double d_beta = __builtin_fma(mu * r, __builtin_fma(k21, w, __builtin_fma(-k65, beta, c2)), -d_phi);
+                d_phi = __builtin_fma(mmidt, in1, d_phi);
+                v += ah;
+                if (clip_v) v = __builtin_fmin(__builtin_fmax(v, vlo), vhi);
+                phi = __builtin_fma(d_phi, dt, phi);
+                beta = __builtin_fma(d_beta, dt, beta);
+                const double eps = (d_phi + d_beta) * dt;
+                const double aeps = __builtin_fabs(eps);
+                if (__ballot(aeps > kEpsTiny) == 0ull) rotate_tiny(eps, c, s);
+                else if (aeps <= kEpsMax) rotate_small(eps, c, s);
+                else sincos_det(phi + beta, s, c);
+            }
+            k_done = n_steps;
+        }
+        for (int k = k_done; k < n_steps; ++k) {
             const double vh = v * dt;
             x = __builtin_fma(vh, c, x);
             y = __builtin_fma(vh, s, y);
