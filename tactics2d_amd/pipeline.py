@@ -7,7 +7,7 @@ runs alone are exposed once per launch.  With G groups in flight those stretches
 busy middle of the others -- and the tail of step k overlaps the start of step k+1 of the next group, which a
 single launch per step cannot do (a kernel boundary is a device-wide barrier).  Measured on the metric scene
 (4096 envs x 64 participants): 32.2 us per step as one launch, 25.0 us as 2 groups, 23.5 us as 4 groups
-(scripts/exp_two_groups.py); 8 groups become host-launch bound.  Results are identical to the single-pool run.
+(scripts/env_groups_sweep.py); 8 groups become host-launch bound.  Results are identical to the single-pool run.
 
 In an RL loop the policy of group g+1 runs while the physics of group g does (the usual double-buffered
 vector env); `EnvGroups` is the plumbing for that.  torch supplies the streams (plumbing only).
