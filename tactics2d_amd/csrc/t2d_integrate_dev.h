@@ -159,8 +159,14 @@ T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, 
                                  __builtin_fabs(eps0) <= kEpsMax && __builtin_fabs(eps_end) <= kEpsMax;
         if (__ballot(!lane_linear) == 0ull) {
             double ce = 1.0, se = 0.0, cD = 1.0, sD = 0.0;
-            rotate_small(eps0, ce, se);  // (cos eps_0, sin eps_0)
-            rotate_small(dlt, cD, sD);   // |dlt| <= |eps_end - eps0| / n <= 2 kEpsMax / n
+            const double amax = __builtin_fmax(__builtin_fabs(eps0), __builtin_fabs(eps_end));
+            if (__ballot(amax > kEpsTiny) == 0ull) {  // the usual case: |sub-step angle| <= 0.01 rad in the whole wave
+                rotate_tiny(eps0, ce, se);
+                rotate_tiny(dlt, cD, sD);
+            } else {
+                rotate_small(eps0, ce, se);  // (cos eps_0, sin eps_0)
+                rotate_small(dlt, cD, sD);   // |dlt| <= |eps_end - eps0| / n <= 2 kEpsMax / n
+            }
             // v_k * dt advances by a constant, phi and v are the closed forms of their sums: 11 operations per sub-step
             double vh = v * dt;
             const double dvh = ah * dt;
