@@ -118,7 +118,7 @@ T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, 
         ovy = v * sp;
     } else {
         double sd, cd;
-        sincos_det(delta, sd, cd);
+        sincos_det_steer(delta, sd, cd);
         const double tw = sd * rcp_nr(cd * wb);  // tan(delta) / wb
         const double t = lr * tw;                // tan(beta)
         // cos(beta) = 1/sqrt(1+t^2), sin(beta) = t*cos(beta): no atan needed
@@ -231,7 +231,7 @@ T2D_DEV StepOut step_dynamics(PF P, double x, double y, double phi, double v, do
         factor_r = (kG * lf + accel * hcg) * inv_wb;
         mmi = mu * mass * rcp_nr(Iz);
         double sd, cd;
-        sincos_det(delta, sd, cd);
+        sincos_det_steer(delta, sd, cd);
         tand = sd * rcp_nr(cd);
         d_phi = v * inv_wb * tand;
         beta = atan_det(lr * rcp_nr(lf) * tand);

@@ -48,6 +48,31 @@ T2D_DEV void sincos_det(double x, double& s_out, double& c_out) {
     c_out = ((quad + 1) & 2) ? -c : c;
 }
 
+// sincos_det for |x| <= pi/4 in EVERY lane of the wave (caller checks with a ballot): the reduction quotient is 0,
+// r = x exactly, so the kernels alone give the very same bits without the rint / fma / quadrant selects.
+T2D_DEV void sincos_det_small(double r, double& s_out, double& c_out) {
+    double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
+    ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
+    ps = __builtin_fma(ps, z, -1.98412698298579493134e-04);
+    ps = __builtin_fma(ps, z, 8.33333333332248946124e-03);
+    ps = __builtin_fma(ps, z, -1.66666666666666324348e-01);
+    s_out = __builtin_fma(r * z, ps, r);
+    double pc = -1.13596475577881948265e-11;
+    pc = __builtin_fma(pc, z, 2.08757232129817482790e-09);
+    pc = __builtin_fma(pc, z, -2.75573143513906633035e-07);
+    pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
+    pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
+    pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+    c_out = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+}
+// steering angles: |delta| <= 0.7 rad practically always
+T2D_DEV void sincos_det_steer(double x, double& s_out, double& c_out) {
+    if (__ballot(!(__builtin_fabs(x) <= 0.78)) == 0ull) sincos_det_small(x, s_out, c_out);
+    else sincos_det(x, s_out, c_out);
+}
+
 T2D_DEV double tan_det(double x) {
     double s, c;
     sincos_det(x, s, c);
