@@ -451,7 +451,7 @@ int t2d_destroy(t2d_pool* p) {
                     p->d_last_pose, p->d_max_iou, p->d_min_dist, p->d_snap_min_dist, p->d_last_valid,
                     p->d_lidar_env_off, p->d_lidar_next, p->d_lidar_xy, p->d_beam_sin, p->d_beam_cos,
                     p->d_snap[0], p->d_snap[1], p->d_snap[2],
-                    p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_idm_rows, p->d_idm_ctrl, p->d_snap_omega[0], p->d_snap_omega[1]};
+                    p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_idm_rows, p->d_idm_ctrl, p->d_snap_omega[0], p->d_snap_omega[1], p->d_time_penalty};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->prof_events) {
@@ -618,6 +618,19 @@ int t2d_set_status_config(t2d_pool* p, const t2d_status_config* cfg) {
     if (cfg->ego_index < 0 || cfg->ego_index >= p->v.A)
         return fail(p, T2D_ERR_INVALID, "ego_index out of range");
     p->status_cfg = *cfg;
+    // time-penalty term of ParkingEnv._get_reward (envs/parking.py:156-158) for every possible step count: the
+    // epilogue then reads one double instead of evaluating tanh on one lane at the very end of the wave
+    T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, hipDeviceSynchronize());
+    std::vector<double> tp;
+    if (cfg->max_step > 0 && cfg->max_step <= (1 << 24)) {
+        tp.resize((size_t)cfg->max_step + 1);
+        for (int c = 0; c <= cfg->max_step; ++c)
+            tp[c] = -tanh((double)c / (double)cfg->max_step) * (double)cfg->time_penalty_scale;
+    }
+    int rc = dev_replace(p, &p->d_time_penalty, tp.data(), tp.size());
+    if (rc != T2D_OK) return rc;
+    p->v.time_penalty = p->d_time_penalty;
     return T2D_OK;
 }
 

@@ -498,6 +498,13 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         pv.applied1[idx] = (float)o.app1;
     }
     T2D_MARK(13);
+    // the time-penalty of the step count this step will reach (table built by t2d_set_status_config); pre_cnt has
+    // arrived by now, and this load's latency hides behind the event phases
+    double pre_tp = 0.0;
+    if (WITH_STATUS && valid && agent == 0 && pv.time_penalty && cfg.max_step > 0) {
+        const int c = pre_cnt + 1;
+        pre_tp = pv.time_penalty[c < cfg.max_step ? c : cfg.max_step];
+    }
     if (FUSE >= 0 && valid && pv.boundary) {  // L2-resident by now (16 B per env)
         const float4 b = reinterpret_cast<const float4*>(pv.boundary)[env];
         bxmin = b.x; bxmax = b.y; bymin = b.z; bymax = b.w;
@@ -869,7 +876,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             else if (scen == T2D_SCENARIO_COMPLETED) rd = cfg.reward_completed;
             else if (traf == T2D_TRAFFIC_COLLISION_DYNAMIC || traf == T2D_TRAFFIC_OFF_LANE) rd = cfg.reward_collision;
             else {
-                rd = cfg.max_step > 0 ? -tanh((double)cnt / (double)cfg.max_step) * (double)cfg.time_penalty_scale : 0.0;
+                rd = cfg.max_step > 0 ? (pv.time_penalty ? pre_tp : -tanh((double)cnt / (double)cfg.max_step) * (double)cfg.time_penalty_scale) : 0.0;
                 if (cfg.shaped_reward) {
                     double mi = pv.max_iou[env];
                     double iou_reward = 0.0;

@@ -63,6 +63,7 @@ struct PoolView {
     double* max_iou;           // [E] ParkingEnv._max_iou
     double* min_dist;          // [E] ParkingEnv._min_dist_to_target
     const double* snap_min_dist;  // [E] value at the snapshot (episode start)
+    const double* time_penalty;   // [max_step + 1] -tanh(cnt / max_step) * time_penalty_scale (host libm), or null
     float* iou;                // [E] last IoU(pose, target), NaN = None
     const float* snap[6];      // episode-start snapshot (x, y, heading, speed, vx, vy) or null
     const uint32_t* snap_ids;
@@ -132,6 +133,7 @@ struct t2d_pool {
     int32_t *d_lidar_env_off = nullptr, *d_lidar_next = nullptr;
     float* d_lidar_xy = nullptr;
     double *d_beam_sin = nullptr, *d_beam_cos = nullptr;
+    double* d_time_penalty = nullptr;
     bool has_drift = false;   // a T2D_MODEL_DRIFT row is in the parameter table
     float* d_snap_omega[2]{};
     // IDM agents (row f3)
