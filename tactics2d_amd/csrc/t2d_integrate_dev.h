@@ -153,8 +153,13 @@ T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, 
         // operations per sub-step instead of 21.  Decided once per step and per wave: if any lane
         // would clip its speed or leave the small-angle range during this step, the whole wave
         // takes the generic loop.
-        const double v_end = v + (double)n_steps * ah;
-        const double eps0 = v * kh, eps_end = v_end * kh, dlt = ah * kh;
+        // a lane sitting exactly on a speed bound with the acceleration pushing outwards stays there for the whole
+        // step (clip(bound + ah) = bound): linear with zero effective acceleration.  (Cyclists braked to their lower
+        // bound 0 would otherwise send their whole wave through the plain loop on every step.)
+        const bool pinned = clip_v && ((v == vhi && ah >= 0.0) || (v == vlo && ah <= 0.0));
+        const double ah_l = pinned ? 0.0 : ah;
+        const double v_end = v + (double)n_steps * ah_l;
+        const double eps0 = v * kh, eps_end = v_end * kh, dlt = ah_l * kh;
         const bool lane_linear = (!clip_v || (v >= vlo && v <= vhi && v_end >= vlo && v_end <= vhi)) &&
                                  __builtin_fabs(eps0) <= kEpsMax && __builtin_fabs(eps_end) <= kEpsMax;
         if (__ballot(!lane_linear) == 0ull) {
@@ -169,7 +174,7 @@ T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, 
             }
             // v_k * dt advances by a constant, phi and v are the closed forms of their sums: 11 operations per sub-step
             double vh = v * dt;
-            const double dvh = ah * dt;
+            const double dvh = ah_l * dt;
             for (int k = 0; k < n_steps; ++k) {
                 x = __builtin_fma(vh, c, x);
                 y = __builtin_fma(vh, s, y);
