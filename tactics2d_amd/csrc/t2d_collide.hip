@@ -50,7 +50,7 @@ namespace {
 #endif
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
-constexpr int kQueueCap = 256;  // queue entries per wave per round
+constexpr int kQueueCap = 320;  // queue entries per wave per round (also holds the broad phase's 3 x 96 staging floats)
 constexpr int kMaxHeads = 512;  // EPB * H when the hash grid is in use (A_pad = 128 or 256)
 constexpr double kRejectMargin = 1e-6;
 
@@ -283,7 +283,7 @@ T2D_DEV void wave_sync() {
 // rounds of kQueueCap entries.  Slots are handed out by one LDS atomic per lane on the wave's
 // counter (cheaper than a 6-step shuffle scan; the order of entries is irrelevant).  Must be
 // called by all 64 lanes of the wave (mask 0 for idle lanes).
-template <bool SWAP, class F>
+template <bool SWAP, bool RING = false, class F>
 T2D_DEV void compact_and_process(unsigned long long mask, int id_base, int own_id, uint32_t* queue, int* qcount,
                                  int lane, F process) {
     // entry = participant | other << 8.  SWAP = false: this lane is the participant (own_id = tid)
@@ -300,8 +300,14 @@ T2D_DEV void compact_and_process(unsigned long long mask, int id_base, int own_i
         for (int e = 0; e < n_emit; ++e) {
             const int a = __ffsll((long long)mask) - 1;
             mask &= mask - 1ull;
-            queue[off + e] = SWAP ? (uint32_t)(id_base + a) | ((uint32_t)own_id << 8)
-                                  : (uint32_t)own_id | ((uint32_t)(id_base + a) << 8);
+            if (RING) {  // bit a = the participant a + 1 lanes further round the wave (pair broad phase, env == wave)
+                const int other = id_base + ((lane + 1 + a) & 63);
+                queue[off + e] = own_id < other ? (uint32_t)own_id | ((uint32_t)other << 8)
+                                                : (uint32_t)other | ((uint32_t)own_id << 8);
+            } else {
+                queue[off + e] = SWAP ? (uint32_t)(id_base + a) | ((uint32_t)own_id << 8)
+                                      : (uint32_t)own_id | ((uint32_t)(id_base + a) << 8);
+            }
         }
         wave_sync();
         const int total = *qcount;
@@ -661,13 +667,18 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             // that agent a lands on bit a.  Inactive lanes are parked at x = 1e30 (distance^2 = inf).
             typedef float f2 __attribute__((ext_vector_type(2)));
             float* const bx = reinterpret_cast<float*>(queue);
-            float* const by = bx + 64;
-            float* const bR = by + 64;
-            static_assert(3 * 64 <= kQueueCap, "broad-phase staging must fit in the wave's queue");
+            float* const by = bx + 96;
+            float* const bR = by + 96;
+            static_assert(3 * 96 <= kQueueCap, "broad-phase staging must fit in the wave's queue");
             const float px = active ? fx : 1e30f;
             bx[lane] = px;
             by[lane] = fy;
             bR[lane] = R32;
+            if (log2A == 6 && lane < 32) {  // entries 64..95 repeat 0..31: the ring sweep below reads lane + offset
+                bx[64 + lane] = px;
+                by[64 + lane] = fy;
+                bR[64 + lane] = R32;
+            }
             wave_sync();
             const f2 px2 = {px, px}, py2 = {fy, fy}, pR2 = {R32, R32};
             uint32_t half[2] = {0u, 0u};
@@ -694,14 +705,32 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             };
             using K1 = std::integral_constant<int, 1>;
             using K4 = std::integral_constant<int, 4>;
-            if (log2A == 6) {  // env == wave: constant trip counts, fully unrolled
+            if (log2A == 6) {
+                // env == wave: every unordered pair once -- lane i looks at the 32 participants i + 1 .. i + 32 round
+                // the wave (offset d lands on bit d - 1; offset 32 is seen from both ends and kept by the lower half)
+                uint32_t h = 0u;
 #pragma unroll
-                for (int hb = 1; hb >= 0; --hb) {
-                    uint32_t h = 0u;
+                for (int top = 25; top >= 1; top -= 8) {   // offsets top + 7 ... top, four pairs per batch
+                    f2 ox[4], oy[4], oR[4];
 #pragma unroll
-                    for (int top = 24; top >= 0; top -= 8) batch(h, hb * 32 + top, K4{});
-                    half[hb] = h;
+                    for (int k = 0; k < 4; ++k) {
+                        const int i0 = lane + top + 2 * (3 - k);   // offsets i0 - lane (lo half) and i0 - lane + 1 (hi half)
+                        ox[k] = f2{bx[i0], bx[i0 + 1]};
+                        oy[k] = f2{by[i0], by[i0 + 1]};
+                        oR[k] = f2{bR[i0], bR[i0 + 1]};
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f2 dx = px2 - ox[k], dy = py2 - oy[k], rr = pR2 + oR[k];
+                        const f2 q = __builtin_elementwise_fma(dy, dy, dx * dx), r = rr * rr;
+                        asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                                     : "+v"(h) : "v"(q.y), "v"(r.y) : "vcc");
+                        asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                                     : "+v"(h) : "v"(q.x), "v"(r.x) : "vcc");
+                    }
                 }
+                if (lane >= 32) h &= 0x7fffffffu;
+                half[0] = h;
             } else {           // several envs per wave: A_pad in {2 .. 32} agents from my env's first lane
                 const int first = lane & ~(A_pad - 1);
                 uint32_t h = 0u;
@@ -715,9 +744,13 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             cand = (unsigned long long)half[0] | ((unsigned long long)half[1] << 32);
         }
         T2D_MARK(3);
-        cand &= ~((2ull << agent) - 1ull);  // partners with a higher index only: each pair once
         if (!active) cand = 0ull;
-        compact_and_process<false>(cand, (env_local << log2A), tid, queue, qcount, lane, process_pair);
+        if (log2A == 6) {
+            compact_and_process<false, true>(cand, (env_local << log2A), tid, queue, qcount, lane, process_pair);
+        } else {
+            cand &= ~((2ull << agent) - 1ull);  // partners with a higher index only: each pair once
+            compact_and_process<false>(cand, (env_local << log2A), tid, queue, qcount, lane, process_pair);
+        }
     } else {
         // spatial-hash walk; pairs go straight to the narrow phase (i < j de-duplicates)
         if (active) {
