@@ -411,17 +411,26 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             has_boundary = pv.boundary_valid ? pv.boundary_valid[env] != 0 : true;
         }
     }
-    if (FUSE >= 0) {  // full parameter table -> LDS (<= 12 x 8 B per thread, loads issued together)
+    if (FUSE >= 0) {  // full parameter table -> LDS, loads issued together (one exposed latency)
         constexpr int kTab = kTabCols * T2D_MAX_TYPES;
-        double tstage[12];
+        if (nthreads == kBlock) {   // the usual launch shape: 3 x 8 B per thread, no per-load bounds logic
+            static_assert(kTab <= 3 * kBlock && kTab > 2 * kBlock, "staging below assumes 2 full rounds + a partial one");
+            const double t0 = pv.params[tid], t1 = pv.params[tid + kBlock];
+            const double t2 = tid + 2 * kBlock < kTab ? pv.params[tid + 2 * kBlock] : 0.0;
+            s_partab[tid] = t0;
+            s_partab[tid + kBlock] = t1;
+            if (tid + 2 * kBlock < kTab) s_partab[tid + 2 * kBlock] = t2;
+        } else {                    // workgroups narrowed by the geometry budget (64 or 128 threads)
+            double tstage[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            tstage[k] = 0.0;
-            if (k * 64 < kTab && tid + k * nthreads < kTab) tstage[k] = pv.params[tid + k * nthreads];
+            for (int k = 0; k < 12; ++k) {
+                tstage[k] = 0.0;
+                if (k * 64 < kTab && tid + k * nthreads < kTab) tstage[k] = pv.params[tid + k * nthreads];
+            }
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+                if (k * 64 < kTab && tid + k * nthreads < kTab) s_partab[tid + k * nthreads] = tstage[k];
         }
-#pragma unroll
-        for (int k = 0; k < 12; ++k)
-            if (k * 64 < kTab && tid + k * nthreads < kTab) s_partab[tid + k * nthreads] = tstage[k];
     }
     double par_stage[2] = {0.0, 0.0};  // events only: 4 shape columns x 32 types, <= 2 per thread
     if (FUSE < 0) {
