@@ -447,11 +447,19 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     constexpr int kBatch = 8;
     const uint4* gsrc = reinterpret_cast<const uint4*>(pv.geo + (size_t)blockIdx.x * gl.stride);
     {
+        // rounds of 16-B loads this record needs (wave-uniform): 1 for the metric scenes (<= 4 KiB per workgroup) --
+        // the unrolled generic form spends more on its per-load bounds logic than on the loads
+        const int rounds = (n_vec + nthreads - 1) / nthreads;
         uint4 geo_stage[kBatch];
+        if (rounds <= 1) {
+            geo_stage[0] = make_uint4(0, 0, 0, 0);
+            if (tid < n_vec) geo_stage[0] = gsrc[tid];
+        } else {
 #pragma unroll
-        for (int k = 0; k < kBatch; ++k) {
-            geo_stage[k] = make_uint4(0, 0, 0, 0);
-            if (tid + k * nthreads < n_vec) geo_stage[k] = gsrc[tid + k * nthreads];
+            for (int k = 0; k < kBatch; ++k) {
+                geo_stage[k] = make_uint4(0, 0, 0, 0);
+                if (tid + k * nthreads < n_vec) geo_stage[k] = gsrc[tid + k * nthreads];
+            }
         }
         if (use_hash_grid)
             for (int k = tid; k < EPB * H; k += nthreads) s_head[k] = -1;
@@ -465,9 +473,13 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                 if (q < 4 * T2D_MAX_TYPES && (k == 0 || nthreads < 4 * T2D_MAX_TYPES)) s_partab[q] = par_stage[k];
             }
         }
+        if (rounds <= 1) {
+            if (tid < n_vec) reinterpret_cast<uint4*>(s_geo)[tid] = geo_stage[0];
+        } else {
 #pragma unroll
-        for (int k = 0; k < kBatch; ++k)
-            if (tid + k * nthreads < n_vec) reinterpret_cast<uint4*>(s_geo)[tid + k * nthreads] = geo_stage[k];
+            for (int k = 0; k < kBatch; ++k)
+                if (tid + k * nthreads < n_vec) reinterpret_cast<uint4*>(s_geo)[tid + k * nthreads] = geo_stage[k];
+        }
     }
     for (int base = kBatch * nthreads; base < n_vec; base += kBatch * nthreads) {  // big records only
         uint4 g2[kBatch];
