@@ -285,28 +285,39 @@ T2D_DEV void wave_sync() {
 // called by all 64 lanes of the wave (mask 0 for idle lanes).
 template <bool SWAP, bool RING = false, class F>
 T2D_DEV void compact_and_process(unsigned long long mask, int id_base, int own_id, uint32_t* queue, int* qcount,
-                                 int lane, F process) {
+                                 int lane, F process, bool narrow = false) {
     // entry = participant | other << 8.  SWAP = false: this lane is the participant (own_id = tid)
     // and the bits name the other object (id_base + bit); SWAP = true: this lane owns the other
     // object (own_id = polygon index) and the bits name participants (id_base + bit).
+    // narrow (wave-uniform): every lane's mask fits in 32 bits -- the emit loop then runs on half the registers.
+    auto entry = [&](int a) -> uint32_t {
+        if (RING) {  // bit a = the participant a + 1 lanes further round the wave (pair broad phase, env == wave)
+            const int other = id_base + ((lane + 1 + a) & 63);
+            return own_id < other ? (uint32_t)own_id | ((uint32_t)other << 8) : (uint32_t)other | ((uint32_t)own_id << 8);
+        }
+        return SWAP ? (uint32_t)(id_base + a) | ((uint32_t)own_id << 8) : (uint32_t)own_id | ((uint32_t)(id_base + a) << 8);
+    };
     for (;;) {
-        const int cnt = __popcll(mask);
+        const int cnt = narrow ? __popc((uint32_t)mask) : __popcll(mask);
         if (__ballot(cnt > 0) == 0ull) break;
         if (lane == 0) *qcount = 0;
         wave_sync();
         const int off = cnt > 0 ? atomicAdd(qcount, cnt) : kQueueCap;
         const int room = kQueueCap - off;
         const int n_emit = room <= 0 ? 0 : (cnt < room ? cnt : room);
-        for (int e = 0; e < n_emit; ++e) {
-            const int a = __ffsll((long long)mask) - 1;
-            mask &= mask - 1ull;
-            if (RING) {  // bit a = the participant a + 1 lanes further round the wave (pair broad phase, env == wave)
-                const int other = id_base + ((lane + 1 + a) & 63);
-                queue[off + e] = own_id < other ? (uint32_t)own_id | ((uint32_t)other << 8)
-                                                : (uint32_t)other | ((uint32_t)own_id << 8);
-            } else {
-                queue[off + e] = SWAP ? (uint32_t)(id_base + a) | ((uint32_t)own_id << 8)
-                                      : (uint32_t)own_id | ((uint32_t)(id_base + a) << 8);
+        if (narrow) {
+            uint32_t m = (uint32_t)mask;
+            for (int e = 0; e < n_emit; ++e) {
+                const int a = __ffs((int)m) - 1;
+                m &= m - 1u;
+                queue[off + e] = entry(a);
+            }
+            mask = m;
+        } else {
+            for (int e = 0; e < n_emit; ++e) {
+                const int a = __ffsll((long long)mask) - 1;
+                mask &= mask - 1ull;
+                queue[off + e] = entry(a);
             }
         }
         wave_sync();
@@ -767,7 +778,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         T2D_MARK(3);
         if (!active) cand = 0ull;
         if (log2A == 6) {
-            compact_and_process<false, true>(cand, (env_local << log2A), tid, queue, qcount, lane, process_pair);
+            compact_and_process<false, true>(cand, (env_local << log2A), tid, queue, qcount, lane, process_pair, true);
         } else {
             cand &= ~((2ull << agent) - 1ull);  // partners with a higher index only: each pair once
             compact_and_process<false>(cand, (env_local << log2A), tid, queue, qcount, lane, process_pair);
@@ -837,8 +848,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                 unsigned long long m = box_sweep(p0 + c0, cn);
                 if (!active) m = 0ull;
                 T2D_MARK(5 + 2 * kd);
-                if (kd == 0) compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_static);
-                else compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_lane);
+                if (kd == 0) compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_static, cn <= 32);
+                else compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_lane, cn <= 32);
                 T2D_MARK(6 + 2 * kd);
             }
         } else {
