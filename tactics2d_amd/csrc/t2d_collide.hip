@@ -23,14 +23,16 @@
 //      box of the pose.
 //   2. broad phase -> compacted work queues -> dense narrow phase, three times (participant
 //      pairs, static polygons, lane polygons):
-//        * pairs: envs that fit a wave (A_pad <= 64) compare bounding circles with cross-lane
-//          shuffles (fp32, 1 cm margin, no LDS traffic) and keep only partners j > i, so each
-//          unordered pair is tested once; larger envs walk an LDS spatial-hash grid (cell >=
+//        * pairs: envs that fit a wave (A_pad <= 64) stage (x, y, R) in LDS and compare bounding circles on
+//          packed fp32 (two partners per v_pk_* instruction, 1 cm margin), each verdict shifted into the lane's
+//          candidate word by v_cmp + v_addc; an env that IS a wave sweeps a ring (lane i against i+1 .. i+32),
+//          so each unordered pair is tested once; larger envs walk an LDS spatial-hash grid (cell >=
 //          largest circum-diameter, atomicExch-built linked lists).
-//        * polygons: a branch-free AABB pass over the env's polygons in the LDS record.
-//      Survivors are compacted with a wave prefix sum into a per-wave LDS queue and processed
+//        * polygons: a branch-free box sweep over the env's polygons in the LDS record (same packed / addc form).
+//      Survivors are compacted (one LDS atomic per lane) into a per-wave LDS queue and processed
 //      one entry per lane -- dense lanes instead of per-lane divergent loops, and no register-
-//      resident per-participant state, which keeps the kernel at 4 waves / SIMD without spills.
+//      resident per-participant state, which keeps the kernel at 4 waves / SIMD.  Odd waves visit the
+//      polygon stages before the pair stage so that a SIMD's waves are not in the same kind of stretch together.
 //      The narrow phase is the oracle's arithmetic: fp64 separating-axis test with strict
 //      separation (touching counts, like shapely), results OR-ed into LDS with atomics.
 //   3. per-env OR of the flags; one lane per env runs the status epilogue.
@@ -38,6 +40,7 @@
 // Every predicate is the exact arithmetic of oracle/t2d_oracle.c (same operation order,
 // -ffp-contract=off, deterministic trig); broad phases are strictly conservative, so flags are
 // bit-exact against the oracle's brute force.
+// With FUSE >= 0 the same kernel first integrates its participants in registers (t2d_step = one launch).
 // Bound: fp64 VALU issue + LDS latency (about 20 B of HBM per participant); see DESIGN.md.
 #include "t2d_integrate_dev.h"
 
