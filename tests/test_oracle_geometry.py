@@ -140,3 +140,84 @@ def test_oracle_batch_loops_do_not_depend_on_thread_count(oracle):
         res.append((o.copy(), f.copy(), ef.copy()))
     assert np.array_equal(res[0][0], res[1][0], equal_nan=True)
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+def _exact_convex_intersects(A, B):
+    """Closed-set `intersects` of two convex CCW polygons in EXACT rational arithmetic: they are disjoint iff some
+    edge of one has every vertex of the other strictly on its outer side (separating-axis theorem for convex sets;
+    touching and containment count).  This is what GEOS's robust predicates compute for shapely's `intersects`."""
+    from fractions import Fraction
+    FA = [(Fraction(float(x)), Fraction(float(y))) for x, y in A]
+    FB = [(Fraction(float(x)), Fraction(float(y))) for x, y in B]
+
+    def separates(P, Q):
+        n = len(P)
+        for i in range(n):
+            (px, py), (qx, qy) = P[i], P[(i + 1) % n]
+            if (px, py) == (qx, qy):
+                continue
+            if all((qx - px) * (ry - py) - (qy - py) * (rx - px) < 0 for rx, ry in Q):
+                return True
+        return False
+    return not (separates(FA, FB) or separates(FB, FA))
+
+
+def test_intersects_against_exact_rational_arithmetic(oracle):
+    """Pins the fp64 orientation-sign SAT of the oracle (= the GPU's predicate) against exact arithmetic on the very
+    same binary64 inputs: random convex quads, and adversarial families that touch exactly (shared edge segments,
+    vertex on edge, shared corner -- dyadic coordinates, so 'touching' is exact) or miss by one fp64 ulp."""
+    rng = np.random.default_rng(2024)
+    n_checked = n_touch = 0
+
+    def check(A, B):
+        nonlocal n_checked
+        want = _exact_convex_intersects(A, B)
+        got = bool(oracle.convex_intersects(np.float64(A), np.float64(B)))
+        assert got == want, (A, B, got, want)
+        n_checked += 1
+        return want
+
+    def quad(cx, cy, L, W, th):
+        c, s = np.cos(th), np.sin(th)
+        loc = np.array([[L / 2, -W / 2], [L / 2, W / 2], [-L / 2, W / 2], [-L / 2, -W / 2]])
+        return loc @ np.array([[c, s], [-s, c]]) + [cx, cy]
+
+    for _ in range(1500):          # generic position: boxes of vehicle size at vehicle distances
+        A = quad(rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(2, 6), rng.uniform(1, 2.5), rng.uniform(0, 6.3))
+        d = rng.uniform(0, 7); a = rng.uniform(0, 6.3)
+        B = quad(A[:, 0].mean() + d * np.cos(a), A[:, 1].mean() + d * np.sin(a), rng.uniform(2, 6), rng.uniform(1, 2.5),
+                 rng.uniform(0, 6.3))
+        check(A, B)
+    for _ in range(600):           # exactly touching, dyadic coordinates: axis-parallel boxes sharing an edge piece / a corner
+        x0, y0 = rng.integers(-400, 400, 2) / 8.0
+        w, h_ = rng.integers(1, 40, 2) / 8.0
+        A = np.array([[x0, y0], [x0 + w, y0], [x0 + w, y0 + h_], [x0, y0 + h_]])
+        kind = rng.integers(0, 3)
+        w2, h2 = rng.integers(1, 40, 2) / 8.0
+        if kind == 0:    # shared edge segment (to the right of A)
+            y1 = y0 + rng.integers(-8, 8) / 8.0
+            B = np.array([[x0 + w, y1], [x0 + w + w2, y1], [x0 + w + w2, y1 + h2], [x0 + w, y1 + h2]])
+            expect = (y1 <= y0 + h_) and (y1 + h2 >= y0)
+        elif kind == 1:  # shared corner only
+            B = np.array([[x0 + w, y0 + h_], [x0 + w + w2, y0 + h_], [x0 + w + w2, y0 + h_ + h2], [x0 + w, y0 + h_ + h2]])
+            expect = True
+        else:            # a vertex of a 45-degree diamond exactly on A's right edge
+            cy = y0 + rng.integers(0, int(h_ * 8) + 1) / 8.0
+            r = rng.integers(1, 24) / 8.0
+            B = np.array([[x0 + w, cy], [x0 + w + r, cy - r], [x0 + w + 2 * r, cy], [x0 + w + r, cy + r]])
+            expect = True
+        n_touch += 1
+        assert check(A, B) == expect
+        # ... and the same pair pulled apart by one ulp must not intersect, pushed together must
+        Bm = B.copy(); Bm[:, 0] = np.nextafter(Bm[:, 0], np.inf)
+        if kind != 0 or expect:
+            assert check(A, Bm) is False or kind == 0 and not expect
+    for _ in range(400):           # near-collinear edges at vehicle scale: rotated copies nudged along the normal by a few ulps
+        th = rng.uniform(0, 6.3)
+        A = quad(rng.uniform(-100, 100), rng.uniform(-100, 100), 4.5, 1.8, th)
+        n = np.array([-np.sin(th), np.cos(th)])
+        B = quad(A[:, 0].mean() + 1.8 * n[0], A[:, 1].mean() + 1.8 * n[1], 4.5, 1.8, th)   # side by side, ~touching
+        k = int(rng.integers(-3, 4))
+        B = B + n * k * np.spacing(100.0)
+        check(A, B)
+    assert n_checked > 3000 and n_touch == 600
