@@ -288,14 +288,14 @@ T2D_DEV void wave_sync() {
 // called by all 64 lanes of the wave (mask 0 for idle lanes).
 template <bool SWAP, bool RING = false, class F>
 T2D_DEV void compact_and_process(unsigned long long mask, int id_base, int own_id, uint32_t* queue, int* qcount,
-                                 int lane, F process, bool narrow = false) {
+                                 int lane, F process, bool narrow = false, int ring_mask = 63) {
     // entry = participant | other << 8.  SWAP = false: this lane is the participant (own_id = tid)
     // and the bits name the other object (id_base + bit); SWAP = true: this lane owns the other
     // object (own_id = polygon index) and the bits name participants (id_base + bit).
     // narrow (wave-uniform): every lane's mask fits in 32 bits -- the emit loop then runs on half the registers.
     auto entry = [&](int a) -> uint32_t {
-        if (RING) {  // bit a = the participant a + 1 lanes further round the wave (pair broad phase, env == wave)
-            const int other = id_base + ((lane + 1 + a) & 63);
+        if (RING) {  // bit a = the participant a + 1 places further round its env (pair broad phase, env <= wave)
+            const int other = id_base + ((own_id - id_base + 1 + a) & ring_mask);
             return own_id < other ? (uint32_t)own_id | ((uint32_t)other << 8) : (uint32_t)other | ((uint32_t)own_id << 8);
         }
         return SWAP ? (uint32_t)(id_base + a) | ((uint32_t)own_id << 8) : (uint32_t)own_id | ((uint32_t)(id_base + a) << 8);
@@ -706,86 +706,64 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             float* const bR = by + 96;
             static_assert(3 * 96 <= kQueueCap, "broad-phase staging must fit in the wave's queue");
             const float px = active ? fx : 1e30f;
-            bx[lane] = px;
-            by[lane] = fy;
-            bR[lane] = R32;
-            if (log2A == 6 && lane < 32) {  // entries 64..95 repeat 0..31: the ring sweep below reads lane + offset
-                bx[64 + lane] = px;
-                by[64 + lane] = fy;
-                bR[64 + lane] = R32;
+            // every env of the wave gets a segment of 1.5 * A_pad entries: its agents, then its first half again, so
+            // that the ring sweep below reads agent + offset without wrapping (64 / A_pad segments: 96 entries in all)
+            const int n_off = A_pad >> 1;                           // partners per lane: agent + 1 .. agent + A_pad / 2
+            const int slot = (lane >> log2A) * (A_pad + n_off) + agent;
+            bx[slot] = px;
+            by[slot] = fy;
+            bR[slot] = R32;
+            if (agent < n_off) {
+                bx[slot + A_pad] = px;
+                by[slot + A_pad] = fy;
+                bR[slot + A_pad] = R32;
             }
             wave_sync();
             const f2 px2 = {px, px}, py2 = {fy, fy}, pR2 = {R32, R32};
-            uint32_t half[2] = {0u, 0u};
-            // K pairs per batch: all 3K LDS reads are issued before the first compare, so one LDS latency
-            // is exposed per batch instead of per pair
-            auto batch = [&](uint32_t& h, int top, auto kc) {   // agents top + 2K - 1 ... top
+            // Ring sweep: lane (agent a) looks at the n_off partners a + 1 .. a + n_off round its env, so every unordered
+            // pair is tested once (offset d lands on bit d - 1; offset n_off is seen from both ends and kept by the
+            // lower half).  K pairs of offsets per batch: all 3K (unaligned 2 x 4 B) LDS reads are issued before the
+            // first compare, so one LDS latency is exposed per batch instead of per pair.
+            uint32_t h = 0u;
+            auto batch = [&](uint32_t& hh, int top, auto kc) {   // offsets top + 2K - 1 ... top
                 constexpr int K = decltype(kc)::value;
                 f2 ox[K], oy[K], oR[K];
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    ox[k] = *reinterpret_cast<const f2*>(&bx[top + 2 * (K - 1 - k)]);
-                    oy[k] = *reinterpret_cast<const f2*>(&by[top + 2 * (K - 1 - k)]);
-                    oR[k] = *reinterpret_cast<const f2*>(&bR[top + 2 * (K - 1 - k)]);
+                    const int i0 = slot + top + 2 * (K - 1 - k);   // offsets i0 - slot (.x) and i0 - slot + 1 (.y)
+                    ox[k] = f2{bx[i0], bx[i0 + 1]};
+                    oy[k] = f2{by[i0], by[i0 + 1]};
+                    oR[k] = f2{bR[i0], bR[i0 + 1]};
                 }
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const f2 dx = px2 - ox[k], dy = py2 - oy[k], rr = pR2 + oR[k];
                     const f2 q = __builtin_elementwise_fma(dy, dy, dx * dx), r = rr * rr;
                     asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                                 : "+v"(h) : "v"(q.y), "v"(r.y) : "vcc");
+                                 : "+v"(hh) : "v"(q.y), "v"(r.y) : "vcc");
                     asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                                 : "+v"(h) : "v"(q.x), "v"(r.x) : "vcc");
+                                 : "+v"(hh) : "v"(q.x), "v"(r.x) : "vcc");
                 }
             };
             using K1 = std::integral_constant<int, 1>;
             using K4 = std::integral_constant<int, 4>;
-            if (log2A == 6) {
-                // env == wave: every unordered pair once -- lane i looks at the 32 participants i + 1 .. i + 32 round
-                // the wave (offset d lands on bit d - 1; offset 32 is seen from both ends and kept by the lower half)
-                uint32_t h = 0u;
+            if (log2A == 6) {          // env == wave: constant trip count, fully unrolled
 #pragma unroll
-                for (int top = 25; top >= 1; top -= 8) {   // offsets top + 7 ... top, four pairs per batch
-                    f2 ox[4], oy[4], oR[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int i0 = lane + top + 2 * (3 - k);   // offsets i0 - lane (lo half) and i0 - lane + 1 (hi half)
-                        ox[k] = f2{bx[i0], bx[i0 + 1]};
-                        oy[k] = f2{by[i0], by[i0 + 1]};
-                        oR[k] = f2{bR[i0], bR[i0 + 1]};
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const f2 dx = px2 - ox[k], dy = py2 - oy[k], rr = pR2 + oR[k];
-                        const f2 q = __builtin_elementwise_fma(dy, dy, dx * dx), r = rr * rr;
-                        asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                                     : "+v"(h) : "v"(q.y), "v"(r.y) : "vcc");
-                        asm volatile("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                                     : "+v"(h) : "v"(q.x), "v"(r.x) : "vcc");
-                    }
-                }
-                if (lane >= 32) h &= 0x7fffffffu;
-                half[0] = h;
-            } else {           // several envs per wave: A_pad in {2 .. 32} agents from my env's first lane
-                const int first = lane & ~(A_pad - 1);
-                uint32_t h = 0u;
-                if (A_pad >= 8) {
-                    for (int top = A_pad - 8; top >= 0; top -= 8) batch(h, first + top, K4{});
-                } else {
-                    for (int top = A_pad - 2; top >= 0; top -= 2) batch(h, first + top, K1{});
-                }
-                half[0] = h;
+                for (int top = 25; top >= 1; top -= 8) batch(h, top, K4{});
+            } else if (n_off >= 8) {   // A_pad = 16 or 32
+                for (int top = n_off - 7; top >= 1; top -= 8) batch(h, top, K4{});
+            } else if (n_off >= 2) {   // A_pad = 4 or 8
+                for (int top = n_off - 1; top >= 1; top -= 2) batch(h, top, K1{});
+            } else {                   // A_pad = 2: the one partner
+                const float dx = px - bx[slot + 1], dy = fy - by[slot + 1], rr = R32 + bR[slot + 1];
+                h = (dx * dx + dy * dy <= rr * rr) ? 1u : 0u;
             }
-            cand = (unsigned long long)half[0] | ((unsigned long long)half[1] << 32);
+            if (agent >= n_off) h &= ~(1u << (n_off - 1));   // the pair at offset n_off belongs to its lower agent
+            cand = h;
         }
         T2D_MARK(3);
         if (!active) cand = 0ull;
-        if (log2A == 6) {
-            compact_and_process<false, true>(cand, (env_local << log2A), tid, queue, qcount, lane, process_pair, true);
-        } else {
-            cand &= ~((2ull << agent) - 1ull);  // partners with a higher index only: each pair once
-            compact_and_process<false>(cand, (env_local << log2A), tid, queue, qcount, lane, process_pair);
-        }
+        compact_and_process<false, true>(cand, (env_local << log2A), tid, queue, qcount, lane, process_pair, true, A_pad - 1);
     } else {
         // spatial-hash walk; pairs go straight to the narrow phase (i < j de-duplicates)
         if (active) {
