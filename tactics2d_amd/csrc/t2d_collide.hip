@@ -464,15 +464,19 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         // rounds of 16-B loads this record needs (wave-uniform): 1 for the metric scenes (<= 4 KiB per workgroup) --
         // the unrolled generic form spends more on its per-load bounds logic than on the loads
         const int rounds = (n_vec + nthreads - 1) / nthreads;
-        uint4 geo_stage[kBatch];
+        uint4 geo_stage0 = make_uint4(0, 0, 0, 0);
         if (rounds <= 1) {
-            geo_stage[0] = make_uint4(0, 0, 0, 0);
-            if (tid < n_vec) geo_stage[0] = gsrc[tid];
+            if (tid < n_vec) geo_stage0 = gsrc[tid];
         } else {
-#pragma unroll
-            for (int k = 0; k < kBatch; ++k) {
-                geo_stage[k] = make_uint4(0, 0, 0, 0);
-                if (tid + k * nthreads < n_vec) geo_stage[k] = gsrc[tid + k * nthreads];
+            // big records (many envs or many polygons per workgroup, e.g. 32 parking lots = 30 KiB for 32 threads):
+            // global_load_lds -- 16 B per lane straight into LDS at M0 + lane * 16, no staging registers -- so ALL
+            // rounds are in flight together and one memory latency is exposed instead of one per 8 loads
+            for (int k = 0; k < rounds; ++k) {
+                const int q = tid + k * nthreads;
+                if (q < n_vec)
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(gsrc + q),
+                        (__attribute__((address_space(3))) void*)(s_geo + 4 * (k * nthreads + (tid & ~63))), 16, 0, 0);
             }
         }
         if (use_hash_grid)
@@ -488,24 +492,10 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             }
         }
         if (rounds <= 1) {
-            if (tid < n_vec) reinterpret_cast<uint4*>(s_geo)[tid] = geo_stage[0];
+            if (tid < n_vec) reinterpret_cast<uint4*>(s_geo)[tid] = geo_stage0;
         } else {
-#pragma unroll
-            for (int k = 0; k < kBatch; ++k)
-                if (tid + k * nthreads < n_vec) reinterpret_cast<uint4*>(s_geo)[tid + k * nthreads] = geo_stage[k];
+            __builtin_amdgcn_s_waitcnt(0);  // the LDS-direct loads are tracked by vmcnt: all landed before the barrier
         }
-    }
-    for (int base = kBatch * nthreads; base < n_vec; base += kBatch * nthreads) {  // big records only
-        uint4 g2[kBatch];
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k) {
-            g2[k] = make_uint4(0, 0, 0, 0);
-            if (base + tid + k * nthreads < n_vec) g2[k] = gsrc[base + tid + k * nthreads];
-        }
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k)
-            if (base + tid + k * nthreads < n_vec)
-                reinterpret_cast<uint4*>(s_geo)[base + tid + k * nthreads] = g2[k];
     }
     __syncthreads();  // (a) tables cleared, type columns + geometry record staged
     T2D_MARK(0);
