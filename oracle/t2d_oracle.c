@@ -14,8 +14,14 @@
  *              in /root/reference, not installed, and whose results no reference test pins.
  *              The predicates below restate shapely's documented *semantics* (closed-set
  *              `intersects`, `contains`) on the reference's own vertex construction, and are
- *              pinned by hand-built KATs (tests/golden/geometry_kats.json) plus an independent
- *              cross-check against matplotlib.path (tests/test_oracle_geometry.py).
+ *              pinned by hand-built KATs (tests/golden/geometry_kats.json), an independent
+ *              cross-check against matplotlib.path and, for `intersects` and the IoU, exact rational
+ *              arithmetic on the same binary64 inputs (tests/test_oracle_geometry.py,
+ *              tests/test_iou_events.py) -- the mathematical values GEOS evaluates robustly.
+ *   IDM controller, verify_state, SingleTrackDrift : PINNED by golden vectors produced by running the
+ *              reference (oracle/gen_golden_idm.py, gen_golden_verify.py, gen_golden_drift.py).
+ *   lidar    : the reference module imports shapely (cannot run here): oracle/lidar_ref.py restates its
+ *              numpy expression sequence; PARITY UNPINNED against the reference itself.
  *
  * Every function cites the reference file:line it follows (paths relative to the
  * tactics2d repo root).  Arithmetic is IEEE fp64, evaluated left-to-right exactly as the
