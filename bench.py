@@ -415,7 +415,7 @@ def main():
                    check=dict(state_finite=finite,
                               flag_rates=[float((flags & b).astype(bool).mean()) for b in (1, 2, 4, 8)],
                               truncated_frac=float(status[:, 3].mean())))
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only (the other ranks would sit in the barrier)
             out["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(out))
     eg.close()
