@@ -167,7 +167,11 @@ def main():
     from tactics2d_amd import dist as D, layout as L
     from tactics2d_amd.pool import ParticipantPool
 
-    rank, local_rank, world = D.init_process_group("nccl")
+    # (T2D_DIST_BACKEND / T2D_FORCE_DEVICE exist to exercise the N > 1 code path on a one-GPU box: gloo, every rank on
+    # the same device; never set in a real run)
+    rank, local_rank, world = D.init_process_group(os.environ.get("T2D_DIST_BACKEND", "nccl"))
+    if "T2D_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["T2D_FORCE_DEVICE"])
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available():
