@@ -17,8 +17,12 @@ with torch's own streams in the process, 4 groups need GPU_MAX_HW_QUEUES >= 8 in
 runtime initialises (bench.py sets it; measured 39 us per step with the default 4 queues, 23.6 us with 8).
 """
 import ctypes as C
+import os
 
 import numpy as np
+
+# effective only if the HIP runtime has not initialised yet (import this module before the first GPU call)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from . import _ffi, layout as L
 from .pool import ParticipantPool
