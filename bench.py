@@ -147,8 +147,8 @@ def cpu_baseline(scene, target_seconds=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="metric", help="metric | cfg2 | cfg3 | cfg4 | cfg5")
     ap.add_argument("--envs", type=int, default=None, help="environments PER GPU")
     ap.add_argument("--agents", type=int, default=None)
