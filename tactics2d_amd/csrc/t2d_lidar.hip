@@ -27,6 +27,7 @@ namespace {
 constexpr int kLidarBlock = 128;
 constexpr int kLidarQueue = 256;  // (beam, edge) candidates per wave per round
 
+// (returns the squared distance; see the note at its end)
 T2D_DEV double lidar_edge(double a, double b, double lx, double ly, double R, double x1, double y1, double x2,
                           double y2) {
     const double tz = 1e-8, tinf = R * 10;
@@ -47,7 +48,7 @@ T2D_DEV double lidar_edge(double a, double b, double lx, double ly, double R, do
     if (ry > (y1 > y2 ? y1 : y2) + tz) ry = tinf;
     if (ry < (y1 < y2 ? y1 : y2) - tz) ry = tinf;
     if (parallel) rx = tinf;
-    return __builtin_sqrt(rx * rx + ry * ry);
+    return rx * rx + ry * ry;   // SQUARED distance: sqrt is monotone, so the per-beam minimum takes one sqrt at the end
 }
 
 // Beam-index span of an edge given in the sensor frame: {first beam, number of further beams} or
@@ -102,6 +103,18 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     const int A = pv.A;
     const size_t base = (size_t)env * A;
     const double kFar = 1e30;  // an edge nobody can see: yields >= 10 R for every beam, like no edge at all
+#ifdef T2D_TIMING
+    unsigned long long lt_prev_ = __builtin_readcyclecounter();
+    const size_t lt_slot_ = ((size_t)env * (kLidarBlock / 64) + (tid >> 6)) * 16;
+#define T2D_LMARK(k)                                                                  \
+    do {                                                                              \
+        const unsigned long long now_ = __builtin_readcyclecounter();                 \
+        if ((tid & 63) == 0) pv.dbg[lt_slot_ + k] = now_ - lt_prev_;                  \
+        lt_prev_ = now_;                                                              \
+    } while (0)
+#else
+#define T2D_LMARK(k)
+#endif
 
     if (tid == 0) {
         const size_t ie = base + lv.ego_index;
@@ -117,6 +130,7 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     }
     __syncthreads();
     const double cs = s_ego[0], sn = s_ego[1], x_off = s_ego[2], y_off = s_ego[3];
+    T2D_LMARK(0);
 
     // ---- phase 1a: static polygon edges (vertex v -> next vertex of its ring) ------------------------
     int n_static = 0;
@@ -175,6 +189,7 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     }
     __syncthreads();
 
+    T2D_LMARK(1);
     // ---- phase 2: beams x candidate edges ------------------------------------------------------------------
     // Pass 1 (edge-major scatter of the spans into per-beam candidate masks, see below).  Pass 2: the candidates of the
     // wave's 64 beams are compacted into an LDS queue and evaluated one per lane (dense lanes: the rounds needed
@@ -212,6 +227,7 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
             }
         }
         __syncthreads();
+        T2D_LMARK(2);
         for (int it = 0; it < n_iter; ++it) {
             const int k = tid + it * kLidarBlock;
             unsigned long long m = k < lv.n_beams ? s_mask[k] : 0ull;
@@ -243,6 +259,7 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
                 wave_sync();
             }
         }
+        T2D_LMARK(3);
         __syncthreads();  // the next chunk clears s_mask
     }
     wave_sync();
@@ -250,12 +267,13 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     for (int k = tid; k < lv.n_beams; k += kLidarBlock) {
         float res = __builtin_inff();
         if (scan) {
-            double best = __longlong_as_double((long long)s_best[k]);
+            double best = __builtin_sqrt(__longlong_as_double((long long)s_best[k]));   // min of sqrt = sqrt of min, bit for bit
             best = best < 0.0 ? 0.0 : (best > R ? R : best);   // np.clip(0, R)
             res = best == R ? __builtin_inff() : (float)best;
         }
         o[k] = res;
     }
+    T2D_LMARK(4);
 }
 
 }  // namespace
