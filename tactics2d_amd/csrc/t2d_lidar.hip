@@ -52,8 +52,8 @@ T2D_DEV double lidar_edge(double a, double b, double lx, double ly, double R, do
 }
 
 // Beam-index span of an edge given in the sensor frame: {first beam, number of further beams} or
-// {0, -1} = invisible.  Beams are at angles k * dbeam.  fp32 is enough: the span is widened by a full
-// beam on each side (dbeam >= 1.5e-3 rad for n_beams <= 4096, fp32 atan2 error ~1e-6).
+// {0, -1} = invisible.  Beams are at angles k * dbeam.  fp32 is enough: the span is widened by the error
+// margin derived below (>= 0.1 beam).
 T2D_DEV int2 edge_span(double x1, double y1, double x2, double y2, double R, int n_beams) {
     const float fx1 = (float)x1, fy1 = (float)y1, fx2 = (float)x2, fy2 = (float)y2;
     const float ex = fx2 - fx1, ey = fy2 - fy1;
@@ -76,9 +76,16 @@ T2D_DEV int2 edge_span(double x1, double y1, double x2, double y2, double R, int
     const float sweep = fabsf(da);
     if (start < 0.0f) start += twopi;
     const float inv = (float)n_beams / twopi;
-    int k0 = (int)floorf(start * inv) - 1;
-    const int len = (int)ceilf(sweep * inv) + 3;
-    if (len >= n_beams) return make_int2(0, n_beams);
+    // beams k with start - m <= k * dbeam <= start + sweep + m.  m covers the fp32 error of the end-point angles:
+    // coordinates good to ~2e-6 m seen from the nearer end point's distance (>= 1 mm here), atan2f's ~1e-6 rad, the
+    // reference's own 1e-8 m segment slack, plus 0.1 beam of plain margin
+    const float rmin2 = d1 < d2 ? d1 : d2;
+    const float mb = 0.1f + inv * (1e-5f + 4e-6f * __builtin_amdgcn_rsqf(rmin2 > 1e-6f ? rmin2 : 1e-6f));
+    int k0 = (int)ceilf(start * inv - mb);
+    const int k1 = (int)floorf((start + sweep) * inv + mb);
+    const int len = k1 - k0;                                    // number of FURTHER beams after k0
+    if (len < 0) return make_int2(0, -1);                       // the arc falls between two beams
+    if (len + 1 >= n_beams) return make_int2(0, n_beams);
     k0 %= n_beams;
     if (k0 < 0) k0 += n_beams;
     return make_int2(k0, len);
