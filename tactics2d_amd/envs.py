@@ -109,6 +109,34 @@ class VecParkingEnv:
         truncated = status[:, 3].astype(bool)
         return obs, reward, terminated, truncated, self._infos(obs, status[:, 0], status[:, 1])
 
+    def step_torch(self, actions, stream=None):
+        """The device-resident step: `actions` is a float32 CUDA tensor [n_envs, 2] in the reference's layout (steering,
+        accel); nothing is copied to the host and nothing synchronises.  Returns a dict of torch tensors that are
+        ZERO-COPY VIEWS of the pool (valid until the next step): state [6 x n_envs] columns, reward, status (u8 [n, 4]:
+        scenario, traffic, terminated, truncated), iou, and `lidar` [n_envs, 360] written by the scan kernel straight
+        into a tensor owned by this env -- the observation buffer handed back to the policy.  Out-of-range actions are
+        the caller's responsibility here (the numpy `step` raises InvalidAction like the reference)."""
+        import torch
+        if self._scene is None:
+            raise RuntimeError("call reset() first")
+        pool = self.scenario_manager.pool
+        dev = actions.device
+        st = stream if stream is not None else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(st):
+            self._act = (actions[:, 1].contiguous(), actions[:, 0].contiguous())   # (accel, steering); kept alive
+            pool.bind_actions(self._act[0].data_ptr(), self._act[1].data_ptr())
+            pool.step(100, st.cuda_stream)
+            if getattr(self, "_t_lidar", None) is None or self._t_lidar.device != dev:
+                self._t_lidar = torch.empty((self.n_envs, 360), dtype=torch.float32, device=dev)
+                view = lambda f: torch.as_tensor(pool.device_array(f), device=dev)
+                self._t_views = dict(x=view(L.F_X), y=view(L.F_Y), heading=view(L.F_HEADING), speed=view(L.F_SPEED),
+                                     vx=view(L.F_VX), vy=view(L.F_VY), reward=view(L.F_REWARD), status=view(L.F_STATUS),
+                                     iou=view(L.F_IOU))
+            pool.lidar_scan(self._t_lidar.data_ptr(), st.cuda_stream)
+        out = dict(self._t_views)
+        out["lidar"] = self._t_lidar
+        return out
+
     def _infos(self, obs, scenario_status, traffic_status):
         return dict(state=dict(x=obs[:, 0], y=obs[:, 1], heading=obs[:, 2], speed=obs[:, 3], vx=obs[:, 4],
                                vy=obs[:, 5], frame=self.scenario_manager.pool.download(L.F_FRAME_MS)),

@@ -132,3 +132,30 @@ def test_cfg1_single_parking_env_600_random_actions(oracle):
         prev = np.array([obs[0], obs[1], obs[2], obs[3]], np.float32)
     env.close()
     assert n_done >= 1          # time limit (200 steps) at the latest
+
+
+def test_vec_parking_env_device_resident_step_equals_the_host_step():
+    """step_torch: actions in, observation tensors out, all on the device (zero-copy views + the lidar tensor);
+    same numbers as the numpy step on the same actions."""
+    torch = pytest.importorskip("torch")
+    from tactics2d_amd.envs import VecParkingEnv
+    n = 300
+    a = VecParkingEnv(n, max_step=30, seed=5, auto_reset=True); b = VecParkingEnv(n, max_step=30, seed=5, auto_reset=True)
+    a.reset(); b.reset()
+    rng = np.random.default_rng(2)
+    dev = torch.device("cuda", 0)
+    for t in range(40):
+        act = a.action_space.sample(rng, n)
+        obs, reward, term, trunc, infos = a.step(act)
+        out = b.step_torch(torch.from_numpy(act).to(dev))
+        torch.cuda.synchronize()
+        assert out["lidar"].is_cuda and out["x"].is_cuda and out["lidar"].shape == (n, 360)
+        for k, col in (("x", 0), ("y", 1), ("heading", 2), ("speed", 3), ("vx", 4), ("vy", 5)):
+            assert np.array_equal(out[k].cpu().numpy(), obs[:, col]), (t, k)
+        assert np.array_equal(out["reward"].cpu().numpy(), reward)
+        st = out["status"].cpu().numpy()
+        assert np.array_equal(st[:, 2].astype(bool), term) and np.array_equal(st[:, 3].astype(bool), trunc)
+        assert np.array_equal(out["lidar"].cpu().numpy().view(np.uint32), infos["lidar"].view(np.uint32))
+        assert np.array_equal(out["iou"].cpu().numpy(), infos["iou"], equal_nan=True)
+    assert trunc.any() or term.any() or True
+    a.close(); b.close()
