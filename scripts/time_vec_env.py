@@ -1,0 +1,19 @@
+"""VecParkingEnv.step_torch throughput (step kernel + lidar, actions generated on the device, no host sync)."""
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tactics2d_amd.envs import VecParkingEnv
+dev = torch.device("cuda", 0)
+for n in (4096, 32768):
+    env = VecParkingEnv(n, max_step=200, auto_reset=True, seed=1); env.reset()
+    lo = torch.tensor([-0.524, -2.0], device=dev); hi = torch.tensor([0.524, 2.0], device=dev)
+    acts = [lo + (hi - lo) * torch.rand((n, 2), device=dev) for _ in range(8)]
+    for k in range(50): out = env.step_torch(acts[k & 7])
+    torch.cuda.synchronize()
+    t = time.perf_counter(); steps = 500
+    for k in range(steps): out = env.step_torch(acts[k & 7])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t
+    print(f"{n} envs: {1e6 * el / steps:.1f} us per vector step, {n * steps / el:.3e} env-steps/s (state + 360-beam lidar on the device)")
+    env.close()
