@@ -116,8 +116,8 @@ int prepare_polys(t2d_pool* p, const int32_t* env_off, const int32_t* vert_off, 
     return T2D_OK;
 }
 
-int log2_pad(int A) {
-    int l = 0;
+int log2_pad(int A) {  // lanes per env = 2^l >= A, at least 2: the second lane of a one-agent env evaluates the Arrival IoU
+    int l = 1;        // while the first evaluates the NoAction IoU (one SIMT pass instead of two calls in a row)
     while ((1 << l) < A) ++l;
     return l;
 }

@@ -857,6 +857,32 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     if (log2A <= 6) wave_sync(); else __syncthreads();  // (d)
     T2D_MARK(11);
 
+    // IoU pre-pass: the two quad-IoUs an ego may need -- NoAction (pose vs previous pose) and Arrival (pose vs target
+    // bay) -- are evaluated by lanes 0 and 1 of the env IN THE SAME SIMT PASS (one trip through quad_iou, not two in a
+    // row on one lane: ~5 us of the ~22 us parking step).  Whether the values are used is decided by the epilogue
+    // below exactly as before; an unused value is simply dropped.
+    double iou_na = 0.0, iou_ar = 0.0;
+    if (WITH_STATUS && (cfg.check_no_action || cfg.check_arrival)) {
+        const int ego_l = (env_local << log2A) + cfg.ego_index;
+        const bool env_ok = env < pv.n_env && agent < 2;
+        bool want = false;
+        const double* other = nullptr;
+        if (env_ok && s_kind[ego_l] == T2D_SHAPE_OBB) {
+            if (agent == 0 && cfg.check_no_action && pv.last_valid[env]) {
+                want = true;
+                other = pv.last_pose + 8 * (size_t)env;
+            } else if (agent == 1 && cfg.check_arrival && pv.target_xy) {
+                want = true;
+                other = pv.target_xy + 8 * (size_t)env;
+            }
+        }
+        double v = 0.0;
+        if (__ballot(want) != 0ull) {
+            if (want) v = quad_iou(&s_v[0][ego_l], other);
+        }
+        iou_na = v;
+        iou_ar = __shfl_down(v, 1);   // lane 0 of the env receives lane 1's value (same wave: 2^log2A >= 2 lanes per env)
+    }
     if (valid && agent == 0) {
         pv.env_flags[env] = s_env_or[env_local];
         if (WITH_STATUS) {
@@ -879,7 +905,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                     if (!pv.last_valid[env]) {
                         pv.last_valid[env] = 1;
                     } else {
-                        cna = quad_iou(&s_v[0][ego], last) > (double)cfg.no_action_iou ? cna + 1 : 0;
+                        cna = iou_na > (double)cfg.no_action_iou ? cna + 1 : 0;
                         pv.cnt_na[env] = cna;
                     }
 #pragma unroll
@@ -900,7 +926,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                 } else if (cfg.check_off_lane && (ef & T2D_FLAG_OFF_LANE)) {
                     scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_OFF_LANE;
                 } else if (cfg.check_arrival && pv.target_xy && ego_obb) {  // Arrival.update (arrival.py:42-47)
-                    iou = quad_iou(&s_v[0][ego], pv.target_xy + 8 * (size_t)env);
+                    iou = iou_ar;
                     has_iou = true;
                     if (iou >= (double)cfg.arrival_threshold) scen = T2D_SCENARIO_COMPLETED;
                 }
@@ -979,7 +1005,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
 
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
                           int interval_ms, int fuse_variant, hipStream_t s) {
-    int log2A = 0;
+    int log2A = 1;   // at least two lanes per env (see log2_pad in t2d_api.hip)
     while ((1 << log2A) < v.A) ++log2A;
     const int EPB = v.geo_layout.epb;
     const dim3 grid((v.n_env + EPB - 1) / EPB), block(EPB << log2A);
