@@ -354,6 +354,34 @@ int t2d_idm_actions(t2d_pool* pool, const int32_t* forced_leader_dev, void* hip_
 int t2d_verify_state(t2d_pool* pool, const float* x_dev, const float* y_dev, const float* heading_dev,
                      const float* speed_dev, int32_t interval_ms, uint8_t* valid_dev, void* hip_stream);
 
+/* Reset-time scene synthesis: ParkingLotGenerator.generate
+ * (map/generator/generate_parking_lot.py:239-444) for n_env independent scenes, one lane per scene, on `device_id`.
+ * PARITY UNPINNED against the reference: it draws from numpy's global MT19937 stream and evaluates its predicates in
+ * shapely (neither available to this build), so the kernel follows the reference's distributions, draw order, control
+ * flow and predicates (closed `intersects`, `distance`, `contains`) on a counter-based stream of its own
+ * (oracle/t2d_oracle.c: t2do_generate_parking states it; the two agree bit for bit).  Scene e uses stream
+ * (seed, first_env + e): a sharded job generates the same scenes whatever the number of ranks.
+ * Outputs are HOST arrays (the call synchronises): quads [n_env][T2D_GEN_MAX_QUADS][4][2] fp32 obstacle quads in
+ * Map.areas order (same id replaces: map.py:444-453), quad_id their reference ids (-1 = unused slot), n_quads,
+ * start [n_env][3] = x, y, heading (fp64, heading not wrapped: +pi when flipped, :409-419), target [n_env][4][2],
+ * target_heading (fp64), boundary [n_env][4] = xmin, xmax, ymin, ymax (:436-440), info = T2D_GEN_* bits |
+ * obstacle attempts << 8 | start attempts << 16.  The reference's rejection loops are unbounded; here an env whose
+ * loop hits the cap is returned with T2D_GEN_UNVERIFIED / T2D_GEN_START_UNVERIFIED set, never silently.        */
+#define T2D_GEN_MAX_QUADS 12
+#define T2D_GEN_MAX_ATTEMPTS 8
+#define T2D_GEN_MAX_START_ATTEMPTS 64
+#define T2D_GEN_BAY 0x01u              /* mode == "bay" (else "parallel") */
+#define T2D_GEN_UNVERIFIED 0x02u       /* _verify_obstacles still False after T2D_GEN_MAX_ATTEMPTS */
+#define T2D_GEN_START_UNVERIFIED 0x04u /* _verify_start_state still False after T2D_GEN_MAX_START_ATTEMPTS */
+#define T2D_GEN_NONCONVEX 0x08u        /* an obstacle quad is not convex (the event kernels need convex polygons) */
+#define T2D_GEN_OVERFLOW 0x10u         /* more than T2D_GEN_MAX_QUADS distinct ids / obstacle list full */
+#define T2D_GEN_START_FLIPPED 0x20u
+#define T2D_GEN_TARGET_FLIPPED 0x40u
+int t2d_generate_parking(int32_t device_id, uint64_t seed, int64_t first_env, int32_t n_env, double type_proportion,
+                         double vehicle_length, double vehicle_width, float* quads, int32_t* quad_id,
+                         int32_t* n_quads, double* start, float* target, double* target_heading, float* boundary,
+                         uint32_t* info);
+
 /* Kernel variants: 0 = exact (library-grade fp64 trig every sub-step), 1 = fast
  * (rotation recurrence, default).  Both satisfy the 1e-5 contract; see DESIGN.md.       */
 int t2d_set_integrator_variant(t2d_pool* pool, int32_t variant);

@@ -387,3 +387,30 @@ def lidar(rows, n_env, A, ego_index, x, y, heading, type_id, active, static, inc
       np.ascontiguousarray(type_id, np.uint8), np.ascontiguousarray(active, np.uint8), sp[0], sp[1], sp[2],
       int(include_participants), int(n_beams), float(max_range), bs, bc, int(trig), out.reshape(-1))
     return out
+
+
+GEN_MAX_QUADS = 12
+GEN_BAY, GEN_UNVERIFIED, GEN_START_UNVERIFIED, GEN_NONCONVEX, GEN_OVERFLOW = 1, 2, 4, 8, 16
+GEN_START_FLIPPED, GEN_TARGET_FLIPPED = 32, 64
+
+
+def generate_parking(seed, n_env, type_proportion=0.5, vehicle_size=(5.3, 2.5), first_env=0, trig=1):
+    """ParkingLotGenerator.generate restated for n_env scenes (row f4; parity unpinned, see t2d_oracle.c).
+    Returns a dict of arrays: quads (n, 12, 4, 2) f32, quad_id (n, 12), n_quads (n,), start (n, 3) f64,
+    target (n, 4, 2) f32, target_heading (n,) f64, boundary (n, 4) f32, info (n,) u32."""
+    out = dict(quads=np.zeros((n_env, GEN_MAX_QUADS, 4, 2), np.float32), quad_id=np.zeros((n_env, GEN_MAX_QUADS), np.int32),
+               n_quads=np.zeros(n_env, np.int32), start=np.zeros((n_env, 3)), target=np.zeros((n_env, 4, 2), np.float32),
+               target_heading=np.zeros(n_env), boundary=np.zeros((n_env, 4), np.float32), info=np.zeros(n_env, np.uint32))
+    f = lib().t2do_generate_parking
+    f.restype = None
+    f.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double, _f32p,
+                  np.ctypeslib.ndpointer(np.int32, flags="C"), np.ctypeslib.ndpointer(np.int32, flags="C"), _f64p, _f32p,
+                  _f64p, _f32p, np.ctypeslib.ndpointer(np.uint32, flags="C")]
+    lib().t2do_set_trig(trig)
+    try:
+        f(int(seed), int(first_env), int(n_env), float(type_proportion), float(vehicle_size[0]), float(vehicle_size[1]),
+          out["quads"], out["quad_id"], out["n_quads"], out["start"], out["target"], out["target_heading"],
+          out["boundary"], out["info"])
+    finally:
+        lib().t2do_set_trig(0)
+    return out

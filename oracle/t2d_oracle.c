@@ -20,6 +20,9 @@
  *              tests/test_iou_events.py) -- the mathematical values GEOS evaluates robustly.
  *   IDM controller, verify_state, SingleTrackDrift : PINNED by golden vectors produced by running the
  *              reference (oracle/gen_golden_idm.py, gen_golden_verify.py, gen_golden_drift.py).
+ *   ParkingLotGenerator : PARITY UNPINNED (numpy global MT19937 stream + shapely predicates; no reference test
+ *              of its output).  t2do_generate_parking restates distributions, draw order, control flow and
+ *              predicate semantics on a counter stream of its own; pinned by property tests (tests/test_generator.py).
  *   lidar    : the reference module imports shapely (cannot run here): oracle/lidar_ref.py restates its
  *              numpy expression sequence; PARITY UNPINNED against the reference itself.
  *
@@ -1227,6 +1230,271 @@ void t2do_drift_batch(const double* rows, int row_stride, int n, const float* x,
             continue;
         }
         t2do_drift(p, x[i], y[i], heading[i], speed[i], omega_f[i], omega_r[i], act0[i], act1[i], interval_ms, o);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Row f4: ParkingLotGenerator.generate (map/generator/generate_parking_lot.py:239-444) restated per
+ * env.  PARITY UNPINNED: the reference draws from numpy's global MT19937 stream and evaluates its
+ * predicates in shapely/GEOS (neither can run here), so this follows the reference's sampling
+ * distributions, draw ORDER, geometric predicates and control flow -- including the two behaviours
+ * that follow from its bookkeeping: side vehicles appended during rejected attempts stay in the
+ * `obstacles` list (:283-285, :320-322), and Map.add_area keys areas by id so a later obstacle with
+ * the same id replaces the earlier one (map.py:444-453; far wall "0003" vs left vehicle "0003") --
+ * on a stream of its own:
+ *     state0 = seed + (env + 1) * 0xD1B54A32D192ED03 ; every draw u = (splitmix64(&state) >> 11) * 2^-53
+ *     uniform(a, b) = a + (b - a) * u ;  normal(m, s) = m + s * sqrt(-2 log(1 - u1)) * cos(2 pi u2)
+ * The kernel in t2d_generate.hip implements the same specification and must agree bit for bit in
+ * deterministic-trig mode.  Rejection loops are capped (T2D_GEN_MAX_ATTEMPTS / _START_ATTEMPTS); a
+ * capped env is reported in `info`, never silently accepted.                                       */
+#define PI_D 3.141592653589793
+#define M_PI_2_D (PI_D / 2)
+typedef struct { uint64_t s; } gen_rng;
+static double gen_u(gen_rng* r) {
+    uint64_t z = (r->s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+static double gen_uniform(gen_rng* r, double a, double b) { return a + (b - a) * gen_u(r); }
+static double gen_normal(gen_rng* r, double mean, double std) {
+    double u1 = 1.0 - gen_u(r), u2 = gen_u(r);
+    double rad = sqrt(-2.0 * (g_trig ? t2do_log(u1) : log(u1)));
+    return mean + std * (rad * T_cos(TWO_PI * u2));
+}
+/* _truncate_gaussian :60-62 */
+static double gen_tg(gen_rng* r, double mean, double std, double lo, double hi) {
+    return clip(gen_normal(r, mean, std), lo, hi);
+}
+/* _get_bbox :64-87 (vertex order and the affine matrix [cos, -sin, sin, cos, cx, cy]) */
+static void gen_bbox(double cx, double cy, double h, double len, double wid, double* q) {
+    const double c = T_cos(h), s = T_sin(h);
+    const double lx[4] = {0.5 * len, 0.5 * len, -0.5 * len, -0.5 * len};
+    const double ly[4] = {-0.5 * wid, 0.5 * wid, 0.5 * wid, -0.5 * wid};
+    for (int k = 0; k < 4; ++k) {
+        q[2 * k] = (c * lx[k] + (-s) * ly[k]) + cx;
+        q[2 * k + 1] = (s * lx[k] + c * ly[k]) + cy;
+    }
+}
+/* _get_random_position :89-99; np.mean / np.std of the 2-tuples */
+static void gen_random_position(gen_rng* r, const double* origin, double a0, double a1, double r0, double r1,
+                                double* out) {
+    double am = (a0 + a1) / 2.0, rm = (r0 + r1) / 2.0;
+    double as = sqrt(((a0 - am) * (a0 - am) + (a1 - am) * (a1 - am)) / 2.0);
+    double rs = sqrt(((r0 - rm) * (r0 - rm) + (r1 - rm) * (r1 - rm)) / 2.0);
+    double angle = gen_tg(r, am, as, a0, a1);
+    double radius = gen_tg(r, rm, rs, r0, r1);
+    out[0] = origin[0] + radius * T_cos(angle);
+    out[1] = origin[1] + radius * T_sin(angle);
+}
+static void gen_ccw(const double* q, double* o) { /* winding normalised for the SAT predicates */
+    if (area2(q, 4) < 0.0) for (int k = 0; k < 4; ++k) { o[2 * k] = q[2 * (3 - k)]; o[2 * k + 1] = q[2 * (3 - k) + 1]; }
+    else memcpy(o, q, 8 * sizeof(double));
+}
+static int gen_convex(const double* q) { /* q counter-clockwise: no right turn */
+    for (int k = 0; k < 4; ++k)
+        if (orient(q + 2 * k, q + 2 * ((k + 1) & 3), q + 2 * ((k + 2) & 3)) < 0.0) return 0;
+    return 1;
+}
+static int gen_intersects(const double* a, const double* b) {
+    double A[8], B[8];
+    gen_ccw(a, A); gen_ccw(b, B);
+    return t2do_convex_intersects(A, 4, B, 4);
+}
+/* shapely distance between two convex quads: 0 when they share a point, else the closest vertex-edge pair */
+static double gen_distance(const double* a, const double* b) {
+    if (gen_intersects(a, b)) return 0.0;
+    double best = INFINITY;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double d1 = seg_dist2(b + 2 * j, b + 2 * ((j + 1) & 3), a + 2 * i);
+            double d2 = seg_dist2(a + 2 * j, a + 2 * ((j + 1) & 3), b + 2 * i);
+            best = fmin(best, fmin(d1, d2));
+        }
+    return sqrt(best);
+}
+#define GEN_LIST_CAP 64
+typedef struct { double q[GEN_LIST_CAP][8]; int id[GEN_LIST_CAP]; int n; int overflow; } gen_list;
+static void gen_append(gen_list* l, int id, const double* q) {
+    if (l->n >= GEN_LIST_CAP) { l->overflow = 1; return; }
+    memcpy(l->q[l->n], q, 8 * sizeof(double));
+    l->id[l->n++] = id;
+}
+/* _get_side_vehicle :175-205 */
+static void gen_side_vehicle(gen_rng* r, int bay, double len, double wid, double d0, double d1, int left, double* q) {
+    double heading = bay ? gen_tg(r, M_PI_2_D, PI_D / 54, PI_D * 4 / 9, PI_D * 5 / 9)
+                         : gen_tg(r, 0.0, PI_D / 54, -PI_D / 18, PI_D / 18);
+    double side = left ? -1.0 : 1.0;
+    double x = 0.0 + side * ((bay ? wid : len) + gen_uniform(r, d0, d1));
+    double t[8];
+    gen_bbox(x, 0.0, heading, len, wid, t);
+    double m = bay ? fmin(t[7], t[5]) : fmin(t[7], t[1]); /* bottom_right, bottom_left | top_right */
+    double min_y = -m + 0.8;
+    double y = gen_tg(r, min_y + 0.4, 0.2, min_y, min_y + 0.8);
+    gen_bbox(x, y, heading, len, wid, q);
+}
+
+void t2do_generate_parking(uint64_t seed, int64_t env0, int n_env, double type_proportion, double len, double wid,
+                           float* quads /* [n_env][12][8] */, int32_t* quad_id /* [n_env][12] */, int32_t* n_quads,
+                           double* start /* [n_env][3] */, float* target /* [n_env][8] */, double* target_heading,
+                           float* boundary /* [n_env][4] */, uint32_t* info) {
+    const double SIZE = 30.0, MARGIN = 13.0, D0 = 0.8, D1 = 1.6;
+    if (!(type_proportion >= 0.0)) type_proportion = 0.0; /* np.clip(type_proportion, 0, 1) :57 */
+    if (type_proportion > 1.0) type_proportion = 1.0;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(g_threads)
+    for (int e = 0; e < n_env; ++e) {
+        gen_rng rng = {seed + (uint64_t)(env0 + e + 1) * 0xD1B54A32D192ED03ull};
+        uint32_t flags = 0;
+        const int bay = gen_u(&rng) < type_proportion; /* :256 */
+        const double slot_len = bay ? 7.0 : 4.5;
+        const double next = bay ? wid : len;
+        const int n_more = bay ? (9 - 3) / 2 : (7 - 3) / 2;
+        const double thr = bay ? 0.85 : 0.25 * len;
+        gen_list L; L.n = 0; L.overflow = 0;
+        double tq[8], th = 0.0, back[8], lo_[8], ro_[8];
+        int attempts = 0, valid = 0;
+        while (!valid) { /* :260-331 */
+            ++attempts;
+            /* _get_target_area :101-117 */
+            th = bay ? gen_tg(&rng, M_PI_2_D, PI_D / 54, PI_D * 4 / 9, PI_D * 5 / 9)
+                     : gen_tg(&rng, 0.0, PI_D / 54, -PI_D / 18, PI_D / 18);
+            gen_bbox(0.0, 0.0, th, len, wid, tq);
+            double y_min = -(bay ? fmin(tq[7], tq[5]) : fmin(tq[7], tq[1])) + D0;
+            double cy = gen_tg(&rng, y_min + 0.4, 0.2, y_min, y_min + 0.8);
+            gen_bbox(0.0, cy, th, len, wid, tq);
+            /* _get_back_wall :119-125 */
+            double ww = gen_uniform(&rng, 0.5, 1.5);
+            gen_bbox(0.0, 0.0 - ww / 2, 0.0, SIZE, ww, back);
+            double d0 = D0 + 0.1, d1 = D1;
+            if (gen_u(&rng) < 0.2) { /* _get_left_wall :127-149 */
+                double a[2], b[2];
+                gen_random_position(&rng, bay ? tq + 2 : tq + 4, PI_D * 11 / 12, PI_D * 13 / 12, d0, d1, a);
+                gen_random_position(&rng, bay ? tq + 4 : tq + 6, PI_D * 11 / 12, PI_D * 13 / 12, d0, d1, b);
+                lo_[0] = a[0]; lo_[1] = a[1]; lo_[2] = b[0]; lo_[3] = b[1];
+                lo_[4] = 0.0 - SIZE / 2; lo_[5] = 0.0; lo_[6] = 0.0 - SIZE / 2; lo_[7] = a[1];
+            } else {
+                gen_side_vehicle(&rng, bay, len, wid, d0, d1, 1, lo_);
+                for (int i = 0; i < n_more; ++i) {
+                    d0 += next + D0; d1 += next + D0;
+                    double q[8];
+                    gen_side_vehicle(&rng, bay, len, wid, d0, d1, 1, q);
+                    gen_append(&L, 2 * i + 3, q);
+                }
+            }
+            double dl = gen_distance(tq, lo_);
+            d0 = fmax(thr - dl, 0.0) + D0; d1 = D1;
+            if (gen_u(&rng) < 0.2) { /* _get_right_wall :151-173 */
+                double a[2], b[2];
+                gen_random_position(&rng, bay ? tq + 6 : tq + 0, -PI_D * 1 / 12, PI_D * 1 / 12, d0, d1, a); /* bottom left */
+                gen_random_position(&rng, bay ? tq + 0 : tq + 2, -PI_D * 1 / 12, PI_D * 1 / 12, d0, d1, b); /* top left */
+                ro_[0] = 0.0 + SIZE / 2; ro_[1] = tq[3]; ro_[2] = 0.0 + SIZE / 2; ro_[3] = 0.0;
+                ro_[4] = a[0]; ro_[5] = a[1]; ro_[6] = b[0]; ro_[7] = b[1];
+            } else {
+                gen_side_vehicle(&rng, bay, len, wid, d0, d1, 0, ro_);
+                for (int i = 0; i < n_more; ++i) {
+                    d0 += next + D0; d1 += next + D0;
+                    double q[8];
+                    gen_side_vehicle(&rng, bay, len, wid, d0, d1, 0, q);
+                    gen_append(&L, 2 * i + 4, q);
+                }
+            }
+            double dr = gen_distance(tq, ro_);
+            /* _verify_obstacles :207-223 (`any(dists) < 0.8` compares a bool: it only rejects dl == dr == 0) */
+            valid = !(gen_intersects(tq, back) || gen_intersects(tq, lo_) || gen_intersects(tq, ro_));
+            if (valid && !(dl != 0.0 || dr != 0.0)) valid = 0;
+            if (valid && dl + dr < thr) valid = 0;
+            if (!valid && attempts >= T2D_GEN_MAX_ATTEMPTS) { flags |= T2D_GEN_UNVERIFIED; break; }
+        }
+        gen_append(&L, 0, back); gen_append(&L, 1, lo_); gen_append(&L, 2, ro_);
+        double y_max = -INFINITY; /* :338-346 */
+        for (int i = 0; i < L.n; ++i)
+            for (int k = 0; k < 4; ++k) y_max = fmax(y_max, L.q[i][2 * k + 1]);
+        y_max += D0;
+        if (gen_u(&rng) < 0.2) { /* far wall :347-356 */
+            double w = gen_uniform(&rng, 0.0, 0.2), q[8];
+            gen_bbox(0.0, y_max + slot_len, 0.0, SIZE, w, q);
+            gen_append(&L, 3, q);
+        } else { /* three perturbed vehicles beyond the start range :357-387 */
+            const double bx0 = 0.0 - SIZE / 2, bx1 = 0.0 + SIZE / 2;
+            const double yc = y_max + slot_len + 4;
+            double bb[8];
+            gen_bbox(0.0, yc, 0.0, SIZE, 8.0, bb);
+            const double y0 = y_max + slot_len + 2, y1 = y_max + slot_len + 6;
+            int id = L.n + 1;
+            for (int t = 0; t < 3; ++t) {
+                double x = gen_uniform(&rng, bx0, bx1);
+                double y = gen_uniform(&rng, y0, y1);
+                double h = gen_u(&rng) * 2 * PI_D;
+                double q[8];
+                gen_bbox(x, y, h, len, wid, q);
+                int inside = 1;
+                for (int k = 0; k < 8; ++k) q[k] = q[k] + 0.5 * gen_u(&rng);
+                for (int k = 0; k < 4; ++k) /* Polygon(bbox).contains(shape): closed rectangle test on the vertices */
+                    if (!(q[2 * k] >= bb[4] && q[2 * k] <= bb[0] && q[2 * k + 1] >= bb[1] && q[2 * k + 1] <= bb[3])) inside = 0;
+                if (inside) { gen_append(&L, id, q); ++id; }
+            }
+        }
+        { /* random drop :389-390 */
+            int m = 0;
+            for (int i = 0; i < L.n; ++i)
+                if (gen_u(&rng) >= 0.05) { if (m != i) { memcpy(L.q[m], L.q[i], sizeof L.q[0]); L.id[m] = L.id[i]; } ++m; }
+            L.n = m;
+        }
+        for (int i = 0; i < L.n; ++i) { /* every obstacle must be usable by the convex predicates */
+            double c[8];
+            gen_ccw(L.q[i], c);
+            if (!gen_convex(c)) flags |= T2D_GEN_NONCONVEX;
+        }
+        /* start state :396-407, _get_start_state :225-229, _verify_start_state :231-237 */
+        double sx = 0.0, sy = 0.0, sh = 0.0;
+        int s_attempts = 0;
+        for (;;) {
+            ++s_attempts;
+            sx = gen_uniform(&rng, -SIZE / 4, SIZE / 4);
+            sy = gen_uniform(&rng, y_max + D0 + 1, y_max + slot_len - 1);
+            sh = gen_tg(&rng, 0.0, PI_D / 54, -PI_D / 18, PI_D / 18);
+            double sq[8];
+            gen_bbox(sx, sy, sh, len, wid, sq);
+            int ok = 1;
+            for (int i = 0; i < L.n && ok; ++i) if (gen_intersects(sq, L.q[i])) ok = 0;
+            if (ok && gen_intersects(sq, tq)) ok = 0;
+            if (ok) break;
+            if (s_attempts >= T2D_GEN_MAX_START_ATTEMPTS) { flags |= T2D_GEN_START_UNVERIFIED; break; }
+        }
+        /* flip :409-434 */
+        double tx = (((tq[0] + tq[2]) + tq[4]) + tq[6]) / 4.0, ty = (((tq[1] + tq[3]) + tq[5]) + tq[7]) / 4.0;
+        if (gen_u(&rng) > 0.5) {
+            double sq[8];
+            gen_bbox(sx, sy, sh, len, wid, sq);
+            double cx = (((sq[0] + sq[2]) + sq[4]) + sq[6]) / 4.0, cyy = (((sq[1] + sq[3]) + sq[5]) + sq[7]) / 4.0;
+            sx = 2 * cx - sx; sy = 2 * cyy - sy; sh += PI_D;
+            if (!bay) { th += PI_D; gen_bbox(tx, ty, th, len, wid, tq); flags |= T2D_GEN_TARGET_FLIPPED; }
+            flags |= T2D_GEN_START_FLIPPED;
+        }
+        /* Map.add_area in list order: same id replaces, position of the first insertion (dict semantics) */
+        int n_out = 0; int ids[T2D_GEN_MAX_QUADS]; double outq[T2D_GEN_MAX_QUADS][8];
+        for (int i = 0; i < L.n; ++i) {
+            int at = -1;
+            for (int k = 0; k < n_out; ++k) if (ids[k] == L.id[i]) at = k;
+            if (at < 0) { if (n_out >= T2D_GEN_MAX_QUADS) { flags |= T2D_GEN_OVERFLOW; continue; } at = n_out++; ids[at] = L.id[i]; }
+            memcpy(outq[at], L.q[i], sizeof outq[0]);
+        }
+        if (L.overflow) flags |= T2D_GEN_OVERFLOW;
+        for (int k = 0; k < T2D_GEN_MAX_QUADS; ++k)
+            for (int c = 0; c < 8; ++c) quads[((size_t)e * T2D_GEN_MAX_QUADS + k) * 8 + c] = k < n_out ? (float)outq[k][c] : 0.0f;
+        for (int k = 0; k < T2D_GEN_MAX_QUADS; ++k) quad_id[(size_t)e * T2D_GEN_MAX_QUADS + k] = k < n_out ? ids[k] : -1;
+        n_quads[e] = n_out;
+        start[3 * (size_t)e] = sx; start[3 * (size_t)e + 1] = sy; start[3 * (size_t)e + 2] = sh;
+        for (int c = 0; c < 8; ++c) target[8 * (size_t)e + c] = (float)tq[c];
+        target_heading[e] = th;
+        /* :436-440 */
+        boundary[4 * (size_t)e] = (float)floor(fmin(sx, tx) - MARGIN);
+        boundary[4 * (size_t)e + 1] = (float)ceil(fmax(sx, tx) + MARGIN);
+        boundary[4 * (size_t)e + 2] = (float)floor(fmin(sy, ty) - MARGIN);
+        boundary[4 * (size_t)e + 3] = (float)ceil(fmax(sy, ty) + MARGIN);
+        info[e] = flags | (bay ? T2D_GEN_BAY : 0u) | ((uint32_t)(attempts > 255 ? 255 : attempts) << 8) |
+                  ((uint32_t)(s_attempts > 255 ? 255 : s_attempts) << 16);
     }
 }
 

@@ -455,10 +455,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                 par_stage[k] = pv.params[(T2D_P_SHAPE + q / T2D_MAX_TYPES) * T2D_MAX_TYPES + q % T2D_MAX_TYPES];
         }
     }
-    // geometry record -> LDS in batches of kBatch 16-B loads per thread (one latency per batch;
-    // one batch covers 8 x nthreads x 16 B, i.e. the whole record whenever A >= 16)
+    // geometry record -> LDS, 16-B loads
     const int n_vec = pv.geo ? gl.stride >> 2 : 0;
-    constexpr int kBatch = 8;
     const uint4* gsrc = reinterpret_cast<const uint4*>(pv.geo + (size_t)blockIdx.x * gl.stride);
     {
         // rounds of 16-B loads this record needs (wave-uniform): 1 for the metric scenes (<= 4 KiB per workgroup) --

@@ -1,0 +1,444 @@
+// t2d_generate.hip -- reset-time scene synthesis on the device (scope row f4).
+//
+// Replaces (reference, tactics2d v0.1.9rc3):
+//   ParkingLotGenerator.generate            map/generator/generate_parking_lot.py:239-444
+//   ._get_target_area / _get_back_wall      :101-125
+//   ._get_left_wall / _get_right_wall       :127-173
+//   ._get_side_vehicle                      :175-205
+//   ._verify_obstacles / _verify_start_state :207-223, :231-237
+//   Map.add_area (same id replaces)         map/element/map.py:444-453
+// PARITY UNPINNED against the reference (numpy's global MT19937 stream + shapely predicates cannot run
+// in this build): distributions, draw order, control flow and predicate semantics follow the reference;
+// the random stream is the counter-based one specified in include/t2d.h / oracle t2do_generate_parking,
+// and this kernel agrees with that oracle bit for bit.
+//
+// One lane per scene.  A scene is a sequential rejection sampler (every draw depends on the outcome of
+// the previous tests), so the parallelism is across scenes only; the obstacle list lives in private
+// memory (4 KB per lane).  Reset-time work: one launch per batch of scenes, not per step.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "../../include/t2d.h"
+#include "t2d_math.h"
+
+namespace t2d {
+
+namespace {
+
+constexpr int kGenBlock = 64;
+constexpr int kListCap = 64;
+constexpr double kPi = 3.141592653589793;
+constexpr double kTwoPi = 2.0 * 3.141592653589793;
+
+struct Quad {
+    double v[8];
+};
+
+struct Stream {  // splitmix64 counter stream, one per scene
+    uint64_t s;
+    T2D_DEV double u() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+    }
+    T2D_DEV double uniform(double a, double b) { return a + (b - a) * u(); }
+    T2D_DEV double normal(double mean, double std) {  // Box-Muller, cosine branch
+        const double u1 = 1.0 - u(), u2 = u();
+        const double rad = __builtin_sqrt(-2.0 * log_det(u1));
+        double sn, cs;
+        sincos_det(kTwoPi * u2, sn, cs);
+        return mean + std * (rad * cs);
+    }
+    T2D_DEV double trunc_gauss(double mean, double std, double lo, double hi) {  // :60-62
+        return clipd(normal(mean, std), lo, hi);
+    }
+};
+
+// _get_bbox: body-frame ring (+L/2,-W/2), (+L/2,+W/2), (-L/2,+W/2), (-L/2,-W/2) through [cos, -sin, sin, cos, cx, cy]
+T2D_DEV Quad make_box(double cx, double cy, double h, double len, double wid) {
+    double sn, cs;
+    sincos_det(h, sn, cs);
+    Quad q;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double lx = (k < 2 ? 0.5 : -0.5) * len;
+        const double ly = (k == 1 || k == 2 ? 0.5 : -0.5) * wid;
+        q.v[2 * k] = (cs * lx + (-sn) * ly) + cx;
+        q.v[2 * k + 1] = (sn * lx + cs * ly) + cy;
+    }
+    return q;
+}
+
+T2D_DEV double turn(const double* p, const double* q, const double* r) {
+    const double a = q[0] - p[0], b = r[1] - p[1];
+    const double c = q[1] - p[1], d = r[0] - p[0];
+    return a * b - c * d;
+}
+
+T2D_DEV double shoelace2(const Quad& q) {
+    double a = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = (i + 1) & 3;
+        a += q.v[2 * i] * q.v[2 * j + 1] - q.v[2 * j] * q.v[2 * i + 1];
+    }
+    return a;
+}
+
+T2D_DEV Quad counter_clockwise(const Quad& q) {
+    if (!(shoelace2(q) < 0.0)) return q;
+    Quad o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        o.v[2 * k] = q.v[2 * (3 - k)];
+        o.v[2 * k + 1] = q.v[2 * (3 - k) + 1];
+    }
+    return o;
+}
+
+T2D_DEV bool is_convex_ccw(const Quad& q) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (turn(&q.v[2 * k], &q.v[2 * ((k + 1) & 3)], &q.v[2 * ((k + 2) & 3)]) < 0.0) ok = false;
+    return ok;
+}
+
+// an edge of the counter-clockwise quad A has every vertex of B strictly on its right
+T2D_DEV bool edge_separates(const Quad& A, const Quad& B) {
+    bool found = false;
+    for (int i = 0; i < 4; ++i) {
+        const double* p = &A.v[2 * i];
+        const double* q = &A.v[2 * ((i + 1) & 3)];
+        bool all_out = true;
+        for (int j = 0; j < 4; ++j)
+            if (!(turn(p, q, &B.v[2 * j]) < 0.0)) all_out = false;
+        found = found || all_out;
+    }
+    return found;
+}
+
+// shapely intersects for convex quads: closed sets share a point (touching counts)
+T2D_DEV bool touches_or_overlaps(const Quad& a, const Quad& b) {
+    const Quad A = counter_clockwise(a), B = counter_clockwise(b);
+    return !(edge_separates(A, B) || edge_separates(B, A));
+}
+
+T2D_DEV double point_segment_d2(const double* p, const double* q, const double* c) {
+    const double dx = q[0] - p[0], dy = q[1] - p[1];
+    const double wx = c[0] - p[0], wy = c[1] - p[1];
+    const double dd = dx * dx + dy * dy;
+    double t = 0.0;
+    if (dd > 0.0) {
+        t = (wx * dx + wy * dy) / dd;
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+    }
+    const double ex = wx - t * dx, ey = wy - t * dy;
+    return ex * ex + ey * ey;
+}
+
+// shapely distance between convex quads
+T2D_DEV double gap(const Quad& a, const Quad& b) {
+    if (touches_or_overlaps(a, b)) return 0.0;
+    double best = INFINITY;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            const double d1 = point_segment_d2(&b.v[2 * j], &b.v[2 * ((j + 1) & 3)], &a.v[2 * i]);
+            const double d2 = point_segment_d2(&a.v[2 * j], &a.v[2 * ((j + 1) & 3)], &b.v[2 * i]);
+            best = __builtin_fmin(best, __builtin_fmin(d1, d2));
+        }
+    return __builtin_sqrt(best);
+}
+
+struct SceneParams {
+    uint64_t seed;
+    int64_t first_env;
+    int n_env;
+    double type_proportion, len, wid;
+    float* quads;
+    int32_t* quad_id;
+    int32_t* n_quads;
+    double* start;
+    float* target;
+    double* target_heading;
+    float* boundary;
+    uint32_t* info;
+};
+
+__global__ __launch_bounds__(kGenBlock) void generate_parking_kernel(SceneParams P) {
+    const int e = blockIdx.x * kGenBlock + threadIdx.x;
+    if (e >= P.n_env) return;
+    constexpr double kSize = 30.0, kMargin = 13.0, kD0 = 0.8, kD1 = 1.6;
+    const double len = P.len, wid = P.wid;
+    Stream rng{P.seed + (uint64_t)(P.first_env + e + 1) * 0xD1B54A32D192ED03ull};
+    uint32_t flags = 0;
+
+    Quad list[kListCap];
+    int list_id[kListCap];
+    int n_list = 0;
+    bool list_full = false;
+    auto append = [&](int id, const Quad& q) {
+        if (n_list >= kListCap) {
+            list_full = true;
+            return;
+        }
+        list[n_list] = q;
+        list_id[n_list++] = id;
+    };
+
+    const bool bay = rng.u() < P.type_proportion;  // :256
+    const double slot_len = bay ? 7.0 : 4.5;
+    const double next = bay ? wid : len;
+    const int n_more = bay ? 3 : 2;  // (n_parking_lots - 3) // 2
+    const double thr = bay ? 0.85 : 0.25 * len;
+
+    auto mode_heading = [&]() {
+        return bay ? rng.trunc_gauss(kPi / 2, kPi / 54, kPi * 4 / 9, kPi * 5 / 9)
+                   : rng.trunc_gauss(0.0, kPi / 54, -kPi / 18, kPi / 18);
+    };
+    // the lower edge of a box placed at y = 0 decides how far it sits from the back wall
+    auto lift = [&](const Quad& at_zero) {
+        const double m = bay ? __builtin_fmin(at_zero.v[7], at_zero.v[5]) : __builtin_fmin(at_zero.v[7], at_zero.v[1]);
+        const double y_min = -m + kD0;
+        return rng.trunc_gauss(y_min + 0.4, 0.2, y_min, y_min + 0.8);
+    };
+    auto side_vehicle = [&](double d0, double d1, bool left) {  // :175-205
+        const double heading = mode_heading();
+        const double x = 0.0 + (left ? -1.0 : 1.0) * ((bay ? wid : len) + rng.uniform(d0, d1));
+        const double y = lift(make_box(x, 0.0, heading, len, wid));
+        return make_box(x, y, heading, len, wid);
+    };
+    auto random_position = [&](const double* origin, double a0, double a1, double r0, double r1, double* out) {  // :89-99
+        const double am = (a0 + a1) / 2.0, rm = (r0 + r1) / 2.0;
+        const double as = __builtin_sqrt(((a0 - am) * (a0 - am) + (a1 - am) * (a1 - am)) / 2.0);
+        const double rs = __builtin_sqrt(((r0 - rm) * (r0 - rm) + (r1 - rm) * (r1 - rm)) / 2.0);
+        const double angle = rng.trunc_gauss(am, as, a0, a1);
+        const double radius = rng.trunc_gauss(rm, rs, r0, r1);
+        double sn, cs;
+        sincos_det(angle, sn, cs);
+        out[0] = origin[0] + radius * cs;
+        out[1] = origin[1] + radius * sn;
+    };
+
+    Quad target, back, left_ob, right_ob;
+    double target_h = 0.0;
+    int attempts = 0;
+    for (;;) {  // :260-331
+        ++attempts;
+        target_h = mode_heading();
+        const double cy = lift(make_box(0.0, 0.0, target_h, len, wid));
+        target = make_box(0.0, cy, target_h, len, wid);
+        const double wall_w = rng.uniform(0.5, 1.5);
+        back = make_box(0.0, 0.0 - wall_w / 2, 0.0, kSize, wall_w);
+
+        double d0 = kD0 + 0.1, d1 = kD1;
+        if (rng.u() < 0.2) {  // wall on the left :127-149
+            double a[2], b[2];
+            random_position(bay ? &target.v[2] : &target.v[4], kPi * 11 / 12, kPi * 13 / 12, d0, d1, a);
+            random_position(bay ? &target.v[4] : &target.v[6], kPi * 11 / 12, kPi * 13 / 12, d0, d1, b);
+            left_ob = Quad{{a[0], a[1], b[0], b[1], 0.0 - kSize / 2, 0.0, 0.0 - kSize / 2, a[1]}};
+        } else {
+            left_ob = side_vehicle(d0, d1, true);
+            for (int i = 0; i < n_more; ++i) {
+                d0 += next + kD0;
+                d1 += next + kD0;
+                append(2 * i + 3, side_vehicle(d0, d1, true));
+            }
+        }
+        const double dl = gap(target, left_ob);
+        d0 = __builtin_fmax(thr - dl, 0.0) + kD0;
+        d1 = kD1;
+        if (rng.u() < 0.2) {  // wall on the right :151-173
+            double a[2], b[2];
+            random_position(bay ? &target.v[6] : &target.v[0], -kPi * 1 / 12, kPi * 1 / 12, d0, d1, a);
+            random_position(bay ? &target.v[0] : &target.v[2], -kPi * 1 / 12, kPi * 1 / 12, d0, d1, b);
+            right_ob = Quad{{0.0 + kSize / 2, target.v[3], 0.0 + kSize / 2, 0.0, a[0], a[1], b[0], b[1]}};
+        } else {
+            right_ob = side_vehicle(d0, d1, false);
+            for (int i = 0; i < n_more; ++i) {
+                d0 += next + kD0;
+                d1 += next + kD0;
+                append(2 * i + 4, side_vehicle(d0, d1, false));
+            }
+        }
+        const double dr = gap(target, right_ob);
+        // _verify_obstacles :207-223 (`any(dists) < 0.8` compares a bool: rejects only dl == dr == 0)
+        bool valid = !(touches_or_overlaps(target, back) || touches_or_overlaps(target, left_ob) ||
+                       touches_or_overlaps(target, right_ob));
+        if (valid && !(dl != 0.0 || dr != 0.0)) valid = false;
+        if (valid && dl + dr < thr) valid = false;
+        if (valid) break;
+        if (attempts >= T2D_GEN_MAX_ATTEMPTS) {
+            flags |= T2D_GEN_UNVERIFIED;
+            break;
+        }
+    }
+    append(0, back);
+    append(1, left_ob);
+    append(2, right_ob);
+
+    double y_max = -INFINITY;  // :338-346
+    for (int i = 0; i < n_list; ++i)
+        for (int k = 0; k < 4; ++k) y_max = __builtin_fmax(y_max, list[i].v[2 * k + 1]);
+    y_max += kD0;
+    if (rng.u() < 0.2) {  // far wall :347-356
+        const double w = rng.uniform(0.0, 0.2);
+        append(3, make_box(0.0, y_max + slot_len, 0.0, kSize, w));
+    } else {  // three perturbed vehicles behind the start range :357-387
+        const Quad bb = make_box(0.0, y_max + slot_len + 4, 0.0, kSize, 8.0);
+        const double y0 = y_max + slot_len + 2, y1 = y_max + slot_len + 6;
+        int id = n_list + 1;
+        for (int t = 0; t < 3; ++t) {
+            const double x = rng.uniform(0.0 - kSize / 2, 0.0 + kSize / 2);
+            const double y = rng.uniform(y0, y1);
+            const double h = rng.u() * 2 * kPi;
+            Quad q = make_box(x, y, h, len, wid);
+            for (int k = 0; k < 8; ++k) q.v[k] = q.v[k] + 0.5 * rng.u();
+            bool inside = true;  // Polygon(bbox).contains(shape): closed rectangle test on the vertices
+            for (int k = 0; k < 4; ++k)
+                if (!(q.v[2 * k] >= bb.v[4] && q.v[2 * k] <= bb.v[0] && q.v[2 * k + 1] >= bb.v[1] &&
+                      q.v[2 * k + 1] <= bb.v[3]))
+                    inside = false;
+            if (inside) {
+                append(id, q);
+                ++id;
+            }
+        }
+    }
+    {  // random drop :389-390
+        int m = 0;
+        for (int i = 0; i < n_list; ++i)
+            if (rng.u() >= 0.05) {
+                if (m != i) {
+                    list[m] = list[i];
+                    list_id[m] = list_id[i];
+                }
+                ++m;
+            }
+        n_list = m;
+    }
+    for (int i = 0; i < n_list; ++i)
+        if (!is_convex_ccw(counter_clockwise(list[i]))) flags |= T2D_GEN_NONCONVEX;
+
+    // start state :396-407
+    double sx = 0.0, sy = 0.0, sh = 0.0;
+    int s_attempts = 0;
+    for (;;) {
+        ++s_attempts;
+        sx = rng.uniform(-kSize / 4, kSize / 4);
+        sy = rng.uniform(y_max + kD0 + 1, y_max + slot_len - 1);
+        sh = rng.trunc_gauss(0.0, kPi / 54, -kPi / 18, kPi / 18);
+        const Quad body = make_box(sx, sy, sh, len, wid);
+        bool ok = true;
+        for (int i = 0; i < n_list && ok; ++i)
+            if (touches_or_overlaps(body, list[i])) ok = false;
+        if (ok && touches_or_overlaps(body, target)) ok = false;
+        if (ok) break;
+        if (s_attempts >= T2D_GEN_MAX_START_ATTEMPTS) {
+            flags |= T2D_GEN_START_UNVERIFIED;
+            break;
+        }
+    }
+    // flip :409-434
+    const double tx = (((target.v[0] + target.v[2]) + target.v[4]) + target.v[6]) / 4.0;
+    const double ty = (((target.v[1] + target.v[3]) + target.v[5]) + target.v[7]) / 4.0;
+    if (rng.u() > 0.5) {
+        const Quad body = make_box(sx, sy, sh, len, wid);
+        const double cx = (((body.v[0] + body.v[2]) + body.v[4]) + body.v[6]) / 4.0;
+        const double cy = (((body.v[1] + body.v[3]) + body.v[5]) + body.v[7]) / 4.0;
+        sx = 2 * cx - sx;
+        sy = 2 * cy - sy;
+        sh += kPi;
+        flags |= T2D_GEN_START_FLIPPED;
+        if (!bay) {
+            target_h += kPi;
+            target = make_box(tx, ty, target_h, len, wid);
+            flags |= T2D_GEN_TARGET_FLIPPED;
+        }
+    }
+
+    // Map.add_area in list order: an id already present keeps its slot and takes the new polygon
+    int slot_id[T2D_GEN_MAX_QUADS];
+    int slot_src[T2D_GEN_MAX_QUADS];
+    int n_out = 0;
+    for (int i = 0; i < n_list; ++i) {
+        int at = -1;
+        for (int k = 0; k < n_out; ++k)
+            if (slot_id[k] == list_id[i]) at = k;
+        if (at < 0) {
+            if (n_out >= T2D_GEN_MAX_QUADS) {
+                flags |= T2D_GEN_OVERFLOW;
+                continue;
+            }
+            at = n_out++;
+            slot_id[at] = list_id[i];
+        }
+        slot_src[at] = i;
+    }
+    if (list_full) flags |= T2D_GEN_OVERFLOW;
+
+    float* oq = P.quads + (size_t)e * T2D_GEN_MAX_QUADS * 8;
+    for (int k = 0; k < T2D_GEN_MAX_QUADS; ++k) {
+        for (int c = 0; c < 8; ++c) oq[8 * k + c] = k < n_out ? (float)list[slot_src[k]].v[c] : 0.0f;
+        P.quad_id[(size_t)e * T2D_GEN_MAX_QUADS + k] = k < n_out ? slot_id[k] : -1;
+    }
+    P.n_quads[e] = n_out;
+    P.start[3 * (size_t)e] = sx;
+    P.start[3 * (size_t)e + 1] = sy;
+    P.start[3 * (size_t)e + 2] = sh;
+    for (int c = 0; c < 8; ++c) P.target[8 * (size_t)e + c] = (float)target.v[c];
+    P.target_heading[e] = target_h;
+    P.boundary[4 * (size_t)e] = (float)__builtin_floor(__builtin_fmin(sx, tx) - kMargin);  // :436-440
+    P.boundary[4 * (size_t)e + 1] = (float)__builtin_ceil(__builtin_fmax(sx, tx) + kMargin);
+    P.boundary[4 * (size_t)e + 2] = (float)__builtin_floor(__builtin_fmin(sy, ty) - kMargin);
+    P.boundary[4 * (size_t)e + 3] = (float)__builtin_ceil(__builtin_fmax(sy, ty) + kMargin);
+    P.info[e] = flags | (bay ? T2D_GEN_BAY : 0u) | ((uint32_t)(attempts > 255 ? 255 : attempts) << 8) |
+                ((uint32_t)(s_attempts > 255 ? 255 : s_attempts) << 16);
+}
+
+}  // namespace
+
+}  // namespace t2d
+
+extern "C" int t2d_generate_parking(int32_t device_id, uint64_t seed, int64_t first_env, int32_t n_env,
+                                    double type_proportion, double vehicle_length, double vehicle_width,
+                                    float* quads, int32_t* quad_id, int32_t* n_quads, double* start, float* target,
+                                    double* target_heading, float* boundary, uint32_t* info) {
+    using namespace t2d;
+    if (n_env < 0 || !quads || !quad_id || !n_quads || !start || !target || !target_heading || !boundary || !info)
+        return T2D_ERR_INVALID;
+    // ParkingLotGenerator.__init__ :45-57: an invalid vehicle size falls back to the default, the proportion is clipped
+    if (vehicle_length < vehicle_width || !(vehicle_length > 0.0) || !(vehicle_width > 0.0)) {
+        vehicle_length = 5.3;
+        vehicle_width = 2.5;
+    }
+    if (!(type_proportion >= 0.0)) type_proportion = 0.0;
+    if (type_proportion > 1.0) type_proportion = 1.0;
+    if (n_env == 0) return T2D_OK;
+    if (hipSetDevice(device_id) != hipSuccess) return T2D_ERR_HIP;
+    const size_t E = (size_t)n_env;
+    const size_t sizes[8] = {E * T2D_GEN_MAX_QUADS * 8 * sizeof(float), E * T2D_GEN_MAX_QUADS * sizeof(int32_t),
+                             E * sizeof(int32_t), E * 3 * sizeof(double), E * 8 * sizeof(float), E * sizeof(double),
+                             E * 4 * sizeof(float), E * sizeof(uint32_t)};
+    void* host[8] = {quads, quad_id, n_quads, start, target, target_heading, boundary, info};
+    size_t total = 0, off[8];
+    for (int k = 0; k < 8; ++k) {
+        off[k] = total;
+        total += (sizes[k] + 255) & ~(size_t)255;
+    }
+    char* dev = nullptr;
+    if (hipMalloc(&dev, total) != hipSuccess) return T2D_ERR_HIP;
+    SceneParams P{seed, first_env, n_env, type_proportion, vehicle_length, vehicle_width,
+                  (float*)(dev + off[0]), (int32_t*)(dev + off[1]), (int32_t*)(dev + off[2]), (double*)(dev + off[3]),
+                  (float*)(dev + off[4]), (double*)(dev + off[5]), (float*)(dev + off[6]), (uint32_t*)(dev + off[7])};
+    hipLaunchKernelGGL(generate_parking_kernel, dim3((n_env + kGenBlock - 1) / kGenBlock), dim3(kGenBlock), 0, 0, P);
+    int rc = T2D_OK;
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = T2D_ERR_HIP;
+    for (int k = 0; k < 8 && rc == T2D_OK; ++k)
+        if (hipMemcpy(host[k], dev + off[k], sizes[k], hipMemcpyDeviceToHost) != hipSuccess) rc = T2D_ERR_HIP;
+    (void)hipFree(dev);
+    return rc;
+}

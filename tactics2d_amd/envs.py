@@ -50,7 +50,16 @@ class VecParkingEnv:
     _max_accel = MAX_ACCEL
     _discrete_actions = {1: (0, 0), 2: (-0.5, 0), 3: (0.5, 0), 4: (0, 1), 5: (0, -1)}  # parking.py:95
 
-    def __init__(self, n_envs, max_step=int(2e4), continuous=True, auto_reset=False, seed=0, device_id=0):
+    def __init__(self, n_envs, max_step=int(2e4), continuous=True, auto_reset=False, seed=0, device_id=0,
+                 scene_source="layout", type_proportion=0.5):
+        """scene_source: "generator" = the device-side ParkingLotGenerator (tactics2d_amd.generator; bay and
+        parallel scenes with the reference's rejection sampler, `type_proportion` as in envs/parking.py:331-333),
+        "layout" = the fixed bay layout of scenarios.parking (BASELINE config 2)."""
+        if scene_source not in ("layout", "generator"):
+            raise ValueError(f"unknown scene_source {scene_source!r}")
+        self.scene_source = scene_source
+        self.type_proportion = type_proportion
+        self.device_id = device_id
         self.n_envs = int(n_envs)
         self.max_step = max_step
         self.continuous = continuous
@@ -64,10 +73,18 @@ class VecParkingEnv:
 
     # ------------------------------------------------------------------ reset
     def reset(self, seed=None, options=None):
-        """New scenes for every env (ParkingLotGenerator-like bay layouts, scenarios.parking)."""
+        """New scenes for every env (envs/parking.py:397-405: map_.reset(), map_generator.generate(map_),
+        agent.reset(start_state))."""
         if seed is not None:
             self._seed = int(seed)
-        sc = scenarios.parking(self.n_envs, seed0=self._seed * self.n_envs)
+        if self.scene_source == "generator":
+            from .generator import ParkingLotGenerator
+            from .participant import VEHICLE_TEMPLATE
+            gen = ParkingLotGenerator(VEHICLE_TEMPLATE["medium_car"][:2], self.type_proportion, self.device_id)
+            self.generated = gen.generate(self.n_envs, self._seed)
+            sc = self.generated.scene(max_step=self.max_step)
+        else:
+            sc = scenarios.parking(self.n_envs, seed0=self._seed * self.n_envs)
         self._scene = sc
         m = self.scenario_manager
         m.pool.set_target_areas(sc.target)
@@ -162,12 +179,13 @@ class ParkingEnv:
     """Single-scene adapter with the reference's 5-tuple (envs/parking.py:256)."""
 
     def __init__(self, type_proportion=0.5, render_mode="rgb_array", render_fps=60, max_step=int(2e4),
-                 continuous=True, seed=0):
+                 continuous=True, seed=0, scene_source="layout"):
         if render_mode not in ("human", "rgb_array"):
             raise NotImplementedError(f"Render mode {render_mode} is not supported.")  # parking.py:119-120
         self.max_step = max_step
         self.continuous = continuous
-        self._vec = VecParkingEnv(1, max_step, continuous, seed=seed)
+        self._vec = VecParkingEnv(1, max_step, continuous, seed=seed, scene_source=scene_source,
+                                  type_proportion=type_proportion)
         self.observation_space = self._vec.observation_space
         self.action_space = self._vec.action_space
         self.scenario_manager = self._vec.scenario_manager

@@ -1,0 +1,253 @@
+"""ParkingLotGenerator (scope row f4).  Parity with the reference is UNPINNED (numpy global stream + shapely
+predicates cannot run here), so the CPU tests check the restatement against the properties the reference's
+algorithm guarantees (generate_parking_lot.py:207-237, 239-444) and against its own exact-rational predicates;
+the GPU tests pin the kernel to the restatement bit for bit."""
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+N = 6000
+
+
+@pytest.fixture(scope="module")
+def scenes(oracle):
+    return oracle.generate_parking(20260927, N, 0.5, (4.284, 1.81))
+
+
+def _exact_intersects(a, b):
+    """Closed convex-quad intersection in exact rational arithmetic (separating edge with strict separation)."""
+    def ccw(q):
+        q = [(Fraction(float(x)), Fraction(float(y))) for x, y in q]
+        area = sum(q[i][0] * q[(i + 1) % 4][1] - q[(i + 1) % 4][0] * q[i][1] for i in range(4))
+        return q if area >= 0 else q[::-1]
+    A, B = ccw(a), ccw(b)
+    for P, Q in ((A, B), (B, A)):
+        for i in range(4):
+            p, q = P[i], P[(i + 1) % 4]
+            if all((q[0] - p[0]) * (r[1] - p[1]) - (q[1] - p[1]) * (r[0] - p[0]) < 0 for r in Q):
+                return False
+    return True
+
+
+def _box(x, y, h, L, W):
+    c, s = np.cos(h), np.sin(h)
+    base = np.array([[L / 2, -W / 2], [L / 2, W / 2], [-L / 2, W / 2], [-L / 2, -W / 2]])
+    return base @ np.array([[c, s], [-s, c]]) + [x, y]
+
+
+def test_flags_and_mode_statistics(oracle, scenes):
+    info = scenes["info"]
+    assert not (info & (oracle.GEN_UNVERIFIED | oracle.GEN_START_UNVERIFIED | oracle.GEN_NONCONVEX | oracle.GEN_OVERFLOW)).any()
+    bay = (info & oracle.GEN_BAY) != 0
+    assert abs(bay.mean() - 0.5) < 0.03                       # type_proportion :256
+    flipped = (info & oracle.GEN_START_FLIPPED) != 0
+    assert abs(flipped.mean() - 0.5) < 0.03                   # :412
+    tflip = (info & oracle.GEN_TARGET_FLIPPED) != 0
+    assert (tflip == (flipped & ~bay)).all()                  # only parallel targets flip :421-431
+    assert ((info >> 8) & 255).min() >= 1 and ((info >> 16) & 255).min() >= 1
+    # proportions 0 / 1 give one mode only; out-of-range values are clipped (:57)
+    assert not (oracle.generate_parking(1, 500, 0.0)["info"] & oracle.GEN_BAY).any()
+    assert (oracle.generate_parking(1, 500, 1.0)["info"] & oracle.GEN_BAY).all()
+    assert (oracle.generate_parking(1, 500, 7.0)["info"] & oracle.GEN_BAY).all()
+    assert not (oracle.generate_parking(1, 500, -2.0)["info"] & oracle.GEN_BAY).any()
+
+
+def test_heading_and_position_ranges(oracle, scenes):
+    info = scenes["info"]
+    bay = (info & oracle.GEN_BAY) != 0
+    flipped = (info & oracle.GEN_START_FLIPPED) != 0
+    th = scenes["target_heading"] - np.where((info & oracle.GEN_TARGET_FLIPPED) != 0, np.pi, 0.0)
+    assert (th[bay] >= np.pi * 4 / 9).all() and (th[bay] <= np.pi * 5 / 9).all()          # :33-36
+    assert (th[~bay] >= -np.pi / 18).all() and (th[~bay] <= np.pi / 18).all()
+    sh = scenes["start"][:, 2] - np.where(flipped, np.pi, 0.0)
+    assert (np.abs(sh) <= np.pi / 18 + 1e-12).all()                                       # :227
+    assert (np.abs(scenes["start"][:, 0]) <= 7.5 + 1e-9).all()                            # :399
+    # clipped Gaussians actually hit both clip ends and the interior
+    assert (th[bay] == np.pi * 4 / 9).any() and (th[bay] == np.pi * 5 / 9).any()
+    assert 0.2 < (np.abs(th[bay] - np.pi / 2) < np.pi / 54).mean() < 0.9
+    # target centre on x = 0, 0.8 .. 1.6 m above the back wall line (:108-113)
+    t = scenes["target"].astype(np.float64)
+    nf = (info & oracle.GEN_TARGET_FLIPPED) == 0
+    assert np.abs(t[nf].mean(axis=1)[:, 0]).max() < 1e-6
+    low = t.min(axis=1)[:, 1]
+    assert (low >= 0.8 - 1e-5).all() and (low <= 1.6 + 1e-5).all()
+
+
+def test_boundary_is_floor_ceil_of_start_and_target(oracle, scenes):
+    t = scenes["target"].astype(np.float64)
+    # the reference's centre = mean of the ring (:410-412); the fp32 ring here is within 1e-6 of the fp64 one
+    tx, ty = t.mean(axis=1).T
+    sx, sy = scenes["start"][:, 0], scenes["start"][:, 1]
+    b = scenes["boundary"].astype(np.float64)
+    near = lambda v: np.abs(v - np.round(v)) < 1e-5    # a value that close to an integer may floor either way
+    for col, want, val in ((0, np.floor(np.minimum(sx, tx) - 13), np.minimum(sx, tx)), (1, np.ceil(np.maximum(sx, tx) + 13), np.maximum(sx, tx)),
+                           (2, np.floor(np.minimum(sy, ty) - 13), np.minimum(sy, ty)), (3, np.ceil(np.maximum(sy, ty) + 13), np.maximum(sy, ty))):
+        ok = (b[:, col] == want) | near(val)
+        assert ok.all(), col
+    assert (b[:, 1] - b[:, 0] >= 26).all() and (b[:, 3] - b[:, 2] >= 26).all()
+
+
+def test_obstacle_ids_follow_map_add_area(oracle, scenes):
+    ids, n = scenes["quad_id"], scenes["n_quads"]
+    for e in range(0, N, 7):
+        row = ids[e, :n[e]]
+        assert (row >= 0).all() and (ids[e, n[e]:] == -1).all()
+        assert len(set(row.tolist())) == n[e]                  # dict keys: one area per id (map.py:444-453)
+    # wall on the left (id 1 with vertices on x = -15) => no further vehicle "0003" on that side (:272-285): an
+    # id-3 area can then only be the far wall (:347-356), which spans the whole scene width.  (Ids 5 / 7 may still
+    # appear: the perturbed vehicles are numbered from len(obstacles) + 1, :371, and Map.add_area lets such an
+    # id replace a parked vehicle with the same id -- kept as the reference does it.)
+    q = scenes["quads"]
+    n_wall = 0
+    for e in range(N):
+        row = ids[e, :n[e]].tolist()
+        if 1 in row and (q[e, row.index(1), :, 0] == -15.0).any():
+            n_wall += 1
+            if 3 in row:
+                xs = q[e, row.index(3), :, 0]
+                assert xs.min() == -15.0 and xs.max() == 15.0
+    assert 0.1 * N < n_wall < 0.3 * N                          # p = 0.2, minus the 5 % drop
+    assert 3 <= n.min() or (n < 3).mean() < 0.01
+    assert n.max() <= oracle.GEN_MAX_QUADS
+
+
+def test_accepted_scenes_satisfy_the_reference_predicates(oracle, scenes):
+    """_verify_obstacles / _verify_start_state: the target touches none of back wall / neighbours, the start
+    footprint touches no obstacle and not the target -- re-checked in exact rational arithmetic on the fp32
+    outputs (a 1e-6 shift cannot create contact: the reference's own margins are >= 0.8 m)."""
+    L, W = 4.284, 1.81
+    info = scenes["info"]
+    flipped = (info & oracle.GEN_START_FLIPPED) != 0
+    for e in range(0, N, 9):
+        n = scenes["n_quads"][e]
+        ids = scenes["quad_id"][e, :n].tolist()
+        tq = scenes["target"][e]
+        for k in range(n):
+            if ids[k] in (0, 1, 2):
+                assert not _exact_intersects(tq, scenes["quads"][e, k]), (e, ids[k])
+        sx, sy, sh = scenes["start"][e]
+        if flipped[e]:   # the flip mirrors (x, y) through the box centre = itself, and turns the heading by pi
+            sh -= np.pi
+        body = _box(sx, sy, sh, L, W)
+        for k in range(n):
+            assert not _exact_intersects(body, scenes["quads"][e, k]), (e, ids[k])
+        assert not _exact_intersects(body, tq)
+
+
+def test_streams_are_per_scene_and_reproducible(oracle):
+    a = oracle.generate_parking(5, 300, 0.5)
+    b = oracle.generate_parking(5, 100, 0.5, first_env=200)
+    for k in a:
+        assert np.array_equal(a[k][200:], b[k]), k          # scene e depends on (seed, first_env + e) only
+    c = oracle.generate_parking(6, 300, 0.5)
+    assert not np.array_equal(a["start"], c["start"])
+    assert len({tuple(r) for r in a["start"].round(9).tolist()}) == 300   # scenes differ from one another
+    # thread count does not change the result
+    oracle.set_threads(4)
+    try:
+        d = oracle.generate_parking(5, 300, 0.5)
+    finally:
+        oracle.set_threads(1)
+    for k in a:
+        assert np.array_equal(a[k], d[k]), k
+
+
+def test_libm_and_deterministic_trig_agree(oracle):
+    """trig=0 uses libm (what numpy calls), trig=1 the deterministic spec the GPU shares: same scenes up to
+    1-ulp effects (a rejection decision could flip in principle; none does on this sample)."""
+    a = oracle.generate_parking(11, 2000, 0.5, trig=0)
+    b = oracle.generate_parking(11, 2000, 0.5, trig=1)
+    same = (a["info"] == b["info"]) & (a["n_quads"] == b["n_quads"])
+    assert same.mean() > 0.999
+    assert np.abs(a["start"][same] - b["start"][same]).max() < 1e-9
+    assert np.abs(a["quads"][same] - b["quads"][same]).max() < 1e-5
+
+
+# --------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_env,prop,size", [(1, 4096, 0.5, (4.284, 1.81)), (2, 1000, 1.0, (5.3, 2.5)),
+                                                   (3, 1000, 0.0, (5.3, 2.5)), (2**63 + 5, 257, 0.3, (4.5, 2.0)),
+                                                   (4, 1, 0.5, (5.3, 2.5))])
+def test_kernel_matches_oracle_bit_for_bit(oracle, seed, n_env, prop, size):
+    from tactics2d_amd.generator import ParkingLotGenerator
+    got = ParkingLotGenerator(size, prop).generate(n_env, seed, first_env=17)
+    want = oracle.generate_parking(seed, n_env, prop, size, first_env=17, trig=1)
+    assert np.array_equal(got.info, want["info"])
+    assert np.array_equal(got.n_quads, want["n_quads"]) and np.array_equal(got.quad_id, want["quad_id"])
+    assert np.array_equal(got.start, want["start"])                     # fp64, bit for bit
+    assert np.array_equal(got.target_heading, want["target_heading"])
+    assert np.array_equal(got.quads.view(np.uint32), want["quads"].view(np.uint32))
+    assert np.array_equal(got.target.view(np.uint32), want["target"].view(np.uint32))
+    assert np.array_equal(got.boundary, want["boundary"])
+
+
+@pytest.mark.gpu
+def test_invalid_vehicle_size_falls_back_and_args_are_checked(oracle):
+    from tactics2d_amd import _ffi
+    from tactics2d_amd.generator import ParkingLotGenerator
+    g = ParkingLotGenerator((2.0, 3.0), 0.5)                              # length < width :45-50
+    assert g.vehicle_size == (5.3, 2.5)
+    got = g.generate(64, 9)
+    want = oracle.generate_parking(9, 64, 0.5, (5.3, 2.5))
+    assert np.array_equal(got.start, want["start"])
+    assert ParkingLotGenerator().generate(0, 1).n_env == 0
+    with pytest.raises(_ffi.T2DError):
+        _ffi.check(_ffi.lib().t2d_generate_parking(0, 1, 0, 4, 0.5, 5.3, 2.5, *([None] * 8)))
+
+
+@pytest.mark.gpu
+def test_generated_scenes_load_and_step(oracle):
+    """The generated batch goes through the ordinary boundary (set_static_geometry / set_target_areas / reset) and
+    the step kernel's events agree with the oracle on it; nobody starts in collision or out of bounds."""
+    import helpers as H
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.generator import ParkingLotGenerator
+    from tactics2d_amd.pool import ParticipantPool
+    n_env = 2048
+    scenes = ParkingLotGenerator((4.284, 1.81), 0.5).generate(n_env, 31)
+    sc = scenes.scene()
+    pool = ParticipantPool(n_env, 1)
+    sc.load(pool)
+    pool.collide()
+    assert not pool.download(L.F_FLAGS).any()                              # _verify_start_state held
+    rng = np.random.default_rng(0)
+    cfg = oracle.make_config(**sc.status)
+    hit = 0
+    for step in range(40):
+        a0, a1 = sc.sample_actions(rng)
+        pool.set_actions(a0, a1)
+        pool.step(100)
+        gx, gy, gh = (pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING))
+        wf, we = oracle.collide(sc.rows, n_env, 1, gx, gy, gh, sc.type_id, sc.active, sc.static, sc.boundary, None, None, 1)
+        assert (pool.download(L.F_FLAGS) == wf).all()
+        hit += int((wf != 0).sum())
+    pool.close()
+
+
+@pytest.mark.gpu
+def test_vec_parking_env_with_generated_scenes():
+    """VecParkingEnv(scene_source="generator"): reset() = generate + install + agent reset (envs/parking.py:397-441);
+    a second reset with another seed gives other scenes; episodes run and terminate through the normal path."""
+    from tactics2d_amd.envs import ParkingEnv, VecParkingEnv
+    env = VecParkingEnv(512, max_step=50, scene_source="generator", type_proportion=0.5, seed=3)
+    obs, infos = env.reset()
+    start = env.generated.start
+    assert np.allclose(obs[:, 0], start[:, 0], atol=1e-5) and np.allclose(obs[:, 1], start[:, 1], atol=1e-5)
+    assert np.array_equal(infos["target_heading"], np.float32(env.generated.target_heading))
+    assert set(np.unique(env.generated.mode)) == {"bay", "parallel"}
+    lidar = infos["lidar"]
+    assert np.isfinite(lidar).any(axis=1).mean() > 0.9              # obstacles within 20 m of nearly every start
+    rng = np.random.default_rng(0)
+    done = np.zeros(512, bool)
+    for _ in range(60):
+        obs, reward, term, trunc, infos = env.step(env.action_space.sample(rng, 512))
+        done |= term | trunc
+    assert done.all()                                               # max_step = 50 truncates whoever survived
+    obs2, _ = env.reset(seed=4)
+    assert not np.allclose(obs2[:, :2], start[:, :2])
+    env.close()
+    one = ParkingEnv(type_proportion=1.0, scene_source="generator", seed=11)
+    o, info = one.reset()
+    assert one._vec.generated.mode[0] == "bay" and o.shape == (6,)
+    one.close()
