@@ -382,12 +382,29 @@ int t2d_generate_parking(int32_t device_id, uint64_t seed, int64_t first_env, in
                          int32_t* n_quads, double* start, float* target, double* target_heading, float* boundary,
                          uint32_t* info);
 
+/* The same generator writing straight into a pool (one participant per env, SingleTrackKinematics/Dynamics/PointMass
+ * agent of type 0): every env's obstacles, boundary, target area (+ area centroid), start pose, episode snapshot and
+ * IoU / shaping state are produced and installed by one launch -- what t2d_set_static_geometry + t2d_set_target_areas
+ * + t2d_reset + t2d_snapshot do for host-described scenes, with nothing crossing PCIe (envs/parking.py:397-441).
+ * Call after t2d_set_param_table / t2d_set_status_config.  Scene of (env e, episode k) = stream
+ * first_env + e + k * env_stride (env_stride = total envs of the job).  regenerate != 0: every later t2d_step /
+ * t2d_check_status is followed, on the same stream, by a launch that gives each env whose episode just ended
+ * (terminated | truncated) the scene of its next episode -- the reference's reset() per episode -- while the terminal
+ * status / reward stay readable until the next step; kernel_id 6 in t2d_profile_read.  Geometry lives in a
+ * fixed-capacity layout (T2D_GEN_MAX_QUADS polygon slots per env); t2d_set_static_geometry leaves this mode.
+ * t2d_get_parking_scenes copies the current scenes (arrays as in t2d_generate_parking, any pointer may be NULL) and
+ * the per-env episode numbers to the host.                                                                         */
+int t2d_parking_scenes(t2d_pool* pool, uint64_t seed, int64_t first_env, int64_t env_stride, double type_proportion,
+                       double vehicle_length, double vehicle_width, int32_t regenerate);
+int t2d_get_parking_scenes(t2d_pool* pool, float* quads, int32_t* quad_id, int32_t* n_quads, double* start,
+                           float* target, double* target_heading, float* boundary, uint32_t* info, int32_t* episode);
+
 /* Kernel variants: 0 = exact (library-grade fp64 trig every sub-step), 1 = fast
  * (rotation recurrence, default).  Both satisfy the 1e-5 contract; see DESIGN.md.       */
 int t2d_set_integrator_variant(t2d_pool* pool, int32_t variant);
 
 /* Per-kernel timing with HIP events recorded on the launch stream around each kernel.
- * kernel_id: 0 = integrate, 1 = collide(+status), 2 = fused step, 3 = lidar, 4 = idm, 5 = drift.                                    */
+ * kernel_id: 0 = integrate, 1 = collide(+status), 2 = fused step, 3 = lidar, 4 = idm, 5 = drift, 6 = scene regeneration.                                   */
 int t2d_profile_enable(t2d_pool* pool, int32_t on);
 int t2d_profile_read(t2d_pool* pool, int32_t kernel_id, double* total_ms, int64_t* launches);
 

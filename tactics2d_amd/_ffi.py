@@ -72,6 +72,8 @@ SYMBOLS = {
     "t2d_verify_state": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
     "t2d_generate_parking": (C.c_int, [C.c_int32, C.c_uint64, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_double]
                              + [_vp] * 8),
+    "t2d_parking_scenes": (C.c_int, [_vp, C.c_uint64, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int32]),
+    "t2d_get_parking_scenes": (C.c_int, [_vp] * 10),
     "t2d_set_integrator_variant": (C.c_int, [_vp, C.c_int32]),
     "t2d_profile_enable": (C.c_int, [_vp, C.c_int32]),
     "t2d_profile_read": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -122,6 +122,18 @@ int log2_pad(int A) {  // lanes per env = 2^l >= A, at least 2: the second lane 
     return l;
 }
 
+// dword offsets of one workgroup's record: env polygon ranges, polygon vertex ranges, AABBs, vertices (static, lanes)
+void fill_layout(t2d::GeoLayout& gl, int epb, const int mp[2], const int mv[2]) {
+    int off = 0;
+    for (int k = 0; k < 2; ++k) { gl.off_pstart[k] = off; off += epb + 1; }
+    for (int k = 0; k < 2; ++k) { gl.off_vstart[k] = off; off += mp[k] + 1; }
+    off = (off + 3) & ~3;  // 16-B align the float4 AABBs
+    for (int k = 0; k < 2; ++k) { gl.off_aabb[k] = off; off += 4 * mp[k]; }
+    for (int k = 0; k < 2; ++k) { gl.off_xy[k] = off; off += 2 * mv[k]; }  // even -> 8-B aligned
+    gl.stride = (off + 3) & ~3;
+    gl.epb = epb;
+}
+
 // (Re)build the packed per-workgroup geometry records from the host CSR copies and upload them.
 int rebuild_geo(t2d_pool* p) {
     const int E = p->v.n_env;
@@ -151,14 +163,7 @@ int rebuild_geo(t2d_pool* p) {
                 mv[k] = std::max(mv[k], g.vert_off[p1] - g.vert_off[p0]);
             }
         }
-        int off = 0;
-        for (int k = 0; k < 2; ++k) { gl.off_pstart[k] = off; off += epb + 1; }
-        for (int k = 0; k < 2; ++k) { gl.off_vstart[k] = off; off += mp[k] + 1; }
-        off = (off + 3) & ~3;  // 16-B align the float4 AABBs
-        for (int k = 0; k < 2; ++k) { gl.off_aabb[k] = off; off += 4 * mp[k]; }
-        for (int k = 0; k < 2; ++k) { gl.off_xy[k] = off; off += 2 * mv[k]; }  // even -> 8-B aligned
-        gl.stride = (off + 3) & ~3;
-        gl.epb = epb;
+        fill_layout(gl, epb, mp, mv);
         if (gl.stride <= kBudgetDwords) break;
         if ((epb << log2A) <= 64 || epb == 1)
             return fail(p, T2D_ERR_GEOMETRY, "static + lane geometry of one workgroup exceeds the 32 KiB LDS record");
@@ -241,7 +246,17 @@ int rebuild_lidar_geo(t2d_pool* p) {
     const auto& g = p->hgeo[0];
     int rc;
     p->lidar.max_static_verts = 0;
-    if (!g.present || g.env_off[E] == 0) {
+    p->lidar.env_vert_cnt = nullptr;
+    if (p->scene_mode) {  // generated scenes: every env owns 4 * T2D_GEN_MAX_QUADS vertex slots of d_lidar_xy, the
+        constexpr int VS = 4 * T2D_GEN_MAX_QUADS;  // scene kernel maintains the vertices and the per-env count
+        std::vector<int32_t> evo(E + 1), nxt((size_t)VS * E);
+        for (int e = 0; e <= E; ++e) evo[e] = VS * e;
+        for (size_t v = 0; v < nxt.size(); ++v) nxt[v] = (int32_t)((v & ~(size_t)3) | ((v + 1) & 3));
+        if ((rc = dev_replace(p, &p->d_lidar_env_off, evo.data(), evo.size()))) return rc;
+        if ((rc = dev_replace(p, &p->d_lidar_next, nxt.data(), nxt.size()))) return rc;
+        p->lidar.max_static_verts = VS;
+        p->lidar.env_vert_cnt = p->d_lidar_cnt;
+    } else if (!g.present || g.env_off[E] == 0) {
         if ((rc = dev_replace<int32_t>(p, &p->d_lidar_env_off, nullptr, 0))) return rc;
         if ((rc = dev_replace<int32_t>(p, &p->d_lidar_next, nullptr, 0))) return rc;
         if ((rc = dev_replace<float>(p, &p->d_lidar_xy, nullptr, 0))) return rc;
@@ -451,7 +466,8 @@ int t2d_destroy(t2d_pool* p) {
                     p->d_last_pose, p->d_max_iou, p->d_min_dist, p->d_snap_min_dist, p->d_last_valid,
                     p->d_lidar_env_off, p->d_lidar_next, p->d_lidar_xy, p->d_beam_sin, p->d_beam_cos,
                     p->d_snap[0], p->d_snap[1], p->d_snap[2],
-                    p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_idm_rows, p->d_idm_ctrl, p->d_snap_omega[0], p->d_snap_omega[1], p->d_time_penalty};
+                    p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_idm_rows, p->d_idm_ctrl, p->d_snap_omega[0], p->d_snap_omega[1], p->d_time_penalty,
+                    p->d_scene_arrays, p->d_lidar_cnt};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->prof_events) {
@@ -512,6 +528,10 @@ int t2d_set_static_geometry(t2d_pool* p, const int32_t* env_poly_offsets,
     T2D_HIP(p, hipDeviceSynchronize());
     const int E = p->v.n_env;
     int rc;
+    if (p->scene_mode) {  // host-described geometry replaces the generated scenes
+        p->scene_mode = p->scene_regen = false;
+        if ((rc = dev_replace<float>(p, &p->d_lidar_xy, nullptr, 0))) return rc;
+    }
     if (env_poly_offsets) {
         if (!poly_vert_offsets || (!verts_xy && env_poly_offsets[E] > 0))
             return fail(p, T2D_ERR_INVALID, "polygon CSR arrays missing");
@@ -542,6 +562,7 @@ int t2d_set_lane_geometry(t2d_pool* p, const int32_t* env_lane_offsets,
     T2D_HIP(p, hipDeviceSynchronize());
     const int E = p->v.n_env;
     int rc;
+    if (p->scene_mode) return fail(p, T2D_ERR_STATE, "lane geometry cannot be combined with generated parking scenes");
     if (env_lane_offsets) {
         if (!lane_vert_offsets || (!verts_xy && env_lane_offsets[E] > 0))
             return fail(p, T2D_ERR_INVALID, "lane CSR arrays missing");
@@ -559,6 +580,8 @@ int t2d_set_target_areas(t2d_pool* p, const float* target_xy, const float* centr
     T2D_HIP(p, hipDeviceSynchronize());
     const int E = p->v.n_env;
     int rc;
+    if (p->scene_mode) return fail(p, T2D_ERR_STATE, "target areas belong to the generated parking scenes; "
+                                                      "call t2d_set_static_geometry first to leave that mode");
     if (!target_xy) {
         if ((rc = dev_replace<double>(p, &p->d_target_xy, nullptr, 0))) return rc;
         if ((rc = dev_replace<double>(p, &p->d_target_c, nullptr, 0))) return rc;
@@ -773,6 +796,15 @@ int t2d_collide(t2d_pool* p, void* hip_stream) {
     return collide_impl(p, false, 0, (hipStream_t)hip_stream);
 }
 
+// generated parking scenes with regeneration on: envs whose episode ended in the launch just enqueued get a new scene
+static int regenerate_done_scenes(t2d_pool* p, hipStream_t s) {
+    if (!p->scene_regen) return T2D_OK;
+    int rc;
+    if ((rc = record_event(p, 6, s, true))) return rc;
+    T2D_HIP(p, t2d::launch_parking_scenes(p->v, p->scene, p->v.n_env, 2, s));
+    return record_event(p, 6, s, false);
+}
+
 int t2d_check_status(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     if (!p) return T2D_ERR_INVALID;
     if (!p->have_params || !p->have_reset)
@@ -781,6 +813,7 @@ int t2d_check_status(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)(p->step_count % T2D_RECORD_RING) * p->v.n_env;
     int rc = collide_impl(p, true, interval_ms, (hipStream_t)hip_stream);
     if (rc == T2D_OK) p->step_count++;
+    if (rc == T2D_OK) rc = regenerate_done_scenes(p, (hipStream_t)hip_stream);
     return rc;
 }
 
@@ -800,6 +833,7 @@ int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     if (p->has_drift && (rc = drift_impl(p, interval_ms, (hipStream_t)hip_stream))) return rc;
     rc = collide_impl(p, true, interval_ms, (hipStream_t)hip_stream, p->integrator_variant);
     if (rc == T2D_OK) p->step_count++;
+    if (rc == T2D_OK) rc = regenerate_done_scenes(p, (hipStream_t)hip_stream);
     return rc;
 }
 
@@ -859,6 +893,145 @@ int t2d_restore(t2d_pool* p, int32_t mode, void* hip_stream) {
     if (!p->have_snapshot) return fail(p, T2D_ERR_STATE, "t2d_snapshot must precede t2d_restore");
     if (mode != 0 && mode != 1) return fail(p, T2D_ERR_INVALID, "mode must be 0 (all) or 1 (done envs)");
     T2D_HIP(p, t2d::launch_restore(p->v, p->d_snap, p->d_snap_ids, mode, (hipStream_t)hip_stream));
+    return T2D_OK;
+}
+
+int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t env_stride, double type_proportion,
+                       double vehicle_length, double vehicle_width, int32_t regenerate) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!p->have_params) return fail(p, T2D_ERR_STATE, "t2d_set_param_table must precede t2d_parking_scenes");
+    if (p->v.A != 1) return fail(p, T2D_ERR_INVALID, "generated parking scenes need a pool with one participant per env");
+    if (p->has_drift) return fail(p, T2D_ERR_INVALID, "SingleTrackDrift agents are not supported in generated parking scenes");
+    if (p->hgeo[1].present) return fail(p, T2D_ERR_STATE, "lane geometry cannot be combined with generated parking scenes");
+    if (env_stride < 0) return fail(p, T2D_ERR_INVALID, "env_stride must be >= 0");
+    if (vehicle_length < vehicle_width || !(vehicle_length > 0.0) || !(vehicle_width > 0.0)) {
+        vehicle_length = 5.3;  // ParkingLotGenerator.__init__ :45-57
+        vehicle_width = 2.5;
+    }
+    if (!(type_proportion >= 0.0)) type_proportion = 0.0;
+    if (type_proportion > 1.0) type_proportion = 1.0;
+    T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, hipDeviceSynchronize());
+    const int E = p->v.n_env;
+    constexpr int K = T2D_GEN_MAX_QUADS;
+    int rc;
+    // geometry records in capacity layout: K polygon slots of 4 vertices per env, a dead slot = a box nothing meets
+    t2d::GeoLayout gl{};
+    const int log2A = log2_pad(1);
+    int epb = 256 >> log2A;
+    for (;; epb >>= 1) {
+        const int mp[2] = {K * epb, 0}, mv[2] = {4 * K * epb, 0};
+        fill_layout(gl, epb, mp, mv);
+        if (gl.stride <= 8192) break;
+        if ((epb << log2A) <= 64) return fail(p, T2D_ERR_GEOMETRY, "scene record exceeds the 32 KiB LDS record");
+    }
+    gl.has[0] = 1;
+    gl.has[1] = 0;
+    const int nb = (E + epb - 1) / epb;
+    {
+        std::vector<uint32_t> rec((size_t)nb * gl.stride, 0u);
+        const float dead[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
+        for (int b = 0; b < nb; ++b) {
+            uint32_t* r = rec.data() + (size_t)b * gl.stride;
+            int32_t* pstart = reinterpret_cast<int32_t*>(r) + gl.off_pstart[0];
+            int32_t* vstart = reinterpret_cast<int32_t*>(r) + gl.off_vstart[0];
+            for (int el = 0; el <= epb; ++el) pstart[el] = K * el;
+            for (int q = 0; q <= K * epb; ++q) vstart[q] = 4 * q;
+            float* bb = reinterpret_cast<float*>(r) + gl.off_aabb[0];
+            for (int q = 0; q < K * epb; ++q) memcpy(bb + 4 * q, dead, sizeof dead);
+        }
+        if ((rc = dev_replace(p, &p->d_geo, rec.data(), rec.size()))) return rc;
+    }
+    p->hgeo[0] = t2d_pool::HostGeo{};
+    p->v.geo = p->d_geo;
+    p->v.geo_layout = gl;
+    {
+        std::vector<float> zf(4 * (size_t)E, 0.f);
+        std::vector<double> zd(8 * (size_t)E, 0.0);
+        if ((rc = dev_replace(p, &p->d_boundary, zf.data(), zf.size()))) return rc;
+        if ((rc = dev_replace<uint8_t>(p, &p->d_boundary_valid, nullptr, 0))) return rc;
+        if ((rc = dev_replace(p, &p->d_target_xy, zd.data(), 8 * (size_t)E))) return rc;
+        if ((rc = dev_replace(p, &p->d_target_c, zd.data(), 2 * (size_t)E))) return rc;
+        std::vector<float> zl(8 * (size_t)K * E, 0.f);
+        std::vector<int32_t> zi(E, 0);
+        if ((rc = dev_replace(p, &p->d_lidar_xy, zl.data(), zl.size()))) return rc;
+        if ((rc = dev_replace(p, &p->d_lidar_cnt, zi.data(), zi.size()))) return rc;
+    }
+    p->v.boundary = p->d_boundary;
+    p->v.boundary_valid = nullptr;
+    p->v.target_xy = p->d_target_xy;
+    p->v.target_c = p->d_target_c;
+    p->have_target = true;
+    const size_t nbytes = 4 * (size_t)p->v.N;
+    for (int k = 0; k < 6; ++k)
+        if (!p->d_snap[k]) T2D_HIP(p, hipMalloc((void**)&p->d_snap[k], nbytes));
+    if (!p->d_snap_ids) T2D_HIP(p, hipMalloc((void**)&p->d_snap_ids, nbytes));
+    // the per-scene arrays (layout of t2d_generate_parking's outputs) + the episode counters
+    const size_t sizes[9] = {(size_t)E * K * 8 * sizeof(float), (size_t)E * K * sizeof(int32_t), (size_t)E * sizeof(int32_t),
+                             (size_t)E * 3 * sizeof(double), (size_t)E * 8 * sizeof(float), (size_t)E * sizeof(double),
+                             (size_t)E * 4 * sizeof(float), (size_t)E * sizeof(uint32_t), (size_t)E * sizeof(int32_t)};
+    size_t off[9], total = 0;
+    for (int k = 0; k < 9; ++k) {
+        off[k] = total;
+        total += (sizes[k] + 255) & ~(size_t)255;
+    }
+    if (p->d_scene_arrays) {
+        T2D_HIP(p, hipFree(p->d_scene_arrays));
+        p->d_scene_arrays = nullptr;
+    }
+    T2D_HIP(p, hipMalloc(&p->d_scene_arrays, total));
+    T2D_HIP(p, hipMemset(p->d_scene_arrays, 0, total));
+    char* base = (char*)p->d_scene_arrays;
+    t2d::SceneView& sv = p->scene;
+    sv = t2d::SceneView{};
+    sv.seed = seed; sv.first_env = first_env; sv.env_stride = env_stride;
+    sv.type_proportion = type_proportion; sv.len = vehicle_length; sv.wid = vehicle_width;
+    sv.quads = (float*)(base + off[0]); sv.quad_id = (int32_t*)(base + off[1]); sv.n_quads = (int32_t*)(base + off[2]);
+    sv.start = (double*)(base + off[3]); sv.target = (float*)(base + off[4]); sv.target_heading = (double*)(base + off[5]);
+    sv.boundary_out = (float*)(base + off[6]); sv.info = (uint32_t*)(base + off[7]); sv.episode = (int32_t*)(base + off[8]);
+    sv.geo = p->d_geo; sv.gl = gl;
+    sv.lidar_xy = p->d_lidar_xy; sv.lidar_cnt = p->d_lidar_cnt;
+    sv.boundary = p->d_boundary; sv.target_xy = p->d_target_xy; sv.target_c = p->d_target_c;
+    for (int k = 0; k < 6; ++k) sv.snap[k] = p->d_snap[k];
+    sv.snap_ids = p->d_snap_ids;
+    sv.snap_min_dist = p->d_snap_min_dist;
+    sv.ids_word = ((uint32_t)(int)p->host_params[0][T2D_P_MODEL] << t2d::kIdsModelShift) | (0u << t2d::kIdsTypeShift) |
+                  (1u << t2d::kIdsActiveShift);
+    p->scene_mode = true;
+    p->scene_regen = regenerate != 0;
+    if ((rc = rebuild_lidar_geo(p))) return rc;
+    {  // t2d_reset's remaining columns: wheel speeds start at zero
+        for (int f : {T2D_F_OMEGA_F, T2D_F_OMEGA_R}) T2D_HIP(p, hipMemset(p->field_ptr[f], 0, nbytes));
+    }
+    T2D_HIP(p, t2d::launch_parking_scenes(p->v, sv, E, 1, nullptr));
+    T2D_HIP(p, hipDeviceSynchronize());
+    p->have_reset = true;
+    p->have_snapshot = true;
+    for (int k = 0; k < 6; ++k) p->v.snap[k] = p->d_snap[k];
+    p->v.snap_ids = p->d_snap_ids;
+    p->v.snap_omega[0] = p->v.snap_omega[1] = nullptr;
+    p->v.auto_reset = p->auto_reset ? 1 : 0;
+    return T2D_OK;
+}
+
+int t2d_get_parking_scenes(t2d_pool* p, float* quads, int32_t* quad_id, int32_t* n_quads, double* start, float* target,
+                           double* target_heading, float* boundary, uint32_t* info, int32_t* episode) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!p->scene_mode) return fail(p, T2D_ERR_STATE, "t2d_parking_scenes has not been called on this pool");
+    T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, hipDeviceSynchronize());
+    const size_t E = (size_t)p->v.n_env;
+    constexpr size_t K = T2D_GEN_MAX_QUADS;
+    const t2d::SceneView& sv = p->scene;
+    if (quads) T2D_HIP(p, hipMemcpy(quads, sv.quads, E * K * 8 * sizeof(float), hipMemcpyDeviceToHost));
+    if (quad_id) T2D_HIP(p, hipMemcpy(quad_id, sv.quad_id, E * K * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (n_quads) T2D_HIP(p, hipMemcpy(n_quads, sv.n_quads, E * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (start) T2D_HIP(p, hipMemcpy(start, sv.start, E * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (target) T2D_HIP(p, hipMemcpy(target, sv.target, E * 8 * sizeof(float), hipMemcpyDeviceToHost));
+    if (target_heading) T2D_HIP(p, hipMemcpy(target_heading, sv.target_heading, E * sizeof(double), hipMemcpyDeviceToHost));
+    if (boundary) T2D_HIP(p, hipMemcpy(boundary, sv.boundary_out, E * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    if (info) T2D_HIP(p, hipMemcpy(info, sv.info, E * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (episode) T2D_HIP(p, hipMemcpy(episode, sv.episode, E * sizeof(int32_t), hipMemcpyDeviceToHost));
     return T2D_OK;
 }
 

@@ -19,8 +19,8 @@
 
 #include <cmath>
 
-#include "../../include/t2d.h"
 #include "t2d_math.h"
+#include "t2d_pool.h"
 
 namespace t2d {
 
@@ -153,27 +153,23 @@ T2D_DEV double gap(const Quad& a, const Quad& b) {
     return __builtin_sqrt(best);
 }
 
-struct SceneParams {
-    uint64_t seed;
-    int64_t first_env;
-    int n_env;
-    double type_proportion, len, wid;
-    float* quads;
-    int32_t* quad_id;
-    int32_t* n_quads;
-    double* start;
-    float* target;
-    double* target_heading;
-    float* boundary;
-    uint32_t* info;
+// Everything `generate` hands back for one scene (registers / private memory of the lane)
+struct Scene {
+    Quad quad[T2D_GEN_MAX_QUADS];  // Map.areas order
+    int id[T2D_GEN_MAX_QUADS];
+    int n;
+    double sx, sy, sh;
+    Quad target;
+    double target_h;
+    float bound[4];
+    uint32_t info;
 };
 
-__global__ __launch_bounds__(kGenBlock) void generate_parking_kernel(SceneParams P) {
-    const int e = blockIdx.x * kGenBlock + threadIdx.x;
-    if (e >= P.n_env) return;
+// ParkingLotGenerator.generate for the scene that owns counter stream `stream_index`
+__device__ __noinline__ void make_scene(uint64_t seed, int64_t stream_index, double type_proportion, double len, double wid,
+                                        Scene& out) {
+    Stream rng{seed + (uint64_t)(stream_index + 1) * 0xD1B54A32D192ED03ull};
     constexpr double kSize = 30.0, kMargin = 13.0, kD0 = 0.8, kD1 = 1.6;
-    const double len = P.len, wid = P.wid;
-    Stream rng{P.seed + (uint64_t)(P.first_env + e + 1) * 0xD1B54A32D192ED03ull};
     uint32_t flags = 0;
 
     Quad list[kListCap];
@@ -189,7 +185,7 @@ __global__ __launch_bounds__(kGenBlock) void generate_parking_kernel(SceneParams
         list_id[n_list++] = id;
     };
 
-    const bool bay = rng.u() < P.type_proportion;  // :256
+    const bool bay = rng.u() < type_proportion;  // :256
     const double slot_len = bay ? 7.0 : 4.5;
     const double next = bay ? wid : len;
     const int n_more = bay ? 3 : 2;  // (n_parking_lots - 3) // 2
@@ -380,26 +376,163 @@ __global__ __launch_bounds__(kGenBlock) void generate_parking_kernel(SceneParams
     }
     if (list_full) flags |= T2D_GEN_OVERFLOW;
 
-    float* oq = P.quads + (size_t)e * T2D_GEN_MAX_QUADS * 8;
+    out.n = n_out;
     for (int k = 0; k < T2D_GEN_MAX_QUADS; ++k) {
-        for (int c = 0; c < 8; ++c) oq[8 * k + c] = k < n_out ? (float)list[slot_src[k]].v[c] : 0.0f;
-        P.quad_id[(size_t)e * T2D_GEN_MAX_QUADS + k] = k < n_out ? slot_id[k] : -1;
+        if (k < n_out) {
+            out.quad[k] = list[slot_src[k]];
+            out.id[k] = slot_id[k];
+        } else {
+            out.quad[k] = Quad{{0, 0, 0, 0, 0, 0, 0, 0}};
+            out.id[k] = -1;
+        }
     }
-    P.n_quads[e] = n_out;
-    P.start[3 * (size_t)e] = sx;
-    P.start[3 * (size_t)e + 1] = sy;
-    P.start[3 * (size_t)e + 2] = sh;
-    for (int c = 0; c < 8; ++c) P.target[8 * (size_t)e + c] = (float)target.v[c];
-    P.target_heading[e] = target_h;
-    P.boundary[4 * (size_t)e] = (float)__builtin_floor(__builtin_fmin(sx, tx) - kMargin);  // :436-440
-    P.boundary[4 * (size_t)e + 1] = (float)__builtin_ceil(__builtin_fmax(sx, tx) + kMargin);
-    P.boundary[4 * (size_t)e + 2] = (float)__builtin_floor(__builtin_fmin(sy, ty) - kMargin);
-    P.boundary[4 * (size_t)e + 3] = (float)__builtin_ceil(__builtin_fmax(sy, ty) + kMargin);
-    P.info[e] = flags | (bay ? T2D_GEN_BAY : 0u) | ((uint32_t)(attempts > 255 ? 255 : attempts) << 8) |
-                ((uint32_t)(s_attempts > 255 ? 255 : s_attempts) << 16);
+    out.sx = sx;
+    out.sy = sy;
+    out.sh = sh;
+    out.target = target;
+    out.target_h = target_h;
+    out.bound[0] = (float)__builtin_floor(__builtin_fmin(sx, tx) - kMargin);  // :436-440
+    out.bound[1] = (float)__builtin_ceil(__builtin_fmax(sx, tx) + kMargin);
+    out.bound[2] = (float)__builtin_floor(__builtin_fmin(sy, ty) - kMargin);
+    out.bound[3] = (float)__builtin_ceil(__builtin_fmax(sy, ty) + kMargin);
+    out.info = flags | (bay ? T2D_GEN_BAY : 0u) | ((uint32_t)(attempts > 255 ? 255 : attempts) << 8) |
+               ((uint32_t)(s_attempts > 255 ? 255 : s_attempts) << 16);
+}
+
+// the per-scene output arrays of t2d_generate_parking / t2d_get_parking_scenes
+T2D_DEV void store_scene(const SceneView& sv, int e, const Scene& sc) {
+    float* oq = sv.quads + (size_t)e * T2D_GEN_MAX_QUADS * 8;
+    for (int k = 0; k < T2D_GEN_MAX_QUADS; ++k) {
+        for (int c = 0; c < 8; ++c) oq[8 * k + c] = (float)sc.quad[k].v[c];
+        sv.quad_id[(size_t)e * T2D_GEN_MAX_QUADS + k] = sc.id[k];
+    }
+    sv.n_quads[e] = sc.n;
+    sv.start[3 * (size_t)e] = sc.sx;
+    sv.start[3 * (size_t)e + 1] = sc.sy;
+    sv.start[3 * (size_t)e + 2] = sc.sh;
+    for (int c = 0; c < 8; ++c) sv.target[8 * (size_t)e + c] = (float)sc.target.v[c];
+    sv.target_heading[e] = sc.target_h;
+    for (int c = 0; c < 4; ++c) sv.boundary_out[4 * (size_t)e + c] = sc.bound[c];
+    sv.info[e] = sc.info;
+}
+
+// fp32 ring -> counter-clockwise fp32 ring, decided like prepare_polys (t2d_api.hip): shoelace of the fp32 values in fp64
+T2D_DEV void ring_ccw_f32(const Quad& q, float* o) {
+    Quad r;
+    for (int c = 0; c < 8; ++c) r.v[c] = (double)(float)q.v[c];
+    const Quad n = counter_clockwise(r);
+    for (int c = 0; c < 8; ++c) o[c] = (float)n.v[c];
+}
+
+// What t2d_set_static_geometry / t2d_set_target_areas / t2d_reset / t2d_snapshot would do for env e, written in place:
+// the env's K polygon slots of the workgroup geometry record (dead slots get a box nothing can meet), its lidar ring
+// slots, boundary, target area + area centroid, the ego's state and episode snapshot, the IoU / shaping state.
+T2D_DEV void install_scene(const PoolView& pv, const SceneView& sv, int e, const Scene& sc, bool first) {
+    constexpr int K = T2D_GEN_MAX_QUADS;
+    const GeoLayout& gl = sv.gl;
+    const int blk = e / gl.epb, el = e - blk * gl.epb;
+    uint32_t* rec = sv.geo + (size_t)blk * gl.stride;
+    float4* bb = reinterpret_cast<float4*>(rec + gl.off_aabb[0]) + K * el;
+    float* xy = reinterpret_cast<float*>(rec + gl.off_xy[0]) + 8 * K * el;
+    float* lxy = sv.lidar_xy + (size_t)e * 8 * K;
+    for (int k = 0; k < K; ++k) {
+        float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
+        if (k < sc.n) {
+            ring_ccw_f32(sc.quad[k], r);
+            box = make_float4(r[0], r[0], r[1], r[1]);
+            for (int v = 1; v < 4; ++v) {
+                box.x = __builtin_fminf(box.x, r[2 * v]);
+                box.y = __builtin_fmaxf(box.y, r[2 * v]);
+                box.z = __builtin_fminf(box.z, r[2 * v + 1]);
+                box.w = __builtin_fmaxf(box.w, r[2 * v + 1]);
+            }
+        }
+        bb[k] = box;
+        for (int c = 0; c < 8; ++c) {
+            xy[8 * k + c] = r[c];
+            lxy[8 * k + c] = r[c];
+        }
+    }
+    sv.lidar_cnt[e] = 4 * sc.n;
+    for (int c = 0; c < 4; ++c) sv.boundary[4 * (size_t)e + c] = sc.bound[c];
+    // target area (t2d_set_target_areas): fp32 ring as doubles, counter-clockwise, area centroid
+    float tr[8];
+    ring_ccw_f32(sc.target, tr);
+    double tq[8], area = 0.0, cx = 0.0, cy = 0.0;
+    for (int c = 0; c < 8; ++c) tq[c] = (double)tr[c];
+    for (int i = 0; i < 4; ++i) {
+        const int j = (i + 1) & 3;
+        area += tq[2 * i] * tq[2 * j + 1] - tq[2 * j] * tq[2 * i + 1];
+    }
+    for (int i = 0; i < 4; ++i) {
+        const int j = (i + 1) & 3;
+        const double w = tq[2 * i] * tq[2 * j + 1] - tq[2 * j] * tq[2 * i + 1];
+        cx += (tq[2 * i] + tq[2 * j]) * w;
+        cy += (tq[2 * i + 1] + tq[2 * j + 1]) * w;
+    }
+    cx = cx / (3.0 * area);
+    cy = cy / (3.0 * area);
+    for (int c = 0; c < 8; ++c) sv.target_xy[8 * (size_t)e + c] = tq[c];
+    sv.target_c[2 * (size_t)e] = cx;
+    sv.target_c[2 * (size_t)e + 1] = cy;
+    // ego state + episode snapshot (t2d_reset with speed 0, then t2d_snapshot); one participant per env
+    const float fx = (float)sc.sx, fy = (float)sc.sy, fh = (float)sc.sh;
+    const float st[6] = {fx, fy, fh, 0.f, 0.f, 0.f};
+    float* cur[6] = {pv.x, pv.y, pv.heading, pv.speed, pv.vx, pv.vy};
+    for (int k = 0; k < 6; ++k) {
+        cur[k][e] = st[k];
+        sv.snap[k][e] = st[k];
+    }
+    pv.ids[e] = sv.ids_word;
+    sv.snap_ids[e] = sv.ids_word;
+    const double dx = (double)fx - cx, dy = (double)fy - cy;
+    const double dist = __builtin_sqrt(dx * dx + dy * dy);
+    pv.min_dist[e] = dist;
+    sv.snap_min_dist[e] = dist;
+    pv.max_iou[e] = -INFINITY;
+    pv.last_valid[e] = 0;
+    pv.cnt_na[e] = 0;
+    pv.iou[e] = NAN;
+    pv.env_flags[e] = 0;
+    pv.cnt_step[e] = 0;
+    pv.frame_ms[e] = 0;
+    if (first) {  // a finished episode keeps its terminal status / reward / flags visible until the next step
+        pv.flags[e] = 0;
+        pv.reward[e] = 0.f;
+        uchar4 s4;
+        s4.x = T2D_SCENARIO_NORMAL; s4.y = T2D_TRAFFIC_NORMAL; s4.z = 0; s4.w = 0;
+        reinterpret_cast<uchar4*>(pv.status)[e] = s4;
+    }
+}
+
+// mode 0: generate into the scene arrays; 1: generate + install every env; 2: the same for envs whose episode just ended
+__global__ __launch_bounds__(kGenBlock) void parking_scene_kernel(PoolView pv, SceneView sv, int n_env, int mode) {
+    const int e = blockIdx.x * kGenBlock + threadIdx.x;
+    if (e >= n_env) return;
+    int episode = 0;
+    if (mode == 2) {
+        const uchar4 st = reinterpret_cast<const uchar4*>(pv.status)[e];
+        if (!(st.z | st.w)) return;
+        episode = sv.episode[e] + 1;
+    }
+    Scene sc;
+    make_scene(sv.seed, sv.first_env + e + (int64_t)episode * sv.env_stride, sv.type_proportion, sv.len, sv.wid, sc);
+    store_scene(sv, e, sc);
+    if (mode != 0) {
+        sv.episode[e] = episode;
+        install_scene(pv, sv, e, sc, mode == 1);
+    }
 }
 
 }  // namespace
+
+hipError_t launch_parking_scenes(const PoolView& v, const SceneView& sv, int n_env, int mode, hipStream_t s) {
+    if (n_env <= 0) return hipSuccess;
+    hipLaunchKernelGGL(parking_scene_kernel, dim3((n_env + kGenBlock - 1) / kGenBlock), dim3(kGenBlock), 0, s, v, sv,
+                       n_env, mode);
+    return hipGetLastError();
+}
 
 }  // namespace t2d
 
@@ -431,12 +564,15 @@ extern "C" int t2d_generate_parking(int32_t device_id, uint64_t seed, int64_t fi
     }
     char* dev = nullptr;
     if (hipMalloc(&dev, total) != hipSuccess) return T2D_ERR_HIP;
-    SceneParams P{seed, first_env, n_env, type_proportion, vehicle_length, vehicle_width,
-                  (float*)(dev + off[0]), (int32_t*)(dev + off[1]), (int32_t*)(dev + off[2]), (double*)(dev + off[3]),
-                  (float*)(dev + off[4]), (double*)(dev + off[5]), (float*)(dev + off[6]), (uint32_t*)(dev + off[7])};
-    hipLaunchKernelGGL(generate_parking_kernel, dim3((n_env + kGenBlock - 1) / kGenBlock), dim3(kGenBlock), 0, 0, P);
+    SceneView sv{};
+    sv.seed = seed; sv.first_env = first_env; sv.env_stride = 0;
+    sv.type_proportion = type_proportion; sv.len = vehicle_length; sv.wid = vehicle_width;
+    sv.quads = (float*)(dev + off[0]); sv.quad_id = (int32_t*)(dev + off[1]); sv.n_quads = (int32_t*)(dev + off[2]);
+    sv.start = (double*)(dev + off[3]); sv.target = (float*)(dev + off[4]); sv.target_heading = (double*)(dev + off[5]);
+    sv.boundary_out = (float*)(dev + off[6]); sv.info = (uint32_t*)(dev + off[7]);
     int rc = T2D_OK;
-    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = T2D_ERR_HIP;
+    if (launch_parking_scenes(PoolView{}, sv, n_env, 0, nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+        rc = T2D_ERR_HIP;
     for (int k = 0; k < 8 && rc == T2D_OK; ++k)
         if (hipMemcpy(host[k], dev + off[k], sizes[k], hipMemcpyDeviceToHost) != hipSuccess) rc = T2D_ERR_HIP;
     (void)hipFree(dev);

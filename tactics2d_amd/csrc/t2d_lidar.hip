@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     int n_static = 0;
     if (lv.env_vert_off) {
         const int v0 = lv.env_vert_off[env];
-        n_static = lv.env_vert_off[env + 1] - v0;
+        n_static = lv.env_vert_cnt ? lv.env_vert_cnt[env] : lv.env_vert_off[env + 1] - v0;
         for (int q = tid; q < n_static; q += kLidarBlock) {
             const float2 p = reinterpret_cast<const float2*>(lv.xy)[v0 + q];
             const float2 r = reinterpret_cast<const float2*>(lv.xy)[lv.next_vert[v0 + q]];

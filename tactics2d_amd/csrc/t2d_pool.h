@@ -77,6 +77,7 @@ struct PoolView {
 // Lidar inputs (t2d_lidar.hip): plain per-env CSR of the static obstacle rings + beam tables.
 struct LidarView {
     const int32_t* env_vert_off;  // [E+1] vertex range of env e, or null (no static obstacles)
+    const int32_t* env_vert_cnt;  // null, or [E] vertices in use when envs own fixed-capacity ranges (generated scenes)
     const int32_t* next_vert;     // [V] index of the next vertex of the same ring
     const float* xy;              // [V][2]
     const double* beam_sin;       // [n_beams] sin / cos of linspace(0, 2pi, n_beams, endpoint=False)
@@ -84,6 +85,23 @@ struct LidarView {
     double max_range;
     int32_t n_beams, include_participants, ego_index, max_static_verts;
     int32_t max_slots;  // LDS edge slots per env: max_static_verts + 4 * max_agents (when participants are scanned)
+};
+
+// Device-side ParkingLotGenerator (t2d_generate.hip): stream parameters, the per-scene output arrays and -- when the
+// scenes are installed in a pool -- the places t2d_set_static_geometry / t2d_set_target_areas / t2d_reset /
+// t2d_snapshot would have written: every env owns T2D_GEN_MAX_QUADS polygon slots of 4 vertices.
+struct SceneView {
+    uint64_t seed;
+    int64_t first_env, env_stride;  // scene of (env e, episode k) = stream first_env + e + k * env_stride
+    double type_proportion, len, wid;
+    float* quads; int32_t* quad_id; int32_t* n_quads; double* start; float* target; double* target_heading;
+    float* boundary_out; uint32_t* info; int32_t* episode;
+    uint32_t* geo;        // the pool's geometry records (capacity layout)
+    GeoLayout gl;
+    float* lidar_xy; int32_t* lidar_cnt;
+    float* boundary; double* target_xy; double* target_c;
+    float* snap[6]; uint32_t* snap_ids; uint32_t ids_word;
+    double* snap_min_dist;
 };
 
 // IDM controllers (t2d_idm.hip): parameter sets + one controller id per participant.
@@ -145,6 +163,11 @@ struct t2d_pool {
     uint32_t* d_snap_ids = nullptr;
     bool have_snapshot = false;
     bool auto_reset = false;
+    // generated parking scenes (row f4): capacity-layout geometry owned by the device
+    bool scene_mode = false, scene_regen = false;
+    t2d::SceneView scene{};
+    void* d_scene_arrays = nullptr;   // one allocation behind scene.quads ... scene.episode
+    int32_t* d_lidar_cnt = nullptr;
     long long step_count = 0;  // t2d_step calls so far (selects the record ring slot)
     // profiling
     bool profiling = false;
@@ -166,4 +189,5 @@ hipError_t launch_verify(const PoolView& v, const float* x, const float* y, cons
 hipError_t launch_idm(const PoolView& v, const IdmView& iv, const int32_t* forced_leader, hipStream_t s);
 hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
                           hipStream_t s);
+hipError_t launch_parking_scenes(const PoolView& v, const SceneView& sv, int n_env, int mode, hipStream_t s);
 }  // namespace t2d

@@ -77,22 +77,32 @@ class VecParkingEnv:
         agent.reset(start_state))."""
         if seed is not None:
             self._seed = int(seed)
+        m = self.scenario_manager
         if self.scene_source == "generator":
-            from .generator import ParkingLotGenerator
-            from .participant import VEHICLE_TEMPLATE
-            gen = ParkingLotGenerator(VEHICLE_TEMPLATE["medium_car"][:2], self.type_proportion, self.device_id)
-            self.generated = gen.generate(self.n_envs, self._seed)
-            sc = self.generated.scene(max_step=self.max_step)
+            # generate + install in one launch on the device; with auto_reset every finished episode continues in a
+            # NEW scene (the reference's reset() per episode), not in a copy of the first one
+            from .participant import VEHICLE_TEMPLATE, vehicle_model
+            size = VEHICLE_TEMPLATE["medium_car"][:2]
+            ego = vehicle_model("medium_car", "kinematics", speed_range=(-0.5, 0.5), accel_range=(-2.0, 2.0),
+                                steer_range=(-0.524, 0.524))
+            rows = ego.param_row(L.SHAPE_OBB, *size)[None]
+            m.configure(rows, check_dynamic=False, check_off_lane=False, check_arrival=1, check_no_action=1,
+                        no_action_max_step=100, shaped_reward=1)
+            m.pool.parking_scenes(self._seed, self.type_proportion, size, regenerate=self.auto_reset)
+            self.generated = m.pool.get_parking_scenes()
+            bad = self.generated.info & 0x1e
+            if bad.any():
+                raise RuntimeError(f"{int((bad != 0).sum())} generated scenes are flagged; use another seed")
+            self._scene = self.generated.scene(max_step=self.max_step)
         else:
             sc = scenarios.parking(self.n_envs, seed0=self._seed * self.n_envs)
-        self._scene = sc
-        m = self.scenario_manager
-        m.pool.set_target_areas(sc.target)
-        m.configure(sc.rows, check_dynamic=False, check_off_lane=False, check_arrival=1, check_no_action=1,
-                    no_action_max_step=100, shaped_reward=1)
-        m.status_checklist["collision"].reset(_csr_to_lists(sc.static))
-        m.status_checklist["out_bound"].reset(sc.boundary)
-        m.reset(sc.x, sc.y, sc.heading, sc.speed, sc.type_id, sc.active)
+            self._scene = sc
+            m.pool.set_target_areas(sc.target)
+            m.configure(sc.rows, check_dynamic=False, check_off_lane=False, check_arrival=1, check_no_action=1,
+                        no_action_max_step=100, shaped_reward=1)
+            m.status_checklist["collision"].reset(_csr_to_lists(sc.static))
+            m.status_checklist["out_bound"].reset(sc.boundary)
+            m.reset(sc.x, sc.y, sc.heading, sc.speed, sc.type_id, sc.active)
         m.pool.set_auto_reset(self.auto_reset)
         # SingleLineLidar(perception_range=20, freq_detect=360 * 10)  envs/parking.py:303-304,422-431
         m.pool.lidar_config(360, 20.0, include_participants=False)
@@ -158,9 +168,17 @@ class VecParkingEnv:
         return dict(state=dict(x=obs[:, 0], y=obs[:, 1], heading=obs[:, 2], speed=obs[:, 3], vx=obs[:, 4],
                                vy=obs[:, 5], frame=self.scenario_manager.pool.download(L.F_FRAME_MS)),
                     scenario_status=scenario_status, traffic_status=traffic_status,
-                    target_area=None if self._scene is None else self._scene.target,
-                    target_heading=None if self._scene is None else self._scene.target_heading,
+                    target_area=None if self._scene is None else self._targets()[0],
+                    target_heading=None if self._scene is None else self._targets()[1],
                     iou=self.scenario_manager.pool.download(L.F_IOU), lidar=self._lidar())
+
+    def _targets(self):
+        """Target areas / headings of the scenes the envs are in NOW (they change per episode when generated scenes
+        are regenerated on the device)."""
+        if self.scene_source == "generator" and self.auto_reset:
+            self.generated = self.scenario_manager.pool.get_parking_scenes()
+            return self.generated.target, np.float32(self.generated.target_heading)
+        return self._scene.target, self._scene.target_heading
 
     def _lidar(self):
         """info["lidar"]: 360 ranges per env, +inf = no return (the reference's scan_result)."""

@@ -154,6 +154,31 @@ class ParticipantPool:
             self.upload(f, v)
         return out
 
+    def parking_scenes(self, seed, type_proportion=0.5, vehicle_size=(5.3, 2.5), regenerate=False, first_env=0,
+                       env_stride=None):
+        """Device-side ParkingLotGenerator writing straight into this pool (one participant per env): obstacles,
+        boundary, target, start pose, snapshot, IoU state -- nothing crosses PCIe.  regenerate=True: after every
+        step, envs whose episode ended get the scene of their next episode (stream first_env + e + k * env_stride)."""
+        stride = self.n_env if env_stride is None else int(env_stride)
+        self._ck(self._lib.t2d_parking_scenes(self._h, int(seed) & (2**64 - 1), int(first_env), stride,
+                                              float(type_proportion), float(vehicle_size[0]), float(vehicle_size[1]),
+                                              int(bool(regenerate))))
+
+    def get_parking_scenes(self):
+        """The scenes currently installed by parking_scenes(): a generator.ParkingScenes plus `.episode`."""
+        from .generator import MAX_QUADS, ParkingScenes
+        n = self.n_env
+        out = ParkingScenes(np.zeros((n, MAX_QUADS, 4, 2), np.float32), np.zeros((n, MAX_QUADS), np.int32),
+                            np.zeros(n, np.int32), np.zeros((n, 3)), np.zeros((n, 4, 2), np.float32), np.zeros(n),
+                            np.zeros((n, 4), np.float32), np.zeros(n, np.uint32), None)
+        episode = np.zeros(n, np.int32)
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._ck(self._lib.t2d_get_parking_scenes(self._h, ptr(out.quads), ptr(out.quad_id), ptr(out.n_quads),
+                                                  ptr(out.start), ptr(out.target), ptr(out.target_heading),
+                                                  ptr(out.boundary), ptr(out.info), ptr(episode)))
+        out.episode = episode
+        return out
+
     def set_integrator_variant(self, variant):
         v = {"exact": 0, "fast": 1}.get(variant, variant)
         self._ck(self._lib.t2d_set_integrator_variant(self._h, int(v)))

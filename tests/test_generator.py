@@ -251,3 +251,153 @@ def test_vec_parking_env_with_generated_scenes():
     o, info = one.reset()
     assert one._vec.generated.mode[0] == "bay" and o.shape == (6,)
     one.close()
+
+
+def _pool_for(sc, n_env):
+    from tactics2d_amd.pool import ParticipantPool
+    pool = ParticipantPool(n_env, 1)
+    pool.set_param_table(sc.rows)
+    pool.set_status_config(**sc.status)
+    return pool
+
+
+_CMP = None
+
+
+def _fields():
+    from tactics2d_amd import layout as L
+    return [L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_VX, L.F_VY, L.F_IDS, L.F_FLAGS, L.F_ENV_FLAGS, L.F_CNT_STEP,
+            L.F_FRAME_MS, L.F_STATUS, L.F_REWARD, L.F_IOU, L.F_CNT_NO_ACTION]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_env", [700, 4096])
+def test_device_installed_scenes_equal_the_host_install(n_env):
+    """t2d_parking_scenes (generate + install in one launch, capacity-layout geometry) against the same scenes taken
+    through the host boundary (generate -> set_static_geometry / set_target_areas / reset / snapshot): every pool
+    field equal after the install and after each of 40 steps, lidar scans included."""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.generator import ParkingLotGenerator
+    size = (4.284, 1.81)
+    scenes = ParkingLotGenerator(size, 0.5).generate(n_env, 77)
+    sc = scenes.scene(max_step=25)
+    host = _pool_for(sc, n_env)
+    sc.load(host)
+    dev = _pool_for(sc, n_env)
+    dev.parking_scenes(77, 0.5, size, regenerate=False)
+    got = dev.get_parking_scenes()
+    assert np.array_equal(got.start, scenes.start) and np.array_equal(got.quads, scenes.quads)
+    assert np.array_equal(got.info, scenes.info) and not got.episode.any()
+    for p in (host, dev):
+        p.set_auto_reset(True)
+        p.lidar_config(360, 20.0, include_participants=False)
+    rng = np.random.default_rng(5)
+    ever_done = False
+    for step in range(41):
+        ever_done |= bool(host.download(L.F_STATUS)[:, 2:].any())
+        for f in _fields():
+            assert np.array_equal(host.download(f), dev.download(f), equal_nan=True), (step, f)
+        if step % 8 == 0:
+            host.lidar_scan(); dev.lidar_scan()
+            assert np.array_equal(host.download(L.F_LIDAR), dev.download(L.F_LIDAR)), step
+        a0, a1 = sc.sample_actions(rng)
+        for p in (host, dev):
+            p.set_actions(a0, a1)
+            p.step(100)
+    assert ever_done                                       # episodes did end (and were auto-reset) on the way
+    host.close(); dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_scene_regeneration_follows_the_episode_streams(oracle, auto_reset):
+    """regenerate=True: an env whose episode ended gets the scene of stream first_env + e + k * stride right after the
+    step; everything it installs is checked against the oracle's scene for that stream, the step's own flags against
+    the oracle's events on the scene that was in place during the step."""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.generator import ParkingLotGenerator
+    n_env, seed, size, first, stride = 320, 12, (4.284, 1.81), 1000, 5000
+    scenes = ParkingLotGenerator(size, 0.5).generate(n_env, seed, first_env=first)
+    sc = scenes.scene(max_step=12)
+    pool = _pool_for(sc, n_env)
+    pool.parking_scenes(seed, 0.5, size, regenerate=True, first_env=first, env_stride=stride)
+    if auto_reset:
+        pool.set_auto_reset(True)
+    cur = pool.get_parking_scenes()
+    assert np.array_equal(cur.start, scenes.start)
+    episode = np.zeros(n_env, np.int64)
+    rng = np.random.default_rng(2)
+    n_regen = 0
+    for step in range(45):
+        a0, a1 = sc.sample_actions(rng)
+        pool.set_actions(a0, a1)
+        before = cur
+        pool.profile_enable(step == 0)
+        pool.step(100)
+        status = pool.download(L.F_STATUS)
+        done = (status[:, 2] | status[:, 3]).astype(bool)
+        cur = pool.get_parking_scenes()
+        # flags of this step were computed on `before`
+        flags = pool.download(L.F_FLAGS)
+        live = ~done
+        gx, gy, gh = (pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING))
+        if live.any() and not auto_reset:
+            idx = np.nonzero(live)[0]
+            sub = ParkingScenesSubset(before, idx)
+            wf, _ = oracle.collide(sc.rows, len(idx), 1, gx[idx], gy[idx], gh[idx], sc.type_id[idx], sc.active[idx],
+                                   sub.static_csr(), sub.boundary, None, None, 1)
+            assert np.array_equal(flags[idx], wf)
+        for e in np.nonzero(done)[0]:
+            episode[e] += 1
+            want = oracle.generate_parking(seed, 1, 0.5, size, first_env=first + e + episode[e] * stride, trig=1)
+            assert cur.episode[e] == episode[e]
+            assert np.array_equal(cur.start[e], want["start"][0]) and np.array_equal(cur.quads[e], want["quads"][0])
+            assert np.array_equal(cur.target[e], want["target"][0]) and cur.info[e] == want["info"][0]
+            assert np.array_equal(cur.boundary[e], want["boundary"][0])
+            assert gx[e] == np.float32(want["start"][0, 0]) and gy[e] == np.float32(want["start"][0, 1])
+            assert gh[e] == np.float32(want["start"][0, 2])
+            n_regen += 1
+        assert np.array_equal(cur.episode, episode)
+        keep = ~done
+        assert np.array_equal(cur.start[keep], before.start[keep])      # nobody else's scene moved
+        assert (pool.download(L.F_CNT_STEP)[done] == 0).all()
+    assert n_regen > n_env                                                # every env went through > 1 episode on average
+    pool.close()
+
+
+class ParkingScenesSubset:
+    """Rows `idx` of a ParkingScenes as the CSR / boundary arguments of the oracle."""
+
+    def __init__(self, scenes, idx):
+        from tactics2d_amd.generator import ParkingScenes
+        self._s = ParkingScenes(scenes.quads[idx], scenes.quad_id[idx], scenes.n_quads[idx], scenes.start[idx],
+                                scenes.target[idx], scenes.target_heading[idx], scenes.boundary[idx], scenes.info[idx], None)
+        self.boundary = np.ascontiguousarray(scenes.boundary[idx], np.float32)
+
+    def static_csr(self):
+        return self._s.static_csr()
+
+
+@pytest.mark.gpu
+def test_vec_env_auto_reset_moves_on_to_new_scenes():
+    """auto_reset + generated scenes: a finished episode continues in the scene of the env's next episode (the
+    reference generates a new lot at every reset), infos follow, and step_torch keeps everything on the device."""
+    import torch
+    from tactics2d_amd.envs import VecParkingEnv
+    env = VecParkingEnv(256, max_step=10, scene_source="generator", auto_reset=True, seed=8)
+    obs, infos = env.reset()
+    first_targets = infos["target_area"].copy()
+    start0 = env.generated.start.copy()
+    rng = np.random.default_rng(1)
+    for _ in range(12):
+        obs, reward, term, trunc, infos = env.step(env.action_space.sample(rng, 256))
+    assert env.generated.episode.min() >= 1                       # max_step = 10: everyone is in a later episode
+    moved = np.abs(env.generated.start[:, :2] - start0[:, :2]).max(axis=1) > 1e-3
+    assert moved.mean() > 0.95
+    assert not np.array_equal(infos["target_area"], first_targets)
+    assert np.array_equal(infos["target_area"], env.generated.target)
+    act = torch.zeros((256, 2), dtype=torch.float32, device="cuda")
+    out = env.step_torch(act)
+    torch.cuda.synchronize()
+    assert out["lidar"].shape == (256, 360) and torch.isfinite(out["lidar"]).any()
+    env.close()
