@@ -1314,7 +1314,7 @@ static double gen_distance(const double* a, const double* b) {
         }
     return sqrt(best);
 }
-#define GEN_LIST_CAP 64
+#define GEN_LIST_CAP 24
 typedef struct { double q[GEN_LIST_CAP][8]; int id[GEN_LIST_CAP]; int n; int overflow; } gen_list;
 static void gen_append(gen_list* l, int id, const double* q) {
     if (l->n >= GEN_LIST_CAP) { l->overflow = 1; return; }

@@ -13,8 +13,8 @@
 // and this kernel agrees with that oracle bit for bit.
 //
 // One lane per scene.  A scene is a sequential rejection sampler (every draw depends on the outcome of
-// the previous tests), so the parallelism is across scenes only; the obstacle list lives in private
-// memory (4 KB per lane).  Reset-time work: one launch per batch of scenes, not per step.
+// the previous tests), so the parallelism is across scenes only; the obstacle list lives in LDS
+// (lane-interleaved, 1.7 KB per lane).  Reset-time work: one launch per batch of scenes, not per step.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -27,7 +27,7 @@ namespace t2d {
 namespace {
 
 constexpr int kGenBlock = 64;
-constexpr int kListCap = 64;
+constexpr int kListCap = 24;  // obstacle list entries per scene (3 rejected attempts' worth; more is flagged)
 constexpr double kPi = 3.141592653589793;
 constexpr double kTwoPi = 2.0 * 3.141592653589793;
 
@@ -153,11 +153,29 @@ T2D_DEV double gap(const Quad& a, const Quad& b) {
     return __builtin_sqrt(best);
 }
 
-// Everything `generate` hands back for one scene (registers / private memory of the lane)
-struct Scene {
-    Quad quad[T2D_GEN_MAX_QUADS];  // Map.areas order
-    int id[T2D_GEN_MAX_QUADS];
-    int n;
+// The obstacle list of a lane and the Map.areas slot tables live in LDS, lane-interleaved (word w of lane t at
+// base[w * kGenBlock + t]: conflict-free): in private memory every list access is a scratch round trip, and a scene is
+// one long dependent chain, so those latencies add up to most of the launch.
+struct LaneMem {
+    double* q;       // [kListCap * 8] list polygons
+    int* id;         // [kListCap] their reference ids
+    int* slot_id;    // [T2D_GEN_MAX_QUADS] ids in Map.areas order
+    int* slot_src;   // [T2D_GEN_MAX_QUADS] list index that holds the area's final polygon
+    T2D_DEV Quad quad(int i) const {
+        Quad r;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) r.v[c] = q[(i * 8 + c) * kGenBlock];
+        return r;
+    }
+    T2D_DEV void put(int i, const Quad& v) const {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) q[(i * 8 + c) * kGenBlock] = v.v[c];
+    }
+};
+
+// What `generate` hands back besides the areas (registers)
+struct SceneHead {
+    int n;  // areas
     double sx, sy, sh;
     Quad target;
     double target_h;
@@ -166,14 +184,12 @@ struct Scene {
 };
 
 // ParkingLotGenerator.generate for the scene that owns counter stream `stream_index`
-__device__ __noinline__ void make_scene(uint64_t seed, int64_t stream_index, double type_proportion, double len, double wid,
-                                        Scene& out) {
+T2D_DEV void make_scene(uint64_t seed, int64_t stream_index, double type_proportion, double len, double wid,
+                        const LaneMem& m, SceneHead& out) {
     Stream rng{seed + (uint64_t)(stream_index + 1) * 0xD1B54A32D192ED03ull};
     constexpr double kSize = 30.0, kMargin = 13.0, kD0 = 0.8, kD1 = 1.6;
     uint32_t flags = 0;
 
-    Quad list[kListCap];
-    int list_id[kListCap];
     int n_list = 0;
     bool list_full = false;
     auto append = [&](int id, const Quad& q) {
@@ -181,8 +197,9 @@ __device__ __noinline__ void make_scene(uint64_t seed, int64_t stream_index, dou
             list_full = true;
             return;
         }
-        list[n_list] = q;
-        list_id[n_list++] = id;
+        m.put(n_list, q);
+        m.id[n_list * kGenBlock] = id;
+        ++n_list;
     };
 
     const bool bay = rng.u() < type_proportion;  // :256
@@ -278,7 +295,7 @@ __device__ __noinline__ void make_scene(uint64_t seed, int64_t stream_index, dou
 
     double y_max = -INFINITY;  // :338-346
     for (int i = 0; i < n_list; ++i)
-        for (int k = 0; k < 4; ++k) y_max = __builtin_fmax(y_max, list[i].v[2 * k + 1]);
+        for (int k = 0; k < 4; ++k) y_max = __builtin_fmax(y_max, m.q[(i * 8 + 2 * k + 1) * kGenBlock]);
     y_max += kD0;
     if (rng.u() < 0.2) {  // far wall :347-356
         const double w = rng.uniform(0.0, 0.2);
@@ -305,19 +322,19 @@ __device__ __noinline__ void make_scene(uint64_t seed, int64_t stream_index, dou
         }
     }
     {  // random drop :389-390
-        int m = 0;
+        int kept = 0;
         for (int i = 0; i < n_list; ++i)
             if (rng.u() >= 0.05) {
-                if (m != i) {
-                    list[m] = list[i];
-                    list_id[m] = list_id[i];
+                if (kept != i) {
+                    m.put(kept, m.quad(i));
+                    m.id[kept * kGenBlock] = m.id[i * kGenBlock];
                 }
-                ++m;
+                ++kept;
             }
-        n_list = m;
+        n_list = kept;
     }
     for (int i = 0; i < n_list; ++i)
-        if (!is_convex_ccw(counter_clockwise(list[i]))) flags |= T2D_GEN_NONCONVEX;
+        if (!is_convex_ccw(counter_clockwise(m.quad(i)))) flags |= T2D_GEN_NONCONVEX;
 
     // start state :396-407
     double sx = 0.0, sy = 0.0, sh = 0.0;
@@ -330,7 +347,7 @@ __device__ __noinline__ void make_scene(uint64_t seed, int64_t stream_index, dou
         const Quad body = make_box(sx, sy, sh, len, wid);
         bool ok = true;
         for (int i = 0; i < n_list && ok; ++i)
-            if (touches_or_overlaps(body, list[i])) ok = false;
+            if (touches_or_overlaps(body, m.quad(i))) ok = false;
         if (ok && touches_or_overlaps(body, target)) ok = false;
         if (ok) break;
         if (s_attempts >= T2D_GEN_MAX_START_ATTEMPTS) {
@@ -357,35 +374,25 @@ __device__ __noinline__ void make_scene(uint64_t seed, int64_t stream_index, dou
     }
 
     // Map.add_area in list order: an id already present keeps its slot and takes the new polygon
-    int slot_id[T2D_GEN_MAX_QUADS];
-    int slot_src[T2D_GEN_MAX_QUADS];
     int n_out = 0;
     for (int i = 0; i < n_list; ++i) {
+        const int id_i = m.id[i * kGenBlock];
         int at = -1;
         for (int k = 0; k < n_out; ++k)
-            if (slot_id[k] == list_id[i]) at = k;
+            if (m.slot_id[k * kGenBlock] == id_i) at = k;
         if (at < 0) {
             if (n_out >= T2D_GEN_MAX_QUADS) {
                 flags |= T2D_GEN_OVERFLOW;
                 continue;
             }
             at = n_out++;
-            slot_id[at] = list_id[i];
+            m.slot_id[at * kGenBlock] = id_i;
         }
-        slot_src[at] = i;
+        m.slot_src[at * kGenBlock] = i;
     }
     if (list_full) flags |= T2D_GEN_OVERFLOW;
 
     out.n = n_out;
-    for (int k = 0; k < T2D_GEN_MAX_QUADS; ++k) {
-        if (k < n_out) {
-            out.quad[k] = list[slot_src[k]];
-            out.id[k] = slot_id[k];
-        } else {
-            out.quad[k] = Quad{{0, 0, 0, 0, 0, 0, 0, 0}};
-            out.id[k] = -1;
-        }
-    }
     out.sx = sx;
     out.sy = sy;
     out.sh = sh;
@@ -400,11 +407,13 @@ __device__ __noinline__ void make_scene(uint64_t seed, int64_t stream_index, dou
 }
 
 // the per-scene output arrays of t2d_generate_parking / t2d_get_parking_scenes
-T2D_DEV void store_scene(const SceneView& sv, int e, const Scene& sc) {
+T2D_DEV void store_scene(const SceneView& sv, int e, const LaneMem& m, const SceneHead& sc) {
     float* oq = sv.quads + (size_t)e * T2D_GEN_MAX_QUADS * 8;
     for (int k = 0; k < T2D_GEN_MAX_QUADS; ++k) {
-        for (int c = 0; c < 8; ++c) oq[8 * k + c] = (float)sc.quad[k].v[c];
-        sv.quad_id[(size_t)e * T2D_GEN_MAX_QUADS + k] = sc.id[k];
+        Quad q{{0, 0, 0, 0, 0, 0, 0, 0}};
+        if (k < sc.n) q = m.quad(m.slot_src[k * kGenBlock]);
+        for (int c = 0; c < 8; ++c) oq[8 * k + c] = (float)q.v[c];
+        sv.quad_id[(size_t)e * T2D_GEN_MAX_QUADS + k] = k < sc.n ? m.slot_id[k * kGenBlock] : -1;
     }
     sv.n_quads[e] = sc.n;
     sv.start[3 * (size_t)e] = sc.sx;
@@ -427,7 +436,8 @@ T2D_DEV void ring_ccw_f32(const Quad& q, float* o) {
 // What t2d_set_static_geometry / t2d_set_target_areas / t2d_reset / t2d_snapshot would do for env e, written in place:
 // the env's K polygon slots of the workgroup geometry record (dead slots get a box nothing can meet), its lidar ring
 // slots, boundary, target area + area centroid, the ego's state and episode snapshot, the IoU / shaping state.
-T2D_DEV void install_scene(const PoolView& pv, const SceneView& sv, int e, const Scene& sc, bool first) {
+T2D_DEV void install_scene(const PoolView& pv, const SceneView& sv, int e, const LaneMem& m, const SceneHead& sc,
+                           bool first) {
     constexpr int K = T2D_GEN_MAX_QUADS;
     const GeoLayout& gl = sv.gl;
     const int blk = e / gl.epb, el = e - blk * gl.epb;
@@ -439,7 +449,7 @@ T2D_DEV void install_scene(const PoolView& pv, const SceneView& sv, int e, const
         float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
         if (k < sc.n) {
-            ring_ccw_f32(sc.quad[k], r);
+            ring_ccw_f32(m.quad(m.slot_src[k * kGenBlock]), r);
             box = make_float4(r[0], r[0], r[1], r[1]);
             for (int v = 1; v < 4; ++v) {
                 box.x = __builtin_fminf(box.x, r[2 * v]);
@@ -516,12 +526,16 @@ __global__ __launch_bounds__(kGenBlock) void parking_scene_kernel(PoolView pv, S
         if (!(st.z | st.w)) return;
         episode = sv.episode[e] + 1;
     }
-    Scene sc;
-    make_scene(sv.seed, sv.first_env + e + (int64_t)episode * sv.env_stride, sv.type_proportion, sv.len, sv.wid, sc);
-    store_scene(sv, e, sc);
+    __shared__ double s_q[kListCap * 8 * kGenBlock];
+    __shared__ int s_i[(kListCap + 2 * T2D_GEN_MAX_QUADS) * kGenBlock];
+    const LaneMem m{s_q + threadIdx.x, s_i + threadIdx.x, s_i + kListCap * kGenBlock + threadIdx.x,
+                    s_i + (kListCap + T2D_GEN_MAX_QUADS) * kGenBlock + threadIdx.x};
+    SceneHead sc;
+    make_scene(sv.seed, sv.first_env + e + (int64_t)episode * sv.env_stride, sv.type_proportion, sv.len, sv.wid, m, sc);
+    store_scene(sv, e, m, sc);
     if (mode != 0) {
         sv.episode[e] = episode;
-        install_scene(pv, sv, e, sc, mode == 1);
+        install_scene(pv, sv, e, m, sc, mode == 1);
     }
 }
 
