@@ -5,8 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tactics2d_amd.envs import VecParkingEnv
 dev = torch.device("cuda", 0)
-for n in (4096, 32768):
-    env = VecParkingEnv(n, max_step=200, auto_reset=True, seed=1); env.reset()
+for n, source in ((4096, "layout"), (4096, "generator"), (32768, "layout"), (32768, "generator")):
+    # "layout": fixed bay layout, finished episodes restart from the snapshot; "generator": ParkingLotGenerator scenes
+    # installed on the device, every finished episode continues in a new scene (staged ahead on the pool's stream)
+    env = VecParkingEnv(n, max_step=200, auto_reset=True, seed=1, scene_source=source); env.reset()
     lo = torch.tensor([-0.524, -2.0], device=dev); hi = torch.tensor([0.524, 2.0], device=dev)
     acts = [lo + (hi - lo) * torch.rand((n, 2), device=dev) for _ in range(8)]
     for k in range(50): out = env.step_torch(acts[k & 7])
@@ -15,5 +17,5 @@ for n in (4096, 32768):
     for k in range(steps): out = env.step_torch(acts[k & 7])
     torch.cuda.synchronize()
     el = time.perf_counter() - t
-    print(f"{n} envs: {1e6 * el / steps:.1f} us per vector step, {n * steps / el:.3e} env-steps/s (state + 360-beam lidar on the device)")
+    print(f"{n} envs, scenes = {source}: {1e6 * el / steps:.1f} us per vector step, {n * steps / el:.3e} env-steps/s (state + 360-beam lidar on the device)")
     env.close()

@@ -460,6 +460,7 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
 int t2d_destroy(t2d_pool* p) {
     if (!p) return T2D_OK;
     (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();  // nothing of this pool may still be running (incl. a scene refill on its own stream)
     for (int f = 0; f < T2D_F_COUNT; ++f)
         if (p->field_ptr[f]) (void)hipFree(p->field_ptr[f]);
     void* bufs[] = {p->d_params, p->d_geo, p->d_boundary, p->d_boundary_valid, p->d_target_xy, p->d_target_c,
@@ -470,6 +471,9 @@ int t2d_destroy(t2d_pool* p) {
                     p->d_scene_arrays, p->d_lidar_cnt};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (p->scene_stream) (void)hipStreamDestroy(p->scene_stream);
+    if (p->ev_scene_commit) (void)hipEventDestroy(p->ev_scene_commit);
+    if (p->ev_scene_refill) (void)hipEventDestroy(p->ev_scene_refill);
     if (p->prof_events) {
         for (int i = 0; i < 2 * t2d_pool::kMaxProfSteps; ++i) (void)hipEventDestroy(p->prof_events[i]);
         delete[] p->prof_events;
@@ -796,13 +800,29 @@ int t2d_collide(t2d_pool* p, void* hip_stream) {
     return collide_impl(p, false, 0, (hipStream_t)hip_stream);
 }
 
-// generated parking scenes with regeneration on: envs whose episode ended in the launch just enqueued get a new scene
+// generated parking scenes with regeneration on: envs whose episode ended in the launch just enqueued move on to
+// their next scene (one cheap launch on the step's stream: staged scenes are copied in); every kSceneRefillPeriod
+// steps the staging ring is topped up on the pool's own stream, off the critical path -- one scene is a ~46 us
+// single-lane chain.  A slot rewritten by a refill is not read by the step stream before `ring` - 1 further episodes of
+// that env (>= 2 steps each), and the step stream waits for the previous refill before the next one is launched.
+constexpr int kSceneRing = 16;
+constexpr int kSceneRefillPeriod = 4;
 static int regenerate_done_scenes(t2d_pool* p, hipStream_t s) {
     if (!p->scene_regen) return T2D_OK;
     int rc;
+    const bool refill = p->scene.ring > 0 && p->step_count % kSceneRefillPeriod == 0;
+    if (refill && p->scene_refill_pending) T2D_HIP(p, hipStreamWaitEvent(s, p->ev_scene_refill, 0));
     if ((rc = record_event(p, 6, s, true))) return rc;
     T2D_HIP(p, t2d::launch_parking_scenes(p->v, p->scene, p->v.n_env, 2, s));
-    return record_event(p, 6, s, false);
+    if ((rc = record_event(p, 6, s, false))) return rc;
+    if (refill) {
+        T2D_HIP(p, hipEventRecord(p->ev_scene_commit, s));
+        T2D_HIP(p, hipStreamWaitEvent(p->scene_stream, p->ev_scene_commit, 0));
+        T2D_HIP(p, t2d::launch_scene_refill(p->scene, p->v.n_env, p->scene_stream));
+        T2D_HIP(p, hipEventRecord(p->ev_scene_refill, p->scene_stream));
+        p->scene_refill_pending = true;
+    }
+    return T2D_OK;
 }
 
 int t2d_check_status(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
@@ -966,15 +986,23 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
     for (int k = 0; k < 6; ++k)
         if (!p->d_snap[k]) T2D_HIP(p, hipMalloc((void**)&p->d_snap[k], nbytes));
     if (!p->d_snap_ids) T2D_HIP(p, hipMalloc((void**)&p->d_snap_ids, nbytes));
-    // the per-scene arrays (layout of t2d_generate_parking's outputs) + the episode counters
-    const size_t sizes[9] = {(size_t)E * K * 8 * sizeof(float), (size_t)E * K * sizeof(int32_t), (size_t)E * sizeof(int32_t),
-                             (size_t)E * 3 * sizeof(double), (size_t)E * 8 * sizeof(float), (size_t)E * sizeof(double),
-                             (size_t)E * 4 * sizeof(float), (size_t)E * sizeof(uint32_t), (size_t)E * sizeof(int32_t)};
-    size_t off[9], total = 0;
-    for (int k = 0; k < 9; ++k) {
-        off[k] = total;
-        total += (sizes[k] + 255) & ~(size_t)255;
-    }
+    // the per-scene arrays (layout of t2d_generate_parking's outputs): live [E] + the staging ring [E * ring] used when
+    // scenes are regenerated (regenerate == 1; == 2 generates on the step's stream instead), episode counters
+    if (regenerate != 0 && regenerate != 1 && regenerate != 2)
+        return fail(p, T2D_ERR_INVALID, "regenerate must be 0 (off), 1 (staged ahead) or 2 (generated in the step's stream)");
+    const int ring = regenerate == 1 ? kSceneRing : 0;
+    const size_t per[8] = {(size_t)K * 8 * sizeof(float), (size_t)K * sizeof(int32_t), sizeof(int32_t), 3 * sizeof(double),
+                           8 * sizeof(float), sizeof(double), 4 * sizeof(float), sizeof(uint32_t)};
+    const size_t counts[3] = {(size_t)E, (size_t)E * ring, 0};
+    size_t off[18], total = 0;
+    for (int set = 0; set < 2; ++set)
+        for (int k = 0; k < 8; ++k) {
+            off[8 * set + k] = total;
+            total += (per[k] * counts[set] + 255) & ~(size_t)255;
+        }
+    off[16] = total; total += ((size_t)E * sizeof(int32_t) + 255) & ~(size_t)255;          // episode
+    off[17] = total; total += ((size_t)E * ring * sizeof(int32_t) + 255) & ~(size_t)255;   // staged_ep
+    if (p->scene_stream) T2D_HIP(p, hipStreamSynchronize(p->scene_stream));
     if (p->d_scene_arrays) {
         T2D_HIP(p, hipFree(p->d_scene_arrays));
         p->d_scene_arrays = nullptr;
@@ -986,9 +1014,23 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
     sv = t2d::SceneView{};
     sv.seed = seed; sv.first_env = first_env; sv.env_stride = env_stride;
     sv.type_proportion = type_proportion; sv.len = vehicle_length; sv.wid = vehicle_width;
-    sv.quads = (float*)(base + off[0]); sv.quad_id = (int32_t*)(base + off[1]); sv.n_quads = (int32_t*)(base + off[2]);
-    sv.start = (double*)(base + off[3]); sv.target = (float*)(base + off[4]); sv.target_heading = (double*)(base + off[5]);
-    sv.boundary_out = (float*)(base + off[6]); sv.info = (uint32_t*)(base + off[7]); sv.episode = (int32_t*)(base + off[8]);
+    t2d::SceneArrays* sets[2] = {&sv.live, &sv.staged};
+    for (int set = 0; set < 2; ++set) {
+        char* b = base;
+        *sets[set] = t2d::SceneArrays{(float*)(b + off[8 * set + 0]), (int32_t*)(b + off[8 * set + 1]), (int32_t*)(b + off[8 * set + 2]),
+                                      (double*)(b + off[8 * set + 3]), (float*)(b + off[8 * set + 4]), (double*)(b + off[8 * set + 5]),
+                                      (float*)(b + off[8 * set + 6]), (uint32_t*)(b + off[8 * set + 7])};
+    }
+    sv.episode = (int32_t*)(base + off[16]);
+    sv.staged_ep = (int32_t*)(base + off[17]);
+    sv.ring = ring;
+    if (ring > 0) {
+        T2D_HIP(p, hipMemset(sv.staged_ep, 0xff, (size_t)E * ring * sizeof(int32_t)));   // -1 = empty slot
+        if (!p->scene_stream) T2D_HIP(p, hipStreamCreateWithFlags(&p->scene_stream, hipStreamNonBlocking));
+        if (!p->ev_scene_commit) T2D_HIP(p, hipEventCreateWithFlags(&p->ev_scene_commit, hipEventDisableTiming));
+        if (!p->ev_scene_refill) T2D_HIP(p, hipEventCreateWithFlags(&p->ev_scene_refill, hipEventDisableTiming));
+    }
+    p->scene_refill_pending = false;
     sv.geo = p->d_geo; sv.gl = gl;
     sv.lidar_xy = p->d_lidar_xy; sv.lidar_cnt = p->d_lidar_cnt;
     sv.boundary = p->d_boundary; sv.target_xy = p->d_target_xy; sv.target_c = p->d_target_c;
@@ -1004,6 +1046,7 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
         for (int f : {T2D_F_OMEGA_F, T2D_F_OMEGA_R}) T2D_HIP(p, hipMemset(p->field_ptr[f], 0, nbytes));
     }
     T2D_HIP(p, t2d::launch_parking_scenes(p->v, sv, E, 1, nullptr));
+    if (ring > 0) T2D_HIP(p, t2d::launch_scene_refill(sv, E, nullptr));   // episodes 1 .. ring of every env
     T2D_HIP(p, hipDeviceSynchronize());
     p->have_reset = true;
     p->have_snapshot = true;
@@ -1023,14 +1066,14 @@ int t2d_get_parking_scenes(t2d_pool* p, float* quads, int32_t* quad_id, int32_t*
     const size_t E = (size_t)p->v.n_env;
     constexpr size_t K = T2D_GEN_MAX_QUADS;
     const t2d::SceneView& sv = p->scene;
-    if (quads) T2D_HIP(p, hipMemcpy(quads, sv.quads, E * K * 8 * sizeof(float), hipMemcpyDeviceToHost));
-    if (quad_id) T2D_HIP(p, hipMemcpy(quad_id, sv.quad_id, E * K * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (n_quads) T2D_HIP(p, hipMemcpy(n_quads, sv.n_quads, E * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (start) T2D_HIP(p, hipMemcpy(start, sv.start, E * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    if (target) T2D_HIP(p, hipMemcpy(target, sv.target, E * 8 * sizeof(float), hipMemcpyDeviceToHost));
-    if (target_heading) T2D_HIP(p, hipMemcpy(target_heading, sv.target_heading, E * sizeof(double), hipMemcpyDeviceToHost));
-    if (boundary) T2D_HIP(p, hipMemcpy(boundary, sv.boundary_out, E * 4 * sizeof(float), hipMemcpyDeviceToHost));
-    if (info) T2D_HIP(p, hipMemcpy(info, sv.info, E * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (quads) T2D_HIP(p, hipMemcpy(quads, sv.live.quads, E * K * 8 * sizeof(float), hipMemcpyDeviceToHost));
+    if (quad_id) T2D_HIP(p, hipMemcpy(quad_id, sv.live.quad_id, E * K * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (n_quads) T2D_HIP(p, hipMemcpy(n_quads, sv.live.n_quads, E * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (start) T2D_HIP(p, hipMemcpy(start, sv.live.start, E * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (target) T2D_HIP(p, hipMemcpy(target, sv.live.target, E * 8 * sizeof(float), hipMemcpyDeviceToHost));
+    if (target_heading) T2D_HIP(p, hipMemcpy(target_heading, sv.live.target_heading, E * sizeof(double), hipMemcpyDeviceToHost));
+    if (boundary) T2D_HIP(p, hipMemcpy(boundary, sv.live.boundary, E * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    if (info) T2D_HIP(p, hipMemcpy(info, sv.live.info, E * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (episode) T2D_HIP(p, hipMemcpy(episode, sv.episode, E * sizeof(int32_t), hipMemcpyDeviceToHost));
     return T2D_OK;
 }

@@ -406,29 +406,76 @@ T2D_DEV void make_scene(uint64_t seed, int64_t stream_index, double type_proport
                ((uint32_t)(s_attempts > 255 ? 255 : s_attempts) << 16);
 }
 
-// the per-scene output arrays of t2d_generate_parking / t2d_get_parking_scenes
-T2D_DEV void store_scene(const SceneView& sv, int e, const LaneMem& m, const SceneHead& sc) {
-    float* oq = sv.quads + (size_t)e * T2D_GEN_MAX_QUADS * 8;
+// one record of the per-scene arrays (t2d_generate_parking / t2d_get_parking_scenes / the staging ring)
+T2D_DEV void store_scene(const SceneArrays& A, size_t at, const LaneMem& m, const SceneHead& sc) {
+    float* oq = A.quads + at * T2D_GEN_MAX_QUADS * 8;
     for (int k = 0; k < T2D_GEN_MAX_QUADS; ++k) {
         Quad q{{0, 0, 0, 0, 0, 0, 0, 0}};
         if (k < sc.n) q = m.quad(m.slot_src[k * kGenBlock]);
         for (int c = 0; c < 8; ++c) oq[8 * k + c] = (float)q.v[c];
-        sv.quad_id[(size_t)e * T2D_GEN_MAX_QUADS + k] = k < sc.n ? m.slot_id[k * kGenBlock] : -1;
+        A.quad_id[at * T2D_GEN_MAX_QUADS + k] = k < sc.n ? m.slot_id[k * kGenBlock] : -1;
     }
-    sv.n_quads[e] = sc.n;
-    sv.start[3 * (size_t)e] = sc.sx;
-    sv.start[3 * (size_t)e + 1] = sc.sy;
-    sv.start[3 * (size_t)e + 2] = sc.sh;
-    for (int c = 0; c < 8; ++c) sv.target[8 * (size_t)e + c] = (float)sc.target.v[c];
-    sv.target_heading[e] = sc.target_h;
-    for (int c = 0; c < 4; ++c) sv.boundary_out[4 * (size_t)e + c] = sc.bound[c];
-    sv.info[e] = sc.info;
+    A.n_quads[at] = sc.n;
+    A.start[3 * at] = sc.sx;
+    A.start[3 * at + 1] = sc.sy;
+    A.start[3 * at + 2] = sc.sh;
+    for (int c = 0; c < 8; ++c) A.target[8 * at + c] = (float)sc.target.v[c];
+    A.target_heading[at] = sc.target_h;
+    for (int c = 0; c < 4; ++c) A.boundary[4 * at + c] = sc.bound[c];
+    A.info[at] = sc.info;
+}
+
+// One record of the scene arrays in registers.  All its loads are issued back to back (16-B vectors, no stores in
+// between), so a lane that takes a staged scene pays one memory latency, not one per word.
+struct SceneRec {
+    float4 quad[2 * T2D_GEN_MAX_QUADS];
+    int32_t id[T2D_GEN_MAX_QUADS];
+    int32_t n;
+    double start[3];
+    float4 target[2];
+    double target_h;
+    float4 bound;
+    uint32_t info;
+};
+T2D_DEV SceneRec load_rec(const SceneArrays& A, size_t at) {
+    SceneRec r;
+    const float4* q = reinterpret_cast<const float4*>(A.quads + at * T2D_GEN_MAX_QUADS * 8);
+    const int4* ids = reinterpret_cast<const int4*>(A.quad_id + at * T2D_GEN_MAX_QUADS);
+    const float4* t = reinterpret_cast<const float4*>(A.target + at * 8);
+#pragma unroll
+    for (int k = 0; k < 2 * T2D_GEN_MAX_QUADS; ++k) r.quad[k] = q[k];
+#pragma unroll
+    for (int k = 0; k < T2D_GEN_MAX_QUADS / 4; ++k) {
+        const int4 v = ids[k];
+        r.id[4 * k] = v.x; r.id[4 * k + 1] = v.y; r.id[4 * k + 2] = v.z; r.id[4 * k + 3] = v.w;
+    }
+    r.n = A.n_quads[at];
+    r.start[0] = A.start[3 * at]; r.start[1] = A.start[3 * at + 1]; r.start[2] = A.start[3 * at + 2];
+    r.target[0] = t[0]; r.target[1] = t[1];
+    r.target_h = A.target_heading[at];
+    r.bound = reinterpret_cast<const float4*>(A.boundary)[at];
+    r.info = A.info[at];
+    return r;
+}
+T2D_DEV void store_rec(const SceneArrays& A, size_t at, const SceneRec& r) {
+    float4* q = reinterpret_cast<float4*>(A.quads + at * T2D_GEN_MAX_QUADS * 8);
+#pragma unroll
+    for (int k = 0; k < 2 * T2D_GEN_MAX_QUADS; ++k) q[k] = r.quad[k];
+#pragma unroll
+    for (int k = 0; k < T2D_GEN_MAX_QUADS; ++k) A.quad_id[at * T2D_GEN_MAX_QUADS + k] = r.id[k];
+    A.n_quads[at] = r.n;
+    A.start[3 * at] = r.start[0]; A.start[3 * at + 1] = r.start[1]; A.start[3 * at + 2] = r.start[2];
+    reinterpret_cast<float4*>(A.target + at * 8)[0] = r.target[0];
+    reinterpret_cast<float4*>(A.target + at * 8)[1] = r.target[1];
+    A.target_heading[at] = r.target_h;
+    reinterpret_cast<float4*>(A.boundary)[at] = r.bound;
+    A.info[at] = r.info;
 }
 
 // fp32 ring -> counter-clockwise fp32 ring, decided like prepare_polys (t2d_api.hip): shoelace of the fp32 values in fp64
-T2D_DEV void ring_ccw_f32(const Quad& q, float* o) {
+T2D_DEV void ring_ccw_f32(const float* q, float* o) {
     Quad r;
-    for (int c = 0; c < 8; ++c) r.v[c] = (double)(float)q.v[c];
+    for (int c = 0; c < 8; ++c) r.v[c] = (double)q[c];
     const Quad n = counter_clockwise(r);
     for (int c = 0; c < 8; ++c) o[c] = (float)n.v[c];
 }
@@ -436,8 +483,8 @@ T2D_DEV void ring_ccw_f32(const Quad& q, float* o) {
 // What t2d_set_static_geometry / t2d_set_target_areas / t2d_reset / t2d_snapshot would do for env e, written in place:
 // the env's K polygon slots of the workgroup geometry record (dead slots get a box nothing can meet), its lidar ring
 // slots, boundary, target area + area centroid, the ego's state and episode snapshot, the IoU / shaping state.
-T2D_DEV void install_scene(const PoolView& pv, const SceneView& sv, int e, const LaneMem& m, const SceneHead& sc,
-                           bool first) {
+T2D_DEV void install_scene(const PoolView& pv, const SceneView& sv, int e, const SceneRec& R, bool first) {
+    const int n_areas = R.n;
     constexpr int K = T2D_GEN_MAX_QUADS;
     const GeoLayout& gl = sv.gl;
     const int blk = e / gl.epb, el = e - blk * gl.epb;
@@ -448,8 +495,10 @@ T2D_DEV void install_scene(const PoolView& pv, const SceneView& sv, int e, const
     for (int k = 0; k < K; ++k) {
         float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
-        if (k < sc.n) {
-            ring_ccw_f32(m.quad(m.slot_src[k * kGenBlock]), r);
+        if (k < n_areas) {
+            const float raw[8] = {R.quad[2 * k].x, R.quad[2 * k].y, R.quad[2 * k].z, R.quad[2 * k].w,
+                                  R.quad[2 * k + 1].x, R.quad[2 * k + 1].y, R.quad[2 * k + 1].z, R.quad[2 * k + 1].w};
+            ring_ccw_f32(raw, r);
             box = make_float4(r[0], r[0], r[1], r[1]);
             for (int v = 1; v < 4; ++v) {
                 box.x = __builtin_fminf(box.x, r[2 * v]);
@@ -459,16 +508,19 @@ T2D_DEV void install_scene(const PoolView& pv, const SceneView& sv, int e, const
             }
         }
         bb[k] = box;
-        for (int c = 0; c < 8; ++c) {
-            xy[8 * k + c] = r[c];
-            lxy[8 * k + c] = r[c];
-        }
+        const float4 lo = make_float4(r[0], r[1], r[2], r[3]), hi = make_float4(r[4], r[5], r[6], r[7]);
+        reinterpret_cast<float4*>(xy)[2 * k] = lo;
+        reinterpret_cast<float4*>(xy)[2 * k + 1] = hi;
+        reinterpret_cast<float4*>(lxy)[2 * k] = lo;
+        reinterpret_cast<float4*>(lxy)[2 * k + 1] = hi;
     }
-    sv.lidar_cnt[e] = 4 * sc.n;
-    for (int c = 0; c < 4; ++c) sv.boundary[4 * (size_t)e + c] = sc.bound[c];
+    sv.lidar_cnt[e] = 4 * n_areas;
+    reinterpret_cast<float4*>(sv.boundary)[e] = R.bound;
     // target area (t2d_set_target_areas): fp32 ring as doubles, counter-clockwise, area centroid
     float tr[8];
-    ring_ccw_f32(sc.target, tr);
+    const float traw[8] = {R.target[0].x, R.target[0].y, R.target[0].z, R.target[0].w,
+                           R.target[1].x, R.target[1].y, R.target[1].z, R.target[1].w};
+    ring_ccw_f32(traw, tr);
     double tq[8], area = 0.0, cx = 0.0, cy = 0.0;
     for (int c = 0; c < 8; ++c) tq[c] = (double)tr[c];
     for (int i = 0; i < 4; ++i) {
@@ -487,7 +539,7 @@ T2D_DEV void install_scene(const PoolView& pv, const SceneView& sv, int e, const
     sv.target_c[2 * (size_t)e] = cx;
     sv.target_c[2 * (size_t)e + 1] = cy;
     // ego state + episode snapshot (t2d_reset with speed 0, then t2d_snapshot); one participant per env
-    const float fx = (float)sc.sx, fy = (float)sc.sy, fh = (float)sc.sh;
+    const float fx = (float)R.start[0], fy = (float)R.start[1], fh = (float)R.start[2];
     const float st[6] = {fx, fy, fh, 0.f, 0.f, 0.f};
     float* cur[6] = {pv.x, pv.y, pv.heading, pv.speed, pv.vx, pv.vy};
     for (int k = 0; k < 6; ++k) {
@@ -516,7 +568,8 @@ T2D_DEV void install_scene(const PoolView& pv, const SceneView& sv, int e, const
     }
 }
 
-// mode 0: generate into the scene arrays; 1: generate + install every env; 2: the same for envs whose episode just ended
+// mode 0: generate into the live arrays; 1: generate + install every env (episode 0); 2: envs whose episode just ended
+// move on to their next episode -- taken from the staging ring when there is one, generated here otherwise
 __global__ __launch_bounds__(kGenBlock) void parking_scene_kernel(PoolView pv, SceneView sv, int n_env, int mode) {
     const int e = blockIdx.x * kGenBlock + threadIdx.x;
     if (e >= n_env) return;
@@ -525,6 +578,17 @@ __global__ __launch_bounds__(kGenBlock) void parking_scene_kernel(PoolView pv, S
         const uchar4 st = reinterpret_cast<const uchar4*>(pv.status)[e];
         if (!(st.z | st.w)) return;
         episode = sv.episode[e] + 1;
+        if (sv.ring > 0) {
+            const size_t slot = (size_t)e * sv.ring + (size_t)(episode % sv.ring);
+            if (sv.staged_ep[slot] == episode) {  // the usual case: prepared ahead by the refill launch
+                const SceneRec R = load_rec(sv.staged, slot);
+                store_rec(sv.live, e, R);
+                install_scene(pv, sv, e, R, false);
+                __threadfence();           // the slot is free for the refill stream only once everything was read
+                sv.episode[e] = episode;
+                return;
+            }
+        }
     }
     __shared__ double s_q[kListCap * 8 * kGenBlock];
     __shared__ int s_i[(kListCap + 2 * T2D_GEN_MAX_QUADS) * kGenBlock];
@@ -532,14 +596,45 @@ __global__ __launch_bounds__(kGenBlock) void parking_scene_kernel(PoolView pv, S
                     s_i + (kListCap + T2D_GEN_MAX_QUADS) * kGenBlock + threadIdx.x};
     SceneHead sc;
     make_scene(sv.seed, sv.first_env + e + (int64_t)episode * sv.env_stride, sv.type_proportion, sv.len, sv.wid, m, sc);
-    store_scene(sv, e, m, sc);
+    store_scene(sv.live, e, m, sc);
     if (mode != 0) {
+        install_scene(pv, sv, e, load_rec(sv.live, e), mode == 1);   // reads back what this lane just stored
         sv.episode[e] = episode;
-        install_scene(pv, sv, e, m, sc, mode == 1);
+    }
+}
+
+// One lane per env, walking its ring: slot j must hold the episode in (k, k + ring] that is congruent to j, k = the
+// env's current episode; a slot holding anything else was consumed and is generated anew (usually none or one per
+// refill).  Runs on the pool's own stream while the env keeps stepping: `episode` may advance meanwhile, a stale
+// (smaller) k only postpones a slot to the next refill, and a slot rewritten here is `ring` episodes away from the one
+// the step stream reads next.  n_env / 64 waves: next to nothing beside the step kernel it overlaps with.
+__global__ __launch_bounds__(kGenBlock) void scene_refill_kernel(SceneView sv, int n_env) {
+    const int e = blockIdx.x * kGenBlock + threadIdx.x;
+    if (e >= n_env) return;
+    __shared__ double s_q[kListCap * 8 * kGenBlock];
+    __shared__ int s_i[(kListCap + 2 * T2D_GEN_MAX_QUADS) * kGenBlock];
+    const LaneMem m{s_q + threadIdx.x, s_i + threadIdx.x, s_i + kListCap * kGenBlock + threadIdx.x,
+                    s_i + (kListCap + T2D_GEN_MAX_QUADS) * kGenBlock + threadIdx.x};
+    const int k = sv.episode[e];
+    for (int j = 0; j < sv.ring; ++j) {
+        const size_t i = (size_t)e * sv.ring + j;
+        const int want = k + 1 + ((j - (k + 1)) % sv.ring + sv.ring) % sv.ring;
+        if (sv.staged_ep[i] == want) continue;
+        SceneHead sc;
+        make_scene(sv.seed, sv.first_env + e + (int64_t)want * sv.env_stride, sv.type_proportion, sv.len, sv.wid, m, sc);
+        store_scene(sv.staged, i, m, sc);
+        __threadfence();
+        sv.staged_ep[i] = want;
     }
 }
 
 }  // namespace
+
+hipError_t launch_scene_refill(const SceneView& sv, int n_env, hipStream_t s) {
+    if (n_env <= 0 || sv.ring <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scene_refill_kernel, dim3((n_env + kGenBlock - 1) / kGenBlock), dim3(kGenBlock), 0, s, sv, n_env);
+    return hipGetLastError();
+}
 
 hipError_t launch_parking_scenes(const PoolView& v, const SceneView& sv, int n_env, int mode, hipStream_t s) {
     if (n_env <= 0) return hipSuccess;
@@ -581,9 +676,8 @@ extern "C" int t2d_generate_parking(int32_t device_id, uint64_t seed, int64_t fi
     SceneView sv{};
     sv.seed = seed; sv.first_env = first_env; sv.env_stride = 0;
     sv.type_proportion = type_proportion; sv.len = vehicle_length; sv.wid = vehicle_width;
-    sv.quads = (float*)(dev + off[0]); sv.quad_id = (int32_t*)(dev + off[1]); sv.n_quads = (int32_t*)(dev + off[2]);
-    sv.start = (double*)(dev + off[3]); sv.target = (float*)(dev + off[4]); sv.target_heading = (double*)(dev + off[5]);
-    sv.boundary_out = (float*)(dev + off[6]); sv.info = (uint32_t*)(dev + off[7]);
+    sv.live = SceneArrays{(float*)(dev + off[0]), (int32_t*)(dev + off[1]), (int32_t*)(dev + off[2]), (double*)(dev + off[3]),
+                          (float*)(dev + off[4]), (double*)(dev + off[5]), (float*)(dev + off[6]), (uint32_t*)(dev + off[7])};
     int rc = T2D_OK;
     if (launch_parking_scenes(PoolView{}, sv, n_env, 0, nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
         rc = T2D_ERR_HIP;

@@ -90,12 +90,19 @@ struct LidarView {
 // Device-side ParkingLotGenerator (t2d_generate.hip): stream parameters, the per-scene output arrays and -- when the
 // scenes are installed in a pool -- the places t2d_set_static_geometry / t2d_set_target_areas / t2d_reset /
 // t2d_snapshot would have written: every env owns T2D_GEN_MAX_QUADS polygon slots of 4 vertices.
+struct SceneArrays {  // one record per scene, the layout of t2d_generate_parking's outputs
+    float* quads; int32_t* quad_id; int32_t* n_quads; double* start; float* target; double* target_heading;
+    float* boundary; uint32_t* info;
+};
 struct SceneView {
     uint64_t seed;
     int64_t first_env, env_stride;  // scene of (env e, episode k) = stream first_env + e + k * env_stride
     double type_proportion, len, wid;
-    float* quads; int32_t* quad_id; int32_t* n_quads; double* start; float* target; double* target_heading;
-    float* boundary_out; uint32_t* info; int32_t* episode;
+    SceneArrays live;     // [n_env] the scenes the envs are in
+    SceneArrays staged;   // [n_env * ring] scenes of coming episodes (episode k of env e in slot k % ring), or nulls
+    int32_t ring;         // staged scenes per env (0 = none: regeneration generates on the step's stream)
+    int32_t* staged_ep;   // [n_env * ring] episode number held by each staged slot (-1 = empty)
+    int32_t* episode;     // [n_env]
     uint32_t* geo;        // the pool's geometry records (capacity layout)
     GeoLayout gl;
     float* lidar_xy; int32_t* lidar_cnt;
@@ -166,7 +173,10 @@ struct t2d_pool {
     // generated parking scenes (row f4): capacity-layout geometry owned by the device
     bool scene_mode = false, scene_regen = false;
     t2d::SceneView scene{};
-    void* d_scene_arrays = nullptr;   // one allocation behind scene.quads ... scene.episode
+    void* d_scene_arrays = nullptr;   // one allocation behind scene.live / scene.staged / scene.episode
+    hipStream_t scene_stream = nullptr;   // staged scenes are refilled here, off the step's stream
+    hipEvent_t ev_scene_commit = nullptr, ev_scene_refill = nullptr;
+    bool scene_refill_pending = false;
     int32_t* d_lidar_cnt = nullptr;
     long long step_count = 0;  // t2d_step calls so far (selects the record ring slot)
     // profiling
@@ -190,4 +200,5 @@ hipError_t launch_idm(const PoolView& v, const IdmView& iv, const int32_t* force
 hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
                           hipStream_t s);
 hipError_t launch_parking_scenes(const PoolView& v, const SceneView& sv, int n_env, int mode, hipStream_t s);
+hipError_t launch_scene_refill(const SceneView& sv, int n_env, hipStream_t s);
 }  // namespace t2d

@@ -158,11 +158,12 @@ class ParticipantPool:
                        env_stride=None):
         """Device-side ParkingLotGenerator writing straight into this pool (one participant per env): obstacles,
         boundary, target, start pose, snapshot, IoU state -- nothing crosses PCIe.  regenerate=True: after every
-        step, envs whose episode ended get the scene of their next episode (stream first_env + e + k * env_stride)."""
+        step, envs whose episode ended get the scene of their next episode (stream first_env + e + k * env_stride);
+        regenerate="inline" generates them on the step's stream instead of staging them ahead (C ABI value 2)."""
         stride = self.n_env if env_stride is None else int(env_stride)
         self._ck(self._lib.t2d_parking_scenes(self._h, int(seed) & (2**64 - 1), int(first_env), stride,
                                               float(type_proportion), float(vehicle_size[0]), float(vehicle_size[1]),
-                                              int(bool(regenerate))))
+                                              2 if regenerate == "inline" else int(bool(regenerate))))
 
     def get_parking_scenes(self):
         """The scenes currently installed by parking_scenes(): a generator.ParkingScenes plus `.episode`."""

@@ -309,8 +309,9 @@ def test_device_installed_scenes_equal_the_host_install(n_env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [True, "inline"])
 @pytest.mark.parametrize("auto_reset", [False, True])
-def test_scene_regeneration_follows_the_episode_streams(oracle, auto_reset):
+def test_scene_regeneration_follows_the_episode_streams(oracle, auto_reset, mode):
     """regenerate=True: an env whose episode ended gets the scene of stream first_env + e + k * stride right after the
     step; everything it installs is checked against the oracle's scene for that stream, the step's own flags against
     the oracle's events on the scene that was in place during the step."""
@@ -318,9 +319,9 @@ def test_scene_regeneration_follows_the_episode_streams(oracle, auto_reset):
     from tactics2d_amd.generator import ParkingLotGenerator
     n_env, seed, size, first, stride = 320, 12, (4.284, 1.81), 1000, 5000
     scenes = ParkingLotGenerator(size, 0.5).generate(n_env, seed, first_env=first)
-    sc = scenes.scene(max_step=12)
+    sc = scenes.scene(max_step=3 if mode is True else 12)
     pool = _pool_for(sc, n_env)
-    pool.parking_scenes(seed, 0.5, size, regenerate=True, first_env=first, env_stride=stride)
+    pool.parking_scenes(seed, 0.5, size, regenerate=mode, first_env=first, env_stride=stride)
     if auto_reset:
         pool.set_auto_reset(True)
     cur = pool.get_parking_scenes()
@@ -328,7 +329,7 @@ def test_scene_regeneration_follows_the_episode_streams(oracle, auto_reset):
     episode = np.zeros(n_env, np.int64)
     rng = np.random.default_rng(2)
     n_regen = 0
-    for step in range(45):
+    for step in range(120 if mode is True else 45):     # staged: long enough to go round the 16-slot ring
         a0, a1 = sc.sample_actions(rng)
         pool.set_actions(a0, a1)
         before = cur
