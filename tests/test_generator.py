@@ -402,3 +402,51 @@ def test_vec_env_auto_reset_moves_on_to_new_scenes():
     torch.cuda.synchronize()
     assert out["lidar"].shape == (256, 360) and torch.isfinite(out["lidar"]).any()
     env.close()
+
+
+@pytest.mark.gpu
+def test_parking_scenes_argument_and_state_checks():
+    """Error behaviour at the boundary: wrong pool shape, call order, mode mixing -- and leaving the generated-scene
+    mode through t2d_set_static_geometry gives an ordinary host-described pool again."""
+    import helpers as H
+    from tactics2d_amd import _ffi, layout as L, scenarios as S
+    from tactics2d_amd.generator import ParkingLotGenerator
+    from tactics2d_amd.pool import ParticipantPool
+    size = (4.284, 1.81)
+    sc = ParkingLotGenerator(size, 0.5).generate(64, 3).scene(max_step=30)
+    p2 = ParticipantPool(8, 2)
+    p2.set_param_table(sc.rows)
+    with pytest.raises(_ffi.T2DError):
+        p2.parking_scenes(1)                                   # one participant per env only
+    p2.close()
+    raw = ParticipantPool(64, 1)
+    with pytest.raises(_ffi.T2DError):
+        raw.parking_scenes(1)                                  # parameter table first
+    with pytest.raises(_ffi.T2DError):
+        raw.get_parking_scenes()                               # nothing generated yet
+    raw.close()
+    pool = _pool_for(sc, 64)
+    with pytest.raises(_ffi.T2DError):
+        _ffi.check(_ffi.lib().t2d_parking_scenes(pool._h, 1, 0, 64, 0.5, size[0], size[1], 7), pool._h)   # regenerate in 0..2
+    with pytest.raises(_ffi.T2DError):
+        _ffi.check(_ffi.lib().t2d_parking_scenes(pool._h, 1, 0, -1, 0.5, size[0], size[1], 0), pool._h)  # stride >= 0
+    pool.parking_scenes(3, 0.5, size, regenerate=True)
+    with pytest.raises(_ffi.T2DError):
+        pool.set_target_areas(sc.target)                       # targets belong to the generated scenes
+    with pytest.raises(_ffi.T2DError):
+        pool.set_lane_geometry(sc.static)
+    rng = np.random.default_rng(0)
+    for _ in range(5):
+        pool.set_actions(*sc.sample_actions(rng)); pool.step(100)
+    # back to a host-described scene: same pool, ordinary path, results equal to a fresh pool's
+    sc.load(pool)
+    fresh = _pool_for(sc, 64); sc.load(fresh)
+    for _ in range(35):
+        a0, a1 = sc.sample_actions(rng)
+        for q in (pool, fresh):
+            q.set_actions(a0, a1); q.step(100)
+    for f in _fields():
+        assert np.array_equal(pool.download(f), fresh.download(f), equal_nan=True), f
+    with pytest.raises(_ffi.T2DError):
+        pool.get_parking_scenes()                              # left the generated-scene mode
+    pool.close(); fresh.close()
