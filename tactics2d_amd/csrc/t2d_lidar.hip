@@ -222,14 +222,34 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
         for (int k = tid; k < lv.n_beams; k += kLidarBlock) s_mask[k] = 0ull;
         __syncthreads();
         {
+            // short spans: the edge's two lanes take alternate beams (<= kLongSpan / 2 rounds); a long span (a wall a
+            // few metres away covers 100+ beams) would keep the other 126 lanes at the barrier for one pair's 50+
+            // rounds, so the wave sweeps each of those together, 64 consecutive beams per round.  Same bits either
+            // way.  (Dealing all pairs out evenly through a prefix sum + search was measured too: no faster -- the
+            // phase is bound by its longest dependent chain, not by the number of atomics.)
+            constexpr int kLongSpan = 24;
             const int q = tid >> 1;
-            if (c0 + q < n_slots) {
-                const int2 sp = s_span[c0 + q];
-                const int last = sp.y < lv.n_beams ? sp.y : lv.n_beams - 1;   // sp.y = -1: invisible
+            int2 sp = make_int2(0, -1);
+            if (c0 + q < n_slots) sp = s_span[c0 + q];
+            const int last = sp.y < lv.n_beams ? sp.y : lv.n_beams - 1;   // sp.y = -1: invisible
+            const bool is_long = last >= kLongSpan;
+            if (!is_long) {
                 for (int i = tid & 1; i <= last; i += 2) {
                     int kb = sp.x + i;
                     kb -= kb >= lv.n_beams ? lv.n_beams : 0;
                     atomicOr(&s_mask[kb], 1ull << q);
+                }
+            }
+            unsigned long long todo = __ballot(is_long && !(tid & 1));   // the even lane of a pair speaks for its edge
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const int first = __builtin_amdgcn_readlane(sp.x, src), n_last = __builtin_amdgcn_readlane(last, src);
+                const unsigned long long bit = 1ull << ((wave * 64 + src) >> 1);
+                for (int i = lane; i <= n_last; i += 64) {
+                    int kb = first + i;
+                    kb -= kb >= lv.n_beams ? lv.n_beams : 0;
+                    atomicOr(&s_mask[kb], bit);
                 }
             }
         }
