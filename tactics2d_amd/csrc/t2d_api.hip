@@ -275,7 +275,7 @@ int rebuild_lidar_geo(t2d_pool* p) {
     p->lidar.next_vert = p->d_lidar_next;
     p->lidar.xy = p->d_lidar_xy;
     p->lidar.max_slots = p->lidar.max_static_verts + (p->lidar.include_participants ? 4 * p->v.A : 0);
-    if ((sizeof(double) * 4 + 8) * (size_t)p->lidar.max_slots + 16 * (size_t)p->lidar.n_beams + 2048 > 60 * 1024)
+    if ((sizeof(double) * (p->lidar.max_slots <= 64 ? 8 : 4) + 8) * (size_t)p->lidar.max_slots + 16 * (size_t)p->lidar.n_beams + 2048 > 60 * 1024)
         return fail(p, T2D_ERR_GEOMETRY, "too many obstacle edges per env for the lidar's LDS edge list");
     return T2D_OK;
 }

@@ -27,26 +27,44 @@ namespace {
 constexpr int kLidarBlock = 128;
 constexpr int kLidarQueue = 256;  // (beam, edge) candidates per wave per round
 
+// What the determinant solve needs of an edge, computed once per edge instead of once per (beam, edge) candidate:
+// d, e, f of the edge's line and the segment's coordinate bounds with the reference's 1e-8 slack already applied --
+// the same expressions, so the same bits.
+struct EdgePre {
+    double d, e, f, x_hi, x_lo, y_hi, y_lo, pad;
+};
+T2D_DEV EdgePre edge_pre(double x1, double y1, double x2, double y2) {
+    const double tz = 1e-8;
+    EdgePre p;
+    p.d = y2 - y1;
+    p.e = x1 - x2;
+    p.f = y1 * x2 - x1 * y2;
+    p.x_hi = (x1 > x2 ? x1 : x2) + tz;
+    p.x_lo = (x1 < x2 ? x1 : x2) - tz;
+    p.y_hi = (y1 > y2 ? y1 : y2) + tz;
+    p.y_lo = (y1 < y2 ? y1 : y2) - tz;
+    p.pad = 0.0;
+    return p;
+}
+
 // (returns the squared distance; see the note at its end)
-T2D_DEV double lidar_edge(double a, double b, double lx, double ly, double R, double x1, double y1, double x2,
-                          double y2) {
+T2D_DEV double lidar_edge(double a, double b, double lx, double ly, double R, const EdgePre& E) {
     const double tz = 1e-8, tinf = R * 10;
-    const double d = y2 - y1, e = x1 - x2, f = y1 * x2 - x1 * y2;
-    double det = a * e - b * d;
+    double det = a * E.e - b * E.d;
     const bool parallel = det == 0.0;
     if (parallel) det = 1.0;
-    double rx = (b * f) / det;
-    double ry = (-(a * f)) / det;
+    double rx = (b * E.f) / det;
+    double ry = (-(a * E.f)) / det;
     const double mx = tz > lx ? tz : lx, nx = -tz < lx ? -tz : lx;
     const double my = tz > ly ? tz : ly, ny = -tz < ly ? -tz : ly;
     if (rx > mx + tz) rx = tinf;
     if (rx < nx - tz) rx = tinf;
     if (ry > my + tz) ry = tinf;
     if (ry < ny - tz) ry = tinf;
-    if (rx > (x1 > x2 ? x1 : x2) + tz) rx = tinf;
-    if (rx < (x1 < x2 ? x1 : x2) - tz) rx = tinf;
-    if (ry > (y1 > y2 ? y1 : y2) + tz) ry = tinf;
-    if (ry < (y1 < y2 ? y1 : y2) - tz) ry = tinf;
+    if (rx > E.x_hi) rx = tinf;
+    if (rx < E.x_lo) rx = tinf;
+    if (ry > E.y_hi) ry = tinf;
+    if (ry < E.y_lo) ry = tinf;
     if (parallel) rx = tinf;
     return rx * rx + ry * ry;   // SQUARED distance: sqrt is monotone, so the per-beam minimum takes one sqrt at the end
 }
@@ -96,8 +114,26 @@ T2D_DEV int2 edge_span(double x1, double y1, double x2, double y2, double R, int
 // (39 vs 47 us at 4096 envs); long lists (participants scanned: 250+ edges) are issue-bound and keep all 98 registers.
 template <int WAVES>
 __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, LidarView lv, float* out) {
-    extern __shared__ __attribute__((aligned(16))) double s_edge[];  // [slots][4] = x1, y1, x2, y2 (sensor frame)
-    int2* const s_span = reinterpret_cast<int2*>(s_edge + 4 * (size_t)lv.max_slots);  // [slots] beam span per edge
+    // short edge lists (the 8-waves-per-SIMD instantiation, ParkingEnv) keep the precomputed EdgePre per edge (64 B);
+    // long lists keep the four end-point coordinates (32 B) and derive it per candidate: twice the LDS per slot would
+    // cost them resident workgroups (47 -> 61 us on the 252-edge scene)
+    constexpr bool kPre = WAVES == 8;
+    constexpr int kSlotDoubles = kPre ? 8 : 4;
+    extern __shared__ __attribute__((aligned(16))) double s_edge_raw[];  // [slots][kSlotDoubles] (sensor frame)
+    auto put_edge = [&](int slot, double x1, double y1, double x2, double y2) {
+        if (kPre) {
+            reinterpret_cast<EdgePre*>(s_edge_raw)[slot] = edge_pre(x1, y1, x2, y2);
+        } else {
+            double* e = s_edge_raw + 4 * (size_t)slot;
+            e[0] = x1; e[1] = y1; e[2] = x2; e[3] = y2;
+        }
+    };
+    auto get_edge = [&](int slot) -> EdgePre {
+        if (kPre) return reinterpret_cast<const EdgePre*>(s_edge_raw)[slot];
+        const double* e = s_edge_raw + 4 * (size_t)slot;
+        return edge_pre(e[0], e[1], e[2], e[3]);
+    };
+    int2* const s_span = reinterpret_cast<int2*>(s_edge_raw + (size_t)kSlotDoubles * lv.max_slots);  // [slots] beam span per edge
     // [n_beams] running minimum per beam as the bit pattern of a non-negative double (monotone), then the wave queues
     unsigned long long* const s_best = reinterpret_cast<unsigned long long*>(s_span + lv.max_slots);
     unsigned long long* const s_mask = s_best + lv.n_beams;   // [n_beams] candidate edges (bit q) of the current 64-edge chunk
@@ -147,12 +183,12 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
         for (int q = tid; q < n_static; q += kLidarBlock) {
             const float2 p = reinterpret_cast<const float2*>(lv.xy)[v0 + q];
             const float2 r = reinterpret_cast<const float2*>(lv.xy)[lv.next_vert[v0 + q]];
-            s_edge[4 * q + 0] = cs * (double)p.x + sn * (double)p.y + x_off;
-            s_edge[4 * q + 1] = -sn * (double)p.x + cs * (double)p.y + y_off;
-            s_edge[4 * q + 2] = cs * (double)r.x + sn * (double)r.y + x_off;
-            s_edge[4 * q + 3] = -sn * (double)r.x + cs * (double)r.y + y_off;
-            s_span[q] = edge_span(s_edge[4 * q], s_edge[4 * q + 1], s_edge[4 * q + 2], s_edge[4 * q + 3], lv.max_range,
-                                  lv.n_beams);
+            const double x1 = cs * (double)p.x + sn * (double)p.y + x_off;
+            const double y1 = -sn * (double)p.x + cs * (double)p.y + y_off;
+            const double x2 = cs * (double)r.x + sn * (double)r.y + x_off;
+            const double y2 = -sn * (double)r.x + cs * (double)r.y + y_off;
+            put_edge(q, x1, y1, x2, y2);
+            s_span[q] = edge_span(x1, y1, x2, y2, lv.max_range, lv.n_beams);
         }
     }
     // ---- phase 1b: the other participants' boxes (4 edges each; skipped slots get the far edge) -------
@@ -184,12 +220,10 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                double* e = s_edge + 4 * (size_t)(n_static + 4 * j + k);
-                e[0] = use ? vx[k] : kFar;
-                e[1] = use ? vy[k] : kFar;
-                e[2] = use ? vx[(k + 1) & 3] : kFar;
-                e[3] = use ? vy[(k + 1) & 3] : kFar + 1.0;
-                s_span[n_static + 4 * j + k] = use ? edge_span(e[0], e[1], e[2], e[3], lv.max_range, lv.n_beams)
+                const double e0 = use ? vx[k] : kFar, e1 = use ? vy[k] : kFar;
+                const double e2 = use ? vx[(k + 1) & 3] : kFar, e3 = use ? vy[(k + 1) & 3] : kFar + 1.0;
+                put_edge(n_static + 4 * j + k, e0, e1, e2, e3);
+                s_span[n_static + 4 * j + k] = use ? edge_span(e0, e1, e2, e3, lv.max_range, lv.n_beams)
                                                    : make_int2(0, -1);
             }
         }
@@ -279,8 +313,7 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
                     const int kb = (int)(en & 0xffffu), q = (int)(en >> 16);
                     const double bs = lv.beam_sin[kb], bc = lv.beam_cos[kb];
                     // a = sin, b = -cos (lidar.py:161-162); lx = cos R, ly = sin R (:201-204)
-                    const double dd = lidar_edge(bs, -bc, bc * R, bs * R, R, s_edge[4 * q], s_edge[4 * q + 1],
-                                                 s_edge[4 * q + 2], s_edge[4 * q + 3]);
+                    const double dd = lidar_edge(bs, -bc, bc * R, bs * R, R, get_edge(q));
                     if (dd == dd) atomicMin(&s_best[kb], (unsigned long long)__double_as_longlong(dd));
                 }
                 wave_sync();
@@ -306,9 +339,10 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
 }  // namespace
 
 hipError_t launch_lidar(const PoolView& v, const LidarView& lv, float* out, hipStream_t s) {
-    const size_t dyn = (sizeof(double) * 4 + sizeof(int2)) * (size_t)lv.max_slots + 16 * (size_t)lv.n_beams +
-                       4 * (size_t)kLidarQueue * (kLidarBlock / 64);
-    if (lv.max_slots <= 64)
+    const bool short_list = lv.max_slots <= 64;   // EdgePre records (64 B) for short lists, end points (32 B) otherwise
+    const size_t dyn = ((short_list ? sizeof(EdgePre) : 4 * sizeof(double)) + sizeof(int2)) * (size_t)lv.max_slots +
+                       16 * (size_t)lv.n_beams + 4 * (size_t)kLidarQueue * (kLidarBlock / 64);
+    if (short_list)
         hipLaunchKernelGGL(lidar_kernel<8>, dim3(v.n_env), dim3(kLidarBlock), dyn, s, v, lv, out);
     else
         hipLaunchKernelGGL(lidar_kernel<4>, dim3(v.n_env), dim3(kLidarBlock), dyn, s, v, lv, out);
