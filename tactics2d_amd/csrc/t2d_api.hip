@@ -1144,8 +1144,19 @@ int t2d_lidar_config(t2d_pool* p, int32_t n_beams, float max_range, int32_t incl
         }
     }
     int rc;
-    if ((rc = dev_replace(p, &p->d_beam_sin, bs.data(), bs.size()))) return rc;
-    if ((rc = dev_replace(p, &p->d_beam_cos, bc.data(), bc.size()))) return rc;
+    {   // what the determinant solve needs of a beam, once per beam instead of once per candidate (same expressions as
+        // lidar.py:161-162, 201-213: a, b of the beam's line, its end point (lx, ly) = (cos, sin) * R widened by 1e-8)
+        const double R = (double)max_range, tz = 1e-8;
+        std::vector<double> pre(6 * (size_t)n_beams);
+        for (int k = 0; k < n_beams; ++k) {
+            const double lx = bc[k] * R, ly = bs[k] * R;
+            const double mx = tz > lx ? tz : lx, nx = -tz < lx ? -tz : lx;
+            const double my = tz > ly ? tz : ly, ny = -tz < ly ? -tz : ly;
+            double* r = &pre[6 * (size_t)k];
+            r[0] = bs[k]; r[1] = -bc[k]; r[2] = mx + tz; r[3] = nx - tz; r[4] = my + tz; r[5] = ny - tz;
+        }
+        if ((rc = dev_replace(p, &p->d_beam_sin, pre.data(), pre.size()))) return rc;
+    }
     if (p->field_ptr[T2D_F_LIDAR]) {
         T2D_HIP(p, hipFree(p->field_ptr[T2D_F_LIDAR]));
         p->field_ptr[T2D_F_LIDAR] = nullptr;
@@ -1153,8 +1164,7 @@ int t2d_lidar_config(t2d_pool* p, int32_t n_beams, float max_range, int32_t incl
     p->field_bytes[T2D_F_LIDAR] = (size_t)p->v.n_env * n_beams * sizeof(float);
     T2D_HIP(p, hipMalloc(&p->field_ptr[T2D_F_LIDAR], p->field_bytes[T2D_F_LIDAR]));
     T2D_HIP(p, hipMemset(p->field_ptr[T2D_F_LIDAR], 0, p->field_bytes[T2D_F_LIDAR]));
-    p->lidar.beam_sin = p->d_beam_sin;
-    p->lidar.beam_cos = p->d_beam_cos;
+    p->lidar.beam_pre = p->d_beam_sin;
     p->lidar.max_range = (double)max_range;
     p->lidar.n_beams = n_beams;
     p->lidar.include_participants = include_participants != 0;

@@ -48,20 +48,19 @@ T2D_DEV EdgePre edge_pre(double x1, double y1, double x2, double y2) {
 }
 
 // (returns the squared distance; see the note at its end)
-T2D_DEV double lidar_edge(double a, double b, double lx, double ly, double R, const EdgePre& E) {
-    const double tz = 1e-8, tinf = R * 10;
+T2D_DEV double lidar_edge(double a, double b, double bx_hi, double bx_lo, double by_hi, double by_lo, double R,
+                          const EdgePre& E) {
+    const double tinf = R * 10;
     double det = a * E.e - b * E.d;
     const bool parallel = det == 0.0;
     if (parallel) det = 1.0;
     double rx = (b * E.f) / det;
     double ry = (-(a * E.f)) / det;
-    const double mx = tz > lx ? tz : lx, nx = -tz < lx ? -tz : lx;
-    const double my = tz > ly ? tz : ly, ny = -tz < ly ? -tz : ly;
-    if (rx > mx + tz) rx = tinf;
-    if (rx < nx - tz) rx = tinf;
-    if (ry > my + tz) ry = tinf;
-    if (ry < ny - tz) ry = tinf;
-    if (rx > E.x_hi) rx = tinf;
+    if (rx > bx_hi) rx = tinf;   // the beam's end-point bounds (t2d_lidar_config) ...
+    if (rx < bx_lo) rx = tinf;
+    if (ry > by_hi) ry = tinf;
+    if (ry < by_lo) ry = tinf;
+    if (rx > E.x_hi) rx = tinf;   // ... and the segment's
     if (rx < E.x_lo) rx = tinf;
     if (ry > E.y_hi) ry = tinf;
     if (ry < E.y_lo) ry = tinf;
@@ -311,9 +310,9 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
                 for (int j = lane; j < n_round; j += 64) {
                     const uint32_t en = queue[j];
                     const int kb = (int)(en & 0xffffu), q = (int)(en >> 16);
-                    const double bs = lv.beam_sin[kb], bc = lv.beam_cos[kb];
-                    // a = sin, b = -cos (lidar.py:161-162); lx = cos R, ly = sin R (:201-204)
-                    const double dd = lidar_edge(bs, -bc, bc * R, bs * R, R, get_edge(q));
+                    const double2* bp = reinterpret_cast<const double2*>(lv.beam_pre + 6 * (size_t)kb);
+                    const double2 ab = bp[0], bx = bp[1], by = bp[2];
+                    const double dd = lidar_edge(ab.x, ab.y, bx.x, bx.y, by.x, by.y, R, get_edge(q));
                     if (dd == dd) atomicMin(&s_best[kb], (unsigned long long)__double_as_longlong(dd));
                 }
                 wave_sync();

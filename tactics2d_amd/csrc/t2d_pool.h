@@ -80,8 +80,8 @@ struct LidarView {
     const int32_t* env_vert_cnt;  // null, or [E] vertices in use when envs own fixed-capacity ranges (generated scenes)
     const int32_t* next_vert;     // [V] index of the next vertex of the same ring
     const float* xy;              // [V][2]
-    const double* beam_sin;       // [n_beams] sin / cos of linspace(0, 2pi, n_beams, endpoint=False)
-    const double* beam_cos;
+    const double* beam_pre;       // [n_beams][6] per beam: a = sin, b = -cos of linspace(0, 2pi, n, endpoint=False)[k]
+                                  // (lidar.py:161-162) and the four slack-widened bounds of its end point (x hi / lo, y hi / lo)
     double max_range;
     int32_t n_beams, include_participants, ego_index, max_static_verts;
     int32_t max_slots;  // LDS edge slots per env: max_static_verts + 4 * max_agents (when participants are scanned)
