@@ -247,32 +247,32 @@ int rebuild_lidar_geo(t2d_pool* p) {
     int rc;
     p->lidar.max_static_verts = 0;
     p->lidar.env_vert_cnt = nullptr;
-    if (p->scene_mode) {  // generated scenes: every env owns 4 * T2D_GEN_MAX_QUADS vertex slots of d_lidar_xy, the
-        constexpr int VS = 4 * T2D_GEN_MAX_QUADS;  // scene kernel maintains the vertices and the per-env count
-        std::vector<int32_t> evo(E + 1), nxt((size_t)VS * E);
+    if (p->scene_mode) {  // generated scenes: every env owns 4 * T2D_GEN_MAX_QUADS edge slots of d_lidar_xy, the
+        constexpr int VS = 4 * T2D_GEN_MAX_QUADS;  // scene kernel maintains the edges and the per-env count
+        std::vector<int32_t> evo(E + 1);
         for (int e = 0; e <= E; ++e) evo[e] = VS * e;
-        for (size_t v = 0; v < nxt.size(); ++v) nxt[v] = (int32_t)((v & ~(size_t)3) | ((v + 1) & 3));
         if ((rc = dev_replace(p, &p->d_lidar_env_off, evo.data(), evo.size()))) return rc;
-        if ((rc = dev_replace(p, &p->d_lidar_next, nxt.data(), nxt.size()))) return rc;
         p->lidar.max_static_verts = VS;
         p->lidar.env_vert_cnt = p->d_lidar_cnt;
     } else if (!g.present || g.env_off[E] == 0) {
         if ((rc = dev_replace<int32_t>(p, &p->d_lidar_env_off, nullptr, 0))) return rc;
-        if ((rc = dev_replace<int32_t>(p, &p->d_lidar_next, nullptr, 0))) return rc;
         if ((rc = dev_replace<float>(p, &p->d_lidar_xy, nullptr, 0))) return rc;
     } else {
         const int P = g.env_off[E], V = g.vert_off[P];
-        std::vector<int32_t> evo(E + 1), nxt(V);
+        std::vector<int32_t> evo(E + 1);
+        std::vector<float> edges(4 * (size_t)V);   // one record per edge: vertex v and the next vertex of its ring
         for (int e = 0; e <= E; ++e) evo[e] = g.vert_off[g.env_off[e]];
         for (int q = 0; q < P; ++q)
-            for (int v = g.vert_off[q]; v < g.vert_off[q + 1]; ++v) nxt[v] = v + 1 < g.vert_off[q + 1] ? v + 1 : g.vert_off[q];
+            for (int v = g.vert_off[q]; v < g.vert_off[q + 1]; ++v) {
+                const int nx = v + 1 < g.vert_off[q + 1] ? v + 1 : g.vert_off[q];
+                edges[4 * (size_t)v] = g.xy[2 * (size_t)v]; edges[4 * (size_t)v + 1] = g.xy[2 * (size_t)v + 1];
+                edges[4 * (size_t)v + 2] = g.xy[2 * (size_t)nx]; edges[4 * (size_t)v + 3] = g.xy[2 * (size_t)nx + 1];
+            }
         for (int e = 0; e < E; ++e) p->lidar.max_static_verts = std::max(p->lidar.max_static_verts, evo[e + 1] - evo[e]);
         if ((rc = dev_replace(p, &p->d_lidar_env_off, evo.data(), evo.size()))) return rc;
-        if ((rc = dev_replace(p, &p->d_lidar_next, nxt.data(), nxt.size()))) return rc;
-        if ((rc = dev_replace(p, &p->d_lidar_xy, g.xy.data(), g.xy.size()))) return rc;
+        if ((rc = dev_replace(p, &p->d_lidar_xy, edges.data(), edges.size()))) return rc;
     }
     p->lidar.env_vert_off = p->d_lidar_env_off;
-    p->lidar.next_vert = p->d_lidar_next;
     p->lidar.xy = p->d_lidar_xy;
     p->lidar.max_slots = p->lidar.max_static_verts + (p->lidar.include_participants ? 4 * p->v.A : 0);
     if ((sizeof(double) * (p->lidar.max_slots <= 64 ? 8 : 4) + 8) * (size_t)p->lidar.max_slots + 16 * (size_t)p->lidar.n_beams + 2048 > 60 * 1024)
@@ -972,7 +972,7 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
         if ((rc = dev_replace<uint8_t>(p, &p->d_boundary_valid, nullptr, 0))) return rc;
         if ((rc = dev_replace(p, &p->d_target_xy, zd.data(), 8 * (size_t)E))) return rc;
         if ((rc = dev_replace(p, &p->d_target_c, zd.data(), 2 * (size_t)E))) return rc;
-        std::vector<float> zl(8 * (size_t)K * E, 0.f);
+        std::vector<float> zl(16 * (size_t)K * E, 0.f);   // 4 edge records of 4 floats per polygon slot
         std::vector<int32_t> zi(E, 0);
         if ((rc = dev_replace(p, &p->d_lidar_xy, zl.data(), zl.size()))) return rc;
         if ((rc = dev_replace(p, &p->d_lidar_cnt, zi.data(), zi.size()))) return rc;

@@ -491,7 +491,7 @@ T2D_DEV void install_scene(const PoolView& pv, const SceneView& sv, int e, const
     uint32_t* rec = sv.geo + (size_t)blk * gl.stride;
     float4* bb = reinterpret_cast<float4*>(rec + gl.off_aabb[0]) + K * el;
     float* xy = reinterpret_cast<float*>(rec + gl.off_xy[0]) + 8 * K * el;
-    float* lxy = sv.lidar_xy + (size_t)e * 8 * K;
+    float4* ledge = reinterpret_cast<float4*>(sv.lidar_xy) + (size_t)e * 4 * K;   // one record per edge
     for (int k = 0; k < K; ++k) {
         float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
@@ -511,8 +511,10 @@ T2D_DEV void install_scene(const PoolView& pv, const SceneView& sv, int e, const
         const float4 lo = make_float4(r[0], r[1], r[2], r[3]), hi = make_float4(r[4], r[5], r[6], r[7]);
         reinterpret_cast<float4*>(xy)[2 * k] = lo;
         reinterpret_cast<float4*>(xy)[2 * k + 1] = hi;
-        reinterpret_cast<float4*>(lxy)[2 * k] = lo;
-        reinterpret_cast<float4*>(lxy)[2 * k + 1] = hi;
+        ledge[4 * k] = lo;                                   // (v0, v1)
+        ledge[4 * k + 1] = make_float4(r[2], r[3], r[4], r[5]);   // (v1, v2)
+        ledge[4 * k + 2] = hi;                                   // (v2, v3)
+        ledge[4 * k + 3] = make_float4(r[6], r[7], r[0], r[1]);   // (v3, v0)
     }
     sv.lidar_cnt[e] = 4 * n_areas;
     reinterpret_cast<float4*>(sv.boundary)[e] = R.bound;

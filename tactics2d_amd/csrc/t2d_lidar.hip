@@ -158,6 +158,15 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
 #define T2D_LMARK(k)
 #endif
 
+    // the first kLidarBlock static edges are fetched before the ego transform is known: their latency overlaps the
+    // ego's loads + sincos instead of following them (one record per edge: no vertex -> next-vertex indirection)
+    int n_static = 0, v0 = 0;
+    float4 first_edge = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lv.env_vert_off) {
+        v0 = lv.env_vert_off[env];
+        n_static = lv.env_vert_cnt ? lv.env_vert_cnt[env] : lv.env_vert_off[env + 1] - v0;
+        if (tid < n_static) first_edge = reinterpret_cast<const float4*>(lv.xy)[v0 + tid];
+    }
     if (tid == 0) {
         const size_t ie = base + lv.ego_index;
         const uint32_t ids = pv.ids[ie];
@@ -175,20 +184,14 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     T2D_LMARK(0);
 
     // ---- phase 1a: static polygon edges (vertex v -> next vertex of its ring) ------------------------
-    int n_static = 0;
-    if (lv.env_vert_off) {
-        const int v0 = lv.env_vert_off[env];
-        n_static = lv.env_vert_cnt ? lv.env_vert_cnt[env] : lv.env_vert_off[env + 1] - v0;
-        for (int q = tid; q < n_static; q += kLidarBlock) {
-            const float2 p = reinterpret_cast<const float2*>(lv.xy)[v0 + q];
-            const float2 r = reinterpret_cast<const float2*>(lv.xy)[lv.next_vert[v0 + q]];
-            const double x1 = cs * (double)p.x + sn * (double)p.y + x_off;
-            const double y1 = -sn * (double)p.x + cs * (double)p.y + y_off;
-            const double x2 = cs * (double)r.x + sn * (double)r.y + x_off;
-            const double y2 = -sn * (double)r.x + cs * (double)r.y + y_off;
-            put_edge(q, x1, y1, x2, y2);
-            s_span[q] = edge_span(x1, y1, x2, y2, lv.max_range, lv.n_beams);
-        }
+    for (int q = tid; q < n_static; q += kLidarBlock) {
+        const float4 ed = q == tid ? first_edge : reinterpret_cast<const float4*>(lv.xy)[v0 + q];
+        const double x1 = cs * (double)ed.x + sn * (double)ed.y + x_off;
+        const double y1 = -sn * (double)ed.x + cs * (double)ed.y + y_off;
+        const double x2 = cs * (double)ed.z + sn * (double)ed.w + x_off;
+        const double y2 = -sn * (double)ed.z + cs * (double)ed.w + y_off;
+        put_edge(q, x1, y1, x2, y2);
+        s_span[q] = edge_span(x1, y1, x2, y2, lv.max_range, lv.n_beams);
     }
     // ---- phase 1b: the other participants' boxes (4 edges each; skipped slots get the far edge) -------
     int n_slots = n_static;

@@ -78,8 +78,7 @@ struct PoolView {
 struct LidarView {
     const int32_t* env_vert_off;  // [E+1] vertex range of env e, or null (no static obstacles)
     const int32_t* env_vert_cnt;  // null, or [E] vertices in use when envs own fixed-capacity ranges (generated scenes)
-    const int32_t* next_vert;     // [V] index of the next vertex of the same ring
-    const float* xy;              // [V][2]
+    const float* xy;              // [V][4] one record per polygon EDGE: x1, y1, x2, y2 (vertex v -> next vertex of its ring)
     const double* beam_pre;       // [n_beams][6] per beam: a = sin, b = -cos of linspace(0, 2pi, n, endpoint=False)[k]
                                   // (lidar.py:161-162) and the four slack-widened bounds of its end point (x hi / lo, y hi / lo)
     double max_range;
