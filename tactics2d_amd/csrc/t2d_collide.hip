@@ -213,6 +213,9 @@ __device__ __noinline__ bool circle_vs_generic(double cx, double cy, double R, c
 // integrated directly -- every edge of A clipped to closed B, every edge of B clipped to A with
 // coincident (parallel, on-the-line) pieces dropped -- and the 8 partial sums are combined in a
 // fixed tree order.  Out of line: only the ego lane of an env runs it.
+// Branch-free on purpose: the four clip parameters of a term -- and the 8 terms of an IoU -- are independent IEEE
+// divisions; written with if / else every one of them sat in its own basic block and the single ego lane walked
+// 33 divisions one after the other.  A division by den == 0 yields inf / nan that is never selected.
 T2D_DEV double clipped_edge_term(double p0x, double p0y, double p1x, double p1y, const Quad& Q, bool strict,
                                  double Ox, double Oy) {
     const double dx = p1x - p0x, dy = p1y - p0y;
@@ -224,18 +227,16 @@ T2D_DEV double clipped_edge_term(double p0x, double p0y, double p1x, double p1y,
         const double ex = Q.x[k] - Q.x[j], ey = Q.y[k] - Q.y[j];
         const double num = ex * (p0y - Q.y[j]) - ey * (p0x - Q.x[j]);
         const double den = ex * dy - ey * dx;
-        if (den == 0.0) {
-            if (num < 0.0 || (strict && num == 0.0)) ok = false;
-        } else {
-            const double tc = -num / den;
-            if (den > 0.0) t0 = tc > t0 ? tc : t0;
-            else t1 = tc < t1 ? tc : t1;
-        }
+        const double tc = -num / den;
+        const bool par = den == 0.0;   // (bitwise, not short-circuit: no control flow)
+        ok = ok & !(par & ((num < 0.0) | (strict & (num == 0.0))));
+        t0 = (!par & (den > 0.0) & (tc > t0)) ? tc : t0;
+        t1 = (!par & (den < 0.0) & (tc < t1)) ? tc : t1;
     }
-    if (!ok || !(t0 < t1)) return 0.0;
     const double ax = p0x + t0 * dx - Ox, ay = p0y + t0 * dy - Oy;
     const double bx = p0x + t1 * dx - Ox, by = p0y + t1 * dy - Oy;
-    return ax * by - bx * ay;
+    const double term = ax * by - bx * ay;
+    return (ok & (t0 < t1)) ? term : 0.0;
 }
 
 T2D_DEV double quad_area2(const Quad& P) {
@@ -261,8 +262,12 @@ __device__ __noinline__ double quad_iou(const double* a_planes, const double* b_
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = (i + 1) & 3;
+        // one term = four independent division chains: enough to keep the issue port busy; the fences stop the
+        // scheduler from interleaving all eight terms (33 divisions in flight spill past the kernel's 128 registers)
         s[i] = clipped_edge_term(A.x[i], A.y[i], A.x[k], A.y[k], B, false, A.x[0], A.y[0]);
+        __builtin_amdgcn_sched_barrier(0);
         s[4 + i] = clipped_edge_term(B.x[i], B.y[i], B.x[k], B.y[k], A, true, A.x[0], A.y[0]);
+        __builtin_amdgcn_sched_barrier(0);
     }
     double inter = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     if (inter < 0.0) inter = 0.0;
