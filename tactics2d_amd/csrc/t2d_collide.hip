@@ -95,13 +95,16 @@ T2D_DEV Quad load_obb_lds(const double* base) {  // &s_v[0][lane], planes kBlock
 // closed-set convex `intersects` of two quads: the orientation evaluations of oracle
 // t2do_convex_intersects(A, 4, B, n) (plus harmless padded ones).
 T2D_DEV bool sat_quads(const Quad& A, const Quad& B) {
+    // straight-line: the lanes of a wave hold different candidate pairs, so an early return on the first separating
+    // edge only saves work when all 64 agree; without the exits the 32 orientation signs are independent
+    bool separated = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = (i + 1) & 3;
         bool all_out = true;
 #pragma unroll
         for (int j = 0; j < 4; ++j) all_out &= orient(A.x[i], A.y[i], A.x[k], A.y[k], B.x[j], B.y[j]) < 0.0;
-        if (all_out) return false;
+        separated |= all_out;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -109,9 +112,9 @@ T2D_DEV bool sat_quads(const Quad& A, const Quad& B) {
         bool all_out = true;
 #pragma unroll
         for (int i = 0; i < 4; ++i) all_out &= orient(B.x[j], B.y[j], B.x[k], B.y[k], A.x[i], A.y[i]) < 0.0;
-        if (all_out) return false;
+        separated |= all_out;
     }
-    return true;
+    return !separated;
 }
 
 T2D_DEV bool point_in_quad(const Quad& B, double x, double y) {
