@@ -924,6 +924,8 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
     if (p->has_drift) return fail(p, T2D_ERR_INVALID, "SingleTrackDrift agents are not supported in generated parking scenes");
     if (p->hgeo[1].present) return fail(p, T2D_ERR_STATE, "lane geometry cannot be combined with generated parking scenes");
     if (env_stride < 0) return fail(p, T2D_ERR_INVALID, "env_stride must be >= 0");
+    if (regenerate != 0 && regenerate != 1 && regenerate != 2)
+        return fail(p, T2D_ERR_INVALID, "regenerate must be 0 (off), 1 (staged ahead) or 2 (generated in the step's stream)");
     if (vehicle_length < vehicle_width || !(vehicle_length > 0.0) || !(vehicle_width > 0.0)) {
         vehicle_length = 5.3;  // ParkingLotGenerator.__init__ :45-57
         vehicle_width = 2.5;
@@ -988,12 +990,10 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
     if (!p->d_snap_ids) T2D_HIP(p, hipMalloc((void**)&p->d_snap_ids, nbytes));
     // the per-scene arrays (layout of t2d_generate_parking's outputs): live [E] + the staging ring [E * ring] used when
     // scenes are regenerated (regenerate == 1; == 2 generates on the step's stream instead), episode counters
-    if (regenerate != 0 && regenerate != 1 && regenerate != 2)
-        return fail(p, T2D_ERR_INVALID, "regenerate must be 0 (off), 1 (staged ahead) or 2 (generated in the step's stream)");
     const int ring = regenerate == 1 ? kSceneRing : 0;
     const size_t per[8] = {(size_t)K * 8 * sizeof(float), (size_t)K * sizeof(int32_t), sizeof(int32_t), 3 * sizeof(double),
                            8 * sizeof(float), sizeof(double), 4 * sizeof(float), sizeof(uint32_t)};
-    const size_t counts[3] = {(size_t)E, (size_t)E * ring, 0};
+    const size_t counts[2] = {(size_t)E, (size_t)E * ring};
     size_t off[18], total = 0;
     for (int set = 0; set < 2; ++set)
         for (int k = 0; k < 8; ++k) {
