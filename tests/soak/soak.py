@@ -1,8 +1,8 @@
 """Randomised soak of the event kernels against the oracle: many seeds x pool shapes, flags bit-exact.
 (The pytest suite runs a fixed handful of these; this is the long version for after kernel changes.)
-Usage on the GPU box: python scripts/soak.py [n_seeds]"""
+Usage on the GPU box: python tests/soak/soak.py [n_seeds]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import helpers as H

@@ -1,7 +1,7 @@
 """Soak of the ParkingLotGenerator kernel against its CPU restatement: many (seed, proportion, vehicle size, first_env)
-combinations, every output array compared bit for bit.   python scripts/soak_generate.py [n_configs] [scenes_per_config]"""
+combinations, every output array compared bit for bit.   python tests/soak/soak_generate.py [n_configs] [scenes_per_config]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import oracle as O

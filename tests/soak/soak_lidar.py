@@ -1,8 +1,8 @@
 """Randomised soak of the lidar kernel against the oracle (bit-exact): random scenes, beam counts 90 / 360 / 1024,
 participants on and off, plus scenes with obstacle vertices very close to the sensor (large angular error of the
-fp32 span estimate).  Usage on the GPU box: python scripts/soak_lidar.py [n_seeds]"""
+fp32 span estimate).  Usage on the GPU box: python tests/soak/soak_lidar.py [n_seeds]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import helpers as H

@@ -4,7 +4,7 @@
      (generate + install in one launch, nothing crosses PCIe);
  (3) per-step cost of regenerating finished episodes: step alone, step + regeneration launch (kernel ids 2 and 6)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import oracle as O

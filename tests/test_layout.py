@@ -106,3 +106,19 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "t2d_oracle" not in src.replace("oracle/t2d_oracle.c", "").replace("oracle t2do_", ""), f
+
+
+def test_only_tests_smoke_and_the_cpu_baseline_touch_the_oracle():
+    """oracle/ is test infrastructure: besides tests/, only __graft_entry__ (build + smoke) and bench.py's cpu_baseline
+    leg may import it; the helper scripts under scripts/ must not."""
+    for f in sorted(os.listdir(os.path.join(ROOT, "scripts"))):
+        if f.endswith((".py", ".sh")):
+            src = open(os.path.join(ROOT, "scripts", f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+            assert "libt2d_oracle" not in src and "t2d_oracle" not in src, f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    uses = [m.start() for m in re.finditer(r"(from|import)\s+oracle\b", bench)]
+    assert uses, "bench.py's cpu_baseline leg is expected to time the oracle"
+    lo = bench.index("def _cpu_leg")          # the two functions of the cpu_baseline leg
+    hi = bench.index("\ndef ", bench.index("def cpu_baseline") + 1)
+    assert all(lo < u < hi for u in uses), "the oracle may only be imported inside the cpu_baseline leg"
