@@ -450,3 +450,33 @@ def test_parking_scenes_argument_and_state_checks():
     with pytest.raises(_ffi.T2DError):
         pool.get_parking_scenes()                              # left the generated-scene mode
     pool.close(); fresh.close()
+
+
+def test_layout_relations_of_the_reference_construction(oracle, scenes):
+    """Relations the reference's construction implies (generate_parking_lot.py:127-205, 338-346, 396-407): the left
+    obstacle (id 1) lies left of the target bay and the right one (id 2) right of it with the 0.8 m clearance, the
+    back wall (id 0) spans the scene below y = 0, and the start pose sits at least 1.8 m above every obstacle that
+    was placed before the start range was fixed (walls and parked vehicles)."""
+    q, ids, n = scenes["quads"].astype(np.float64), scenes["quad_id"], scenes["n_quads"]
+    t = scenes["target"].astype(np.float64)
+    checked = {0: 0, 1: 0, 2: 0}
+    for e in range(0, N, 5):
+        row = ids[e, :n[e]].tolist()
+        tx0, tx1 = t[e, :, 0].min(), t[e, :, 0].max()
+        if 0 in row:
+            w = q[e, row.index(0)]
+            assert w[:, 0].min() == -15.0 and w[:, 0].max() == 15.0 and w[:, 1].max() == 0.0 and -1.5 <= w[:, 1].min() <= -0.5
+            checked[0] += 1
+        if 1 in row:
+            assert q[e, row.index(1), :, 0].max() < tx0 - 0.3          # rotated boxes: corner gaps shrink below 0.8
+            checked[1] += 1
+        if 2 in row:
+            assert q[e, row.index(2), :, 0].min() > tx1 + 0.3
+            checked[2] += 1
+        # placed before the start range was fixed = walls and parked vehicles: they stand on the back-wall side
+        # (lowest vertex below y = 3); the far wall and the perturbed vehicles are beyond the start range
+        early = [k for k in range(len(row)) if q[e, k, :, 1].min() < 3.0]
+        if early:
+            top = max(q[e, k, :, 1].max() for k in early)
+            assert scenes["start"][e, 1] >= top + 1.8 - 1e-6
+    assert min(checked.values()) > 0.8 * len(range(0, N, 5))          # the 5 % drop removes a few
