@@ -165,7 +165,6 @@ def main():
 
     import torch
     from tactics2d_amd import dist as D, layout as L
-    from tactics2d_amd.pool import ParticipantPool
 
     # (T2D_DIST_BACKEND / T2D_FORCE_DEVICE exist to exercise the N > 1 code path on a one-GPU box: gloo, every rank on
     # the same device; never set in a real run)

@@ -12,7 +12,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
-import helpers as H
 from tactics2d_amd import layout as L
 from tactics2d_amd import scenarios as S
 from tactics2d_amd.pool import ParticipantPool

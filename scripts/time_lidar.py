@@ -1,6 +1,5 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 from tactics2d_amd import scenarios as S
 from tactics2d_amd.pool import ParticipantPool
 for name, sc, part in (("cfg2 parking 4096x1", S.parking(4096), False), ("metric mixed 4096x64", S.mixed(4096, 64), True)):

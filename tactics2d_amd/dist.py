@@ -8,7 +8,6 @@ plumbing only: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU test
 """
 import os
 
-import numpy as np
 
 
 def env_info():

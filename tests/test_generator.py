@@ -200,7 +200,6 @@ def test_invalid_vehicle_size_falls_back_and_args_are_checked(oracle):
 def test_generated_scenes_load_and_step(oracle):
     """The generated batch goes through the ordinary boundary (set_static_geometry / set_target_areas / reset) and
     the step kernel's events agree with the oracle on it; nobody starts in collision or out of bounds."""
-    import helpers as H
     from tactics2d_amd import layout as L
     from tactics2d_amd.generator import ParkingLotGenerator
     from tactics2d_amd.pool import ParticipantPool
@@ -408,8 +407,7 @@ def test_vec_env_auto_reset_moves_on_to_new_scenes():
 def test_parking_scenes_argument_and_state_checks():
     """Error behaviour at the boundary: wrong pool shape, call order, mode mixing -- and leaving the generated-scene
     mode through t2d_set_static_geometry gives an ordinary host-described pool again."""
-    import helpers as H
-    from tactics2d_amd import _ffi, layout as L, scenarios as S
+    from tactics2d_amd import _ffi
     from tactics2d_amd.generator import ParkingLotGenerator
     from tactics2d_amd.pool import ParticipantPool
     size = (4.284, 1.81)

@@ -7,7 +7,6 @@ hand-derived sequences following envs/parking.py:361-392 and :148-190 line by li
 import numpy as np
 import pytest
 
-import helpers as H
 
 
 def box(cx, cy, h, L_, W_):
