@@ -175,6 +175,7 @@ T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, 
             // v_k * dt advances by a constant, phi and v are the closed forms of their sums: 11 operations per sub-step
             double vh = v * dt;
             const double dvh = ah_l * dt;
+#pragma unroll 4
             for (int k = 0; k < n_steps; ++k) {
                 x = __builtin_fma(vh, c, x);
                 y = __builtin_fma(vh, s, y);
@@ -296,6 +297,7 @@ T2D_DEV StepOut step_dynamics(PF P, double x, double y, double phi, double v, do
         int k_done = 0;
         if (__ballot(!always_fast) == 0ull) {
             const double mmidt = mmi * dt;
+#pragma unroll 2
             for (int k = 0; k < n_steps; ++k) {
                 const double vh = v * dt;
                 x = __builtin_fma(vh, c, x);
