@@ -27,7 +27,9 @@
  *                            StaticCollision.update          traffic/event_detection/collision.py:37-43
  *                            DynamicCollision.update         traffic/event_detection/collision.py:18-25 (intended semantics)
  *                            OutBound.update                 traffic/event_detection/out_bound.py:37-48
- *                            OffLane.update                  traffic/event_detection/off_lane.py:16-17 (stub; build-defined)
+ *                            OffLane.update                  traffic/event_detection/off_lane.py:16-17 (stub; build-defined:
+ *                                                            not union(lane polygons).contains(pose), the predicate of
+ *                                                            out_bound.py:37-48 applied to the lanes)
  *   t2d_snapshot/restore  <- ParkingEnv.reset / _ParkingScenarioManager.reset       envs/parking.py:262-298,397-441
  *   t2d_set_target_areas  <- Arrival.reset                traffic/event_detection/arrival.py:49-51
  *                            Arrival.update / NoAction.update (IoU)   arrival.py:32-47, no_action.py:32-53
@@ -56,7 +58,7 @@
 extern "C" {
 #endif
 
-#define T2D_ABI_VERSION 3
+#define T2D_ABI_VERSION 4
 
 /* ---- status codes --------------------------------------------------------------- */
 #define T2D_OK            0
@@ -157,7 +159,7 @@ enum {
 #define T2D_FLAG_COLLISION_DYNAMIC 1u   /* OBB/circle intersects another active participant */
 #define T2D_FLAG_COLLISION_STATIC  2u   /* intersects a static polygon (StaticCollision)    */
 #define T2D_FLAG_OUT_BOUND         4u   /* not boundary.contains(pose)  (OutBound)          */
-#define T2D_FLAG_OFF_LANE          8u   /* build-defined, see DESIGN.md                      */
+#define T2D_FLAG_OFF_LANE          8u   /* not union(lanes).contains(pose); build-defined, DESIGN.md */
 
 /* ---- ScenarioStatus / TrafficStatus values: traffic/status.py:10-61 ----------------- */
 #define T2D_TRAFFIC_NO_ACTION_QUIRK 5  /* parking.py:373 stores ScenarioStatus.NO_ACTION (5) in traffic_status */
@@ -227,7 +229,10 @@ int t2d_set_static_geometry(t2d_pool* pool, const int32_t* env_poly_offsets,
                             const float* boundary, const uint8_t* boundary_valid);
 
 /* Lane polygons for the build-defined off-lane flag; same CSR convention.  Envs with no
- * lane polygons never raise T2D_FLAG_OFF_LANE (== the reference stub).                  */
+ * lane polygons never raise T2D_FLAG_OFF_LANE (== the reference stub).  The flag is
+ * `not union(lanes).contains(pose)`: the boundary of the union of each env's lanes is extracted
+ * here, once (lanes that abut must share their vertices exactly, or overlap: a sliver between two
+ * almost-collinear edges is a real gap of the union).                                      */
 int t2d_set_lane_geometry(t2d_pool* pool, const int32_t* env_lane_offsets,
                           const int32_t* lane_vert_offsets, const float* verts_xy);
 
@@ -411,6 +416,11 @@ int t2d_set_integrator_variant(t2d_pool* pool, int32_t variant);
  * kernel_id: 0 = integrate, 1 = collide(+status), 2 = fused step, 3 = lidar, 4 = idm, 5 = drift, 6 = scene regeneration.                                   */
 int t2d_profile_enable(t2d_pool* pool, int32_t on);
 int t2d_profile_read(t2d_pool* pool, int32_t kernel_id, double* total_ms, int64_t* launches);
+
+/* Introspection: resident workgroups per CU of the fused step kernel with this pool's geometry, and its LDS bytes
+ * per workgroup (static tables + the workgroup's geometry record).  The 4096 x 64 metric launch is one wave-round
+ * of 1024 workgroups on 256 CUs and needs 4; a scene whose record grows past the LDS budget halves the rate.    */
+int t2d_debug_step_occupancy(t2d_pool* pool, int32_t* blocks_per_cu, int64_t* lds_bytes);
 
 #ifdef __cplusplus
 }

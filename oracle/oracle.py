@@ -56,6 +56,9 @@ def lib():
         _lib.t2do_circle_convex_intersects.argtypes = [_f64p, C.c_double, _f64p, C.c_int]
         _lib.t2do_circle_circle_intersects.argtypes = [_f64p, C.c_double, _f64p, C.c_double]
         _lib.t2do_polygon_is_convex.argtypes = [_f32p, C.c_int]
+        _lib.t2do_pose_in_lane_union.argtypes = [_f64p, _f64p, _i32p, _f32p, C.c_int, C.c_int]
+        _lib.t2do_circle_in_lane_union.argtypes = [_f64p, C.c_double, _i32p, _f32p, C.c_int, C.c_int]
+        _lib.t2do_lane_boundary.argtypes = [_i32p, _f32p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         _lib.t2do_collide.argtypes = [_f64p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, _f32p, _u8p,
                                       _u8p] + [C.c_void_p] * 8 + [C.c_int, _u32p, _u32p]
         _lib.t2do_status.argtypes = [C.POINTER(StatusConfig), C.c_int, C.c_int, _u32p, C.c_int,
@@ -124,6 +127,36 @@ def circle_circle_intersects(c1, R1, c2, R2):
 def polygon_is_convex(verts):
     v = np.ascontiguousarray(verts, np.float32)
     return bool(lib().t2do_polygon_is_convex(v, len(v)))
+
+
+def _lane_csr(lanes):
+    vo = np.zeros(len(lanes) + 1, np.int32)
+    vo[1:] = np.cumsum([len(q) for q in lanes])
+    xy = np.ascontiguousarray(np.concatenate([np.asarray(q, np.float32).reshape(-1, 2) for q in lanes]), np.float32)
+    return vo, xy
+
+
+def lane_boundary(lanes):
+    """Boundary pieces of the union of the convex lane polygons (t2do_lane_boundary): (pieces[k, 4] = Ax, Ay, Bx, By
+    in fp64, owner[k] = index of the lane polygon the piece is a part of an edge of)."""
+    vo, xy = _lane_csr(lanes)
+    n = lib().t2do_lane_boundary(vo, xy, 0, len(lanes), None, None, 0)
+    pieces = np.zeros((max(n, 1), 4), np.float64); owner = np.zeros(max(n, 1), np.int32)
+    lib().t2do_lane_boundary(vo, xy, 0, len(lanes), pieces.ctypes.data_as(C.c_void_p), owner.ctypes.data_as(C.c_void_p), n)
+    return pieces[:n], owner[:n]
+
+
+def pose_in_lane_union(pose, centre, lanes):
+    """`union(lanes).contains(pose)` (build-defined off-lane, t2d_oracle.c): pose = 4 x (x, y) in the vertex order
+    of pose_obb, centre = (x, y), lanes = list of convex polygons (fp32 vertices, either winding)."""
+    vo, xy = _lane_csr(lanes)
+    return bool(lib().t2do_pose_in_lane_union(np.ascontiguousarray(pose, np.float64).reshape(8),
+                                              np.ascontiguousarray(centre, np.float64), vo, xy, 0, len(lanes)))
+
+
+def circle_in_lane_union(c, R, lanes):
+    vo, xy = _lane_csr(lanes)
+    return bool(lib().t2do_circle_in_lane_union(np.ascontiguousarray(c, np.float64), float(R), vo, xy, 0, len(lanes)))
 
 
 def collide(rows, n_env, A, x, y, heading, type_id, active, static=None, boundary=None,

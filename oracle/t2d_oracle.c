@@ -532,15 +532,207 @@ int t2do_polygon_is_convex(const float* verts_xy, int n) {
     return 1;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Off-lane = `not union(lanes).contains(pose)`.  The reference's OffLane.update
+ * (off_lane.py:16-17) is a stub; the predicate mirrored is OutBound.update out_bound.py:37-48:
+ * `not region.contains(pose)`, shapely `contains` = no point of the pose in the exterior of the
+ * region (touching the region's boundary from inside is still contained).  BUILD-DEFINED, parity
+ * unpinned (no shapely here, and the reference never evaluates it).
+ *
+ * region U = closed union of the env's convex lane polygons.  For a convex pose P:
+ *     P in U   <=>   centre(P) in U   and   no piece of the boundary of U meets the interior of P
+ * (the interior of P is connected: if it does not meet the boundary of U it lies wholly inside or
+ * wholly outside U, and the centre decides which).  Two exact short cuts come first, in this order:
+ * a pose with all four vertices in ONE lane polygon is contained (convexity); a pose with a vertex
+ * in NO lane polygon is not.  Only bodies that straddle lanes reach the boundary test.  This catches bodies that cut a corner of the
+ * union with all four vertices in lanes, holes of the union inside a body, and a body that exactly
+ * fills a gap between lanes.
+ *
+ * Boundary of U (computed once per env when the lanes are installed -- t2do_lane_boundary here,
+ * build_lane_boundary in t2d_api.hip): every edge q0 -> q1 of every lane polygon L (CCW) minus the
+ * parts whose right-hand (outer) side is covered by another lane M.  "Covered by M" = the closed
+ * parametric clip of the edge against M's half-planes (num + t den >= 0, tc = -num / den, IEEE
+ * division) with positive length, where an edge of M that is collinear with q0 -> q1 AND points
+ * the same way rejects M (M then lies on L's own side of the line).  The covered intervals are
+ * merged in ascending order; two that meet within T2D_LANE_TAU (in t) count as joined -- adjacent
+ * lanes share a vertex, and the two clip parameters of that vertex agree only up to rounding.
+ * What is left over becomes boundary pieces [A, B] in fp64 (A = q0 when the piece starts at t = 0,
+ * else q0 + t d; likewise B).  Lane polygons that are meant to abut must share their edge LINE
+ * exactly (same fp32 vertices, or axis-parallel): a sliver between two almost-collinear edges is a
+ * real gap of U.
+ *
+ * Tests on the pose (orientation signs only, like t2do_convex_intersects):
+ *   box:    piece [A, B] misses the open quad P  <=>  some edge of P has A and B on its outer side
+ *           or on it (orient <= 0), or all four vertices of P lie on one closed side of line AB
+ *   circle: piece within the open disc  <=>  squared distance(centre, [A, B]) < R^2
+ * ---------------------------------------------------------------------------------------- */
+#define T2D_LANE_TAU 1e-9
+
+/* part of q0 -> q1 whose right-hand side is covered by the CCW convex polygon M: 1 and (*a, *b) */
+static int edge_covered_by(const double* q0, const double* q1, const double* M, int n, double* a, double* b) {
+    const double dx = q1[0] - q0[0], dy = q1[1] - q0[1];
+    double t0 = 0.0, t1 = 1.0;
+    for (int j = 0; j < n; ++j) {
+        const double* f0 = M + 2 * j;
+        const double* f1 = M + 2 * ((j + 1) % n);
+        const double ex = f1[0] - f0[0], ey = f1[1] - f0[1];
+        const double num = ex * (q0[1] - f0[1]) - ey * (q0[0] - f0[0]); /* inside <=> num + t*den >= 0 */
+        const double den = ex * dy - ey * dx;
+        if (den == 0.0) {
+            if (num < 0.0) return 0;
+            if (num == 0.0 && ex * dx + ey * dy > 0.0) return 0;
+        } else {
+            const double tc = -num / den;
+            if (den > 0.0) t0 = tc > t0 ? tc : t0;
+            else t1 = tc < t1 ? tc : t1;
+        }
+    }
+    if (!(t0 < t1)) return 0;
+    *a = t0; *b = t1;
+    return 1;
+}
+
+/* Boundary pieces of the union of the lane polygons [l0, l1) (CSR as in t2d_set_lane_geometry).
+ * pieces[4 * k] = Ax, Ay, Bx, By; owner[k] = lane polygon (absolute index) the piece is an edge part of.
+ * Pieces are emitted lane by lane, edge by edge, in ascending t.  Returns the number of pieces; nothing is
+ * written beyond cap (call with cap = 0 to size the arrays). */
+int t2do_lane_boundary(const int32_t* lane_vert_off, const float* lane_xy, int l0, int l1, double* pieces,
+                       int32_t* owner, int cap) {
+    const int nl = l1 - l0;
+    int count = 0;
+    if (nl <= 0) return 0;
+    double* polys = (double*)malloc(sizeof(double) * 2 * T2D_MAX_POLY_VERTS * (size_t)nl);
+    int* pn = (int*)malloc(sizeof(int) * (size_t)nl);
+    double* ia = (double*)malloc(sizeof(double) * 2 * (size_t)nl);
+    double* ib = ia + nl;
+    for (int i = 0; i < nl; ++i)
+        pn[i] = load_poly(lane_xy, lane_vert_off[l0 + i], lane_vert_off[l0 + i + 1], polys + 2 * T2D_MAX_POLY_VERTS * (size_t)i);
+    for (int i = 0; i < nl; ++i) {
+        const double* L = polys + 2 * T2D_MAX_POLY_VERTS * (size_t)i;
+        for (int j = 0; j < pn[i]; ++j) {
+            const double* q0 = L + 2 * j;
+            const double* q1 = L + 2 * ((j + 1) % pn[i]);
+            const double dx = q1[0] - q0[0], dy = q1[1] - q0[1];
+            if (dx == 0.0 && dy == 0.0) continue;
+            int m = 0;
+            for (int k = 0; k < nl; ++k) {
+                if (k == i) continue;
+                double a, b;
+                if (!edge_covered_by(q0, q1, polys + 2 * T2D_MAX_POLY_VERTS * (size_t)k, pn[k], &a, &b)) continue;
+                int pos = m++;   /* insertion sort by start */
+                while (pos > 0 && ia[pos - 1] > a) { ia[pos] = ia[pos - 1]; ib[pos] = ib[pos - 1]; --pos; }
+                ia[pos] = a; ib[pos] = b;
+            }
+            double r = 0.0;
+            for (int k = 0; k <= m; ++k) {
+                const double a = k < m ? ia[k] : 1.0;
+                const int gap = k < m ? a > r + T2D_LANE_TAU : r < 1.0 - T2D_LANE_TAU;
+                if (gap) {
+                    if (count < cap) {
+                        double* P = pieces + 4 * (size_t)count;
+                        P[0] = r == 0.0 ? q0[0] : q0[0] + r * dx;
+                        P[1] = r == 0.0 ? q0[1] : q0[1] + r * dy;
+                        P[2] = a == 1.0 ? q1[0] : q0[0] + a * dx;
+                        P[3] = a == 1.0 ? q1[1] : q0[1] + a * dy;
+                        owner[count] = l0 + i;
+                    }
+                    ++count;
+                }
+                if (k < m && ib[k] > r) r = ib[k];
+            }
+        }
+    }
+    free(polys); free(pn); free(ia);
+    return count;
+}
+
+/* 1 when the boundary piece A -> B meets the interior of the CCW convex quad pose8 */
+int t2do_piece_meets_quad_interior(const double* piece, const double* pose8) {
+    const double* A = piece;
+    const double* B = piece + 2;
+    for (int i = 0; i < 4; ++i) {
+        const double* p = pose8 + 2 * i;
+        const double* q = pose8 + 2 * ((i + 1) & 3);
+        if (orient(p, q, A) <= 0.0 && orient(p, q, B) <= 0.0) return 0;
+    }
+    int all_ge = 1, all_le = 1;
+    for (int k = 0; k < 4; ++k) {
+        const double o = orient(A, B, pose8 + 2 * k);
+        if (!(o >= 0.0)) all_ge = 0;
+        if (!(o <= 0.0)) all_le = 0;
+    }
+    return !(all_ge || all_le);
+}
+
+static int point_in_lanes(const double* pt, const int32_t* lane_vert_off, const float* lane_xy, int l0, int l1) {
+    for (int li = l0; li < l1; ++li) {
+        double P[2 * T2D_MAX_POLY_VERTS];
+        int n = load_poly(lane_xy, lane_vert_off[li], lane_vert_off[li + 1], P);
+        if (t2do_point_in_convex(P, n, pt)) return 1;
+    }
+    return 0;
+}
+
+/* `union(lanes).contains(pose)`: box pose (8 doubles, vertex order of t2do_pose_obb, centre cxy) */
+static int box_in_lane_union(const double* pose8, const double* cxy, const int32_t* lane_vert_off,
+                             const float* lane_xy, int l0, int l1, const double* pieces, int n_pieces) {
+    for (int li = l0; li < l1; ++li) {   /* all four vertices in one convex lane polygon: contained */
+        double P[2 * T2D_MAX_POLY_VERTS];
+        int n = load_poly(lane_xy, lane_vert_off[li], lane_vert_off[li + 1], P), k = 0;
+        while (k < 4 && t2do_point_in_convex(P, n, pose8 + 2 * k)) ++k;
+        if (k == 4) return 1;
+    }
+    for (int k = 0; k < 4; ++k)          /* a vertex in no lane polygon: not contained */
+        if (!point_in_lanes(pose8 + 2 * k, lane_vert_off, lane_xy, l0, l1)) return 0;
+    if (!point_in_lanes(cxy, lane_vert_off, lane_xy, l0, l1)) return 0;
+    for (int k = 0; k < n_pieces; ++k)
+        if (t2do_piece_meets_quad_interior(pieces + 4 * (size_t)k, pose8)) return 0;
+    return 1;
+}
+
+/* circle pose (pedestrian.py:138-149): centre in U and no boundary piece inside the open disc */
+static int circle_in_lane_union(const double* c, double R, const int32_t* lane_vert_off, const float* lane_xy,
+                                int l0, int l1, const double* pieces, int n_pieces) {
+    if (!point_in_lanes(c, lane_vert_off, lane_xy, l0, l1)) return 0;
+    const double R2 = R * R;
+    for (int k = 0; k < n_pieces; ++k)
+        if (seg_dist2(pieces + 4 * (size_t)k, pieces + 4 * (size_t)k + 2, c) < R2) return 0;
+    return 1;
+}
+
+/* stand-alone forms for the known-answer tests (the boundary is rebuilt on every call) */
+int t2do_pose_in_lane_union(const double* pose8, const double* cxy, const int32_t* lane_vert_off,
+                            const float* lane_xy, int l0, int l1) {
+    const int n = t2do_lane_boundary(lane_vert_off, lane_xy, l0, l1, NULL, NULL, 0);
+    double* pieces = (double*)malloc(sizeof(double) * 4 * (size_t)(n + 1));
+    int32_t* owner = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    t2do_lane_boundary(lane_vert_off, lane_xy, l0, l1, pieces, owner, n);
+    const int r = box_in_lane_union(pose8, cxy, lane_vert_off, lane_xy, l0, l1, pieces, n);
+    free(pieces); free(owner);
+    return r;
+}
+
+int t2do_circle_in_lane_union(const double* c, double R, const int32_t* lane_vert_off, const float* lane_xy,
+                              int l0, int l1) {
+    const int n = t2do_lane_boundary(lane_vert_off, lane_xy, l0, l1, NULL, NULL, 0);
+    double* pieces = (double*)malloc(sizeof(double) * 4 * (size_t)(n + 1));
+    int32_t* owner = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    t2do_lane_boundary(lane_vert_off, lane_xy, l0, l1, pieces, owner, n);
+    const int r = circle_in_lane_union(c, R, lane_vert_off, lane_xy, l0, l1, pieces, n);
+    free(pieces); free(owner);
+    return r;
+}
+
 /* Event flags of every participant (what t2d_collide does on the GPU), brute force:
  *   COLLISION_DYNAMIC  intended DynamicCollision (collision.py:18-25): pose intersects the
  *                      pose of any other ACTIVE participant of the same env, all pairs
  *   COLLISION_STATIC   StaticCollision.update (collision.py:37-43): any static polygon
  *   OUT_BOUND          OutBound.update (out_bound.py:37-48): not boundary.contains(pose);
  *                      touching the boundary from inside is still contained -> strict tests
- *   OFF_LANE           build-defined (reference stub off_lane.py:16-17 returns False): some
- *                      pose vertex (circle: the centre) lies in no lane polygon (closed);
- *                      never raised for an env without lane polygons
+ *   OFF_LANE           build-defined (reference stub off_lane.py:16-17 returns False):
+ *                      not union(lane polygons).contains(pose), t2do_pose_in_lane_union above
+ *                      (circle: its centre lies in no lane polygon); never raised for an env
+ *                      without lane polygons
  * CSR arrays as in t2d_set_static_geometry / t2d_set_lane_geometry (may be NULL = none).   */
 void t2do_collide(const double* rows, int row_stride, int n_env, int A, const float* x,
                   const float* y, const float* heading, const uint8_t* type_id,
@@ -556,6 +748,15 @@ void t2do_collide(const double* rows, int row_stride, int n_env, int A, const fl
 #pragma omp for schedule(dynamic, 4)
     for (int e = 0; e < n_env; ++e) {
         size_t base = (size_t)e * A;
+        const int n_lanes_e = env_lane_off ? env_lane_off[e + 1] - env_lane_off[e] : 0;
+        int n_pieces = 0;
+        double* pieces = NULL;
+        if (n_lanes_e > 0) {   /* boundary of the env's lane union (the GPU path builds it once, at t2d_set_lane_geometry) */
+            n_pieces = t2do_lane_boundary(lane_vert_off, lane_xy, env_lane_off[e], env_lane_off[e + 1], NULL, NULL, 0);
+            pieces = (double*)malloc((sizeof(double) * 4 + sizeof(int32_t)) * (size_t)(n_pieces + 1));
+            t2do_lane_boundary(lane_vert_off, lane_xy, env_lane_off[e], env_lane_off[e + 1], pieces,
+                               (int32_t*)(pieces + 4 * (size_t)(n_pieces + 1)), n_pieces);
+        }
         for (int i = 0; i < A; ++i) {
             flags[base + i] = 0;
             if (!active[base + i]) continue;
@@ -612,25 +813,20 @@ void t2do_collide(const double* rows, int row_stride, int n_env, int A, const fl
                 }
                 if (out) f |= T2D_FLAG_OUT_BOUND;
             }
-            /* lanes (build-defined) */
-            if (env_lane_off && env_lane_off[e + 1] > env_lane_off[e]) {
-                int nv = kind[i] == T2D_SHAPE_OBB ? 4 : 1;
-                for (int k = 0; k < nv; ++k) {
-                    const double* pt = kind[i] == T2D_SHAPE_OBB ? V + 8 * i + 2 * k : C + 3 * i;
-                    int inside = 0;
-                    for (int li = env_lane_off[e]; li < env_lane_off[e + 1] && !inside; ++li) {
-                        double P[2 * T2D_MAX_POLY_VERTS];
-                        int n = load_poly(lane_xy, lane_vert_off[li], lane_vert_off[li + 1], P);
-                        inside = t2do_point_in_convex(P, n, pt);
-                    }
-                    if (!inside) { f |= T2D_FLAG_OFF_LANE; break; }
-                }
+            /* lanes (build-defined): not union(lanes).contains(pose) */
+            if (n_lanes_e > 0) {
+                const int l0 = env_lane_off[e], l1 = env_lane_off[e + 1];
+                const int in = kind[i] == T2D_SHAPE_OBB
+                                   ? box_in_lane_union(V + 8 * i, C + 3 * i, lane_vert_off, lane_xy, l0, l1, pieces, n_pieces)
+                                   : circle_in_lane_union(C + 3 * i, C[3 * i + 2], lane_vert_off, lane_xy, l0, l1, pieces, n_pieces);
+                if (!in) f |= T2D_FLAG_OFF_LANE;
             }
             flags[base + i] = f;
         }
         uint32_t ef = 0;
         for (int i = 0; i < A; ++i) ef |= flags[base + i];
         env_flags[e] = ef;
+        free(pieces);
     }
     free(V); free(C); free(kind);
     }

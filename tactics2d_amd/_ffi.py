@@ -77,6 +77,8 @@ SYMBOLS = {
     "t2d_set_integrator_variant": (C.c_int, [_vp, C.c_int32]),
     "t2d_profile_enable": (C.c_int, [_vp, C.c_int32]),
     "t2d_profile_read": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    # introspection, not part of include/t2d.h
+    "t2d_debug_step_occupancy": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
 }
 
 _lib = None

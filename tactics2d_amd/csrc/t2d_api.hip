@@ -116,6 +116,81 @@ int prepare_polys(t2d_pool* p, const int32_t* env_off, const int32_t* vert_off, 
     return T2D_OK;
 }
 
+// Boundary of the union of every env's lane polygons (off-lane = not union(lanes).contains(pose); the
+// reference's OffLane is a stub, the predicate mirrored is OutBound.update out_bound.py:37-48).  Same specification as
+// t2do_lane_boundary in oracle/t2d_oracle.c (independent restatement, same IEEE operations in the same order): every
+// edge q0 -> q1 of every CCW lane polygon minus the parts whose right-hand side is covered by another lane of the env
+// -- closed parametric clip against the other polygon's half-planes with positive length, a collinear edge of the same
+// direction rejects the polygon -- covered intervals merged in ascending order, joined when they meet within kLaneTau.
+constexpr double kLaneTau = 1e-9;
+
+bool edge_covered_by(const double* q0, const double* q1, const double* M, int n, double& a, double& b) {
+    const double dx = q1[0] - q0[0], dy = q1[1] - q0[1];
+    double t0 = 0.0, t1 = 1.0;
+    for (int j = 0; j < n; ++j) {
+        const double* f0 = M + 2 * j;
+        const double* f1 = M + 2 * ((j + 1) % n);
+        const double ex = f1[0] - f0[0], ey = f1[1] - f0[1];
+        const double num = ex * (q0[1] - f0[1]) - ey * (q0[0] - f0[0]);
+        const double den = ex * dy - ey * dx;
+        if (den == 0.0) {
+            if (num < 0.0) return false;
+            if (num == 0.0 && ex * dx + ey * dy > 0.0) return false;
+        } else {
+            const double tc = -num / den;
+            if (den > 0.0) t0 = tc > t0 ? tc : t0;
+            else t1 = tc < t1 ? tc : t1;
+        }
+    }
+    if (!(t0 < t1)) return false;
+    a = t0; b = t1;
+    return true;
+}
+
+void build_lane_boundary(int E, t2d_pool::HostGeo& g) {
+    const int P = g.env_off[E];
+    g.bnd_off.assign((size_t)P + 1, 0);
+    g.bnd.clear();
+    std::vector<std::pair<double, double>> iv;
+    for (int e = 0; e < E; ++e) {
+        const int l0 = g.env_off[e], l1 = g.env_off[e + 1];
+        for (int li = l0; li < l1; ++li) {
+            const int v0 = g.vert_off[li], n = g.vert_off[li + 1] - v0;
+            double L[2 * T2D_MAX_POLY_VERTS];
+            for (int k = 0; k < 2 * n; ++k) L[k] = (double)g.xy[2 * (size_t)v0 + k];   // already CCW (prepare_polys)
+            for (int j = 0; j < n; ++j) {
+                const double* q0 = L + 2 * j;
+                const double* q1 = L + 2 * ((j + 1) % n);
+                const double dx = q1[0] - q0[0], dy = q1[1] - q0[1];
+                if (dx == 0.0 && dy == 0.0) continue;
+                iv.clear();
+                for (int mi = l0; mi < l1; ++mi) {
+                    if (mi == li) continue;
+                    const int w0 = g.vert_off[mi], m = g.vert_off[mi + 1] - w0;
+                    double M[2 * T2D_MAX_POLY_VERTS];
+                    for (int k = 0; k < 2 * m; ++k) M[k] = (double)g.xy[2 * (size_t)w0 + k];
+                    double a, b;
+                    if (edge_covered_by(q0, q1, M, m, a, b)) iv.emplace_back(a, b);
+                }
+                std::stable_sort(iv.begin(), iv.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+                double r = 0.0;
+                for (size_t k = 0; k <= iv.size(); ++k) {
+                    const double a = k < iv.size() ? iv[k].first : 1.0;
+                    const bool gap = k < iv.size() ? a > r + kLaneTau : r < 1.0 - kLaneTau;
+                    if (gap) {
+                        g.bnd.push_back(r == 0.0 ? q0[0] : q0[0] + r * dx);
+                        g.bnd.push_back(r == 0.0 ? q0[1] : q0[1] + r * dy);
+                        g.bnd.push_back(a == 1.0 ? q1[0] : q0[0] + a * dx);
+                        g.bnd.push_back(a == 1.0 ? q1[1] : q0[1] + a * dy);
+                    }
+                    if (k < iv.size() && iv[k].second > r) r = iv[k].second;
+                }
+            }
+            g.bnd_off[(size_t)li + 1] = (int32_t)(g.bnd.size() / 4);
+        }
+    }
+}
+
 int log2_pad(int A) {  // lanes per env = 2^l >= A, at least 2: the second lane of a one-agent env evaluates the Arrival IoU
     int l = 1;        // while the first evaluates the NoAction IoU (one SIMT pass instead of two calls in a row)
     while ((1 << l) < A) ++l;
@@ -123,13 +198,16 @@ int log2_pad(int A) {  // lanes per env = 2^l >= A, at least 2: the second lane 
 }
 
 // dword offsets of one workgroup's record: env polygon ranges, polygon vertex ranges, AABBs, vertices (static, lanes)
-void fill_layout(t2d::GeoLayout& gl, int epb, const int mp[2], const int mv[2]) {
+void fill_layout(t2d::GeoLayout& gl, int epb, const int mp[2], const int mv[2], int mb = 0) {
     int off = 0;
     for (int k = 0; k < 2; ++k) { gl.off_pstart[k] = off; off += epb + 1; }
     for (int k = 0; k < 2; ++k) { gl.off_vstart[k] = off; off += mp[k] + 1; }
+    gl.off_bstart = off; off += mp[1] + 1;
     off = (off + 3) & ~3;  // 16-B align the float4 AABBs
     for (int k = 0; k < 2; ++k) { gl.off_aabb[k] = off; off += 4 * mp[k]; }
     for (int k = 0; k < 2; ++k) { gl.off_xy[k] = off; off += 2 * mv[k]; }  // even -> 8-B aligned
+    off = (off + 3) & ~3;  // 16-B align the fp64 boundary pieces
+    gl.off_bnd = off; off += 8 * mb;
     gl.stride = (off + 3) & ~3;
     gl.epb = epb;
 }
@@ -149,9 +227,10 @@ int rebuild_geo(t2d_pool* p) {
         return rc;
     }
     int epb = epb_max;
-    int mp[2], mv[2];
+    int mp[2], mv[2], mb;
     for (;; epb >>= 1) {
         const int nb = (E + epb - 1) / epb;
+        mb = 0;
         for (int k = 0; k < 2; ++k) {
             mp[k] = mv[k] = 0;
             const auto& g = p->hgeo[k];
@@ -161,9 +240,10 @@ int rebuild_geo(t2d_pool* p) {
                 const int p0 = g.env_off[e0], p1 = g.env_off[e1];
                 mp[k] = std::max(mp[k], p1 - p0);
                 mv[k] = std::max(mv[k], g.vert_off[p1] - g.vert_off[p0]);
+                if (k == 1) mb = std::max(mb, g.bnd_off[p1] - g.bnd_off[p0]);
             }
         }
-        fill_layout(gl, epb, mp, mv);
+        fill_layout(gl, epb, mp, mv, mb);
         if (gl.stride <= kBudgetDwords) break;
         if ((epb << log2A) <= 64 || epb == 1)
             return fail(p, T2D_ERR_GEOMETRY, "static + lane geometry of one workgroup exceeds the 32 KiB LDS record");
@@ -188,6 +268,12 @@ int rebuild_geo(t2d_pool* p) {
             float* xy = reinterpret_cast<float*>(r) + gl.off_xy[k];
             memcpy(bb, g.aabb.data() + 4 * (size_t)pb, sizeof(float) * 4 * np);
             memcpy(xy, g.xy.data() + 2 * (size_t)vb, sizeof(float) * 2 * vstart[np]);
+            if (k == 1) {   // boundary pieces of the lane unions, grouped by lane polygon
+                int32_t* bstart = reinterpret_cast<int32_t*>(r) + gl.off_bstart;
+                const int bb0 = g.bnd_off[pb];
+                for (int q = 0; q <= np; ++q) bstart[q] = g.bnd_off[pb + q] - bb0;
+                memcpy(r + gl.off_bnd, g.bnd.data() + 4 * (size_t)bb0, sizeof(double) * 4 * bstart[np]);
+            }
         }
     }
     int rc = dev_replace(p, &p->d_geo, rec.data(), rec.size());
@@ -572,6 +658,7 @@ int t2d_set_lane_geometry(t2d_pool* p, const int32_t* env_lane_offsets,
             return fail(p, T2D_ERR_INVALID, "lane CSR arrays missing");
         if ((rc = prepare_polys(p, env_lane_offsets, lane_vert_offsets, verts_xy, p->hgeo[1])) != T2D_OK)
             return rc;
+        build_lane_boundary(E, p->hgeo[1]);
     } else {
         p->hgeo[1] = t2d_pool::HostGeo{};
     }
@@ -1087,6 +1174,19 @@ int t2d_debug_read(t2d_pool* p, unsigned long long* out, size_t n_words) {
     return T2D_OK;
 }
 #endif
+
+// introspection (not part of the ABI of include/t2d.h): resident workgroups per CU of the fused step kernel for this
+// pool's geometry, and its LDS bytes per workgroup -- the regression guard of tests/test_gpu_api.py
+int t2d_debug_step_occupancy(t2d_pool* p, int32_t* blocks_per_cu, int64_t* lds_bytes) {
+    if (!p || !blocks_per_cu || !lds_bytes) return T2D_ERR_INVALID;
+    T2D_HIP(p, hipSetDevice(p->device));
+    int b = 0;
+    size_t l = 0;
+    T2D_HIP(p, t2d::step_occupancy(p->v, &b, &l));
+    *blocks_per_cu = b;
+    *lds_bytes = (int64_t)l;
+    return T2D_OK;
+}
 
 int t2d_get_field(t2d_pool* p, int32_t f, void** dev_ptr, size_t* nbytes) {
     if (!p) return T2D_ERR_INVALID;

@@ -53,9 +53,10 @@ namespace {
 #endif
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
-constexpr int kQueueCap = 320;  // queue entries per wave per round (also holds the broad phase's 3 x 96 staging floats)
+constexpr int kQueueCap = 288;  // queue entries per wave per round (also holds the broad phase's 3 x 96 staging floats)
 constexpr int kMaxHeads = 512;  // EPB * H when the hash grid is in use (A_pad = 128 or 256)
 constexpr double kRejectMargin = 1e-6;
+constexpr int kLaneShift = 8;   // s_flags bits 8.. hold the off-lane evidence of process_lane
 
 T2D_DEV double orient(double px, double py, double qx, double qy, double rx, double ry) {
     double a = qx - px, b = ry - py;
@@ -212,6 +213,59 @@ __device__ __noinline__ bool circle_vs_generic(double cx, double cy, double R, c
     return hit;
 }
 
+// ---- off-lane = not union(lanes).contains(pose): boundary pieces of the union vs the pose --------------------------
+// oracle t2do_piece_meets_quad_interior: the piece A -> B misses the open CCW quad P when some edge of P has A and B
+// on its outer side or on it, or all four vertices of P lie on one closed side of the line AB
+T2D_DEV bool piece_meets_quad_interior(const Quad& P, double ax, double ay, double bx, double by) {
+    bool sep = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = (i + 1) & 3;
+        sep |= (orient(P.x[i], P.y[i], P.x[k], P.y[k], ax, ay) <= 0.0) & (orient(P.x[i], P.y[i], P.x[k], P.y[k], bx, by) <= 0.0);
+    }
+    bool all_ge = true, all_le = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double o = orient(ax, ay, bx, by, P.x[k], P.y[k]);
+        all_ge &= o >= 0.0;
+        all_le &= o <= 0.0;
+    }
+    return !(sep | all_ge | all_le);
+}
+
+// pieces [b0, b1) of the lane union's boundary (fp64 Ax, Ay, Bx, By in LDS) against the open quad P.  The box test only
+// skips pieces at least 1e-6 m clear of P's bounding box: those are separated by an edge normal of P or of the piece by
+// >= 0.7e-6 m, far beyond the rounding of the orientation signs, so skipping them cannot change a verdict.
+T2D_DEV bool pieces_meet_quad(const Quad& P, const double* bnd, int b0, int b1) {
+    double lox = P.x[0], hix = P.x[0], loy = P.y[0], hiy = P.y[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        lox = __builtin_fmin(lox, P.x[k]); hix = __builtin_fmax(hix, P.x[k]);
+        loy = __builtin_fmin(loy, P.y[k]); hiy = __builtin_fmax(hiy, P.y[k]);
+    }
+    lox -= 1e-6; loy -= 1e-6; hix += 1e-6; hiy += 1e-6;
+    bool hit = false;
+    for (int b = b0; b < b1; ++b) {
+        const double2 A = reinterpret_cast<const double2*>(bnd)[2 * b], B = reinterpret_cast<const double2*>(bnd)[2 * b + 1];
+        const bool near = !(__builtin_fmax(A.x, B.x) < lox || __builtin_fmin(A.x, B.x) > hix ||
+                            __builtin_fmax(A.y, B.y) < loy || __builtin_fmin(A.y, B.y) > hiy);
+        if (__ballot(near) != 0ull) {
+            if (near) hit |= piece_meets_quad_interior(P, A.x, A.y, B.x, B.y);
+        }
+    }
+    return hit;
+}
+
+// circle pose (pedestrian): bit 0 = centre in the lane polygon, bit 1 = a boundary piece inside the open disc
+__device__ __noinline__ uint32_t circle_lane_bits(double cx, double cy, double R, const PolyRef B, const double* bnd,
+                                                  int b0, int b1) {
+    uint32_t bits = point_in_generic(B, cx, cy) ? 1u : 0u;
+    const double R2 = R * R;
+    for (int b = b0; b < b1; ++b)
+        if (seg_dist2(bnd[4 * b], bnd[4 * b + 1], bnd[4 * b + 2], bnd[4 * b + 3], cx, cy) < R2) bits |= 2u;
+    return bits;
+}
+
 // ---- IoU of two convex quads (Arrival / NoAction), oracle t2do_quad_iou: the boundary of A n B is
 // integrated directly -- every edge of A clipped to closed B, every edge of B clipped to A with
 // coincident (parallel, on-the-line) pieces dropped -- and the 8 partial sums are combined in a
@@ -358,15 +412,17 @@ template <bool WITH_STATUS, int FUSE>
 __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv, t2d_status_config cfg,
                                                                             int interval_ms, int log2A) {
     __shared__ double s_v[8][kBlock];   // OBB vertex coordinate planes x0,y0,...,x3,y3
-    __shared__ double s_c[3][kBlock];   // centre x, centre y, radius (circle) / bounding radius (OBB)
+    __shared__ float s_cxy[2][kBlock];  // centre x, centre y (the stored fp32 state: exact)
+    __shared__ double s_rad[kBlock];    // radius (circle) / bounding radius (OBB)
     // type table in LDS, [column][type]: all columns up to the bounding radius when fused, else only
     // the 4 shape columns (length, width, shape, bounding radius)
     constexpr int kTabCols = T2D_P_RESERVED0 + 1;
     __shared__ double s_partab[FUSE >= 0 ? kTabCols * T2D_MAX_TYPES : 4 * T2D_MAX_TYPES];
-    __shared__ int s_kind[kBlock];      // T2D_SHAPE_* or -1 = inactive
-    __shared__ uint32_t s_flags[kBlock];   // event bits, OR-ed by the narrow phase
-    __shared__ uint32_t s_inside[kBlock];  // bit k: pose vertex k lies in some lane polygon
-    __shared__ uint32_t s_env_or[kBlock];
+    __shared__ signed char s_kind[kBlock];  // T2D_SHAPE_* or -1 = inactive
+    // event bits OR-ed by the narrow phases (T2D_FLAG_*), and above them (<< kLaneShift) the off-lane evidence of
+    // process_lane.  LDS is what decides 4 resident workgroups per CU for the metric scenes: keep this compact.
+    __shared__ uint32_t s_flags[kBlock];
+    __shared__ uint32_t s_env_or[kBlock / 2];  // per env of the workgroup (an env has at least 2 lanes)
     __shared__ uint32_t s_queue[kWaves][kQueueCap];
     __shared__ int s_qcount[kWaves];
     // the spatial-hash lists (envs wider than a wave only) live in the queue storage: they are dead
@@ -487,9 +543,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         }
         if (use_hash_grid)
             for (int k = tid; k < EPB * H; k += nthreads) s_head[k] = -1;
-        s_env_or[tid] = 0;
+        if (tid < kBlock / 2) s_env_or[tid] = 0;
         s_flags[tid] = 0;
-        s_inside[tid] = 0;
         if (FUSE < 0) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -586,20 +641,20 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                 lo_x = ax[k] < lo_x ? ax[k] : lo_x; hi_x = ax[k] > hi_x ? ax[k] : hi_x;
                 lo_y = ay[k] < lo_y ? ay[k] : lo_y; hi_y = ay[k] > hi_y ? ay[k] : hi_y;
             }
-            s_c[2][tid] = R;
+            s_rad[tid] = R;
             // OutBound.update: not boundary.contains(pose); touching from inside is contained
             if (has_boundary)
                 out = lo_x < (double)bxmin || hi_x > (double)bxmax || lo_y < (double)bymin || hi_y > (double)bymax;
         } else {
             lo_x = cx - rad; hi_x = cx + rad; lo_y = cy - rad; hi_y = cy + rad;
-            s_c[2][tid] = rad;
+            s_rad[tid] = rad;
             if (has_boundary)
                 out = cx - rad < (double)bxmin || cx + rad > (double)bxmax || cy - rad < (double)bymin ||
                       cy + rad > (double)bymax;
         }
         if (out) f_own |= T2D_FLAG_OUT_BOUND;
-        s_c[0][tid] = cx;
-        s_c[1][tid] = cy;
+        s_cxy[0][tid] = fx;
+        s_cxy[1][tid] = fy;
         // fp32 box rounded outwards (relative 2^-23 + 1e-6 m): conservative for the AABB passes
         box_lo_x = (float)lo_x; box_lo_x -= __builtin_fabsf(box_lo_x) * 1.2e-7f + 1e-6f;
         box_hi_x = (float)hi_x; box_hi_x += __builtin_fabsf(box_hi_x) * 1.2e-7f + 1e-6f;
@@ -627,12 +682,12 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         if (ki == T2D_SHAPE_OBB && kj == T2D_SHAPE_OBB) {
             hit = sat_quads(load_obb_lds(&s_v[0][i]), load_obb_lds(&s_v[0][j]));
         } else if (ki == T2D_SHAPE_OBB) {   // circle j against box i
-            hit = circle_vs_generic(s_c[0][j], s_c[1][j], s_c[2][j], PolyRef{nullptr, &s_v[0][i], 4});
+            hit = circle_vs_generic((double)s_cxy[0][j], (double)s_cxy[1][j], s_rad[j], PolyRef{nullptr, &s_v[0][i], 4});
         } else if (kj == T2D_SHAPE_OBB) {   // circle i against box j
-            hit = circle_vs_generic(s_c[0][i], s_c[1][i], s_c[2][i], PolyRef{nullptr, &s_v[0][j], 4});
+            hit = circle_vs_generic((double)s_cxy[0][i], (double)s_cxy[1][i], s_rad[i], PolyRef{nullptr, &s_v[0][j], 4});
         } else {                            // circle - circle (oracle: c1 = i, c2 = j)
-            const double dx = s_c[0][i] - s_c[0][j], dy = s_c[1][i] - s_c[1][j];
-            const double rr = s_c[2][i] + s_c[2][j];
+            const double dx = (double)s_cxy[0][i] - (double)s_cxy[0][j], dy = (double)s_cxy[1][i] - (double)s_cxy[1][j];
+            const double rr = s_rad[i] + s_rad[j];
             hit = dx * dx + dy * dy <= rr * rr;
         }
         if (hit) {
@@ -651,11 +706,15 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             if (n <= 4) hit = sat_quads(load_obb_lds(&s_v[0][i]), load_quad_f32(xy + 2 * v0, n));
             else hit = sat_generic(PolyRef{nullptr, &s_v[0][i], 4}, PolyRef{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n});
         } else {
-            hit = circle_vs_generic(s_c[0][i], s_c[1][i], s_c[2][i],
+            hit = circle_vs_generic((double)s_cxy[0][i], (double)s_cxy[1][i], s_rad[i],
                                     PolyRef{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n});
         }
         if (hit) atomicOr(&s_flags[i], T2D_FLAG_COLLISION_STATIC);
     };
+    // off-lane = not union(lanes).contains(pose) (oracle box_in_lane_union / circle_in_lane_union), evidence collected in
+    // s_flags >> kLaneShift.  Stage 1, per (participant, lane polygon) candidate: bits 0-3 = pose vertex k lies in this
+    // polygon, bit 4 = all four do (contained outright: the polygon is convex).  Circles are finished here: bit 5 =
+    // the centre lies in this polygon, bit 6 = a boundary piece of the union reaches inside the open disc.
     auto process_lane = [&](uint32_t e) {
         const int i = (int)(e & 255u), p = (int)(e >> 8);
         const int* vstart = geo_i + gl.off_vstart[1];
@@ -673,15 +732,38 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                 for (int k = 0; k < 4; ++k)
                     bits |= (uint32_t)point_in_generic(B, s_v[2 * k][i], s_v[2 * k + 1][i]) << k;
             }
+            if (bits == 15u) bits |= 16u;
         } else {
-            bits = point_in_generic(PolyRef{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n}, s_c[0][i], s_c[1][i]);
+            const int* bstart = geo_i + gl.off_bstart;
+            bits = circle_lane_bits((double)s_cxy[0][i], (double)s_cxy[1][i], s_rad[i],
+                                    PolyRef{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n},
+                                    reinterpret_cast<const double*>(s_geo + gl.off_bnd), bstart[p], bstart[p + 1]) << 5;
         }
-        if (bits) atomicOr(&s_inside[i], bits);
+        if (bits) atomicOr(&s_flags[i], bits << kLaneShift);
+    };
+    // Stage 2, only for boxes with every vertex in some lane but no single lane holding all four (bodies straddling
+    // lanes: a few per wave), again per (participant, lane polygon) candidate: bit 5 = the centre lies in this polygon,
+    // bit 6 = one of the union's boundary pieces that are part of this polygon's edges reaches inside the open pose.
+    auto process_lane_slow = [&](uint32_t e) {
+        const int i = (int)(e & 255u), p = (int)(e >> 8);
+        const int* vstart = geo_i + gl.off_vstart[1];
+        const int* bstart = geo_i + gl.off_bstart;
+        const float* xy = reinterpret_cast<const float*>(s_geo + gl.off_xy[1]);
+        const int v0 = vstart[p], n = vstart[p + 1] - v0;
+        const int b0 = bstart[p], b1 = bstart[p + 1];
+        const Quad A = load_obb_lds(&s_v[0][i]);
+        const double cx = (double)s_cxy[0][i], cy = (double)s_cxy[1][i];
+        bool centre;
+        if (n <= 4) centre = point_in_quad(load_quad_f32(xy + 2 * v0, n), cx, cy);
+        else centre = point_in_generic(PolyRef{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n}, cx, cy);
+        uint32_t bits = centre ? 32u : 0u;
+        if (pieces_meet_quad(A, reinterpret_cast<const double*>(s_geo + gl.off_bnd), b0, b1)) bits |= 64u;
+        if (bits) atomicOr(&s_flags[i], bits << kLaneShift);
     };
     int n_lane_polys = 0;
     // Odd waves visit the polygon stages before the pair stage: the four waves of a SIMD start together
     // and would otherwise sit in the same latency-bound (LDS compaction) or issue-bound (narrow phase)
-    // stretch at the same time.  The stages are independent (results are OR-ed into s_flags / s_inside).
+    // stretch at the same time.  The stages are independent (results are OR-ed into s_flags).
     const bool polys_first = log2A <= 6 && ((tid >> 6) & 1);
     for (int stage_it = 0; stage_it < 2; ++stage_it) {
     if ((stage_it == 0) != polys_first) {
@@ -763,17 +845,17 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     } else {
         // spatial-hash walk; pairs go straight to the narrow phase (i < j de-duplicates)
         if (active) {
-            const double cx = s_c[0][tid], cy = s_c[1][tid];
+            const double cx = (double)s_cxy[0][tid], cy = (double)s_cxy[1][tid];
             for (int oy_ = -1; oy_ <= 1; ++oy_)
                 for (int ox_ = -1; ox_ <= 1; ++ox_) {
                     const int b = env_local * H + (int)(cell_hash(gcx + ox_, gcy + oy_) & (uint32_t)(H - 1));
                     for (int j = s_head[b]; j >= 0; j = s_next[j]) {
                         if (j <= tid) continue;
-                        const int jx = (int)__builtin_floor(s_c[0][j] * pv.inv_cell);
-                        const int jy = (int)__builtin_floor(s_c[1][j] * pv.inv_cell);
+                        const int jx = (int)__builtin_floor((double)s_cxy[0][j] * pv.inv_cell);
+                        const int jy = (int)__builtin_floor((double)s_cxy[1][j] * pv.inv_cell);
                         if (jx != gcx + ox_ || jy != gcy + oy_) continue;  // hash alias of another cell
-                        const double dx = cx - s_c[0][j], dy = cy - s_c[1][j];
-                        const double rr = s_c[2][tid] + s_c[2][j] + kRejectMargin;
+                        const double dx = cx - (double)s_cxy[0][j], dy = cy - (double)s_cxy[1][j];
+                        const double rr = s_rad[tid] + s_rad[j] + kRejectMargin;
                         if (dx * dx + dy * dy > rr * rr) continue;  // cannot touch
                         process_pair((uint32_t)tid | ((uint32_t)j << 8));
                     }
@@ -818,12 +900,14 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             }
             return (unsigned long long)hw[0] | ((unsigned long long)hw[1] << 32);
         };
+        unsigned long long m_first = 0ull;   // lanes: candidates of the first 64 polygons, kept for stage 2
         if (log2A == 6) {
             const int np = p1 - p0;  // wave-uniform
             for (int c0 = 0; c0 < np; c0 += 64) {
                 const int cn = np - c0 < 64 ? np - c0 : 64;
                 unsigned long long m = box_sweep(p0 + c0, cn);
                 if (!active) m = 0ull;
+                if (kd == 1 && c0 == 0) m_first = m;
                 T2D_MARK(5 + 2 * kd);
                 if (kd == 0) compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_static, cn <= 32);
                 else compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_lane, cn <= 32);
@@ -835,10 +919,26 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                 if (__ballot(left > 0) == 0ull) break;
                 const int cn = left < 64 ? left : 64;
                 const unsigned long long m = cn > 0 ? box_sweep(p0 + c0, cn) : 0ull;
+                if (kd == 1 && c0 == 0) m_first = m;
                 T2D_MARK(5 + 2 * kd);
                 if (kd == 0) compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_static);
                 else compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_lane);
                 T2D_MARK(6 + 2 * kd);
+            }
+        }
+        if (kd == 1) {
+            // stage 2 of the off-lane test (every stage-1 entry of this wave's participants was processed by this wave,
+            // and compact_and_process ends on a wave_sync: s_flags[tid] is complete as far as stage 1 goes)
+            const uint32_t ev = s_flags[tid] >> kLaneShift;
+            const bool slow = active && kind == T2D_SHAPE_OBB && (ev & 31u) == 15u;
+            if (__ballot(slow) != 0ull) {
+                for (int c0 = 0;; c0 += 64) {
+                    const int left = slow ? p1 - p0 - c0 : 0;
+                    if (__ballot(left > 0) == 0ull) break;
+                    const int cn = left < 64 ? left : 64;
+                    const unsigned long long m = cn <= 0 ? 0ull : (c0 == 0 ? m_first : box_sweep(p0 + c0, cn));
+                    compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_lane_slow);
+                }
             }
         }
     }
@@ -847,14 +947,17 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     }
     // ---------------- phase 3: reduce + status epilogue ------------------------------------
     T2D_MARK(9);
-    if (log2A <= 6) wave_sync(); else __syncthreads();  // (c) every queue drained: s_flags / s_inside complete
+    if (log2A <= 6) wave_sync(); else __syncthreads();  // (c) every queue drained: s_flags complete
     T2D_MARK(10);
     uint32_t f = 0;
     if (active) {
-        f = f_own | s_flags[tid];
-        if (n_lane_polys > 0) {  // build-defined off-lane: some pose vertex (circle: the centre) in no lane
-            const uint32_t all = kind == T2D_SHAPE_OBB ? 15u : 1u;
-            if ((s_inside[tid] & all) != all) f |= T2D_FLAG_OFF_LANE;
+        const uint32_t sf = s_flags[tid];
+        f = f_own | (sf & ((1u << kLaneShift) - 1u));
+        if (n_lane_polys > 0) {  // build-defined off-lane: not union(lanes).contains(pose)
+            const uint32_t b = sf >> kLaneShift;   // see process_lane / process_lane_slow
+            const bool in = kind == T2D_SHAPE_OBB ? (b & 16u) || ((b & 15u) == 15u && (b & 32u) && !(b & 64u))
+                                                  : (b & 32u) && !(b & 64u);
+            if (!in) f |= T2D_FLAG_OFF_LANE;
         }
     }
     if (valid) pv.flags[idx] = f;
@@ -952,8 +1055,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                     rd = rd + iou_reward;
                     if (has_iou) pv.max_iou[env] = mi > iou ? mi : iou;
                     if (pv.target_c) {
-                        const double dx = s_c[0][ego] - pv.target_c[2 * (size_t)env];
-                        const double dy = s_c[1][ego] - pv.target_c[2 * (size_t)env + 1];
+                        const double dx = (double)s_cxy[0][ego] - pv.target_c[2 * (size_t)env];
+                        const double dy = (double)s_cxy[1][ego] - pv.target_c[2 * (size_t)env + 1];
                         const double d = __builtin_sqrt(dx * dx + dy * dy);
                         const double md = pv.min_dist[env];
                         if (d < md) {
@@ -1008,6 +1111,20 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
 }
 
 }  // namespace
+
+// resident workgroups per CU of the fused step kernel with this pool's geometry record (the metric scenes are sized
+// for 4: one wave-round of 1024 workgroups on 256 CUs) and the LDS bytes per workgroup
+hipError_t step_occupancy(const PoolView& v, int* blocks_per_cu, size_t* lds_bytes) {
+    int log2A = 1;
+    while ((1 << log2A) < v.A) ++log2A;
+    const int block = v.geo_layout.epb << log2A;
+    const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
+    hipFuncAttributes fa{};
+    hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&collide_kernel<true, 1>));
+    if (e != hipSuccess) return e;
+    *lds_bytes = fa.sharedSizeBytes + dyn;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, collide_kernel<true, 1>, block, dyn);
+}
 
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
                           int interval_ms, int fuse_variant, hipStream_t s) {

@@ -27,13 +27,17 @@ namespace t2d {
 //   vstart[k][MP_k+1]  first vertex of each polygon inside the record (int)
 //   aabb[k][MP_k]      xmin, xmax, ymin, ymax (fp32, exact: vertices are fp32)
 //   xy[k][MV_k]        CCW vertices x, y (fp32)
-// MP_k / MV_k = largest polygon / vertex count of any workgroup; stride is a multiple of 4
+//   bstart[MP_1+1]     lanes only: first boundary piece of each lane polygon inside the record (int)
+//   bnd[MB][4]         lanes only: boundary pieces of the union of the env's lanes, fp64 Ax, Ay, Bx, By (16-B aligned),
+//                      grouped by the lane polygon whose edge they are part of (off-lane = not union.contains(pose))
+// MP_k / MV_k / MB = largest polygon / vertex / piece count of any workgroup; stride is a multiple of 4
 // dwords so records are copied to LDS with 16-B loads.
 struct GeoLayout {
     int32_t stride;          // dwords per record (0 when there is no geometry)
     int32_t epb;             // environments per collide workgroup
     int32_t has[2];
     int32_t off_pstart[2], off_vstart[2], off_aabb[2], off_xy[2];  // dword offsets
+    int32_t off_bstart, off_bnd;                                   // lanes: boundary pieces of the union (dword offsets)
 };
 
 // What kernels receive by value.
@@ -146,6 +150,9 @@ struct t2d_pool {
         bool present = false;
         std::vector<int32_t> env_off, vert_off;
         std::vector<float> xy, aabb;
+        // lanes only: boundary pieces of the union of each env's lanes, CSR per lane polygon (build_lane_boundary)
+        std::vector<int32_t> bnd_off;
+        std::vector<double> bnd;
     } hgeo[2];
     double *d_target_xy = nullptr, *d_target_c = nullptr, *d_last_pose = nullptr, *d_max_iou = nullptr,
            *d_min_dist = nullptr, *d_snap_min_dist = nullptr;
@@ -191,6 +198,7 @@ namespace t2d {
 hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hipStream_t s);
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
                           int interval_ms, int fuse_variant, hipStream_t s);
+hipError_t step_occupancy(const PoolView& v, int* blocks_per_cu, size_t* lds_bytes);
 hipError_t launch_lidar(const PoolView& v, const LidarView& lv, float* out, hipStream_t s);
 hipError_t launch_drift(const PoolView& v, int interval_ms, hipStream_t s);
 hipError_t launch_verify(const PoolView& v, const float* x, const float* y, const float* heading, const float* speed,

@@ -268,6 +268,12 @@ class ParticipantPool:
     def sync(self):
         self._ck(self._lib.t2d_sync(self._h))
 
+    def step_occupancy(self):
+        """(resident workgroups per CU, LDS bytes per workgroup) of the fused step kernel with this pool's geometry."""
+        b, l = C.c_int32(), C.c_int64()
+        self._ck(self._lib.t2d_debug_step_occupancy(self._h, C.byref(b), C.byref(l)))
+        return b.value, l.value
+
     # ---------------------------------------------------------------- profiling
     def profile_enable(self, on=True):
         self._ck(self._lib.t2d_profile_enable(self._h, int(bool(on))))

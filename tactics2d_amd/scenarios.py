@@ -220,7 +220,9 @@ def _roundabout_env(rng, A, rows_by_name):
     arm_len = 26.0 + ((A - n_ring + 3) // 4) * 7.5 + 6.0
     lanes = []
     for k in range(nseg):                                          # annulus as 12 convex trapezoids
-        a0, a1 = TWO_PI * k / nseg, TWO_PI * (k + 1) / nseg
+        # the last trapezoid closes on the first one's vertices exactly (sin(2 pi) is not 0 in floating point, and a
+        # 3e-15 m sliver between two lanes is a real gap of the union for `contains`)
+        a0, a1 = TWO_PI * k / nseg, TWO_PI * ((k + 1) % nseg) / nseg
         lanes.append(np.float32([[r_in * np.cos(a0), r_in * np.sin(a0)], [r_out * np.cos(a0), r_out * np.sin(a0)],
                                  [r_out * np.cos(a1), r_out * np.sin(a1)], [r_in * np.cos(a1), r_in * np.sin(a1)]]))
     for ax_, ay_ in ((1, 0), (-1, 0), (0, 1), (0, -1)):            # 4 arms

@@ -67,8 +67,53 @@ S = [
     scene("box pokes out of lane", [(0, 0.125, 0, 0)], [8], lanes=[[[-5, -1], [5, -1], [5, 1], [-5, 1]]]),
     scene("box straddles two adjacent lanes", [(0, 1, 0, 0)], [0],
           lanes=[[[-5, -1], [5, -1], [5, 1], [-5, 1]], [[-5, 1], [5, 1], [5, 3], [-5, 3]]]),
-    scene("pedestrian centre on lane edge", [(0, 1, 0, 2)], [0], lanes=[[[-5, -1], [5, -1], [5, 1], [-5, 1]]]),
+    scene("pedestrian centre on the lane's outer edge: half the disc is outside", [(0, 1, 0, 2)], [8],
+          lanes=[[[-5, -1], [5, -1], [5, 1], [-5, 1]]]),
     scene("pedestrian centre off lane", [(0, 1.125, 0, 2)], [8], lanes=[[[-5, -1], [5, -1], [5, 1], [-5, 1]]]),
+    scene("pedestrian disc touches the lane edge from inside: contained", [(0, 0.5, 0, 2)], [0],
+          lanes=[[[-5, -1], [5, -1], [5, 1], [-5, 1]]]),
+    scene("pedestrian disc pokes out by 1/8", [(0, 0.625, 0, 2)], [8], lanes=[[[-5, -1], [5, -1], [5, 1], [-5, 1]]]),
+    scene("pedestrian centre on the shared edge of two lanes", [(0, 1, 0, 2)], [0],
+          lanes=[[[-5, -1], [5, -1], [5, 1], [-5, 1]], [[-5, 1], [5, 1], [5, 3], [-5, 3]]]),
+    scene("pedestrian over a gap of 1/8 between two lanes", [(0.0625, 0, 0, 2)], [8],
+          lanes=[[[-5, -1], [0, -1], [0, 1], [-5, 1]], [[0.125, -1], [5, -1], [5, 1], [0.125, 1]]]),
+    # ---- off-lane = not union(lanes).contains(pose): the edge half.  Crossing roads as diamonds
+    # |x - y| <= 2 and |x + y| <= 2 (exact coordinates), reflex corners of the union at (+-2, 0), (0, +-2).
+    scene("all four vertices in lanes, right edge cuts the corner of two crossing roads", [(2, 0, 0, 1)], [8],
+          lanes=[[[-9, -11], [11, 9], [9, 11], [-11, -9]], [[-11, 9], [9, -11], [11, -9], [-9, 11]]]),
+    scene("edge passes exactly through the reflex corner of the union: contained", [(1, 0, 0, 1)], [0],
+          lanes=[[[-9, -11], [11, 9], [9, 11], [-11, -9]], [[-11, 9], [9, -11], [11, -9], [-9, 11]]]),
+    scene("inside the crossing of the two roads", [(0, 0, 0, 1)], [0],
+          lanes=[[[-9, -11], [11, 9], [9, 11], [-11, -9]], [[-11, 9], [9, -11], [11, -9], [-9, 11]]]),
+    scene("body edge runs along the outer boundary across two abutting lanes (edge on edge)", [(0, 0, 0, 0)], [0],
+          lanes=[[[-5, -1], [0, -1], [0, 1], [-5, 1]], [[0, -1], [5, -1], [5, 1], [0, 1]]]),
+    scene("gap of 1/8 between two lanes, all vertices in lanes", [(0, 0, 0, 0)], [8],
+          lanes=[[[-5, -1], [0, -1], [0, 1], [-5, 1]], [[0.125, -1], [5, -1], [5, 1], [0.125, 1]]]),
+    scene("chain of three lanes covers the long edges", [(0, 0, 0, 0)], [0],
+          lanes=[[[-6, -1], [-1, -1], [-1, 1], [-6, 1]], [[-1, -1], [1, -1], [1, 1], [-1, 1]],
+                 [[1, -1], [6, -1], [6, 1], [1, 1]]]),
+    scene("chain with the middle lane missing", [(0, 0, 0, 0)], [8],
+          lanes=[[[-6, -1], [-1, -1], [-1, 1], [-6, 1]], [[1, -1], [6, -1], [6, 1], [1, 1]]]),
+    scene("middle lane covers only the lower half: upper long edge leaves the union", [(0, 0, 0, 0)], [8],
+          lanes=[[[-6, -1], [-1, -1], [-1, 1], [-6, 1]], [[-1, -1], [1, -1], [1, 0], [-1, 0]],
+                 [[1, -1], [6, -1], [6, 1], [1, 1]]]),
+    scene("overlapping lanes", [(0, 0, 0, 0)], [0],
+          lanes=[[[-6, -1], [0.5, -1], [0.5, 1], [-6, 1]], [[-0.5, -1], [6, -1], [6, 1], [-0.5, 1]]]),
+    scene("nested lanes: body crosses the inner lane's boundary inside the outer lane", [(0, 0, 0, 0)], [0],
+          lanes=[[[-6, -3], [6, -3], [6, 3], [-6, 3]], [[-1, -1], [1, -1], [1, 1], [-1, 1]]]),
+    scene("vertex on the shared corner of four lanes", [(2, 1, 0, 0)], [0],
+          lanes=[[[-4, -4], [0, -4], [0, 0], [-4, 0]], [[0, -4], [4, -4], [4, 0], [0, 0]],
+                 [[0, 0], [4, 0], [4, 4], [0, 4]], [[-4, 0], [0, 0], [0, 4], [-4, 4]]]),
+    scene("frame of four lanes: the hole of the union lies inside the body", [(2, 2, 0, 0)], [8],
+          lanes=[[[0, 0], [4, 0], [4, 1], [0, 1]], [[0, 1], [1, 1], [1, 4], [0, 4]],
+                 [[3, 1], [4, 1], [4, 4], [3, 4]], [[0, 3], [4, 3], [4, 4], [0, 4]]]),
+    scene("body exactly fills the gap between two lanes (vertices on both, interior outside)", [(0, 0, 0, 0)], [8],
+          lanes=[[[-5, -3], [5, -3], [5, -1], [-5, -1]], [[-5, 1], [5, 1], [5, 3], [-5, 3]]]),
+    scene("body is exactly the hole of a frame of four lanes", [(2, 2, 0, 1)], [8],
+          lanes=[[[0, 0], [4, 0], [4, 1], [0, 1]], [[0, 1], [1, 1], [1, 3], [0, 3]],
+                 [[3, 1], [4, 1], [4, 3], [3, 3]], [[0, 3], [4, 3], [4, 4], [0, 4]]]),
+    scene("pentagon lane + triangle lane sharing an edge (clockwise triangle)", [(0, 0, 0, 1)], [0],
+          lanes=[[[-3, -2], [0, -2], [0, 2], [-3, 2], [-4, 0]], [[0, -2], [0, 2], [4, 0]]]),
     scene("everything at once", [(0, 0, 0, 0), (3, 0.5, 0, 0), (30, 0, 0, 2)], [1 | 2, 1 | 8, 4 | 8],
           static=[[[-3, -3], [-1, -3], [-1, -0.5], [-3, -0.5]]], lanes=[[[-6, -1], [6, -1], [6, 1], [-6, 1]]],
           boundary=[-20, 20, -20, 20]),

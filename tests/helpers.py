@@ -179,6 +179,73 @@ def random_scene(rng, n_env, A, extent=(60.0, 20.0), n_static=6, n_lanes=0, with
                 static=static, lanes=lanes, boundary=boundary, boundary_valid=bvalid)
 
 
+def structured_lanes(rng, kind):
+    """Lane sets whose polygons ABUT exactly (shared fp32 vertices) or overlap: a straight multi-lane road in an
+    arbitrary direction, a polygonal ring of trapezoids with an arm, crossing roads with corner fillets, a frame of
+    four strips around a hole.  The union's boundary pieces (off-lane = not union.contains(pose)) matter here."""
+    if kind == 0:
+        th = rng.uniform(0, np.pi); n_l = int(rng.integers(2, 5)); w = 3.75
+        c, s = np.cos(th), np.sin(th)
+        rails = [np.float32([[-40 * c - o * s, -40 * s + o * c], [40 * c - o * s, 40 * s + o * c]])
+                 for o in (np.arange(n_l + 1) - n_l / 2) * w]
+        return [np.float32([rails[k][0], rails[k][1], rails[k + 1][1], rails[k + 1][0]]) for k in range(n_l)]
+    if kind == 1:
+        nseg = int(rng.integers(6, 13)); r_in, r_out = 12.0, 20.0
+        ang = TWO_PI * (np.arange(nseg + 1) % nseg) / nseg
+        ri = np.float32(np.stack([r_in * np.cos(ang), r_in * np.sin(ang)], 1))
+        ro = np.float32(np.stack([r_out * np.cos(ang), r_out * np.sin(ang)], 1))
+        lanes = [np.float32([ri[k], ro[k], ro[k + 1], ri[k + 1]]) for k in range(nseg)]
+        lanes.append(np.float32([[19, -3.75], [45, -3.75], [45, 3.75], [19, 3.75]]))
+        return lanes
+    if kind == 2:
+        half = 30.0
+        lanes = [np.float32([[-half, -3.75], [half, -3.75], [half, 3.75], [-half, 3.75]]),
+                 np.float32([[-3.75, -half], [3.75, -half], [3.75, half], [-3.75, half]])]
+        for sx in (-1, 1):
+            for sy in (-1, 1):
+                lanes.append(np.float32([[sx * 3.75, sy * 3.75], [sx * 7.75, sy * 3.75], [sx * 3.75, sy * 7.75]]))
+        return lanes
+    g = rng.uniform(0.3, 3.0); t = rng.uniform(0.5, 3.0); o = g + t
+    return [np.float32([[-o, -o], [o, -o], [o, -g], [-o, -g]]), np.float32([[-o, g], [o, g], [o, o], [-o, o]]),
+            np.float32([[-o, -g], [-g, -g], [-g, g], [-o, g]]), np.float32([[g, -g], [o, -g], [o, g], [g, g]])]
+
+
+def structured_lane_scene(rng, n_env, A, with_peds=True):
+    """Participants scattered over structured lane unions (one family per env), random headings."""
+    rows = shape_rows(with_peds)
+    per, X, Y = [], [], []
+    for e in range(n_env):
+        kind = e % 4
+        per.append(structured_lanes(rng, kind))
+        ext = (9.0, 21.0, 9.0, 4.0)[kind]
+        X.append(rng.uniform(-ext, ext, A)); Y.append(rng.uniform(-ext, ext, A))
+    N = n_env * A
+    return dict(rows=rows, n_env=n_env, A=A, x=np.concatenate(X).astype(np.float32), y=np.concatenate(Y).astype(np.float32),
+                heading=rng.uniform(0, TWO_PI, N).astype(np.float32), type_id=rng.integers(0, len(rows), N).astype(np.uint8),
+                active=np.ones(N, np.uint8), static=None, lanes=to_csr(per), boundary=None, boundary_valid=None)
+
+
+def count_vertices_in_but_not_contained(O, sc, flags, envs=None):
+    """Box participants flagged off-lane although each of their four vertices lies in some lane polygon -- the
+    case a vertex-only rule misses (body cutting a corner of the union, a hole or gap under the body)."""
+    eo, vo, xy = sc["lanes"]
+    A = sc["A"]
+    n = 0
+    for e in (range(sc["n_env"]) if envs is None else envs):
+        polys = []
+        for p in range(eo[e], eo[e + 1]):
+            P = np.float64(xy[vo[p]:vo[p + 1]])
+            a2 = sum(P[i, 0] * P[(i + 1) % len(P), 1] - P[(i + 1) % len(P), 0] * P[i, 1] for i in range(len(P)))
+            polys.append(np.ascontiguousarray(P if a2 > 0 else P[::-1]))
+        for i in range(e * A, (e + 1) * A):
+            r = sc["rows"][sc["type_id"][i]]
+            if r[18] != 0 or not sc["active"][i] or not (flags[i] & 8):
+                continue
+            pose = O.pose_obb(sc["x"][i], sc["y"][i], sc["heading"][i], r[19], r[20])
+            n += all(any(O.point_in_convex(P, v) for P in polys) for v in pose)
+    return n
+
+
 def gpu_collide(sc):
     from tactics2d_amd import layout as L
     from tactics2d_amd.pool import ParticipantPool

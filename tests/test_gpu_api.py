@@ -189,3 +189,18 @@ def test_idm_verify_and_drift_argument_checks():
         p.set_param_table(drift[None])
     assert "SingleTrackDrift" in str(e.value)
     p.close()
+
+
+def test_metric_scene_keeps_four_workgroups_per_cu():
+    """The 4096 x 64 metric launch is exactly one wave-round: 1024 workgroups of 4 waves on 256 CUs need 4 resident
+    workgroups per CU, and LDS (static tables + the workgroup's geometry record incl. the lane-union boundary pieces)
+    is what decides it -- a record that grows past the budget silently doubles the step time."""
+    from tactics2d_amd import scenarios as S
+    from tactics2d_amd.pool import ParticipantPool
+    sc = S.mixed(96, 64, seed=3)
+    pool = ParticipantPool(sc.n_env, sc.A)
+    sc.load(pool)
+    blocks, lds = pool.step_occupancy()
+    pool.close()
+    print(f"step kernel: {blocks} workgroups / CU, {lds} B of LDS per workgroup")
+    assert blocks >= 4, (blocks, lds)

@@ -36,6 +36,24 @@ def test_flags_bit_exact(oracle, n_env, A, extent, kw):
         assert 0.005 < frac[1] < 0.99
 
 
+@pytest.mark.parametrize("n_env,A", [(64, 64), (96, 32), (40, 8), (6, 150)])
+def test_off_lane_is_contains_on_structured_lane_unions(oracle, n_env, A):
+    """Off-lane = not union(lanes).contains(pose): abutting lanes (shared vertices), rings, crossing roads with fillets,
+    frames with a hole -- bit-exact against the oracle, with bodies that have all four vertices in lanes and still
+    leave the union (the half a vertex-only rule misses) present in numbers."""
+    rng = np.random.default_rng(5 * n_env + A)
+    sc = H.structured_lane_scene(rng, n_env, A)
+    want_f, want_e = H.oracle_collide(oracle, sc)
+    got_f, got_e = H.gpu_collide(sc)
+    bad = np.nonzero(got_f != want_f)[0]
+    assert bad.size == 0, f"{bad.size} participants differ, first {bad[:8]}: got {got_f[bad[:8]]} want {want_f[bad[:8]]}"
+    assert (got_e == want_e).all()
+    rate = (want_f & 8).astype(bool).mean()
+    n_edge = H.count_vertices_in_but_not_contained(oracle, sc, want_f)
+    print(f"E={n_env} A={A}: off-lane rate {rate:.3f}, vertices-in-but-not-contained {n_edge}")
+    assert 0.1 < rate < 0.9 and n_edge >= (10 if n_env * A > 1000 else 1)
+
+
 def test_geometry_kats(oracle):
     """Hand-built touching / nesting / near-miss cases (tests/golden/geometry_kats.json)."""
     kats = H.load_json("geometry_kats.json")

@@ -132,6 +132,14 @@ def test_full_size_config(oracle, name):
         assert rates[1] > 0.001, rates
     if sc.lanes is not None:
         assert rates[3] > 0.005
+        # off-lane is `not union(lanes).contains(pose)`: among the sampled envs there must be bodies with all four
+        # vertices in lanes that are off-lane all the same (corner of the crossing cut, gap under the body)
+        scd = dict(rows=sc.rows, n_env=E, A=A, x=big["state"][0], y=big["state"][1], heading=big["state"][2],
+                   type_id=sc.type_id, active=sc.active, lanes=sc.lanes)
+        n_edge = H.count_vertices_in_but_not_contained(oracle, scd, big["flags"], envs=[int(e) for e in envs])
+        print(f"{name}: vertices-in-but-not-contained among {len(envs)} sampled envs: {n_edge}")
+        if name in ("cfg4", "cfg5", "metric"):
+            assert n_edge > 0
     print(f"{name}: E={E} A={A} flag rates dyn/static/out/lane = {np.round(rates, 4)}; "
           f"status counts = {dict(zip(*np.unique(big['status'][:, 0], return_counts=True)))}")
 

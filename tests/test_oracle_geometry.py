@@ -221,3 +221,132 @@ def test_intersects_against_exact_rational_arithmetic(oracle):
         B = B + n * k * np.spacing(100.0)
         check(A, B)
     assert n_checked > 3000 and n_touch == 600
+
+
+# ------------------------------------------------------------------ off-lane = not union(lanes).contains(pose)
+def _exact_pose_in_union(pose, lanes):
+    """P subset of the closed union U of convex polygons, in EXACT rational arithmetic and by a route that shares
+    nothing with the oracle's (which walks the boundary of U): subtract every lane from P by cutting along its edge
+    lines -- what is cut off outside an edge line stays, what is left inside all of them is discarded -- and P is
+    contained iff no piece of positive area survives (P is the closure of its interior, U is closed)."""
+    from fractions import Fraction as Fr
+
+    def F(P):
+        return [(Fr(float(x)), Fr(float(y))) for x, y in P]
+
+    def area2(P):
+        return sum(P[i][0] * P[(i + 1) % len(P)][1] - P[(i + 1) % len(P)][0] * P[i][1] for i in range(len(P)))
+
+    def cut(P, a, b):
+        """split the convex polygon P by the directed line a -> b: (left-or-on part, strictly-right part)"""
+        def side(p):
+            return (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0])
+        left, right = [], []
+        n = len(P)
+        for i in range(n):
+            p, q = P[i], P[(i + 1) % n]
+            sp, sq = side(p), side(q)
+            if sp >= 0:
+                left.append(p)
+            if sp <= 0:
+                right.append(p)
+            if (sp > 0 and sq < 0) or (sp < 0 and sq > 0):
+                t = sp / (sp - sq)
+                x = (p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1]))
+                left.append(x); right.append(x)
+        return left, right
+
+    pieces = [F(pose)]
+    for L in lanes:
+        L = F(np.float32(L))
+        if area2(L) < 0:
+            L = L[::-1]
+        nxt = []
+        for piece in pieces:
+            rest = piece
+            for j in range(len(L)):
+                if len(rest) < 3:
+                    break
+                rest, out = cut(rest, L[j], L[(j + 1) % len(L)])
+                if len(out) >= 3 and area2(out) > 0:
+                    nxt.append(out)
+        pieces = nxt
+    return not pieces
+
+
+def _strip(cx, cy, th, length, width):
+    c, s = np.cos(th), np.sin(th)
+    loc = np.array([[length / 2, -width / 2], [length / 2, width / 2], [-length / 2, width / 2], [-length / 2, -width / 2]])
+    return np.float32(loc @ np.array([[c, s], [-s, c]]) + [cx, cy])
+
+
+def test_contains_against_exact_rational_arithmetic(oracle):
+    """Pins the oracle's `union(lanes).contains(box)` (centre in the union + no boundary piece of the union inside the
+    open box) against exact rational arithmetic on the same binary64 inputs, three families: random overlapping strips
+    (crossing roads, corners cut with all four vertices in lanes, partial overlaps), lanes that abut exactly (shared
+    fp32 vertices: straight multi-lane roads and polygonal rings, bodies straddling the shared edges), and frames with
+    a hole."""
+    rng = np.random.default_rng(77)
+    stats = dict(n=0, inside=0, cut_corner=0)
+
+    def check(lanes, x, y, h, L_, W_):
+        x, y, h = float(np.float32(x)), float(np.float32(y)), float(np.float32(h))
+        pose = oracle.pose_obb(x, y, h, L_, W_, trig=0)
+        got = oracle.pose_in_lane_union(pose, (x, y), lanes)
+        want = _exact_pose_in_union(pose, lanes)
+        assert got == want, (lanes, x, y, h, L_, W_, got, want)
+        stats["n"] += 1; stats["inside"] += want
+        if not want and all(any(oracle.point_in_convex(oracle.ccw(np.float64(np.float32(q))), v) for q in lanes) for v in pose):
+            stats["cut_corner"] += 1        # the case the vertex-only rule of round 1 missed
+
+    for _ in range(500):       # random strips through a common area
+        lanes = [_strip(rng.uniform(-3, 3), rng.uniform(-3, 3), rng.uniform(0, np.pi), rng.uniform(15, 40), rng.uniform(3, 8))
+                 for _ in range(int(rng.integers(1, 5)))]
+        for _ in range(4):
+            check(lanes, rng.uniform(-9, 9), rng.uniform(-9, 9), rng.uniform(0, 6.3), rng.uniform(2, 5), rng.uniform(1, 2.2))
+    for _ in range(150):       # straight road of abutting lanes (shared fp32 vertices), arbitrary direction
+        th = rng.uniform(0, np.pi); n_l = int(rng.integers(2, 5)); w = 3.75
+        c, s = np.cos(th), np.sin(th)
+        rails = [np.float32([[-40 * c - o * s, -40 * s + o * c], [40 * c - o * s, 40 * s + o * c]])
+                 for o in (np.arange(n_l + 1) - n_l / 2) * w]
+        lanes = [np.float32([rails[k][0], rails[k][1], rails[k + 1][1], rails[k + 1][0]]) for k in range(n_l)]
+        for _ in range(6):
+            o = rng.uniform(-n_l * w / 2 - 1, n_l * w / 2 + 1); a = rng.uniform(-30, 30)
+            check(lanes, a * c - o * s, a * s + o * c, th + rng.normal(0, 0.2), rng.uniform(3, 5), rng.uniform(1.5, 2.0))
+    for _ in range(100):       # polygonal ring of trapezoids sharing their radial edges + one arm
+        nseg = int(rng.integers(6, 14)); r_in, r_out = 12.0, 20.0
+        ang = 2 * np.pi * np.arange(nseg + 1) / nseg
+        ri = np.float32(np.stack([r_in * np.cos(ang), r_in * np.sin(ang)], 1)); ro = np.float32(np.stack([r_out * np.cos(ang), r_out * np.sin(ang)], 1))
+        ri[-1], ro[-1] = ri[0], ro[0]
+        lanes = [np.float32([ri[k], ro[k], ro[k + 1], ri[k + 1]]) for k in range(nseg)]
+        lanes.append(np.float32([[19, -3.75], [45, -3.75], [45, 3.75], [19, 3.75]]))
+        for _ in range(6):
+            a = rng.uniform(0, 6.3); rr = rng.uniform(11, 22)
+            check(lanes, rr * np.cos(a), rr * np.sin(a), a + np.pi / 2 + rng.normal(0, 0.3), rng.uniform(3, 5), rng.uniform(1.5, 2.0))
+    for _ in range(100):       # frames: four strips around a hole that may fit inside a body
+        g = rng.uniform(0.3, 3.0); t = rng.uniform(0.5, 3.0); o = g + t
+        lanes = [np.float32([[-o, -o], [o, -o], [o, -g], [-o, -g]]), np.float32([[-o, g], [o, g], [o, o], [-o, o]]),
+                 np.float32([[-o, -g], [-g, -g], [-g, g], [-o, g]]), np.float32([[g, -g], [o, -g], [o, g], [g, g]])]
+        for _ in range(4):
+            check(lanes, rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(0, 6.3), rng.uniform(1, 6), rng.uniform(1, 3))
+    assert stats["n"] > 3500 and 0.15 < stats["inside"] / stats["n"] < 0.85 and stats["cut_corner"] > 30, stats
+
+
+def test_lane_boundary_of_abutting_lanes_is_their_outline(oracle):
+    """Four 3.75 m lanes side by side: the boundary of the union is the outer rectangle -- 2 long sides and 2 x 4
+    end caps -- and none of the three shared lane lines; crossing roads keep only the outline of the cross."""
+    ys = [-7.5, -3.75, 0.0, 3.75, 7.5]
+    lanes = [np.float32([[-210, ys[k]], [210, ys[k]], [210, ys[k + 1]], [-210, ys[k + 1]]]) for k in range(4)]
+    pieces, owner = oracle.lane_boundary(lanes)
+    assert len(pieces) == 10
+    horiz = pieces[pieces[:, 1] == pieces[:, 3]]
+    assert sorted(set(horiz[:, 1].tolist())) == [-7.5, 7.5]
+    assert np.isclose(np.abs(pieces[:, 2:] - pieces[:, :2]).sum(), 2 * 420 + 2 * 15)
+    cross = [np.float32([[-60, -3.75], [60, -3.75], [60, 3.75], [-60, 3.75]]),
+             np.float32([[-3.75, -60], [3.75, -60], [3.75, 60], [-3.75, 60]])]
+    pieces, owner = oracle.lane_boundary(cross)
+    assert len(pieces) == 12 and np.isclose(np.abs(pieces[:, 2:] - pieces[:, :2]).sum(), 8 * 56.25 + 4 * 7.5)
+    # overlapping duplicates of one polygon: the outline once from each copy's point of view is covered by the other
+    dup = [np.float32([[0, 0], [4, 0], [4, 2], [0, 2]])] * 2
+    pieces, _ = oracle.lane_boundary(dup)
+    assert len(pieces) == 8       # collinear same-direction edges do not cover each other: both outlines stay
