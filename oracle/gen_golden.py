@@ -83,9 +83,32 @@ def state_out(s, pm=False):
     return [s.x, s.y, s.heading, s.speed, vx, vy]
 
 
+def conditioning(State, model, x, y, h0, v0, a0, s0, interval, o=None):
+    """The largest change of the reference's own output (x, y, wrapped heading, speed) when ONE of its inputs (heading,
+    speed, acceleration, steering angle) moves by one fp64 ulp, either way.  The deterministic trig of this build
+    differs from numpy's by <= 1 ulp per call (a few dozen calls per step), so this is the yardstick for what any
+    tolerance can mean: where the reference's explicit Euler is unstable (tyre-force branch at crawling speed) it
+    reaches O(1) and beyond."""
+    def run(hh, vv, aa, ss):
+        return state_out(model.step(State(0, x=x, y=y, heading=hh, speed=vv), aa, ss, interval)[0])
+    up = lambda z: float(np.nextafter(np.float64(z), np.inf))
+    dn = lambda z: float(np.nextafter(np.float64(z), -np.inf))
+    if o is None:
+        o = run(h0, v0, a0, s0)
+    worst = 0.0
+    for probe in ((up(h0), v0, a0, s0), (dn(h0), v0, a0, s0), (h0, up(v0), a0, s0), (h0, dn(v0), a0, s0),
+                  (h0, v0, up(a0), s0), (h0, v0, a0, up(s0)), (h0, v0, a0, dn(s0))):
+        o2 = run(*probe)
+        dh = abs(o[2] - o2[2]); dh = min(dh, abs(2 * np.pi - dh))
+        worst = max(worst, abs(o[0] - o2[0]), abs(o[1] - o2[1]), dh, abs(o[3] - o2[3]))
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="", help="comma-separated fixture names to (re)write, e.g. dyn_random.npz; "
+                    "everything is still computed, so the seeded stream stays the same")
     args = ap.parse_args()
     sys.dont_write_bytecode = True
     sys.path.insert(0, args.ref)
@@ -93,6 +116,14 @@ def main():
     from tactics2d.physics import PointMass, SingleTrackDynamics, SingleTrackKinematics
 
     os.makedirs(OUT, exist_ok=True)
+    only = set(filter(None, args.only.split(",")))
+
+    import tempfile
+    scratch = tempfile.mkdtemp(prefix="gen_golden_")
+
+    def target(name):   # where a fixture is written: its place, or a scratch directory when --only excludes it
+        return os.path.join(OUT if not only or name in only else scratch, name)
+
     rng = np.random.default_rng(20240915)
 
     # ------------------------------------------------------------------ rigs
@@ -116,11 +147,13 @@ def main():
     # ------------------------------------------------------------------ KATs
     kats = []
 
-    def kat(model_name, ctor, row, s0, action, interval, out, applied=None):
+    def kat(model_name, ctor, row, s0, action, interval, out, applied=None, sens=None):
         kats.append(dict(model=model_name, ctor=ctor, row=[float(v) for v in row],
                          state=s0, action=[float(a) for a in action], interval=interval,
                          out=[float(v) for v in out],
                          applied=None if applied is None else [float(a) for a in applied]))
+        if sens is not None:   # dynamics only: conditioning of the reference at this input (see conditioning())
+            kats[-1]["sens"] = float(sens)
 
     mk = SingleTrackKinematics(**MED, **park_ranges, interval=100)
     rk = row_from_model(mk, KIN)
@@ -140,14 +173,15 @@ def main():
                     ((0, 0, 1.0, 0.09), (3, 0.2)), ((0, 0, 1.0, 25.0), (-4, 0.05)),
                     ((5, -2, 0.5, -3.0), (-2, 0.1)), ((5, -2, 0.5, 30.0), (20.0, -0.9))]:
         s, a, d = md.step(State(0, x=s0[0], y=s0[1], heading=s0[2], speed=s0[3]), act[0], act[1])
-        kat("dynamics", "medium_car", rd, list(s0), act, 100, state_out(s), (a, d))
+        kat("dynamics", "medium_car", rd, list(s0), act, 100, state_out(s), (a, d),
+            sens=conditioning(State, md, *[float(q) for q in s0], float(act[0]), float(act[1]), 100))
     # dynamics drops the remainder sub-step: interval 9 / delta_t 5
     md9 = SingleTrackDynamics(**MED, mass=1620, mass_height=0.726, **med_ranges, interval=9,
                               delta_t=5)
     mk9 = SingleTrackKinematics(**MED, **med_ranges, interval=9, delta_t=5)
     s, a, d = md9.step(State(0, x=0, y=0, heading=0.2, speed=2.0), 3.0, 0.1)
     kat("dynamics", "medium_car_9_5", row_from_model(md9, DYN), [0, 0, 0.2, 2.0], (3.0, 0.1), 9,
-        state_out(s), (a, d))
+        state_out(s), (a, d), sens=conditioning(State, md9, 0.0, 0.0, 0.2, 2.0, 3.0, 0.1, 9))
     s, a, d = mk9.step(State(0, x=0, y=0, heading=0.2, speed=2.0), 3.0, 0.1)
     kat("kinematics", "medium_car_9_5", row_from_model(mk9, KIN), [0, 0, 0.2, 2.0], (3.0, 0.1), 9,
         state_out(s), (a, d))
@@ -168,7 +202,7 @@ def main():
         s = mp.step(State(0, x=s0[0], y=s0[1], vx=s0[2], vy=s0[3]), act)
         out = [s.x, s.y, s.heading, s.speed, s.vx, s.vy]
         kat("pointmass", repr(ctor), row_from_model(mp, PM), list(s0), act, 100, out)
-    with open(os.path.join(OUT, "physics_kats.json"), "w") as f:
+    with open(target("physics_kats.json"), "w") as f:
         json.dump(kats, f, indent=1)
 
     # ------------------------------------------------------------ kinematics random
@@ -198,7 +232,7 @@ def main():
             type_id += [tid] * n
             st_in.append(np.stack([x, y, h, v], 1)); act_in.append(np.stack([acc, steer], 1))
             tim += [[interval, dt]] * n
-    np.savez_compressed(os.path.join(OUT, "kin_random.npz"), rows=np.array(rows),
+    np.savez_compressed(target("kin_random.npz"), rows=np.array(rows),
                         type_id=np.array(type_id, np.int32), state=np.concatenate(st_in),
                         action=np.concatenate(act_in), timing=np.array(tim, np.int32),
                         out=np.array(st_out), applied=np.array(app_out))
@@ -231,17 +265,13 @@ def main():
                 st = State(0, x=float(x[i]), y=float(y[i]), heading=float(h[i]), speed=float(v[i]))
                 s, a, d = model.step(st, float(acc[i]), float(steer[i]), interval)
                 o = state_out(s)
-                # conditioning: perturb steer by one fp64 ulp (perturbs tan/atan by ~1 ulp)
-                d2 = float(np.nextafter(np.float64(steer[i]), np.inf))
-                s2, _, _ = model.step(st, float(acc[i]), d2, interval)
-                o2 = state_out(s2)
-                dh = abs(o[2] - o2[2]); dh = min(dh, abs(2 * np.pi - dh))
-                sens.append(max(abs(o[0] - o2[0]), abs(o[1] - o2[1]), dh, abs(o[3] - o2[3])))
+                sens.append(conditioning(State, model, float(x[i]), float(y[i]), float(h[i]), float(v[i]),
+                                         float(acc[i]), float(steer[i]), interval, o))
                 st_out.append(o); app_out.append([a, d])
             type_id += [tid] * n
             st_in.append(np.stack([x, y, h, v], 1)); act_in.append(np.stack([acc, steer], 1))
             tim += [[interval, dt]] * n
-    np.savez_compressed(os.path.join(OUT, "dyn_random.npz"), rows=np.array(rows),
+    np.savez_compressed(target("dyn_random.npz"), rows=np.array(rows),
                         type_id=np.array(type_id, np.int32), state=np.concatenate(st_in),
                         action=np.concatenate(act_in), timing=np.array(tim, np.int32),
                         out=np.array(st_out), applied=np.array(app_out), sens=np.array(sens))
@@ -271,7 +301,7 @@ def main():
             type_id += [tid] * n
             st_in.append(np.stack([x, y, vx, vy], 1)); act_in.append(np.stack([ax, ay], 1))
             tim += [[interval, 5]] * n
-    np.savez_compressed(os.path.join(OUT, "pm_random.npz"), rows=np.array(rows),
+    np.savez_compressed(target("pm_random.npz"), rows=np.array(rows),
                         type_id=np.array(type_id, np.int32), state=np.concatenate(st_in),
                         action=np.concatenate(act_in), timing=np.array(tim, np.int32),
                         out=np.array(st_out))
@@ -293,6 +323,11 @@ def main():
             roll[f"{tag}_{interval}_{dt}_act"] = np.array(acts, float)
             roll[f"{tag}_{interval}_{dt}_row"] = row_from_model(model, mid)
             roll[f"{tag}_{interval}_{dt}_frame"] = np.array([s.frame])
+            if tag == "dyn":   # conditioning of every step, teacher-forced from the fp32-rounded state like the tests
+                t32 = np.float64(f32(np.array(traj[:-1]))); a32 = np.float64(f32(np.array(acts, float)))
+                roll[f"{tag}_{interval}_{dt}_sens"] = np.array(
+                    [conditioning(State, model, *[float(q) for q in t32[k]], float(a32[k, 0]), float(a32[k, 1]), interval)
+                     for k in range(len(acts))])
     for k, (sr, ar, interval, dt) in enumerate([([0, 5], [0, 2], 100, 5), ([-5, 5], [-2, 2], 9, 5),
                                                 ([5, 5], [2, 2], 50, 3), (5, 2, 100, 5),
                                                 (-5, -2, 100, 5), (None, None, 100, 5)]):
@@ -308,7 +343,7 @@ def main():
         roll[f"pm_{k}_traj"] = np.array(traj); roll[f"pm_{k}_euler"] = np.array(traje)
         roll[f"pm_{k}_act"] = np.array(acts, float)
         roll[f"pm_{k}_row"] = row_from_model(mp, PM); roll[f"pm_{k}_timing"] = np.array([interval, dt])
-    np.savez_compressed(os.path.join(OUT, "rollouts.npz"), **roll)
+    np.savez_compressed(target("rollouts.npz"), **roll)
 
     # ------------------------------------------------------------ constructor normalisation
     ctor_cases = []
@@ -325,7 +360,7 @@ def main():
                                    kin=row_from_model(mk_, KIN).tolist(),
                                    dyn=row_from_model(md_, DYN).tolist(),
                                    pm=row_from_model(mp_, PM).tolist()))
-    with open(os.path.join(OUT, "ctor_rows.json"), "w") as f:
+    with open(target("ctor_rows.json"), "w") as f:
         json.dump(ctor_cases, f)
     print("golden vectors written to", os.path.normpath(OUT))
 

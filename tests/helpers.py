@@ -30,24 +30,23 @@ def state_err(got, want, cols=4):
     return e
 
 
-def dyn_is_stiff(rows, type_id, state, action, timing, vmax_stiff=1.5):
-    """A SingleTrackDynamics step is 'stiff' when some sub-step runs the tyre-force branch
-    (|v| >= 0.1) below ~1.5 m/s: explicit Euler at 5 ms is unstable there in the reference
-    itself (DESIGN.md 'Dynamics conditioning'), so 1-ulp trig differences are amplified."""
-    rows = np.asarray(rows)
-    v0 = state[:, 3].astype(np.float64)
-    a = action[:, 0].astype(np.float64)
-    r = rows[type_id]
-    flags = r[:, 10].astype(int)
-    a = np.where(flags & 4, np.clip(a, r[:, 8], r[:, 9]), a)
-    T = (timing[:, 0] // timing[:, 1]) * timing[:, 1] / 1000.0
-    v1 = v0 + a * T
-    v1 = np.where(flags & 2, np.clip(v1, r[:, 6], r[:, 7]), v1)
-    lo = np.minimum(v0, v1); hi = np.maximum(v0, v1)
-    crosses_zero = (lo <= 0) & (hi >= 0)
-    vmin_abs = np.where(crosses_zero, 0.0, np.minimum(np.abs(v0), np.abs(v1)))
-    vmax_abs = np.maximum(np.abs(v0), np.abs(v1))
-    return (vmin_abs < vmax_stiff) & (vmax_abs >= 0.1 - 1e-9)
+# Conditioning of a SingleTrackDynamics step.  Column `sens` of dyn_random.npz (oracle/gen_golden.py) is the largest
+# change of the REFERENCE's own output when one of its inputs (heading, speed, acceleration, steering angle) moves by one
+# fp64 ulp.  The deterministic trig differs from numpy's by <= 1 ulp per call, ~80 calls per step, so:
+#   * 100 x sens < 1e-6  -> the north-star tolerance (1e-5 abs after the fp32 store) is asserted as is;
+#   * sens < 1e-3        -> a conditioning-scaled bound is asserted: 1e-5 + 1000 x sens;
+#   * sens >= 1e-3       -> one ulp moves the reference's own result by a millimetre or more (its explicit Euler is
+#                           unstable in the tyre-force branch at crawling speed, DESIGN.md "Dynamics conditioning"):
+#                           reported, and covered by the bit-exact comparison with the deterministic oracle.
+SENS_STRICT = 1e-8
+SENS_CHAOTIC = 1e-3
+
+
+def dyn_tolerance(sens, tol=1e-5):
+    """per-case tolerance (np.inf where the reference is chaotic) and the mask of the strictly asserted cases"""
+    sens = np.asarray(sens, np.float64)
+    t = np.where(sens < SENS_STRICT, tol, np.where(sens < SENS_CHAOTIC, tol + 1000.0 * sens, np.inf))
+    return t, sens < SENS_STRICT
 
 
 # --------------------------------------------------------------------------- GPU drivers

@@ -65,22 +65,24 @@ def test_pointmass_within_1e5_of_reference(variant):
 
 
 @pytest.mark.parametrize("variant", ["fast", "exact"])
-def test_dynamics_within_1e5_of_reference_outside_stiff_regime(variant):
+def test_dynamics_within_1e5_of_reference_wherever_it_is_conditioned(variant):
+    """Every dyn_random case against the reference's own result, with the tolerance its conditioning allows
+    (helpers.dyn_tolerance): 1e-5 where 100 ulp-sensitivities stay under 1e-6 (5731 of 6000 cases), 1e-5 + 1000 x
+    sensitivity up to a sensitivity of 1 mm per ulp (221 more), and only the 48 cases beyond that reported."""
     d = H.load_npz("dyn_random.npz")
-    stiff = H.dyn_is_stiff(d["rows"], d["type_id"], d["state"], d["action"], d["timing"])
-    worst = np.zeros(4); worst_stiff = np.zeros(4)
+    tol, strict = H.dyn_tolerance(d["sens"], TOL)
+    err = np.zeros(len(tol))
     for iv, m in _groups(d):
         got = H.gpu_physics(d["rows"], d["type_id"][m], d["state"][m], d["action"][m], iv, variant, "dyn")
-        e = H.state_err(got, d["out"][m], cols=4)
-        s = stiff[m]
-        if (~s).any():
-            worst = np.maximum(worst, e[~s].max(0))
-        if s.any():
-            worst_stiff = np.maximum(worst_stiff, e[s].max(0))
-    print(f"dynamics {variant}: non-stiff {int((~stiff).sum())} cases max err {worst}; "
-          f"stiff {int(stiff.sum())} cases max err {worst_stiff} (reported, not asserted)")
-    assert (~stiff).sum() > 4000
-    assert worst.max() <= TOL, worst
+        err[m] = H.state_err(got, d["out"][m], cols=4).max(1)
+    chaotic = ~np.isfinite(tol)
+    print(f"dynamics {variant}: {int(strict.sum())} cases at 1e-5 (max err {err[strict].max():.3g}), "
+          f"{int((~strict & ~chaotic).sum())} at the conditioning-scaled bound (max err / bound "
+          f"{(err / tol)[~strict & ~chaotic].max():.3g}), {int(chaotic.sum())} chaotic in the reference itself "
+          f"(reported: {int((err[chaotic] > TOL).sum())} of them beyond 1e-5)")
+    assert strict.sum() > 5700 and chaotic.sum() < 60
+    assert (err[strict] <= TOL).all(), err[strict].max()
+    assert (err[~chaotic] <= tol[~chaotic]).all(), (err / tol)[~chaotic].max()
 
 
 def test_known_answers():
@@ -92,17 +94,17 @@ def test_known_answers():
         if not (np.float64(st) == np.array([k["state"]])).all():
             continue  # KAT input is not fp32-representable (e.g. speed -1e-15 is) -> skip
         row = np.array([k["row"]])
-        stiff = model == "dyn" and H.dyn_is_stiff(row, np.array([0]), st, act,
-                                                  np.array([[k["interval"], int(k["row"][17])]]))[0]
+        # dynamics KATs carry the reference's conditioning at their input (oracle/gen_golden.py: conditioning())
+        tol = H.dyn_tolerance([k["sens"]], TOL)[0][0] if model == "dyn" else TOL
         for variant in ("fast", "exact"):
             got = H.gpu_physics(row, np.array([0]), st, act, k["interval"], variant, model)
             want = np.array([k["out"]])
             cols = 4 if model == "dyn" else 6
             e = H.state_err(got, want, cols=cols)
-            if stiff:  # reference integrator unstable here: covered by the bit-exact test instead
-                print("stiff KAT", k["state"], k["action"], variant, "err vs reference", e.max(0))
+            if not np.isfinite(tol):  # one ulp of an input moves the reference's own result by > 1 mm here
+                print("chaotic KAT", k["state"], k["action"], variant, "sens", k["sens"], "err vs reference", e.max(0))
                 continue
-            assert e.max() <= TOL, (k["model"], k["ctor"], variant, got, want)
+            assert e.max() <= tol, (k["model"], k["ctor"], variant, got, want, tol)
             if k["applied"] is not None:
                 assert np.allclose(got[0, 6:8], np.float32(k["applied"]), atol=0)
 
@@ -131,9 +133,10 @@ def test_rollout_teacher_forced_and_free_running(oracle, tag):
     ref = H.oracle_physics(oracle, row[None], np.zeros(n, np.uint8), st, act, interval, model, trig=0)
     got = H.gpu_physics(row[None], np.zeros(n, np.uint8), st, act, interval, "fast", model)
     e = H.state_err(got, ref, cols=4)
-    stiff = H.dyn_is_stiff(row[None], np.zeros(n, int), st, act, np.tile([interval, int(row[17])], (n, 1))) \
-        if model == "dyn" else np.zeros(n, bool)
-    assert e[~stiff].max() <= TOL, e[~stiff].max(0)
+    # the dynamics roll-outs carry the reference's conditioning per step: every step of them is well conditioned
+    if model == "dyn":
+        assert H.dyn_tolerance(r[f"{tag}_sens"], TOL)[1].all()
+    assert e.max() <= TOL, e.max(0)
     # free running on the device, state re-rounded to fp32 every step
     pool = ParticipantPool(1, 1)
     pool.set_param_table(row[None])
@@ -145,7 +148,7 @@ def test_rollout_teacher_forced_and_free_running(oracle, tag):
     fin = np.array([pool.download(f)[0] for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED)], np.float64)
     pool.close()
     drift = np.abs(fin - traj[-1]); drift[2] = H.ang_err(fin[2], traj[-1, 2])
-    print(f"{tag}: {n} steps, teacher-forced max err {e[~stiff].max(0)}, free-running fp32 drift {drift}")
+    print(f"{tag}: {n} steps, teacher-forced max err {e.max(0)}, free-running fp32 drift {drift}")
     if model == "kin":
         assert drift.max() < 5e-3  # fp32 re-rounding over hundreds of steps; reported in DESIGN.md
 

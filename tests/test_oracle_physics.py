@@ -29,19 +29,18 @@ def test_pointmass_matches_reference(oracle):
     assert e.max() < 1e-12, e.max(0)
 
 
-def test_dynamics_matches_reference_outside_stiff_regime(oracle):
+def test_dynamics_matches_reference_wherever_it_is_conditioned(oracle):
+    """libm-mode oracle vs the reference's own fp64 results, tolerance set by the fixture's conditioning column
+    (helpers.dyn_tolerance): rounding noise where the reference is conditioned, nothing asserted only where one ulp
+    of an input moves the reference's own output by a millimetre or more."""
     d = H.load_npz("dyn_random.npz")
     out = _run(oracle, d, "dyn")
-    e = H.state_err(out, d["out"], cols=4)
-    stiff = H.dyn_is_stiff(d["rows"], d["type_id"], d["state"], d["action"], d["timing"])
-    assert (~stiff).sum() > 4000
-    assert e[~stiff].max() < 1e-12, e[~stiff].max(0)
-    # inside the stiff regime the reference itself is ill-conditioned: a 1-ulp change of its own
-    # steering input moves its output by up to O(1) (column `sens` of the fixture).  Most stiff
-    # cases still agree to 1e-9; the disagreeing ones all carry that conditioning signature.
-    bad = e.max(1) > 1e-9
-    assert not (bad & ~stiff).any()
-    assert bad.sum() < 0.02 * stiff.sum() + 10, int(bad.sum())
+    e = H.state_err(out, d["out"], cols=4).max(1)
+    sens = d["sens"]
+    chaotic = sens >= H.SENS_CHAOTIC
+    assert chaotic.sum() < 60 and (sens < 1e-12).sum() > 5000
+    # libm's and numpy's trig may differ in the last bit here and there: a few ulp-sensitivities at most
+    assert (e[~chaotic] <= 1e-12 + 10.0 * sens[~chaotic]).all(), (e / (1e-12 + 10.0 * sens))[~chaotic].max()
     assert np.isnan(out[:, 4]).all()  # vx, vy are None in the reference's dynamics State
     assert np.array_equal(out[:, 6:8], d["applied"])
 
@@ -128,9 +127,11 @@ def test_deterministic_trig_mode_agrees_with_libm_mode(oracle):
         d = H.load_npz(name)
         a = _run(oracle, d, model, 0); b = _run(oracle, d, model, 1)
         e = H.state_err(a, b, cols=cols).max(1)
-        if model == "dyn":
-            e = e[~H.dyn_is_stiff(d["rows"], d["type_id"], d["state"], d["action"], d["timing"])]
-        assert e.max() < 1e-9, (name, e.max())
+        if model == "dyn":   # a few hundred ulp-sensitivities (about 80 trig calls per step, each <= 1 ulp apart)
+            ok = d["sens"] < H.SENS_CHAOTIC
+            assert (e[ok] <= 1e-9 + 1000.0 * d["sens"][ok]).all(), (name, (e[ok] / (1e-9 + 1000.0 * d["sens"][ok])).max())
+        else:
+            assert e.max() < 1e-9, (name, e.max())
 
 
 def test_dynamics_ignores_the_remainder_substep(oracle):
