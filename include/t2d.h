@@ -42,7 +42,10 @@
  * Threading: one host thread per pool.  t2d_integrate / t2d_collide / t2d_step are
  * asynchronous on the supplied hipStream_t (passed as void*; NULL = the null stream).
  * Nothing synchronises implicitly except t2d_download / t2d_upload / t2d_reset /
- * t2d_sync / the t2d_set_* calls (which copy from host memory).
+ * t2d_sync / the t2d_set_* calls (which copy from host memory), and those wait for THIS
+ * pool's work only -- the streams it was launched on since the last such call plus its own
+ * internal streams -- never for the whole device: other pools (env groups) and a policy
+ * running on other streams keep going.
  *
  * Ownership: the pool owns every device buffer.  Host pointers passed in are read
  * during the call and never retained.  Device pointers handed out by t2d_get_field
@@ -256,7 +259,10 @@ int t2d_reset(t2d_pool* pool, const uint8_t* env_mask, const float* x, const flo
 
 /* Zero-copy actions: make the integrator read ACT0/ACT1 from caller-owned DEVICE memory (e.g. a
  * policy's output tensor, N floats each) instead of the pool's own buffers.  NULL, NULL rebinds
- * the pool's buffers.  The caller keeps the memory alive and orders its writes on the stream.  */
+ * the pool's buffers.  The caller keeps the memory alive and orders its writes on the stream;
+ * the library only ever READS it (IDM-controlled participants take their action from the pool's
+ * own ACT0/ACT1 fields, where t2d_idm_actions writes).  t2d_upload of ACT0 / ACT1 ends a binding:
+ * uploaded actions are the actions from then on.                                                */
 int t2d_bind_actions(t2d_pool* pool, const float* act0_dev, const float* act1_dev);
 
 /* Physics only: one PhysicsModelBase.step(interval_ms) for every active participant,
@@ -321,8 +327,9 @@ int t2d_lidar_scan(t2d_pool* pool, float* out_dev, void* hip_stream);
  * columns of the build-defined leader rule; ctrl_id: host array [n_env * max_agents], index of the
  * participant's parameter set or T2D_IDM_NONE (its action stays whatever the caller supplied).
  * n_ctrl = 0 uninstalls.  t2d_idm_actions = IDMController.step :59-93 for every controlled participant:
- * acceleration (np.clip-ed to [-comfortable_deceleration, max_acceleration]) -> action 0, steering 0.0 ->
- * action 1 (written into the bound action buffers when t2d_bind_actions is in effect), leader index ->
+ * acceleration (np.clip-ed to [-comfortable_deceleration, max_acceleration]) -> the pool's T2D_F_ACT0, steering
+ * 0.0 -> T2D_F_ACT1 (always the pool's own fields: memory bound with t2d_bind_actions is never written; controlled
+ * participants are integrated from the pool's fields, the others from the bound memory), leader index ->
  * T2D_F_LEADER.  The reference takes `leading_state` from its caller; here the leader is the nearest active
  * participant ahead (0 < longitudinal offset <= horizon along the own heading) inside the own corridor
  * (|lateral offset| <= lane_half_width), lowest index on ties; none -> free-flow branch.  Distance is

@@ -27,6 +27,29 @@ int fail(t2d_pool* p, int code, const std::string& msg) {
             return fail(p, T2D_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Streams the pool has launched on since it was last quiesced.  Set-up calls, up/downloads and t2d_sync wait for
+// THESE (plus the pool's own internal streams), not for the device: another pool's env group or a policy running on
+// other streams is not stalled by them (no hidden device-wide syncs).
+void touch(t2d_pool* p, hipStream_t s) {
+    for (int k = 0; k < p->n_live_streams; ++k)
+        if (p->live_streams[k] == s) return;
+    if (p->n_live_streams < t2d_pool::kMaxLiveStreams) p->live_streams[p->n_live_streams++] = s;
+    else p->live_overflow = true;   // more distinct streams than tracked: the next quiesce falls back to the device
+}
+
+hipError_t quiesce(t2d_pool* p) {
+    hipError_t e = hipSuccess;
+    if (p->live_overflow) {
+        e = hipDeviceSynchronize();
+    } else {
+        for (int k = 0; k < p->n_live_streams && e == hipSuccess; ++k) e = hipStreamSynchronize(p->live_streams[k]);
+        if (e == hipSuccess && p->scene_stream) e = hipStreamSynchronize(p->scene_stream);
+    }
+    p->n_live_streams = 0;
+    p->live_overflow = false;
+    return e;
+}
+
 size_t field_elem_bytes(int f) {
     switch (f) {
         case T2D_F_RECORD: return 8 * T2D_RECORD_RING;  // ring slots x {u32 reward bits, u32 status word} per env
@@ -546,7 +569,7 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
 int t2d_destroy(t2d_pool* p) {
     if (!p) return T2D_OK;
     (void)hipSetDevice(p->device);
-    (void)hipDeviceSynchronize();  // nothing of this pool may still be running (incl. a scene refill on its own stream)
+    (void)quiesce(p);  // nothing of this pool may still be running (incl. a scene refill on its own stream)
     for (int f = 0; f < T2D_F_COUNT; ++f)
         if (p->field_ptr[f]) (void)hipFree(p->field_ptr[f]);
     void* bufs[] = {p->d_params, p->d_geo, p->d_boundary, p->d_boundary_valid, p->d_target_xy, p->d_target_c,
@@ -615,7 +638,7 @@ int t2d_set_static_geometry(t2d_pool* p, const int32_t* env_poly_offsets,
                             const float* boundary, const uint8_t* boundary_valid) {
     if (!p) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     const int E = p->v.n_env;
     int rc;
     if (p->scene_mode) {  // host-described geometry replaces the generated scenes
@@ -649,7 +672,7 @@ int t2d_set_lane_geometry(t2d_pool* p, const int32_t* env_lane_offsets,
                           const int32_t* lane_vert_offsets, const float* verts_xy) {
     if (!p) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     const int E = p->v.n_env;
     int rc;
     if (p->scene_mode) return fail(p, T2D_ERR_STATE, "lane geometry cannot be combined with generated parking scenes");
@@ -668,7 +691,7 @@ int t2d_set_lane_geometry(t2d_pool* p, const int32_t* env_lane_offsets,
 int t2d_set_target_areas(t2d_pool* p, const float* target_xy, const float* centroid) {
     if (!p) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     const int E = p->v.n_env;
     int rc;
     if (p->scene_mode) return fail(p, T2D_ERR_STATE, "target areas belong to the generated parking scenes; "
@@ -735,7 +758,7 @@ int t2d_set_status_config(t2d_pool* p, const t2d_status_config* cfg) {
     // time-penalty term of ParkingEnv._get_reward (envs/parking.py:156-158) for every possible step count: the
     // epilogue then reads one double instead of evaluating tanh on one lane at the very end of the wave
     T2D_HIP(p, hipSetDevice(p->device));
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     std::vector<double> tp;
     if (cfg->max_step > 0 && cfg->max_step <= (1 << 24)) {
         tp.resize((size_t)cfg->max_step + 1);
@@ -756,7 +779,7 @@ int t2d_reset(t2d_pool* p, const uint8_t* env_mask, const float* x, const float*
     if (!x || !y || !heading || !speed || !type_id || !active)
         return fail(p, T2D_ERR_INVALID, "x, y, heading, speed, type_id, active are required");
     T2D_HIP(p, hipSetDevice(p->device));
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     const int E = p->v.n_env, A = p->v.A, N = p->v.N;
     std::vector<float> hx(N), hy(N), hh(N), hs(N), hvx(N), hvy(N);
     std::vector<uint32_t> hids(N), hflags(N);
@@ -835,17 +858,29 @@ int t2d_reset(t2d_pool* p, const uint8_t* env_mask, const float* x, const float*
     return T2D_OK;
 }
 
+// IDM lanes read the pool's own action fields; only while caller-owned actions are bound do the kernels need to tell
+// the two apart
+static void refresh_idm_view(t2d_pool* p) {
+    const bool bound = p->v.act0 != (const float*)p->field_ptr[T2D_F_ACT0];
+    const bool sel = p->idm_on && bound;
+    p->v.idm_ctrl = sel ? p->d_idm_ctrl : nullptr;
+    p->v.own_act0 = sel ? (const float*)p->field_ptr[T2D_F_ACT0] : nullptr;
+    p->v.own_act1 = sel ? (const float*)p->field_ptr[T2D_F_ACT1] : nullptr;
+}
+
 int t2d_bind_actions(t2d_pool* p, const float* act0_dev, const float* act1_dev) {
     if (!p) return T2D_ERR_INVALID;
     if ((act0_dev == nullptr) != (act1_dev == nullptr))
         return fail(p, T2D_ERR_INVALID, "bind both action arrays or neither");
-    p->v.act0 = act0_dev ? const_cast<float*>(act0_dev) : (float*)p->field_ptr[T2D_F_ACT0];
-    p->v.act1 = act1_dev ? const_cast<float*>(act1_dev) : (float*)p->field_ptr[T2D_F_ACT1];
+    p->v.act0 = act0_dev ? act0_dev : (const float*)p->field_ptr[T2D_F_ACT0];
+    p->v.act1 = act1_dev ? act1_dev : (const float*)p->field_ptr[T2D_F_ACT1];
+    refresh_idm_view(p);
     return T2D_OK;
 }
 
 static int drift_impl(t2d_pool* p, int interval_ms, hipStream_t s) {
     int rc;
+    touch(p, s);
     if ((rc = record_event(p, 5, s, true))) return rc;
     T2D_HIP(p, t2d::launch_drift(p->v, interval_ms, s));
     return record_event(p, 5, s, false);
@@ -853,8 +888,10 @@ static int drift_impl(t2d_pool* p, int interval_ms, hipStream_t s) {
 
 static int idm_impl(t2d_pool* p, hipStream_t s, const int32_t* forced_leader = nullptr) {
     int rc;
+    touch(p, s);
     if ((rc = record_event(p, 4, s, true))) return rc;
-    T2D_HIP(p, t2d::launch_idm(p->v, p->idm, forced_leader, s));
+    T2D_HIP(p, t2d::launch_idm(p->v, p->idm, forced_leader, (float*)p->field_ptr[T2D_F_ACT0],
+                               (float*)p->field_ptr[T2D_F_ACT1], s));
     return record_event(p, 4, s, false);
 }
 
@@ -865,6 +902,7 @@ int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     if (interval_ms <= 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be positive");
     hipStream_t s = (hipStream_t)hip_stream;
     int rc;
+    touch(p, s);
     if (p->idm_on && (rc = idm_impl(p, s))) return rc;
     if (p->has_drift && (rc = drift_impl(p, interval_ms, s))) return rc;
     if ((rc = record_event(p, 0, s, true))) return rc;
@@ -874,6 +912,7 @@ int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
 
 static int collide_impl(t2d_pool* p, bool with_status, int interval_ms, hipStream_t s, int fuse_variant = -1) {
     int rc;
+    touch(p, s);
     const int kid = fuse_variant >= 0 ? 2 : 1;
     if ((rc = record_event(p, kid, s, true))) return rc;
     T2D_HIP(p, t2d::launch_collide(p->v, p->status_cfg, with_status, interval_ms, fuse_variant, s));
@@ -965,7 +1004,7 @@ int t2d_snapshot(t2d_pool* p) {
     if (!p) return T2D_ERR_INVALID;
     if (!p->have_reset) return fail(p, T2D_ERR_STATE, "t2d_reset must precede t2d_snapshot");
     T2D_HIP(p, hipSetDevice(p->device));
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     const size_t nb = 4 * (size_t)p->v.N;
     float* src[6] = {p->v.x, p->v.y, p->v.heading, p->v.speed, p->v.vx, p->v.vy};
     for (int k = 0; k < 6; ++k) {
@@ -999,6 +1038,7 @@ int t2d_restore(t2d_pool* p, int32_t mode, void* hip_stream) {
     if (!p) return T2D_ERR_INVALID;
     if (!p->have_snapshot) return fail(p, T2D_ERR_STATE, "t2d_snapshot must precede t2d_restore");
     if (mode != 0 && mode != 1) return fail(p, T2D_ERR_INVALID, "mode must be 0 (all) or 1 (done envs)");
+    touch(p, (hipStream_t)hip_stream);
     T2D_HIP(p, t2d::launch_restore(p->v, p->d_snap, p->d_snap_ids, mode, (hipStream_t)hip_stream));
     return T2D_OK;
 }
@@ -1020,7 +1060,7 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
     if (!(type_proportion >= 0.0)) type_proportion = 0.0;
     if (type_proportion > 1.0) type_proportion = 1.0;
     T2D_HIP(p, hipSetDevice(p->device));
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     const int E = p->v.n_env;
     constexpr int K = T2D_GEN_MAX_QUADS;
     int rc;
@@ -1132,9 +1172,10 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
     {  // t2d_reset's remaining columns: wheel speeds start at zero
         for (int f : {T2D_F_OMEGA_F, T2D_F_OMEGA_R}) T2D_HIP(p, hipMemset(p->field_ptr[f], 0, nbytes));
     }
+    touch(p, nullptr);   // the two set-up launches below run on the null stream
     T2D_HIP(p, t2d::launch_parking_scenes(p->v, sv, E, 1, nullptr));
     if (ring > 0) T2D_HIP(p, t2d::launch_scene_refill(sv, E, nullptr));   // episodes 1 .. ring of every env
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     p->have_reset = true;
     p->have_snapshot = true;
     for (int k = 0; k < 6; ++k) p->v.snap[k] = p->d_snap[k];
@@ -1149,7 +1190,7 @@ int t2d_get_parking_scenes(t2d_pool* p, float* quads, int32_t* quad_id, int32_t*
     if (!p) return T2D_ERR_INVALID;
     if (!p->scene_mode) return fail(p, T2D_ERR_STATE, "t2d_parking_scenes has not been called on this pool");
     T2D_HIP(p, hipSetDevice(p->device));
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     const size_t E = (size_t)p->v.n_env;
     constexpr size_t K = T2D_GEN_MAX_QUADS;
     const t2d::SceneView& sv = p->scene;
@@ -1169,7 +1210,7 @@ int t2d_get_parking_scenes(t2d_pool* p, float* quads, int32_t* quad_id, int32_t*
 // profiling builds only (not part of the ABI): read and clear the phase cycle accumulators
 int t2d_debug_read(t2d_pool* p, unsigned long long* out, size_t n_words) {
     if (!p || !p->v.dbg) return T2D_ERR_INVALID;
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     T2D_HIP(p, hipMemcpy(out, p->v.dbg, n_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return T2D_OK;
 }
@@ -1202,7 +1243,7 @@ int t2d_download(t2d_pool* p, int32_t f, void* host_dst, size_t nbytes) {
         return fail(p, T2D_ERR_INVALID, "bad field id / size (expected " +
                                             std::to_string(f >= 0 && f < T2D_F_COUNT ? p->field_bytes[f] : 0) + " bytes)");
     T2D_HIP(p, hipSetDevice(p->device));
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     T2D_HIP(p, hipMemcpy(host_dst, p->field_ptr[f], nbytes, hipMemcpyDeviceToHost));
     return T2D_OK;
 }
@@ -1212,15 +1253,22 @@ int t2d_upload(t2d_pool* p, int32_t f, const void* host_src, size_t nbytes) {
     if (f < 0 || f >= T2D_F_COUNT || !host_src || nbytes != p->field_bytes[f])
         return fail(p, T2D_ERR_INVALID, "bad field id / size");
     T2D_HIP(p, hipSetDevice(p->device));
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     T2D_HIP(p, hipMemcpy(p->field_ptr[f], host_src, nbytes, hipMemcpyHostToDevice));
+    // actions uploaded into the pool's own fields are the actions from now on: a binding to caller-owned device memory
+    // (t2d_bind_actions) ends here, or the kernels would keep reading the caller's stale tensors
+    if (f == T2D_F_ACT0 || f == T2D_F_ACT1) {
+        p->v.act0 = (const float*)p->field_ptr[T2D_F_ACT0];
+        p->v.act1 = (const float*)p->field_ptr[T2D_F_ACT1];
+        refresh_idm_view(p);
+    }
     return T2D_OK;
 }
 
 int t2d_sync(t2d_pool* p) {
     if (!p) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     return T2D_OK;
 }
 
@@ -1231,7 +1279,7 @@ int t2d_lidar_config(t2d_pool* p, int32_t n_beams, float max_range, int32_t incl
         return fail(p, T2D_ERR_INVALID, "need 1 <= n_beams <= 4096 and max_range > 0");
     if ((beam_sin == nullptr) != (beam_cos == nullptr)) return fail(p, T2D_ERR_INVALID, "pass both beam tables or neither");
     T2D_HIP(p, hipSetDevice(p->device));
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     std::vector<double> bs(n_beams), bc(n_beams);
     for (int k = 0; k < n_beams; ++k) {
         if (beam_sin) {
@@ -1257,13 +1305,18 @@ int t2d_lidar_config(t2d_pool* p, int32_t n_beams, float max_range, int32_t incl
         }
         if ((rc = dev_replace(p, &p->d_beam_sin, pre.data(), pre.size()))) return rc;
     }
-    if (p->field_ptr[T2D_F_LIDAR]) {
-        T2D_HIP(p, hipFree(p->field_ptr[T2D_F_LIDAR]));
-        p->field_ptr[T2D_F_LIDAR] = nullptr;
+    // the scan buffer is kept when the beam count is unchanged (every VecParkingEnv.reset reconfigures the lidar): a
+    // zero-copy view a caller took with t2d_get_field stays valid until the size really changes
+    const size_t lidar_bytes = (size_t)p->v.n_env * n_beams * sizeof(float);
+    if (!p->field_ptr[T2D_F_LIDAR] || p->field_bytes[T2D_F_LIDAR] != lidar_bytes) {
+        if (p->field_ptr[T2D_F_LIDAR]) {
+            T2D_HIP(p, hipFree(p->field_ptr[T2D_F_LIDAR]));
+            p->field_ptr[T2D_F_LIDAR] = nullptr;
+        }
+        p->field_bytes[T2D_F_LIDAR] = lidar_bytes;
+        T2D_HIP(p, hipMalloc(&p->field_ptr[T2D_F_LIDAR], lidar_bytes));
     }
-    p->field_bytes[T2D_F_LIDAR] = (size_t)p->v.n_env * n_beams * sizeof(float);
-    T2D_HIP(p, hipMalloc(&p->field_ptr[T2D_F_LIDAR], p->field_bytes[T2D_F_LIDAR]));
-    T2D_HIP(p, hipMemset(p->field_ptr[T2D_F_LIDAR], 0, p->field_bytes[T2D_F_LIDAR]));
+    T2D_HIP(p, hipMemset(p->field_ptr[T2D_F_LIDAR], 0, lidar_bytes));
     p->lidar.beam_pre = p->d_beam_sin;
     p->lidar.max_range = (double)max_range;
     p->lidar.n_beams = n_beams;
@@ -1281,6 +1334,7 @@ int t2d_lidar_scan(t2d_pool* p, float* out_dev, void* hip_stream) {
     p->lidar.ego_index = p->status_cfg.ego_index;
     hipStream_t s = (hipStream_t)hip_stream;
     int rc;
+    touch(p, s);
     if ((rc = record_event(p, 3, s, true))) return rc;
     T2D_HIP(p, t2d::launch_lidar(p->v, p->lidar, out_dev ? out_dev : (float*)p->field_ptr[T2D_F_LIDAR], s));
     return record_event(p, 3, s, false);
@@ -1289,9 +1343,10 @@ int t2d_lidar_scan(t2d_pool* p, float* out_dev, void* hip_stream) {
 int t2d_set_idm(t2d_pool* p, const double* ctrl_rows, int32_t n_ctrl, int32_t row_stride, const uint8_t* ctrl_id) {
     if (!p) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     if (n_ctrl == 0) {
         p->idm_on = false;
+        refresh_idm_view(p);
         return T2D_OK;
     }
     if (!ctrl_rows || !ctrl_id || n_ctrl < 0 || n_ctrl >= T2D_IDM_NONE || row_stride < T2D_IDM_COLS)
@@ -1321,6 +1376,7 @@ int t2d_set_idm(t2d_pool* p, const double* ctrl_rows, int32_t n_ctrl, int32_t ro
     p->idm.n_ctrl = n_ctrl;
     T2D_HIP(p, hipMemset(p->field_ptr[T2D_F_LEADER], 0xff, p->field_bytes[T2D_F_LEADER]));
     p->idm_on = true;
+    refresh_idm_view(p);
     return T2D_OK;
 }
 
@@ -1339,6 +1395,7 @@ int t2d_verify_state(t2d_pool* p, const float* x_dev, const float* y_dev, const 
     if (!x_dev || !y_dev || !heading_dev || !speed_dev || !valid_dev)
         return fail(p, T2D_ERR_INVALID, "t2d_verify_state: null device array");
     if (interval_ms < 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be >= 0");
+    touch(p, (hipStream_t)hip_stream);
     T2D_HIP(p, t2d::launch_verify(p->v, x_dev, y_dev, heading_dev, speed_dev, interval_ms, valid_dev,
                                   (hipStream_t)hip_stream));
     return T2D_OK;
@@ -1367,7 +1424,7 @@ int t2d_profile_read(t2d_pool* p, int32_t kernel_id, double* total_ms, int64_t* 
     if (!p) return T2D_ERR_INVALID;
     if (!total_ms || !launches) return fail(p, T2D_ERR_INVALID, "null output");
     T2D_HIP(p, hipSetDevice(p->device));
-    T2D_HIP(p, hipDeviceSynchronize());
+    T2D_HIP(p, quiesce(p));
     double tot = 0.0;
     int64_t n = 0;
     for (int i = 0; i + 1 < p->prof_count; i += 2) {

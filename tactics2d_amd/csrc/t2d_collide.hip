@@ -221,7 +221,7 @@ T2D_DEV bool piece_meets_quad_interior(const Quad& P, double ax, double ay, doub
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int k = (i + 1) & 3;
-        sep |= (orient(P.x[i], P.y[i], P.x[k], P.y[k], ax, ay) <= 0.0) & (orient(P.x[i], P.y[i], P.x[k], P.y[k], bx, by) <= 0.0);
+        sep |= (int)(orient(P.x[i], P.y[i], P.x[k], P.y[k], ax, ay) <= 0.0) & (int)(orient(P.x[i], P.y[i], P.x[k], P.y[k], bx, by) <= 0.0);
     }
     bool all_ge = true, all_le = true;
 #pragma unroll
@@ -482,6 +482,10 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             fv = pv.speed[idx];
             fa0 = pv.act0[idx];
             fa1 = pv.act1[idx];
+            if (pv.idm_ctrl && pv.idm_ctrl[idx] != T2D_IDM_NONE) {  // IDM lane while caller actions are bound
+                fa0 = pv.own_act0[idx];
+                fa1 = pv.own_act1[idx];
+            }
         }
         if (FUSE < 0 && pv.boundary) {  // fused: fetched after the integrator (register pressure)
             const float4 b = reinterpret_cast<const float4*>(pv.boundary)[env];

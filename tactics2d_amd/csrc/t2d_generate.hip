@@ -681,7 +681,7 @@ extern "C" int t2d_generate_parking(int32_t device_id, uint64_t seed, int64_t fi
     sv.live = SceneArrays{(float*)(dev + off[0]), (int32_t*)(dev + off[1]), (int32_t*)(dev + off[2]), (double*)(dev + off[3]),
                           (float*)(dev + off[4]), (double*)(dev + off[5]), (float*)(dev + off[6]), (uint32_t*)(dev + off[7])};
     int rc = T2D_OK;
-    if (launch_parking_scenes(PoolView{}, sv, n_env, 0, nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+    if (launch_parking_scenes(PoolView{}, sv, n_env, 0, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
         rc = T2D_ERR_HIP;
     for (int k = 0; k < 8 && rc == T2D_OK; ++k)
         if (hipMemcpy(host[k], dev + off[k], sizes[k], hipMemcpyDeviceToHost) != hipSuccess) rc = T2D_ERR_HIP;

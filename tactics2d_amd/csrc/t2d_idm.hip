@@ -12,8 +12,8 @@
 // One lane per participant, EPB = 256 / A_pad whole envs per workgroup.  The env's (x, y, speed, active)
 // go through LDS once; every controlled lane sweeps its env's list with wave-uniform LDS reads (broadcast,
 // conflict free), ~12 fp64 operations per candidate, then evaluates the IDM law once.  Output: accel ->
-// act0, steer 0 -> act1 (the reference returns (steering, acceleration); the physics models take
-// (accel, steer)), leader index -> T2D_F_LEADER.  HBM: 17 B read + 12 B written per participant.
+// the pool's act0 field, steer 0 -> its act1 field (the reference returns (steering, acceleration); the physics
+// models take (accel, steer)), leader index -> T2D_F_LEADER.  HBM: 17 B read + 12 B written per participant.
 #include "t2d_math.h"
 #include "t2d_pool.h"
 
@@ -47,7 +47,10 @@ T2D_DEV double idm_law(const double* c, double v, bool has_lead, double dx, doub
     return clipd(a, -b, amax);  // np.clip :90
 }
 
-__global__ __launch_bounds__(kIdmBlock) void idm_kernel(PoolView pv, IdmView iv, const int32_t* forced, int log2A) {
+// act0_own / act1_own: the POOL's action fields (T2D_F_ACT0 / ACT1) -- never caller-owned memory bound with
+// t2d_bind_actions; while a binding is in effect the integrators take the controlled lanes' actions from there
+__global__ __launch_bounds__(kIdmBlock) void idm_kernel(PoolView pv, IdmView iv, const int32_t* forced, float* act0_own,
+                                                        float* act1_own, int log2A) {
     // (x, y) as fp64 pairs, NaN for inactive slots: every comparison of the sweep is then false for
     // them, and a participant never selects itself (its own offset is exactly 0, not > 0)
     __shared__ double2 s_xy[kIdmBlock];
@@ -110,19 +113,20 @@ __global__ __launch_bounds__(kIdmBlock) void idm_kernel(PoolView pv, IdmView iv,
             dy = s_xy[base + lead].y - y0;
             vl = (double)s_v[base + lead];
         }
-        pv.act0[idx] = (float)idm_law(c, (double)fv, lead >= 0, dx, dy, vl);
-        pv.act1[idx] = 0.0f;
+        act0_own[idx] = (float)idm_law(c, (double)fv, lead >= 0, dx, dy, vl);
+        act1_own[idx] = 0.0f;
     }
     iv.leader[idx] = lead;
 }
 
 }  // namespace
 
-hipError_t launch_idm(const PoolView& v, const IdmView& iv, const int32_t* forced_leader, hipStream_t s) {
+hipError_t launch_idm(const PoolView& v, const IdmView& iv, const int32_t* forced_leader, float* act0_own, float* act1_own,
+                      hipStream_t s) {
     int log2A = 0;
     while ((1 << log2A) < v.A) ++log2A;
     const int epb = kIdmBlock >> log2A;
-    hipLaunchKernelGGL(idm_kernel, dim3((v.n_env + epb - 1) / epb), dim3(kIdmBlock), 0, s, v, iv, forced_leader, log2A);
+    hipLaunchKernelGGL(idm_kernel, dim3((v.n_env + epb - 1) / epb), dim3(kIdmBlock), 0, s, v, iv, forced_leader, act0_own, act1_own, log2A);
     return hipGetLastError();
 }
 

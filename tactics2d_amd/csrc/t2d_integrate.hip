@@ -50,6 +50,10 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(PoolView pv, int inte
         fv = pv.speed[i];
         fa0 = pv.act0[i];
         fa1 = pv.act1[i];
+        if (pv.idm_ctrl && pv.idm_ctrl[i] != T2D_IDM_NONE) {  // IDM lane while caller actions are bound
+            fa0 = pv.own_act0[i];
+            fa1 = pv.own_act1[i];
+        }
     }
     // table staging: all three 8-B loads per thread in flight together (one exposed latency)
     static_assert(T2D_PARAM_COLS * T2D_MAX_TYPES == 3 * kBlock, "staging assumes 3 loads per thread");

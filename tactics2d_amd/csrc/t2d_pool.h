@@ -44,7 +44,12 @@ struct GeoLayout {
 struct LidarView;
 struct PoolView {
     int32_t n_env, A, N;
-    float *x, *y, *heading, *speed, *vx, *vy, *act0, *act1, *applied0, *applied1;
+    float *x, *y, *heading, *speed, *vx, *vy, *applied0, *applied1;
+    const float *act0, *act1;   // the pool's own action fields, or caller-owned device memory (t2d_bind_actions): read only
+    // IDM agents while caller actions are bound: controlled lanes (idm_ctrl[i] != T2D_IDM_NONE) take their action from the
+    // pool's own fields, where the idm kernel writes -- never into the caller's memory.  Null otherwise.
+    const uint8_t* idm_ctrl;
+    const float *own_act0, *own_act1;
     float *omega_f, *omega_r;  // SingleTrackDrift wheel speeds
     uint32_t *ids, *flags, *env_flags;
     int32_t *cnt_step, *frame_ms;
@@ -185,6 +190,11 @@ struct t2d_pool {
     bool scene_refill_pending = false;
     int32_t* d_lidar_cnt = nullptr;
     long long step_count = 0;  // t2d_step calls so far (selects the record ring slot)
+    // streams with work of this pool possibly in flight (what the set-up calls / t2d_sync wait for)
+    static constexpr int kMaxLiveStreams = 4;
+    hipStream_t live_streams[kMaxLiveStreams]{};
+    int n_live_streams = 0;
+    bool live_overflow = false;
     // profiling
     bool profiling = false;
     static constexpr int kMaxProfSteps = 4096;
@@ -203,7 +213,8 @@ hipError_t launch_lidar(const PoolView& v, const LidarView& lv, float* out, hipS
 hipError_t launch_drift(const PoolView& v, int interval_ms, hipStream_t s);
 hipError_t launch_verify(const PoolView& v, const float* x, const float* y, const float* heading, const float* speed,
                          int interval_ms, uint8_t* valid, hipStream_t s);
-hipError_t launch_idm(const PoolView& v, const IdmView& iv, const int32_t* forced_leader, hipStream_t s);
+hipError_t launch_idm(const PoolView& v, const IdmView& iv, const int32_t* forced_leader, float* act0_own, float* act1_own,
+                      hipStream_t s);
 hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
                           hipStream_t s);
 hipError_t launch_parking_scenes(const PoolView& v, const SceneView& sv, int n_env, int mode, hipStream_t s);

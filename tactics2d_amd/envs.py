@@ -103,6 +103,7 @@ class VecParkingEnv:
             m.status_checklist["collision"].reset(_csr_to_lists(sc.static))
             m.status_checklist["out_bound"].reset(sc.boundary)
             m.reset(sc.x, sc.y, sc.heading, sc.speed, sc.type_id, sc.active)
+        m.pool.bind_actions(None, None)   # a step_torch binding does not outlive the episode set-up
         m.pool.set_auto_reset(self.auto_reset)
         # SingleLineLidar(perception_range=20, freq_detect=360 * 10)  envs/parking.py:303-304,422-431
         m.pool.lidar_config(360, 20.0, include_participants=False)
@@ -127,6 +128,7 @@ class VecParkingEnv:
             raise RuntimeError("call reset() first")
         a = self._to_continuous(actions)
         m = self.scenario_manager
+        # (set_actions uploads into the pool's own action fields, which also ends a step_torch binding)
         m.step(a[:, 1], a[:, 0])  # physics_model.step(state, accel, steering)  parking.py:355
         pool = m.pool
         status = pool.download(L.F_STATUS)
@@ -139,7 +141,8 @@ class VecParkingEnv:
     def step_torch(self, actions, stream=None):
         """The device-resident step: `actions` is a float32 CUDA tensor [n_envs, 2] in the reference's layout (steering,
         accel); nothing is copied to the host and nothing synchronises.  Returns a dict of torch tensors that are
-        ZERO-COPY VIEWS of the pool (valid until the next step): state [6 x n_envs] columns, reward, status (u8 [n, 4]:
+        ZERO-COPY VIEWS of the pool (valid until the next step): state [6 x n_envs] columns (vx, vy as written by the ego's
+        SingleTrackKinematics -- a dynamics / drift ego leaves those two fields alone, include/t2d.h), reward, status (u8 [n, 4]:
         scenario, traffic, terminated, truncated), iou, and `lidar` [n_envs, 360] written by the scan kernel straight
         into a tensor owned by this env -- the observation buffer handed back to the policy.  Out-of-range actions are
         the caller's responsibility here (the numpy `step` raises InvalidAction like the reference)."""

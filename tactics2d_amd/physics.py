@@ -52,26 +52,60 @@ def _resolve_delta_t(delta_t, interval):
 
 
 class BatchedState:
-    """SoA stand-in for a batch of `State` objects (participant/trajectory/state.py:12-223).
+    """SoA stand-in for a batch of `State` objects (participant/trajectory/state.py:12-223): the same typed record, the
+    same lazily derived fields, one float32 column per field (what the pool stores) and one `frame` (ms) for the batch.
 
-    Columns are float32 numpy arrays of equal length; `frame` is an int (ms).  Derived fields
-    follow State: `velocity` = (vx, vy) when set, else (speed*cos(heading), speed*sin(heading))
-    (state.py:152-169); `speed` = ||(vx, vy)|| when only the velocity is set (state.py:135-150).
+    * typed `__setattr__` (:108-126): `frame` is coerced to int, every other annotated field to a float column (a
+      scalar fills the batch); None stays None; a value that cannot be converted raises ValueError with the
+      reference's message;
+    * `speed` (:135-150) = the scalar that was set, else ||(vx, vy)||, else None;
+    * `velocity` (:152-169) = (vx, vy) when set, else (speed cos(heading), speed sin(heading)), else None;
+    * `accel` (:171-186) = ||(ax, ay)|| when set, else the NORM of `acceleration` -- for a state that only carries the
+      scalar (what the physics models return) that is ||accel (cos h, sin h)|| = |accel| up to rounding
+      (0.9999999999999999 for accel = 1.0, heading = 0.3), not the signed scalar itself, which stays in `_accel`;
+    * `acceleration` (:188-204) = (ax, ay) when set, else (accel cos h, accel sin h), else None.
+    Derived values are fp64 arrays computed from the stored fp32 columns with the reference's expressions.
     """
 
-    def __init__(self, frame, x, y, heading=None, vx=None, vy=None, speed=None, accel=None):
-        self.frame = int(frame)
-        self.x = np.ascontiguousarray(x, np.float32)
-        self.y = np.ascontiguousarray(y, np.float32)
-        n = self.x.size
-        self.heading = np.zeros(n, np.float32) if heading is None else np.ascontiguousarray(heading, np.float32)
-        self.vx = None if vx is None else np.ascontiguousarray(vx, np.float32)
-        self.vy = None if vy is None else np.ascontiguousarray(vy, np.float32)
-        self._speed = None if speed is None else np.ascontiguousarray(speed, np.float32)
-        self.accel = None if accel is None else np.ascontiguousarray(accel, np.float32)
+    __annotations__ = {"frame": int, "x": float, "y": float, "heading": float, "vx": float, "vy": float, "_speed": float,
+                       "ax": float, "ay": float, "_accel": float}
+
+    def __init__(self, frame, x=0, y=0, heading=0, vx=None, vy=None, speed=None, ax=None, ay=None, accel=None):
+        object.__setattr__(self, "_n", max(np.size(x), np.size(y), 1))
+        self.frame = frame
+        self.x = x
+        self.y = y
+        self.heading = heading
+        self.vx = vx
+        self.vy = vy
+        self._speed = speed
+        self.ax = ax
+        self.ay = ay
+        self._accel = accel
+
+    def __setattr__(self, name, value):
+        kind = self.__annotations__.get(name)
+        if kind is None or value is None:
+            object.__setattr__(self, name, value)
+            return
+        try:
+            if kind is int:
+                value = value if isinstance(value, int) else int(value)
+            else:
+                col = np.asarray(value, dtype=np.float32)
+                if col.ndim > 1 or col.size not in (1, self._n):
+                    raise TypeError("not a column of the batch")
+                value = np.ascontiguousarray(np.broadcast_to(col.reshape(-1), (self._n,)))
+        except Exception:
+            raise ValueError(f"Failed to convert {value} to the expected type of {name}: ({kind}).") from None
+        object.__setattr__(self, name, value)
 
     def __len__(self):
-        return self.x.size
+        return self._n
+
+    def __str__(self):
+        return (f"{self.__class__.__name__}(frame={self.frame}, x={self.x}, y={self.y}, heading={self.heading}, "
+                f"vx={self.vx}, vy={self.vy}, speed={self.speed}, ax={self.ax}, ay={self.ay}, accel={self.accel})")
 
     @property
     def location(self):
@@ -82,18 +116,53 @@ class BatchedState:
         if self._speed is not None:
             return self._speed
         if self.vx is not None and self.vy is not None:
-            return np.sqrt(self.vx.astype(np.float64) ** 2 + self.vy.astype(np.float64) ** 2).astype(np.float32)
+            vx, vy = self.vx.astype(np.float64), self.vy.astype(np.float64)
+            return np.sqrt(vx * vx + vy * vy)                   # np.linalg.norm([vx, vy])
         return None
 
     @property
     def velocity(self):
         if self.vx is not None and self.vy is not None:
             return self.vx, self.vy
-        if self._speed is not None:
-            h = self.heading.astype(np.float64)
-            s = self._speed.astype(np.float64)
-            return (s * np.cos(h)).astype(np.float32), (s * np.sin(h)).astype(np.float32)
+        v = self.speed
+        if v is not None and self.heading is not None:
+            h, v = self.heading.astype(np.float64), np.asarray(v, np.float64)
+            return v * np.cos(h), v * np.sin(h)
         return None
+
+    @property
+    def acceleration(self):
+        if self.ax is not None and self.ay is not None:
+            return self.ax, self.ay
+        if self._accel is not None and self.heading is not None:
+            h, a = self.heading.astype(np.float64), self._accel.astype(np.float64)
+            return a * np.cos(h), a * np.sin(h)
+        return None
+
+    @property
+    def accel(self):
+        acc = self.acceleration
+        if acc is None:
+            return None
+        ax, ay = np.asarray(acc[0], np.float64), np.asarray(acc[1], np.float64)
+        return np.sqrt(ax * ax + ay * ay)                       # np.linalg.norm(...)
+
+    def set_heading(self, heading):
+        self.heading = heading
+
+    def set_velocity(self, vx, vy):
+        self.vx = vx
+        self.vy = vy
+
+    def set_speed(self, speed):
+        self._speed = speed
+
+    def set_accel(self, ax, ay):
+        """sets ax, ay and the scalar ||(ax, ay)|| (state.py:218-223)"""
+        self.ax = ax
+        self.ay = ay
+        a, b = self.ax.astype(np.float64), self.ay.astype(np.float64)
+        self._accel = np.sqrt(a * a + b * b)
 
 
 class _BatchedModel:

@@ -115,8 +115,9 @@ class OutBound(_FlagDetector):
 
 
 class OffLane(_FlagDetector):
-    """The reference detector is a stub that returns False (off_lane.py:16-17).  Here it becomes real
-    once lanes are supplied: a pose vertex in no lane polygon (build-defined)."""
+    """The reference detector is a stub that returns False (off_lane.py:16-17).  Here it becomes real once lanes
+    are supplied: `not union(lane polygons).contains(pose)` -- the predicate of OutBound (out_bound.py:37-48) applied
+    to the lanes (build-defined; lanes that abut must share their vertices exactly or overlap)."""
     bit = L.FLAG_OFF_LANE
 
     def __init__(self, manager=None):
@@ -238,6 +239,15 @@ class BatchedScenarioManager:
         (the reference returns a rendered camera image, scenario_manager.py:96-98: not on this path)."""
         cols = [self.pool.download(f).reshape(self.n_env, self.max_agents)[:, self.ego_index]
                 for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_VX, L.F_VY)]
+        # SingleTrackDynamics / SingleTrackDrift return a State without vx, vy (single_track_dynamics.py:220-227) and
+        # the pool's VX / VY fields are not written by those models (include/t2d.h): State.velocity then DERIVES
+        # (speed cos(heading), speed sin(heading)) (state.py:152-169) -- done here the same way, lazily
+        model = self.pool.download(L.F_IDS).reshape(self.n_env, self.max_agents)[:, self.ego_index] & 0xff
+        derived = (model == L.MODEL_DYNAMICS) | (model == L.MODEL_DRIFT)
+        if derived.any():
+            h, v = cols[2].astype(np.float64), cols[3].astype(np.float64)
+            cols[4] = np.where(derived, (v * np.cos(h)).astype(np.float32), cols[4])
+            cols[5] = np.where(derived, (v * np.sin(h)).astype(np.float32), cols[5])
         return np.stack(cols, 1)
 
     def close(self):

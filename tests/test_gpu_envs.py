@@ -109,29 +109,65 @@ def test_parking_env_reaches_completed_when_parked_on_the_target():
 
 def test_cfg1_single_parking_env_600_random_actions(oracle):
     """BASELINE.json configs[0] / the reference's own env test (tests/test_env.py:49-52: 600 samples of the action
-    space through one ParkingEnv): every step's state against the oracle, teacher-forced on the fp32 state, the
-    5-tuple contract, and a reset whenever the episode ends."""
+    space through one ParkingEnv).  EVERY step, everything the 5-tuple carries is held against the oracle chain
+    integrate -> collide -> status / reward / IoU -> 360-beam scan, teacher-forced on the env's own fp32 state:
+    state within 1e-5 (default fast integrator), event flags, status bytes, terminated / truncated, NoAction counter
+    and lidar bit for bit, reward and IoU to the last fp32 bit or two.  The env is reset whenever the episode ends."""
+    from tactics2d_amd import layout as L
     from tactics2d_amd.envs import ParkingEnv
-    env = ParkingEnv(max_step=200, seed=0)
+    from tactics2d_amd.traffic import ScenarioStatus, TrafficStatus
+    env = ParkingEnv(max_step=150, seed=0)
     obs, infos = env.reset()
     sc = env._vec._scene
+    pool = env.scenario_manager.pool
+    cfg = oracle.make_config(**{**sc.status, "max_step": 150})
+    start_xy = np.stack([sc.x[:1], sc.y[:1]], 1)
+    ep = oracle.EpisodeState(1, sc.target, None, start_xy)
+    cnt = np.zeros(1, np.int32); frame = np.zeros(1, np.int32)
     rng = np.random.default_rng(0)
     n_done = 0
+    seen = set()
+    n_hits = 0
     prev = np.array([obs[0], obs[1], obs[2], obs[3]], np.float32)
+    w0 = oracle.lidar(sc.rows, 1, 1, 0, prev[0:1], prev[1:2], prev[2:3], sc.type_id[:1], sc.active[:1], sc.static, 0, 360, 20.0)
+    assert np.array_equal(np.float32(infos["lidar"]).view(np.uint32), w0[0].view(np.uint32))
     for t in range(600):
         act = env.action_space.sample(rng)
+        if t % 7 == 3:
+            act = np.float32([act[0], 0.0]) if t % 2 else act * np.float32(0.01)   # stretches of (almost) no action
         obs, reward, terminated, truncated, infos = env.step(act)
         o = oracle.integrate(sc.rows, prev[0:1], prev[1:2], prev[2:3], prev[3:4], None, None,
                              np.float32([act[1]]), np.float32([act[0]]), sc.type_id[:1], sc.active[:1], 100)
         assert np.abs(np.asarray(obs[:4], np.float64) - o[0, :4]).max() <= 1e-5, (t, obs[:4], o[0, :4])
         assert isinstance(reward, float) and np.isfinite(reward)
-        assert infos["state"]["frame"] % 100 == 0
+        # events, status, reward, IoU and scan of the pose the env reports (fp32), by the oracle
+        x, y, h = (np.float32([obs[k]]) for k in range(3))
+        wf, _ = oracle.collide(sc.rows, 1, 1, x, y, h, sc.type_id[:1], sc.active[:1], sc.static, sc.boundary,
+                               sc.boundary_valid, None, 0)
+        assert np.array_equal(pool.download(L.F_FLAGS), wf), (t, wf)
+        wst, wrw, wiou = oracle.status_ex(cfg, 1, wf, 100, cnt, frame, sc.rows, x, y, h, sc.type_id[:1], ep)
+        assert (int(infos["scenario_status"]), int(infos["traffic_status"])) == (int(wst[0, 0]), int(wst[0, 1])), (t, wst)
+        assert isinstance(infos["scenario_status"], ScenarioStatus) and isinstance(infos["traffic_status"], TrafficStatus)
+        assert (terminated, truncated) == (bool(wst[0, 2]), bool(wst[0, 3])), (t, wst)
+        assert abs(reward - float(wrw[0])) <= 2e-6, (t, reward, wrw)
+        giou = np.float32(infos["iou"])
+        assert np.isnan(giou) == np.isnan(wiou[0]) and (np.isnan(giou) or abs(float(giou) - float(wiou[0])) <= 1e-7), (t, giou, wiou)
+        assert infos["state"]["frame"] == frame[0] and frame[0] % 100 == 0
+        assert pool.download(L.F_CNT_NO_ACTION)[0] == ep.cnt_na[0] and pool.download(L.F_CNT_STEP)[0] == cnt[0]
+        wl = oracle.lidar(sc.rows, 1, 1, 0, x, y, h, sc.type_id[:1], sc.active[:1], sc.static, 0, 360, 20.0)
+        gl = np.float32(infos["lidar"])
+        assert gl.shape == (360,) and np.array_equal(gl.view(np.uint32), wl[0].view(np.uint32)), (t, int((gl != wl[0]).sum()))
+        n_hits += int(np.isfinite(gl).sum())
+        seen.add((int(wst[0, 0]), int(wst[0, 1])))
         if terminated or truncated:
             n_done += 1
             obs, infos = env.reset()
+            cnt[:] = 0; frame[:] = 0
+            ep.reset_envs(np.ones(1, bool), start_xy)
         prev = np.array([obs[0], obs[1], obs[2], obs[3]], np.float32)
     env.close()
-    assert n_done >= 1          # time limit (200 steps) at the latest
+    print(f"cfg1: {n_done} episodes, statuses seen {sorted(seen)}, {n_hits} lidar returns")
+    assert n_done >= 3 and len(seen) >= 3 and n_hits > 20000
 
 
 def test_vec_parking_env_device_resident_step_equals_the_host_step():
@@ -157,5 +193,4 @@ def test_vec_parking_env_device_resident_step_equals_the_host_step():
         assert np.array_equal(st[:, 2].astype(bool), term) and np.array_equal(st[:, 3].astype(bool), trunc)
         assert np.array_equal(out["lidar"].cpu().numpy().view(np.uint32), infos["lidar"].view(np.uint32))
         assert np.array_equal(out["iou"].cpu().numpy(), infos["iou"], equal_nan=True)
-    assert trunc.any() or term.any() or True
     a.close(); b.close()

@@ -167,3 +167,56 @@ def test_batched_trajectory_follows_the_reference_rules(caplog):
     assert t.frames == [0] and t.get_state().frame == 0
     t.reset(s(500, 1.0))
     assert t.frames == [500]
+
+
+def test_batched_state_keeps_the_reference_state_semantics():
+    """Row a6: derived speed / velocity / accel / acceleration and the typed __setattr__ of `State`
+    (participant/trajectory/state.py:108-204) against vectors produced by the reference itself
+    (oracle/gen_golden_state.py -> tests/golden/state_kats.json)."""
+    from tactics2d_amd.physics import BatchedState
+    k = H.load_json("state_kats.json")
+    for case in k["derived"]:
+        kw = {key: [val] for key, val in case["kw"].items()}
+        s = BatchedState(0, x=[1.0], y=[2.0], **kw)
+        for name in ("speed", "velocity", "accel", "acceleration"):
+            got, want = getattr(s, name), case[name]
+            if want is None:
+                assert got is None, (case["kw"], name, got)
+                continue
+            got = np.asarray(got, np.float64).reshape(-1)
+            assert np.allclose(got, want, rtol=4e-16, atol=0), (case["kw"], name, got, want)
+    # the accel quirk: a state that only carries the scalar reports ||accel (cos h, sin h)||, not the scalar
+    q = k["quirk"]
+    s = BatchedState(0, x=[0.0], y=[0.0], heading=[np.float32(q["heading"])], accel=[q["accel_in"]])
+    assert q["accel_out"] == 0.9999999999999999 and abs(s.accel[0] - 1.0) < 3e-16 and s._accel[0] == 1.0
+    s = BatchedState(0, x=[0.0, 1.0], y=[0.0, 0.0], heading=[0.3, 2.0], accel=[-2.5, 4.0])
+    assert np.allclose(s.accel, [2.5, 4.0], rtol=3e-16)                  # |accel|: the sign is gone, as in the reference
+    # typed __setattr__: coercion, None, and the reference's ValueError text
+    s = BatchedState("12", x=[0.0, 1.0], y=3)                            # frame "12" -> 12, y scalar fills the batch
+    assert s.frame == 12 and isinstance(s.frame, int) and s.y.tolist() == [3.0, 3.0] and s.x.dtype == np.float32
+    s.frame = 7.9
+    assert s.frame == 7
+    for c in k["coerced"]:
+        if c["name"] == "frame":
+            s.frame = eval(c["value"])
+            assert s.frame == c["stored"]
+    for e in k["errors"]:
+        if not e["raised"]:
+            setattr(s, e["name"], eval(e["value"]))
+            assert getattr(s, e["name"]) is None
+            continue
+        if e["name"] == "heading":      # a list is one scalar too many for the reference, and a column here
+            continue
+        with pytest.raises(ValueError) as ei:
+            setattr(s, e["name"], eval(e["value"]))
+        assert str(ei.value) == e["message"]
+    with pytest.raises(ValueError):
+        s.vx = [1.0, 2.0, 3.0]                                              # not a column of this batch
+    # setters (state.py:206-223)
+    s2 = BatchedState(5, x=[0.0], y=[0.0], vx=[3.0], vy=[4.0])
+    s2.set_accel([1.0], [-2.0])
+    assert abs(s2.accel[0] - k["setters"]["accel_after_set_accel"]) < 1e-15 and abs(s2._accel[0] - k["setters"]["_accel"]) < 1e-6
+    s3 = BatchedState(5, x=[1.0], y=[2.0], heading=[0.5], speed=[3.0])
+    s3.set_velocity([1.0], [1.0])
+    assert [float(v[0]) for v in s3.velocity] == k["setters"]["velocity_after_set_velocity"]
+    assert float(s3.speed[0]) == k["setters"]["speed_after_set_velocity"] == 3.0
