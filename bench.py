@@ -11,10 +11,12 @@ for N > 1, the asynchronous RCCL all-gather of the 8-byte per-env result records
 (state, actions, geometry) are resident in HBM before the timed region starts.  Weak scaling:
 every rank owns --envs environments (default 4096 x 64 participants, the metric workload).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (per-kernel HIP
-event timing recorded on the launch stream inside the timed region) and `cpu_baseline` (the C
-oracle -- a port of the reference's algorithm -- timed on one host core and on all host cores,
-OpenMP over envs, on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (the step kernel
+is bound by fp64 VALU issue, not by HBM: the line gives the fraction of the VALU issue roof --
+instructions per launch from the committed rocprofv3 SQ pass over the launch duration measured here
+with HIP events -- and the HBM figure beside it), `configs` (BASELINE.json's other configurations,
+timed in the same run) and `cpu_baseline` (the C oracle -- a port of the reference's algorithm --
+timed on one host core and on all host cores, OpenMP over envs, on a bounded sample).
 """
 import argparse
 import json
@@ -32,6 +34,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+# VALU issue roof: a SIMD issues one wave64 VALU instruction (fp64 included: full rate on CDNA4) per 4 cycles;
+# 256 CUs x 4 SIMDs at the 2.4 GHz peak clock of the same guide
+VALU_ISSUE_PEAK_GINST = 256 * 4 * 2.4 / 4.0
 INTEGRATOR_BYTES = 44          # algorithmic bytes per participant-step
 COLLIDE_BYTES = 20             # + per-env geometry (computed from the scene)
 
@@ -144,6 +149,45 @@ def cpu_baseline(scene, target_seconds=10.0):
     return out
 
 
+DEFAULTS = {"metric": (4096, 64), "cfg5": (1024, 64), "cfg2": (4096, 1), "cfg3": (1024, 64), "cfg4": (512, 32)}
+GATHER_EVERY = 8
+
+
+def time_config(name, steps, warmup, dev, variant="fast"):
+    """One BASELINE.json configuration at its per-GPU size, single launch per step, device-resident actions, auto-reset
+    on: (participant-steps/s, us per step).  cfg4 / cfg5 are the per-GPU shards of the 4- / 8-GPU configurations."""
+    import torch
+    from tactics2d_amd.pool import ParticipantPool
+    n_env, agents = DEFAULTS[name]
+    scene = build_scene(name, n_env, agents, seed=0)
+    pool = ParticipantPool(scene.n_env, scene.A, dev.index)
+    scene.load(pool)
+    pool.set_integrator_variant(variant)
+    pool.set_auto_reset(True)
+    rng = np.random.default_rng(5)
+    ring = []
+    for _ in range(4):
+        a0, a1 = scene.sample_actions(rng)
+        ring.append((torch.from_numpy(a0).to(dev), torch.from_numpy(a1).to(dev)))
+    st = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+
+    def run(n):
+        for k in range(n):
+            a0, a1 = ring[k & 3]
+            pool.bind_actions(a0.data_ptr(), a1.data_ptr())
+            pool.step(scene.interval_ms, st.cuda_stream)
+    run(warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    pool.close()
+    return dict(envs=n_env, participants_per_env=agents, value=scene.n * steps / el, unit="participant-steps/s",
+                us_per_step=1e6 * el / steps, steps=steps, warmup=warmup)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +199,7 @@ def main():
     ap.add_argument("--variant", default="fast", choices=["fast", "exact"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events")
+    ap.add_argument("--no-configs", action="store_true", help="skip timing BASELINE.json's other configurations")
     ap.add_argument("--no-reset", action="store_true", help="skip the device-side auto-reset")
     ap.add_argument("--idm", action="store_true", help="non-ego vehicles driven by on-device IDM controllers (row f3); "
                     "adds the idm kernel to every step (not the metric configuration)")
@@ -168,7 +213,8 @@ def main():
 
     # (T2D_DIST_BACKEND / T2D_FORCE_DEVICE exist to exercise the N > 1 code path on a one-GPU box: gloo, every rank on
     # the same device; never set in a real run)
-    rank, local_rank, world = D.init_process_group(os.environ.get("T2D_DIST_BACKEND", "nccl"))
+    backend = os.environ.get("T2D_DIST_BACKEND", "nccl")
+    rank, local_rank, world = D.init_process_group(backend)
     if "T2D_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["T2D_FORCE_DEVICE"])
     if world != args.gpus and rank == 0:
@@ -179,9 +225,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    defaults = {"metric": (4096, 64), "cfg5": (1024, 64), "cfg2": (4096, 1), "cfg3": (1024, 64),
-                "cfg4": (512, 32)}
-    n_env, agents = defaults[args.config]
+    n_env, agents = DEFAULTS[args.config]
     n_env = args.envs or n_env
     agents = args.agents or agents
     scene = build_scene(args.config, n_env, agents, seed=rank)
@@ -218,14 +262,20 @@ def main():
     for _ in range(4):
         a0, a1 = scene.sample_actions(rng)
         ring.append((torch.from_numpy(a0).to(dev), torch.from_numpy(a1).to(dev)))
-    # N > 1: the per-env result records of 8 consecutive steps travel in one RCCL all-gather per group (rollout
-    # fragment), issued on the group's stream so that it is ordered after that group's step kernels only
-    gather_every = 8
+    # N > 1: the per-env result records of 8 consecutive steps travel in ONE all-gather per group (a rollout fragment).
+    # With RCCL (the real run) the library issues it itself -- t2d_gather: ncclAllGather reading the record ring in
+    # place, on a stream of the pool's own, ordered after the group's steps by events; torch.distributed only ships the
+    # communicator id.  Without RCCL (gloo, the one-GPU rehearsal) the same exchange goes through torch.distributed.
     gathers = []
+    native_gather = backend == "nccl" and not os.environ.get("T2D_GATHER_TORCH")
     if world > 1 or os.environ.get("T2D_FORCE_GATHER"):
         for p in eg.pools:
-            rec = torch.as_tensor(p.device_array(L.F_RECORD), device=dev).view(torch.int32)
-            gathers.append(D.ResultGather(rec, world, every=gather_every))
+            if native_gather:
+                D.NativeGather.bootstrap(p, rank, world)
+                gathers.append(D.NativeGather(p, world, every=GATHER_EVERY, device=dev))
+            else:
+                rec = torch.as_tensor(p.device_array(L.F_RECORD), device=dev).view(torch.int32)
+                gathers.append(D.ResultGather(rec, world, every=GATHER_EVERY))
     step_no = [0]
     torch.cuda.synchronize()
 
@@ -235,8 +285,11 @@ def main():
         eg.step(scene.interval_ms)
         if gathers:
             for g, s in zip(gathers, eg.streams):
-                with torch.cuda.stream(s):
-                    g.launch(step_no[0])
+                if native_gather:
+                    g.launch(step_no[0], s.cuda_stream)
+                else:
+                    with torch.cuda.stream(s):
+                        g.launch(step_no[0])
         step_no[0] += 1
 
     def drain():
@@ -277,9 +330,12 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- per-kernel pass: the same steps again with HIP events recorded on the launch streams around every
-    # kernel (event packets cost ~2 us per kernel, so they stay out of `value`) --------------------------
+    # ---- per-kernel pass (outside `value`): the same steps again with HIP events recorded on the launch streams around
+    # every kernel (the event packets cost ~2 us per kernel).  At least PROF_MIN launches per kernel whatever --steps
+    # is, and every kernel form is run PREWARM times untimed first: the two-kernel form's kernels have never run in
+    # this process before that, and a first launch (code object load, cold instruction cache) is not a launch duration.
     kern = {}
+    PREWARM, PROF_MIN = 10, 100
 
     def read_kernels(ids):
         for kid, name in ids:
@@ -290,20 +346,26 @@ def main():
             if cnt:
                 kern[name] = dict(avg_us=1e3 * tot / cnt, launches=cnt)
 
-    if not args.no_profile:
-        n_prof = min(args.steps, 2000 // G)
-        eg.configure(lambda p: p.profile_enable(True))
-        for k in range(n_prof):
+    def profiled_pass(n):
+        eg.configure(lambda p: p.profile_enable(False))
+        for k in range(PREWARM):
             one_step(k)
         drain()
         barrier()
+        eg.configure(lambda p: p.profile_enable(True))
+        for k in range(n):
+            one_step(k)
+        drain()
+        barrier()
+
+    n_prof = 0
+    if not args.no_profile:
+        n_prof = min(max(args.steps, PROF_MIN), 2000 // G)
+        profiled_pass(n_prof)
         read_kernels(((0, "integrate_kernel"), (1, "collide_kernel"), (2, "step_kernel"), (4, "idm_kernel")))
         if not args.split:   # also time the two stand-alone kernels (the integrator is north_star's roofline kernel)
-            eg.configure(lambda p: (p.set_fused_step(False), p.profile_enable(True)))
-            for k in range(min(n_prof, 200)):
-                one_step(k)
-            drain()
-            barrier()
+            eg.configure(lambda p: p.set_fused_step(False))
+            profiled_pass(min(n_prof, 200))
             read_kernels(((0, "integrate_kernel"), (1, "collide_kernel")))
             eg.configure(lambda p: p.set_fused_step(True))
         eg.configure(lambda p: p.profile_enable(False))
@@ -320,7 +382,7 @@ def main():
         eg = EnvGroups(scene, pipelined_G, device_id=local_rank)
         eg.configure(setup)
         torch.cuda.synchronize()
-        for k in range(args.warmup):
+        for k in range(max(args.warmup, 20)):
             one_step(k)
         barrier()
         evp = torch.cuda.Event(enable_timing=True)
@@ -343,6 +405,17 @@ def main():
                               f"{pipelined_G} HIP streams (tactics2d_amd/pipeline.py, t2d_step_groups): one group's start-up "
                               f"latency and tail overlap the others' busy middle and the next step of the next group; "
                               f"results identical to the single launch (tests/test_gpu_pipeline.py)")
+    eg.close()
+
+    # ---- BASELINE.json's other configurations, timed by the same process ("for each config") ----------
+    configs = None
+    if world == 1 and rank == 0 and not args.no_configs and args.config == "metric":
+        configs = {}
+        for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
+            configs[name] = time_config(name, max(args.steps, 100), max(args.warmup, 20), dev, args.variant)
+        configs["note"] = ("per-GPU sizes (cfg4 = 2048 x 32 over 4 GPUs, cfg5 = 8192 x 64 over 8 GPUs), one launch per step, "
+                           "device-resident actions, auto-reset on, >= 100 timed steps after >= 20 warm-up steps each; "
+                           "wall time of the step loop incl. the final synchronise")
 
     if rank == 0:
         value = world * N * args.steps / elapsed
@@ -375,24 +448,34 @@ def main():
             if same:   # PMC counters cannot be read from inside the process: taken from the committed rocprofv3
                 traffic = tj["hbm_bytes_per_launch"].get(dom)       # pass of the same command (scripts/profile_round.sh)
                 traffic_src = f"profiles/traffic_latest.json ({tj.get('tag')}): " + tj.get("source", "")
-            valu = None
             sq = tj.get("sq_counters_per_dispatch", {}).get(dom) if same else None
-            if sq:     # report VALU busy next to the HBM figure (the kernel is fp64-issue bound)
-                n_simd = 256 * 4
+            hbm = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                       algorithmic_bytes_per_launch=per_launch[dom], per_launch_GBs=per_launch_gbs,
+                       note="what north_star names; the kernel is not under this roof (20 fp64 Euler sub-steps per "
+                            "participant-step: ~2000 VALU instructions per wave for 48 B per lane)")
+            if sq:
+                # The roof the step kernel IS under: fp64 VALU issue.  Instructions per launch from the
+                # committed SQ pass of this very command and kernel (a property of kernel + data, like the algorithmic
+                # bytes), launch duration measured here.  SQ_ACTIVE_INST_VALU (quad-cycles) of the same pass gives the
+                # VALU-busy fraction of that (serialised, slower-clocked) profiled launch for comparison.
+                insts = float(sq["SQ_INSTS_VALU"])
+                ach_i = insts / (kern[dom]["avg_us"] * 1e-6) / 1e9
                 kcyc = sq["SQ_BUSY_CYCLES"] / 32.0          # summed over 8 XCDs x 4 SEs
-                valu = dict(busy_frac=4.0 * sq["SQ_ACTIVE_INST_VALU"] / (n_simd * kcyc),
-                            valu_insts_per_wave=sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"], kernel_cycles=kcyc,
-                            source="SQ_* counters of the committed rocprofv3 pass (profiles/traffic_latest.json; PMC passes "
-                                   "serialise the launches); SQ_ACTIVE_INST_VALU counts quad-cycles")
-            roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, valu=valu,
-                        concurrent_launches=G, launches_in_timed_region=G * args.steps, timed_region_event_span_ms=span_ms,
-                        algorithmic_bytes_per_launch=per_launch[dom], avg_kernel_us=kern[dom]["avg_us"],
-                        per_launch_GBs=per_launch_gbs,
-                        how=(f"achieved = algorithmic_bytes_per_launch x launches_in_timed_region / HIP-event span of the timed "
-                             f"region on the launch streams; {G} launch(es) of the kernel run concurrently (one per env group), "
-                             f"so this is ~ concurrent_launches x per_launch_GBs; avg_kernel_us / per_launch_GBs are per launch, "
-                             f"timed with HIP events around each kernel in a second pass of the same steps"),
+                roof = dict(bound="valu_fp64_issue", kernel=dom, achieved=ach_i, peak=VALU_ISSUE_PEAK_GINST,
+                            unit="G wave-instructions/s", frac=ach_i / VALU_ISSUE_PEAK_GINST,
+                            valu_insts_per_launch=insts, valu_insts_per_wave=insts / sq["SQ_WAVES"],
+                            valu_busy_frac_in_profiled_launch=4.0 * sq["SQ_ACTIVE_INST_VALU"] / (256 * 4 * kcyc),
+                            peak_is="256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (fp64 is full rate)",
+                            counters_source=traffic_src)
+            else:
+                roof = dict(hbm, kernel=dom)
+            roof.update(traffic=traffic, traffic_source=traffic_src, hbm=hbm, concurrent_launches=G,
+                        launches_in_timed_region=G * args.steps, timed_region_event_span_ms=span_ms,
+                        avg_kernel_us=kern[dom]["avg_us"],
+                        how=(f"avg_kernel_us: HIP events around each launch of the kernel on its launch stream, {kern[dom]['launches']} "
+                             f"launches in a second pass of the same steps after {PREWARM} untimed launches of the same form (outside "
+                             f"`value`); hbm.achieved = algorithmic bytes of all launches in the timed region / HIP-event span of "
+                             f"that region"),
                         kernels={k_: dict(avg_us=v["avg_us"], launches=v["launches"],
                                           algorithmic_bytes=per_launch[k_],
                                           achieved_GBs=per_launch[k_] / (v["avg_us"] * 1e-6) / 1e9)
@@ -401,6 +484,8 @@ def main():
             step_bytes = (INTEGRATOR_BYTES + 4) * N + geo_bytes
             pipelined["aggregate_GBs"] = step_bytes * args.steps / (pipelined["timed_region_event_span_ms"] * 1e-3) / 1e9
             pipelined["aggregate_frac_of_hbm_peak"] = pipelined["aggregate_GBs"] / HBM_PEAK_GBS
+        gather_how = ("t2d_gather: RCCL all-gather issued by the library from the record ring, on a stream of the pool's own"
+                      if native_gather else "torch.distributed all_gather_into_tensor (no RCCL on this backend)")
         out = dict(metric="participant-steps/sec (physics+collision)", value=value,
                    unit="participant-steps/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling="weak",
@@ -412,16 +497,18 @@ def main():
                                         (f", {G} env groups of {n_env // G} envs pipelined on {G} HIP streams" if G > 1 else ""),
                                config=args.config, envs_per_gpu=n_env, participants_per_env=agents, env_groups=G,
                                host_enqueue_us_per_step=host_enqueue_us,
-                               parallelism=f"env-sharded x{world}, per env group one async RCCL all-gather of the 8 B/env result records per {gather_every} steps"
+                               untimed_prewarm=f"{args.warmup} warm-up steps before the timed region; per-kernel pass: {PREWARM} untimed "
+                                               f"launches of each kernel form, then {n_prof} timed ones",
+                               parallelism=f"env-sharded x{world}, per env group one async all-gather of the 8 B/env result records per "
+                                           f"{GATHER_EVERY} steps ({gather_how})"
                                if world > 1 else "single GPU"),
-                   roofline=roof, pipelined=pipelined,
+                   roofline=roof, pipelined=pipelined, configs=configs,
                    check=dict(state_finite=finite,
                               flag_rates=[float((flags & b).astype(bool).mean()) for b in (1, 2, 4, 8)],
                               truncated_frac=float(status[:, 3].mean())))
         if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only (the other ranks would sit in the barrier)
             out["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(out))
-    eg.close()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -424,6 +424,27 @@ int t2d_set_integrator_variant(t2d_pool* pool, int32_t variant);
 int t2d_profile_enable(t2d_pool* pool, int32_t on);
 int t2d_profile_read(t2d_pool* pool, int32_t kernel_id, double* total_ms, int64_t* launches);
 
+/* ---- multi-GPU: environments shard across ranks, one process per GPU, no data-path collective.  The only
+ * exchange is an all-gather of the 8-byte per-env result records {reward bits, status word} -- RCCL over xGMI, issued
+ * from here, reading the record ring (T2D_F_RECORD) in place.
+ *   t2d_comm_unique_id  ncclGetUniqueId: rank 0 calls it and ships the 128 bytes to the other ranks by whatever the
+ *                       launcher offers (a torch.distributed store, MPI, a file): that bootstrap is the host's business.
+ *   t2d_comm_init       ncclCommInitRank on the pool's device (collective over the ranks).  world = 1 with id = NULL
+ *                       needs no RCCL at all.  RCCL is opened with dlopen here, not linked.
+ *   t2d_gather          all-gather of the records of the LAST n_steps steps (n_steps divides T2D_RECORD_RING and the
+ *                       number of steps taken so far) into out_dev = u32 [world][n_steps][n_env][2], caller-owned device
+ *                       memory.  nccl_comm = an ncclComm_t of the caller's, or NULL = the pool's own.  Ordered after
+ *                       what is enqueued on hip_stream (the steps' stream) and run on a stream of the pool's own, so the
+ *                       following steps do not wait for it; a later step that is about to overwrite a slot a gather
+ *                       still reads waits for that gather first (event wait on the step's stream, inside t2d_step).
+ *   t2d_gather_wait     makes hip_stream wait for every gather issued so far (block_host = 0), or blocks the host until
+ *                       they are done (block_host != 0); out_dev may be read after that.                              */
+#define T2D_COMM_ID_BYTES 128
+int t2d_comm_unique_id(uint8_t* id_out);
+int t2d_comm_init(t2d_pool* pool, const uint8_t* id, int32_t rank, int32_t world);
+int t2d_gather(t2d_pool* pool, void* nccl_comm, int32_t n_steps, void* out_dev, void* hip_stream);
+int t2d_gather_wait(t2d_pool* pool, void* hip_stream, int32_t block_host);
+
 /* Introspection: resident workgroups per CU of the fused step kernel with this pool's geometry, and its LDS bytes
  * per workgroup (static tables + the workgroup's geometry record).  The 4096 x 64 metric launch is one wave-round
  * of 1024 workgroups on 256 CUs and needs 4; a scene whose record grows past the LDS budget halves the rate.    */

@@ -7,7 +7,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 # --groups 1 = the headline configuration only (the default run appends the 4-group pipelined measurement, whose
 # quarter-size launches of the same kernel would otherwise be averaged into the same kernel-stats row)
-BENCH="python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --groups 1"
+BENCH="python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-configs --groups 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/bench_trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o bench -- $BENCH --no-profile > $OUT/bench_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o bench -- $BENCH --no-profile > $OUT/bench_write.log 2>&1

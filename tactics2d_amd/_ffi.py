@@ -77,7 +77,11 @@ SYMBOLS = {
     "t2d_set_integrator_variant": (C.c_int, [_vp, C.c_int32]),
     "t2d_profile_enable": (C.c_int, [_vp, C.c_int32]),
     "t2d_profile_read": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
-    # introspection, not part of include/t2d.h
+    "t2d_comm_unique_id": (C.c_int, [_vp]),
+    "t2d_comm_init": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32]),
+    "t2d_gather": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
+    "t2d_gather_wait": (C.c_int, [_vp, _vp, C.c_int32]),
+    # introspection
     "t2d_debug_step_occupancy": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
 }
 

@@ -32,7 +32,7 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("T2D_EXTRA_FLAGS", "").split()
-    cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+    cmd = [hipcc] + FLAGS + extra + [os.path.join(CSRC, f) for f in SOURCES] + ["-ldl", "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1,8 +1,11 @@
 // t2d_api.hip -- host side of libt2d_hip.so: pool lifetime, uploads, launches (C ABI of
 // include/t2d.h).  No CPU compute fallback exists: every entry point that needs the GPU
 // returns T2D_ERR_HIP with the HIP error text when the device / runtime is unavailable.
+#include <dlfcn.h>
 #include <math.h>
 #include <string.h>
+
+#include <rccl/rccl.h>   // types and enums only: the library is opened with dlopen when a communicator is asked for
 
 #include <algorithm>
 #include <new>
@@ -27,6 +30,38 @@ int fail(t2d_pool* p, int code, const std::string& msg) {
             return fail(p, T2D_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// RCCL, opened on demand (t2d_comm_unique_id / t2d_comm_init): libt2d_hip.so itself does not link it, so a single-GPU
+// user never loads it, and a process that already holds a copy (torch ships one) shares that copy by soname.
+struct Rccl {
+    bool tried = false, ok = false;
+    std::string err;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl& rccl() {
+    static Rccl r;
+    if (r.tried) return r;
+    r.tried = true;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+        if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) {
+        r.err = std::string("cannot open librccl: ") + dlerror();
+        return r;
+    }
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
+    if (!r.ok) r.err = "librccl lacks an expected symbol";
+    return r;
+}
+
 // Streams the pool has launched on since it was last quiesced.  Set-up calls, up/downloads and t2d_sync wait for
 // THESE (plus the pool's own internal streams), not for the device: another pool's env group or a policy running on
 // other streams is not stalled by them (no hidden device-wide syncs).
@@ -44,6 +79,7 @@ hipError_t quiesce(t2d_pool* p) {
     } else {
         for (int k = 0; k < p->n_live_streams && e == hipSuccess; ++k) e = hipStreamSynchronize(p->live_streams[k]);
         if (e == hipSuccess && p->scene_stream) e = hipStreamSynchronize(p->scene_stream);
+        if (e == hipSuccess && p->gather_stream) e = hipStreamSynchronize(p->gather_stream);
     }
     p->n_live_streams = 0;
     p->live_overflow = false;
@@ -580,6 +616,11 @@ int t2d_destroy(t2d_pool* p) {
                     p->d_scene_arrays, p->d_lidar_cnt};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (p->comm && rccl().ok) (void)rccl().CommDestroy((ncclComm_t)p->comm);
+    if (p->gather_stream) (void)hipStreamDestroy(p->gather_stream);
+    if (p->ev_frag_ready) (void)hipEventDestroy(p->ev_frag_ready);
+    for (hipEvent_t e : p->ev_gather)
+        if (e) (void)hipEventDestroy(e);
     if (p->scene_stream) (void)hipStreamDestroy(p->scene_stream);
     if (p->ev_scene_commit) (void)hipEventDestroy(p->ev_scene_commit);
     if (p->ev_scene_refill) (void)hipEventDestroy(p->ev_scene_refill);
@@ -951,13 +992,27 @@ static int regenerate_done_scenes(t2d_pool* p, hipStream_t s) {
     return T2D_OK;
 }
 
+// this step's slot of the record ring; a gather still reading that slot (enqueued RING steps ago or less) is waited for
+// on the step's stream first -- an event wait, nothing blocks the host
+static int claim_record_slot(t2d_pool* p, hipStream_t s) {
+    const int k = (int)(p->step_count % T2D_RECORD_RING);
+    if (hipEvent_t e = p->slot_event[k]) {   // one wait covers every slot that gather reads (one event per gather)
+        T2D_HIP(p, hipStreamWaitEvent(s, e, 0));
+        for (hipEvent_t& q : p->slot_event)
+            if (q == e) q = nullptr;
+    }
+    p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)k * p->v.n_env;
+    return T2D_OK;
+}
+
 int t2d_check_status(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     if (!p) return T2D_ERR_INVALID;
     if (!p->have_params || !p->have_reset)
         return fail(p, T2D_ERR_STATE, "t2d_set_param_table and t2d_reset must precede t2d_check_status");
     if (interval_ms <= 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be positive");
-    p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)(p->step_count % T2D_RECORD_RING) * p->v.n_env;
-    int rc = collide_impl(p, true, interval_ms, (hipStream_t)hip_stream);
+    int rc;
+    if ((rc = claim_record_slot(p, (hipStream_t)hip_stream))) return rc;
+    rc = collide_impl(p, true, interval_ms, (hipStream_t)hip_stream);
     if (rc == T2D_OK) p->step_count++;
     if (rc == T2D_OK) rc = regenerate_done_scenes(p, (hipStream_t)hip_stream);
     return rc;
@@ -973,8 +1028,8 @@ int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     if (!p->have_params || !p->have_reset)
         return fail(p, T2D_ERR_STATE, "t2d_set_param_table and t2d_reset must precede t2d_step");
     if (interval_ms <= 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be positive");
-    p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)(p->step_count % T2D_RECORD_RING) * p->v.n_env;
     int rc;
+    if ((rc = claim_record_slot(p, (hipStream_t)hip_stream))) return rc;
     if (p->idm_on && (rc = idm_impl(p, (hipStream_t)hip_stream))) return rc;
     if (p->has_drift && (rc = drift_impl(p, interval_ms, (hipStream_t)hip_stream))) return rc;
     rc = collide_impl(p, true, interval_ms, (hipStream_t)hip_stream, p->integrator_variant);
@@ -1215,6 +1270,91 @@ int t2d_debug_read(t2d_pool* p, unsigned long long* out, size_t n_words) {
     return T2D_OK;
 }
 #endif
+
+// ---- multi-GPU: the all-gather of the per-env result records ------------------------------------------
+int t2d_comm_unique_id(uint8_t* id) {
+    if (!id) return T2D_ERR_INVALID;
+    if (!rccl().ok) return fail(nullptr, T2D_ERR_HIP, rccl().err);
+    ncclUniqueId u;
+    const ncclResult_t r = rccl().GetUniqueId(&u);
+    if (r != ncclSuccess) return fail(nullptr, T2D_ERR_HIP, std::string("ncclGetUniqueId: ") + rccl().GetErrorString(r));
+    static_assert(sizeof(u) == T2D_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    memcpy(id, &u, sizeof(u));
+    return T2D_OK;
+}
+
+static int ensure_gather_objects(t2d_pool* p) {
+    if (p->gather_stream) return T2D_OK;
+    T2D_HIP(p, hipStreamCreateWithFlags(&p->gather_stream, hipStreamNonBlocking));
+    T2D_HIP(p, hipEventCreateWithFlags(&p->ev_frag_ready, hipEventDisableTiming));
+    for (hipEvent_t& e : p->ev_gather) T2D_HIP(p, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return T2D_OK;
+}
+
+int t2d_comm_init(t2d_pool* p, const uint8_t* id, int32_t rank, int32_t world) {
+    if (!p) return T2D_ERR_INVALID;
+    if (world < 1 || rank < 0 || rank >= world) return fail(p, T2D_ERR_INVALID, "t2d_comm_init: need 0 <= rank < world");
+    if (world > 1 && !id) return fail(p, T2D_ERR_INVALID, "t2d_comm_init: the communicator id of t2d_comm_unique_id is required");
+    T2D_HIP(p, hipSetDevice(p->device));
+    int rc;
+    if ((rc = ensure_gather_objects(p))) return rc;
+    if (p->comm) {
+        (void)rccl().CommDestroy((ncclComm_t)p->comm);
+        p->comm = nullptr;
+    }
+    p->comm_rank = rank;
+    p->comm_world = world;
+    if (!id) return T2D_OK;   // a world of one without RCCL: t2d_gather degenerates to a copy on the gather stream
+    if (!rccl().ok) return fail(p, T2D_ERR_HIP, rccl().err);
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclComm_t c = nullptr;
+    const ncclResult_t r = rccl().CommInitRank(&c, world, u, rank);
+    if (r != ncclSuccess) return fail(p, T2D_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
+    p->comm = c;
+    return T2D_OK;
+}
+
+int t2d_gather(t2d_pool* p, void* nccl_comm, int32_t n_steps, void* out_dev, void* hip_stream) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!out_dev) return fail(p, T2D_ERR_INVALID, "t2d_gather: out_dev is null");
+    if (n_steps < 1 || T2D_RECORD_RING % n_steps || p->step_count < n_steps || p->step_count % n_steps)
+        return fail(p, T2D_ERR_INVALID, "t2d_gather: n_steps must divide the record ring (" + std::to_string(T2D_RECORD_RING) +
+                                            ") and the step count (" + std::to_string(p->step_count) + ") must be a positive multiple of it");
+    T2D_HIP(p, hipSetDevice(p->device));
+    int rc;
+    if ((rc = ensure_gather_objects(p))) return rc;
+    ncclComm_t comm = nccl_comm ? (ncclComm_t)nccl_comm : (ncclComm_t)p->comm;
+    if (!comm && p->comm_world > 1) return fail(p, T2D_ERR_STATE, "t2d_gather: no communicator (t2d_comm_init)");
+    if (comm && !rccl().ok) return fail(p, T2D_ERR_HIP, rccl().err);
+    hipStream_t s = (hipStream_t)hip_stream;
+    const int first = (int)((p->step_count - n_steps) % T2D_RECORD_RING);   // contiguous: n_steps divides the ring
+    const size_t count = (size_t)n_steps * p->v.n_env * 2;                  // u32 words of this rank's fragment
+    const uint32_t* src = (const uint32_t*)p->field_ptr[T2D_F_RECORD] + (size_t)first * p->v.n_env * 2;
+    // the gather stream picks up after the fragment's last step; the step stream does not wait for the collective
+    T2D_HIP(p, hipEventRecord(p->ev_frag_ready, s));
+    T2D_HIP(p, hipStreamWaitEvent(p->gather_stream, p->ev_frag_ready, 0));
+    if (comm) {
+        const ncclResult_t r = rccl().AllGather(src, out_dev, count, ncclUint32, comm, p->gather_stream);
+        if (r != ncclSuccess) return fail(p, T2D_ERR_HIP, std::string("ncclAllGather: ") + rccl().GetErrorString(r));
+    } else {
+        T2D_HIP(p, hipMemcpyAsync(out_dev, src, count * sizeof(uint32_t), hipMemcpyDeviceToDevice, p->gather_stream));
+    }
+    hipEvent_t done = p->ev_gather[first];
+    T2D_HIP(p, hipEventRecord(done, p->gather_stream));
+    for (int k = first; k < first + n_steps; ++k) p->slot_event[k] = done;   // whoever overwrites these slots waits for it
+    p->last_gather = done;
+    return T2D_OK;
+}
+
+int t2d_gather_wait(t2d_pool* p, void* hip_stream, int32_t block_host) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!p->last_gather) return T2D_OK;
+    T2D_HIP(p, hipSetDevice(p->device));
+    if (block_host) T2D_HIP(p, hipEventSynchronize(p->last_gather));
+    else T2D_HIP(p, hipStreamWaitEvent((hipStream_t)hip_stream, p->last_gather, 0));
+    return T2D_OK;
+}
 
 // introspection (not part of the ABI of include/t2d.h): resident workgroups per CU of the fused step kernel for this
 // pool's geometry, and its LDS bytes per workgroup -- the regression guard of tests/test_gpu_api.py

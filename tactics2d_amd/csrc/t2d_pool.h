@@ -190,6 +190,16 @@ struct t2d_pool {
     bool scene_refill_pending = false;
     int32_t* d_lidar_cnt = nullptr;
     long long step_count = 0;  // t2d_step calls so far (selects the record ring slot)
+    // result gather (the one collective of the path): RCCL communicator + a stream of its own, so that the steps that
+    // follow a fragment do not wait for its all-gather; slot_event[k] != null = a gather that reads record slot k was
+    // enqueued and the step about to overwrite that slot must wait for it first
+    void* comm = nullptr;          // ncclComm_t created by t2d_comm_init (null: none / world of one)
+    int comm_rank = 0, comm_world = 1;
+    hipStream_t gather_stream = nullptr;
+    hipEvent_t ev_frag_ready = nullptr;
+    hipEvent_t ev_gather[T2D_RECORD_RING]{};
+    hipEvent_t slot_event[T2D_RECORD_RING]{};
+    hipEvent_t last_gather = nullptr;
     // streams with work of this pool possibly in flight (what the set-up calls / t2d_sync wait for)
     static constexpr int kMaxLiveStreams = 4;
     hipStream_t live_streams[kMaxLiveStreams]{};

@@ -3,8 +3,12 @@ only collective on the path -- an all-gather of the 8-byte per-env result record
 scenario_status u8, traffic_status u8, terminated u8, truncated u8}.
 
 Environments never interact (traffic/scenario_manager.py:52-61: one ScenarioManager owns one
-scene), so there is no data-path exchange: every rank steps its own pool.  torch.distributed is
-plumbing only: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+scene), so there is no data-path exchange: every rank steps its own pool.  On GPUs the collective
+is issued by the library itself (`NativeGather` -> t2d_gather: RCCL all-gather over xGMI reading
+the pool's record ring in place, on a stream of the pool's own); torch.distributed is the
+BOOTSTRAP only (rendezvous, shipping the 128-byte communicator id, the bench's barrier).
+`ResultGather` is the same exchange through torch.distributed, kept for backends without RCCL
+(the world_size-2 gloo tests on CPU and on a one-GPU box).
 """
 import os
 
@@ -16,9 +20,14 @@ def env_info():
             int(os.environ.get("WORLD_SIZE", 1)))
 
 
-def shard_range(n_env_total, rank, world):
-    """Contiguous block sharding: rank r owns envs [r*E/G, (r+1)*E/G) (remainder to low ranks)."""
+def shard_range(n_env_total, rank, world, allow_uneven=False):
+    """Contiguous block sharding: rank r owns envs [r*E/G, (r+1)*E/G).  The result gather ships equally sized
+    fragments (all_gather requires it, and result() assumes a rank-major layout), so E must be a multiple of G;
+    allow_uneven=True gives the low ranks the remainder for jobs that never gather."""
     base, rem = divmod(n_env_total, world)
+    if rem and not allow_uneven:
+        raise ValueError(f"{n_env_total} environments do not split evenly over {world} ranks "
+                         f"(the result gather needs equal shards; pad the job or pass allow_uneven=True)")
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
 
@@ -57,9 +66,11 @@ class ResultGather:
     step number % ring), so the collective reads them in place: no packing kernels.  `every` = K ships the
     records of K consecutive steps in ONE message (a rollout fragment): a collective costs ~10 us of launch /
     stream-event overhead per call however small it is, which per step would be a third of the step itself;
-    K must divide the ring and leave at least two fragments in it (K <= ring / 2), so the next fragment is
-    written while the previous one is in flight.  `records` is an int32 tensor view [ring, E, 2] of that field
-    (a CPU tensor in the gloo tests)."""
+    K must divide the ring and leave at least two fragments in it (K <= ring / 2).  At most ONE gather is in flight:
+    launch() first waits (a stream wait for RCCL, a host wait for gloo) for the previous fragment's gather -- the steps
+    the caller enqueues next are the ones that overwrite the slots that gather was reading, and the previous output
+    buffer is free again.  `records` is an int32 tensor view [ring, E, 2] of that field (a CPU tensor in the gloo
+    tests)."""
 
     def __init__(self, records, world, every=1):
         import torch
@@ -84,9 +95,9 @@ class ResultGather:
             return None
         k = self._frag & 1
         self._frag += 1
-        if self.work[k] is not None:
-            self.work[k].wait()
-            self.work[k] = None
+        # every earlier gather must be done before the caller's next steps reuse its ring slots (with two fragments in
+        # the ring the very next step does), and before its output buffer is written again
+        self.wait()
         s0 = (step + 1 - self.every) % self.ring
         src = self.records[s0:s0 + self.every]          # contiguous: `every` whole slots
         if self.world > 1:
@@ -105,6 +116,52 @@ class ResultGather:
     def result(self, k, j=None):
         """Records of buffer k: (reward f32[world*E], status u8[world*E, 4]) of the fragment's j-th step
         (default: its last), rank-major env order."""
+        self.wait(k)
+        j = self.every - 1 if j is None else j
+        return unpack_record(self.out[k][:, j].reshape(self.world * self.n, 2))
+
+
+class NativeGather:
+    """The result gather issued by the library (t2d_gather): an RCCL all-gather over xGMI that reads the pool's record
+    ring in place, on a stream owned by the pool, ordered after the steps' stream by events -- the steps that follow a
+    fragment do not wait for it, and a step that would overwrite a slot still being read waits inside t2d_step.
+    torch is used for the two output tensors only.  Same calling convention as ResultGather."""
+
+    def __init__(self, pool, world, every=8, device=None):
+        import torch
+        from . import layout as L
+        if every < 1 or L.RECORD_RING % every or L.RECORD_RING // every < 2:
+            raise ValueError(f"every={every} must divide the record ring ({L.RECORD_RING}) and be <= ring / 2")
+        self.pool, self.world, self.every, self.n = pool, world, every, pool.n_env
+        self.out = [torch.empty((world, every, self.n, 2), dtype=torch.int32, device=device) for _ in range(2)]
+        self._frag = 0
+        self._stream = None
+
+    @staticmethod
+    def bootstrap(pool, rank, world):
+        """Create the pool's RCCL communicator: rank 0 draws the id, torch.distributed (any backend) ships it."""
+        uid = [None]
+        if world > 1:
+            import torch.distributed as dist
+            if rank == 0:
+                uid[0] = pool.comm_unique_id()
+            dist.broadcast_object_list(uid, src=0)
+        pool.comm_init(uid[0], rank, world)
+
+    def launch(self, step, stream=None):
+        """Call after (0-based) step `step`, with the stream the steps run on (raw handle or None)."""
+        if (step + 1) % self.every:
+            return None
+        k = self._frag & 1
+        self._frag += 1
+        self._stream = stream
+        self.pool.gather(self.every, self.out[k].data_ptr(), stream)
+        return k
+
+    def wait(self, k=None):
+        self.pool.gather_wait(self._stream, block_host=True)
+
+    def result(self, k, j=None):
         self.wait(k)
         j = self.every - 1 if j is None else j
         return unpack_record(self.out[k][:, j].reshape(self.world * self.n, 2))

@@ -268,6 +268,29 @@ class ParticipantPool:
     def sync(self):
         self._ck(self._lib.t2d_sync(self._h))
 
+    # ---------------------------------------------------------------- multi-GPU result gather
+    @staticmethod
+    def comm_unique_id():
+        """ncclGetUniqueId (rank 0): 128 bytes for the other ranks' comm_init, shipped by the launcher's own channel."""
+        from . import _ffi
+        buf = (C.c_uint8 * 128)()
+        _ffi.check(_ffi.lib().t2d_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        """ncclCommInitRank on this pool's device (collective).  unique_id None = a world of one without RCCL."""
+        buf = None if unique_id is None else (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._ck(self._lib.t2d_comm_init(self._h, buf, int(rank), int(world)))
+        self._comm_id = buf
+
+    def gather(self, n_steps, out_ptr, stream=None, comm=None):
+        """All-gather of the per-env result records of the last n_steps steps into caller-owned device memory
+        (u32 [world][n_steps][n_env][2]); asynchronous, ordered after `stream`."""
+        self._ck(self._lib.t2d_gather(self._h, comm, int(n_steps), out_ptr, stream))
+
+    def gather_wait(self, stream=None, block_host=False):
+        self._ck(self._lib.t2d_gather_wait(self._h, stream, int(bool(block_host))))
+
     def step_occupancy(self):
         """(resident workgroups per CU, LDS bytes per workgroup) of the fused step kernel with this pool's geometry."""
         b, l = C.c_int32(), C.c_int64()

@@ -1,0 +1,163 @@
+"""Multi-GPU path on a one-GPU box: the native result gather (t2d_gather: RCCL opened by the library, world of one)
+and two ranks that each step a REAL pool holding their shard of the environments and exchange the records (gloo, both
+ranks on device 0 -- RCCL refuses two ranks on one GPU), against a single pool that owns every environment."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+N_ENV, A, STEPS, EVERY = 48, 64, 32, 8
+
+
+def _scene():
+    from tactics2d_amd import scenarios as S
+    return S.mixed(N_ENV, A, seed=12)
+
+
+def _actions(sc):
+    rng = np.random.default_rng(99)
+    return [sc.sample_actions(rng) for _ in range(STEPS)]
+
+
+def _single_pool_records(sc, acts):
+    """reward / status of every step from ONE pool owning all environments (downloaded step by step)."""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    pool = ParticipantPool(sc.n_env, sc.A)
+    sc.load(pool)
+    pool.set_auto_reset(True)
+    out = []
+    for a0, a1 in acts:
+        pool.set_actions(a0, a1)
+        pool.step(100)
+        out.append((pool.download(L.F_REWARD), pool.download(L.F_STATUS)))
+    pool.close()
+    return out
+
+
+@pytest.mark.parametrize("with_rccl", [False, True])
+def test_native_gather_reads_the_record_ring_in_place(with_rccl):
+    """t2d_gather on a world of one: every fragment of 8 steps arrives complete while later steps keep overwriting the
+    ring (32 steps = the 16-slot ring twice), with and without an RCCL communicator behind it."""
+    from tactics2d_amd.dist import NativeGather
+    from tactics2d_amd.pool import ParticipantPool
+    sc = _scene()
+    acts = _actions(sc)
+    want = _single_pool_records(sc, acts)
+    pool = ParticipantPool(sc.n_env, sc.A)
+    sc.load(pool)
+    pool.set_auto_reset(True)
+    if with_rccl:
+        pool.comm_init(pool.comm_unique_id(), 0, 1)       # ncclCommInitRank, one rank: dlopen + the real collective
+    else:
+        NativeGather.bootstrap(pool, 0, 1)
+    g = NativeGather(pool, 1, every=EVERY, device="cuda")
+    st = torch.cuda.Stream()
+    got = {}
+    pending = None
+    for t, (a0, a1) in enumerate(acts):
+        pool.set_actions(a0, a1)
+        pool.step(100, st.cuda_stream)
+        k = g.launch(t, st.cuda_stream)
+        if pending is not None and k is None and (t + 1) % EVERY == 3:   # read a fragment while later steps are in flight
+            kk, t_last = pending
+            for j in range(EVERY):
+                rw, s = g.result(kk, j)
+                got[t_last - EVERY + 1 + j] = (rw.cpu().numpy(), s.cpu().numpy())
+            pending = None
+        if k is not None:
+            pending = (k, t)
+    kk, t_last = pending
+    for j in range(EVERY):
+        rw, s = g.result(kk, j)
+        got[t_last - EVERY + 1 + j] = (rw.cpu().numpy(), s.cpu().numpy())
+    pool.close()
+    assert sorted(got) == list(range(STEPS))
+    for t in range(STEPS):
+        assert np.array_equal(got[t][0], want[t][0]) and np.array_equal(got[t][1], want[t][1]), t
+    assert any(w[1][:, 3].any() for w in want)            # some episodes ended: the records are not trivial
+
+
+def test_gather_argument_checks():
+    from tactics2d_amd import _ffi
+    from tactics2d_amd.pool import ParticipantPool
+    sc = _scene()
+    pool = ParticipantPool(sc.n_env, sc.A)
+    sc.load(pool)
+    out = torch.empty((1, 8, sc.n_env, 2), dtype=torch.int32, device="cuda")
+    with pytest.raises(_ffi.T2DError):
+        pool.gather(8, out.data_ptr())                    # no steps taken yet
+    a0, a1 = sc.sample_actions(np.random.default_rng(0))
+    pool.set_actions(a0, a1)
+    for _ in range(3):
+        pool.step(100)
+    with pytest.raises(_ffi.T2DError):
+        pool.gather(3, out.data_ptr())                    # 3 does not divide the ring
+    with pytest.raises(_ffi.T2DError):
+        pool.gather(2, out.data_ptr())                    # 3 steps taken: not a multiple of 2
+    pool.step(100)
+    pool.gather(4, out.data_ptr())
+    pool.gather_wait(block_host=True)
+    with pytest.raises(_ffi.T2DError):
+        pool.comm_init(None, 0, 2)                        # a world of two needs the communicator id
+    pool.close()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _rank(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from tactics2d_amd import dist as D, layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    D.init_process_group("gloo")
+    torch.cuda.set_device(0)                              # both ranks on the one GPU of the box
+    sc = _scene()
+    acts = _actions(sc)
+    lo, hi = D.shard_range(sc.n_env, rank, world)
+    part = sc.shard(lo, hi)
+    pool = ParticipantPool(part.n_env, part.A, 0)
+    part.load(pool)
+    pool.set_auto_reset(True)
+    rec = torch.as_tensor(pool.device_array(L.F_RECORD), device="cuda:0").view(torch.int32)
+    g = D.ResultGather(rec, world, every=EVERY)
+    rows = []
+    for t, (a0, a1) in enumerate(acts):
+        pool.set_actions(a0[lo * A:hi * A], a1[lo * A:hi * A])
+        pool.step(100)
+        pool.sync()                                       # gloo reads the record tensor from the host side
+        k = g.launch(t)
+        if k is not None:
+            for j in range(EVERY):
+                rw, s = g.result(k, j)
+                rows.append((rw.cpu().numpy().copy(), s.cpu().numpy().copy()))
+    np.save(os.path.join(out_dir, f"rank{rank}_reward.npy"), np.stack([r[0] for r in rows]))
+    np.save(os.path.join(out_dir, f"rank{rank}_status.npy"), np.stack([r[1] for r in rows]))
+    pool.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_real_pools_gather_what_one_pool_computes(tmp_path):
+    """N > 1 with pools behind it: two processes, each stepping its contiguous shard of scenarios.mixed through its own
+    pool for 32 steps, gather the per-env records fragment by fragment; every rank must end up with exactly the
+    records a single pool owning all environments produces (envs never interact, shards are contiguous, rank-major
+    order = env order)."""
+    import torch.multiprocessing as mp
+    sc = _scene()
+    want = _single_pool_records(sc, _actions(sc))
+    world = 2
+    mp.spawn(_rank, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        rw = np.load(tmp_path / f"rank{rank}_reward.npy"); st = np.load(tmp_path / f"rank{rank}_status.npy")
+        assert rw.shape == (STEPS, N_ENV) and st.shape == (STEPS, N_ENV, 4)
+        for t in range(STEPS):
+            assert np.array_equal(rw[t], want[t][0]) and np.array_equal(st[t], want[t][1]), (rank, t)

@@ -106,7 +106,10 @@ def test_parking_scene_follows_the_reference_layout():
 def test_shard_ranges_cover_every_env_once():
     from tactics2d_amd.dist import shard_range
     for total, world in ((8192, 8), (4096, 3), (10, 4), (5, 8)):
-        got = [shard_range(total, r, world) for r in range(world)]
+        if total % world:   # the result gather needs equal shards: uneven splits must be asked for explicitly
+            with pytest.raises(ValueError):
+                shard_range(total, 0, world)
+        got = [shard_range(total, r, world, allow_uneven=True) for r in range(world)]
         assert got[0][0] == 0 and got[-1][1] == total
         assert all(got[i][1] == got[i + 1][0] for i in range(world - 1))
         sizes = [hi - lo for lo, hi in got]
