@@ -178,7 +178,7 @@ enum {
 #define T2D_TRAFFIC_OFF_LANE          6
 
 /* ---- geometry limits ----------------------------------------------------------------- */
-#define T2D_MAX_POLY_VERTS 8      /* static / lane polygons: convex, 3..8 vertices        */
+#define T2D_MAX_POLY_VERTS 8      /* static / lane polygons: convex, 3..8 vertices (5..8: evaluated as a fan of quads) */
 #define T2D_RECORD_RING 16      /* slots of the per-env result-record ring (T2D_F_RECORD) */
 #define T2D_MAX_AGENTS 256        /* participants per env                                 */
 
@@ -226,7 +226,9 @@ int t2d_set_param_table(t2d_pool* pool, const double* rows, int32_t n_types, int
  *   verts_xy          [2 * n_vert] interleaved x,y
  *   boundary          [4 * n_env]  xmin, xmax, ymin, ymax (OutBound tuple order) or NULL
  *   boundary_valid    [n_env]      0 = "boundary is None" -> never out of bound; NULL = all valid
- * Polygons must be convex with 3..T2D_MAX_POLY_VERTS vertices; either winding accepted.  */
+ * Polygons must be convex with 3..T2D_MAX_POLY_VERTS vertices; either winding accepted.  A polygon of
+ * 5..8 vertices is evaluated as its fan of quads (v0 v1 v2 v3), (v0 v3 v4 v5), (v0 v5 v6 v7): the union is the
+ * polygon, `intersects` is the OR over the parts; the lidar scans the undivided ring.             */
 int t2d_set_static_geometry(t2d_pool* pool, const int32_t* env_poly_offsets,
                             const int32_t* poly_vert_offsets, const float* verts_xy,
                             const float* boundary, const uint8_t* boundary_valid);

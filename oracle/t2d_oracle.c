@@ -532,6 +532,48 @@ int t2do_polygon_is_convex(const float* verts_xy, int n) {
     return 1;
 }
 
+/* Polygons as the event kernels see them (t2d_api.hip prepare_polys does the same at t2d_set_*_geometry): a convex
+ * polygon of 5..8 vertices is replaced by its fan of quads (v0 v1 v2 v3), (v0 v3 v4 v5), (v0 v5 v6 v7) -- the last
+ * part a triangle for odd counts, parts without area dropped.  The union of the parts IS the polygon, so closed
+ * `intersects` and point-in tests are the OR over the parts; evaluated on the parts, the fp64 orientation signs are
+ * the ones the GPU evaluates.  P: CCW fp64 vertices.  Returns the number of parts (<= 3). */
+static int fan_parts(const double* P, int n, double parts[3][8], int pn[3]) {
+    int m = 0;
+    if (n <= 4) {
+        for (int k = 0; k < 2 * n; ++k) parts[0][k] = P[k];
+        pn[0] = n;
+        return 1;
+    }
+    for (int k = 1; k < n - 1; k += 2) {
+        const int cnt = k + 2 <= n - 1 ? 4 : 3;
+        const int idx[4] = {0, k, k + 1, k + 2};
+        for (int j = 0; j < cnt; ++j) { parts[m][2 * j] = P[2 * idx[j]]; parts[m][2 * j + 1] = P[2 * idx[j] + 1]; }
+        if (area2(parts[m], cnt) > 0.0) pn[m++] = cnt;
+    }
+    return m;
+}
+
+/* the lane polygons [l0, l1) as their parts: a CSR of its own (fp32 vertices, CCW); caller frees *vo and *xy */
+static int decompose_lanes(const int32_t* lane_vert_off, const float* lane_xy, int l0, int l1, int32_t** vo, float** xy) {
+    const int nl = l1 - l0 > 0 ? l1 - l0 : 0;
+    *vo = (int32_t*)malloc(sizeof(int32_t) * (3 * (size_t)nl + 1));
+    *xy = (float*)malloc(sizeof(float) * 2 * 4 * 3 * (size_t)(nl + 1));
+    int np = 0;
+    (*vo)[0] = 0;
+    for (int li = l0; li < l1; ++li) {
+        double P[2 * T2D_MAX_POLY_VERTS], parts[3][8];
+        int pn[3];
+        const int n = load_poly(lane_xy, lane_vert_off[li], lane_vert_off[li + 1], P);
+        const int m = fan_parts(P, n, parts, pn);
+        for (int k = 0; k < m; ++k) {
+            for (int j = 0; j < 2 * pn[k]; ++j) (*xy)[2 * (*vo)[np] + j] = (float)parts[k][j];
+            (*vo)[np + 1] = (*vo)[np] + pn[k];
+            ++np;
+        }
+    }
+    return np;
+}
+
 /* ------------------------------------------------------------------------------------------
  * Off-lane = `not union(lanes).contains(pose)`.  The reference's OffLane.update
  * (off_lane.py:16-17) is a stub; the predicate mirrored is OutBound.update out_bound.py:37-48:
@@ -596,8 +638,8 @@ static int edge_covered_by(const double* q0, const double* q1, const double* M, 
  * pieces[4 * k] = Ax, Ay, Bx, By; owner[k] = lane polygon (absolute index) the piece is an edge part of.
  * Pieces are emitted lane by lane, edge by edge, in ascending t.  Returns the number of pieces; nothing is
  * written beyond cap (call with cap = 0 to size the arrays). */
-int t2do_lane_boundary(const int32_t* lane_vert_off, const float* lane_xy, int l0, int l1, double* pieces,
-                       int32_t* owner, int cap) {
+static int lane_boundary_parts(const int32_t* lane_vert_off, const float* lane_xy, int l0, int l1, double* pieces,
+                               int32_t* owner, int cap) {
     const int nl = l1 - l0;
     int count = 0;
     if (nl <= 0) return 0;
@@ -644,6 +686,16 @@ int t2do_lane_boundary(const int32_t* lane_vert_off, const float* lane_xy, int l
     }
     free(polys); free(pn); free(ia);
     return count;
+}
+
+/* public form: lane polygons as given (3..8 vertices); owner[k] indexes their PARTS (fan_parts), in order */
+int t2do_lane_boundary(const int32_t* lane_vert_off, const float* lane_xy, int l0, int l1, double* pieces,
+                       int32_t* owner, int cap) {
+    int32_t* vo; float* xy;
+    const int np = decompose_lanes(lane_vert_off, lane_xy, l0, l1, &vo, &xy);
+    const int n = lane_boundary_parts(vo, xy, 0, np, pieces, owner, cap);
+    free(vo); free(xy);
+    return n;
 }
 
 /* 1 when the boundary piece A -> B meets the interior of the CCW convex quad pose8 */
@@ -700,26 +752,30 @@ static int circle_in_lane_union(const double* c, double R, const int32_t* lane_v
     return 1;
 }
 
-/* stand-alone forms for the known-answer tests (the boundary is rebuilt on every call) */
+/* stand-alone forms for the known-answer tests (parts and boundary are rebuilt on every call) */
 int t2do_pose_in_lane_union(const double* pose8, const double* cxy, const int32_t* lane_vert_off,
                             const float* lane_xy, int l0, int l1) {
-    const int n = t2do_lane_boundary(lane_vert_off, lane_xy, l0, l1, NULL, NULL, 0);
+    int32_t* vo; float* xy;
+    const int np = decompose_lanes(lane_vert_off, lane_xy, l0, l1, &vo, &xy);
+    const int n = lane_boundary_parts(vo, xy, 0, np, NULL, NULL, 0);
     double* pieces = (double*)malloc(sizeof(double) * 4 * (size_t)(n + 1));
     int32_t* owner = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
-    t2do_lane_boundary(lane_vert_off, lane_xy, l0, l1, pieces, owner, n);
-    const int r = box_in_lane_union(pose8, cxy, lane_vert_off, lane_xy, l0, l1, pieces, n);
-    free(pieces); free(owner);
+    lane_boundary_parts(vo, xy, 0, np, pieces, owner, n);
+    const int r = box_in_lane_union(pose8, cxy, vo, xy, 0, np, pieces, n);
+    free(pieces); free(owner); free(vo); free(xy);
     return r;
 }
 
 int t2do_circle_in_lane_union(const double* c, double R, const int32_t* lane_vert_off, const float* lane_xy,
                               int l0, int l1) {
-    const int n = t2do_lane_boundary(lane_vert_off, lane_xy, l0, l1, NULL, NULL, 0);
+    int32_t* vo; float* xy;
+    const int np = decompose_lanes(lane_vert_off, lane_xy, l0, l1, &vo, &xy);
+    const int n = lane_boundary_parts(vo, xy, 0, np, NULL, NULL, 0);
     double* pieces = (double*)malloc(sizeof(double) * 4 * (size_t)(n + 1));
     int32_t* owner = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n + 1));
-    t2do_lane_boundary(lane_vert_off, lane_xy, l0, l1, pieces, owner, n);
-    const int r = circle_in_lane_union(c, R, lane_vert_off, lane_xy, l0, l1, pieces, n);
-    free(pieces); free(owner);
+    lane_boundary_parts(vo, xy, 0, np, pieces, owner, n);
+    const int r = circle_in_lane_union(c, R, vo, xy, 0, np, pieces, n);
+    free(pieces); free(owner); free(vo); free(xy);
     return r;
 }
 
@@ -749,13 +805,15 @@ void t2do_collide(const double* rows, int row_stride, int n_env, int A, const fl
     for (int e = 0; e < n_env; ++e) {
         size_t base = (size_t)e * A;
         const int n_lanes_e = env_lane_off ? env_lane_off[e + 1] - env_lane_off[e] : 0;
-        int n_pieces = 0;
+        int n_pieces = 0, n_lane_parts = 0;
         double* pieces = NULL;
-        if (n_lanes_e > 0) {   /* boundary of the env's lane union (the GPU path builds it once, at t2d_set_lane_geometry) */
-            n_pieces = t2do_lane_boundary(lane_vert_off, lane_xy, env_lane_off[e], env_lane_off[e + 1], NULL, NULL, 0);
+        int32_t* lvo = NULL;
+        float* lxy = NULL;
+        if (n_lanes_e > 0) {   /* parts + boundary of the env's lane union (the GPU path builds both once, at t2d_set_lane_geometry) */
+            n_lane_parts = decompose_lanes(lane_vert_off, lane_xy, env_lane_off[e], env_lane_off[e + 1], &lvo, &lxy);
+            n_pieces = lane_boundary_parts(lvo, lxy, 0, n_lane_parts, NULL, NULL, 0);
             pieces = (double*)malloc((sizeof(double) * 4 + sizeof(int32_t)) * (size_t)(n_pieces + 1));
-            t2do_lane_boundary(lane_vert_off, lane_xy, env_lane_off[e], env_lane_off[e + 1], pieces,
-                               (int32_t*)(pieces + 4 * (size_t)(n_pieces + 1)), n_pieces);
+            lane_boundary_parts(lvo, lxy, 0, n_lane_parts, pieces, (int32_t*)(pieces + 4 * (size_t)(n_pieces + 1)), n_pieces);
         }
         for (int i = 0; i < A; ++i) {
             flags[base + i] = 0;
@@ -788,13 +846,17 @@ void t2do_collide(const double* rows, int row_stride, int n_env, int A, const fl
             }
             /* participant vs static polygons */
             if (env_poly_off) {
-                for (int pi = env_poly_off[e]; pi < env_poly_off[e + 1]; ++pi) {
-                    double P[2 * T2D_MAX_POLY_VERTS];
+                for (int pi = env_poly_off[e]; pi < env_poly_off[e + 1] && !(f & T2D_FLAG_COLLISION_STATIC); ++pi) {
+                    double P[2 * T2D_MAX_POLY_VERTS], parts[3][8];
+                    int pn[3];
                     int n = load_poly(poly_xy, poly_vert_off[pi], poly_vert_off[pi + 1], P);
-                    int hit = kind[i] == T2D_SHAPE_OBB
-                                  ? t2do_convex_intersects(V + 8 * i, 4, P, n)
-                                  : t2do_circle_convex_intersects(C + 3 * i, C[3 * i + 2], P, n);
-                    if (hit) { f |= T2D_FLAG_COLLISION_STATIC; break; }
+                    const int m = fan_parts(P, n, parts, pn);   /* the polygon as its quads: OR over the parts */
+                    for (int k = 0; k < m; ++k) {
+                        int hit = kind[i] == T2D_SHAPE_OBB
+                                      ? t2do_convex_intersects(V + 8 * i, 4, parts[k], pn[k])
+                                      : t2do_circle_convex_intersects(C + 3 * i, C[3 * i + 2], parts[k], pn[k]);
+                        if (hit) { f |= T2D_FLAG_COLLISION_STATIC; break; }
+                    }
                 }
             }
             /* map boundary */
@@ -815,10 +877,9 @@ void t2do_collide(const double* rows, int row_stride, int n_env, int A, const fl
             }
             /* lanes (build-defined): not union(lanes).contains(pose) */
             if (n_lanes_e > 0) {
-                const int l0 = env_lane_off[e], l1 = env_lane_off[e + 1];
                 const int in = kind[i] == T2D_SHAPE_OBB
-                                   ? box_in_lane_union(V + 8 * i, C + 3 * i, lane_vert_off, lane_xy, l0, l1, pieces, n_pieces)
-                                   : circle_in_lane_union(C + 3 * i, C[3 * i + 2], lane_vert_off, lane_xy, l0, l1, pieces, n_pieces);
+                                   ? box_in_lane_union(V + 8 * i, C + 3 * i, lvo, lxy, 0, n_lane_parts, pieces, n_pieces)
+                                   : circle_in_lane_union(C + 3 * i, C[3 * i + 2], lvo, lxy, 0, n_lane_parts, pieces, n_pieces);
                 if (!in) f |= T2D_FLAG_OFF_LANE;
             }
             flags[base + i] = f;
@@ -826,7 +887,7 @@ void t2do_collide(const double* rows, int row_stride, int n_env, int A, const fl
         uint32_t ef = 0;
         for (int i = 0; i < A; ++i) ef |= flags[base + i];
         env_flags[e] = ef;
-        free(pieces);
+        free(pieces); free(lvo); free(lxy);
     }
     free(V); free(C); free(kind);
     }

@@ -122,8 +122,9 @@ double orient_h(const double* p, const double* q, const double* r) {
     return a * b - c * d;
 }
 
-// fp32 CSR polygons -> CCW-normalised fp32 copy + per-polygon AABB.  Validates convexity with the
-// same fp64 orientation arithmetic the kernels use.
+// fp32 CSR polygons -> what the kernels consume: CCW-normalised, polygons of more than 4 vertices cut into a fan of
+// quads (see HostGeo), per-part AABB; plus the undivided CCW rings for the lidar.  Validates convexity with the same
+// fp64 orientation arithmetic the kernels use.
 int prepare_polys(t2d_pool* p, const int32_t* env_off, const int32_t* vert_off, const float* xy,
                   t2d_pool::HostGeo& out) {
     const int E = p->v.n_env;
@@ -135,12 +136,29 @@ int prepare_polys(t2d_pool* p, const int32_t* env_off, const int32_t* vert_off, 
     const int V = P > 0 ? vert_off[P] : 0;
     t2d_pool::HostGeo g;
     g.present = true;
-    g.env_off.assign(env_off, env_off + E + 1);
-    g.vert_off.assign(vert_off, vert_off + P + 1);
-    if (P == 0) g.vert_off.assign(1, 0);
-    g.xy.assign(2 * (size_t)V, 0.f);
-    g.aabb.assign(4 * (size_t)P, 0.f);
+    g.ring_env_off.assign(env_off, env_off + E + 1);
+    g.ring_vert_off.assign(vert_off, vert_off + P + 1);
+    if (P == 0) g.ring_vert_off.assign(1, 0);
+    g.ring_xy.assign(2 * (size_t)V, 0.f);
+    g.env_off.assign(1, 0);
+    g.vert_off.assign(1, 0);
+    auto emit = [&](const double* poly, const int* idx, int m) {   // one part; dropped when it has no area
+        std::vector<double> part(2 * m);
+        for (int k = 0; k < m; ++k) { part[2 * k] = poly[2 * idx[k]]; part[2 * k + 1] = poly[2 * idx[k] + 1]; }
+        if (!(area2(part) > 0.0)) return;
+        float xmin = (float)part[0], xmax = xmin, ymin = (float)part[1], ymax = ymin;
+        for (int k = 0; k < m; ++k) {
+            const float fx = (float)part[2 * k], fy = (float)part[2 * k + 1];  // exact: inputs are fp32
+            g.xy.push_back(fx); g.xy.push_back(fy);
+            xmin = std::min(xmin, fx); xmax = std::max(xmax, fx);
+            ymin = std::min(ymin, fy); ymax = std::max(ymax, fy);
+        }
+        g.aabb.push_back(xmin); g.aabb.push_back(xmax); g.aabb.push_back(ymin); g.aabb.push_back(ymax);
+        g.vert_off.push_back(g.vert_off.back() + m);
+    };
+    int e = 0;
     for (int q = 0; q < P; ++q) {
+        while (e < E && q >= env_off[e + 1]) { g.env_off.push_back((int32_t)g.vert_off.size() - 1); ++e; }
         const int v0 = vert_off[q], n = vert_off[q + 1] - v0;
         if (n < 3 || n > T2D_MAX_POLY_VERTS)
             return fail(p, T2D_ERR_GEOMETRY, "polygon " + std::to_string(q) + " has " +
@@ -160,17 +178,21 @@ int prepare_polys(t2d_pool* p, const int32_t* env_off, const int32_t* vert_off, 
             if (orient_h(&poly[2 * i], &poly[2 * ((i + 1) % n)], &poly[2 * ((i + 2) % n)]) < 0.0)
                 return fail(p, T2D_ERR_GEOMETRY,
                             "polygon " + std::to_string(q) + " is not convex (decompose on the host)");
-        float xmin = (float)poly[0], xmax = xmin, ymin = (float)poly[1], ymax = ymin;
         for (int i = 0; i < n; ++i) {
-            const float fx = (float)poly[2 * i], fy = (float)poly[2 * i + 1];  // exact: inputs are fp32
-            g.xy[2 * (size_t)(v0 + i)] = fx;
-            g.xy[2 * (size_t)(v0 + i) + 1] = fy;
-            xmin = std::min(xmin, fx); xmax = std::max(xmax, fx);
-            ymin = std::min(ymin, fy); ymax = std::max(ymax, fy);
+            g.ring_xy[2 * (size_t)(v0 + i)] = (float)poly[2 * i];
+            g.ring_xy[2 * (size_t)(v0 + i) + 1] = (float)poly[2 * i + 1];
         }
-        g.aabb[4 * (size_t)q] = xmin; g.aabb[4 * (size_t)q + 1] = xmax;
-        g.aabb[4 * (size_t)q + 2] = ymin; g.aabb[4 * (size_t)q + 3] = ymax;
+        if (n <= 4) {
+            const int idx[4] = {0, 1, 2, 3};
+            emit(poly.data(), idx, n);
+        } else {
+            for (int k = 1; k < n - 1; k += 2) {
+                const int idx[4] = {0, k, k + 1, k + 2};
+                emit(poly.data(), idx, k + 2 <= n - 1 ? 4 : 3);
+            }
+        }
     }
+    while (e < E) { g.env_off.push_back((int32_t)g.vert_off.size() - 1); ++e; }
     out = std::move(g);
     return T2D_OK;
 }
@@ -399,19 +421,19 @@ int rebuild_lidar_geo(t2d_pool* p) {
         if ((rc = dev_replace(p, &p->d_lidar_env_off, evo.data(), evo.size()))) return rc;
         p->lidar.max_static_verts = VS;
         p->lidar.env_vert_cnt = p->d_lidar_cnt;
-    } else if (!g.present || g.env_off[E] == 0) {
+    } else if (!g.present || g.ring_env_off[E] == 0) {
         if ((rc = dev_replace<int32_t>(p, &p->d_lidar_env_off, nullptr, 0))) return rc;
         if ((rc = dev_replace<float>(p, &p->d_lidar_xy, nullptr, 0))) return rc;
-    } else {
-        const int P = g.env_off[E], V = g.vert_off[P];
+    } else {   // the caller's rings, not the event kernels' fans
+        const int P = g.ring_env_off[E], V = g.ring_vert_off[P];
         std::vector<int32_t> evo(E + 1);
         std::vector<float> edges(4 * (size_t)V);   // one record per edge: vertex v and the next vertex of its ring
-        for (int e = 0; e <= E; ++e) evo[e] = g.vert_off[g.env_off[e]];
+        for (int e = 0; e <= E; ++e) evo[e] = g.ring_vert_off[g.ring_env_off[e]];
         for (int q = 0; q < P; ++q)
-            for (int v = g.vert_off[q]; v < g.vert_off[q + 1]; ++v) {
-                const int nx = v + 1 < g.vert_off[q + 1] ? v + 1 : g.vert_off[q];
-                edges[4 * (size_t)v] = g.xy[2 * (size_t)v]; edges[4 * (size_t)v + 1] = g.xy[2 * (size_t)v + 1];
-                edges[4 * (size_t)v + 2] = g.xy[2 * (size_t)nx]; edges[4 * (size_t)v + 3] = g.xy[2 * (size_t)nx + 1];
+            for (int v = g.ring_vert_off[q]; v < g.ring_vert_off[q + 1]; ++v) {
+                const int nx = v + 1 < g.ring_vert_off[q + 1] ? v + 1 : g.ring_vert_off[q];
+                edges[4 * (size_t)v] = g.ring_xy[2 * (size_t)v]; edges[4 * (size_t)v + 1] = g.ring_xy[2 * (size_t)v + 1];
+                edges[4 * (size_t)v + 2] = g.ring_xy[2 * (size_t)nx]; edges[4 * (size_t)v + 3] = g.ring_xy[2 * (size_t)nx + 1];
             }
         for (int e = 0; e < E; ++e) p->lidar.max_static_verts = std::max(p->lidar.max_static_verts, evo[e + 1] - evo[e]);
         if ((rc = dev_replace(p, &p->d_lidar_env_off, evo.data(), evo.size()))) return rc;

@@ -128,7 +128,7 @@ T2D_DEV bool point_in_quad(const Quad& B, double x, double y) {
     return in;
 }
 
-// ---- generic (slow, rare) paths: circles and 5..8-vertex polygons, streamed from LDS ----------
+// ---- generic (slow, rare) paths: circles (pedestrians) against polygons streamed from LDS ------
 // Kept out of line so their registers do not count against the hot quad-vs-quad code.
 struct PolyRef {           // a polygon in LDS: either fp32 interleaved x,y or an OBB in s_v planes
     const float2* f32;     // non-null: fp32 vertices
@@ -145,29 +145,6 @@ struct PolyRef {           // a polygon in LDS: either fp32 interleaved x,y or a
         }
     }
 };
-
-__device__ __noinline__ bool sat_generic(const PolyRef A, const PolyRef B) {
-    for (int pass = 0; pass < 2; ++pass) {
-        const PolyRef& P = pass == 0 ? A : B;  // edges of P against vertices of Q
-        const PolyRef& Q = pass == 0 ? B : A;
-        double px, py;
-        P.get(P.n - 1, px, py);
-        for (int i = 0; i < P.n; ++i) {
-            double qx, qy;
-            P.get(i, qx, qy);
-            bool all_out = true;
-            for (int j = 0; j < Q.n; ++j) {
-                double rx, ry;
-                Q.get(j, rx, ry);
-                all_out &= orient(px, py, qx, qy, rx, ry) < 0.0;
-            }
-            if (all_out) return false;
-            px = qx;
-            py = qy;
-        }
-    }
-    return true;
-}
 
 __device__ __noinline__ bool point_in_generic(const PolyRef B, double x, double y) {
     bool in = true;
@@ -261,8 +238,14 @@ __device__ __noinline__ uint32_t circle_lane_bits(double cx, double cy, double R
                                                   int b0, int b1) {
     uint32_t bits = point_in_generic(B, cx, cy) ? 1u : 0u;
     const double R2 = R * R;
-    for (int b = b0; b < b1; ++b)
-        if (seg_dist2(bnd[4 * b], bnd[4 * b + 1], bnd[4 * b + 2], bnd[4 * b + 3], cx, cy) < R2) bits |= 2u;
+    const double m = R + 1e-6;   // pieces whose box is further than R (+ 1 um) from the centre cannot come within R
+    for (int b = b0; b < b1; ++b) {
+        const double ax = bnd[4 * b], ay = bnd[4 * b + 1], bx = bnd[4 * b + 2], by = bnd[4 * b + 3];
+        if (__builtin_fmax(ax, bx) < cx - m || __builtin_fmin(ax, bx) > cx + m || __builtin_fmax(ay, by) < cy - m ||
+            __builtin_fmin(ay, by) > cy + m)
+            continue;
+        if (seg_dist2(ax, ay, bx, by, cx, cy) < R2) bits |= 2u;
+    }
     return bits;
 }
 
@@ -707,8 +690,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         const int v0 = vstart[p], n = vstart[p + 1] - v0;
         bool hit;
         if (s_kind[i] == T2D_SHAPE_OBB) {
-            if (n <= 4) hit = sat_quads(load_obb_lds(&s_v[0][i]), load_quad_f32(xy + 2 * v0, n));
-            else hit = sat_generic(PolyRef{nullptr, &s_v[0][i], 4}, PolyRef{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n});
+            // (3 or 4 vertices: t2d_set_static_geometry cuts larger polygons into fans of quads)
+            hit = sat_quads(load_obb_lds(&s_v[0][i]), load_quad_f32(xy + 2 * v0, n));
         } else {
             hit = circle_vs_generic((double)s_cxy[0][i], (double)s_cxy[1][i], s_rad[i],
                                     PolyRef{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n});
@@ -726,16 +709,10 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         const int v0 = vstart[p], n = vstart[p + 1] - v0;
         uint32_t bits = 0;
         if (s_kind[i] == T2D_SHAPE_OBB) {
-            if (n <= 4) {
-                const Quad A = load_obb_lds(&s_v[0][i]);
-                const Quad B = load_quad_f32(xy + 2 * v0, n);
+            const Quad A = load_obb_lds(&s_v[0][i]);
+            const Quad B = load_quad_f32(xy + 2 * v0, n);   // 3 or 4 vertices (fans of quads, t2d_set_lane_geometry)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) bits |= (uint32_t)point_in_quad(B, A.x[k], A.y[k]) << k;
-            } else {
-                const PolyRef B{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n};
-                for (int k = 0; k < 4; ++k)
-                    bits |= (uint32_t)point_in_generic(B, s_v[2 * k][i], s_v[2 * k + 1][i]) << k;
-            }
+            for (int k = 0; k < 4; ++k) bits |= (uint32_t)point_in_quad(B, A.x[k], A.y[k]) << k;
             if (bits == 15u) bits |= 16u;
         } else {
             const int* bstart = geo_i + gl.off_bstart;
@@ -757,9 +734,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         const int b0 = bstart[p], b1 = bstart[p + 1];
         const Quad A = load_obb_lds(&s_v[0][i]);
         const double cx = (double)s_cxy[0][i], cy = (double)s_cxy[1][i];
-        bool centre;
-        if (n <= 4) centre = point_in_quad(load_quad_f32(xy + 2 * v0, n), cx, cy);
-        else centre = point_in_generic(PolyRef{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n}, cx, cy);
+        const bool centre = point_in_quad(load_quad_f32(xy + 2 * v0, n), cx, cy);
         uint32_t bits = centre ? 32u : 0u;
         if (pieces_meet_quad(A, reinterpret_cast<const double*>(s_geo + gl.off_bnd), b0, b1)) bits |= 64u;
         if (bits) atomicOr(&s_flags[i], bits << kLaneShift);

@@ -153,8 +153,15 @@ struct t2d_pool {
     // host copies of the CCW-normalised CSR geometry, kind 0 static / 1 lanes
     struct HostGeo {
         bool present = false;
+        // polygons as the EVENT kernels see them: CCW, and every polygon with 5..8 vertices replaced by its fan of
+        // quads (v0 v1 v2 v3), (v0 v3 v4 v5), (v0 v5 v6 v7) (last part a triangle for odd counts): the union is the
+        // polygon, so `intersects` / point-in tests are the OR over the parts, and the kernels only ever meet 3- and
+        // 4-vertex polygons (fan_parts in oracle/t2d_oracle.c states the same)
         std::vector<int32_t> env_off, vert_off;
         std::vector<float> xy, aabb;
+        // the caller's rings, CCW, undivided: what the lidar scans (a fan's inner diagonals are not walls)
+        std::vector<int32_t> ring_env_off, ring_vert_off;
+        std::vector<float> ring_xy;
         // lanes only: boundary pieces of the union of each env's lanes, CSR per lane polygon (build_lane_boundary)
         std::vector<int32_t> bnd_off;
         std::vector<double> bnd;
