@@ -233,20 +233,19 @@ T2D_DEV bool pieces_meet_quad(const Quad& P, const double* bnd, int b0, int b1) 
     return hit;
 }
 
-// circle pose (pedestrian): bit 0 = centre in the lane polygon, bit 1 = a boundary piece inside the open disc
-__device__ __noinline__ uint32_t circle_lane_bits(double cx, double cy, double R, const PolyRef B, const double* bnd,
-                                                  int b0, int b1) {
-    uint32_t bits = point_in_generic(B, cx, cy) ? 1u : 0u;
+// circle pose (pedestrian): some boundary piece of [b0, b1) comes inside the open disc (oracle circle_in_lane_union)
+__device__ __noinline__ bool circle_pieces_within(double cx, double cy, double R, const double* bnd, int b0, int b1) {
     const double R2 = R * R;
     const double m = R + 1e-6;   // pieces whose box is further than R (+ 1 um) from the centre cannot come within R
+    bool hit = false;
     for (int b = b0; b < b1; ++b) {
         const double ax = bnd[4 * b], ay = bnd[4 * b + 1], bx = bnd[4 * b + 2], by = bnd[4 * b + 3];
         if (__builtin_fmax(ax, bx) < cx - m || __builtin_fmin(ax, bx) > cx + m || __builtin_fmax(ay, by) < cy - m ||
             __builtin_fmin(ay, by) > cy + m)
             continue;
-        if (seg_dist2(ax, ay, bx, by, cx, cy) < R2) bits |= 2u;
+        if (seg_dist2(ax, ay, bx, by, cx, cy) < R2) hit = true;
     }
-    return bits;
+    return hit;
 }
 
 // ---- IoU of two convex quads (Arrival / NoAction), oracle t2do_quad_iou: the boundary of A n B is
@@ -319,11 +318,13 @@ T2D_DEV uint32_t cell_hash(int cx, int cy) {
     return ((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u);
 }
 
-// LDS writes of this wave -> visible to the other lanes of this wave
+// LDS writes of this wave -> visible to the other lanes of this wave.  LDS operations of one wave complete in order, so
+// waiting for the outstanding ones (lgkmcnt) is all it takes; a workgroup-scope release fence would also wait for every
+// GLOBAL store in flight (vmcnt(0)) -- the state / flag / record stores just issued: 1-2 k cycles of store round trip at
+// each sync that follows them, for nothing (no other lane reads those addresses in this launch).
 T2D_DEV void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // Compact the set bits of every lane's `mask` into the wave's LDS queue (entry = tid | id << 8,
@@ -714,17 +715,16 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
 #pragma unroll
             for (int k = 0; k < 4; ++k) bits |= (uint32_t)point_in_quad(B, A.x[k], A.y[k]) << k;
             if (bits == 15u) bits |= 16u;
-        } else {
-            const int* bstart = geo_i + gl.off_bstart;
-            bits = circle_lane_bits((double)s_cxy[0][i], (double)s_cxy[1][i], s_rad[i],
-                                    PolyRef{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n},
-                                    reinterpret_cast<const double*>(s_geo + gl.off_bnd), bstart[p], bstart[p + 1]) << 5;
+        } else {   // circle: the centre now, the boundary pieces in stage 2
+            const Quad B = load_quad_f32(xy + 2 * v0, n);
+            bits = point_in_quad(B, (double)s_cxy[0][i], (double)s_cxy[1][i]) ? 32u : 0u;
         }
         if (bits) atomicOr(&s_flags[i], bits << kLaneShift);
     };
     // Stage 2, only for boxes with every vertex in some lane but no single lane holding all four (bodies straddling
-    // lanes: a few per wave), again per (participant, lane polygon) candidate: bit 5 = the centre lies in this polygon,
-    // bit 6 = one of the union's boundary pieces that are part of this polygon's edges reaches inside the open pose.
+    // lanes: a few per wave) and for circles with their centre in a lane, again per (participant, lane polygon)
+    // candidate: bit 5 = the centre lies in this polygon (boxes), bit 6 = one of the union's boundary pieces that are
+    // part of this polygon's edges reaches inside the open pose.
     auto process_lane_slow = [&](uint32_t e) {
         const int i = (int)(e & 255u), p = (int)(e >> 8);
         const int* vstart = geo_i + gl.off_vstart[1];
@@ -732,18 +732,26 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         const float* xy = reinterpret_cast<const float*>(s_geo + gl.off_xy[1]);
         const int v0 = vstart[p], n = vstart[p + 1] - v0;
         const int b0 = bstart[p], b1 = bstart[p + 1];
-        const Quad A = load_obb_lds(&s_v[0][i]);
+        const double* bnd = reinterpret_cast<const double*>(s_geo + gl.off_bnd);
         const double cx = (double)s_cxy[0][i], cy = (double)s_cxy[1][i];
-        const bool centre = point_in_quad(load_quad_f32(xy + 2 * v0, n), cx, cy);
-        uint32_t bits = centre ? 32u : 0u;
-        if (pieces_meet_quad(A, reinterpret_cast<const double*>(s_geo + gl.off_bnd), b0, b1)) bits |= 64u;
+        uint32_t bits = 0;
+        if (s_kind[i] == T2D_SHAPE_OBB) {
+            const Quad A = load_obb_lds(&s_v[0][i]);
+            if (point_in_quad(load_quad_f32(xy + 2 * v0, n), cx, cy)) bits = 32u;
+            if (pieces_meet_quad(A, bnd, b0, b1)) bits |= 64u;
+        } else if (circle_pieces_within(cx, cy, s_rad[i], bnd, b0, b1)) {   // pedestrian: a boundary piece inside the open disc
+            bits = 64u;
+        }
         if (bits) atomicOr(&s_flags[i], bits << kLaneShift);
     };
     int n_lane_polys = 0;
     // Odd waves visit the polygon stages before the pair stage: the four waves of a SIMD start together
     // and would otherwise sit in the same latency-bound (LDS compaction) or issue-bound (narrow phase)
     // stretch at the same time.  The stages are independent (results are OR-ed into s_flags).
-    const bool polys_first = log2A <= 6 && ((tid >> 6) & 1);
+    // (the workgroups of a launch go round the XCDs, then round an XCD's 32 CUs: workgroups b, b + 256, b + 512, b + 768
+    // share a CU, and wave w of each lands on SIMD w -- so the order alternates with the workgroup's round, too, or the
+    // four waves of a SIMD would all be "wave w" and keep the same order)
+    const bool polys_first = log2A <= 6 && ((((int)blockIdx.x >> 8) + (tid >> 6)) & 1);
     for (int stage_it = 0; stage_it < 2; ++stage_it) {
     if ((stage_it == 0) != polys_first) {
     if (!use_hash_grid) {
@@ -909,7 +917,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             // stage 2 of the off-lane test (every stage-1 entry of this wave's participants was processed by this wave,
             // and compact_and_process ends on a wave_sync: s_flags[tid] is complete as far as stage 1 goes)
             const uint32_t ev = s_flags[tid] >> kLaneShift;
-            const bool slow = active && kind == T2D_SHAPE_OBB && (ev & 31u) == 15u;
+            // boxes with every vertex in some lane and no single lane holding all four; circles whose centre is in a lane
+            const bool slow = active && (kind == T2D_SHAPE_OBB ? (ev & 31u) == 15u : (ev & 32u) != 0u);
             if (__ballot(slow) != 0ull) {
                 for (int c0 = 0;; c0 += 64) {
                     const int left = slow ? p1 - p0 - c0 : 0;
