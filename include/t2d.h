@@ -281,6 +281,11 @@ int t2d_check_status(t2d_pool* pool, int32_t interval_ms, void* hip_stream);
  * bit-identical.  kernel_id 2 of t2d_profile_read times the fused launch.                   */
 int t2d_step(t2d_pool* pool, int32_t interval_ms, void* hip_stream);
 int t2d_set_fused_step(t2d_pool* pool, int32_t on);
+/* Pools with ONE participant per env (ParkingEnv, BASELINE config 2) whose parameter table holds box-shaped types only
+ * and that have no lane geometry take their fused step with one WAVE per env instead of one lane per participant (the
+ * quads of the lot, the constraints of the two IoUs spread over the wave's lanes: ~2.5x faster at 4096 envs).  Same
+ * arithmetic, same results bit for bit; on by default, t2d_set_ego_kernel(pool, 0) keeps the pool on the general kernel. */
+int t2d_set_ego_kernel(t2d_pool* pool, int32_t on);
 /* One step of n pools in a single call -- env groups on separate streams (independent environments cut into
  * groups whose launches overlap: one group's start-up latency and tail hide behind the others' busy middle,
  * DESIGN.md "Env groups").  For i in [0, n): if act0 / act1 are non-NULL, t2d_bind_actions(pools[i],

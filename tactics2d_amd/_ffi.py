@@ -57,6 +57,7 @@ SYMBOLS = {
     "t2d_check_status": (C.c_int, [_vp, C.c_int32, _vp]),
     "t2d_step": (C.c_int, [_vp, C.c_int32, _vp]),
     "t2d_set_fused_step": (C.c_int, [_vp, C.c_int32]),
+    "t2d_set_ego_kernel": (C.c_int, [_vp, C.c_int32]),
     "t2d_step_groups": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32]),
     "t2d_get_field": (C.c_int, [_vp, C.c_int32, C.POINTER(_vp), C.POINTER(C.c_size_t)]),
     "t2d_download": (C.c_int, [_vp, C.c_int32, _vp, C.c_size_t]),

@@ -689,6 +689,9 @@ int t2d_set_param_table(t2d_pool* p, const double* rows, int32_t n_types, int32_
     }
     p->v.n_types = n_types;
     p->has_drift = has_drift;
+    p->all_boxes = true;
+    for (int ty = 0; ty < n_types; ++ty)
+        if ((int)p->host_params[ty][T2D_P_SHAPE] != T2D_SHAPE_OBB) p->all_boxes = false;
     p->v.cell = dmax * 1.001 + 1e-3;  // 3x3 cell neighbourhood is then provably sufficient
     p->v.inv_cell = 1.0 / p->v.cell;
     T2D_HIP(p, hipMemcpy(p->d_params, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
@@ -978,7 +981,13 @@ static int collide_impl(t2d_pool* p, bool with_status, int interval_ms, hipStrea
     touch(p, s);
     const int kid = fuse_variant >= 0 ? 2 : 1;
     if ((rc = record_event(p, kid, s, true))) return rc;
-    T2D_HIP(p, t2d::launch_collide(p->v, p->status_cfg, with_status, interval_ms, fuse_variant, s));
+    // single-ego pools (ParkingEnv: one box-shaped participant per env, no lanes) step with one WAVE per env
+    // (t2d_ego.hip) instead of one lane per participant; same arithmetic, same results (t2d_set_ego_kernel(pool, 0)
+    // keeps such a pool on the general kernel: the two are held against each other in tests/test_gpu_ego.py)
+    if (fuse_variant >= 0 && p->ego_kernel && p->v.A == 1 && p->all_boxes && !p->has_drift && !p->hgeo[1].present)
+        T2D_HIP(p, t2d::launch_ego_step(p->v, p->status_cfg, interval_ms, fuse_variant, s));
+    else
+        T2D_HIP(p, t2d::launch_collide(p->v, p->status_cfg, with_status, interval_ms, fuse_variant, s));
     return record_event(p, kid, s, false);
 }
 
@@ -1074,6 +1083,12 @@ int t2d_step_groups(t2d_pool* const* pools, const float* const* act0_dev, const 
 int t2d_set_fused_step(t2d_pool* p, int32_t on) {
     if (!p) return T2D_ERR_INVALID;
     p->fused_step = on != 0;
+    return T2D_OK;
+}
+
+int t2d_set_ego_kernel(t2d_pool* p, int32_t on) {
+    if (!p) return T2D_ERR_INVALID;
+    p->ego_kernel = on != 0;
     return T2D_OK;
 }
 

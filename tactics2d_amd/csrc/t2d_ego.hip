@@ -1,0 +1,351 @@
+// t2d_ego.hip -- the ScenarioManager step of SINGLE-EGO environments (max_agents = 1: ParkingEnv, BASELINE.json
+// config 2: 4096 vectorised parking envs x 1 ego), SIXTEEN LANES per environment.
+//
+// Replaces (reference, tactics2d v0.1.9rc3) -- the same functions as the fused step kernel of t2d_collide.hip:
+//   SingleTrackKinematics.step / _step   physics/single_track_kinematics.py:126-198 (any of the three models)
+//   Vehicle.get_pose                     participant/element/vehicle.py:263-281
+//   StaticCollision.update               traffic/event_detection/collision.py:37-43
+//   OutBound.update                      traffic/event_detection/out_bound.py:37-48
+//   Arrival.update / NoAction.update     arrival.py:32-47, no_action.py:32-53 (IoU of two quads)
+//   _ParkingScenarioManager.update + check_status, ParkingEnv.step / _get_reward   envs/parking.py:352-392, 219-256, 148-190
+//
+// Why a kernel of its own: with one participant per environment the general kernel's mapping (one lane per
+// participant) has every lane walk the whole chain alone -- 20 sub-steps, a sweep over the parking lot's quads, two quad
+// IoUs of 32 IEEE divisions each, the status epilogue: 17.5 us of dependent latency at 4096 envs (64 waves on 1024
+// SIMDs).  Here SIXTEEN lanes share one environment (four envs per wave; 4096 envs = 1024 waves = one per SIMD):
+//   * the integrator and the pose are evaluated by all 16 lanes alike (the instruction stream one lane would run);
+//   * static collision: one lane per obstacle quad (16 at a time), the verdicts meet in a ballot;
+//   * the two IoUs: 2 IoUs x 8 clipped-edge terms = 16 lanes, each term the oracle's clipped_edge_term (4 IEEE
+//     divisions in flight), the eight terms of an IoU summed in the oracle's tree ((s0+s1)+(s2+s3))+((s4+s5)+(s6+s7))
+//     -- a butterfly over neighbouring lanes, fp addition being commutative;
+//   * the epilogue runs on the group's first lane.
+// (A whole wave per env was measured first: 64 x the integrator's instructions, 25 us -- issue-bound on redundancy.)
+// Every value is produced by the arithmetic of the general kernel (same device functions, same operation order), so
+// with the exact integrator the two agree bit for bit (tests/test_gpu_ego.py), and with the oracle.
+#include "t2d_geom_dev.h"
+#include "t2d_integrate_dev.h"
+
+namespace t2d {
+
+namespace {
+
+using namespace geom;
+
+constexpr int kEgoBlock = 256;
+constexpr int kEgoLanes = 16;                        // lanes per environment
+constexpr int kEgoPerWave = 64 / kEgoLanes;          // environments per wave
+constexpr int kEgoPerBlock = kEgoBlock / kEgoLanes;  // environments per workgroup
+
+T2D_DEV void ego_wave_sync() {   // LDS writes of this wave -> visible to its other lanes
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int VARIANT>
+__global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d_status_config cfg, int interval_ms) {
+    // the two quads of each IoU, [env of the workgroup][iou][A | B][x0 y0 ... x3 y3]
+    __shared__ double s_quad[kEgoPerBlock][2][2][8];
+    const int lane = threadIdx.x & 63;
+    const int l = threadIdx.x & (kEgoLanes - 1);        // lane inside the env's group
+    const int grp = threadIdx.x / kEgoLanes;            // env inside the workgroup
+    const int gbase = lane & ~(kEgoLanes - 1);          // first lane of the group inside the wave
+    const unsigned long long gmask = ((1ull << kEgoLanes) - 1ull) << gbase;
+    const int env_raw = blockIdx.x * kEgoPerBlock + grp;
+    const bool live = env_raw < pv.n_env;               // (padding groups of the last workgroup run along on env 0, write nothing)
+    const int env = live ? env_raw : 0;
+    const int idx = env;                                // max_agents == 1
+
+    // ---------------- loads (group-uniform addresses) -------------------------------------------------------------
+    const uint32_t ids = pv.ids[idx];
+    float fx = pv.x[idx], fy = pv.y[idx], fh = pv.heading[idx];
+    const float fv = pv.speed[idx];
+    float fa0 = pv.act0[idx], fa1 = pv.act1[idx];
+    if (pv.idm_ctrl && pv.idm_ctrl[idx] != T2D_IDM_NONE) {
+        fa0 = pv.own_act0[idx];
+        fa1 = pv.own_act1[idx];
+    }
+    const int pre_cnt = pv.cnt_step[env], pre_frame = pv.frame_ms[env];
+    float bxmin = 0, bxmax = 0, bymin = 0, bymax = 0;
+    bool has_boundary = false;
+    if (pv.boundary) {
+        const float4 b = reinterpret_cast<const float4*>(pv.boundary)[env];
+        bxmin = b.x; bxmax = b.y; bymin = b.z; bymax = b.w;
+        has_boundary = pv.boundary_valid ? pv.boundary_valid[env] != 0 : true;
+    }
+    // this env's obstacle quads in the packed geometry record of its group of envs (t2d_pool.h GeoLayout)
+    const GeoLayout& gl = pv.geo_layout;
+    int p0 = 0, p1 = 0;
+    const uint32_t* rec = nullptr;
+    if (pv.geo && gl.has[0]) {
+        rec = pv.geo + (size_t)(env / gl.epb) * gl.stride;
+        const int* pstart = reinterpret_cast<const int*>(rec) + gl.off_pstart[0];
+        const int el = env % gl.epb;
+        p0 = pstart[el];
+        p1 = pstart[el + 1];
+    }
+
+    const bool active = live && ((ids >> kIdsActiveShift) & 0xffu);
+    const int type = (ids >> kIdsTypeShift) & 0xff;
+    const int model = (ids >> kIdsModelShift) & 0xff;
+    auto P = [&](int col) -> double { return pv.params[col * T2D_MAX_TYPES + type]; };
+
+    // ---------------- physics: one PhysicsModelBase.step, the group's lanes all the same --------------------------
+    if (active && model != T2D_MODEL_DRIFT) {   // (SingleTrackDrift participants are integrated by drift_kernel)
+        double pvx = 0.0, pvy = 0.0;
+        if (model == T2D_MODEL_POINTMASS) {
+            pvx = (double)pv.vx[idx];
+            pvy = (double)pv.vy[idx];
+        }
+        const integ::StepOut o = integ::step_participant<VARIANT>(model, P, (double)fx, (double)fy, (double)fh, (double)fv, pvx,
+                                                                  pvy, (double)fa0, (double)fa1, interval_ms);
+        fx = (float)o.x;
+        fy = (float)o.y;
+        fh = (float)o.heading;
+        if (l == 0) {
+            pv.x[idx] = fx;
+            pv.y[idx] = fy;
+            pv.heading[idx] = fh;
+            pv.speed[idx] = (float)o.speed;
+            if (o.has_velocity) {
+                pv.vx[idx] = (float)o.vx;
+                pv.vy[idx] = (float)o.vy;
+            }
+            pv.applied0[idx] = (float)o.app0;
+            pv.applied1[idx] = (float)o.app1;
+        }
+    }
+    double pre_tp = 0.0;
+    if (pv.time_penalty && cfg.max_step > 0) {
+        const int c = pre_cnt + 1;
+        pre_tp = pv.time_penalty[c < cfg.max_step ? c : cfg.max_step];
+    }
+
+    // ---------------- pose, out-of-bound, conservative fp32 box (as in collide_kernel phase 1) ---------------------
+    Quad A{};
+    bool ego_obb = false;
+    uint32_t f = 0;
+    float box_lo_x = 0, box_hi_x = 0, box_lo_y = 0, box_hi_y = 0;
+    const double cx = (double)fx, cy = (double)fy;
+    if (active) {
+        const int kind = (int)P(T2D_P_SHAPE);
+        const double L = P(T2D_P_LENGTH), W = P(T2D_P_WIDTH);
+        double lo_x, hi_x, lo_y, hi_y;
+        bool out = false;
+        if (kind == T2D_SHAPE_OBB) {
+            ego_obb = true;
+            double s, c;
+            sincos_det((double)fh, s, c);
+            const double hl = 0.5 * L, hw = 0.5 * W;
+            const double lx[4] = {hl, hl, -hl, -hl};
+            const double ly[4] = {-hw, hw, hw, -hw};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                A.x[k] = c * lx[k] - s * ly[k] + cx;
+                A.y[k] = s * lx[k] + c * ly[k] + cy;
+            }
+            lo_x = hi_x = A.x[0];
+            lo_y = hi_y = A.y[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                lo_x = A.x[k] < lo_x ? A.x[k] : lo_x; hi_x = A.x[k] > hi_x ? A.x[k] : hi_x;
+                lo_y = A.y[k] < lo_y ? A.y[k] : lo_y; hi_y = A.y[k] > hi_y ? A.y[k] : hi_y;
+            }
+            if (has_boundary)
+                out = lo_x < (double)bxmin || hi_x > (double)bxmax || lo_y < (double)bymin || hi_y > (double)bymax;
+        } else {   // (a circular ego never reaches this kernel: the host keeps such pools on the general one)
+            const double rad = 0.5 * W;
+            lo_x = cx - rad; hi_x = cx + rad; lo_y = cy - rad; hi_y = cy + rad;
+            if (has_boundary)
+                out = cx - rad < (double)bxmin || cx + rad > (double)bxmax || cy - rad < (double)bymin ||
+                      cy + rad > (double)bymax;
+        }
+        if (out) f |= T2D_FLAG_OUT_BOUND;
+        box_lo_x = (float)lo_x; box_lo_x -= __builtin_fabsf(box_lo_x) * 1.2e-7f + 1e-6f;
+        box_hi_x = (float)hi_x; box_hi_x += __builtin_fabsf(box_hi_x) * 1.2e-7f + 1e-6f;
+        box_lo_y = (float)lo_y; box_lo_y -= __builtin_fabsf(box_lo_y) * 1.2e-7f + 1e-6f;
+        box_hi_y = (float)hi_y; box_hi_y += __builtin_fabsf(box_hi_y) * 1.2e-7f + 1e-6f;
+    }
+
+    // ---------------- static collision: one obstacle quad per lane, 16 at a time ------------------------------------
+    {
+        bool hit = false;
+        for (int c0 = 0;; c0 += kEgoLanes) {
+            if (__ballot(ego_obb && p0 + c0 < p1) == 0ull) break;
+            const int p = p0 + c0 + l;
+            bool near = false;
+            int v0 = 0, n = 0;
+            if (ego_obb && p < p1) {
+                const float4 bb = reinterpret_cast<const float4*>(rec + gl.off_aabb[0])[p];
+                const int* vstart = reinterpret_cast<const int*>(rec) + gl.off_vstart[0];
+                v0 = vstart[p];
+                n = vstart[p + 1] - v0;
+                // boxes that do not meet cannot intersect (the pose box is rounded outwards: strictly conservative)
+                near = !(bb.x > box_hi_x || bb.y < box_lo_x || bb.z > box_hi_y || bb.w < box_lo_y);
+            }
+            if (__ballot(near) != 0ull) {
+                if (near) {
+                    const float* xy = reinterpret_cast<const float*>(rec + gl.off_xy[0]);
+                    hit |= sat_quads(A, load_quad_f32(xy + 2 * v0, n));
+                }
+            }
+        }
+        if ((__ballot(hit) & gmask) != 0ull) f |= T2D_FLAG_COLLISION_STATIC;
+    }
+    if (live && l == 0) {
+        pv.flags[idx] = f;
+        pv.env_flags[env] = f;
+    }
+
+    // ---------------- the two quad IoUs of the ego: 16 lanes = 2 IoUs x 8 clipped-edge terms -----------------------
+    double iou_na = 0.0, iou_ar = 0.0;
+    if (__ballot(ego_obb && (cfg.check_no_action || cfg.check_arrival)) != 0ull) {
+        const bool mine = ego_obb && (cfg.check_no_action || cfg.check_arrival);
+        const int k = l >> 3;      // 0: NoAction (pose vs the previous pose), 1: Arrival (pose vs the target bay)
+        const int t = l & 7;       // term: 0-3 = edges of the pose clipped to the other quad, 4-7 = the other way round
+        const bool want = mine && (k == 0 ? (cfg.check_no_action && pv.last_valid[env])
+                                          : (cfg.check_arrival && pv.target_xy != nullptr));
+        const double* other = k == 0 ? pv.last_pose + 8 * (size_t)env : pv.target_xy + 8 * (size_t)env;
+        {   // lane t of each IoU writes coordinate t of A (the pose, from registers) and of B
+            double v = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v = t == 2 * q ? A.x[q] : v;
+                v = t == 2 * q + 1 ? A.y[q] : v;
+            }
+            s_quad[grp][k][0][t] = v;
+            s_quad[grp][k][1][t] = want ? other[t] : 0.0;
+        }
+        ego_wave_sync();
+        double value = 0.0;
+        if (__ballot(want) != 0ull) {
+            Quad QA, QB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                QA.x[q] = s_quad[grp][k][0][2 * q]; QA.y[q] = s_quad[grp][k][0][2 * q + 1];
+                QB.x[q] = s_quad[grp][k][1][2 * q]; QB.y[q] = s_quad[grp][k][1][2 * q + 1];
+            }
+            const bool strict = t >= 4;   // edges of B are clipped to A with coincident boundary pieces dropped
+            const double* S = s_quad[grp][k][strict ? 1 : 0];
+            const int i0 = t & 3, i1 = (t + 1) & 3;
+            const double p0x = S[2 * i0], p0y = S[2 * i0 + 1], p1x = S[2 * i1], p1y = S[2 * i1 + 1];
+            double s = clipped_edge_term(p0x, p0y, p1x, p1y, strict ? QA : QB, strict, QA.x[0], QA.y[0]);
+            // ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7)): the terms sit on neighbouring lanes
+            s = s + __shfl_xor(s, 1);
+            s = s + __shfl_xor(s, 2);
+            s = s + __shfl_xor(s, 4);
+            double inter = s;
+            if (inter < 0.0) inter = 0.0;
+            const double uni = quad_area2(QA) + quad_area2(QB) - inter;
+            value = want ? inter / uni : 0.0;
+        }
+        iou_na = __shfl(value, gbase);
+        iou_ar = __shfl(value, gbase + 8);
+    }
+
+    // ---------------- status / reward epilogue (collide_kernel phase 3), the group's first lane --------------------
+    if (!live || l != 0) return;
+    const int cnt = pre_cnt + 1;  // parking.py:353
+    pv.cnt_step[env] = cnt;
+    pv.frame_ms[env] = pre_frame + interval_ms;
+    int scen = T2D_SCENARIO_NORMAL, traf = T2D_TRAFFIC_NORMAL;
+    double iou = 0.0;
+    bool has_iou = false;
+    if (cfg.max_step > 0 && cnt > cfg.max_step) {
+        scen = T2D_SCENARIO_TIME_EXCEEDED;  // later detectors are not updated (parking.py:366-369)
+    } else {
+        bool na = false;
+        if (cfg.check_no_action && ego_obb) {  // NoAction.update (no_action.py:41-53)
+            double* last = pv.last_pose + 8 * (size_t)env;
+            int cna = pv.cnt_na[env];
+            if (!pv.last_valid[env]) {
+                pv.last_valid[env] = 1;
+            } else {
+                cna = iou_na > (double)cfg.no_action_iou ? cna + 1 : 0;
+                pv.cnt_na[env] = cna;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                last[2 * k] = A.x[k];
+                last[2 * k + 1] = A.y[k];
+            }
+            na = cna > cfg.no_action_max_step;
+        }
+        if (na) {
+            traf = T2D_TRAFFIC_NO_ACTION_QUIRK;  // parking.py:373 writes ScenarioStatus.NO_ACTION here
+        } else if (f & T2D_FLAG_OUT_BOUND) {
+            scen = T2D_SCENARIO_OUT_BOUND;
+        } else if (f & T2D_FLAG_COLLISION_STATIC) {
+            scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_COLLISION_STATIC;
+        } else if (cfg.check_arrival && pv.target_xy && ego_obb) {  // Arrival.update (arrival.py:42-47)
+            iou = iou_ar;
+            has_iou = true;
+            if (iou >= (double)cfg.arrival_threshold) scen = T2D_SCENARIO_COMPLETED;
+        }
+    }
+    double rd;  // ParkingEnv._get_reward (envs/parking.py:148-190)
+    if (traf == T2D_TRAFFIC_COLLISION_STATIC) rd = cfg.reward_collision;
+    else if (scen == T2D_SCENARIO_TIME_EXCEEDED || scen == T2D_SCENARIO_NO_ACTION) rd = cfg.reward_time_exceed;
+    else if (scen == T2D_SCENARIO_OUT_BOUND) rd = cfg.reward_out_bound;
+    else if (scen == T2D_SCENARIO_COMPLETED) rd = cfg.reward_completed;
+    else {
+        rd = cfg.max_step > 0 ? (pv.time_penalty ? pre_tp : -tanh((double)cnt / (double)cfg.max_step) * (double)cfg.time_penalty_scale) : 0.0;
+        if (cfg.shaped_reward) {
+            double mi = pv.max_iou[env];
+            double iou_reward = 0.0;
+            if (has_iou) iou_reward = mi == -INFINITY ? iou : iou - mi;
+            rd = rd + iou_reward;
+            if (has_iou) pv.max_iou[env] = mi > iou ? mi : iou;
+            if (pv.target_c) {
+                const double dx = cx - pv.target_c[2 * (size_t)env];
+                const double dy = cy - pv.target_c[2 * (size_t)env + 1];
+                const double d = __builtin_sqrt(dx * dx + dy * dy);
+                const double md = pv.min_dist[env];
+                if (d < md) {
+                    rd += (md - d) * (double)cfg.dist_reward_scale;
+                    pv.min_dist[env] = d;
+                }
+            }
+        }
+    }
+    const float r = (float)rd;
+    pv.iou[env] = has_iou ? (float)iou : __builtin_nanf("");
+    const bool terminated = scen == T2D_SCENARIO_COMPLETED;
+    const bool truncated = !terminated && (scen != T2D_SCENARIO_NORMAL || traf != T2D_TRAFFIC_NORMAL);
+    uchar4 st;
+    st.x = (unsigned char)scen; st.y = (unsigned char)traf;
+    st.z = terminated; st.w = truncated;
+    reinterpret_cast<uchar4*>(pv.status)[env] = st;
+    pv.reward[env] = r;
+    pv.record[env] = make_uint2(__float_as_uint(r), (uint32_t)scen | (uint32_t)traf << 8 |
+                                                        (uint32_t)terminated << 16 | (uint32_t)truncated << 24);
+    if (pv.auto_reset && (terminated || truncated)) {  // ParkingEnv.reset: state, counters, detector state back to the start
+        pv.cnt_step[env] = 0;
+        pv.frame_ms[env] = 0;
+        pv.last_valid[env] = 0;
+        pv.cnt_na[env] = 0;
+        pv.max_iou[env] = -INFINITY;
+        pv.min_dist[env] = pv.snap_min_dist[env];
+        pv.x[idx] = pv.snap[0][idx];
+        pv.y[idx] = pv.snap[1][idx];
+        pv.heading[idx] = pv.snap[2][idx];
+        pv.speed[idx] = pv.snap[3][idx];
+        pv.vx[idx] = pv.snap[4][idx];
+        pv.vy[idx] = pv.snap[5][idx];
+        pv.ids[idx] = pv.snap_ids[idx];
+        if (pv.snap_omega[0]) {
+            pv.omega_f[idx] = pv.snap_omega[0][idx];
+            pv.omega_r[idx] = pv.snap_omega[1][idx];
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_ego_step(const PoolView& v, const t2d_status_config& cfg, int interval_ms, int variant, hipStream_t s) {
+    const dim3 grid((v.n_env + kEgoPerBlock - 1) / kEgoPerBlock), block(kEgoBlock);
+    if (variant == 0) hipLaunchKernelGGL(ego_step_kernel<0>, grid, block, 0, s, v, cfg, interval_ms);
+    else hipLaunchKernelGGL(ego_step_kernel<1>, grid, block, 0, s, v, cfg, interval_ms);
+    return hipGetLastError();
+}
+
+}  // namespace t2d

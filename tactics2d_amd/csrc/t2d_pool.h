@@ -140,6 +140,8 @@ struct t2d_pool {
     bool have_reset = false;
     int integrator_variant = 1;
     bool fused_step = true;  // t2d_step = one launch (integrate + events + status)
+    bool ego_kernel = true;  // single-ego pools step with one wave per env (t2d_ego.hip) when they qualify
+    bool all_boxes = false;  // every row of the parameter table is T2D_SHAPE_OBB
     t2d_status_config status_cfg{};
     std::string err;
     double host_params[T2D_MAX_TYPES][T2D_PARAM_COLS]{};
@@ -225,6 +227,7 @@ namespace t2d {
 hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hipStream_t s);
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
                           int interval_ms, int fuse_variant, hipStream_t s);
+hipError_t launch_ego_step(const PoolView& v, const t2d_status_config& cfg, int interval_ms, int variant, hipStream_t s);
 hipError_t step_occupancy(const PoolView& v, int* blocks_per_cu, size_t* lds_bytes);
 hipError_t launch_lidar(const PoolView& v, const LidarView& lv, float* out, hipStream_t s);
 hipError_t launch_drift(const PoolView& v, int interval_ms, hipStream_t s);

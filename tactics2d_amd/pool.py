@@ -261,6 +261,10 @@ class ParticipantPool:
         """step() as one fused launch (default) or as integrate + check_status (two launches)."""
         self._ck(self._lib.t2d_set_fused_step(self._h, int(bool(on))))
 
+    def set_ego_kernel(self, on=True):
+        """single-ego pools: one wave per env (default) or the general one-lane-per-participant kernel"""
+        self._ck(self._lib.t2d_set_ego_kernel(self._h, int(bool(on))))
+
     def set_auto_reset(self, on=True):
         """Fuse the reset of finished envs (to the snapshot) into every step()."""
         self._ck(self._lib.t2d_set_auto_reset(self._h, int(bool(on))))
