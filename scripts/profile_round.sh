@@ -13,5 +13,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o b
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o bench -- $BENCH --no-profile > $OUT/bench_write.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -o cal -- python scripts/calib_traffic.py > $OUT/cal_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -o cal -- python scripts/calib_traffic.py > $OUT/cal_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq -o bench -- $BENCH --no-profile > $OUT/bench_sq.log 2>&1
+# (the SQ_WAIT_* counters slow the kernel by ~20 %: not collected with the ones ratios are taken from)
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq -o bench -- $BENCH --no-profile > $OUT/bench_sq.log 2>&1
 python scripts/summarize_profile.py $OUT $TAG

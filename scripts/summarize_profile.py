@@ -19,7 +19,7 @@ def short(name):
     return name[:40]
 
 
-summary = {"tag": tag, "command": "python bench.py --steps 200 --warmup 20 --no-cpu-baseline"}
+summary = {"tag": tag, "command": "python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-configs --groups 1"}
 f = find("trace", "kernel_trace.csv")
 if f:
     d = collections.defaultdict(list)
@@ -76,4 +76,19 @@ for log in ("bench_trace.log",):
             summary["bench_json"] = json.loads(lines[-1])
 os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
 json.dump(summary, open(os.path.join(root, "gpurun_out", f"{tag}_summary.json"), "w"), indent=1)
+if "kernel_stats_csv" in summary:
+    open(os.path.join(root, "gpurun_out", f"{tag}_kernel_stats.csv"), "w").write(summary["kernel_stats_csv"])
+# what bench.py reads for roofline.traffic / the VALU-issue roofline (PMC counters cannot be read in-process)
+bj = summary.get("bench_json", {}).get("config", {})
+latest = dict(tag=tag, config=bj.get("config", "metric"), envs_per_gpu=bj.get("envs_per_gpu", 4096),
+              participants_per_env=bj.get("participants_per_env", 64), groups=bj.get("env_groups", 1),
+              hbm_bytes_per_launch={k: v["hbm_bytes_corrected"] for k, v in traffic.items() if "kernel" in k},
+              fetch_factor=cal.get("fetch_factor"), write_factor=cal.get("write_factor"),
+              source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (scripts/profile_round.sh); FETCH_SIZE "
+                     "and WRITE_SIZE scaled by the factors calibrated on restore_kernel's known byte count (same 4-B/lane pattern)",
+              sq_counters_per_dispatch=sq,
+              sq_source="rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES "
+                        "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY pass of the headline command; SQ_ACTIVE_INST_* count quad-cycles",
+              kernel_trace_avg_us={k: v["avg_us"] for k, v in summary.get("kernel_trace", {}).items()})
+json.dump(latest, open(os.path.join(root, "gpurun_out", f"{tag}_traffic_latest.json"), "w"), indent=1)
 print(json.dumps({k: summary[k] for k in ("kernel_trace", "traffic_calibration", "traffic") if k in summary}, indent=1)[:3000])

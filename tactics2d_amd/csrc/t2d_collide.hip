@@ -356,10 +356,6 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     // the status epilogue's inputs, fetched now by the lane that will run it (agent 0): their latency
     // would otherwise sit, unhidden, at the very end of the wave
     int pre_cnt = 0, pre_frame = 0;
-    if (WITH_STATUS && valid && agent == 0) {
-        pre_cnt = pv.cnt_step[env];
-        pre_frame = pv.frame_ms[env];
-    }
     if (valid) {
         ids = pv.ids[idx];
         fx = pv.x[idx];
@@ -481,13 +477,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         pv.applied1[idx] = (float)o.app1;
     }
     T2D_MARK(13);
-    // the time-penalty of the step count this step will reach (table built by t2d_set_status_config); pre_cnt has
-    // arrived by now, and this load's latency hides behind the event phases
     double pre_tp = 0.0;
-    if (WITH_STATUS && valid && agent == 0 && pv.time_penalty && cfg.max_step > 0) {
-        const int c = pre_cnt + 1;
-        pre_tp = pv.time_penalty[c < cfg.max_step ? c : cfg.max_step];
-    }
     if (FUSE >= 0 && valid && pv.boundary) {  // L2-resident by now (16 B per env)
         const float4 b = reinterpret_cast<const float4*>(pv.boundary)[env];
         bxmin = b.x; bxmax = b.y; bymin = b.z; bymax = b.w;
@@ -837,6 +827,17 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     }
     }
     // ---------------- phase 3: reduce + status epilogue ------------------------------------
+    // the status epilogue's inputs, requested now by the lane that will run it (agent 0): the reduce hides part of their
+    // latency.  (Fetched at the top of the kernel they sat in registers through every event phase, and at the 128
+    // registers of 4 waves / SIMD that meant scratch spills: 8 B per lane stored and re-read, 13 MB of HBM traffic.)
+    if (WITH_STATUS && valid && agent == 0) {
+        pre_cnt = pv.cnt_step[env];
+        pre_frame = pv.frame_ms[env];
+        if (pv.time_penalty && cfg.max_step > 0) {
+            const int c = pre_cnt + 1;
+            pre_tp = pv.time_penalty[c < cfg.max_step ? c : cfg.max_step];
+        }
+    }
     T2D_MARK(9);
     if (log2A <= 6) wave_sync(); else __syncthreads();  // (c) every queue drained: s_flags complete
     T2D_MARK(10);

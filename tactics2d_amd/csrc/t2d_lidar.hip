@@ -245,10 +245,9 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     const int lane = tid & 63, wave = tid >> 6;
     uint32_t* const queue = s_queue + wave * kLidarQueue;
     int* const qcount = &s_qcount[wave];
-    auto wave_sync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    auto wave_sync = [] {   // LDS traffic of this wave only: its LDS operations complete in order (see t2d_collide.hip)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     const bool scan = s_ego_active && n_slots > 0;
     const int n_iter = (lv.n_beams + kLidarBlock - 1) / kLidarBlock;
