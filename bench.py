@@ -241,6 +241,8 @@ def main():
     eg = EnvGroups(scene, G, device_id=local_rank)
     N = scene.n
 
+    geo_record_bytes = sum(p.geometry_bytes_per_launch() for p in eg.pools)
+
     def setup(p):
         p.set_integrator_variant(args.variant)
         p.set_fused_step(not args.split)
@@ -426,11 +428,9 @@ def main():
 
     if rank == 0:
         value = world * N * args.steps / elapsed
-        geo_bytes = 0
-        for csr in (scene.static, scene.lanes):
-            if csr is not None:
-                geo_bytes += 8 * int(csr[1][-1])
-        geo_bytes += 16 * n_env
+        # geometry the step reads per launch: the packed per-workgroup records (fp32 vertices and boxes, the fp64
+        # boundary pieces of the lane unions, index ranges) as the library lays them out + the 16-B map boundary per env
+        geo_bytes = geo_record_bytes + 16 * n_env
         roof = None
         if kern:
             # ALGORITHMIC bytes of ONE launch = one env group of N / G participants

@@ -452,10 +452,12 @@ int t2d_comm_init(t2d_pool* pool, const uint8_t* id, int32_t rank, int32_t world
 int t2d_gather(t2d_pool* pool, void* nccl_comm, int32_t n_steps, void* out_dev, void* hip_stream);
 int t2d_gather_wait(t2d_pool* pool, void* hip_stream, int32_t block_host);
 
-/* Introspection: resident workgroups per CU of the fused step kernel with this pool's geometry, and its LDS bytes
- * per workgroup (static tables + the workgroup's geometry record).  The 4096 x 64 metric launch is one wave-round
- * of 1024 workgroups on 256 CUs and needs 4; a scene whose record grows past the LDS budget halves the rate.    */
-int t2d_debug_step_occupancy(t2d_pool* pool, int32_t* blocks_per_cu, int64_t* lds_bytes);
+/* Introspection: resident workgroups per CU of the fused step kernel with this pool's geometry, its LDS bytes per
+ * workgroup (static tables + the workgroup's geometry record), and (may be NULL) the bytes of packed geometry records
+ * the workgroups of one step launch stage into LDS.  The 4096 x 64 metric launch is one wave-round of 1024 workgroups
+ * on 256 CUs and needs 4; a scene whose record grows past the LDS budget halves the rate.                          */
+int t2d_debug_step_occupancy(t2d_pool* pool, int32_t* blocks_per_cu, int64_t* lds_bytes,
+                             int64_t* geometry_bytes_per_launch);
 
 #ifdef __cplusplus
 }

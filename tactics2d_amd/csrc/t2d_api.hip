@@ -1395,7 +1395,7 @@ int t2d_gather_wait(t2d_pool* p, void* hip_stream, int32_t block_host) {
 
 // introspection (not part of the ABI of include/t2d.h): resident workgroups per CU of the fused step kernel for this
 // pool's geometry, and its LDS bytes per workgroup -- the regression guard of tests/test_gpu_api.py
-int t2d_debug_step_occupancy(t2d_pool* p, int32_t* blocks_per_cu, int64_t* lds_bytes) {
+int t2d_debug_step_occupancy(t2d_pool* p, int32_t* blocks_per_cu, int64_t* lds_bytes, int64_t* geometry_bytes_per_launch) {
     if (!p || !blocks_per_cu || !lds_bytes) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));
     int b = 0;
@@ -1403,6 +1403,11 @@ int t2d_debug_step_occupancy(t2d_pool* p, int32_t* blocks_per_cu, int64_t* lds_b
     T2D_HIP(p, t2d::step_occupancy(p->v, &b, &l));
     *blocks_per_cu = b;
     *lds_bytes = (int64_t)l;
+    if (geometry_bytes_per_launch) {   // the packed records every workgroup of a step launch stages into LDS
+        const int epb = p->v.geo_layout.epb > 0 ? p->v.geo_layout.epb : 1;
+        const int64_t n_blocks = (p->v.n_env + epb - 1) / epb;
+        *geometry_bytes_per_launch = p->v.geo ? n_blocks * (int64_t)p->v.geo_layout.stride * 4 : 0;
+    }
     return T2D_OK;
 }
 

@@ -476,6 +476,9 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         pv.applied0[idx] = (float)o.app0;
         pv.applied1[idx] = (float)o.app1;
     }
+    // the event phases are chains of LDS round trips and syncs: a wave in them should get its issue slot the moment it is
+    // ready, ahead of the SIMD's waves that are still in the (issue-hungry) integrator
+    if (FUSE >= 0) __builtin_amdgcn_s_setprio(2);
     T2D_MARK(13);
     double pre_tp = 0.0;
     if (FUSE >= 0 && valid && pv.boundary) {  // L2-resident by now (16 B per env)

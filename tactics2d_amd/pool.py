@@ -297,9 +297,15 @@ class ParticipantPool:
 
     def step_occupancy(self):
         """(resident workgroups per CU, LDS bytes per workgroup) of the fused step kernel with this pool's geometry."""
-        b, l = C.c_int32(), C.c_int64()
-        self._ck(self._lib.t2d_debug_step_occupancy(self._h, C.byref(b), C.byref(l)))
+        b, l, g = C.c_int32(), C.c_int64(), C.c_int64()
+        self._ck(self._lib.t2d_debug_step_occupancy(self._h, C.byref(b), C.byref(l), C.byref(g)))
         return b.value, l.value
+
+    def geometry_bytes_per_launch(self):
+        """bytes of packed geometry records (polygons, boxes, lane-union boundary pieces) one step launch stages into LDS"""
+        b, l, g = C.c_int32(), C.c_int64(), C.c_int64()
+        self._ck(self._lib.t2d_debug_step_occupancy(self._h, C.byref(b), C.byref(l), C.byref(g)))
+        return g.value
 
     # ---------------------------------------------------------------- profiling
     def profile_enable(self, on=True):

@@ -204,3 +204,57 @@ def test_metric_scene_keeps_four_workgroups_per_cu():
     pool.close()
     print(f"step kernel: {blocks} workgroups / CU, {lds} B of LDS per workgroup")
     assert blocks >= 4, (blocks, lds)
+
+
+def test_bound_action_memory_is_read_only_and_uploads_end_a_binding():
+    """(1) IDM agents must not write into caller-owned action tensors bound with t2d_bind_actions (the
+    controlled lanes take their action from the pool's own fields instead); (2) t2d_upload of an action field ends a
+    binding -- the kernels would otherwise keep reading the caller's stale tensors; (3) the lidar buffer survives a
+    reconfiguration with the same beam count (zero-copy views stay valid)."""
+    torch = pytest.importorskip("torch")
+    from tactics2d_amd import layout as L, scenarios as S
+    from tactics2d_amd.controller import IDMController, install
+    from tactics2d_amd.pool import ParticipantPool
+    sc = S.highway(24, 64, seed=4)
+    rng = np.random.default_rng(0)
+    a0, a1 = sc.sample_actions(rng)
+    cid = np.full((sc.n_env, sc.A), L.IDM_NONE, np.uint8)
+    cid[:, 1::2] = 0                                           # every other participant follows its leader
+    pools = []
+    for _ in range(2):
+        p = ParticipantPool(sc.n_env, sc.A)
+        sc.load(p)
+        p.set_integrator_variant("exact")
+        install(p, [IDMController(desired_speed=25.0, horizon=120.0)], cid.reshape(-1))
+        pools.append(p)
+    a, b = pools
+    t0, t1 = torch.from_numpy(a0).cuda(), torch.from_numpy(a1).cuda()
+    keep0, keep1 = t0.clone(), t1.clone()
+    a.bind_actions(t0.data_ptr(), t1.data_ptr())               # pool a: caller-owned tensors
+    b.set_actions(a0, a1)                                      # pool b: the pool's own fields
+    for _ in range(3):
+        a.step(100); b.step(100)
+    torch.cuda.synchronize()
+    assert torch.equal(t0, keep0) and torch.equal(t1, keep1), "IDM wrote into bound action memory"
+    for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_LEADER):
+        assert np.array_equal(a.download(f), b.download(f)), f
+    act = a.download(L.F_ACT0).reshape(sc.n_env, sc.A)
+    assert (act[:, 1::2] != a0.reshape(sc.n_env, sc.A)[:, 1::2]).any()    # the IDM accelerations live in the pool's field
+    # (2) an upload ends the binding
+    z = np.zeros(sc.n, np.float32)
+    a.set_actions(z, z); b.set_actions(z, z)
+    t0.fill_(3.0)                                              # a stale tensor nobody should read any more
+    a.step(100); b.step(100)
+    for f in (L.F_X, L.F_SPEED, L.F_APPLIED0):
+        assert np.array_equal(a.download(f), b.download(f)), f
+    a.close(); b.close()
+    # (3) the lidar buffer is kept across a reconfiguration with the same beam count
+    sp = S.parking(16)
+    p = ParticipantPool(sp.n_env, sp.A); sp.load(p)
+    p.lidar_config(360, 20.0, False)
+    ptr = p.field_ptr(L.F_LIDAR)[0]
+    p.lidar_config(360, 20.0, False)
+    assert p.field_ptr(L.F_LIDAR)[0] == ptr
+    p.lidar_config(180, 20.0, False)
+    assert p.field_ptr(L.F_LIDAR)[1] == 16 * 180 * 4
+    p.close()
