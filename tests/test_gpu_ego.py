@@ -113,10 +113,10 @@ def test_wave_per_env_kernel_on_generated_lots_and_odd_sizes():
         ended += int(a.download(L.F_STATUS)[:, 3].sum())
     assert ended >= 1027                                       # every env ran into the 40-step limit at least once
     a.close(); b.close()
-    # (b) plain static scene with triangles, no targets / boundary / IoU events; 70 obstacles per env (two rounds of lanes)
+    # (b) plain static scene with triangles, no targets / boundary / IoU events; up to 18 obstacles per env (two rounds of 16 lanes)
     import helpers as H
     n = 203
-    sc = H.random_scene(rng, n, 1, (30.0, 20.0), n_static=70, with_peds=False, inactive_frac=0.05, bounded=False)
+    sc = H.random_scene(rng, n, 1, (30.0, 20.0), n_static=18, with_peds=False, inactive_frac=0.05, bounded=False)
     eo, vo, xy = sc["static"]
     keep = np.ones(len(xy), bool)
     for q in range(0, len(vo) - 1, 3):                         # every third quad loses a vertex: a triangle
