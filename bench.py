@@ -303,7 +303,7 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for k in range(args.warmup):
         one_step(k)

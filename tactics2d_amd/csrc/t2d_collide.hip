@@ -221,12 +221,14 @@ T2D_DEV uint32_t cell_hash(int cx, int cy) {
     return ((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u);
 }
 
-// LDS writes of this wave -> visible to the other lanes of this wave.  LDS operations of one wave complete in order, so
-// waiting for the outstanding ones (lgkmcnt) is all it takes; a workgroup-scope release fence would also wait for every
-// GLOBAL store in flight (vmcnt(0)) -- the state / flag / record stores just issued: 1-2 k cycles of store round trip at
-// each sync that follows them, for nothing (no other lane reads those addresses in this launch).
+// LDS writes of this wave -> visible to the other lanes of this wave.  The LDS executes one wave's operations in the
+// order they were issued, so a read (or atomic) that follows a write in program order sees it whichever lane wrote: all
+// that is needed is that the COMPILER keeps the order -- no s_waitcnt (the values a lane uses are waited for where they
+// are used, as always), let alone a workgroup-scope release fence, which would also drain every global store in flight.
+// (Round 1 had the fences: 1-2 k cycles of store round trip at each sync after the state / flag stores; waiting for
+// lgkmcnt(0) at each of the ~25 syncs of a wave still stalled it on every LDS round trip.)
 T2D_DEV void wave_sync() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
 
