@@ -111,7 +111,7 @@ T2D_DEV int2 edge_span(double x1, double y1, double x2, double y2, double R, int
 // WAVES = waves per SIMD the register allocation is held to: short edge lists (ParkingEnv: ~32 edges) are bound by
 // the chain of dependent latencies per workgroup, so twice the resident workgroups beat the 22 spilled registers
 // (39 vs 47 us at 4096 envs); long lists (participants scanned: 250+ edges) are issue-bound and keep all 98 registers.
-template <int WAVES>
+template <int WAVES, bool PARTS>
 __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, LidarView lv, float* out) {
     // short edge lists (the 8-waves-per-SIMD instantiation, ParkingEnv) keep the precomputed EdgePre per edge (64 B);
     // long lists keep the four end-point coordinates (32 B) and derive it per candidate: twice the LDS per slot would
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     }
     // ---- phase 1b: the other participants' boxes (4 edges each; skipped slots get the far edge) -------
     int n_slots = n_static;
-    if (lv.include_participants) {
+    if (PARTS && lv.include_participants) {
         n_slots += 4 * A;
         for (int j = tid; j < A; j += kLidarBlock) {
             const uint32_t ids = pv.ids[base + j];
@@ -343,10 +343,14 @@ hipError_t launch_lidar(const PoolView& v, const LidarView& lv, float* out, hipS
     const bool short_list = lv.max_slots <= 64;   // EdgePre records (64 B) for short lists, end points (32 B) otherwise
     const size_t dyn = ((short_list ? sizeof(EdgePre) : 4 * sizeof(double)) + sizeof(int2)) * (size_t)lv.max_slots +
                        16 * (size_t)lv.n_beams + 4 * (size_t)kLidarQueue * (kLidarBlock / 64);
-    if (short_list)
-        hipLaunchKernelGGL(lidar_kernel<8>, dim3(v.n_env), dim3(kLidarBlock), dyn, s, v, lv, out);
+    // (the scan of static obstacles only -- ParkingEnv -- is compiled without the participants' phase: at the 64
+    // registers of 8 waves / SIMD that code cost the whole kernel 27 spilled registers, reloaded in the evaluation loop)
+    if (short_list && !lv.include_participants)
+        hipLaunchKernelGGL((lidar_kernel<8, false>), dim3(v.n_env), dim3(kLidarBlock), dyn, s, v, lv, out);
+    else if (short_list)
+        hipLaunchKernelGGL((lidar_kernel<8, true>), dim3(v.n_env), dim3(kLidarBlock), dyn, s, v, lv, out);
     else
-        hipLaunchKernelGGL(lidar_kernel<4>, dim3(v.n_env), dim3(kLidarBlock), dyn, s, v, lv, out);
+        hipLaunchKernelGGL((lidar_kernel<4, true>), dim3(v.n_env), dim3(kLidarBlock), dyn, s, v, lv, out);
     return hipGetLastError();
 }
 
