@@ -139,6 +139,35 @@ def random_quads(rng, n, cx_range, cy_range, size=(2.0, 6.0)):
     return polys
 
 
+def random_convex_polys(rng, n, cx_range, cy_range, size=(2.0, 6.0)):
+    """n random convex polygons with 3..8 vertices (points of an ellipse at sorted random angles), random winding."""
+    polys = []
+    for _ in range(n):
+        k = int(rng.integers(3, 9))
+        ang = np.sort(rng.uniform(0, TWO_PI, k))
+        if np.min(np.diff(np.concatenate([ang, [ang[0] + TWO_PI]]))) < 0.15:     # keep the vertices apart
+            ang = TWO_PI * (np.arange(k) + rng.uniform(0, 0.3, k)) / k
+        a, b = rng.uniform(*size) / 2, rng.uniform(size[0] / 2, size[1] / 2) / 2
+        h = rng.uniform(0, TWO_PI)
+        q = np.stack([a * np.cos(ang), b * np.sin(ang)], 1)
+        R = np.array([[np.cos(h), -np.sin(h)], [np.sin(h), np.cos(h)]])
+        q = q @ R.T + [rng.uniform(*cx_range), rng.uniform(*cy_range)]
+        if rng.uniform() < 0.5:
+            q = q[::-1]
+        polys.append(q.astype(np.float32))
+    return polys
+
+
+def polygon_scene(rng, n_env, A, extent=(40.0, 24.0), n_static=5, n_lanes=3, with_peds=True):
+    """Static obstacles and lanes with 3..8 vertices (the library evaluates 5..8-gons as fans of quads)."""
+    sc = random_scene(rng, n_env, A, extent, n_static=0, n_lanes=0, with_peds=with_peds)
+    sc["static"] = to_csr([random_convex_polys(rng, int(rng.integers(0, n_static + 1)), (-extent[0] / 2, extent[0] / 2),
+                                               (-extent[1] / 2, extent[1] / 2)) for _ in range(n_env)])
+    sc["lanes"] = to_csr([random_convex_polys(rng, int(rng.integers(0, n_lanes + 1)), (-extent[0] / 3, extent[0] / 3),
+                                              (-extent[1] / 3, extent[1] / 3), size=(10.0, 36.0)) for _ in range(n_env)])
+    return sc
+
+
 def to_csr(per_env_polys):
     eo = [0]; vo = [0]; xy = []
     for polys in per_env_polys:

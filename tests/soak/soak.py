@@ -28,6 +28,19 @@ for seed in range(n_seeds):
         if bad:
             i = np.nonzero(gf != wf)[0][:5]
             print("MISMATCH seed", seed, "shape", n_env, A, "count", bad, "first", i, gf[i], wf[i])
+# lane unions that abut / overlap / leave holes (off-lane = contains) and polygons of 3..8 vertices (fans of quads)
+for seed in range(n_seeds):
+    for (n_env, A) in ((48, 64), (64, 32), (100, 8), (5, 150)):
+        for kind in ("structured", "polygons"):
+            rng = np.random.default_rng(7000000 + 100000 * seed + n_env * 1000 + A)
+            sc = H.structured_lane_scene(rng, n_env, A) if kind == "structured" else H.polygon_scene(rng, n_env, A)
+            wf, we = H.oracle_collide(O, sc)
+            gf, ge = H.gpu_collide(sc)
+            bad = int((gf != wf).sum()) + int((ge != we).sum())
+            total += gf.size; bad_total += bad
+            if bad:
+                i = np.nonzero(gf != wf)[0][:5]
+                print("MISMATCH", kind, "seed", seed, "shape", n_env, A, "count", bad, "first", i, gf[i], wf[i])
 # stepping soak: fused exact step vs oracle (integrate -> collide), teacher-forced on the pool's fp32 state
 from tactics2d_amd import layout as L, scenarios as S
 from tactics2d_amd.pool import ParticipantPool

@@ -54,6 +54,20 @@ def test_off_lane_is_contains_on_structured_lane_unions(oracle, n_env, A):
     assert 0.1 < rate < 0.9 and n_edge >= (10 if n_env * A > 1000 else 1)
 
 
+@pytest.mark.parametrize("n_env,A", [(64, 64), (120, 16), (300, 1)])
+def test_polygons_of_up_to_eight_vertices(oracle, n_env, A):
+    """Static obstacles and lanes with 3..8 vertices: the library cuts 5..8-gons into fans of quads (t2d_set_*_geometry),
+    the oracle does the same (fan_parts); flags bit-exact, either winding."""
+    rng = np.random.default_rng(31 * n_env + A)
+    sc = H.polygon_scene(rng, n_env, A)
+    want_f, want_e = H.oracle_collide(oracle, sc)
+    got_f, got_e = H.gpu_collide(sc)
+    assert np.array_equal(got_f, want_f) and np.array_equal(got_e, want_e), int((got_f != want_f).sum())
+    rates = [(want_f & b).astype(bool).mean() for b in (2, 8)]
+    print(f"E={n_env} A={A}: static / off-lane rates {np.round(rates, 3)}")
+    assert 0.02 < rates[0] < 0.9 and 0.05 < rates[1] < 0.99
+
+
 def test_geometry_kats(oracle):
     """Hand-built touching / nesting / near-miss cases (tests/golden/geometry_kats.json)."""
     kats = H.load_json("geometry_kats.json")
