@@ -774,12 +774,23 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             for (int hb = 1; hb >= 0; --hb) {
                 uint32_t h = 0u;
                 const int top = cn - hb * 32 < 32 ? cn - hb * 32 : 32;   // polygons of this half-word
-                for (int a = top - 1; a >= 0; --a) {
-                    const float4 b = bb[first + hb * 32 + a];
+                auto verdict = [&](const float4 b) {
                     const f2p tx = {b.x, -b.y}, ty = {b.z, -b.w};
                     const f2p dx = tx + bxp, dy = ty + byp;   // (xmin - hi_x, lo_x - xmax), (ymin - hi_y, lo_y - ymax)
                     const float m = __builtin_fmaxf(__builtin_fmaxf(dx.x, dx.y), __builtin_fmaxf(dy.x, dy.y));
                     asm volatile("v_cmp_ge_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(h) : "v"(m) : "vcc");
+                };
+                // the (top & 3) highest polygons one at a time, the rest four per trip with the four 16-B reads issued
+                // before the first compare: one LDS round trip per four polygons instead of one each
+                int a = top - 1;
+                for (; (a & 3) != 3 && a >= 0; --a) verdict(bb[first + hb * 32 + a]);
+                for (; a >= 3; a -= 4) {
+                    const float4* q = bb + first + hb * 32 + a;
+                    const float4 b0 = q[0], b1 = q[-1], b2 = q[-2], b3 = q[-3];
+                    verdict(b0);
+                    verdict(b1);
+                    verdict(b2);
+                    verdict(b3);
                 }
                 hw[hb] = h;
             }

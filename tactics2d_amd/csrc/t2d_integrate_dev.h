@@ -297,8 +297,9 @@ T2D_DEV StepOut step_dynamics(PF P, double x, double y, double phi, double v, do
         int k_done = 0;
         if (__ballot(!always_fast) == 0ull) {
             const double mmidt = mmi * dt;
-#pragma unroll 2
-            for (int k = 0; k < n_steps; ++k) {
+            // unbounded speed = bounds at -inf / +inf: one min / max pair per sub-step, no per-lane select
+            const double vlo_e = clip_v ? vlo : -__builtin_inf(), vhi_e = clip_v ? vhi : __builtin_inf();
+            auto sub_step = [&]() {
                 const double vh = v * dt;
                 x = __builtin_fma(vh, c, x);
                 y = __builtin_fma(vh, s, y);
@@ -307,8 +308,7 @@ T2D_DEV StepOut step_dynamics(PF P, double x, double y, double phi, double v, do
                 const double in1 = __builtin_fma(-k34, w, __builtin_fma(k21, beta, c1));
                 const double d_beta = __builtin_fma(mu * r, __builtin_fma(k21, w, __builtin_fma(-k65, beta, c2)), -d_phi);
                 d_phi = __builtin_fma(mmidt, in1, d_phi);
-                v += ah;
-                if (clip_v) v = __builtin_fmin(__builtin_fmax(v, vlo), vhi);
+                v = __builtin_fmin(__builtin_fmax(v + ah, vlo_e), vhi_e);
                 phi = __builtin_fma(d_phi, dt, phi);
                 beta = __builtin_fma(d_beta, dt, beta);
                 const double eps = (d_phi + d_beta) * dt;
@@ -316,7 +316,14 @@ T2D_DEV StepOut step_dynamics(PF P, double x, double y, double phi, double v, do
                 if (__ballot(aeps > kEpsTiny) == 0ull) rotate_tiny(eps, c, s);
                 else if (aeps <= kEpsMax) rotate_small(eps, c, s);
                 else sincos_det(phi + beta, s, c);
+            };
+            // two sub-steps per trip: half the loop bookkeeping (the trip count is per lane: delta_t is a type parameter)
+            int k = 0;
+            for (; k + 2 <= n_steps; k += 2) {
+                sub_step();
+                sub_step();
             }
+            if (k < n_steps) sub_step();
             k_done = n_steps;
         }
         for (int k = k_done; k < n_steps; ++k) {
