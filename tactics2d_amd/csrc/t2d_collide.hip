@@ -297,7 +297,9 @@ T2D_DEV void compact_and_process(unsigned long long mask, int id_base, int own_i
 // one launch -- the participant is first integrated in registers (exact / fast variant, the same
 // device functions as integrate_kernel), written back, and its new pose goes straight into the event
 // phases: no second launch, no state reload.
-template <bool WITH_STATUS, int FUSE>
+// IOU = false: a pool whose status configuration checks neither NoAction nor Arrival (everything but the parking envs)
+// runs the instantiation without the quad-IoU code: its out-of-line body brings a 168-B private segment with it.
+template <bool WITH_STATUS, int FUSE, bool IOU = true>
 __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv, t2d_status_config cfg,
                                                                             int interval_ms, int log2A) {
     __shared__ double s_v[8][kBlock];   // OBB vertex coordinate planes x0,y0,...,x3,y3
@@ -879,7 +881,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     // row on one lane: ~5 us of the ~22 us parking step).  Whether the values are used is decided by the epilogue
     // below exactly as before; an unused value is simply dropped.
     double iou_na = 0.0, iou_ar = 0.0;
-    if (WITH_STATUS && (cfg.check_no_action || cfg.check_arrival)) {
+    if (WITH_STATUS && IOU && (cfg.check_no_action || cfg.check_arrival)) {
         const int ego_l = (env_local << log2A) + cfg.ego_index;
         const bool env_ok = env < pv.n_env && agent < 2;
         bool want = false;
@@ -916,7 +918,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                 scen = T2D_SCENARIO_TIME_EXCEEDED;  // later detectors are not updated (parking.py:366-369)
             } else {
                 bool na = false;
-                if (cfg.check_no_action && ego_obb) {  // NoAction.update (no_action.py:41-53)
+                if (IOU && cfg.check_no_action && ego_obb) {  // NoAction.update (no_action.py:41-53)
                     double* last = pv.last_pose + 8 * (size_t)env;
                     int cna = pv.cnt_na[env];
                     if (!pv.last_valid[env]) {
@@ -942,7 +944,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                     scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_COLLISION_DYNAMIC;
                 } else if (cfg.check_off_lane && (ef & T2D_FLAG_OFF_LANE)) {
                     scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_OFF_LANE;
-                } else if (cfg.check_arrival && pv.target_xy && ego_obb) {  // Arrival.update (arrival.py:42-47)
+                } else if (IOU && cfg.check_arrival && pv.target_xy && ego_obb) {  // Arrival.update (arrival.py:42-47)
                     iou = iou_ar;
                     has_iou = true;
                     if (iou >= (double)cfg.arrival_threshold) scen = T2D_SCENARIO_COMPLETED;
@@ -1028,10 +1030,10 @@ hipError_t step_occupancy(const PoolView& v, int* blocks_per_cu, size_t* lds_byt
     const int block = v.geo_layout.epb << log2A;
     const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
     hipFuncAttributes fa{};
-    hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&collide_kernel<true, 1>));
+    hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&collide_kernel<true, 1, false>));
     if (e != hipSuccess) return e;
     *lds_bytes = fa.sharedSizeBytes + dyn;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, collide_kernel<true, 1>, block, dyn);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, collide_kernel<true, 1, false>, block, dyn);
 }
 
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
@@ -1041,15 +1043,20 @@ hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool 
     const int EPB = v.geo_layout.epb;
     const dim3 grid((v.n_env + EPB - 1) / EPB), block(EPB << log2A);
     const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
+    const bool iou = cfg.check_no_action || cfg.check_arrival;
     if (fuse_variant >= 0) {  // the fused step always runs the status epilogue
-        if (fuse_variant == 0)
-            hipLaunchKernelGGL((collide_kernel<true, 0>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
-        else
-            hipLaunchKernelGGL((collide_kernel<true, 1>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        if (fuse_variant == 0) {
+            if (iou) hipLaunchKernelGGL((collide_kernel<true, 0, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+            else hipLaunchKernelGGL((collide_kernel<true, 0, false>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        } else {
+            if (iou) hipLaunchKernelGGL((collide_kernel<true, 1, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+            else hipLaunchKernelGGL((collide_kernel<true, 1, false>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        }
     } else if (with_status) {
-        hipLaunchKernelGGL((collide_kernel<true, -1>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        if (iou) hipLaunchKernelGGL((collide_kernel<true, -1, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        else hipLaunchKernelGGL((collide_kernel<true, -1, false>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
     } else {
-        hipLaunchKernelGGL((collide_kernel<false, -1>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        hipLaunchKernelGGL((collide_kernel<false, -1, false>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
     }
     return hipGetLastError();
 }
