@@ -89,7 +89,7 @@ struct PolyRef {           // a polygon in LDS: either fp32 interleaved x,y or a
     }
 };
 
-__device__ __noinline__ bool point_in_generic(const PolyRef B, double x, double y) {
+T2D_DEV bool point_in_generic(const PolyRef B, double x, double y) {
     bool in = true;
     double px, py;
     B.get(B.n - 1, px, py);
@@ -670,7 +670,9 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             float* const by = bx + 96;
             float* const bR = by + 96;
             static_assert(3 * 96 <= kQueueCap, "broad-phase staging must fit in the wave's queue");
-            const float px = active ? fx : 1e30f;
+            // (the centre comes back from LDS: carried in registers since the pose phase it cost the kernel a spill)
+            const float fx_b = s_cxy[0][tid], fy = s_cxy[1][tid];
+            const float px = active ? fx_b : 1e30f;
             // every env of the wave gets a segment of 1.5 * A_pad entries: its agents, then its first half again, so
             // that the ring sweep below reads agent + offset without wrapping (64 / A_pad segments: 96 entries in all)
             const int n_off = A_pad >> 1;                           // partners per lane: agent + 1 .. agent + A_pad / 2
