@@ -326,17 +326,32 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     int* const s_done = reinterpret_cast<int*>(s_env_or);
     extern __shared__ __attribute__((aligned(16))) uint32_t s_geo[];  // packed geometry record
 
+    // Every kernel argument the start-up phase needs, requested in ONE scalar round trip.  Left to itself the compiler
+    // fetches each PoolView field where it is first used -- behind `if (valid)`, behind the previous batch's wait -- and
+    // the phase becomes a chain of five or six dependent s_load round trips, each a scalar-cache miss while all 4096
+    // waves of the launch start together: 3.7 k of the phase's 5.3 k cycles (-DT2D_TIMING) before the first state load
+    // is even issued.  The empty asm makes all of them live here, so their loads are issued back to back.
+    const uint32_t* a_ids = pv.ids;
+    const float *a_x = pv.x, *a_y = pv.y, *a_h = pv.heading, *a_v = pv.speed, *a_act0 = pv.act0, *a_act1 = pv.act1;
+    const uint8_t* a_idm = pv.idm_ctrl;
+    const double* a_params = pv.params;
+    const uint32_t* a_geo = pv.geo;
+    int a_n_env = pv.n_env, a_A = pv.A, a_stride = pv.geo_layout.stride, a_epb = pv.geo_layout.epb;
+    // (in-out operands: the values after the asm are new to the compiler, so it keeps them in registers instead of
+    // dropping them and fetching the same arguments again behind the next branch)
+    asm volatile("" : "+s"(a_ids), "+s"(a_x), "+s"(a_y), "+s"(a_h), "+s"(a_v), "+s"(a_act0), "+s"(a_act1), "+s"(a_idm),
+                      "+s"(a_params), "+s"(a_geo), "+s"(a_n_env), "+s"(a_A), "+s"(a_stride), "+s"(a_epb));
     const GeoLayout& gl = pv.geo_layout;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int A_pad = 1 << log2A;
-    const int EPB = gl.epb;
+    const int EPB = a_epb;
     const int nthreads = EPB << log2A;
     const int env_local = tid >> log2A;
     const int agent = tid & (A_pad - 1);
     const int env = blockIdx.x * EPB + env_local;
-    const bool valid = env < pv.n_env && agent < pv.A;
-    const int idx = valid ? env * pv.A + agent : 0;
+    const bool valid = env < a_n_env && agent < a_A;
+    const int idx = valid ? env * a_A + agent : 0;
     const bool use_hash_grid = log2A > 6;  // envs larger than a wave use the LDS spatial hash
     const int H = 2 * A_pad;               // buckets per env (power of two)
     uint32_t* const queue = s_queue[tid >> 6];
@@ -361,15 +376,15 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     // would otherwise sit, unhidden, at the very end of the wave
     int pre_cnt = 0, pre_frame = 0;
     if (valid) {
-        ids = pv.ids[idx];
-        fx = pv.x[idx];
-        fy = pv.y[idx];
-        fh = pv.heading[idx];
+        ids = a_ids[idx];
+        fx = a_x[idx];
+        fy = a_y[idx];
+        fh = a_h[idx];
         if (FUSE >= 0) {
-            fv = pv.speed[idx];
-            fa0 = pv.act0[idx];
-            fa1 = pv.act1[idx];
-            if (pv.idm_ctrl && pv.idm_ctrl[idx] != T2D_IDM_NONE) {  // IDM lane while caller actions are bound
+            fv = a_v[idx];
+            fa0 = a_act0[idx];
+            fa1 = a_act1[idx];
+            if (a_idm && a_idm[idx] != T2D_IDM_NONE) {  // IDM lane while caller actions are bound
                 fa0 = pv.own_act0[idx];
                 fa1 = pv.own_act1[idx];
             }
@@ -384,8 +399,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         constexpr int kTab = kTabCols * T2D_MAX_TYPES;
         if (nthreads == kBlock) {   // the usual launch shape: 3 x 8 B per thread, no per-load bounds logic
             static_assert(kTab <= 3 * kBlock && kTab > 2 * kBlock, "staging below assumes 2 full rounds + a partial one");
-            const double t0 = pv.params[tid], t1 = pv.params[tid + kBlock];
-            const double t2 = tid + 2 * kBlock < kTab ? pv.params[tid + 2 * kBlock] : 0.0;
+            const double t0 = a_params[tid], t1 = a_params[tid + kBlock];
+            const double t2 = tid + 2 * kBlock < kTab ? a_params[tid + 2 * kBlock] : 0.0;
             s_partab[tid] = t0;
             s_partab[tid + kBlock] = t1;
             if (tid + 2 * kBlock < kTab) s_partab[tid + 2 * kBlock] = t2;
@@ -411,8 +426,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         }
     }
     // geometry record -> LDS, 16-B loads
-    const int n_vec = pv.geo ? gl.stride >> 2 : 0;
-    const uint4* gsrc = reinterpret_cast<const uint4*>(pv.geo + (size_t)blockIdx.x * gl.stride);
+    const int n_vec = a_geo ? a_stride >> 2 : 0;
+    const uint4* gsrc = reinterpret_cast<const uint4*>(a_geo + (size_t)blockIdx.x * a_stride);
     {
         // rounds of 16-B loads this record needs (wave-uniform): 1 for the metric scenes (<= 4 KiB per workgroup) --
         // the unrolled generic form spends more on its per-load bounds logic than on the loads
