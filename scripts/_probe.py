@@ -13,5 +13,5 @@ pool.sync()
 buf = np.zeros(2 * 65536, np.uint64)
 lib.t2d_debug_read(pool._h, buf.ctypes.data_as(C.c_void_p), buf.size)
 a = buf[65536:].reshape(4096, 16).astype(np.float64)
-print("startup split (ticks per wave): kernarg+issue state loads %.0f | issue rest %.0f | wait all loads %.0f | LDS stores %.0f | barrier %.0f" % tuple(a[:, k].mean() for k in range(5)))
+print("startup split (ticks per wave): kernargs %.0f | issue state loads %.0f | issue rest %.0f | wait all loads %.0f | LDS stores %.0f | barrier %.0f" % tuple(a[:, k].mean() for k in (5, 0, 1, 2, 3, 4)))
 print("p10/p50/p90 of wait:", np.percentile(a[:, 2], [10, 50, 90]), " of first:", np.percentile(a[:, 0], [10, 50, 90]))

@@ -1021,16 +1021,28 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     if (WITH_STATUS && pv.auto_reset) {  // fused vector-env auto-reset: finished envs go back to the snapshot
         if (log2A <= 6) wave_sync(); else __syncthreads();
         if (valid && s_done[env_local]) {
-            pv.x[idx] = pv.snap[0][idx];
-            pv.y[idx] = pv.snap[1][idx];
-            pv.heading[idx] = pv.snap[2][idx];
-            pv.speed[idx] = pv.snap[3][idx];
-            pv.vx[idx] = pv.snap[4][idx];
-            pv.vy[idx] = pv.snap[5][idx];
-            pv.ids[idx] = pv.snap_ids[idx];
-            if (pv.snap_omega[0]) {  // SingleTrackDrift wheel speeds (only with a drift type in the table)
-                pv.omega_f[idx] = pv.snap_omega[0][idx];
-                pv.omega_r[idx] = pv.snap_omega[1][idx];
+            // every snapshot value first, then the stores: written as load / store pairs, each pair waits for its own
+            // memory round trip (a store may alias the next load as far as the compiler knows) -- seven in a row at
+            // the very end of the wave, where nothing is left to hide them
+            const float r0 = pv.snap[0][idx], r1 = pv.snap[1][idx], r2 = pv.snap[2][idx], r3 = pv.snap[3][idx];
+            const float r4 = pv.snap[4][idx], r5 = pv.snap[5][idx];
+            const uint32_t rid = pv.snap_ids[idx];
+            const bool drift = pv.snap_omega[0] != nullptr;   // SingleTrackDrift wheel speeds (only with a drift type in the table)
+            float w0 = 0.f, w1 = 0.f;
+            if (drift) {
+                w0 = pv.snap_omega[0][idx];
+                w1 = pv.snap_omega[1][idx];
+            }
+            pv.x[idx] = r0;
+            pv.y[idx] = r1;
+            pv.heading[idx] = r2;
+            pv.speed[idx] = r3;
+            pv.vx[idx] = r4;
+            pv.vy[idx] = r5;
+            pv.ids[idx] = rid;
+            if (drift) {
+                pv.omega_f[idx] = w0;
+                pv.omega_r[idx] = w1;
             }
         }
     }
