@@ -862,13 +862,51 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     }
     }
     // ---------------- phase 3: reduce + status epilogue ------------------------------------
+    // every kernel argument the epilogue touches, requested together (see the start-up phase): the status lane's chain
+    // and the restore of a finished env are the last thing a wave does, with nothing behind them to hide a scalar round
+    // trip per pointer
+    auto e_flags = pv.flags;
+    auto e_env_flags = pv.env_flags;
+    auto e_cnt_step = pv.cnt_step;
+    auto e_frame_ms = pv.frame_ms;
+    auto e_status = pv.status;
+    auto e_reward = pv.reward;
+    auto e_record = pv.record;
+    auto e_time_penalty = pv.time_penalty;
+    auto e_iou = pv.iou;
+    auto e_last_valid = pv.last_valid;
+    auto e_cnt_na = pv.cnt_na;
+    auto e_max_iou = pv.max_iou;
+    auto e_min_dist = pv.min_dist;
+    auto e_snap_min_dist = pv.snap_min_dist;
+    auto e_snap0 = pv.snap[0];
+    auto e_snap1 = pv.snap[1];
+    auto e_snap2 = pv.snap[2];
+    auto e_snap3 = pv.snap[3];
+    auto e_snap4 = pv.snap[4];
+    auto e_snap5 = pv.snap[5];
+    auto e_snap_ids = pv.snap_ids;
+    auto e_snap_omega0 = pv.snap_omega[0];
+    auto e_snap_omega1 = pv.snap_omega[1];
+    auto e_x = pv.x;
+    auto e_y = pv.y;
+    auto e_heading = pv.heading;
+    auto e_speed = pv.speed;
+    auto e_vx = pv.vx;
+    auto e_vy = pv.vy;
+    auto e_ids = pv.ids;
+    auto e_omega_f = pv.omega_f;
+    auto e_omega_r = pv.omega_r;
+    int e_auto_reset = pv.auto_reset;
+    asm volatile("" : "+s"(e_flags), "+s"(e_env_flags), "+s"(e_cnt_step), "+s"(e_frame_ms), "+s"(e_status), "+s"(e_reward), "+s"(e_record), "+s"(e_time_penalty), "+s"(e_iou), "+s"(e_last_valid), "+s"(e_cnt_na), "+s"(e_max_iou), "+s"(e_min_dist), "+s"(e_snap_min_dist), "+s"(e_auto_reset));
+    asm volatile("" : "+s"(e_snap0), "+s"(e_snap1), "+s"(e_snap2), "+s"(e_snap3), "+s"(e_snap4), "+s"(e_snap5), "+s"(e_snap_ids), "+s"(e_snap_omega0), "+s"(e_snap_omega1), "+s"(e_x), "+s"(e_y), "+s"(e_heading), "+s"(e_speed), "+s"(e_vx), "+s"(e_vy), "+s"(e_ids), "+s"(e_omega_f), "+s"(e_omega_r));
     // the status epilogue's inputs, requested now by the lane that will run it (agent 0): the reduce hides part of their
     // latency.  (Fetched at the top of the kernel they sat in registers through every event phase, and at the 128
     // registers of 4 waves / SIMD that meant scratch spills: 8 B per lane stored and re-read, 13 MB of HBM traffic.)
     if (WITH_STATUS && valid && agent == 0) {
         pre_cnt = pv.cnt_step[env];
         pre_frame = pv.frame_ms[env];
-        if (pv.time_penalty && cfg.max_step > 0) {
+        if (e_time_penalty && cfg.max_step > 0) {
             const int c = pre_cnt + 1;
             pre_tp = pv.time_penalty[c < cfg.max_step ? c : cfg.max_step];
         }
@@ -974,7 +1012,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             else if (scen == T2D_SCENARIO_COMPLETED) rd = cfg.reward_completed;
             else if (traf == T2D_TRAFFIC_COLLISION_DYNAMIC || traf == T2D_TRAFFIC_OFF_LANE) rd = cfg.reward_collision;
             else {
-                rd = cfg.max_step > 0 ? (pv.time_penalty ? pre_tp : -tanh((double)cnt / (double)cfg.max_step) * (double)cfg.time_penalty_scale) : 0.0;
+                rd = cfg.max_step > 0 ? (e_time_penalty ? pre_tp : -tanh((double)cnt / (double)cfg.max_step) * (double)cfg.time_penalty_scale) : 0.0;
                 if (cfg.shaped_reward) {
                     double mi = pv.max_iou[env];
                     double iou_reward = 0.0;
@@ -1000,11 +1038,11 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             uchar4 st;
             st.x = (unsigned char)scen; st.y = (unsigned char)traf;
             st.z = terminated; st.w = truncated;
-            reinterpret_cast<uchar4*>(pv.status)[env] = st;
+            reinterpret_cast<uchar4*>(e_status)[env] = st;
             pv.reward[env] = r;
             pv.record[env] = make_uint2(__float_as_uint(r), (uint32_t)scen | (uint32_t)traf << 8 |
                                                                 (uint32_t)terminated << 16 | (uint32_t)truncated << 24);
-            if (pv.auto_reset) {
+            if (e_auto_reset) {
                 const bool done = terminated || truncated;
                 s_done[env_local] = done;
                 if (done) {  // ParkingEnv.reset: counters and detector state back to the episode start
@@ -1018,7 +1056,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             }
         }
     }
-    if (WITH_STATUS && pv.auto_reset) {  // fused vector-env auto-reset: finished envs go back to the snapshot
+    if (WITH_STATUS && e_auto_reset) {  // fused vector-env auto-reset: finished envs go back to the snapshot
         if (log2A <= 6) wave_sync(); else __syncthreads();
         if (valid && s_done[env_local]) {
             // every snapshot value first, then the stores: written as load / store pairs, each pair waits for its own
@@ -1027,7 +1065,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             const float r0 = pv.snap[0][idx], r1 = pv.snap[1][idx], r2 = pv.snap[2][idx], r3 = pv.snap[3][idx];
             const float r4 = pv.snap[4][idx], r5 = pv.snap[5][idx];
             const uint32_t rid = pv.snap_ids[idx];
-            const bool drift = pv.snap_omega[0] != nullptr;   // SingleTrackDrift wheel speeds (only with a drift type in the table)
+            const bool drift = e_snap_omega0 != nullptr;   // SingleTrackDrift wheel speeds (only with a drift type in the table)
             float w0 = 0.f, w1 = 0.f;
             if (drift) {
                 w0 = pv.snap_omega[0][idx];
