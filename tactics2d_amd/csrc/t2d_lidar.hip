@@ -138,8 +138,6 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     unsigned long long* const s_mask = s_best + lv.n_beams;   // [n_beams] candidate edges (bit q) of the current 64-edge chunk
     uint32_t* const s_queue = reinterpret_cast<uint32_t*>(s_mask + lv.n_beams);       // [kLidarBlock / 64][kLidarQueue]
     __shared__ int s_qcount[kLidarBlock / 64];
-    __shared__ double s_ego[4];                                       // cos, sin, x_off, y_off
-    __shared__ int s_ego_active;
     const int env = blockIdx.x;
     const int tid = threadIdx.x;
     const int A = pv.A;
@@ -167,20 +165,15 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
         n_static = lv.env_vert_cnt ? lv.env_vert_cnt[env] : lv.env_vert_off[env + 1] - v0;
         if (tid < n_static) first_edge = reinterpret_cast<const float4*>(lv.xy)[v0 + tid];
     }
-    if (tid == 0) {
-        const size_t ie = base + lv.ego_index;
-        const uint32_t ids = pv.ids[ie];
-        s_ego_active = (ids >> kIdsActiveShift) & 0xff;
-        double sn, cs;
-        sincos_det((double)pv.heading[ie], sn, cs);
-        const double px = pv.x[ie], py = pv.y[ie];
-        s_ego[0] = cs;
-        s_ego[1] = sn;
-        s_ego[2] = -px * cs - py * sn;   // lidar.py:112-113
-        s_ego[3] = px * sn - py * cs;
-    }
-    __syncthreads();
-    const double cs = s_ego[0], sn = s_ego[1], x_off = s_ego[2], y_off = s_ego[3];
+    // the ego transform, by every lane for itself: the same instructions whether one lane or sixty-four execute them, and
+    // no LDS hand-over + workgroup barrier before the first edge can be transformed
+    const size_t ie = base + lv.ego_index;
+    const bool ego_active = ((pv.ids[ie] >> kIdsActiveShift) & 0xff) != 0;
+    double sn, cs;
+    sincos_det((double)pv.heading[ie], sn, cs);
+    const double ego_x = pv.x[ie], ego_y = pv.y[ie];
+    const double x_off = -ego_x * cs - ego_y * sn;   // lidar.py:112-113
+    const double y_off = ego_x * sn - ego_y * cs;
     T2D_LMARK(0);
 
     // ---- phase 1a: static polygon edges (vertex v -> next vertex of its ring) ------------------------
@@ -249,7 +242,7 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     };
-    const bool scan = s_ego_active && n_slots > 0;
+    const bool scan = ego_active && n_slots > 0;
     const int n_iter = (lv.n_beams + kLidarBlock - 1) / kLidarBlock;
     for (int c0 = 0; c0 < n_slots && scan; c0 += 64) {
         // pass 1, edge-major: every edge of the chunk ORs its bit into the masks of the beams of its span (two
