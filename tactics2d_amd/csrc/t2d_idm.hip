@@ -93,19 +93,28 @@ __global__ __launch_bounds__(kIdmBlock) void idm_kernel(PoolView pv, IdmView iv,
         if (want >= 0 && want < pv.A && want != agent && s_xy[base + want].x == s_xy[base + want].x)
             lead = want;  // the caller's leading_state
         if (want == T2D_IDM_LEADER_SEARCH) {
+            auto sweep = [&](int j0, int j1) {
 #pragma unroll 4
-            for (int j = 0; j < pv.A; ++j) {
-                const double2 q = s_xy[base + j];
-                const double dx = q.x - x0, dy = q.y - y0;
-                const double lon = __builtin_fma(dx, cs, dy * sn);
-                const double lat = __builtin_fma(dy, cs, -(dx * sn));
-                const bool ok = lon > 0.0 && lon <= horizon && __builtin_fabs(lat) <= hw;
-                const double key = ok ? lon : __builtin_inf();
-                if (key < best) {
-                    best = key;
-                    lead = j;
+                for (int j = j0; j < j1; ++j) {
+                    const double2 q = s_xy[base + j];
+                    const double dx = q.x - x0, dy = q.y - y0;
+                    const double lon = __builtin_fma(dx, cs, dy * sn);
+                    const double lat = __builtin_fma(dy, cs, -(dx * sn));
+                    const bool ok = lon > 0.0 && lon <= horizon && __builtin_fabs(lat) <= hw;
+                    const double key = ok ? lon : __builtin_inf();
+                    if (key < best) {
+                        best = key;
+                        lead = j;
+                    }
                 }
-            }
+            };
+            // wave priority by progress (see the step kernel): the launch is one wave-round, a SIMD's waves should finish
+            // together.  The sweep in quarters, the quarter's number is the priority.
+            const int q1 = pv.A >> 2, q2 = pv.A >> 1, q3 = q1 + q2;
+            __builtin_amdgcn_s_setprio(3); sweep(0, q1);
+            __builtin_amdgcn_s_setprio(2); sweep(q1, q2);
+            __builtin_amdgcn_s_setprio(1); sweep(q2, q3);
+            __builtin_amdgcn_s_setprio(0); sweep(q3, pv.A);
         }
         double dx = 0.0, dy = 0.0, vl = 0.0;
         if (lead >= 0) {
