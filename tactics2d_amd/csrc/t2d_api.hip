@@ -610,6 +610,7 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
     for (int k = 0; k < 6; ++k) v.snap[k] = nullptr;
     v.snap_ids = nullptr;
     v.auto_reset = 0;
+    v.overlapped = 0;
 #ifdef T2D_TIMING
     (void)hipMalloc((void**)&v.dbg, (size_t)(n_env + 64) * 16 * 4 * sizeof(unsigned long long));
     (void)hipMemset(v.dbg, 0, (size_t)(n_env + 64) * 16 * 4 * sizeof(unsigned long long));
@@ -1074,8 +1075,12 @@ int t2d_step_groups(t2d_pool* const* pools, const float* const* act0_dev, const 
     if (!pools || !hip_streams || n <= 0 || (act0_dev == nullptr) != (act1_dev == nullptr)) return T2D_ERR_INVALID;
     for (int i = 0; i < n; ++i) {
         int rc;
+        if (!pools[i]) return T2D_ERR_INVALID;
         if (act0_dev && (rc = t2d_bind_actions(pools[i], act0_dev[i], act1_dev[i])) != T2D_OK) return rc;
-        if ((rc = t2d_step(pools[i], interval_ms, hip_streams[i])) != T2D_OK) return rc;
+        pools[i]->v.overlapped = n > 1;   // several groups in flight: the kernels' wave priorities favour retiring workgroups
+        rc = t2d_step(pools[i], interval_ms, hip_streams[i]);
+        pools[i]->v.overlapped = 0;
+        if (rc != T2D_OK) return rc;
     }
     return T2D_OK;
 }

@@ -372,7 +372,11 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     // least progress first they finish close together, instead of one after the other with the last one running alone at
     // half the issue rate.  Measured: 27.45 us per step without priorities (27.4 with the round-1 rule "event phases
     // first"), 26.1 with two levels, 25.0 with these four (3 / 3 / 2 / 0 and 3 / 2 / 2 / 0: 25.6 / 26.0).
-    __builtin_amdgcn_s_setprio(3);
+    // When the launches of several env groups overlap (pv.overlapped, t2d_step_groups) the opposite holds: a workgroup
+    // that retires makes room for the next launch's, so waves past the integrator go first (0, then 2) -- 4 groups:
+    // 20.0 us per step of all envs with that rule, 20.3 without priorities, 23.4 with the single-launch rule.
+    const bool behind_first = pv.overlapped == 0;
+    if (behind_first) __builtin_amdgcn_s_setprio(3);
     // ---------------- phase 0: issue every global load, clear LDS tables ------------------
     uint32_t ids = 0;
     float fx = 0, fy = 0, fh = 0;
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     // four waves of a SIMD would all be "wave w" and keep the same order)
     const bool polys_first = log2A <= 6 && ((((int)blockIdx.x >> 8) + (tid >> 6)) & 1);
     for (int stage_it = 0; stage_it < 2; ++stage_it) {
-    if (stage_it == 0) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+    if (behind_first && stage_it == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
     if ((stage_it == 0) != polys_first) {
     if (!use_hash_grid) {
         // every lane against all agents of its env: fp32 circles, 1 cm margin (strictly
@@ -866,7 +870,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
 
     }
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (behind_first) __builtin_amdgcn_s_setprio(0);
     // ---------------- phase 3: reduce + status epilogue ------------------------------------
     // every kernel argument the epilogue touches, requested together (see the start-up phase): the status lane's chain
     // and the restore of a finished env are the last thing a wave does, with nothing behind them to hide a scalar round

@@ -78,6 +78,10 @@ struct PoolView {
     const uint32_t* snap_ids;
     const float* snap_omega[2];  // wheel speeds at the snapshot; null unless a drift type is present
     int32_t auto_reset;        // t2d_step restores finished envs in its epilogue
+    // 0: the step launch has the GPU to itself (one wave-round): waves that are BEHIND go first, so that a SIMD's four
+    // waves finish together.  1: launches of several pools overlap (t2d_step_groups): waves past the integrator go first,
+    // so that workgroups retire and the next launch's can start.  See the priority note in t2d_collide.hip.
+    int32_t overlapped;
     unsigned long long* dbg;  // phase cycle accumulators (profiling builds with -DT2D_TIMING only)
     double cell;      // spatial-hash cell edge (m) >= max circum-diameter * 1.001
     double inv_cell;
