@@ -668,13 +668,16 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         if (bits) atomicOr(&s_flags[i], bits << kLaneShift);
     };
     int n_lane_polys = 0;
-    // Odd waves visit the polygon stages before the pair stage: the four waves of a SIMD start together
-    // and would otherwise sit in the same latency-bound (LDS compaction) or issue-bound (narrow phase)
-    // stretch at the same time.  The stages are independent (results are OR-ed into s_flags).
-    // (the workgroups of a launch go round the XCDs, then round an XCD's 32 CUs: workgroups b, b + 256, b + 512, b + 768
-    // share a CU, and wave w of each lands on SIMD w -- so the order alternates with the workgroup's round, too, or the
-    // four waves of a SIMD would all be "wave w" and keep the same order)
-    const bool polys_first = log2A <= 6 && ((((int)blockIdx.x >> 8) + (tid >> 6)) & 1);
+    // Some waves visit the polygon stages before the pair stage: the four waves of a SIMD start together and would
+    // otherwise sit in the same latency-bound (LDS compaction) or issue-bound (narrow phase) stretch at the same time.
+    // The stages are independent (results are OR-ed into s_flags).  (The workgroups of a launch go round the XCDs, then
+    // round an XCD's 32 CUs: workgroups b, b + 256, b + 512, b + 768 share a CU, and a SIMD holds one wave of each.)
+    // Which waves take the polygon stages first.  The launch that has the GPU to itself: the third and fourth of the four
+    // workgroups that share a CU (a SIMD holds one wave of each) -- measured against none 25.3, all 24.6, every other
+    // workgroup 24.5, alternating waves 25.1 us per step: 24.2.  Overlapping launches of env groups (256 workgroups
+    // each): alternating waves and workgroup rounds, as before.
+    const bool polys_first = log2A <= 6 && (pv.overlapped ? ((((int)blockIdx.x >> 8) + (tid >> 6)) & 1) != 0
+                                                          : (((int)blockIdx.x >> 9) & 1) != 0);
     for (int stage_it = 0; stage_it < 2; ++stage_it) {
     if (behind_first && stage_it == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
     if ((stage_it == 0) != polys_first) {
