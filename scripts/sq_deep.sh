@@ -21,7 +21,7 @@ import csv, glob, collections
 for f in sorted(glob.glob('$OUT/p*/run_counter_collection.csv')):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
-        if 'collide_kernel<true, 1>' not in r['Kernel_Name']: continue
+        if 'collide_kernel<true, 1' not in r['Kernel_Name']: continue
         a = acc[r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
     w = acc['SQ_WAVES'][0] / max(acc['SQ_WAVES'][1], 1)
     print(f.split('/')[-2], 'waves', w, ' '.join(f"{k}={v[0] / v[1] / max(w, 1):.1f}" for k, v in acc.items() if k != 'SQ_WAVES' and v[1]))

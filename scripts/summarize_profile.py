@@ -11,8 +11,8 @@ def find(d, suffix):
 
 
 def short(name):
-    if "collide_kernel" in name:   # collide_kernel<WITH_STATUS, FUSE>: FUSE >= 0 is the fused step launch
-        return "collide_kernel" if "-1>" in name.replace(" ", "") else "step_kernel"
+    if "collide_kernel" in name:   # collide_kernel<WITH_STATUS, FUSE, IOU>: FUSE >= 0 is the fused step launch
+        return "collide_kernel" if ",-1" in name.replace(" ", "") else "step_kernel"
     for k in ("integrate_kernel", "restore_env_kernel", "restore_kernel"):
         if k in name:
             return k
