@@ -456,6 +456,13 @@ int t2d_gather_wait(t2d_pool* pool, void* hip_stream, int32_t block_host);
  * workgroup (static tables + the workgroup's geometry record), and (may be NULL) the bytes of packed geometry records
  * the workgroups of one step launch stage into LDS.  The 4096 x 64 metric launch is one wave-round of 1024 workgroups
  * on 256 CUs and needs 4; a scene whose record grows past the LDS budget halves the rate.                          */
+/* Placement of the step launch: entry b = logical workgroup (the envs [g * epb, (g + 1) * epb), epb = 256 / padded
+ * max_agents unless the geometry budget narrowed it) | wave rotation 0..3 << 16 that physical workgroup b steps.  Must be a
+ * permutation of the launch's workgroups; NULL / 0 restores the identity.  Results never depend on it -- the hardware
+ * places workgroup b on XCD b mod 8 and its waves on fixed SIMDs, so the map only decides which envs share a SIMD and
+ * which XCD (they start up to 2.5 us apart) gets the expensive ones.  Reset by every t2d_set_*_geometry.  Host memory. */
+int t2d_debug_set_step_placement(t2d_pool* pool, const uint32_t* map_host, int32_t n_workgroups);
+
 int t2d_debug_step_occupancy(t2d_pool* pool, int32_t* blocks_per_cu, int64_t* lds_bytes,
                              int64_t* geometry_bytes_per_launch);
 

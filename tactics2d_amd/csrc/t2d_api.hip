@@ -305,6 +305,8 @@ int rebuild_geo(t2d_pool* p) {
         int rc = dev_replace<uint32_t>(p, &p->d_geo, nullptr, 0);
         p->v.geo = nullptr;
         p->v.geo_layout = gl;
+    p->v.wgmap = nullptr;   // the launch shape may have changed
+        p->v.wgmap = nullptr;   // the launch shape may have changed
         return rc;
     }
     int epb = epb_max;
@@ -361,6 +363,7 @@ int rebuild_geo(t2d_pool* p) {
     if (rc != T2D_OK) return rc;
     p->v.geo = p->d_geo;
     p->v.geo_layout = gl;
+    p->v.wgmap = nullptr;   // the launch shape may have changed
     return T2D_OK;
 }
 
@@ -611,6 +614,7 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
     v.snap_ids = nullptr;
     v.auto_reset = 0;
     v.overlapped = 0;
+    v.wgmap = nullptr;
 #ifdef T2D_TIMING
     (void)hipMalloc((void**)&v.dbg, (size_t)(n_env + 64) * 16 * 4 * sizeof(unsigned long long));
     (void)hipMemset(v.dbg, 0, (size_t)(n_env + 64) * 16 * 4 * sizeof(unsigned long long));
@@ -635,7 +639,7 @@ int t2d_destroy(t2d_pool* p) {
                     p->d_last_pose, p->d_max_iou, p->d_min_dist, p->d_snap_min_dist, p->d_last_valid,
                     p->d_lidar_env_off, p->d_lidar_next, p->d_lidar_xy, p->d_beam_sin, p->d_beam_cos,
                     p->d_snap[0], p->d_snap[1], p->d_snap[2],
-                    p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_idm_rows, p->d_idm_ctrl, p->d_snap_omega[0], p->d_snap_omega[1], p->d_time_penalty,
+                    p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_wgmap, p->d_idm_rows, p->d_idm_ctrl, p->d_snap_omega[0], p->d_snap_omega[1], p->d_time_penalty,
                     p->d_scene_arrays, p->d_lidar_cnt};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -1191,6 +1195,7 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
     p->hgeo[0] = t2d_pool::HostGeo{};
     p->v.geo = p->d_geo;
     p->v.geo_layout = gl;
+    p->v.wgmap = nullptr;   // the launch shape may have changed
     {
         std::vector<float> zf(4 * (size_t)E, 0.f);
         std::vector<double> zd(8 * (size_t)E, 0.0);
@@ -1400,6 +1405,30 @@ int t2d_gather_wait(t2d_pool* p, void* hip_stream, int32_t block_host) {
 
 // introspection (not part of the ABI of include/t2d.h): resident workgroups per CU of the fused step kernel for this
 // pool's geometry, and its LDS bytes per workgroup -- the regression guard of tests/test_gpu_api.py
+int t2d_debug_set_step_placement(t2d_pool* p, const uint32_t* map_host, int32_t n_workgroups) {
+    if (!p) return T2D_ERR_INVALID;
+    T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, quiesce(p));
+    if (!map_host || n_workgroups <= 0) {   // back to the identity
+        p->v.wgmap = nullptr;
+        return T2D_OK;
+    }
+    const int epb = p->v.geo_layout.epb > 0 ? p->v.geo_layout.epb : 1;
+    const int n_blocks = (p->v.n_env + epb - 1) / epb;
+    if (n_workgroups != n_blocks) return fail(p, T2D_ERR_INVALID, "placement map must have one entry per workgroup of the step launch");
+    std::vector<uint8_t> seen((size_t)n_blocks, 0);
+    for (int b = 0; b < n_blocks; ++b) {   // a permutation of the workgroups, rotations 0..3
+        const uint32_t g = map_host[b] & 0xffffu, r = map_host[b] >> 16;
+        if (g >= (uint32_t)n_blocks || r > 3u || seen[g]) return fail(p, T2D_ERR_INVALID, "placement map is not a permutation with rotations 0..3");
+        seen[g] = 1;
+    }
+    if (!p->d_wgmap) T2D_HIP(p, hipMalloc((void**)&p->d_wgmap, sizeof(uint32_t) * 65536));
+    if (n_blocks > 65536) return fail(p, T2D_ERR_INVALID, "placement map: at most 65536 workgroups");
+    T2D_HIP(p, hipMemcpy(p->d_wgmap, map_host, sizeof(uint32_t) * (size_t)n_blocks, hipMemcpyHostToDevice));
+    p->v.wgmap = p->d_wgmap;
+    return T2D_OK;
+}
+
 int t2d_debug_step_occupancy(t2d_pool* p, int32_t* blocks_per_cu, int64_t* lds_bytes, int64_t* geometry_bytes_per_launch) {
     if (!p || !blocks_per_cu || !lds_bytes) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));

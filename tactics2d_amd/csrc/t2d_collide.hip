@@ -342,14 +342,23 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     asm volatile("" : "+s"(a_ids), "+s"(a_x), "+s"(a_y), "+s"(a_h), "+s"(a_v), "+s"(a_act0), "+s"(a_act1), "+s"(a_idm),
                       "+s"(a_params), "+s"(a_geo), "+s"(a_n_env), "+s"(a_A), "+s"(a_stride), "+s"(a_epb));
     const GeoLayout& gl = pv.geo_layout;
-    const int tid = threadIdx.x;
+    // Placement of the step launch (t2d_debug_set_step_placement): which logical workgroup -- which EPB envs -- this physical
+    // workgroup steps, and by how many waves its lane -> participant map is rotated.  Results do not depend on it; the
+    // hardware places workgroup b on XCD b mod 8 and its waves on fixed SIMDs, so the map decides which envs share a SIMD.
+    int wg = blockIdx.x, wave_rot = 0;
+    if (pv.wgmap) {
+        const uint32_t m = pv.wgmap[blockIdx.x];
+        wg = (int)(m & 0xffffu);
+        wave_rot = (int)(m >> 16);
+    }
+    const int tid = blockDim.x == kBlock ? (int)((threadIdx.x + 64u * (unsigned)wave_rot) & (kBlock - 1u)) : (int)threadIdx.x;
     const int lane = tid & 63;
     const int A_pad = 1 << log2A;
     const int EPB = a_epb;
     const int nthreads = EPB << log2A;
     const int env_local = tid >> log2A;
     const int agent = tid & (A_pad - 1);
-    const int env = blockIdx.x * EPB + env_local;
+    const int env = wg * EPB + env_local;
     const bool valid = env < a_n_env && agent < a_A;
     const int idx = valid ? env * a_A + agent : 0;
     const bool use_hash_grid = log2A > 6;  // envs larger than a wave use the LDS spatial hash
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     }
     // geometry record -> LDS, 16-B loads
     const int n_vec = a_geo ? a_stride >> 2 : 0;
-    const uint4* gsrc = reinterpret_cast<const uint4*>(a_geo + (size_t)blockIdx.x * a_stride);
+    const uint4* gsrc = reinterpret_cast<const uint4*>(a_geo + (size_t)wg * a_stride);
     {
         // rounds of 16-B loads this record needs (wave-uniform): 1 for the metric scenes (<= 4 KiB per workgroup) --
         // the unrolled generic form spends more on its per-load bounds logic than on the loads

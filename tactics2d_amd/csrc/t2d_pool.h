@@ -82,6 +82,8 @@ struct PoolView {
     // waves finish together.  1: launches of several pools overlap (t2d_step_groups): waves past the integrator go first,
     // so that workgroups retire and the next launch's can start.  See the priority note in t2d_collide.hip.
     int32_t overlapped;
+    // step launch: physical workgroup -> (logical workgroup | wave rotation << 16), or null = identity (t2d_set_step_placement)
+    const uint32_t* wgmap;
     unsigned long long* dbg;  // phase cycle accumulators (profiling builds with -DT2D_TIMING only)
     double cell;      // spatial-hash cell edge (m) >= max circum-diameter * 1.001
     double inv_cell;
@@ -192,6 +194,7 @@ struct t2d_pool {
     uint8_t* d_idm_ctrl = nullptr;
     float* d_snap[6]{};      // x, y, heading, speed, vx, vy at episode start
     uint32_t* d_snap_ids = nullptr;
+    uint32_t* d_wgmap = nullptr;   // step-launch placement (t2d_debug_set_step_placement)
     bool have_snapshot = false;
     bool auto_reset = false;
     // generated parking scenes (row f4): capacity-layout geometry owned by the device

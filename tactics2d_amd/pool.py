@@ -295,6 +295,15 @@ class ParticipantPool:
     def gather_wait(self, stream=None, block_host=False):
         self._ck(self._lib.t2d_gather_wait(self._h, stream, int(bool(block_host))))
 
+    def set_step_placement(self, wgmap=None):
+        """Which logical workgroup (and wave rotation << 16) each physical workgroup of the step launch steps; None = identity.
+        Never changes a result (t2d.h: t2d_debug_set_step_placement)."""
+        if wgmap is None:
+            self._ck(self._lib.t2d_debug_set_step_placement(self._h, None, 0))
+            return
+        m = np.ascontiguousarray(wgmap, np.uint32)
+        self._ck(self._lib.t2d_debug_set_step_placement(self._h, m.ctypes.data_as(C.POINTER(C.c_uint32)), int(m.size)))
+
     def step_occupancy(self):
         """(resident workgroups per CU, LDS bytes per workgroup) of the fused step kernel with this pool's geometry."""
         b, l, g = C.c_int32(), C.c_int64(), C.c_int64()
