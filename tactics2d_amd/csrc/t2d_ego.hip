@@ -84,6 +84,29 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d
         p1 = pstart[el + 1];
     }
 
+    // The inputs of the IoU phase and of the epilogue that do not depend on the new pose, requested now: one wave per SIMD
+    // hides nothing, so fetched where they are used each of them is a memory round trip of its own at the end of the chain
+    // (integrator -> pose -> obstacles -> IoUs -> status); requested here they arrive while the integrator runs.
+    const bool iou_on = cfg.check_no_action || cfg.check_arrival;
+    const int iou_k = l >> 3, iou_t = l & 7;   // lane's role in the IoU phase: which IoU, which coordinate / term
+    uint8_t pre_last_valid = 0;
+    double pre_other = 0.0;
+    int pre_cna = 0;
+    double pre_max_iou = 0.0, pre_min_dist = 0.0, pre_tcx = 0.0, pre_tcy = 0.0;
+    if (iou_on) {
+        pre_last_valid = pv.last_valid[env];
+        const double* other = iou_k == 0 ? pv.last_pose + 8 * (size_t)env : (pv.target_xy ? pv.target_xy + 8 * (size_t)env : nullptr);
+        if (other) pre_other = other[iou_t];
+        pre_cna = pv.cnt_na[env];
+    }
+    if (cfg.shaped_reward) {
+        pre_max_iou = pv.max_iou[env];
+        if (pv.target_c) {
+            pre_tcx = pv.target_c[2 * (size_t)env];
+            pre_tcy = pv.target_c[2 * (size_t)env + 1];
+            pre_min_dist = pv.min_dist[env];
+        }
+    }
     const bool active = live && ((ids >> kIdsActiveShift) & 0xffu);
     const int type = (ids >> kIdsTypeShift) & 0xff;
     const int model = (ids >> kIdsModelShift) & 0xff;
@@ -202,9 +225,8 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d
         const bool mine = ego_obb && (cfg.check_no_action || cfg.check_arrival);
         const int k = l >> 3;      // 0: NoAction (pose vs the previous pose), 1: Arrival (pose vs the target bay)
         const int t = l & 7;       // term: 0-3 = edges of the pose clipped to the other quad, 4-7 = the other way round
-        const bool want = mine && (k == 0 ? (cfg.check_no_action && pv.last_valid[env])
+        const bool want = mine && (k == 0 ? (cfg.check_no_action && pre_last_valid)
                                           : (cfg.check_arrival && pv.target_xy != nullptr));
-        const double* other = k == 0 ? pv.last_pose + 8 * (size_t)env : pv.target_xy + 8 * (size_t)env;
         {   // lane t of each IoU writes coordinate t of A (the pose, from registers) and of B
             double v = 0.0;
 #pragma unroll
@@ -213,7 +235,7 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d
                 v = t == 2 * q + 1 ? A.y[q] : v;
             }
             s_quad[grp][k][0][t] = v;
-            s_quad[grp][k][1][t] = want ? other[t] : 0.0;
+            s_quad[grp][k][1][t] = want ? pre_other : 0.0;
         }
         ego_wave_sync();
         double value = 0.0;
@@ -256,8 +278,8 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d
         bool na = false;
         if (cfg.check_no_action && ego_obb) {  // NoAction.update (no_action.py:41-53)
             double* last = pv.last_pose + 8 * (size_t)env;
-            int cna = pv.cnt_na[env];
-            if (!pv.last_valid[env]) {
+            int cna = pre_cna;
+            if (!pre_last_valid) {
                 pv.last_valid[env] = 1;
             } else {
                 cna = iou_na > (double)cfg.no_action_iou ? cna + 1 : 0;
@@ -290,16 +312,16 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d
     else {
         rd = cfg.max_step > 0 ? (pv.time_penalty ? pre_tp : -tanh((double)cnt / (double)cfg.max_step) * (double)cfg.time_penalty_scale) : 0.0;
         if (cfg.shaped_reward) {
-            double mi = pv.max_iou[env];
+            double mi = pre_max_iou;
             double iou_reward = 0.0;
             if (has_iou) iou_reward = mi == -INFINITY ? iou : iou - mi;
             rd = rd + iou_reward;
             if (has_iou) pv.max_iou[env] = mi > iou ? mi : iou;
             if (pv.target_c) {
-                const double dx = cx - pv.target_c[2 * (size_t)env];
-                const double dy = cy - pv.target_c[2 * (size_t)env + 1];
+                const double dx = cx - pre_tcx;
+                const double dy = cy - pre_tcy;
                 const double d = __builtin_sqrt(dx * dx + dy * dy);
-                const double md = pv.min_dist[env];
+                const double md = pre_min_dist;
                 if (d < md) {
                     rd += (md - d) * (double)cfg.dist_reward_scale;
                     pv.min_dist[env] = d;
@@ -319,22 +341,33 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d
     pv.record[env] = make_uint2(__float_as_uint(r), (uint32_t)scen | (uint32_t)traf << 8 |
                                                         (uint32_t)terminated << 16 | (uint32_t)truncated << 24);
     if (pv.auto_reset && (terminated || truncated)) {  // ParkingEnv.reset: state, counters, detector state back to the start
+        // (every snapshot value first, then the stores: as load / store pairs each pair waits for its own memory round trip)
+        const double smd = pv.snap_min_dist[env];
+        const float r0 = pv.snap[0][idx], r1 = pv.snap[1][idx], r2 = pv.snap[2][idx], r3 = pv.snap[3][idx];
+        const float r4 = pv.snap[4][idx], r5 = pv.snap[5][idx];
+        const uint32_t rid = pv.snap_ids[idx];
+        const bool drift = pv.snap_omega[0] != nullptr;
+        float w0 = 0.f, w1 = 0.f;
+        if (drift) {
+            w0 = pv.snap_omega[0][idx];
+            w1 = pv.snap_omega[1][idx];
+        }
         pv.cnt_step[env] = 0;
         pv.frame_ms[env] = 0;
         pv.last_valid[env] = 0;
         pv.cnt_na[env] = 0;
         pv.max_iou[env] = -INFINITY;
-        pv.min_dist[env] = pv.snap_min_dist[env];
-        pv.x[idx] = pv.snap[0][idx];
-        pv.y[idx] = pv.snap[1][idx];
-        pv.heading[idx] = pv.snap[2][idx];
-        pv.speed[idx] = pv.snap[3][idx];
-        pv.vx[idx] = pv.snap[4][idx];
-        pv.vy[idx] = pv.snap[5][idx];
-        pv.ids[idx] = pv.snap_ids[idx];
-        if (pv.snap_omega[0]) {
-            pv.omega_f[idx] = pv.snap_omega[0][idx];
-            pv.omega_r[idx] = pv.snap_omega[1][idx];
+        pv.min_dist[env] = smd;
+        pv.x[idx] = r0;
+        pv.y[idx] = r1;
+        pv.heading[idx] = r2;
+        pv.speed[idx] = r3;
+        pv.vx[idx] = r4;
+        pv.vy[idx] = r5;
+        pv.ids[idx] = rid;
+        if (drift) {
+            pv.omega_f[idx] = w0;
+            pv.omega_r[idx] = w1;
         }
     }
 }
