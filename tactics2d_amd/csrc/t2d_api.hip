@@ -305,7 +305,6 @@ int rebuild_geo(t2d_pool* p) {
         int rc = dev_replace<uint32_t>(p, &p->d_geo, nullptr, 0);
         p->v.geo = nullptr;
         p->v.geo_layout = gl;
-    p->v.wgmap = nullptr;   // the launch shape may have changed
         p->v.wgmap = nullptr;   // the launch shape may have changed
         return rc;
     }
