@@ -290,8 +290,11 @@ int t2d_set_ego_kernel(t2d_pool* pool, int32_t on);
  * groups whose launches overlap: one group's start-up latency and tail hide behind the others' busy middle,
  * DESIGN.md "Env groups").  For i in [0, n): if act0 / act1 are non-NULL, t2d_bind_actions(pools[i],
  * act0[i], act1[i]); then t2d_step(pools[i], interval_ms, hip_streams[i]).  Exists because at ~6 us of GPU
- * time per group and step, one host call per pool and per step is what limits the rate.  Returns the first
- * error (its message is on that pool).                                                                  */
+ * time per group and step, one host call per pool and per step is what limits the rate.  With n > 1 the step
+ * kernels are also told that launches overlap, which turns their wave priorities round (a launch that has the GPU
+ * to itself serves the waves that are behind first, overlapping launches the waves that are about to retire:
+ * DESIGN.md 4.2); pools stepped on different streams through separate t2d_step calls keep the single-launch rule.
+ * Returns the first error (its message is on that pool).                                                 */
 int t2d_step_groups(t2d_pool* const* pools, const float* const* act0_dev, const float* const* act1_dev,
                     void* const* hip_streams, int32_t n, int32_t interval_ms);
 
