@@ -42,6 +42,10 @@
 // bit-exact against the oracle's brute force.
 // With FUSE >= 0 the same kernel first integrates its participants in registers (t2d_step = one launch).
 // Bound: fp64 VALU issue + LDS latency (about 20 B of HBM per participant); see DESIGN.md.
+// This translation unit takes the fp64 constants of the deterministic trig kernels from constant memory (t2d_math.h):
+// 4 waves per SIMD hide the scalar loads and the kernel is issue-bound (- 1 %); the single-ego kernel, one wave per
+// SIMD and latency-bound, keeps them as literals (+ 4 % with the table).
+#define T2D_TRIG_TABLE 1
 #include "t2d_geom_dev.h"
 #include "t2d_integrate_dev.h"
 

@@ -18,9 +18,47 @@ constexpr double kPio2Mid = 6.123233995736766e-17;
 constexpr double kPio2Lo = -1.4973849048591698e-33;
 constexpr double kTwoOverPi = 0.6366197723675814;
 
+#ifdef T2D_TRIG_TABLE
+// (defined by a translation unit before it includes this header: t2d_collide.hip)
+// The fp64 constants of sincos_det / atan_det as tables in constant memory: as literals each of them costs two move
+// instructions every time the function runs (an fp64 literal cannot be an instruction operand), a table row comes in with
+// one scalar load for eight of them.  Same values, same operations, same bits.  (External linkage on purpose: a static
+// table that nothing writes is folded back into literals by the compiler.)
+__constant__ double kSinCosTab[16] = {
+    0.6366197723675814, 1.5707963267948966, 6.123233995736766e-17, -1.4973849048591698e-33,
+    1.58969099521155010221e-10, -2.50507602534068634195e-08, 2.75573137070700676789e-06, -1.98412698298579493134e-04,
+    8.33333333332248946124e-03, -1.66666666666666324348e-01,
+    -1.13596475577881948265e-11, 2.08757232129817482790e-09, -2.75573143513906633035e-07, 2.48015872894767294178e-05,
+    -1.38888888888741095749e-03, 4.16666666666666019037e-02};
+__constant__ double kAtanTab[12] = {
+    3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01, -1.11111104054623557880e-01,
+    9.09088713343650656196e-02, -7.69187620504482999495e-02, 6.66107313738753120669e-02, -5.83357013379057348645e-02,
+    4.97687799461593236017e-02, -3.65315727442169155270e-02, 1.62858201153657823623e-02, 0.0};
+#endif
 // sin/cos of x: 3-term Cody-Waite reduction by pi/2 (fma), minimax kernels on [-pi/4, pi/4].
 // <= 1 ulp against libm for |x| < ~1e5 (tests/test_oracle_geometry.py, tests/test_gpu_math.py).
 T2D_DEV void sincos_det(double x, double& s_out, double& c_out) {
+#ifdef T2D_TRIG_TABLE
+    const double* T = kSinCosTab;
+    double k = __builtin_rint(x * T[0]);
+    double r = __builtin_fma(-k, T[1], x);
+    r = __builtin_fma(-k, T[2], r);
+    r = __builtin_fma(-k, T[3], r);
+    double z = r * r;
+    double ps = T[4];
+    ps = __builtin_fma(ps, z, T[5]);
+    ps = __builtin_fma(ps, z, T[6]);
+    ps = __builtin_fma(ps, z, T[7]);
+    ps = __builtin_fma(ps, z, T[8]);
+    ps = __builtin_fma(ps, z, T[9]);
+    double sr = __builtin_fma(r * z, ps, r);
+    double pc = T[10];
+    pc = __builtin_fma(pc, z, T[11]);
+    pc = __builtin_fma(pc, z, T[12]);
+    pc = __builtin_fma(pc, z, T[13]);
+    pc = __builtin_fma(pc, z, T[14]);
+    pc = __builtin_fma(pc, z, T[15]);
+#else
     double k = __builtin_rint(x * kTwoOverPi);
     double r = __builtin_fma(-k, kPio2Hi, x);
     r = __builtin_fma(-k, kPio2Mid, r);
@@ -39,6 +77,7 @@ T2D_DEV void sincos_det(double x, double& s_out, double& c_out) {
     pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
     pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
     pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+#endif
     double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
     long long q = (long long)k;
     int quad = (int)(q & 3);
@@ -52,6 +91,22 @@ T2D_DEV void sincos_det(double x, double& s_out, double& c_out) {
 // r = x exactly, so the kernels alone give the very same bits without the rint / fma / quadrant selects.
 T2D_DEV void sincos_det_small(double r, double& s_out, double& c_out) {
     double z = r * r;
+#ifdef T2D_TRIG_TABLE
+    const double* T = kSinCosTab;
+    double ps = T[4];
+    ps = __builtin_fma(ps, z, T[5]);
+    ps = __builtin_fma(ps, z, T[6]);
+    ps = __builtin_fma(ps, z, T[7]);
+    ps = __builtin_fma(ps, z, T[8]);
+    ps = __builtin_fma(ps, z, T[9]);
+    s_out = __builtin_fma(r * z, ps, r);
+    double pc = T[10];
+    pc = __builtin_fma(pc, z, T[11]);
+    pc = __builtin_fma(pc, z, T[12]);
+    pc = __builtin_fma(pc, z, T[13]);
+    pc = __builtin_fma(pc, z, T[14]);
+    pc = __builtin_fma(pc, z, T[15]);
+#else
     double ps = 1.58969099521155010221e-10;
     ps = __builtin_fma(ps, z, -2.50507602534068634195e-08);
     ps = __builtin_fma(ps, z, 2.75573137070700676789e-06);
@@ -65,6 +120,7 @@ T2D_DEV void sincos_det_small(double r, double& s_out, double& c_out) {
     pc = __builtin_fma(pc, z, 2.48015872894767294178e-05);
     pc = __builtin_fma(pc, z, -1.38888888888741095749e-03);
     pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
+#endif
     c_out = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
 }
 // steering angles: |delta| <= 0.7 rad practically always
@@ -81,12 +137,18 @@ T2D_DEV double tan_det(double x) {
 
 // atan: 4-breakpoint reduction + odd polynomial (no fma; see oracle t2do_atan).
 T2D_DEV double atan_det(double x) {
+#ifdef T2D_TRIG_TABLE
+    const double* AT = kAtanTab;
+    const double aT0 = AT[0], aT1 = AT[1], aT2 = AT[2], aT3 = AT[3], aT4 = AT[4], aT5 = AT[5], aT6 = AT[6], aT7 = AT[7],
+                 aT8 = AT[8], aT9 = AT[9], aT10 = AT[10];
+#else
     const double aT0 = 3.33333333333329318027e-01, aT1 = -1.99999999998764832476e-01,
                  aT2 = 1.42857142725034663711e-01, aT3 = -1.11111104054623557880e-01,
                  aT4 = 9.09088713343650656196e-02, aT5 = -7.69187620504482999495e-02,
                  aT6 = 6.66107313738753120669e-02, aT7 = -5.83357013379057348645e-02,
                  aT8 = 4.97687799461593236017e-02, aT9 = -3.65315727442169155270e-02,
                  aT10 = 1.62858201153657823623e-02;
+#endif
     bool neg = x < 0.0;
     double ax = __builtin_fabs(x);
     if (ax != ax) return x;
