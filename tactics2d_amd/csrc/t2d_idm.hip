@@ -56,23 +56,30 @@ __global__ __launch_bounds__(kIdmBlock) void idm_kernel(PoolView pv, IdmView iv,
     __shared__ double2 s_xy[kIdmBlock];
     __shared__ float s_v[kIdmBlock];
     const int tid = threadIdx.x;
+    // every kernel argument of the load phase in one scalar round trip (see collide_kernel)
+    const uint32_t* a_ids = pv.ids;
+    const float *a_x = pv.x, *a_y = pv.y, *a_h = pv.heading, *a_v = pv.speed;
+    const uint8_t* a_ctrl = iv.ctrl_id;
+    const double* a_rows = iv.rows;
+    int a_n_env = pv.n_env, a_A = pv.A;
+    asm volatile("" : "+s"(a_ids), "+s"(a_x), "+s"(a_y), "+s"(a_h), "+s"(a_v), "+s"(a_ctrl), "+s"(a_rows), "+s"(a_n_env), "+s"(a_A));
     const int A_pad = 1 << log2A;
     const int epb = kIdmBlock >> log2A;
     const int env_local = tid >> log2A;
     const int agent = tid & (A_pad - 1);
     const int env = blockIdx.x * epb + env_local;
-    const bool valid = env < pv.n_env && agent < pv.A;
-    const int idx = valid ? env * pv.A + agent : 0;
+    const bool valid = env < a_n_env && agent < a_A;
+    const int idx = valid ? env * a_A + agent : 0;
     float fx = 0, fy = 0, fh = 0, fv = 0;
     uint32_t ids = 0;
     int ctrl = T2D_IDM_NONE;
     if (valid) {
-        ids = pv.ids[idx];
-        fx = pv.x[idx];
-        fy = pv.y[idx];
-        fh = pv.heading[idx];
-        fv = pv.speed[idx];
-        ctrl = iv.ctrl_id[idx];
+        ids = a_ids[idx];
+        fx = a_x[idx];
+        fy = a_y[idx];
+        fh = a_h[idx];
+        fv = a_v[idx];
+        ctrl = a_ctrl[idx];
     }
     const bool active = valid && ((ids >> kIdsActiveShift) & 0xffu);
     const double qnan = __builtin_nan("");
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(kIdmBlock) void idm_kernel(PoolView pv, IdmView iv,
     if (!valid) return;
     int lead = -1;
     if (active && ctrl != T2D_IDM_NONE && ctrl < iv.n_ctrl) {
-        const double* c = iv.rows + (size_t)ctrl * T2D_IDM_COLS;
+        const double* c = a_rows + (size_t)ctrl * T2D_IDM_COLS;
         const double hw = c[T2D_IDM_LANE_HALF_WIDTH], horizon = c[T2D_IDM_HORIZON];
         double sn, cs;
         sincos_det((double)fh, sn, cs);
