@@ -266,6 +266,10 @@ int t2d_reset(t2d_pool* pool, const uint8_t* env_mask, const float* x, const flo
  * own ACT0/ACT1 fields, where t2d_idm_actions writes).  t2d_upload of ACT0 / ACT1 ends a binding:
  * uploaded actions are the actions from then on.                                                */
 int t2d_bind_actions(t2d_pool* pool, const float* act0_dev, const float* act1_dev);
+/* The same with a stride: participant i's actions are act0_dev[i * stride] and act1_dev[i * stride] (stride in
+ * elements, >= 1).  A policy's [N, 2] output in the reference's (steering, accel) layout (envs/parking.py:130-139)
+ * binds as act0 = out + 1, act1 = out, stride = 2 -- no copy kernels between the policy and the step.              */
+int t2d_bind_actions_strided(t2d_pool* pool, const float* act0_dev, const float* act1_dev, int32_t stride);
 
 /* Physics only: one PhysicsModelBase.step(interval_ms) for every active participant,
  * actions taken from fields ACT0/ACT1.                                                  */

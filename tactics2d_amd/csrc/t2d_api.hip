@@ -584,6 +584,7 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
     v.vy = (float*)p->field_ptr[T2D_F_VY];
     v.act0 = (float*)p->field_ptr[T2D_F_ACT0];
     v.act1 = (float*)p->field_ptr[T2D_F_ACT1];
+    v.act_stride = 1;
     v.applied0 = (float*)p->field_ptr[T2D_F_APPLIED0];
     v.applied1 = (float*)p->field_ptr[T2D_F_APPLIED1];
     v.omega_f = (float*)p->field_ptr[T2D_F_OMEGA_F];
@@ -938,14 +939,20 @@ static void refresh_idm_view(t2d_pool* p) {
     p->v.own_act1 = sel ? (const float*)p->field_ptr[T2D_F_ACT1] : nullptr;
 }
 
-int t2d_bind_actions(t2d_pool* p, const float* act0_dev, const float* act1_dev) {
+int t2d_bind_actions_strided(t2d_pool* p, const float* act0_dev, const float* act1_dev, int32_t stride) {
     if (!p) return T2D_ERR_INVALID;
     if ((act0_dev == nullptr) != (act1_dev == nullptr))
         return fail(p, T2D_ERR_INVALID, "bind both action arrays or neither");
+    if (act0_dev && stride < 1) return fail(p, T2D_ERR_INVALID, "action stride must be >= 1 element");
     p->v.act0 = act0_dev ? act0_dev : (const float*)p->field_ptr[T2D_F_ACT0];
     p->v.act1 = act1_dev ? act1_dev : (const float*)p->field_ptr[T2D_F_ACT1];
+    p->v.act_stride = act0_dev ? stride : 1;
     refresh_idm_view(p);
     return T2D_OK;
+}
+
+int t2d_bind_actions(t2d_pool* p, const float* act0_dev, const float* act1_dev) {
+    return t2d_bind_actions_strided(p, act0_dev, act1_dev, 1);
 }
 
 static int drift_impl(t2d_pool* p, int interval_ms, hipStream_t s) {
@@ -1475,6 +1482,7 @@ int t2d_upload(t2d_pool* p, int32_t f, const void* host_src, size_t nbytes) {
     if (f == T2D_F_ACT0 || f == T2D_F_ACT1) {
         p->v.act0 = (const float*)p->field_ptr[T2D_F_ACT0];
         p->v.act1 = (const float*)p->field_ptr[T2D_F_ACT1];
+        p->v.act_stride = 1;
         refresh_idm_view(p);
     }
     return T2D_OK;

@@ -340,11 +340,11 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     const uint8_t* a_idm = pv.idm_ctrl;
     const double* a_params = pv.params;
     const uint32_t* a_geo = pv.geo;
-    int a_n_env = pv.n_env, a_A = pv.A, a_stride = pv.geo_layout.stride, a_epb = pv.geo_layout.epb;
+    int a_n_env = pv.n_env, a_A = pv.A, a_stride = pv.geo_layout.stride, a_epb = pv.geo_layout.epb, a_act_stride = pv.act_stride;
     // (in-out operands: the values after the asm are new to the compiler, so it keeps them in registers instead of
     // dropping them and fetching the same arguments again behind the next branch)
     asm volatile("" : "+s"(a_ids), "+s"(a_x), "+s"(a_y), "+s"(a_h), "+s"(a_v), "+s"(a_act0), "+s"(a_act1), "+s"(a_idm),
-                      "+s"(a_params), "+s"(a_geo), "+s"(a_n_env), "+s"(a_A), "+s"(a_stride), "+s"(a_epb));
+                      "+s"(a_params), "+s"(a_geo), "+s"(a_n_env), "+s"(a_A), "+s"(a_stride), "+s"(a_epb), "+s"(a_act_stride));
     const GeoLayout& gl = pv.geo_layout;
     // Placement of the step launch (t2d_debug_set_step_placement): which logical workgroup -- which EPB envs -- this physical
     // workgroup steps, and by how many waves its lane -> participant map is rotated.  Results do not depend on it; the
@@ -406,8 +406,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         fh = a_h[idx];
         if (FUSE >= 0) {
             fv = a_v[idx];
-            fa0 = a_act0[idx];
-            fa1 = a_act1[idx];
+            fa0 = a_act0[(size_t)idx * a_act_stride];
+            fa1 = a_act1[(size_t)idx * a_act_stride];
             if (a_idm && a_idm[idx] != T2D_IDM_NONE) {  // IDM lane while caller actions are bound
                 fa0 = pv.own_act0[idx];
                 fa1 = pv.own_act1[idx];

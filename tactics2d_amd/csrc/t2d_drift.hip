@@ -85,7 +85,8 @@ __global__ __launch_bounds__(kDriftBlock) void drift_kernel(PoolView pv, int int
     double x = (double)pv.x[i], y = (double)pv.y[i], phi = (double)pv.heading[i], v = (double)pv.speed[i];
     double omega_wf = (double)pv.omega_f[i], omega_wr = (double)pv.omega_r[i];
     const bool idm_lane = pv.idm_ctrl && pv.idm_ctrl[i] != T2D_IDM_NONE;   // IDM lane while caller actions are bound
-    double accel = (double)(idm_lane ? pv.own_act0[i] : pv.act0[i]), delta = (double)(idm_lane ? pv.own_act1[i] : pv.act1[i]);
+    double accel = (double)(idm_lane ? pv.own_act0[i] : pv.act0[(size_t)i * pv.act_stride]),
+           delta = (double)(idm_lane ? pv.own_act1[i] : pv.act1[(size_t)i * pv.act_stride]);
     const int flags = (int)P(T2D_P_RANGE_FLAGS);
     if (flags & T2D_RANGE_ACCEL) accel = clipd(accel, P(T2D_P_ACCEL_LO), P(T2D_P_ACCEL_HI));
     if (flags & T2D_RANGE_STEER) delta = clipd(delta, P(T2D_P_STEER_LO), P(T2D_P_STEER_HI));

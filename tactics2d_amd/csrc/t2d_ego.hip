@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d
     const uint32_t ids = pv.ids[idx];
     float fx = pv.x[idx], fy = pv.y[idx], fh = pv.heading[idx];
     const float fv = pv.speed[idx];
-    float fa0 = pv.act0[idx], fa1 = pv.act1[idx];
+    float fa0 = pv.act0[(size_t)idx * pv.act_stride], fa1 = pv.act1[(size_t)idx * pv.act_stride];
     if (pv.idm_ctrl && pv.idm_ctrl[idx] != T2D_IDM_NONE) {
         fa0 = pv.own_act0[idx];
         fa1 = pv.own_act1[idx];

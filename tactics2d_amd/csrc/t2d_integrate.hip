@@ -48,8 +48,8 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(PoolView pv, int inte
         fy = pv.y[i];
         fh = pv.heading[i];
         fv = pv.speed[i];
-        fa0 = pv.act0[i];
-        fa1 = pv.act1[i];
+        fa0 = pv.act0[(size_t)i * pv.act_stride];
+        fa1 = pv.act1[(size_t)i * pv.act_stride];
         if (pv.idm_ctrl && pv.idm_ctrl[i] != T2D_IDM_NONE) {  // IDM lane while caller actions are bound
             fa0 = pv.own_act0[i];
             fa1 = pv.own_act1[i];

@@ -46,6 +46,7 @@ struct PoolView {
     int32_t n_env, A, N;
     float *x, *y, *heading, *speed, *vx, *vy, *applied0, *applied1;
     const float *act0, *act1;   // the pool's own action fields, or caller-owned device memory (t2d_bind_actions): read only
+    int32_t act_stride;         // participant i's actions are act0[i * act_stride], act1[i * act_stride] (1 unless bound strided)
     // IDM agents while caller actions are bound: controlled lanes (idm_ctrl[i] != T2D_IDM_NONE) take their action from the
     // pool's own fields, where the idm kernel writes -- never into the caller's memory.  Null otherwise.
     const uint8_t* idm_ctrl;

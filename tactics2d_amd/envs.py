@@ -153,8 +153,13 @@ class VecParkingEnv:
         dev = actions.device
         st = stream if stream is not None else torch.cuda.current_stream(dev)
         with torch.cuda.stream(st):
-            self._act = (actions[:, 1].contiguous(), actions[:, 0].contiguous())   # (accel, steering); kept alive
-            pool.bind_actions(self._act[0].data_ptr(), self._act[1].data_ptr())
+            # the [n, 2] (steering, accel) tensor is read in place: accel = column 1, steering = column 0, stride 2
+            # (two copy kernels per step otherwise: 4.7 us of a 36 us vector step); kept alive until the next step
+            if actions.dtype != torch.float32 or tuple(actions.shape) != (self.n_envs, 2):
+                raise ValueError(f"actions must be float32 [{self.n_envs}, 2]")
+            self._act = actions if actions.is_contiguous() else actions.contiguous()
+            base = self._act.data_ptr()
+            pool.bind_actions(base + 4, base, stride=2)
             pool.step(100, st.cuda_stream)
             if getattr(self, "_t_lidar", None) is None or self._t_lidar.device != dev:
                 self._t_lidar = torch.empty((self.n_envs, 360), dtype=torch.float32, device=dev)

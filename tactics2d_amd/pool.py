@@ -219,9 +219,13 @@ class ParticipantPool:
         self.upload(L.F_ACT0, act0)
         self.upload(L.F_ACT1, act1)
 
-    def bind_actions(self, act0_ptr=None, act1_ptr=None):
-        """Zero-copy actions from caller-owned device memory (raw pointers, e.g. tensor.data_ptr())."""
-        self._ck(self._lib.t2d_bind_actions(self._h, act0_ptr, act1_ptr))
+    def bind_actions(self, act0_ptr=None, act1_ptr=None, stride=1):
+        """Zero-copy actions from caller-owned device memory (raw pointers, e.g. tensor.data_ptr()); participant i reads
+        element i * stride of each (a policy's [N, 2] (steering, accel) tensor: act0 = ptr + 4, act1 = ptr, stride = 2)."""
+        if stride == 1:
+            self._ck(self._lib.t2d_bind_actions(self._h, act0_ptr, act1_ptr))
+        else:
+            self._ck(self._lib.t2d_bind_actions_strided(self._h, act0_ptr, act1_ptr, int(stride)))
 
     def field_ptr(self, field):
         ptr, nb = C.c_void_p(), C.c_size_t()

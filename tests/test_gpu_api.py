@@ -295,3 +295,41 @@ def test_step_placement_never_changes_a_result():
             pool.set_step_placement(m)
     pool.set_step_placement(None)
     pool.close()
+
+
+@pytest.mark.gpu
+def test_strided_action_binding_equals_split_arrays():
+    """t2d_bind_actions_strided: a policy's [N, 2] (steering, accel) tensor read in place gives the step the split
+    contiguous arrays give -- fused step, two-launch step, single-ego kernel; stride < 1 is rejected."""
+    import torch
+    from tactics2d_amd import scenarios as S, layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    from tactics2d_amd._ffi import T2DError
+    dev = torch.device("cuda", 0)
+    for sc, fused in ((S.mixed(48, 64, 7), True), (S.mixed(48, 64, 7), False), (S.parking(200), True)):
+        rng = np.random.default_rng(11)
+        outs = []
+        for strided in (False, True):
+            pool = ParticipantPool(sc.n_env, sc.A); sc.load(pool); pool.set_fused_step(fused)
+            res = []
+            keep = []
+            for k in range(5):
+                a0, a1 = sc.sample_actions(np.random.default_rng(100 + k))
+                if strided:
+                    t = torch.from_numpy(np.stack([a1, a0], 1).copy()).to(dev)     # [N, 2] = (steering, accel)
+                    pool.bind_actions(t.data_ptr() + 4, t.data_ptr(), stride=2)
+                else:
+                    t = (torch.from_numpy(a0).to(dev), torch.from_numpy(a1).to(dev))
+                    pool.bind_actions(t[0].data_ptr(), t[1].data_ptr())
+                keep.append(t)
+                pool.step(100)
+                res.append([pool.download(f).copy() for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_APPLIED0, L.F_APPLIED1, L.F_FLAGS)])
+            pool.sync()
+            outs.append(res)
+            if strided:
+                with pytest.raises(T2DError):
+                    pool.bind_actions(keep[-1].data_ptr() + 4, keep[-1].data_ptr(), stride=0)
+            pool.close()
+        for ra, rb in zip(*outs):
+            for a, b in zip(ra, rb):
+                assert np.array_equal(a, b, equal_nan=True)
