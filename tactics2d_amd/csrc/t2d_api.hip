@@ -1409,8 +1409,7 @@ int t2d_gather_wait(t2d_pool* p, void* hip_stream, int32_t block_host) {
     return T2D_OK;
 }
 
-// introspection (not part of the ABI of include/t2d.h): resident workgroups per CU of the fused step kernel for this
-// pool's geometry, and its LDS bytes per workgroup -- the regression guard of tests/test_gpu_api.py
+// placement of the step launch (include/t2d.h): a permutation of its workgroups + a wave rotation per workgroup
 int t2d_debug_set_step_placement(t2d_pool* p, const uint32_t* map_host, int32_t n_workgroups) {
     if (!p) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));
@@ -1435,6 +1434,8 @@ int t2d_debug_set_step_placement(t2d_pool* p, const uint32_t* map_host, int32_t 
     return T2D_OK;
 }
 
+// introspection: resident workgroups per CU of the fused step kernel for this pool's geometry, and its LDS bytes per
+// workgroup -- the regression guard of tests/test_gpu_api.py
 int t2d_debug_step_occupancy(t2d_pool* p, int32_t* blocks_per_cu, int64_t* lds_bytes, int64_t* geometry_bytes_per_launch) {
     if (!p || !blocks_per_cu || !lds_bytes) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));
