@@ -512,7 +512,13 @@ def main():
                 # bytes), launch duration measured here.  SQ_ACTIVE_INST_VALU (quad-cycles) of the same pass gives the
                 # VALU-busy fraction of that (serialised, slower-clocked) profiled launch for comparison.
                 insts = float(sq["SQ_INSTS_VALU"])
-                ach_i = insts / (kern[dom]["avg_us"] * 1e-6) / 1e9
+                # launch duration: with ONE launch per step and the launches back to back on one stream (fused step, one env
+                # group) the HIP-event span of the timed region divided by its launches IS the average launch duration
+                # -- the figure rocprofv3 reports for the same command (profiles/*_kernel_stats.csv); events recorded
+                # around every single launch (the second pass) put ~2.4 us of event packets between the kernels
+                back_to_back = G == 1 and in_step == {"step_kernel"}
+                launch_us = span_ms * 1e3 / args.steps if back_to_back else kern[dom]["avg_us"]
+                ach_i = insts / (launch_us * 1e-6) / 1e9
                 kcyc = sq["SQ_BUSY_CYCLES"] / 32.0          # summed over 8 XCDs x 4 SEs
                 roof = dict(bound="valu_fp64_issue", kernel=dom, achieved=ach_i, peak=VALU_ISSUE_PEAK_GINST,
                             unit="G wave-instructions/s", frac=ach_i / VALU_ISSUE_PEAK_GINST,
@@ -525,7 +531,10 @@ def main():
             roof.update(traffic=traffic, traffic_source=traffic_src, hbm=hbm, concurrent_launches=G,
                         launches_in_timed_region=G * args.steps, timed_region_event_span_ms=span_ms,
                         avg_kernel_us=kern[dom]["avg_us"],
-                        how=(f"avg_kernel_us: HIP events around each launch of the kernel on its launch stream, {kern[dom]['launches']} "
+                        launch_us=(span_ms * 1e3 / args.steps if (G == 1 and in_step == {"step_kernel"}) else kern[dom]["avg_us"]),
+                        how=(f"launch_us (what `achieved` divides by): HIP-event span of the timed region / its launches when there "
+                             f"is one back-to-back launch per step, else avg_kernel_us; "
+                             f"avg_kernel_us: HIP events around each launch of the kernel on its launch stream, {kern[dom]['launches']} "
                              f"launches in a second pass of the same steps after {PREWARM} untimed launches of the same form (outside "
                              f"`value`); hbm.achieved = algorithmic bytes of all launches in the timed region / HIP-event span of "
                              f"that region"),
