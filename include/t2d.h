@@ -467,7 +467,7 @@ int t2d_gather_wait(t2d_pool* pool, void* hip_stream, int32_t block_host);
  * max_agents unless the geometry budget narrowed it) | wave rotation 0..3 << 16 that physical workgroup b steps.  Must be a
  * permutation of the launch's workgroups; NULL / 0 restores the identity.  Results never depend on it -- the hardware
  * places workgroup b on XCD b mod 8 and its waves on fixed SIMDs, so the map only decides which envs share a SIMD and
- * which XCD (they start up to 2.5 us apart) gets the expensive ones.  Reset by every t2d_set_*_geometry.  Host memory. */
+ * which XCD gets the expensive ones.  Reset by every t2d_set_*_geometry.  Host memory.                                  */
 int t2d_debug_set_step_placement(t2d_pool* pool, const uint32_t* map_host, int32_t n_workgroups);
 
 int t2d_debug_step_occupancy(t2d_pool* pool, int32_t* blocks_per_cu, int64_t* lds_bytes,
