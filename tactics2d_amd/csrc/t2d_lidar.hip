@@ -47,25 +47,50 @@ T2D_DEV EdgePre edge_pre(double x1, double y1, double x2, double y2) {
     return p;
 }
 
+// n1 / d and n2 / d, each correctly rounded exactly as the `/` operator rounds it: the compiler's own fp64 division sequence
+// (v_div_scale, v_rcp + two Newton steps on the scaled denominator, quotient, residual, v_div_fmas, v_div_fixup), written
+// out so that the two quotients share the refined reciprocal -- it depends on the scaled denominator alone.  The scaling
+// looks at the numerator's exponent too, so the sharing is conditional on both divisions scaling the denominator alike
+// (always, for coordinates in metres); a lane where they differ divides the second quotient on its own.
+T2D_DEV void div_pair(double n1, double n2, double d, double& q1, double& q2) {
+    bool f1, f2, unused;
+    const double ds1 = __builtin_amdgcn_div_scale(n1, d, false, &unused);   // scaled denominator
+    const double ds2 = __builtin_amdgcn_div_scale(n2, d, false, &unused);
+    const double ns1 = __builtin_amdgcn_div_scale(n1, d, true, &f1);        // scaled numerators
+    const double ns2 = __builtin_amdgcn_div_scale(n2, d, true, &f2);
+    double r = __builtin_amdgcn_rcp(ds1);
+    double e = __builtin_fma(-ds1, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-ds1, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double qa = ns1 * r;
+    const double ra = __builtin_fma(-ds1, qa, ns1);
+    q1 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(ra, r, qa, f1), d, n1);
+    if (__builtin_expect(__double_as_longlong(ds1) == __double_as_longlong(ds2), 1)) {
+        const double qb = ns2 * r;
+        const double rb = __builtin_fma(-ds1, qb, ns2);
+        q2 = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(rb, r, qb, f2), d, n2);
+    } else {
+        q2 = n2 / d;
+    }
+}
+
 // (returns the squared distance; see the note at its end)
 T2D_DEV double lidar_edge(double a, double b, double bx_hi, double bx_lo, double by_hi, double by_lo, double R,
                           const EdgePre& E) {
-    const double tinf = R * 10;
     double det = a * E.e - b * E.d;
     const bool parallel = det == 0.0;
     if (parallel) det = 1.0;
-    double rx = (b * E.f) / det;
-    double ry = (-(a * E.f)) / det;
-    if (rx > bx_hi) rx = tinf;   // the beam's end-point bounds (t2d_lidar_config) ...
-    if (rx < bx_lo) rx = tinf;
-    if (ry > by_hi) ry = tinf;
-    if (ry < by_lo) ry = tinf;
-    if (rx > E.x_hi) rx = tinf;   // ... and the segment's
-    if (rx < E.x_lo) rx = tinf;
-    if (ry > E.y_hi) ry = tinf;
-    if (ry < E.y_lo) ry = tinf;
-    if (parallel) rx = tinf;
-    return rx * rx + ry * ry;   // SQUARED distance: sqrt is monotone, so the per-beam minimum takes one sqrt at the end
+    double rx, ry;
+    div_pair(b * E.f, -(a * E.f), det, rx, ry);
+    // The reference replaces a coordinate that fails one of its eight bounds by 10 R, which makes the candidate's distance
+    // >= 10 R: clipped to R at the end, i.e. "no return".  Any value >= R does the same, so the eight tests are collected
+    // (bitwise: no control flow) and a rejected candidate contributes +inf.  A NaN coordinate fails no test and makes the
+    // distance NaN, which the caller skips -- as in the reference's sequence of replacements.
+    const bool bad = parallel | (rx > bx_hi) | (rx < bx_lo) | (ry > by_hi) | (ry < by_lo) | (rx > E.x_hi) | (rx < E.x_lo) |
+                     (ry > E.y_hi) | (ry < E.y_lo);
+    const double dd = rx * rx + ry * ry;   // SQUARED distance: sqrt is monotone, so the per-beam minimum takes one sqrt at the end
+    return bad ? __builtin_inf() : dd;
 }
 
 // Beam-index span of an edge given in the sensor frame: {first beam, number of further beams} or
