@@ -33,7 +33,6 @@ using namespace geom;
 
 constexpr int kEgoBlock = 256;
 constexpr int kEgoLanes = 16;                        // lanes per environment
-constexpr int kEgoPerWave = 64 / kEgoLanes;          // environments per wave
 constexpr int kEgoPerBlock = kEgoBlock / kEgoLanes;  // environments per workgroup
 
 T2D_DEV void ego_wave_sync() {   // LDS writes of this wave -> visible to its other lanes

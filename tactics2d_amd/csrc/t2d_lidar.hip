@@ -252,6 +252,11 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
             }
         }
     }
+    // (the beam tables of phase 2 are initialised on this side of the barrier: the first chunk then needs none of its own)
+    for (int k = tid; k < lv.n_beams; k += kLidarBlock) {
+        s_best[k] = 0x7ff0000000000000ull;
+        s_mask[k] = 0ull;
+    }
     __syncthreads();
 
     T2D_LMARK(1);
@@ -263,8 +268,6 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     // 64-bit LDS atomic min on the bit pattern (distances are >= 0, so the order of bit patterns is the order of
     // values).  min over the same set of values: the result does not depend on the evaluation order.
     const double R = lv.max_range;
-    const unsigned long long inf_bits = 0x7ff0000000000000ull;
-    for (int k = tid; k < lv.n_beams; k += kLidarBlock) s_best[k] = inf_bits;
     const int lane = tid & 63, wave = tid >> 6;
     uint32_t* const queue = s_queue + wave * kLidarQueue;
     int* const qcount = &s_qcount[wave];
@@ -277,8 +280,10 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     for (int c0 = 0; c0 < n_slots && scan; c0 += 64) {
         // pass 1, edge-major: every edge of the chunk ORs its bit into the masks of the beams of its span (two
         // lanes per edge, alternate beams) -- sum of span lengths instead of beams x edges comparisons
-        for (int k = tid; k < lv.n_beams; k += kLidarBlock) s_mask[k] = 0ull;
-        __syncthreads();
+        if (c0 > 0) {
+            for (int k = tid; k < lv.n_beams; k += kLidarBlock) s_mask[k] = 0ull;
+            __syncthreads();
+        }
         {
             // short spans: the edge's two lanes take alternate beams (<= kLongSpan / 2 rounds); a long span (a wall a
             // few metres away covers 100+ beams) would keep the other 126 lanes at the barrier for one pair's 50+
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
             }
         }
         T2D_LMARK(3);
-        __syncthreads();  // the next chunk clears s_mask
+        if (c0 + 64 < n_slots) __syncthreads();  // the next chunk clears s_mask
     }
     wave_sync();
     __builtin_amdgcn_s_setprio(0);
