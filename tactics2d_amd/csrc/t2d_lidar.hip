@@ -78,17 +78,17 @@ T2D_DEV void div_pair(double n1, double n2, double d, double& q1, double& q2) {
 // (returns the squared distance; see the note at its end)
 T2D_DEV double lidar_edge(double a, double b, double bx_hi, double bx_lo, double by_hi, double by_lo, double R,
                           const EdgePre& E) {
-    double det = a * E.e - b * E.d;
-    const bool parallel = det == 0.0;
-    if (parallel) det = 1.0;
+    const double det = a * E.e - b * E.d;
     double rx, ry;
     div_pair(b * E.f, -(a * E.f), det, rx, ry);
     // The reference replaces a coordinate that fails one of its eight bounds by 10 R, which makes the candidate's distance
-    // >= 10 R: clipped to R at the end, i.e. "no return".  Any value >= R does the same, so the eight tests are collected
-    // (bitwise: no control flow) and a rejected candidate contributes +inf.  A NaN coordinate fails no test and makes the
-    // distance NaN, which the caller skips -- as in the reference's sequence of replacements.
-    const bool bad = parallel | (rx > bx_hi) | (rx < bx_lo) | (ry > by_hi) | (ry < by_lo) | (rx > E.x_hi) | (rx < E.x_lo) |
-                     (ry > E.y_hi) | (ry < E.y_lo);
+    // >= 10 R: clipped to R at the end, i.e. "no return".  Any value >= R does the same, so a rejected candidate
+    // contributes +inf, and the two bounds on each side of a coordinate -- the beam's and the segment's -- are one
+    // (rx > hi1 or rx > hi2  <=>  rx > min(hi1, hi2)).  A NaN coordinate fails no test and makes the distance NaN, which
+    // the caller skips -- as in the reference's sequence of replacements.  Parallel beam and edge (det = 0; the reference
+    // divides by 1 instead and rejects the candidate): the quotients are +-inf, which fail a bound, or NaN.
+    const bool bad = (rx > __builtin_fmin(bx_hi, E.x_hi)) | (rx < __builtin_fmax(bx_lo, E.x_lo)) |
+                     (ry > __builtin_fmin(by_hi, E.y_hi)) | (ry < __builtin_fmax(by_lo, E.y_lo));
     const double dd = rx * rx + ry * ry;   // SQUARED distance: sqrt is monotone, so the per-beam minimum takes one sqrt at the end
     return bad ? __builtin_inf() : dd;
 }
