@@ -416,6 +416,7 @@ int rebuild_lidar_geo(t2d_pool* p) {
     int rc;
     p->lidar.max_static_verts = 0;
     p->lidar.env_vert_cnt = nullptr;
+    p->lidar.edge_meta = nullptr;
     if (p->scene_mode) {  // generated scenes: every env owns 4 * T2D_GEN_MAX_QUADS edge slots of d_lidar_xy, the
         constexpr int VS = 4 * T2D_GEN_MAX_QUADS;  // scene kernel maintains the edges and the per-env count
         std::vector<int32_t> evo(E + 1);
@@ -438,8 +439,31 @@ int rebuild_lidar_geo(t2d_pool* p) {
                 edges[4 * (size_t)v + 2] = g.ring_xy[2 * (size_t)nx]; edges[4 * (size_t)v + 3] = g.ring_xy[2 * (size_t)nx + 1];
             }
         for (int e = 0; e < E; ++e) p->lidar.max_static_verts = std::max(p->lidar.max_static_verts, evo[e + 1] - evo[e]);
+        // which rings may take part in the scan's occlusion culling (t2d_lidar.hip): well-shaped rings (the chord bound of
+        // the culling argument needs sin(interior angle) >= 0.05 at every vertex) of envs with <= 16 rings and <= 32 edges
+        std::vector<uint8_t> meta((size_t)V, 0xff);
+        for (int e = 0; e < E; ++e) {
+            const int q0 = g.ring_env_off[e], q1 = g.ring_env_off[e + 1];
+            if (q1 - q0 > 16 || evo[e + 1] - evo[e] > 32) continue;
+            for (int q = q0; q < q1; ++q) {
+                const int a = g.ring_vert_off[q], n = g.ring_vert_off[q + 1] - a;
+                bool ok = true;
+                for (int i = 0; i < n && ok; ++i) {
+                    const float* v = &g.ring_xy[2 * (size_t)(a + i)];
+                    const float* pr = &g.ring_xy[2 * (size_t)(a + (i + n - 1) % n)];
+                    const float* nx = &g.ring_xy[2 * (size_t)(a + (i + 1) % n)];
+                    const double ux = (double)pr[0] - v[0], uy = (double)pr[1] - v[1], wx = (double)nx[0] - v[0], wy = (double)nx[1] - v[1];
+                    const double cr = std::fabs(ux * wy - uy * wx), den = std::sqrt((ux * ux + uy * uy) * (wx * wx + wy * wy));
+                    ok = den > 0.0 && cr >= 0.05 * den;
+                }
+                if (ok)
+                    for (int i = 0; i < n; ++i) meta[(size_t)(a + i)] = (uint8_t)(q - q0);
+            }
+        }
         if ((rc = dev_replace(p, &p->d_lidar_env_off, evo.data(), evo.size()))) return rc;
         if ((rc = dev_replace(p, &p->d_lidar_xy, edges.data(), edges.size()))) return rc;
+        if ((rc = dev_replace(p, &p->d_lidar_meta, meta.data(), meta.size()))) return rc;
+        p->lidar.edge_meta = p->d_lidar_meta;
     }
     p->lidar.env_vert_off = p->d_lidar_env_off;
     p->lidar.xy = p->d_lidar_xy;
@@ -637,7 +661,7 @@ int t2d_destroy(t2d_pool* p) {
         if (p->field_ptr[f]) (void)hipFree(p->field_ptr[f]);
     void* bufs[] = {p->d_params, p->d_geo, p->d_boundary, p->d_boundary_valid, p->d_target_xy, p->d_target_c,
                     p->d_last_pose, p->d_max_iou, p->d_min_dist, p->d_snap_min_dist, p->d_last_valid,
-                    p->d_lidar_env_off, p->d_lidar_next, p->d_lidar_xy, p->d_beam_sin, p->d_beam_cos,
+                    p->d_lidar_env_off, p->d_lidar_next, p->d_lidar_meta, p->d_lidar_xy, p->d_beam_sin, p->d_beam_cos,
                     p->d_snap[0], p->d_snap[1], p->d_snap[2],
                     p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_wgmap, p->d_idm_rows, p->d_idm_ctrl, p->d_snap_omega[0], p->d_snap_omega[1], p->d_time_penalty,
                     p->d_scene_arrays, p->d_lidar_cnt};

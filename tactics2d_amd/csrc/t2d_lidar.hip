@@ -96,12 +96,19 @@ T2D_DEV double lidar_edge(double a, double b, double bx_hi, double bx_lo, double
 // Beam-index span of an edge given in the sensor frame: {first beam, number of further beams} or
 // {0, -1} = invisible.  Beams are at angles k * dbeam.  fp32 is enough: the span is widened by the error
 // margin derived below (>= 0.1 beam).
-T2D_DEV int2 edge_span(double x1, double y1, double x2, double y2, double R, int n_beams) {
+// facing (may be null): +1 = the sensor is on the OUTER side of this edge of a CCW ring (the edge faces the sensor), -1 =
+// on the inner side (a back edge as long as the sensor is outside the ring), 0 = too close to call (within 1 mm of the
+// edge's line, an edge shorter than 10 cm, an end point within 1 cm of the sensor): such an edge is neither.
+T2D_DEV int2 edge_span(double x1, double y1, double x2, double y2, double R, int n_beams, int* facing = nullptr) {
     const float fx1 = (float)x1, fy1 = (float)y1, fx2 = (float)x2, fy2 = (float)y2;
     const float ex = fx2 - fx1, ey = fy2 - fy1;
     const float len2 = ex * ex + ey * ey;
     const float d1 = fx1 * fx1 + fy1 * fy1, d2 = fx2 * fx2 + fy2 * fy2;
-    const float cross = fx1 * fy2 - fx2 * fy1;
+    const float cross = fx1 * fy2 - fx2 * fy1;   // = orient(P1, P2, sensor): > 0 with the sensor on the left of P1 -> P2
+    if (facing) {
+        const bool sure = len2 >= 1e-2f && cross * cross > 1e-6f * len2 && d1 >= 1e-4f && d2 >= 1e-4f && d1 < 1e30f && d2 < 1e30f;
+        *facing = !sure ? 0 : (cross < 0.0f ? 1 : -1);
+    }
     if (!(len2 > 0.0f) || !(d1 < 1e30f) || !(d2 < 1e30f)) return make_int2(0, -1);  // degenerate / placeholder
     const float dline2 = cross * cross / len2;                 // squared distance sensor -> edge line
     const float t = -(fx1 * ex + fy1 * ey) / len2;             // foot point parameter
@@ -163,6 +170,16 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     unsigned long long* const s_mask = s_best + lv.n_beams;   // [n_beams] candidate edges (bit q) of the current 64-edge chunk
     uint32_t* const s_queue = reinterpret_cast<uint32_t*>(s_mask + lv.n_beams);       // [kLidarBlock / 64][kLidarQueue]
     __shared__ int s_qcount[kLidarBlock / 64];
+    // Occlusion culling (short static lists, rings described by lv.edge_meta): per edge q its ring | facing, per ring the
+    // bits of its back edges.  A beam that passes through the CORE of a front edge of a ring -- its span less two beams at
+    // either end -- crosses that edge in its interior, enters the (convex) ring there and leaves it through a back edge at
+    // least r_V sin(0.9 beam) sin(gamma) >= 1e-5 m further out (r_V >= 1 cm the nearer end point's distance, gamma the
+    // ring's interior angle there, sin >= 0.05 by the host's choice of rings): the front edge's hit is accepted whenever the
+    // back edge's would be, and it is strictly the smaller one -- the back edge's candidate cannot be the beam's minimum
+    // and is dropped before the exact arithmetic.  Bits 32..47 of a beam's candidate word name the rings whose core covers it.
+    constexpr bool kCull = kPre && !PARTS;
+    __shared__ uint32_t s_back[kCull ? 16 : 1];
+    __shared__ uint8_t s_core[kCull ? 32 : 1];     // per edge of the (single) chunk: 16 + its ring when it is a front edge with a core, else 0
     const int env = blockIdx.x;
     const int tid = threadIdx.x;
     const int A = pv.A;
@@ -206,6 +223,10 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     T2D_LMARK(0);
 
     // ---- phase 1a: static polygon edges (vertex v -> next vertex of its ring) ------------------------
+    const bool cull_on = kCull && lv.edge_meta != nullptr && n_static <= 32;   // (workgroup-uniform)
+    if (kCull && tid < 16) s_back[tid] = 0u;
+    uint8_t meta_first = 0xff;
+    if (cull_on && tid < n_static) meta_first = lv.edge_meta[v0 + tid];
     for (int q = tid; q < n_static; q += kLidarBlock) {
         const float4 ed = q == tid ? first_edge : reinterpret_cast<const float4*>(lv.xy)[v0 + q];
         const double x1 = cs * (double)ed.x + sn * (double)ed.y + x_off;
@@ -213,7 +234,21 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
         const double x2 = cs * (double)ed.z + sn * (double)ed.w + x_off;
         const double y2 = -sn * (double)ed.z + cs * (double)ed.w + y_off;
         put_edge(q, x1, y1, x2, y2);
-        s_span[q] = edge_span(x1, y1, x2, y2, lv.max_range, lv.n_beams);
+        if (cull_on) {   // (n_static <= 32: q == tid)
+            int facing = 0;
+            const int2 sp = edge_span(x1, y1, x2, y2, lv.max_range, lv.n_beams, &facing);
+            s_span[q] = sp;
+            const int ring = meta_first;
+            uint8_t core = 0;
+            if (ring != 0xff) {
+                // a front edge has a core when its span is a proper arc of at least five beams
+                if (facing > 0 && sp.y >= 4 && sp.y < lv.n_beams) core = (uint8_t)(16 + ring);
+                if (facing < 0) atomicOr(&s_back[ring], 1u << q);
+            }
+            s_core[q] = core;
+        } else {
+            s_span[q] = edge_span(x1, y1, x2, y2, lv.max_range, lv.n_beams);
+        }
     }
     // ---- phase 1b: the other participants' boxes (4 edges each; skipped slots get the far edge) -------
     int n_slots = n_static;
@@ -296,11 +331,17 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
             if (c0 + q < n_slots) sp = s_span[c0 + q];
             const int last = sp.y < lv.n_beams ? sp.y : lv.n_beams - 1;   // sp.y = -1: invisible
             const bool is_long = last >= kLongSpan;
+            // beams i = 2 .. last - 2 of a front edge's span are its core: they also get the bit of its ring
+            unsigned long long core_bit = 0ull;
+            if (cull_on && c0 + q < n_slots) {
+                const int cr = s_core[q];
+                if (cr) core_bit = 1ull << (32 + (cr & 15));
+            }
             if (!is_long) {
                 for (int i = tid & 1; i <= last; i += 2) {
                     int kb = sp.x + i;
                     kb -= kb >= lv.n_beams ? lv.n_beams : 0;
-                    atomicOr(&s_mask[kb], 1ull << q);
+                    atomicOr(&s_mask[kb], (1ull << q) | ((i >= 2 && i <= last - 2) ? core_bit : 0ull));
                 }
             }
             unsigned long long todo = __ballot(is_long && !(tid & 1));   // the even lane of a pair speaks for its edge
@@ -309,10 +350,11 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
                 todo &= todo - 1ull;
                 const int first = __builtin_amdgcn_readlane(sp.x, src), n_last = __builtin_amdgcn_readlane(last, src);
                 const unsigned long long bit = 1ull << ((wave * 64 + src) >> 1);
+                const unsigned long long cbit = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(core_bit >> 32), src)) << 32;
                 for (int i = lane; i <= n_last; i += 64) {
                     int kb = first + i;
                     kb -= kb >= lv.n_beams ? lv.n_beams : 0;
-                    atomicOr(&s_mask[kb], bit);
+                    atomicOr(&s_mask[kb], bit | ((i >= 2 && i <= n_last - 2) ? cbit : 0ull));
                 }
             }
         }
@@ -322,6 +364,15 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
         for (int it = 0; it < n_iter; ++it) {
             const int k = tid + it * kLidarBlock;
             unsigned long long m = k < lv.n_beams ? s_mask[k] : 0ull;
+            if (cull_on) {   // drop the back edges of every ring whose core covers this beam (see s_back above)
+                uint32_t cov = (uint32_t)(m >> 32) & 0xffffu, cull = 0u;
+                while (cov) {
+                    const int r = __ffs((int)cov) - 1;
+                    cov &= cov - 1u;
+                    cull |= s_back[r];
+                }
+                m = (unsigned long long)((uint32_t)m & ~cull);
+            }
             for (;;) {  // compaction rounds (all 64 lanes take part)
                 const int cnt = __popcll(m);
                 if (__ballot(cnt > 0) == 0ull) break;

@@ -95,6 +95,9 @@ struct LidarView {
     const int32_t* env_vert_off;  // [E+1] vertex range of env e, or null (no static obstacles)
     const int32_t* env_vert_cnt;  // null, or [E] vertices in use when envs own fixed-capacity ranges (generated scenes)
     const float* xy;              // [V][4] one record per polygon EDGE: x1, y1, x2, y2 (vertex v -> next vertex of its ring)
+    // [V] per edge: index (0..15) of its ring among its env's rings when the ring may take part in the occlusion culling of
+    // the scan (CCW, convex, every interior angle with sin >= 0.05, <= 16 rings and <= 32 edges in the env), else 0xff; or null
+    const uint8_t* edge_meta;
     const double* beam_pre;       // [n_beams][6] per beam: a = sin, b = -cos of linspace(0, 2pi, n, endpoint=False)[k]
                                   // (lidar.py:161-162) and the four slack-widened bounds of its end point (x hi / lo, y hi / lo)
     double max_range;
@@ -183,6 +186,7 @@ struct t2d_pool {
     bool lidar_on = false;
     t2d::LidarView lidar{};
     int32_t *d_lidar_env_off = nullptr, *d_lidar_next = nullptr;
+    uint8_t* d_lidar_meta = nullptr;
     float* d_lidar_xy = nullptr;
     double *d_beam_sin = nullptr, *d_beam_cos = nullptr;
     double* d_time_penalty = nullptr;

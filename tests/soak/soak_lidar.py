@@ -18,7 +18,11 @@ for seed in range(n_seeds):
             (24, 16, (40.0, 30.0), dict(n_static=8, n_lanes=0), 360, 20.0, True),
             (12, 64, (60.0, 16.0), dict(n_static=6, n_lanes=0), 1024, 35.0, True),
             (30, 4, (12.0, 8.0), dict(n_static=5, n_lanes=0), 90, 8.0, True),
-            (30, 1, (3.0, 3.0), dict(n_static=10, n_lanes=0), 720, 20.0, False)]:   # cramped: vertices centimetres away
+            (30, 1, (3.0, 3.0), dict(n_static=10, n_lanes=0), 720, 20.0, False),   # cramped: vertices centimetres away
+            # <= 32 edges, static only: the scan drops back edges behind a front edge of their ring (occlusion culling)
+            (48, 1, (24.0, 16.0), dict(n_static=8, n_lanes=0), 360, 20.0, False),
+            (36, 1, (5.0, 4.0), dict(n_static=7, n_lanes=0), 360, 20.0, False),
+            (36, 1, (2.0, 2.0), dict(n_static=6, n_lanes=0), 1024, 12.0, False)]:
         rng = np.random.default_rng(7000 * seed + n_env * 100 + A)
         sc = H.random_scene(rng, n_env, A, extent, **kw)
         pool = ParticipantPool(n_env, A)
