@@ -171,9 +171,10 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     uint32_t* const s_queue = reinterpret_cast<uint32_t*>(s_mask + lv.n_beams);       // [kLidarBlock / 64][kLidarQueue]
     __shared__ int s_qcount[kLidarBlock / 64];
     // Occlusion culling (short static lists, rings described by lv.edge_meta): per edge q its ring | facing, per ring the
-    // bits of its back edges.  A beam that passes through the CORE of a front edge of a ring -- its span less two beams at
-    // either end -- crosses that edge in its interior, enters the (convex) ring there and leaves it through a back edge at
-    // least r_V sin(0.9 beam) sin(gamma) >= 1e-5 m further out (r_V >= 1 cm the nearer end point's distance, gamma the
+    // bits of its back edges.  A beam that passes through the CORE of a front edge of a ring -- its span less one beam at
+    // either end: the span is the edge's arc widened by < 0.15 beam, so a core beam lies >= 0.85 beam inside the arc --
+    // crosses that edge in its interior, enters the (convex) ring there and leaves it through a back edge at
+    // least r_V sin(0.85 beam) sin(gamma) >= 2e-6 m further out (1024 beams) (r_V >= 1 cm the nearer end point's distance, gamma the
     // ring's interior angle there, sin >= 0.05 by the host's choice of rings): the front edge's hit is accepted whenever the
     // back edge's would be, and it is strictly the smaller one -- the back edge's candidate cannot be the beam's minimum
     // and is dropped before the exact arithmetic.  Bits 32..47 of a beam's candidate word name the rings whose core covers it.
@@ -241,8 +242,8 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
             const int ring = meta_first;
             uint8_t core = 0;
             if (ring != 0xff) {
-                // a front edge has a core when its span is a proper arc of at least five beams
-                if (facing > 0 && sp.y >= 4 && sp.y < lv.n_beams) core = (uint8_t)(16 + ring);
+                // a front edge has a core when its span is a proper arc of at least three beams
+                if (facing > 0 && sp.y >= 2 && sp.y < lv.n_beams) core = (uint8_t)(16 + ring);
                 if (facing < 0) atomicOr(&s_back[ring], 1u << q);
             }
             s_core[q] = core;
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
             if (c0 + q < n_slots) sp = s_span[c0 + q];
             const int last = sp.y < lv.n_beams ? sp.y : lv.n_beams - 1;   // sp.y = -1: invisible
             const bool is_long = last >= kLongSpan;
-            // beams i = 2 .. last - 2 of a front edge's span are its core: they also get the bit of its ring
+            // beams i = 1 .. last - 1 of a front edge's span are its core: they also get the bit of its ring
             unsigned long long core_bit = 0ull;
             if (cull_on && c0 + q < n_slots) {
                 const int cr = s_core[q];
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
                 for (int i = tid & 1; i <= last; i += 2) {
                     int kb = sp.x + i;
                     kb -= kb >= lv.n_beams ? lv.n_beams : 0;
-                    atomicOr(&s_mask[kb], (1ull << q) | ((i >= 2 && i <= last - 2) ? core_bit : 0ull));
+                    atomicOr(&s_mask[kb], (1ull << q) | ((i >= 1 && i <= last - 1) ? core_bit : 0ull));
                 }
             }
             unsigned long long todo = __ballot(is_long && !(tid & 1));   // the even lane of a pair speaks for its edge
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
                 for (int i = lane; i <= n_last; i += 64) {
                     int kb = first + i;
                     kb -= kb >= lv.n_beams ? lv.n_beams : 0;
-                    atomicOr(&s_mask[kb], bit | ((i >= 2 && i <= n_last - 2) ? cbit : 0ull));
+                    atomicOr(&s_mask[kb], bit | ((i >= 1 && i <= n_last - 1) ? cbit : 0ull));
                 }
             }
         }
