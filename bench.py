@@ -150,7 +150,7 @@ def cpu_baseline(scene, target_seconds=10.0):
 
 
 DEFAULTS = {"metric": (4096, 64), "cfg5": (1024, 64), "cfg2": (4096, 1), "cfg3": (1024, 64), "cfg4": (512, 32)}
-GATHER_EVERY = 8
+GATHER_EVERY = 16
 
 
 def time_config(name, steps, warmup, dev, variant="fast", clock_warm=None):
@@ -268,7 +268,7 @@ def main():
     for _ in range(4):
         a0, a1 = scene.sample_actions(rng)
         ring.append((torch.from_numpy(a0).to(dev), torch.from_numpy(a1).to(dev)))
-    # N > 1: the per-env result records of 8 consecutive steps travel in ONE all-gather per group (a rollout fragment).
+    # N > 1: the per-env result records of 16 consecutive steps travel in ONE all-gather per group (a rollout fragment).
     # With RCCL (the real run) the library issues it itself -- t2d_gather: ncclAllGather reading the record ring in
     # place, on a stream of the pool's own, ordered after the group's steps by events; torch.distributed only ships the
     # communicator id.  Without RCCL (gloo, the one-GPU rehearsal) the same exchange goes through torch.distributed.

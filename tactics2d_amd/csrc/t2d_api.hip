@@ -1362,7 +1362,11 @@ int t2d_comm_unique_id(uint8_t* id) {
 
 static int ensure_gather_objects(t2d_pool* p) {
     if (p->gather_stream) return T2D_OK;
-    T2D_HIP(p, hipStreamCreateWithFlags(&p->gather_stream, hipStreamNonBlocking));
+    // Lowest stream priority: the collective's workgroups take the slots the step kernel leaves free at
+    // its start and tail instead of displacing step workgroups out of the one-wave-round launch.
+    int prio_least = 0, prio_greatest = 0;
+    T2D_HIP(p, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    T2D_HIP(p, hipStreamCreateWithPriority(&p->gather_stream, hipStreamNonBlocking, prio_least));
     T2D_HIP(p, hipEventCreateWithFlags(&p->ev_frag_ready, hipEventDisableTiming));
     for (hipEvent_t& e : p->ev_gather) T2D_HIP(p, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return T2D_OK;

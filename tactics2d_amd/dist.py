@@ -127,7 +127,7 @@ class NativeGather:
     fragment do not wait for it, and a step that would overwrite a slot still being read waits inside t2d_step.
     torch is used for the two output tensors only.  Same calling convention as ResultGather."""
 
-    def __init__(self, pool, world, every=8, device=None):
+    def __init__(self, pool, world, every=16, device=None):
         import torch
         from . import layout as L
         if every < 1 or L.RECORD_RING % every or L.RECORD_RING // every < 2:

@@ -328,7 +328,7 @@ def test_scene_regeneration_follows_the_episode_streams(oracle, auto_reset, mode
     episode = np.zeros(n_env, np.int64)
     rng = np.random.default_rng(2)
     n_regen = 0
-    for step in range(120 if mode is True else 45):     # staged: long enough to go round the 16-slot ring
+    for step in range(120 if mode is True else 45):     # staged: long enough to go round the record ring
         a0, a1 = sc.sample_actions(rng)
         pool.set_actions(a0, a1)
         before = cur

@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-N_ENV, A, STEPS, EVERY = 48, 64, 32, 8
+N_ENV, A, STEPS, EVERY = 48, 64, 64, 16
 
 
 def _scene():
@@ -41,8 +41,8 @@ def _single_pool_records(sc, acts):
 
 @pytest.mark.parametrize("with_rccl", [False, True])
 def test_native_gather_reads_the_record_ring_in_place(with_rccl):
-    """t2d_gather on a world of one: every fragment of 8 steps arrives complete while later steps keep overwriting the
-    ring (32 steps = the 16-slot ring twice), with and without an RCCL communicator behind it."""
+    """t2d_gather on a world of one: every fragment of 16 steps arrives complete while later steps keep overwriting the
+    ring (64 steps = the 32-slot ring twice), with and without an RCCL communicator behind it."""
     from tactics2d_amd.dist import NativeGather
     from tactics2d_amd.pool import ParticipantPool
     sc = _scene()
