@@ -335,11 +335,14 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     // the phase becomes a chain of five or six dependent s_load round trips, each a scalar-cache miss while all 4096
     // waves of the launch start together: 3.7 k of the phase's 5.3 k cycles (-DT2D_TIMING) before the first state load
     // is even issued.  The empty asm makes all of them live here, so their loads are issued back to back.
-    const uint32_t* a_ids = pv.ids;
-    const float *a_x = pv.x, *a_y = pv.y, *a_h = pv.heading, *a_v = pv.speed, *a_act0 = pv.act0, *a_act1 = pv.act1;
-    const uint8_t* a_idm = pv.idm_ctrl;
-    const double* a_params = pv.params;
-    const uint32_t* a_geo = pv.geo;
+    // (as_global: a plain pointer comes out of the asm generic, and generic means flat_load, which also counts against
+    // the LDS wait counter -- every LDS wait would then wait for the state loads in flight as well)
+    auto a_ids = as_global(pv.ids);
+    auto a_x = as_global(pv.x), a_y = as_global(pv.y), a_h = as_global(pv.heading), a_v = as_global(pv.speed);
+    auto a_act0 = as_global(pv.act0), a_act1 = as_global(pv.act1);
+    auto a_idm = as_global(pv.idm_ctrl);
+    auto a_params = as_global(pv.params);
+    auto a_geo = as_global(pv.geo);
     int a_n_env = pv.n_env, a_A = pv.A, a_stride = pv.geo_layout.stride, a_epb = pv.geo_layout.epb, a_act_stride = pv.act_stride;
     // (in-out operands: the values after the asm are new to the compiler, so it keeps them in registers instead of
     // dropping them and fetching the same arguments again behind the next branch)
@@ -451,12 +454,13 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     }
     // geometry record -> LDS, 16-B loads
     const int n_vec = a_geo ? a_stride >> 2 : 0;
-    const uint4* gsrc = reinterpret_cast<const uint4*>(a_geo + (size_t)wg * a_stride);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a struct: no assignment across address spaces)
+    const T2D_GLOBAL u32x4* gsrc = (const T2D_GLOBAL u32x4*)(a_geo + (size_t)wg * a_stride);
     {
         // rounds of 16-B loads this record needs (wave-uniform): 1 for the metric scenes (<= 4 KiB per workgroup) --
         // the unrolled generic form spends more on its per-load bounds logic than on the loads
         const int rounds = (n_vec + nthreads - 1) / nthreads;
-        uint4 geo_stage0 = make_uint4(0, 0, 0, 0);
+        u32x4 geo_stage0 = {0u, 0u, 0u, 0u};
         if (rounds <= 1) {
             if (tid < n_vec) geo_stage0 = gsrc[tid];
         } else {
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             }
         }
         if (rounds <= 1) {
-            if (tid < n_vec) reinterpret_cast<uint4*>(s_geo)[tid] = geo_stage0;
+            if (tid < n_vec) reinterpret_cast<u32x4*>(s_geo)[tid] = geo_stage0;
         } else {
             __builtin_amdgcn_s_waitcnt(0);  // the LDS-direct loads are tracked by vmcnt: all landed before the barrier
         }
@@ -891,38 +895,38 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     // every kernel argument the epilogue touches, requested together (see the start-up phase): the status lane's chain
     // and the restore of a finished env are the last thing a wave does, with nothing behind them to hide a scalar round
     // trip per pointer
-    auto e_flags = pv.flags;
-    auto e_env_flags = pv.env_flags;
-    auto e_cnt_step = pv.cnt_step;
-    auto e_frame_ms = pv.frame_ms;
-    auto e_status = pv.status;
-    auto e_reward = pv.reward;
-    auto e_record = pv.record;
-    auto e_time_penalty = pv.time_penalty;
-    auto e_iou = pv.iou;
-    auto e_last_valid = pv.last_valid;
-    auto e_cnt_na = pv.cnt_na;
-    auto e_max_iou = pv.max_iou;
-    auto e_min_dist = pv.min_dist;
-    auto e_snap_min_dist = pv.snap_min_dist;
-    auto e_snap0 = pv.snap[0];
-    auto e_snap1 = pv.snap[1];
-    auto e_snap2 = pv.snap[2];
-    auto e_snap3 = pv.snap[3];
-    auto e_snap4 = pv.snap[4];
-    auto e_snap5 = pv.snap[5];
-    auto e_snap_ids = pv.snap_ids;
-    auto e_snap_omega0 = pv.snap_omega[0];
-    auto e_snap_omega1 = pv.snap_omega[1];
-    auto e_x = pv.x;
-    auto e_y = pv.y;
-    auto e_heading = pv.heading;
-    auto e_speed = pv.speed;
-    auto e_vx = pv.vx;
-    auto e_vy = pv.vy;
-    auto e_ids = pv.ids;
-    auto e_omega_f = pv.omega_f;
-    auto e_omega_r = pv.omega_r;
+    auto e_flags = as_global(pv.flags);
+    auto e_env_flags = as_global(pv.env_flags);
+    auto e_cnt_step = as_global(pv.cnt_step);
+    auto e_frame_ms = as_global(pv.frame_ms);
+    auto e_status = as_global(pv.status);
+    auto e_reward = as_global(pv.reward);
+    auto e_record = as_global(pv.record);
+    auto e_time_penalty = as_global(pv.time_penalty);
+    auto e_iou = as_global(pv.iou);
+    auto e_last_valid = as_global(pv.last_valid);
+    auto e_cnt_na = as_global(pv.cnt_na);
+    auto e_max_iou = as_global(pv.max_iou);
+    auto e_min_dist = as_global(pv.min_dist);
+    auto e_snap_min_dist = as_global(pv.snap_min_dist);
+    auto e_snap0 = as_global(pv.snap[0]);
+    auto e_snap1 = as_global(pv.snap[1]);
+    auto e_snap2 = as_global(pv.snap[2]);
+    auto e_snap3 = as_global(pv.snap[3]);
+    auto e_snap4 = as_global(pv.snap[4]);
+    auto e_snap5 = as_global(pv.snap[5]);
+    auto e_snap_ids = as_global(pv.snap_ids);
+    auto e_snap_omega0 = as_global(pv.snap_omega[0]);
+    auto e_snap_omega1 = as_global(pv.snap_omega[1]);
+    auto e_x = as_global(pv.x);
+    auto e_y = as_global(pv.y);
+    auto e_heading = as_global(pv.heading);
+    auto e_speed = as_global(pv.speed);
+    auto e_vx = as_global(pv.vx);
+    auto e_vy = as_global(pv.vy);
+    auto e_ids = as_global(pv.ids);
+    auto e_omega_f = as_global(pv.omega_f);
+    auto e_omega_r = as_global(pv.omega_r);
     int e_auto_reset = pv.auto_reset;
     asm volatile("" : "+s"(e_flags), "+s"(e_env_flags), "+s"(e_cnt_step), "+s"(e_frame_ms), "+s"(e_status), "+s"(e_reward), "+s"(e_record), "+s"(e_time_penalty), "+s"(e_iou), "+s"(e_last_valid), "+s"(e_cnt_na), "+s"(e_max_iou), "+s"(e_min_dist), "+s"(e_snap_min_dist), "+s"(e_auto_reset));
     asm volatile("" : "+s"(e_snap0), "+s"(e_snap1), "+s"(e_snap2), "+s"(e_snap3), "+s"(e_snap4), "+s"(e_snap5), "+s"(e_snap_ids), "+s"(e_snap_omega0), "+s"(e_snap_omega1), "+s"(e_x), "+s"(e_y), "+s"(e_heading), "+s"(e_speed), "+s"(e_vx), "+s"(e_vy), "+s"(e_ids), "+s"(e_omega_f), "+s"(e_omega_r));
@@ -1061,13 +1065,11 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             pv.iou[env] = has_iou ? (float)iou : __builtin_nanf("");
             const bool terminated = scen == T2D_SCENARIO_COMPLETED;
             const bool truncated = !terminated && (scen != T2D_SCENARIO_NORMAL || traf != T2D_TRAFFIC_NORMAL);
-            uchar4 st;
-            st.x = (unsigned char)scen; st.y = (unsigned char)traf;
-            st.z = terminated; st.w = truncated;
-            reinterpret_cast<uchar4*>(e_status)[env] = st;
+            // {scenario, traffic, terminated, truncated}: the four status bytes are also the record's second word
+            const uint32_t st = (uint32_t)scen | (uint32_t)traf << 8 | (uint32_t)terminated << 16 | (uint32_t)truncated << 24;
+            ((T2D_GLOBAL uint32_t*)e_status)[env] = st;
             pv.reward[env] = r;
-            pv.record[env] = make_uint2(__float_as_uint(r), (uint32_t)scen | (uint32_t)traf << 8 |
-                                                                (uint32_t)terminated << 16 | (uint32_t)truncated << 24);
+            pv.record[env] = make_uint2(__float_as_uint(r), st);
             if (e_auto_reset) {
                 const bool done = terminated || truncated;
                 s_done[env_local] = done;

@@ -24,9 +24,12 @@ namespace {
 constexpr int kIdmBlock = 256;
 
 // IDMController.step + _idm_acceleration for one participant (oracle t2do_idm_accel)
-T2D_DEV double idm_law(const double* c, double v, bool has_lead, double dx, double dy, double v_lead) {
-    const double des = c[T2D_IDM_DESIRED_SPEED], T = c[T2D_IDM_TIME_HEADWAY], s0 = c[T2D_IDM_MIN_SPACING];
-    const double amax = c[T2D_IDM_MAX_ACCEL], b = c[T2D_IDM_COMF_DECEL], delta = c[T2D_IDM_DELTA];
+struct IdmRow {
+    double des, T, s0, amax, b, delta, hw, horizon;
+};
+
+T2D_DEV double idm_law(const IdmRow& c, double v, bool has_lead, double dx, double dy, double v_lead) {
+    const double des = c.des, T = c.T, s0 = c.s0, amax = c.amax, b = c.b, delta = c.delta;
     double a;
     if (!has_lead) {  // :75-85
         if (des > 0.0) a = amax * (1.0 - pow_det(v / des, delta));
@@ -47,6 +50,14 @@ T2D_DEV double idm_law(const double* c, double v, bool has_lead, double dx, doub
     return clipd(a, -b, amax);  // np.clip :90
 }
 
+// the smallest double above h for h >= 0 (h itself when it is +inf or NaN: `lon < h` then equals `lon <= h` for every
+// finite lon); 0 for h < 0, where no offset is both > 0 and <= h
+T2D_DEV double just_above(double h) {
+    if (!(h >= 0.0)) return h != h ? h : 0.0;
+    if (h == __builtin_inf()) return h;
+    return __longlong_as_double(__double_as_longlong(h + 0.0) + 1);   // h + 0.0: -0.0 -> +0.0
+}
+
 // act0_own / act1_own: the POOL's action fields (T2D_F_ACT0 / ACT1) -- never caller-owned memory bound with
 // t2d_bind_actions; while a binding is in effect the integrators take the controlled lanes' actions from there
 __global__ __launch_bounds__(kIdmBlock) void idm_kernel(PoolView pv, IdmView iv, const int32_t* forced, float* act0_own,
@@ -57,10 +68,13 @@ __global__ __launch_bounds__(kIdmBlock) void idm_kernel(PoolView pv, IdmView iv,
     __shared__ float s_v[kIdmBlock];
     const int tid = threadIdx.x;
     // every kernel argument of the load phase in one scalar round trip (see collide_kernel)
-    const uint32_t* a_ids = pv.ids;
-    const float *a_x = pv.x, *a_y = pv.y, *a_h = pv.heading, *a_v = pv.speed;
-    const uint8_t* a_ctrl = iv.ctrl_id;
-    const double* a_rows = iv.rows;
+    // (global address space kept through the asm: plain pointers come out of it generic, i.e. as flat loads, which
+    // count against the LDS wait counter as well)
+    const T2D_GLOBAL uint32_t* a_ids = (const T2D_GLOBAL uint32_t*)pv.ids;
+    const T2D_GLOBAL float *a_x = (const T2D_GLOBAL float*)pv.x, *a_y = (const T2D_GLOBAL float*)pv.y,
+                           *a_h = (const T2D_GLOBAL float*)pv.heading, *a_v = (const T2D_GLOBAL float*)pv.speed;
+    const T2D_GLOBAL uint8_t* a_ctrl = (const T2D_GLOBAL uint8_t*)iv.ctrl_id;
+    const T2D_GLOBAL double* a_rows = (const T2D_GLOBAL double*)iv.rows;
     int a_n_env = pv.n_env, a_A = pv.A;
     asm volatile("" : "+s"(a_ids), "+s"(a_x), "+s"(a_y), "+s"(a_h), "+s"(a_v), "+s"(a_ctrl), "+s"(a_rows), "+s"(a_n_env), "+s"(a_A));
     const int A_pad = 1 << log2A;
@@ -82,19 +96,30 @@ __global__ __launch_bounds__(kIdmBlock) void idm_kernel(PoolView pv, IdmView iv,
         ctrl = a_ctrl[idx];
     }
     const bool active = valid && ((ids >> kIdsActiveShift) & 0xffu);
+    // the controller's row and the heading's sine / cosine before the barrier: the row is a second dependent round trip
+    // to memory (after ctrl_id) and every wave of the launch reaches it at the same time -- it overlaps the LDS fill
+    const bool controlled = active && ctrl != T2D_IDM_NONE && ctrl < iv.n_ctrl;
+    IdmRow c{};
+    double sn = 0.0, cs = 1.0;
+    if (controlled) {
+        const T2D_GLOBAL double* r = a_rows + (size_t)ctrl * T2D_IDM_COLS;
+        c.des = r[T2D_IDM_DESIRED_SPEED]; c.T = r[T2D_IDM_TIME_HEADWAY]; c.s0 = r[T2D_IDM_MIN_SPACING];
+        c.amax = r[T2D_IDM_MAX_ACCEL]; c.b = r[T2D_IDM_COMF_DECEL]; c.delta = r[T2D_IDM_DELTA];
+        c.hw = r[T2D_IDM_LANE_HALF_WIDTH]; c.horizon = r[T2D_IDM_HORIZON];
+    }
     const double qnan = __builtin_nan("");
     s_xy[tid] = active ? make_double2((double)fx, (double)fy) : make_double2(qnan, qnan);
     s_v[tid] = fv;
+    if (controlled) sincos_det((double)fh, sn, cs);
     __syncthreads();
     if (!valid) return;
     int lead = -1;
-    if (active && ctrl != T2D_IDM_NONE && ctrl < iv.n_ctrl) {
-        const double* c = a_rows + (size_t)ctrl * T2D_IDM_COLS;
-        const double hw = c[T2D_IDM_LANE_HALF_WIDTH], horizon = c[T2D_IDM_HORIZON];
-        double sn, cs;
-        sincos_det((double)fh, sn, cs);
+    if (controlled) {
+        const double hw = c.hw, horizon = c.horizon;
         const int base = env_local << log2A;
-        double best = __builtin_inf();
+        // `lon <= horizon` rides on the running minimum: it starts at the first double above the horizon and a candidate
+        // must be strictly below it -- one compare and two selects fewer per candidate than testing the horizon apart
+        double best = just_above(horizon);
         const double x0 = (double)fx, y0 = (double)fy;
         const int want = forced ? forced[idx] : T2D_IDM_LEADER_SEARCH;
         if (want >= 0 && want < pv.A && want != agent && s_xy[base + want].x == s_xy[base + want].x)
@@ -107,12 +132,9 @@ __global__ __launch_bounds__(kIdmBlock) void idm_kernel(PoolView pv, IdmView iv,
                     const double dx = q.x - x0, dy = q.y - y0;
                     const double lon = __builtin_fma(dx, cs, dy * sn);
                     const double lat = __builtin_fma(dy, cs, -(dx * sn));
-                    const bool ok = lon > 0.0 && lon <= horizon && __builtin_fabs(lat) <= hw;
-                    const double key = ok ? lon : __builtin_inf();
-                    if (key < best) {
-                        best = key;
-                        lead = j;
-                    }
+                    const bool take = lon > 0.0 && lon < best && __builtin_fabs(lat) <= hw;   // strict: lowest index on ties
+                    best = take ? lon : best;
+                    lead = take ? j : lead;
                 }
             };
             // wave priority by progress (see the step kernel): the launch is one wave-round, a SIMD's waves should finish

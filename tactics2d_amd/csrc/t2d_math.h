@@ -9,6 +9,10 @@
 #include <stdint.h>
 
 #define T2D_DEV __device__ __forceinline__
+// pointer into device memory proper (global_load / global_store, not the generic flat forms)
+#define T2D_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ T2D_GLOBAL T* as_global(T* p) { return (T2D_GLOBAL T*)p; }
 
 namespace t2d {
 

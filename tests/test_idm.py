@@ -181,6 +181,45 @@ def test_gpu_leader_rule_and_law_match_oracle_on_random_traffic(oracle, A):
 
 
 @pytest.mark.gpu
+def test_gpu_leader_rule_at_the_edges_of_the_horizon(oracle):
+    """`lon <= horizon` at equality, one ulp either side, and for horizons of inf and DBL_MAX: the kernel folds the
+    horizon into its running minimum (t2d_idm.hip just_above), the oracle tests it apart.  (t2d_set_idm refuses a
+    horizon that is not > 0, NaN included.)"""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    horizons = [50.0, np.nextafter(50.0, 0.0), np.nextafter(50.0, 100.0), np.inf, 1.7976931348623157e308, 80.0, 49.0, 5e-324]
+    want = [1, -1, 1, 1, 1, 1, -1, -1]
+    n_env, A = len(horizons), 4
+    # heading 0: lon = dx exactly.  slot 1 at 50 m, slot 2 at 50 m too (tie: the lower index wins), slot 3 at 90 m
+    x = np.tile(np.float32([0, 50, 50, 90]), n_env); y = np.tile(np.float32([0, 0.25, -0.25, 0]), n_env)
+    h = np.zeros(n_env * A, np.float32); v = np.tile(np.float32([10, 4, 5, 6]), n_env)
+    act = np.ones(n_env * A, np.uint8)
+    rows = np.array([[30.0, 1.5, 2.0, 1.0, 3.0, 4.0, 1.875, hz] for hz in horizons])
+    cid = np.full((n_env, A), L.IDM_NONE, np.uint8); cid[:, 0] = np.arange(n_env)
+    cid = cid.reshape(-1)
+    a0 = np.zeros(n_env * A, np.float32); a1 = np.zeros(n_env * A, np.float32)
+    row = np.zeros((1, L.PARAM_COLS)); row[0, [L.P_LF, L.P_LR, L.P_WB, L.P_DELTA_T_MS, L.P_LENGTH, L.P_WIDTH]] = 1.2, 1.3, 2.5, 5, 4.5, 1.8
+    w0, w1, wl = oracle.idm(rows, cid, n_env, A, x, y, h, v, act, a0, a1)
+    assert list(wl.reshape(n_env, A)[:, 0]) == want
+    pool = ParticipantPool(n_env, A)
+    try:
+        pool.set_param_table(row)
+        pool.reset(x, y, h, v, np.zeros(n_env * A, np.uint8), active=act)
+        pool.set_actions(a0, a1)
+        pool.set_idm(rows, cid)
+        pool.idm_actions()
+        g0, gl = pool.download(L.F_ACT0), pool.download(L.F_LEADER)
+        assert np.array_equal(gl, wl)
+        assert np.array_equal(g0.view(np.uint32), w0.view(np.uint32))
+        for bad in (0.0, -0.0, -3.0, np.nan):
+            r = rows.copy(); r[0, L.IDM_HORIZON] = bad
+            with pytest.raises(Exception):
+                pool.set_idm(r, cid)
+    finally:
+        pool.close()
+
+
+@pytest.mark.gpu
 def test_gpu_controller_mirror_step_matches_reference_cases():
     from tactics2d_amd.controller import IDMController
     from tactics2d_amd.physics import BatchedState
