@@ -1449,6 +1449,7 @@ int t2d_debug_set_step_placement(t2d_pool* p, const uint32_t* map_host, int32_t 
     const int epb = p->v.geo_layout.epb > 0 ? p->v.geo_layout.epb : 1;
     const int n_blocks = (p->v.n_env + epb - 1) / epb;
     if (n_workgroups != n_blocks) return fail(p, T2D_ERR_INVALID, "placement map must have one entry per workgroup of the step launch");
+    if (n_blocks > 65536) return fail(p, T2D_ERR_INVALID, "placement map: at most 65536 workgroups");   // 16-bit workgroup ids
     std::vector<uint8_t> seen((size_t)n_blocks, 0);
     for (int b = 0; b < n_blocks; ++b) {   // a permutation of the workgroups, rotations 0..3
         const uint32_t g = map_host[b] & 0xffffu, r = map_host[b] >> 16;
@@ -1456,7 +1457,6 @@ int t2d_debug_set_step_placement(t2d_pool* p, const uint32_t* map_host, int32_t 
         seen[g] = 1;
     }
     if (!p->d_wgmap) T2D_HIP(p, hipMalloc((void**)&p->d_wgmap, sizeof(uint32_t) * 65536));
-    if (n_blocks > 65536) return fail(p, T2D_ERR_INVALID, "placement map: at most 65536 workgroups");
     T2D_HIP(p, hipMemcpy(p->d_wgmap, map_host, sizeof(uint32_t) * (size_t)n_blocks, hipMemcpyHostToDevice));
     p->v.wgmap = p->d_wgmap;
     return T2D_OK;

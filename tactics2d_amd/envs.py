@@ -151,7 +151,10 @@ class VecParkingEnv:
             raise RuntimeError("call reset() first")
         pool = self.scenario_manager.pool
         dev = actions.device
-        st = stream if stream is not None else torch.cuda.current_stream(dev)
+        cur = torch.cuda.current_stream(dev)
+        st = stream if stream is not None else cur
+        if st != cur:
+            st.wait_stream(cur)   # `actions` was produced on the caller's current stream; the step reads it in place
         with torch.cuda.stream(st):
             # the [n, 2] (steering, accel) tensor is read in place: accel = column 1, steering = column 0, stride 2
             # (two copy kernels per step otherwise: 4.7 us of a 36 us vector step); kept alive until the next step
