@@ -14,6 +14,8 @@
 // conflict free), ~12 fp64 operations per candidate, then evaluates the IDM law once.  Output: accel ->
 // the pool's act0 field, steer 0 -> its act1 field (the reference returns (steering, acceleration); the physics
 // models take (accel, steer)), leader index -> T2D_F_LEADER.  HBM: 17 B read + 12 B written per participant.
+#include <type_traits>
+
 #include "t2d_math.h"
 #include "t2d_pool.h"
 
@@ -137,13 +139,38 @@ __global__ __launch_bounds__(kIdmBlock) void idm_kernel(PoolView pv, IdmView iv,
                     lead = take ? j : lead;
                 }
             };
+            // the same sweep with constant bounds: fully unrolled, the candidate's index is an inline constant of its
+            // select and its LDS address an immediate offset (no loop counter, no index register: ~2.5 of ~16 issued
+            // instructions per candidate)
+            auto sweep_const = [&](auto j0c, auto j1c) {
+#pragma unroll
+                for (int j = decltype(j0c)::value; j < decltype(j1c)::value; ++j) {
+                    const double2 q = s_xy[base + j];
+                    const double dx = q.x - x0, dy = q.y - y0;
+                    const double lon = __builtin_fma(dx, cs, dy * sn);
+                    const double lat = __builtin_fma(dy, cs, -(dx * sn));
+                    const bool take = lon > 0.0 && lon < best && __builtin_fabs(lat) <= hw;
+                    best = take ? lon : best;
+                    lead = take ? j : lead;
+                }
+            };
             // wave priority by progress (see the step kernel): the launch is one wave-round, a SIMD's waves should finish
             // together.  The sweep in quarters, the quarter's number is the priority.
-            const int q1 = pv.A >> 2, q2 = pv.A >> 1, q3 = q1 + q2;
-            __builtin_amdgcn_s_setprio(3); sweep(0, q1);
-            __builtin_amdgcn_s_setprio(2); sweep(q1, q2);
-            __builtin_amdgcn_s_setprio(1); sweep(q2, q3);
-            __builtin_amdgcn_s_setprio(0); sweep(q3, pv.A);
+            if (pv.A == 64) {
+                using I0 = std::integral_constant<int, 0>; using I16 = std::integral_constant<int, 16>;
+                using I32 = std::integral_constant<int, 32>; using I48 = std::integral_constant<int, 48>;
+                using I64 = std::integral_constant<int, 64>;
+                __builtin_amdgcn_s_setprio(3); sweep_const(I0{}, I16{});
+                __builtin_amdgcn_s_setprio(2); sweep_const(I16{}, I32{});
+                __builtin_amdgcn_s_setprio(1); sweep_const(I32{}, I48{});
+                __builtin_amdgcn_s_setprio(0); sweep_const(I48{}, I64{});
+            } else {
+                const int q1 = pv.A >> 2, q2 = pv.A >> 1, q3 = q1 + q2;
+                __builtin_amdgcn_s_setprio(3); sweep(0, q1);
+                __builtin_amdgcn_s_setprio(2); sweep(q1, q2);
+                __builtin_amdgcn_s_setprio(1); sweep(q2, q3);
+                __builtin_amdgcn_s_setprio(0); sweep(q3, pv.A);
+            }
         }
         double dx = 0.0, dy = 0.0, vl = 0.0;
         if (lead >= 0) {
