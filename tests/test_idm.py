@@ -180,23 +180,37 @@ def test_gpu_leader_rule_and_law_match_oracle_on_random_traffic(oracle, A):
         pool.close()
 
 
-@pytest.mark.gpu
-def test_gpu_leader_rule_at_the_edges_of_the_horizon(oracle):
-    """`lon <= horizon` at equality, one ulp either side, and for horizons of inf and DBL_MAX: the kernel folds the
-    horizon into its running minimum (t2d_idm.hip just_above), the oracle tests it apart.  (t2d_set_idm refuses a
-    horizon that is not > 0, NaN included.)"""
+def _horizon_edge_scene():
+    """ego at the origin heading +x (lon = dx exactly), slots 1 and 2 at 50 m (a tie: the lower index wins), slot 3 at 90 m;
+    one env per horizon."""
     from tactics2d_amd import layout as L
-    from tactics2d_amd.pool import ParticipantPool
     horizons = [50.0, np.nextafter(50.0, 0.0), np.nextafter(50.0, 100.0), np.inf, 1.7976931348623157e308, 80.0, 49.0, 5e-324]
     want = [1, -1, 1, 1, 1, 1, -1, -1]
     n_env, A = len(horizons), 4
-    # heading 0: lon = dx exactly.  slot 1 at 50 m, slot 2 at 50 m too (tie: the lower index wins), slot 3 at 90 m
     x = np.tile(np.float32([0, 50, 50, 90]), n_env); y = np.tile(np.float32([0, 0.25, -0.25, 0]), n_env)
     h = np.zeros(n_env * A, np.float32); v = np.tile(np.float32([10, 4, 5, 6]), n_env)
     act = np.ones(n_env * A, np.uint8)
     rows = np.array([[30.0, 1.5, 2.0, 1.0, 3.0, 4.0, 1.875, hz] for hz in horizons])
     cid = np.full((n_env, A), L.IDM_NONE, np.uint8); cid[:, 0] = np.arange(n_env)
-    cid = cid.reshape(-1)
+    return n_env, A, x, y, h, v, act, rows, cid.reshape(-1), want
+
+
+def test_leader_rule_at_the_edges_of_the_horizon(oracle):
+    """`lon <= horizon` at equality, one ulp either side, inf, DBL_MAX and a denormal horizon (the oracle's definition)."""
+    n_env, A, x, y, h, v, act, rows, cid, want = _horizon_edge_scene()
+    z = np.zeros(n_env * A, np.float32)
+    _, _, wl = oracle.idm(rows, cid, n_env, A, x, y, h, v, act, z, z)
+    assert list(wl.reshape(n_env, A)[:, 0]) == want and (wl.reshape(n_env, A)[:, 1:] == -1).all()
+
+
+@pytest.mark.gpu
+def test_gpu_leader_rule_at_the_edges_of_the_horizon(oracle):
+    """The kernel folds `lon <= horizon` into its running minimum (t2d_idm.hip just_above), the oracle tests it apart:
+    same leaders and accelerations at equality, one ulp either side, inf, DBL_MAX and a denormal horizon.  (t2d_set_idm
+    refuses a horizon that is not > 0, NaN included.)"""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    n_env, A, x, y, h, v, act, rows, cid, want = _horizon_edge_scene()
     a0 = np.zeros(n_env * A, np.float32); a1 = np.zeros(n_env * A, np.float32)
     row = np.zeros((1, L.PARAM_COLS)); row[0, [L.P_LF, L.P_LR, L.P_WB, L.P_DELTA_T_MS, L.P_LENGTH, L.P_WIDTH]] = 1.2, 1.3, 2.5, 5, 4.5, 1.8
     w0, w1, wl = oracle.idm(rows, cid, n_env, A, x, y, h, v, act, a0, a1)
