@@ -32,9 +32,12 @@ struct IdmRow {
 
 T2D_DEV double idm_law(const IdmRow& c, double v, bool has_lead, double dx, double dy, double v_lead) {
     const double des = c.des, T = c.T, s0 = c.s0, amax = c.amax, b = c.b, delta = c.delta;
+    // (v / v_des)^delta once, ahead of the regimes: a wave with leaders for some lanes and none for others runs both
+    // branches, and the power (deterministic log + exp) is the bulk of either
+    const double pw = des > 0.0 ? pow_det(v / des, delta) : 0.0;
     double a;
     if (!has_lead) {  // :75-85
-        if (des > 0.0) a = amax * (1.0 - pow_det(v / des, delta));
+        if (des > 0.0) a = amax * (1.0 - pw);
         else a = v > 0.0 ? -b : 0.0;
     } else {  // :106-141
         const double dist = __builtin_sqrt(dx * dx + dy * dy);  // np.hypot
@@ -42,7 +45,7 @@ T2D_DEV double idm_law(const IdmRow& c, double v, bool has_lead, double dx, doub
         double s_star = s0 + v * T + (v * dv) / (2.0 * __builtin_sqrt(amax * b));
         if (s0 > s_star) s_star = s0;  // max(s_star, min_spacing)
         if (dist > 0.0) {
-            const double term = des > 0.0 ? pow_det(v / des, delta) : (v > 0.0 ? 1.0 : 0.0);
+            const double term = des > 0.0 ? pw : (v > 0.0 ? 1.0 : 0.0);
             const double q = s_star / dist;
             a = amax * (1.0 - term - q * q);
         } else {
