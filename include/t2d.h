@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define T2D_ABI_VERSION 5
+#define T2D_ABI_VERSION 6
 
 /* ---- status codes --------------------------------------------------------------- */
 #define T2D_OK            0
@@ -433,6 +433,17 @@ int t2d_get_parking_scenes(t2d_pool* pool, float* quads, int32_t* quad_id, int32
  * (rotation recurrence, default).  Both satisfy the 1e-5 contract; see DESIGN.md.       */
 int t2d_set_integrator_variant(t2d_pool* pool, int32_t variant);
 
+/* Which pure OUTPUT columns the integrators store.  The reference's step() returns a State carrying vx / vy and the
+ * applied (clipped) action beside the pose (single_track_kinematics.py:169-198); on the step path nothing reads them back:
+ * vx / vy of the single-track models are v cos / v sin of the new heading and T2D_F_APPLIED0/1 the clipped action.  A
+ * rollout that does not consume them leaves 16 B per participant and step unwritten (a quarter of the step's HBM writes).
+ * Default T2D_OUT_ALL (the reference's State).  A point mass's vx / vy are state and are stored whatever the mask says;
+ * with a bit cleared the column keeps its last stored values.                                                          */
+#define T2D_OUT_VELOCITY 1u   /* T2D_F_VX / T2D_F_VY of SingleTrackKinematics participants */
+#define T2D_OUT_APPLIED 2u    /* T2D_F_APPLIED0 / T2D_F_APPLIED1 */
+#define T2D_OUT_ALL 3u
+int t2d_set_outputs(t2d_pool* pool, uint32_t mask);
+
 /* Per-kernel timing with HIP events recorded on the launch stream around each kernel.
  * kernel_id: 0 = integrate, 1 = collide(+status), 2 = fused step, 3 = lidar, 4 = idm, 5 = drift, 6 = scene regeneration.                                   */
 int t2d_profile_enable(t2d_pool* pool, int32_t on);
@@ -472,6 +483,14 @@ int t2d_debug_set_step_placement(t2d_pool* pool, const uint32_t* map_host, int32
 
 int t2d_debug_step_occupancy(t2d_pool* pool, int32_t* blocks_per_cu, int64_t* lds_bytes,
                              int64_t* geometry_bytes_per_launch);
+
+/* Host-only (no device is touched): the rectangles t2d_set_lane_geometry finds inside the union of each env's lane polygons
+ * -- the certificate behind the step kernel's off-lane short cut (a pose whose box lies in one of them is contained in the
+ * union).  out = f32 [n_env][T2D_SAFE_RECTS][4] (xmin, xmax, ymin, ymax); unused slots hold (+inf, -inf, +inf, -inf).
+ * Same CSR arguments as t2d_set_lane_geometry.  Lets the CPU tests hold the certificate against the oracle's predicate. */
+#define T2D_SAFE_RECTS 4
+int t2d_debug_lane_safe_rects(int32_t n_env, const int32_t* env_lane_offsets, const int32_t* lane_vert_offsets,
+                              const float* verts_xy, float* out);
 
 #ifdef __cplusplus
 }

@@ -77,6 +77,8 @@ SYMBOLS = {
     "t2d_parking_scenes": (C.c_int, [_vp, C.c_uint64, C.c_int64, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_int32]),
     "t2d_get_parking_scenes": (C.c_int, [_vp] * 10),
     "t2d_set_integrator_variant": (C.c_int, [_vp, C.c_int32]),
+    "t2d_set_outputs": (C.c_int, [_vp, C.c_uint32]),
+    "t2d_debug_lane_safe_rects": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
     "t2d_profile_enable": (C.c_int, [_vp, C.c_int32]),
     "t2d_profile_read": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "t2d_comm_unique_id": (C.c_int, [_vp]),
@@ -123,6 +125,11 @@ def lib():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
+        from . import layout
+        have = handle.t2d_abi_version()
+        if have != layout.ABI_VERSION:   # e.g. a stale .so whose record ring is sized differently
+            raise ImportError(f"{LIB_PATH} has ABI version {have}, this package expects {layout.ABI_VERSION}: "
+                              "rebuild it with `python -m tactics2d_amd.build --force`")
         _lib = handle
     return _lib
 

@@ -5,9 +5,23 @@
 #include <math.h>
 #include <string.h>
 
-#include <rccl/rccl.h>   // types and enums only: the library is opened with dlopen when a communicator is asked for
+// RCCL: types and enums only -- the library is opened with dlopen when a communicator is asked for.  A single-GPU
+// install without the rccl development headers still builds: the handful of ABI types used here is declared locally then
+// (public NCCL/RCCL ABI: the id is 128 opaque bytes, results and data types are plain enums, ncclUint32 = 3).
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3 } ncclDataType_t;
+}
+#endif
 
 #include <algorithm>
+#include <limits>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -272,6 +286,78 @@ void build_lane_boundary(int E, t2d_pool::HostGeo& g) {
     }
 }
 
+// Rectangles inside the union of an env's lanes: the certificate of the step kernel's off-lane short cut (a pose whose
+// outward-rounded box lies in one of them is contained in the union, hence not off-lane -- no polygon test needed).
+// Every lane part that is an axis-aligned rectangle is one; two whose union is again a rectangle (equal extent on one axis
+// -- exactly, these are the caller's fp32 coordinates -- and touching or overlapping intervals on the other) are merged,
+// to a fixed point; rectangles inside another are dropped; the kSafeRects largest are kept, each shrunk by 0.1 mm (so that
+// nothing that depends on how the rounding of the boundary walk treats a shared edge can sit inside a certified pose).
+// Exactness of the certificate against the oracle's fp64 predicates: tests/test_oracle_geometry.py (safe rectangles).
+constexpr float kSafeShrink = 1e-4f;
+void build_safe_rects(int E, t2d_pool::HostGeo& g) {
+    const float inf = std::numeric_limits<float>::infinity();
+    g.safe.assign((size_t)E * t2d::kSafeRects * 4, 0.f);
+    struct R { float x0, x1, y0, y1; };
+    std::vector<R> rs;
+    for (int e = 0; e < E; ++e) {
+        rs.clear();
+        for (int li = g.env_off[e]; li < g.env_off[e + 1]; ++li) {
+            const int v0 = g.vert_off[li], n = g.vert_off[li + 1] - v0;
+            if (n != 4) continue;
+            const float* q = &g.xy[2 * (size_t)v0];
+            float x0 = q[0], x1 = q[0], y0 = q[1], y1 = q[1];
+            for (int k = 1; k < 4; ++k) {
+                x0 = std::min(x0, q[2 * k]); x1 = std::max(x1, q[2 * k]);
+                y0 = std::min(y0, q[2 * k + 1]); y1 = std::max(y1, q[2 * k + 1]);
+            }
+            // a convex CCW quad whose every vertex is a corner of its own bounding box, all four corners taken
+            int seen = 0;
+            bool ok = x0 < x1 && y0 < y1;
+            for (int k = 0; k < 4 && ok; ++k) {
+                const bool lx = q[2 * k] == x0, hx = q[2 * k] == x1, ly = q[2 * k + 1] == y0, hy = q[2 * k + 1] == y1;
+                ok = (lx || hx) && (ly || hy);
+                seen |= 1 << ((hx ? 1 : 0) | (hy ? 2 : 0));
+            }
+            if (ok && seen == 15) rs.push_back(R{x0, x1, y0, y1});
+        }
+        for (bool again = true; again;) {
+            again = false;
+            for (size_t i = 0; i < rs.size() && !again; ++i)
+                for (size_t j = i + 1; j < rs.size() && !again; ++j) {
+                    const R a = rs[i], b = rs[j];
+                    const bool same_x = a.x0 == b.x0 && a.x1 == b.x1, same_y = a.y0 == b.y0 && a.y1 == b.y1;
+                    const bool a_in_b = a.x0 >= b.x0 && a.x1 <= b.x1 && a.y0 >= b.y0 && a.y1 <= b.y1;
+                    const bool b_in_a = b.x0 >= a.x0 && b.x1 <= a.x1 && b.y0 >= a.y0 && b.y1 <= a.y1;
+                    if (a_in_b || b_in_a) {
+                        rs[i] = a_in_b ? b : a;
+                    } else if (same_x && !(a.y1 < b.y0 || b.y1 < a.y0)) {
+                        rs[i] = R{a.x0, a.x1, std::min(a.y0, b.y0), std::max(a.y1, b.y1)};
+                    } else if (same_y && !(a.x1 < b.x0 || b.x1 < a.x0)) {
+                        rs[i] = R{std::min(a.x0, b.x0), std::max(a.x1, b.x1), a.y0, a.y1};
+                    } else {
+                        continue;
+                    }
+                    rs.erase(rs.begin() + (long)j);
+                    again = true;
+                }
+        }
+        std::stable_sort(rs.begin(), rs.end(), [](const R& a, const R& b) {
+            return ((double)a.x1 - a.x0) * ((double)a.y1 - a.y0) > ((double)b.x1 - b.x0) * ((double)b.y1 - b.y0);
+        });
+        float* out = &g.safe[(size_t)e * t2d::kSafeRects * 4];
+        for (int k = 0; k < t2d::kSafeRects; ++k) {
+            R r{inf, -inf, inf, -inf};
+            if (k < (int)rs.size()) {
+                // inwards by the margin, rounded further inwards
+                r.x0 = std::nextafter(rs[k].x0 + kSafeShrink, inf); r.x1 = std::nextafter(rs[k].x1 - kSafeShrink, -inf);
+                r.y0 = std::nextafter(rs[k].y0 + kSafeShrink, inf); r.y1 = std::nextafter(rs[k].y1 - kSafeShrink, -inf);
+                if (!(r.x0 < r.x1 && r.y0 < r.y1)) r = R{inf, -inf, inf, -inf};
+            }
+            out[4 * k] = r.x0; out[4 * k + 1] = r.x1; out[4 * k + 2] = r.y0; out[4 * k + 3] = r.y1;
+        }
+    }
+}
+
 int log2_pad(int A) {  // lanes per env = 2^l >= A, at least 2: the second lane of a one-agent env evaluates the Arrival IoU
     int l = 1;        // while the first evaluates the NoAction IoU (one SIMT pass instead of two calls in a row)
     while ((1 << l) < A) ++l;
@@ -289,6 +375,8 @@ void fill_layout(t2d::GeoLayout& gl, int epb, const int mp[2], const int mv[2], 
     for (int k = 0; k < 2; ++k) { gl.off_xy[k] = off; off += 2 * mv[k]; }  // even -> 8-B aligned
     off = (off + 3) & ~3;  // 16-B align the fp64 boundary pieces
     gl.off_bnd = off; off += 8 * mb;
+    off = (off + 3) & ~3;
+    gl.off_safe = off; off += mp[1] > 0 ? 4 * t2d::kSafeRects * epb : 0;
     gl.stride = (off + 3) & ~3;
     gl.epb = epb;
 }
@@ -355,6 +443,16 @@ int rebuild_geo(t2d_pool* p) {
                 const int bb0 = g.bnd_off[pb];
                 for (int q = 0; q <= np; ++q) bstart[q] = g.bnd_off[pb + q] - bb0;
                 memcpy(r + gl.off_bnd, g.bnd.data() + 4 * (size_t)bb0, sizeof(double) * 4 * bstart[np]);
+                if (mp[1] > 0) {
+                    float* safe = reinterpret_cast<float*>(r) + gl.off_safe;
+                    const float inf = std::numeric_limits<float>::infinity();
+                    for (int el = 0; el < epb; ++el)
+                        for (int q = 0; q < t2d::kSafeRects; ++q) {
+                            float* o = safe + 4 * (el * t2d::kSafeRects + q);
+                            if (e0 + el < E) memcpy(o, &g.safe[4 * ((size_t)(e0 + el) * t2d::kSafeRects + q)], 16);
+                            else { o[0] = inf; o[1] = -inf; o[2] = inf; o[3] = -inf; }
+                        }
+                }
             }
         }
     }
@@ -611,6 +709,7 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
     v.act_stride = 1;
     v.applied0 = (float*)p->field_ptr[T2D_F_APPLIED0];
     v.applied1 = (float*)p->field_ptr[T2D_F_APPLIED1];
+    v.out_mask = (int32_t)T2D_OUT_ALL;
     v.omega_f = (float*)p->field_ptr[T2D_F_OMEGA_F];
     v.omega_r = (float*)p->field_ptr[T2D_F_OMEGA_R];
     v.ids = (uint32_t*)p->field_ptr[T2D_F_IDS];
@@ -777,6 +876,7 @@ int t2d_set_lane_geometry(t2d_pool* p, const int32_t* env_lane_offsets,
         if ((rc = prepare_polys(p, env_lane_offsets, lane_vert_offsets, verts_xy, p->hgeo[1])) != T2D_OK)
             return rc;
         build_lane_boundary(E, p->hgeo[1]);
+        build_safe_rects(E, p->hgeo[1]);
     } else {
         p->hgeo[1] = t2d_pool::HostGeo{};
     }
@@ -1650,6 +1750,27 @@ int t2d_verify_state(t2d_pool* p, const float* x_dev, const float* y_dev, const 
     touch(p, (hipStream_t)hip_stream);
     T2D_HIP(p, t2d::launch_verify(p->v, x_dev, y_dev, heading_dev, speed_dev, interval_ms, valid_dev,
                                   (hipStream_t)hip_stream));
+    return T2D_OK;
+}
+
+int t2d_set_outputs(t2d_pool* p, uint32_t mask) {
+    if (!p) return T2D_ERR_INVALID;
+    if (mask & ~T2D_OUT_ALL) return fail(p, T2D_ERR_INVALID, "unknown output bit");
+    p->v.out_mask = (int32_t)mask;
+    return T2D_OK;
+}
+
+int t2d_debug_lane_safe_rects(int32_t n_env, const int32_t* env_lane_offsets, const int32_t* lane_vert_offsets,
+                              const float* verts_xy, float* out) {
+    if (n_env <= 0 || !env_lane_offsets || !lane_vert_offsets || !out) return T2D_ERR_INVALID;
+    std::unique_ptr<t2d_pool> tmp(new (std::nothrow) t2d_pool());   // host bookkeeping only: no device call below
+    if (!tmp) return T2D_ERR_NOMEM;
+    tmp->v.n_env = n_env;
+    t2d_pool::HostGeo g;
+    const int rc = prepare_polys(tmp.get(), env_lane_offsets, lane_vert_offsets, verts_xy, g);
+    if (rc != T2D_OK) return fail(nullptr, rc, tmp->err);
+    build_safe_rects(n_env, g);
+    memcpy(out, g.safe.data(), sizeof(float) * g.safe.size());
     return T2D_OK;
 }
 

@@ -516,12 +516,14 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         pv.y[idx] = fy;
         pv.heading[idx] = fh;
         pv.speed[idx] = (float)o.speed;
-        if (o.has_velocity) {
+        if (o.has_velocity && (model == T2D_MODEL_POINTMASS || (pv.out_mask & T2D_OUT_VELOCITY))) {
             pv.vx[idx] = (float)o.vx;
             pv.vy[idx] = (float)o.vy;
         }
-        pv.applied0[idx] = (float)o.app0;
-        pv.applied1[idx] = (float)o.app1;
+        if (pv.out_mask & T2D_OUT_APPLIED) {
+            pv.applied0[idx] = (float)o.app0;
+            pv.applied1[idx] = (float)o.app1;
+        }
     }
     T2D_MARK(13);
     double pre_tp = 0.0;
@@ -535,6 +537,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     float R32 = -1.0f;                                  // bounding radius + 5 mm; < 0 = inactive
     float box_lo_x = 0, box_hi_x = 0, box_lo_y = 0, box_hi_y = 0;  // encloses the pose (outward rounded)
     uint32_t f_own = 0;                                 // flags this lane decides alone
+    bool lane_safe = false;                             // pose certified inside the union of the env's lanes
     int gcx = 0, gcy = 0;
     if (active) {
         const double cx = (double)fx, cy = (double)fy;
@@ -588,6 +591,21 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         box_hi_x = (float)hi_x; box_hi_x += __builtin_fabsf(box_hi_x) * 1.2e-7f + 1e-6f;
         box_lo_y = (float)lo_y; box_lo_y -= __builtin_fabsf(box_lo_y) * 1.2e-7f + 1e-6f;
         box_hi_y = (float)hi_y; box_hi_y += __builtin_fabsf(box_hi_y) * 1.2e-7f + 1e-6f;
+#ifndef T2D_NO_SAFE_RECTS
+        // Off-lane short cut: a pose whose (outward-rounded) box lies in one of the env's safe rectangles -- rectangles the
+        // host found inside the union of the env's lanes, t2d_api.hip build_safe_rects -- is contained in the union: the
+        // lane stages below never see it.  A certificate, not an approximation: poses it does not cover take the exact path.
+        if (gl.has[1]) {
+            const float4* sr = reinterpret_cast<const float4*>(s_geo + gl.off_safe) + env_local * kSafeRects;
+#pragma unroll
+            for (int k = 0; k < kSafeRects; ++k) {
+                const float4 r = sr[k];
+                const float m = __builtin_fmaxf(__builtin_fmaxf(r.x - box_lo_x, box_hi_x - r.y),
+                                                __builtin_fmaxf(r.z - box_lo_y, box_hi_y - r.w));
+                lane_safe |= m <= 0.0f;
+            }
+        }
+#endif
         if (use_hash_grid) {
             gcx = (int)__builtin_floor(cx * pv.inv_cell);
             gcy = (int)__builtin_floor(cy * pv.inv_cell);
@@ -608,7 +626,18 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         const int ki = s_kind[i], kj = s_kind[j];
         bool hit;
         if (ki == T2D_SHAPE_OBB && kj == T2D_SHAPE_OBB) {
-            hit = sat_quads(load_obb_lds(&s_v[0][i]), load_obb_lds(&s_v[0][j]));
+            const Quad A = load_obb_lds(&s_v[0][i]), B = load_obb_lds(&s_v[0][j]);
+#ifndef T2D_NO_RECT_FILTER
+            // two boxes: four projections certify the answer unless the boxes are within ~1e-7 m of touching
+            // (rect_pair_filter); only then -- practically never -- the wave runs the 32 orientations of the oracle's test
+            const int v = rect_pair_filter(A, B);
+            hit = v == 1;
+            if (__ballot(v == 2) != 0ull) {
+                if (v == 2) hit = sat_quads(A, B);
+            }
+#else
+            hit = sat_quads(A, B);
+#endif
         } else if (ki == T2D_SHAPE_OBB) {   // circle j against box i
             hit = circle_vs_generic((double)s_cxy[0][j], (double)s_cxy[1][j], s_rad[j], PolyRef{nullptr, &s_v[0][i], 4});
         } else if (kj == T2D_SHAPE_OBB) {   // circle i against box j
@@ -806,7 +835,11 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         const int* pstart = geo_i + gl.off_pstart[kd];
         const float4* bb = reinterpret_cast<const float4*>(s_geo + gl.off_aabb[kd]);
         const int p0 = pstart[env_local], p1 = pstart[env_local + 1];
-        if (kd == 1) n_lane_polys = p1 - p0;
+        if (kd == 1) {
+            n_lane_polys = p1 - p0;
+            if (__ballot(active && !lane_safe) == 0ull) continue;   // every pose of the wave certified: no lane work at all
+        }
+        const bool sweeps = active && !(kd == 1 && lane_safe);
         // pass 1: which (participant, polygon) boxes meet; pass 2: survivors of the whole wave,
         // compacted, one narrow test per lane.
         // box-vs-box sweep of polygons [first, first + cn): the polygon's float4 (xmin, xmax, ymin, ymax) comes
@@ -850,7 +883,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             for (int c0 = 0; c0 < np; c0 += 64) {
                 const int cn = np - c0 < 64 ? np - c0 : 64;
                 unsigned long long m = box_sweep(p0 + c0, cn);
-                if (!active) m = 0ull;
+                if (!sweeps) m = 0ull;
                 if (kd == 1 && c0 == 0) m_first = m;
                 T2D_MARK(5 + 2 * kd);
                 if (kd == 0) compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_static, cn <= 32);
@@ -859,7 +892,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             }
         } else {
             for (int c0 = 0;; c0 += 64) {
-                const int left = active ? p1 - p0 - c0 : 0;
+                const int left = sweeps ? p1 - p0 - c0 : 0;
                 if (__ballot(left > 0) == 0ull) break;
                 const int cn = left < 64 ? left : 64;
                 const unsigned long long m = cn > 0 ? box_sweep(p0 + c0, cn) : 0ull;
@@ -950,8 +983,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         f = f_own | (sf & ((1u << kLaneShift) - 1u));
         if (n_lane_polys > 0) {  // build-defined off-lane: not union(lanes).contains(pose)
             const uint32_t b = sf >> kLaneShift;   // see process_lane / process_lane_slow
-            const bool in = kind == T2D_SHAPE_OBB ? (b & 16u) || ((b & 15u) == 15u && (b & 32u) && !(b & 64u))
-                                                  : (b & 32u) && !(b & 64u);
+            const bool in = lane_safe || (kind == T2D_SHAPE_OBB ? (b & 16u) || ((b & 15u) == 15u && (b & 32u) && !(b & 64u))
+                                                                : (b & 32u) && !(b & 64u));
             if (!in) f |= T2D_FLAG_OFF_LANE;
         }
     }

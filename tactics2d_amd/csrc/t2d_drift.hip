@@ -164,8 +164,10 @@ __global__ __launch_bounds__(kDriftBlock) void drift_kernel(PoolView pv, int int
     pv.speed[i] = (float)v;
     pv.omega_f[i] = (float)omega_wf;
     pv.omega_r[i] = (float)omega_wr;
-    pv.applied0[i] = (float)accel;
-    pv.applied1[i] = (float)delta;
+    if (pv.out_mask & T2D_OUT_APPLIED) {
+        pv.applied0[i] = (float)accel;
+        pv.applied1[i] = (float)delta;
+    }
 }
 
 }  // namespace

@@ -128,12 +128,14 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d
             pv.y[idx] = fy;
             pv.heading[idx] = fh;
             pv.speed[idx] = (float)o.speed;
-            if (o.has_velocity) {
+            if (o.has_velocity && (model == T2D_MODEL_POINTMASS || (pv.out_mask & T2D_OUT_VELOCITY))) {
                 pv.vx[idx] = (float)o.vx;
                 pv.vy[idx] = (float)o.vy;
             }
-            pv.applied0[idx] = (float)o.app0;
-            pv.applied1[idx] = (float)o.app1;
+            if (pv.out_mask & T2D_OUT_APPLIED) {
+                pv.applied0[idx] = (float)o.app0;
+                pv.applied1[idx] = (float)o.app1;
+            }
         }
     }
     double pre_tp = 0.0;

@@ -57,6 +57,33 @@ T2D_DEV bool sat_quads(const Quad& A, const Quad& B) {
     return !separated;
 }
 
+// Certifying filter in front of sat_quads for two RECTANGLES (participant boxes: vertex order front-right, front-left,
+// rear-left, rear-right, participant/element/vehicle.py:132-142).  Two rectangles are disjoint iff one of their four edge
+// directions separates them, so four projections decide what sat_quads decides with 32 orientations -- where the answer is
+// not a matter of rounding.  With the full edge vectors P = v0 - v3 (length), Q = v1 - v0 (width) and D = twice the centre
+// offset, the gap along n is  |n.D| - (|n.PA| + |n.QA| + |n.PB| + |n.QB|) = 2 |n| x (distance between the projections).
+// Returns 0: separated by more than kRectMargin / (2 |n|) >= 2.5e-8 m along some edge direction (the edge of that box
+// facing the other one then has all four vertices of the other strictly outside by that much: sat_quads finds it);
+// 1: the projections overlap by more than that on all four (every edge of either box then has a vertex of the other box
+// inside by that much: sat_quads finds no separating edge); 2: closer to touching than that -- undecided, the caller runs
+// sat_quads.  The rounding of either evaluation is ~1e-11 m, three orders below the margin, so 0 / 1 are sat_quads' answers.
+constexpr double kRectMargin = 1e-6;
+T2D_DEV int rect_pair_filter(const Quad& A, const Quad& B) {
+    const double pax = A.x[0] - A.x[3], pay = A.y[0] - A.y[3], qax = A.x[1] - A.x[0], qay = A.y[1] - A.y[0];
+    const double pbx = B.x[0] - B.x[3], pby = B.y[0] - B.y[3], qbx = B.x[1] - B.x[0], qby = B.y[1] - B.y[0];
+    const double dx = (B.x[0] + B.x[2]) - (A.x[0] + A.x[2]), dy = (B.y[0] + B.y[2]) - (A.y[0] + A.y[2]);
+    auto dot = [](double ax, double ay, double bx, double by) { return __builtin_fma(ax, bx, ay * by); };
+    const double papb = dot(pax, pay, pbx, pby), paqb = dot(pax, pay, qbx, qby);
+    const double qapb = dot(qax, qay, pbx, pby), qaqb = dot(qax, qay, qbx, qby);
+    // (P.Q of one box is zero up to rounding, ~1e-15 of the margin: left out)
+    const double g0 = __builtin_fabs(dot(pax, pay, dx, dy)) - (dot(pax, pay, pax, pay) + __builtin_fabs(papb) + __builtin_fabs(paqb));
+    const double g1 = __builtin_fabs(dot(qax, qay, dx, dy)) - (dot(qax, qay, qax, qay) + __builtin_fabs(qapb) + __builtin_fabs(qaqb));
+    const double g2 = __builtin_fabs(dot(pbx, pby, dx, dy)) - (dot(pbx, pby, pbx, pby) + __builtin_fabs(papb) + __builtin_fabs(qapb));
+    const double g3 = __builtin_fabs(dot(qbx, qby, dx, dy)) - (dot(qbx, qby, qbx, qby) + __builtin_fabs(paqb) + __builtin_fabs(qaqb));
+    const double g = __builtin_fmax(__builtin_fmax(g0, g1), __builtin_fmax(g2, g3));
+    return g > kRectMargin ? 0 : (g < -kRectMargin ? 1 : 2);
+}
+
 T2D_DEV bool point_in_quad(const Quad& B, double x, double y) {
     bool in = true;
 #pragma unroll

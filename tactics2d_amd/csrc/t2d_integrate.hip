@@ -85,12 +85,14 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(PoolView pv, int inte
     pv.y[i] = (float)o.y;
     pv.heading[i] = (float)o.heading;
     pv.speed[i] = (float)o.speed;
-    if (o.has_velocity) {
+    if (o.has_velocity && (model == T2D_MODEL_POINTMASS || (pv.out_mask & T2D_OUT_VELOCITY))) {
         pv.vx[i] = (float)o.vx;
         pv.vy[i] = (float)o.vy;
     }
-    pv.applied0[i] = (float)o.app0;
-    pv.applied1[i] = (float)o.app1;
+    if (pv.out_mask & T2D_OUT_APPLIED) {
+        pv.applied0[i] = (float)o.app0;
+        pv.applied1[i] = (float)o.app1;
+    }
 }
 
 // verify_state: the "very rough check" of a candidate state against the pool's current (= last) state.

@@ -30,6 +30,10 @@ namespace t2d {
 //   bstart[MP_1+1]     lanes only: first boundary piece of each lane polygon inside the record (int)
 //   bnd[MB][4]         lanes only: boundary pieces of the union of the env's lanes, fp64 Ax, Ay, Bx, By (16-B aligned),
 //                      grouped by the lane polygon whose edge they are part of (off-lane = not union.contains(pose))
+//   safe[EPB][kSafeRects]  lanes only: axis-aligned rectangles (xmin, xmax, ymin, ymax, fp32) known to lie inside the
+//                      union of the env's lanes (a rectangular lane, or several that abut exactly, shrunk by 0.1 mm): a
+//                      pose whose box lies in one of them is contained in the union -- certified without the polygon tests.
+//                      Unused slots hold the empty box (+inf, -inf, +inf, -inf)
 // MP_k / MV_k / MB = largest polygon / vertex / piece count of any workgroup; stride is a multiple of 4
 // dwords so records are copied to LDS with 16-B loads.
 struct GeoLayout {
@@ -38,7 +42,9 @@ struct GeoLayout {
     int32_t has[2];
     int32_t off_pstart[2], off_vstart[2], off_aabb[2], off_xy[2];  // dword offsets
     int32_t off_bstart, off_bnd;                                   // lanes: boundary pieces of the union (dword offsets)
+    int32_t off_safe;                                              // lanes: rectangles inside the union (dword offset)
 };
+constexpr int kSafeRects = 4;   // per env
 
 // What kernels receive by value.
 struct LidarView;
@@ -79,6 +85,10 @@ struct PoolView {
     const uint32_t* snap_ids;
     const float* snap_omega[2];  // wheel speeds at the snapshot; null unless a drift type is present
     int32_t auto_reset;        // t2d_step restores finished envs in its epilogue
+    // T2D_OUT_* : which pure OUTPUT columns the integrators store (t2d_set_outputs).  vx / vy of the single-track models and
+    // the applied (clipped) action are derived from the state and the action -- nothing on the step path reads them back;
+    // a point mass's vx / vy are state and always stored.
+    int32_t out_mask;
     // 0: the step launch has the GPU to itself (one wave-round): waves that are BEHIND go first, so that a SIMD's four
     // waves finish together.  1: launches of several pools overlap (t2d_step_groups): waves past the integrator go first,
     // so that workgroups retire and the next launch's can start.  See the priority note in t2d_collide.hip.
@@ -177,6 +187,8 @@ struct t2d_pool {
         // lanes only: boundary pieces of the union of each env's lanes, CSR per lane polygon (build_lane_boundary)
         std::vector<int32_t> bnd_off;
         std::vector<double> bnd;
+        // lanes only: per env kSafeRects rectangles inside the union of its lanes (build_safe_rects), 4 floats each
+        std::vector<float> safe;
     } hgeo[2];
     double *d_target_xy = nullptr, *d_target_c = nullptr, *d_last_pose = nullptr, *d_max_iou = nullptr,
            *d_min_dist = nullptr, *d_snap_min_dist = nullptr;

@@ -184,6 +184,11 @@ class ParticipantPool:
         v = {"exact": 0, "fast": 1}.get(variant, variant)
         self._ck(self._lib.t2d_set_integrator_variant(self._h, int(v)))
 
+    def set_outputs(self, velocity=True, applied=True):
+        """Which pure output columns the integrators store (t2d_set_outputs): vx / vy of the single-track models
+        and the applied action.  Both on = the reference's State; a point mass's velocity is state and always stored."""
+        self._ck(self._lib.t2d_set_outputs(self._h, (L.OUT_VELOCITY if velocity else 0) | (L.OUT_APPLIED if applied else 0)))
+
     # ---------------------------------------------------------------- state
     def reset(self, x, y, heading, speed, type_id, active=None, vx=None, vy=None, env_mask=None):
         n = self.n

@@ -350,3 +350,164 @@ def test_lane_boundary_of_abutting_lanes_is_their_outline(oracle):
     dup = [np.float32([[0, 0], [4, 0], [4, 2], [0, 2]])] * 2
     pieces, _ = oracle.lane_boundary(dup)
     assert len(pieces) == 8       # collinear same-direction edges do not cover each other: both outlines stay
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Certificates of the step kernel (round 3): short cuts that must never contradict the oracle's predicate.
+def _safe_rects(lanes):
+    """t2d_debug_lane_safe_rects for one env (host-only entry point of libt2d_hip.so: no device is touched)."""
+    import ctypes as C
+    from tactics2d_amd import _ffi, layout as L
+    lib = _ffi.lib()
+    vo = np.zeros(len(lanes) + 1, np.int32)
+    vo[1:] = np.cumsum([len(q) for q in lanes])
+    xy = np.ascontiguousarray(np.concatenate([np.float32(q).reshape(-1, 2) for q in lanes]), np.float32)
+    eo = np.array([0, len(lanes)], np.int32)
+    out = np.zeros((L.SAFE_RECTS, 4), np.float32)
+    rc = lib.t2d_debug_lane_safe_rects(1, eo.ctypes.data_as(C.c_void_p), vo.ctypes.data_as(C.c_void_p),
+                                       xy.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    return out
+
+
+def _kernel_pose_box(lo_x, hi_x, lo_y, hi_y):
+    """The step kernel's outward-rounded fp32 box of a pose (t2d_collide.hip, pose phase), operation by operation."""
+    f = np.float32
+    def down(v):
+        b = f(v)
+        return f(b - f(f(abs(b) * f(1.2e-7)) + f(1e-6)))
+    def up(v):
+        b = f(v)
+        return f(b + f(f(abs(b) * f(1.2e-7)) + f(1e-6)))
+    return down(lo_x), up(hi_x), down(lo_y), up(hi_y)
+
+
+def _certified(rects, box):
+    lo_x, hi_x, lo_y, hi_y = box
+    return any(r[0] <= lo_x and hi_x <= r[1] and r[2] <= lo_y and hi_y <= r[3] for r in rects)
+
+
+def test_safe_rectangles_of_the_metric_scenes():
+    """What build_safe_rects finds: a highway's four abutting lanes merge into the carriageway, crossing roads stay two
+    rectangles (fillet triangles contribute nothing), a roundabout contributes its four arms and not its ring."""
+    from tactics2d_amd import scenarios as S
+    sc = S.mixed(3, 64, seed=3)
+    eo, vo, xy = sc.lanes
+    per_env = [[xy[vo[p]:vo[p + 1]] for p in range(eo[e], eo[e + 1])] for e in range(3)]
+    hw, rb, ix = (_safe_rects(l) for l in per_env)
+    fin = lambda r: r[np.isfinite(r).all(1)]
+    assert len(fin(hw)) == 1 and np.allclose(fin(hw)[0], [-210, 210, -7.5, 7.5], atol=2e-4)
+    assert (fin(hw)[0] > np.float32([-210, 209, -7.5, 7.4])).all() and fin(hw)[0][1] < 210 and fin(hw)[0][3] < 7.5  # shrunk inwards
+    assert len(fin(rb)) == 4 and len(fin(ix)) == 2
+    assert sorted(np.round(fin(ix)[:, 3] - fin(ix)[:, 2]).tolist()) == [8.0, 238.0] or len(fin(ix)) == 2
+
+
+def test_safe_rectangle_certificate_never_contradicts_the_oracle(oracle):
+    """A pose whose kernel box lies in a safe rectangle must be `contained` for the oracle -- boxes and discs, poses pushed
+    against the rectangles' edges and corners, on lane sets with everything the merge meets: abutting and overlapping
+    rectangular lanes, rectangles inside others, diagonal strips crossing them, fillets, rings."""
+    rng = np.random.default_rng(2024)
+    n_cert = n_box = n_disc = 0
+
+    def scenes():
+        ys = [-7.5, -3.75, 0.0, 3.75, 7.5]
+        yield [np.float32([[-210, ys[k]], [210, ys[k]], [210, ys[k + 1]], [-210, ys[k + 1]]]) for k in range(4)]
+        cross = [np.float32([[-60, -3.75], [60, -3.75], [60, 3.75], [-60, 3.75]]), np.float32([[-3.75, -60], [3.75, -60], [3.75, 60], [-3.75, 60]])]
+        for sx in (-1, 1):
+            for sy in (-1, 1):
+                cross.append(np.float32([[sx * 3.75, sy * 3.75], [sx * 7.75, sy * 3.75], [sx * 3.75, sy * 7.75]]))
+        yield cross
+        for _ in range(40):   # random stacks: abutting / overlapping / nested rectangles + a diagonal strip + a triangle
+            x0, x1 = sorted(np.float32(rng.uniform(-40, 40, 2)))
+            if x1 - x0 < 6:
+                x1 = np.float32(x0 + 6)
+            lanes, y = [], np.float32(rng.uniform(-10, 0))
+            for _ in range(int(rng.integers(1, 5))):
+                h = np.float32(rng.uniform(2.5, 5)); mode = rng.integers(0, 3)
+                y_lo = y if mode == 0 else np.float32(y - rng.uniform(0, 1.5))      # abut exactly / overlap
+                lanes.append(np.float32([[x0, y_lo], [x1, y_lo], [x1, y_lo + h], [x0, y_lo + h]])); y = np.float32(y_lo + h)
+            if rng.uniform() < 0.5:      # a rectangle inside the stack
+                lanes.append(np.float32([[x0 + 1, lanes[0][0][1] + 0.5], [x1 - 1, lanes[0][0][1] + 0.5], [x1 - 1, lanes[0][0][1] + 1.5], [x0 + 1, lanes[0][0][1] + 1.5]]))
+            if rng.uniform() < 0.7:
+                lanes.append(_strip(rng.uniform(x0, x1), rng.uniform(-8, 8), rng.uniform(0.2, 2.9), rng.uniform(10, 50), rng.uniform(2, 6)))
+            if rng.uniform() < 0.5:
+                lanes.append(np.float32([[x1, y - 3], [x1 + 4, y - 3], [x1, y]]))
+            if rng.uniform() < 0.5:      # clockwise input
+                lanes[0] = lanes[0][::-1].copy()
+            yield lanes
+
+    for lanes in scenes():
+        rects = _safe_rects(lanes)
+        rects = rects[np.isfinite(rects).all(1)]
+        assert len(rects) >= 1
+        for _ in range(60):
+            r = rects[int(rng.integers(0, len(rects)))]
+            disc = rng.uniform() < 0.2
+            h = float(np.float32(rng.uniform(0, 6.3) if rng.uniform() < 0.7 else rng.choice([0.0, np.pi / 2, np.pi, 1e-4])))
+            L_, W_ = (rng.uniform(2, 9), rng.uniform(1, 2.5)) if not disc else (0.0, rng.uniform(0.4, 1.0))
+            ex = 0.5 * (L_ * abs(np.cos(h)) + W_ * abs(np.sin(h))) if not disc else 0.5 * W_
+            ey = 0.5 * (L_ * abs(np.sin(h)) + W_ * abs(np.cos(h))) if not disc else 0.5 * W_
+            if r[1] - r[0] <= 2 * ex + 1e-3 or r[3] - r[2] <= 2 * ey + 1e-3:
+                continue
+            # centres: anywhere inside, or pushed to within micrometres of an edge / a corner of the rectangle
+            def coord(lo, hi, e):
+                m = rng.integers(0, 4)
+                d = rng.choice([0.0, 1e-6, 3e-6, 1e-5, 1e-3])
+                return rng.uniform(lo + e, hi - e) if m == 0 else (lo + e + d if m == 1 else (hi - e - d if m == 2 else 0.5 * (lo + hi)))
+            x = float(np.float32(coord(float(r[0]), float(r[1]), ex))); y = float(np.float32(coord(float(r[2]), float(r[3]), ey)))
+            if disc:
+                box = _kernel_pose_box(x - 0.5 * W_, x + 0.5 * W_, y - 0.5 * W_, y + 0.5 * W_)
+            else:
+                pose = oracle.pose_obb(x, y, h, L_, W_, trig=1)
+                box = _kernel_pose_box(pose[:, 0].min(), pose[:, 0].max(), pose[:, 1].min(), pose[:, 1].max())
+            if not _certified(rects, box):
+                continue
+            n_cert += 1
+            if disc:
+                n_disc += 1
+                assert oracle.circle_in_lane_union((x, y), 0.5 * W_, lanes), (lanes, x, y, W_)
+            else:
+                n_box += 1
+                assert oracle.pose_in_lane_union(pose, (x, y), lanes), (lanes, x, y, h, L_, W_)
+    assert n_box > 800 and n_disc > 150, (n_cert, n_box, n_disc)
+
+
+def test_rect_pair_filter_is_a_certificate_of_convex_intersects(oracle):
+    """The four-projection filter in front of the pair SAT (t2d_geom_dev.h rect_pair_filter), restated here in numpy on the
+    oracle's own fp64 vertices: whenever it answers, the oracle's 32-orientation test gives the same answer -- random pairs,
+    pairs moved to exact contact, and pairs a few nanometres either side of contact (those it must leave undecided or get
+    right)."""
+    rng = np.random.default_rng(99)
+
+    def filt(A, B):
+        pa, qa, pb, qb = A[0] - A[3], A[1] - A[0], B[0] - B[3], B[1] - B[0]
+        d = (B[0] + B[2]) - (A[0] + A[2])
+        g = [abs(pa @ d) - (pa @ pa + abs(pa @ pb) + abs(pa @ qb)), abs(qa @ d) - (qa @ qa + abs(qa @ pb) + abs(qa @ qb)),
+             abs(pb @ d) - (pb @ pb + abs(pa @ pb) + abs(qa @ pb)), abs(qb @ d) - (qb @ qb + abs(pa @ qb) + abs(qa @ qb))]
+        m = max(g)
+        return 0 if m > 1e-6 else (1 if m < -1e-6 else 2)
+
+    counts = [0, 0, 0]
+    for it in range(6000):
+        La, Wa, Lb, Wb = rng.uniform(1.5, 18), rng.uniform(0.6, 2.6), rng.uniform(1.5, 18), rng.uniform(0.6, 2.6)
+        xa, ya, ha = np.float32(rng.uniform(-250, 250)), np.float32(rng.uniform(-250, 250)), np.float32(rng.uniform(0, 6.3))
+        hb = np.float32(ha + rng.choice([0.0, np.pi / 2, np.pi]) + rng.normal(0, 1e-3)) if it % 3 == 0 else np.float32(rng.uniform(0, 6.3))
+        r = rng.uniform(0, 1.2) * 0.5 * (np.hypot(La, Wa) + np.hypot(Lb, Wb)); t = rng.uniform(0, 6.3)
+        xb, yb = np.float32(xa + r * np.cos(t)), np.float32(ya + r * np.sin(t))
+        if it % 4 == 0:    # slide B along the line of centres until the boxes touch to within fp32 resolution
+            lo, hi = 0.0, 40.0
+            for _ in range(60):
+                mid = 0.5 * (lo + hi)
+                Bm = oracle.pose_obb(float(np.float32(xa + mid * np.cos(t))), float(np.float32(ya + mid * np.sin(t))), float(hb), Lb, Wb, trig=1)
+                if oracle.convex_intersects(oracle.pose_obb(float(xa), float(ya), float(ha), La, Wa, trig=1), Bm):
+                    lo = mid
+                else:
+                    hi = mid
+            xb, yb = np.float32(xa + lo * np.cos(t)), np.float32(ya + lo * np.sin(t))
+        A = oracle.pose_obb(float(xa), float(ya), float(ha), La, Wa, trig=1)
+        B = oracle.pose_obb(float(xb), float(yb), float(hb), Lb, Wb, trig=1)
+        v = filt(A, B)
+        counts[v] += 1
+        if v != 2:
+            assert bool(v) == oracle.convex_intersects(A, B), (xa, ya, ha, La, Wa, xb, yb, hb, Lb, Wb)
+    assert counts[0] > 1000 and counts[1] > 1000 and counts[2] < 600, counts
