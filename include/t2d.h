@@ -302,6 +302,23 @@ int t2d_set_ego_kernel(t2d_pool* pool, int32_t on);
 int t2d_step_groups(t2d_pool* const* pools, const float* const* act0_dev, const float* const* act1_dev,
                     void* const* hip_streams, int32_t n, int32_t interval_ms);
 
+/* n_steps consecutive t2d_step's enqueued by ONE call -- a rollout fragment on resident actions (the loop of
+ * envs/parking.py:219-256 without a host round trip per step).  Step k reads participant i's action at
+ * act[i * stride + k * act_step_stride] of the bound (or the pool's own) action arrays: act_step_stride = 0 repeats one
+ * action set (frame skip), n_env * max_agents * stride walks an action ring laid out [n_steps][N].  Results are exactly
+ * those of n_steps t2d_step calls; per-step rewards / statuses are in the record ring (T2D_F_RECORD), the participant
+ * fields hold the last step's values.
+ * How: pools whose step is the fused kernel alone (no IDM / drift / regenerated scenes / single-ego kernel) get ONE launch
+ * holding all the steps: workgroup (g, k) takes step k of the envs of workgroup g and is ordered after workgroup (g, k - 1)
+ * by a per-workgroup counter in device memory (release / acquire at agent scope) -- no launch boundary between steps, so the
+ * start-up of step k + 1 overlaps the tail of step k, and small pools stop paying one launch per step.  A wait is bounded:
+ * if it ever ran out, the next t2d_sync / t2d_download / t2d_step_n returns T2D_ERR_STATE.  Other pools, and every pool after
+ * t2d_set_step_chaining(pool, 0, *), take n_steps ordinary launches.  priority_rule: wave priorities inside a chained launch
+ * (1, default: the rule for overlapping work; 0: the single-launch rule).  kernel_id 7 in t2d_profile_read
+ * (one "launch" = one chained launch of up to T2D_RECORD_RING steps).                                                    */
+int t2d_step_n(t2d_pool* pool, int32_t interval_ms, int32_t n_steps, int64_t act_step_stride, void* hip_stream);
+int t2d_set_step_chaining(t2d_pool* pool, int32_t on, int32_t priority_rule);
+
 /* Zero-copy device pointer of a field (for wrapping as a torch tensor).                 */
 int t2d_get_field(t2d_pool* pool, int32_t field_id, void** dev_ptr, size_t* nbytes);
 /* Synchronous host<->device copies of a whole field (parity tests, small envs).         */

@@ -88,15 +88,35 @@ void touch(t2d_pool* p, hipStream_t s) {
 
 hipError_t quiesce(t2d_pool* p) {
     hipError_t e = hipSuccess;
-    if (p->live_overflow) {
+    bool whole_device = p->live_overflow;
+    for (int k = 0; k < p->n_live_streams && !whole_device; ++k)
+        if (hipStreamSynchronize(p->live_streams[k]) != hipSuccess) {
+            // a caller's stream that no longer exists (stepped on a temporary stream and destroyed it): its work cannot be
+            // waited for by handle any more -- wait for the device instead of failing or skipping the rest
+            (void)hipGetLastError();
+            whole_device = true;
+        }
+    if (whole_device) {
         e = hipDeviceSynchronize();
-    } else {
-        for (int k = 0; k < p->n_live_streams && e == hipSuccess; ++k) e = hipStreamSynchronize(p->live_streams[k]);
-        if (e == hipSuccess && p->scene_stream) e = hipStreamSynchronize(p->scene_stream);
-        if (e == hipSuccess && p->gather_stream) e = hipStreamSynchronize(p->gather_stream);
+    } else {   // the pool's own streams, whatever happened above
+        if (p->scene_stream) e = hipStreamSynchronize(p->scene_stream);
+        if (p->gather_stream) {
+            const hipError_t e2 = hipStreamSynchronize(p->gather_stream);
+            if (e == hipSuccess) e = e2;
+        }
     }
     p->n_live_streams = 0;
     p->live_overflow = false;
+    if (e == hipSuccess && p->chain_used) {   // a chained launch reports a wait that ran out through a word in device memory
+        uint32_t err = 0;
+        e = hipMemcpy(&err, p->d_chain + p->chain_slots, sizeof(err), hipMemcpyDeviceToHost);
+        p->chain_used = false;
+        if (e == hipSuccess && err) {
+            (void)hipMemset(p->d_chain + p->chain_slots, 0, sizeof(err));
+            p->chain_failed = true;
+            p->chain_steps = false;   // whatever broke the hand-off (a wait that ran out, workgroups of one env set on two XCDs) may do so again
+        }
+    }
     return e;
 }
 
@@ -692,6 +712,8 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
         alloc((void**)&p->d_min_dist, E * sizeof(double));
         alloc((void**)&p->d_snap_min_dist, E * sizeof(double));
         alloc((void**)&p->d_last_valid, E);
+        p->chain_slots = (n_env + 7 + 8) & ~7;   // one counter per step workgroup (at most one per env) + padding; then the error word
+        alloc((void**)&p->d_chain, sizeof(unsigned long long) * ((size_t)p->chain_slots + 1));
         if (e2 != hipSuccess) {
             t2d_destroy(p);
             return fail(nullptr, T2D_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e2));
@@ -763,7 +785,7 @@ int t2d_destroy(t2d_pool* p) {
                     p->d_lidar_env_off, p->d_lidar_next, p->d_lidar_meta, p->d_lidar_xy, p->d_beam_sin, p->d_beam_cos,
                     p->d_snap[0], p->d_snap[1], p->d_snap[2],
                     p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_wgmap, p->d_idm_rows, p->d_idm_ctrl, p->d_snap_omega[0], p->d_snap_omega[1], p->d_time_penalty,
-                    p->d_scene_arrays, p->d_lidar_cnt};
+                    p->d_scene_arrays, p->d_lidar_cnt, p->d_chain};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->comm && rccl().ok) (void)rccl().CommDestroy((ncclComm_t)p->comm);
@@ -1204,6 +1226,69 @@ int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     return rc;
 }
 
+int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_step_stride, void* hip_stream) {
+    if (!p) return T2D_ERR_INVALID;
+    if (n_steps < 1 || act_step_stride < 0) return fail(p, T2D_ERR_INVALID, "n_steps must be >= 1 and act_step_stride >= 0");
+    if (p->chain_failed)
+        return fail(p, T2D_ERR_STATE, "an earlier t2d_step_n launch timed out waiting for its previous step (results invalid)");
+    if (!p->have_params || !p->have_reset)
+        return fail(p, T2D_ERR_STATE, "t2d_set_param_table and t2d_reset must precede t2d_step_n");
+    if (interval_ms <= 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be positive");
+    hipStream_t s = (hipStream_t)hip_stream;
+    const bool ego = p->ego_kernel && p->v.A == 1 && p->all_boxes && !p->has_drift && !p->hgeo[1].present;
+    const bool iou = p->status_cfg.check_no_action || p->status_cfg.check_arrival;   // per-env history read by the epilogue
+    const bool chain = p->chain_steps && n_steps >= 2 && p->fused_step && !p->idm_on && !p->has_drift && !p->scene_regen && !ego && !iou;
+    const float *a0 = p->v.act0, *a1 = p->v.act1;
+    int rc = T2D_OK;
+    if (!chain) {   // kernels outside the fused step (IDM, drift, scene regeneration, the single-ego kernel): step by step
+        for (int k = 0; k < n_steps && rc == T2D_OK; ++k) {
+            p->v.act0 = a0 + (size_t)k * act_step_stride;
+            p->v.act1 = a1 + (size_t)k * act_step_stride;
+            rc = t2d_step(p, interval_ms, hip_stream);
+        }
+        p->v.act0 = a0;
+        p->v.act1 = a1;
+        return rc;
+    }
+    touch(p, s);
+    for (int done = 0; done < n_steps && rc == T2D_OK;) {
+        // one launch covers at most a ring of record slots (and a gather that still reads any of them is waited for first)
+        const int n = std::min(n_steps - done, (int)T2D_RECORD_RING);
+        const int slot0 = (int)(p->step_count % T2D_RECORD_RING);
+        for (int k = 0; k < n; ++k) {
+            if ((rc = claim_record_slot(p, s))) return rc;
+            p->step_count++;
+        }
+        t2d::PoolView v = p->v;
+        v.wgmap = nullptr;
+        v.overlapped = p->chain_priority;
+        v.act0 = a0 + (size_t)done * act_step_stride;
+        v.act1 = a1 + (size_t)done * act_step_stride;
+        v.chain_done = p->d_chain;
+        v.chain_err = reinterpret_cast<uint32_t*>(p->d_chain + p->chain_slots);
+        v.chain_base = p->chain_count;
+        v.chain_real_wgs = (p->v.n_env + p->v.geo_layout.epb - 1) / p->v.geo_layout.epb;
+        v.chain_act_step = act_step_stride;
+        v.record_ring = (uint2*)p->field_ptr[T2D_F_RECORD];
+        v.record_slot0 = slot0;
+        if ((rc = record_event(p, 7, s, true))) return rc;
+        T2D_HIP(p, t2d::launch_step_chain(v, p->status_cfg, interval_ms, p->integrator_variant, n, s));
+        if ((rc = record_event(p, 7, s, false))) return rc;
+        p->chain_count += (uint32_t)n;
+        p->chain_used = true;
+        done += n;
+    }
+    p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)((p->step_count + T2D_RECORD_RING - 1) % T2D_RECORD_RING) * p->v.n_env;
+    return rc;
+}
+
+int t2d_set_step_chaining(t2d_pool* p, int32_t on, int32_t priority_rule) {
+    if (!p) return T2D_ERR_INVALID;
+    p->chain_steps = on != 0;
+    p->chain_priority = priority_rule != 0;
+    return T2D_OK;
+}
+
 int t2d_step_groups(t2d_pool* const* pools, const float* const* act0_dev, const float* const* act1_dev,
                     void* const* hip_streams, int32_t n, int32_t interval_ms) {
     if (!pools || !hip_streams || n <= 0 || (act0_dev == nullptr) != (act1_dev == nullptr)) return T2D_ERR_INVALID;
@@ -1595,6 +1680,8 @@ int t2d_download(t2d_pool* p, int32_t f, void* host_dst, size_t nbytes) {
                                             std::to_string(f >= 0 && f < T2D_F_COUNT ? p->field_bytes[f] : 0) + " bytes)");
     T2D_HIP(p, hipSetDevice(p->device));
     T2D_HIP(p, quiesce(p));
+    if (p->chain_failed)
+        return fail(p, T2D_ERR_STATE, "a t2d_step_n launch timed out waiting for its previous step (results invalid)");
     T2D_HIP(p, hipMemcpy(host_dst, p->field_ptr[f], nbytes, hipMemcpyDeviceToHost));
     return T2D_OK;
 }
@@ -1621,6 +1708,8 @@ int t2d_sync(t2d_pool* p) {
     if (!p) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));
     T2D_HIP(p, quiesce(p));
+    if (p->chain_failed)
+        return fail(p, T2D_ERR_STATE, "a t2d_step_n launch timed out waiting for its previous step (results invalid)");
     return T2D_OK;
 }
 

@@ -303,7 +303,31 @@ T2D_DEV void compact_and_process(unsigned long long mask, int id_base, int own_i
 // phases: no second launch, no state reload.
 // IOU = false: a pool whose status configuration checks neither NoAction nor Arrival (everything but the parking envs)
 // runs the instantiation without the quad-IoU code: its out-of-line body brings a 168-B private segment with it.
-template <bool WITH_STATUS, int FUSE, bool IOU = true>
+// CHAIN = true (t2d_step_n): the launch holds several steps.  Workgroup (x, y) takes step y of the envs workgroup x owns and
+// is ordered after the workgroup that took their step y - 1 by a per-workgroup word in global memory.  What it buys: no
+// launch boundary between steps -- the start-up of step y + 1 and the tail of step y overlap like env groups on separate
+// streams do, inside one launch.
+// The hand-off stays inside one XCD's L2 (MI355X_MICROARCH.md, inter-workgroup visibility: an agent-scope release / acquire
+// pair costs microseconds per workgroup -- the first version of this, with fences, ran 5x slower than separate launches):
+//   producer: plain stores -> every wave s_waitcnt vmcnt(0) (acknowledged by the L2) -> barrier -> ONE relaxed agent-scope
+//             8-byte store {steps done, XCC id};
+//   consumer: one lane polls that word with relaxed agent-scope loads (sc1: served by the L2, never by this CU's L1),
+//             barrier, then reads the mutable state with sc1 loads as well.
+// That is coherent only if both workgroups run on the same XCD (per-XCD L2s are not coherent with each other).  The grid's x
+// extent is a multiple of 8 and the hardware places linear workgroup id i on XCD i mod 8 -- observed, not promised -- so
+// the consumer CHECKS it: the producer's XCC id travels in the word, a mismatch (or a wait that runs out: kChainSpinLimit)
+// raises chain_err, the host reports the launch as failed and stops chaining.  Never a silent stale read, never a hang.
+constexpr int kChainSpinLimit = 1 << 18;   // ~0.2 s of polling: far beyond any step, short enough not to look like a hang
+T2D_DEV unsigned long long chain_word(uint32_t steps_done) {   // {steps done, XCC id of the workgroup that did the last one}
+    return (unsigned long long)steps_done | ((unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg(63508) << 32);
+}
+// a load of state the previous step of a chained launch stored: sc1 (through the L2), plain otherwise
+template <bool CHAIN, class T>
+T2D_DEV T ld_state(const T2D_GLOBAL T* p) {
+    if (CHAIN) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool WITH_STATUS, int FUSE, bool IOU = true, bool CHAIN = false>
 __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv, t2d_status_config cfg,
                                                                             int interval_ms, int log2A) {
     __shared__ double s_v[8][kBlock];   // OBB vertex coordinate planes x0,y0,...,x3,y3
@@ -353,7 +377,13 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     // workgroup steps, and by how many waves its lane -> participant map is rotated.  Results do not depend on it; the
     // hardware places workgroup b on XCD b mod 8 and its waves on fixed SIMDs, so the map decides which envs share a SIMD.
     int wg = blockIdx.x, wave_rot = 0;
-    if (pv.wgmap) {
+    const int step_k = CHAIN ? (int)blockIdx.y : 0;
+    if (CHAIN && wg >= pv.chain_real_wgs) {   // padding of the grid's x extent to a multiple of 8 (see launch_step_chain)
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&pv.chain_done[wg], chain_word(pv.chain_base + (uint32_t)step_k + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (!CHAIN && pv.wgmap) {
         const uint32_t m = pv.wgmap[blockIdx.x];
         wg = (int)(m & 0xffffu);
         wave_rot = (int)(m >> 16);
@@ -393,6 +423,31 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     // 20.0 us per step of all envs with that rule, 20.3 without priorities, 23.4 with the single-launch rule.
     const bool behind_first = pv.overlapped == 0;
     if (behind_first) __builtin_amdgcn_s_setprio(3);
+    // chained launch: wait for the step before this one of the same envs (one lane polls, s_sleep between polls)
+    auto chain_wait = [&]() {
+        if (tid == 0) {
+            const uint32_t want = pv.chain_base + (uint32_t)step_k;
+            int spins = 0;
+            unsigned long long w;
+            // (a signed difference: the counter may wrap after 2^32 steps of a pool)
+            while ((int32_t)((uint32_t)(w = __hip_atomic_load(&pv.chain_done[wg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - want) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                ++spins;
+                // give up when the wait ran out -- or when another workgroup's did (checked now and then): one failure
+                // ends the launch in about one limit, not in one limit per workgroup
+                if (spins > kChainSpinLimit ||
+                    ((spins & 255) == 0 && __hip_atomic_load(pv.chain_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    __hip_atomic_store(pv.chain_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w = chain_word(want);
+                    break;
+                }
+            }
+            // the previous step's stores sit in ITS XCD's L2: the sc1 loads below see them only from the same XCD
+            if ((uint32_t)(w >> 32) != (uint32_t)__builtin_amdgcn_s_getreg(63508))
+                __hip_atomic_store(pv.chain_err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    };
     // ---------------- phase 0: issue every global load, clear LDS tables ------------------
     uint32_t ids = 0;
     float fx = 0, fy = 0, fh = 0;
@@ -402,15 +457,17 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     // the status epilogue's inputs, fetched now by the lane that will run it (agent 0): their latency
     // would otherwise sit, unhidden, at the very end of the wave
     int pre_cnt = 0, pre_frame = 0;
+    if (CHAIN && step_k > 0) chain_wait();
     if (valid) {
-        ids = a_ids[idx];
-        fx = a_x[idx];
-        fy = a_y[idx];
-        fh = a_h[idx];
+        ids = ld_state<CHAIN>(a_ids + idx);
+        fx = ld_state<CHAIN>(a_x + idx);
+        fy = ld_state<CHAIN>(a_y + idx);
+        fh = ld_state<CHAIN>(a_h + idx);
         if (FUSE >= 0) {
-            fv = a_v[idx];
-            fa0 = a_act0[(size_t)idx * a_act_stride];
-            fa1 = a_act1[(size_t)idx * a_act_stride];
+            fv = ld_state<CHAIN>(a_v + idx);
+            const size_t ai = (size_t)idx * a_act_stride + (CHAIN ? (size_t)step_k * (size_t)pv.chain_act_step : 0);
+            fa0 = a_act0[ai];
+            fa1 = a_act1[ai];
             if (a_idm && a_idm[idx] != T2D_IDM_NONE) {  // IDM lane while caller actions are bound
                 fa0 = pv.own_act0[idx];
                 fa1 = pv.own_act1[idx];
@@ -504,8 +561,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         auto P = [&](int col) -> double { return s_partab[col * T2D_MAX_TYPES + type]; };
         double pvx = 0.0, pvy = 0.0;
         if (model == T2D_MODEL_POINTMASS) {
-            pvx = (double)pv.vx[idx];
-            pvy = (double)pv.vy[idx];
+            pvx = (double)ld_state<CHAIN>(as_global(pv.vx) + idx);
+            pvy = (double)ld_state<CHAIN>(as_global(pv.vy) + idx);
         }
         const integ::StepOut o = integ::step_participant<(FUSE > 0 ? 1 : 0)>(
             model, P, (double)fx, (double)fy, (double)fh, (double)fv, pvx, pvy, (double)fa0, (double)fa1, interval_ms);
@@ -967,8 +1024,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     // latency.  (Fetched at the top of the kernel they sat in registers through every event phase, and at the 128
     // registers of 4 waves / SIMD that meant scratch spills: 8 B per lane stored and re-read, 13 MB of HBM traffic.)
     if (WITH_STATUS && valid && agent == 0) {
-        pre_cnt = pv.cnt_step[env];
-        pre_frame = pv.frame_ms[env];
+        pre_cnt = ld_state<CHAIN>(e_cnt_step + env);
+        pre_frame = ld_state<CHAIN>(e_frame_ms + env);
         if (e_time_penalty && cfg.max_step > 0) {
             const int c = pre_cnt + 1;
             pre_tp = pv.time_penalty[c < cfg.max_step ? c : cfg.max_step];
@@ -1102,7 +1159,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             const uint32_t st = (uint32_t)scen | (uint32_t)traf << 8 | (uint32_t)terminated << 16 | (uint32_t)truncated << 24;
             ((T2D_GLOBAL uint32_t*)e_status)[env] = st;
             pv.reward[env] = r;
-            pv.record[env] = make_uint2(__float_as_uint(r), st);
+            if (CHAIN) pv.record_ring[(size_t)((pv.record_slot0 + step_k) & (T2D_RECORD_RING - 1)) * (size_t)pv.n_env + env] = make_uint2(__float_as_uint(r), st);
+            else pv.record[env] = make_uint2(__float_as_uint(r), st);
             if (e_auto_reset) {
                 const bool done = terminated || truncated;
                 s_done[env_local] = done;
@@ -1146,6 +1204,12 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         }
     }
     T2D_MARK(12);
+    if (CHAIN) {   // this step of these envs is complete: every store above is in the L2 before the word moves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(&pv.chain_done[wg], chain_word(pv.chain_base + (uint32_t)step_k + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 }  // namespace
@@ -1162,6 +1226,24 @@ hipError_t step_occupancy(const PoolView& v, int* blocks_per_cu, size_t* lds_byt
     if (e != hipSuccess) return e;
     *lds_bytes = fa.sharedSizeBytes + dyn;
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, collide_kernel<true, 1, false>, block, dyn);
+}
+
+hipError_t launch_step_chain(const PoolView& v, const t2d_status_config& cfg, int interval_ms, int variant, int n_steps,
+                             hipStream_t s) {
+    int log2A = 1;
+    while ((1 << log2A) < v.A) ++log2A;
+    const int EPB = v.geo_layout.epb;
+    // x extent rounded up to a multiple of 8: workgroup ids go round the 8 XCDs, so step k + 1 of a set of envs then runs on
+    // the XCD that ran their step k and finds their state in that XCD's L2 (the padding workgroups only move their counter)
+    const int real = (v.n_env + EPB - 1) / EPB, padded = (real + 7) & ~7;
+    const dim3 grid(padded, n_steps), block(EPB << log2A);
+    const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
+    // (pools with IoU events keep per-env history -- last pose, counters -- that the epilogue reads through plain pointers:
+    // the caller steps those one launch at a time)
+    if (cfg.check_no_action || cfg.check_arrival) return hipErrorInvalidValue;
+    if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+    else hipLaunchKernelGGL((collide_kernel<true, 1, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+    return hipGetLastError();
 }
 
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,

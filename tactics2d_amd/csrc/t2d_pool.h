@@ -95,6 +95,16 @@ struct PoolView {
     int32_t overlapped;
     // step launch: physical workgroup -> (logical workgroup | wave rotation << 16), or null = identity (t2d_set_step_placement)
     const uint32_t* wgmap;
+    // Chained multi-step launch (t2d_step_n; collide_kernel<..., CHAIN>): ONE launch of n_steps x chain_wgs workgroups,
+    // workgroup (x = g, y = k) takes step k of the envs of workgroup g and first waits until chain_done[g] == chain_base + k
+    // (set by the workgroup that took step k - 1 of the same envs).  Null for the plain one-step launch.
+    unsigned long long* chain_done;   // [chain_wgs] {steps of its envs completed so far (a count that only ever grows), XCC id}
+    uint32_t* chain_err;        // 1: a workgroup's wait ran out, 2: its predecessor ran on another XCD (never expected; the host checks)
+    uint32_t chain_base;        // what chain_done[] holds when this launch starts
+    int32_t chain_real_wgs;     // workgroups that own envs; the grid's x extent is rounded up to a multiple of 8
+    int64_t chain_act_step;     // elements between the action sets of consecutive steps (0: the same actions every step)
+    uint2* record_ring;         // the whole ring of per-env result records; step k writes slot (record_slot0 + k) % ring
+    int32_t record_slot0;
     unsigned long long* dbg;  // phase cycle accumulators (profiling builds with -DT2D_TIMING only)
     double cell;      // spatial-hash cell edge (m) >= max circum-diameter * 1.001
     double inv_cell;
@@ -223,6 +233,13 @@ struct t2d_pool {
     bool scene_refill_pending = false;
     int32_t* d_lidar_cnt = nullptr;
     long long step_count = 0;  // t2d_step calls so far (selects the record ring slot)
+    // chained multi-step launches (t2d_step_n): per-workgroup step counters + one error word behind them
+    unsigned long long* d_chain = nullptr;   // chain_slots words, then the error word
+    int chain_slots = 0;
+    uint32_t chain_count = 0;      // what every counter holds once the launches enqueued so far have run
+    bool chain_steps = true;       // t2d_set_step_chaining(pool, 0, *): t2d_step_n falls back to one launch per step
+    bool chain_priority = true;    // wave priorities of a chained launch: 1 = the rule for overlapping work (PoolView::overlapped)
+    bool chain_used = false, chain_failed = false;
     // result gather (the one collective of the path): RCCL communicator + a stream of its own, so that the steps that
     // follow a fragment do not wait for its all-gather; slot_event[k] != null = a gather that reads record slot k was
     // enqueued and the step about to overwrite that slot must wait for it first
@@ -251,6 +268,9 @@ namespace t2d {
 hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hipStream_t s);
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
                           int interval_ms, int fuse_variant, hipStream_t s);
+// n_steps fused steps in one launch (v.chain_* set by the caller); see PoolView::chain_done
+hipError_t launch_step_chain(const PoolView& v, const t2d_status_config& cfg, int interval_ms, int variant, int n_steps,
+                             hipStream_t s);
 hipError_t launch_ego_step(const PoolView& v, const t2d_status_config& cfg, int interval_ms, int variant, hipStream_t s);
 hipError_t step_occupancy(const PoolView& v, int* blocks_per_cu, size_t* lds_bytes);
 hipError_t launch_lidar(const PoolView& v, const LidarView& lv, float* out, hipStream_t s);

@@ -258,6 +258,14 @@ class ParticipantPool:
     def step(self, interval_ms=100, stream=None):
         self._ck(self._lib.t2d_step(self._h, int(interval_ms), stream))
 
+    def step_n(self, n_steps, interval_ms=100, act_step_stride=0, stream=None):
+        """n_steps consecutive steps enqueued by one call (t2d_step_n): step k reads the action of participant i at
+        act[i * stride + k * act_step_stride]; 0 repeats one action set.  Same results as n_steps `step` calls."""
+        self._ck(self._lib.t2d_step_n(self._h, int(interval_ms), int(n_steps), int(act_step_stride), stream))
+
+    def set_step_chaining(self, on=True, priority_rule=1):
+        self._ck(self._lib.t2d_set_step_chaining(self._h, int(bool(on)), int(priority_rule)))
+
     def snapshot(self):
         """Record the current state as the episode start for device-side resets."""
         self._ck(self._lib.t2d_snapshot(self._h))

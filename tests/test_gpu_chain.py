@@ -1,0 +1,124 @@
+"""t2d_step_n: n steps enqueued by one call -- for pools stepped by the fused kernel alone ONE launch in which workgroup
+(g, k) takes step k of the envs of workgroup g, ordered after (g, k - 1) by a counter in device memory.  The contract is
+exact: every pool field, and every slot of the record ring, equals what n separate t2d_step calls leave behind.
+(Reference loop: envs/parking.py:219-256, one env.step() after the other.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _fields():
+    from tactics2d_amd import layout as L
+    return (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_VX, L.F_VY, L.F_APPLIED0, L.F_APPLIED1, L.F_IDS, L.F_FLAGS,
+            L.F_ENV_FLAGS, L.F_CNT_STEP, L.F_FRAME_MS, L.F_STATUS, L.F_REWARD, L.F_RECORD, L.F_IOU, L.F_CNT_NO_ACTION)
+
+
+def _pool(sc, variant, ego_kernel=True):
+    from tactics2d_amd.pool import ParticipantPool
+    pool = ParticipantPool(sc.n_env, sc.A)
+    sc.load(pool)
+    pool.set_integrator_variant(variant)
+    pool.set_auto_reset(True)
+    if not ego_kernel:
+        pool._ck(pool._lib.t2d_set_ego_kernel(pool._h, 0))
+    return pool
+
+
+def _compare(sc, n_steps, variant, calls=(None,), ego_kernel=True, same_actions=False):
+    """reference: n_steps t2d_step calls on an action ring; candidate: the same ring through t2d_step_n, split into `calls`"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(4)
+    n = sc.n
+    sets = [sc.sample_actions(rng) for _ in range(1 if same_actions else n_steps)]
+    a0 = torch.from_numpy(np.stack([s[0] for s in sets])).to(dev).contiguous()   # [steps][N]
+    a1 = torch.from_numpy(np.stack([s[1] for s in sets])).to(dev).contiguous()
+    stride = 0 if same_actions else n
+    ref = _pool(sc, variant, ego_kernel)
+    for k in range(n_steps):
+        ref.bind_actions(a0.data_ptr() + 4 * stride * k, a1.data_ptr() + 4 * stride * k)
+        ref.step(sc.interval_ms)
+    want = [ref.download(f) for f in _fields()]
+    ref.close()
+    got_pool = _pool(sc, variant, ego_kernel)
+    done = 0
+    for c in calls:
+        c = n_steps - done if c is None else c
+        got_pool.bind_actions(a0.data_ptr() + 4 * stride * done, a1.data_ptr() + 4 * stride * done)
+        got_pool.step_n(c, sc.interval_ms, stride)
+        done += c
+    assert done == n_steps
+    got = [got_pool.download(f) for f in _fields()]
+    got_pool.close()
+    for f, g, w in zip(_fields(), got, want):
+        assert np.array_equal(g, w, equal_nan=True), (f, int((g != w).sum()))
+    return want
+
+
+@pytest.mark.parametrize("variant", ["exact", "fast"])
+def test_chained_steps_equal_single_steps_on_the_mixed_scene(variant):
+    from tactics2d_amd import layout as L, scenarios as S
+    sc = S.mixed(203, 64, seed=5)          # 51 workgroups: the grid is padded to 56, the last workgroup is ragged
+    want = _compare(sc, 24, variant)
+    st = want[_fields().index(L.F_STATUS)]
+    rec = want[_fields().index(L.F_RECORD)].reshape(L.RECORD_RING, sc.n_env, 2)
+    assert (rec[:24, :, 1] >> 16).astype(bool).any(), "no episode ended in 24 steps: the auto-reset path was not exercised"
+    assert st.shape == (sc.n_env, 4)
+
+
+def test_chained_steps_in_several_calls_and_past_the_record_ring():
+    from tactics2d_amd import scenarios as S
+    sc = S.intersection(64, 32, seed=8)    # A = 32: two envs per wave, eight per workgroup
+    _compare(sc, 70, "exact", calls=(3, 40, 1, 26))   # 40 > the ring of 32 slots: two launches inside one call; 1: plain step
+
+
+def test_chained_steps_repeat_one_action_set():
+    from tactics2d_amd import scenarios as S
+    sc = S.highway(40, 64, seed=2)
+    _compare(sc, 12, "fast", same_actions=True)
+
+
+def test_chained_steps_with_iou_events_on_the_general_kernel():
+    """parking envs (Arrival / NoAction IoU, shaped reward) kept on the general kernel: the IoU instantiation of the chain;
+    with the single-ego kernel t2d_step_n takes ordinary launches -- same answers either way"""
+    from tactics2d_amd import scenarios as S
+    sc = S.parking(300)
+    _compare(sc, 20, "exact", ego_kernel=False)
+    _compare(sc, 20, "exact", ego_kernel=True)
+
+
+def test_chaining_off_and_idm_pools_fall_back_to_single_launches():
+    from tactics2d_amd import layout as L, scenarios as S
+    from tactics2d_amd.controller import IDMController, install
+    from tactics2d_amd.pool import ParticipantPool
+    sc = S.highway(24, 64, seed=3)
+    rng = np.random.default_rng(0)
+    a0, a1 = sc.sample_actions(rng)
+    outs = []
+    for mode in ("steps", "step_n", "step_n_unchained"):
+        pool = ParticipantPool(sc.n_env, sc.A)
+        sc.load(pool)
+        cid = np.full((sc.n_env, sc.A), L.IDM_NONE, np.uint8)
+        cid[:, 1:] = 0
+        install(pool, [IDMController(desired_speed=25.0, horizon=120.0)], cid.reshape(-1))
+        pool.set_actions(a0, a1)
+        if mode == "step_n_unchained":
+            pool.set_step_chaining(False)
+        if mode == "steps":
+            for _ in range(6):
+                pool.step(100)
+        else:
+            pool.step_n(6, 100, 0)
+        outs.append([pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_FLAGS, L.F_RECORD)])
+        pool.close()
+    for o in outs[1:]:
+        for g, w in zip(o, outs[0]):
+            assert np.array_equal(g, w)
+
+
+def test_chained_steps_at_the_metric_size():
+    """4096 x 64: 1024 workgroups per step = one wave-round of the GPU, so step k + 1's workgroups start as step k's retire"""
+    from tactics2d_amd import scenarios as S
+    sc = S.mixed(4096, 64, seed=3)
+    _compare(sc, 16, "fast")
