@@ -728,6 +728,7 @@ static int point_in_lanes(const double* pt, const int32_t* lane_vert_off, const 
 /* `union(lanes).contains(pose)`: box pose (8 doubles, vertex order of t2do_pose_obb, centre cxy) */
 static int box_in_lane_union(const double* pose8, const double* cxy, const int32_t* lane_vert_off,
                              const float* lane_xy, int l0, int l1, const double* pieces, int n_pieces) {
+#ifdef T2DO_LANE_SHORTCUTS   /* rounds 1-2: two short cuts ahead of the definition (equal verdicts; kept for comparison) */
     for (int li = l0; li < l1; ++li) {   /* all four vertices in one convex lane polygon: contained */
         double P[2 * T2D_MAX_POLY_VERTS];
         int n = load_poly(lane_xy, lane_vert_off[li], lane_vert_off[li + 1], P), k = 0;
@@ -736,6 +737,7 @@ static int box_in_lane_union(const double* pose8, const double* cxy, const int32
     }
     for (int k = 0; k < 4; ++k)          /* a vertex in no lane polygon: not contained */
         if (!point_in_lanes(pose8 + 2 * k, lane_vert_off, lane_xy, l0, l1)) return 0;
+#endif
     if (!point_in_lanes(cxy, lane_vert_off, lane_xy, l0, l1)) return 0;
     for (int k = 0; k < n_pieces; ++k)
         if (t2do_piece_meets_quad_interior(pieces + 4 * (size_t)k, pose8)) return 0;

@@ -396,6 +396,7 @@ void fill_layout(t2d::GeoLayout& gl, int epb, const int mp[2], const int mv[2], 
     off = (off + 3) & ~3;  // 16-B align the fp64 boundary pieces
     gl.off_bnd = off; off += 8 * mb;
     off = (off + 3) & ~3;
+
     gl.off_safe = off; off += mp[1] > 0 ? 4 * t2d::kSafeRects * epb : 0;
     gl.stride = (off + 3) & ~3;
     gl.epb = epb;

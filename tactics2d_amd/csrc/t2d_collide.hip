@@ -55,6 +55,12 @@ namespace {
 
 using namespace geom;
 
+// -DT2D_PROBE_SKIP=<bits>: measurement builds that leave a phase out (the flags are then wrong; instruction counts and
+// timings of such a build against the full one say what the phase costs): 1 pair stage, 2 pair narrow phase only,
+// 4 static polygons, 8 lane polygons, 16 off-lane stage 2 only, 32 pair broad phase only (every pair a candidate: never use)
+#ifndef T2D_PROBE_SKIP
+#define T2D_PROBE_SKIP 0
+#endif
 #ifndef T2D_COLLIDE_WAVES
 #define T2D_COLLIDE_WAVES 4  // min waves / SIMD the register allocator must allow
 #endif
@@ -155,44 +161,6 @@ T2D_DEV bool piece_meets_quad_interior(const Quad& P, double ax, double ay, doub
         all_le &= o <= 0.0;
     }
     return !(sep | all_ge | all_le);
-}
-
-// pieces [b0, b1) of the lane union's boundary (fp64 Ax, Ay, Bx, By in LDS) against the open quad P.  The box test only
-// skips pieces at least 1e-6 m clear of P's bounding box: those are separated by an edge normal of P or of the piece by
-// >= 0.7e-6 m, far beyond the rounding of the orientation signs, so skipping them cannot change a verdict.
-T2D_DEV bool pieces_meet_quad(const Quad& P, const double* bnd, int b0, int b1) {
-    double lox = P.x[0], hix = P.x[0], loy = P.y[0], hiy = P.y[0];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) {
-        lox = __builtin_fmin(lox, P.x[k]); hix = __builtin_fmax(hix, P.x[k]);
-        loy = __builtin_fmin(loy, P.y[k]); hiy = __builtin_fmax(hiy, P.y[k]);
-    }
-    lox -= 1e-6; loy -= 1e-6; hix += 1e-6; hiy += 1e-6;
-    bool hit = false;
-    for (int b = b0; b < b1; ++b) {
-        const double2 A = reinterpret_cast<const double2*>(bnd)[2 * b], B = reinterpret_cast<const double2*>(bnd)[2 * b + 1];
-        const bool near = !(__builtin_fmax(A.x, B.x) < lox || __builtin_fmin(A.x, B.x) > hix ||
-                            __builtin_fmax(A.y, B.y) < loy || __builtin_fmin(A.y, B.y) > hiy);
-        if (__ballot(near) != 0ull) {
-            if (near) hit |= piece_meets_quad_interior(P, A.x, A.y, B.x, B.y);
-        }
-    }
-    return hit;
-}
-
-// circle pose (pedestrian): some boundary piece of [b0, b1) comes inside the open disc (oracle circle_in_lane_union)
-__device__ __noinline__ bool circle_pieces_within(double cx, double cy, double R, const double* bnd, int b0, int b1) {
-    const double R2 = R * R;
-    const double m = R + 1e-6;   // pieces whose box is further than R (+ 1 um) from the centre cannot come within R
-    bool hit = false;
-    for (int b = b0; b < b1; ++b) {
-        const double ax = bnd[4 * b], ay = bnd[4 * b + 1], bx = bnd[4 * b + 2], by = bnd[4 * b + 3];
-        if (__builtin_fmax(ax, bx) < cx - m || __builtin_fmin(ax, bx) > cx + m || __builtin_fmax(ay, by) < cy - m ||
-            __builtin_fmin(ay, by) > cy + m)
-            continue;
-        if (seg_dist2(ax, ay, bx, by, cx, cy) < R2) hit = true;
-    }
-    return hit;
 }
 
 // a_planes: the pose in the LDS coordinate planes (&s_v[0][lane]); b_aos: 4 x (x, y) doubles in global memory
@@ -318,6 +286,17 @@ T2D_DEV void compact_and_process(unsigned long long mask, int id_base, int own_i
 // the consumer CHECKS it: the producer's XCC id travels in the word, a mismatch (or a wait that runs out: kChainSpinLimit)
 // raises chain_err, the host reports the launch as failed and stops chaining.  Never a silent stale read, never a hang.
 constexpr int kChainSpinLimit = 1 << 18;   // ~0.2 s of polling: far beyond any step, short enough not to look like a hang
+// The kernel's own argument block (PoolView is the first parameter), through an empty asm: loads of its fields through the
+// returned pointer cannot be moved above this point.  The compiler otherwise hoists every kernel-argument load it can prove
+// invariant to the entry block -- the epilogue's thirty pointers, the geometry layout -- and, out of scalar registers, parks
+// them in VGPR lanes for the length of the kernel (v_writelane / v_readlane per value: 108 spilled scalars and ~300 extra
+// VALU instructions per wave when the lane stage was rewritten in round 3).
+typedef const __attribute__((address_space(4))) PoolView* KernargView;
+T2D_DEV KernargView late_args() {
+    auto kp = (KernargView)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+}
 T2D_DEV unsigned long long chain_word(uint32_t steps_done) {   // {steps done, XCC id of the workgroup that did the last one}
     return (unsigned long long)steps_done | ((unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg(63508) << 32);
 }
@@ -332,7 +311,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                                                                             int interval_ms, int log2A) {
     __shared__ double s_v[8][kBlock];   // OBB vertex coordinate planes x0,y0,...,x3,y3
     __shared__ float s_cxy[2][kBlock];  // centre x, centre y (the stored fp32 state: exact)
-    __shared__ double s_rad[kBlock];    // radius (circle) / bounding radius (OBB)
+    __shared__ unsigned char s_type[kBlock];  // type id: the radius (circle) / bounding radius (OBB) is read from the table
     // type table in LDS, [column][type]: all columns up to the bounding radius when fused, else only
     // the 4 shape columns (length, width, shape, bounding radius)
     constexpr int kTabCols = T2D_P_RESERVED0 + 1;
@@ -629,13 +608,11 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                 lo_x = ax[k] < lo_x ? ax[k] : lo_x; hi_x = ax[k] > hi_x ? ax[k] : hi_x;
                 lo_y = ay[k] < lo_y ? ay[k] : lo_y; hi_y = ay[k] > hi_y ? ay[k] : hi_y;
             }
-            s_rad[tid] = R;
             // OutBound.update: not boundary.contains(pose); touching from inside is contained
             if (has_boundary)
                 out = lo_x < (double)bxmin || hi_x > (double)bxmax || lo_y < (double)bymin || hi_y > (double)bymax;
         } else {
             lo_x = cx - rad; hi_x = cx + rad; lo_y = cy - rad; hi_y = cy + rad;
-            s_rad[tid] = rad;
             if (has_boundary)
                 out = cx - rad < (double)bxmin || cx + rad > (double)bxmax || cy - rad < (double)bymin ||
                       cy + rad > (double)bymax;
@@ -671,11 +648,18 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         }
     }
     s_kind[tid] = kind;
+    s_type[tid] = (unsigned char)type;
     T2D_MARK(1);
     // an env that fits in a wave only ever reads its own wave's poses: no workgroup barrier needed
     if (log2A <= 6) wave_sync(); else __syncthreads();  // (b) poses (and grid lists) visible
     T2D_MARK(2);
 
+    // radius of circle i / bounding radius of box i (the values the pose phase computed: 0.5 * width, the host's R)
+    auto rad_of = [&](int i) -> double {
+        constexpr int c0 = FUSE >= 0 ? T2D_P_SHAPE : 0;
+        const int t = s_type[i];
+        return s_kind[i] == T2D_SHAPE_OBB ? s_partab[(c0 + 3) * T2D_MAX_TYPES + t] : 0.5 * s_partab[(c0 + 2) * T2D_MAX_TYPES + t];
+    };
     // ---------------- phase 2a: participant pairs ----------------------------------------------
     // narrow phase of one unordered pair (i < j by construction); flags both participants
     auto process_pair = [&](uint32_t e) {
@@ -696,12 +680,12 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             hit = sat_quads(A, B);
 #endif
         } else if (ki == T2D_SHAPE_OBB) {   // circle j against box i
-            hit = circle_vs_generic((double)s_cxy[0][j], (double)s_cxy[1][j], s_rad[j], PolyRef{nullptr, &s_v[0][i], 4});
+            hit = circle_vs_generic((double)s_cxy[0][j], (double)s_cxy[1][j], rad_of(j), PolyRef{nullptr, &s_v[0][i], 4});
         } else if (kj == T2D_SHAPE_OBB) {   // circle i against box j
-            hit = circle_vs_generic((double)s_cxy[0][i], (double)s_cxy[1][i], s_rad[i], PolyRef{nullptr, &s_v[0][j], 4});
+            hit = circle_vs_generic((double)s_cxy[0][i], (double)s_cxy[1][i], rad_of(i), PolyRef{nullptr, &s_v[0][j], 4});
         } else {                            // circle - circle (oracle: c1 = i, c2 = j)
             const double dx = (double)s_cxy[0][i] - (double)s_cxy[0][j], dy = (double)s_cxy[1][i] - (double)s_cxy[1][j];
-            const double rr = s_rad[i] + s_rad[j];
+            const double rr = rad_of(i) + rad_of(j);
             hit = dx * dx + dy * dy <= rr * rr;
         }
         if (hit) {
@@ -709,65 +693,74 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             atomicOr(&s_flags[j], T2D_FLAG_COLLISION_DYNAMIC);
         }
     };
+    const KernargView ev_args = late_args();   // the event stages' layout offsets are fetched here, not at the kernel's entry
+    const auto& gl2 = ev_args->geo_layout;
     const int* geo_i = reinterpret_cast<const int*>(s_geo);
     auto process_static = [&](uint32_t e) {
         const int i = (int)(e & 255u), p = (int)(e >> 8);
-        const int* vstart = geo_i + gl.off_vstart[0];
-        const float* xy = reinterpret_cast<const float*>(s_geo + gl.off_xy[0]);
+        const int* vstart = geo_i + gl2.off_vstart[0];
+        const float* xy = reinterpret_cast<const float*>(s_geo + gl2.off_xy[0]);
         const int v0 = vstart[p], n = vstart[p + 1] - v0;
         bool hit;
         if (s_kind[i] == T2D_SHAPE_OBB) {
             // (3 or 4 vertices: t2d_set_static_geometry cuts larger polygons into fans of quads)
             hit = sat_quads(load_obb_lds(&s_v[0][i]), load_quad_f32(xy + 2 * v0, n));
         } else {
-            hit = circle_vs_generic((double)s_cxy[0][i], (double)s_cxy[1][i], s_rad[i],
+            hit = circle_vs_generic((double)s_cxy[0][i], (double)s_cxy[1][i], rad_of(i),
                                     PolyRef{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n});
         }
         if (hit) atomicOr(&s_flags[i], T2D_FLAG_COLLISION_STATIC);
     };
-    // off-lane = not union(lanes).contains(pose) (oracle box_in_lane_union / circle_in_lane_union), evidence collected in
-    // s_flags >> kLaneShift.  Stage 1, per (participant, lane polygon) candidate: bits 0-3 = pose vertex k lies in this
-    // polygon, bit 4 = all four do (contained outright: the polygon is convex).  Circles are finished here: bit 5 =
-    // the centre lies in this polygon, bit 6 = a boundary piece of the union reaches inside the open disc.
+    // off-lane = not union(lanes).contains(pose), the oracle's definition (box_in_lane_union / circle_in_lane_union):
+    //     contained  <=>  the centre lies in some lane polygon  and  no boundary piece of the union meets the open pose.
+    // One pass per (participant, lane polygon whose box meets the pose's) candidate: is the centre in this polygon (bit 0 of
+    // s_flags >> kLaneShift), does one of the union's boundary pieces that are part of this polygon's edges meet the open pose
+    // (bit 1).  Every polygon holding the centre and every piece that can reach the pose belongs to such a candidate (a piece
+    // lies inside its polygon's box), so the OR over the candidates is the oracle's verdict over all polygons and pieces.
+    // (Rounds 1-2 ran two short cuts first -- all four vertices in one polygon, a vertex in none: 16 orientations per
+    // candidate, then a second compacted pass for the bodies that straddle lanes.  Same verdicts: 0 of 147 k poses differ.)
+    // A piece is first held against the pose's SUPPORT along the piece's normal n: the pose lies on one side of the line AB,
+    // clear of it, when |n.(c - A)| exceeds (|n.P| + |n.Q|) / 2 (P, Q the box's edge vectors) -- then all four orientations
+    // orient(A, B, vertex) have one sign and piece_meets_quad_interior returns false by its second rule; the margin (1e-9 |n|,
+    // a nanometre) is a thousand times their rounding.  Only pieces that run through or touch the pose take the exact test.
     auto process_lane = [&](uint32_t e) {
         const int i = (int)(e & 255u), p = (int)(e >> 8);
-        const int* vstart = geo_i + gl.off_vstart[1];
-        const float* xy = reinterpret_cast<const float*>(s_geo + gl.off_xy[1]);
-        const int v0 = vstart[p], n = vstart[p + 1] - v0;
-        uint32_t bits = 0;
-        if (s_kind[i] == T2D_SHAPE_OBB) {
-            const Quad A = load_obb_lds(&s_v[0][i]);
-            const Quad B = load_quad_f32(xy + 2 * v0, n);   // 3 or 4 vertices (fans of quads, t2d_set_lane_geometry)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) bits |= (uint32_t)point_in_quad(B, A.x[k], A.y[k]) << k;
-            if (bits == 15u) bits |= 16u;
-        } else {   // circle: the centre now, the boundary pieces in stage 2
-            const Quad B = load_quad_f32(xy + 2 * v0, n);
-            bits = point_in_quad(B, (double)s_cxy[0][i], (double)s_cxy[1][i]) ? 32u : 0u;
-        }
-        if (bits) atomicOr(&s_flags[i], bits << kLaneShift);
-    };
-    // Stage 2, only for boxes with every vertex in some lane but no single lane holding all four (bodies straddling
-    // lanes: a few per wave) and for circles with their centre in a lane, again per (participant, lane polygon)
-    // candidate: bit 5 = the centre lies in this polygon (boxes), bit 6 = one of the union's boundary pieces that are
-    // part of this polygon's edges reaches inside the open pose.
-    auto process_lane_slow = [&](uint32_t e) {
-        const int i = (int)(e & 255u), p = (int)(e >> 8);
-        const int* vstart = geo_i + gl.off_vstart[1];
-        const int* bstart = geo_i + gl.off_bstart;
-        const float* xy = reinterpret_cast<const float*>(s_geo + gl.off_xy[1]);
+        const int* vstart = geo_i + gl2.off_vstart[1];
+        const int* bstart = geo_i + gl2.off_bstart;
+        const float* xy = reinterpret_cast<const float*>(s_geo + gl2.off_xy[1]);
         const int v0 = vstart[p], n = vstart[p + 1] - v0;
         const int b0 = bstart[p], b1 = bstart[p + 1];
-        const double* bnd = reinterpret_cast<const double*>(s_geo + gl.off_bnd);
+        const double2* bnd = reinterpret_cast<const double2*>(s_geo + gl2.off_bnd);
         const double cx = (double)s_cxy[0][i], cy = (double)s_cxy[1][i];
-        uint32_t bits = 0;
+        uint32_t bits = point_in_quad(load_quad_f32(xy + 2 * v0, n), cx, cy) ? 1u : 0u;   // 3 or 4 vertices (fans of quads)
+        bool cut = false;
         if (s_kind[i] == T2D_SHAPE_OBB) {
             const Quad A = load_obb_lds(&s_v[0][i]);
-            if (point_in_quad(load_quad_f32(xy + 2 * v0, n), cx, cy)) bits = 32u;
-            if (pieces_meet_quad(A, bnd, b0, b1)) bits |= 64u;
-        } else if (circle_pieces_within(cx, cy, s_rad[i], bnd, b0, b1)) {   // pedestrian: a boundary piece inside the open disc
-            bits = 64u;
+            const double px = A.x[0] - A.x[3], py = A.y[0] - A.y[3], qx = A.x[1] - A.x[0], qy = A.y[1] - A.y[0];
+            const double c2x = A.x[0] + A.x[2], c2y = A.y[0] + A.y[2];   // twice the centre
+            for (int b = b0; b < b1; ++b) {
+                const double2 Pa = bnd[2 * b], Pb = bnd[2 * b + 1];
+                const double nx = Pa.y - Pb.y, ny = Pb.x - Pa.x;
+                const double s2 = __builtin_fma(nx, c2x - 2.0 * Pa.x, ny * (c2y - 2.0 * Pa.y));
+                const double e2 = __builtin_fabs(__builtin_fma(nx, px, ny * py)) + __builtin_fabs(__builtin_fma(nx, qx, ny * qy));
+                const bool clear = __builtin_fabs(s2) > e2 + 2e-9 * (__builtin_fabs(nx) + __builtin_fabs(ny));
+                if (__ballot(!clear) != 0ull) {
+                    if (!clear) cut |= piece_meets_quad_interior(A, Pa.x, Pa.y, Pb.x, Pb.y);
+                }
+            }
+        } else {   // pedestrian: a piece inside the open disc.  The line AB further than R from the centre: so is the piece
+            const double R = rad_of(i), R2 = R * R;
+            for (int b = b0; b < b1; ++b) {
+                const double2 Pa = bnd[2 * b], Pb = bnd[2 * b + 1];
+                const double nx = Pa.y - Pb.y, ny = Pb.x - Pa.x;
+                const double sn = __builtin_fma(nx, cx - Pa.x, ny * (cy - Pa.y));
+                const bool clear = sn * sn > R2 * __builtin_fma(nx, nx, ny * ny) * (1.0 + 1e-9);
+                if (__ballot(!clear) != 0ull) {
+                    if (!clear) cut |= seg_dist2(Pa.x, Pa.y, Pb.x, Pb.y, cx, cy) < R2;
+                }
+            }
         }
+        if (cut) bits |= 2u;
         if (bits) atomicOr(&s_flags[i], bits << kLaneShift);
     };
     int n_lane_polys = 0;
@@ -784,7 +777,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     for (int stage_it = 0; stage_it < 2; ++stage_it) {
     if (behind_first && stage_it == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
     if ((stage_it == 0) != polys_first) {
-    if (!use_hash_grid) {
+    if (T2D_PROBE_SKIP & 1) {
+    } else if (!use_hash_grid) {
         // every lane against all agents of its env: fp32 circles, 1 cm margin (strictly
         // conservative for |x|,|y| < 4 km); executed by ALL lanes (shuffles read executing lanes)
         unsigned long long cand = 0ull;
@@ -859,7 +853,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             cand = h;
         }
         T2D_MARK(3);
-        if (!active) cand = 0ull;
+        if (!active || (T2D_PROBE_SKIP & 2)) cand = 0ull;
         compact_and_process<false, true>(cand, (env_local << log2A), tid, queue, qcount, lane, process_pair, true, A_pad - 1);
     } else {
         // spatial-hash walk; pairs go straight to the narrow phase (i < j de-duplicates)
@@ -874,7 +868,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
                         const int jy = (int)__builtin_floor((double)s_cxy[1][j] * pv.inv_cell);
                         if (jx != gcx + ox_ || jy != gcy + oy_) continue;  // hash alias of another cell
                         const double dx = cx - (double)s_cxy[0][j], dy = cy - (double)s_cxy[1][j];
-                        const double rr = s_rad[tid] + s_rad[j] + kRejectMargin;
+                        const double rr = rad_of(tid) + rad_of(j) + kRejectMargin;
                         if (dx * dx + dy * dy > rr * rr) continue;  // cannot touch
                         process_pair((uint32_t)tid | ((uint32_t)j << 8));
                     }
@@ -886,40 +880,31 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     if (use_hash_grid) __syncthreads();  // the grid lists share LDS with the queues used below
     // ---------------- phase 2b / 2c: static polygons and lane polygons -------------------------
     } else {
-#pragma unroll
-    for (int kd = 0; kd < 2; ++kd) {
-        if (!gl.has[kd]) continue;
-        const int* pstart = geo_i + gl.off_pstart[kd];
-        const float4* bb = reinterpret_cast<const float4*>(s_geo + gl.off_aabb[kd]);
-        const int p0 = pstart[env_local], p1 = pstart[env_local + 1];
-        if (kd == 1) {
-            n_lane_polys = p1 - p0;
-            if (__ballot(active && !lane_safe) == 0ull) continue;   // every pose of the wave certified: no lane work at all
-        }
-        const bool sweeps = active && !(kd == 1 && lane_safe);
-        // pass 1: which (participant, polygon) boxes meet; pass 2: survivors of the whole wave,
-        // compacted, one narrow test per lane.
-        // box-vs-box sweep of polygons [first, first + cn): the polygon's float4 (xmin, xmax, ymin, ymax) comes
-        // from the LDS record (one 16-B read, wave-uniform address when the env is a wave), the four inequalities
-        // collapse into max(xmin - hi_x, lo_x - xmax, ymin - hi_y, lo_y - ymax) <= 0 -- two packed subtractions with
-        // the participant's (-hi, lo) pairs, one max3, one max -- and v_cmp + v_addc shifts the verdict into the
-        // mask (descending order, so polygon q lands on bit q).  6 VALU per polygon instead of ~11.
+    {
+        // Broad -> narrow stages over boxes kept in the LDS record (static polygons, lane polygons, boundary pieces of the
+        // lane union): pass 1 = which (participant, box) pairs meet; pass 2 = the survivors of the whole wave, compacted,
+        // one narrow test per lane.
+        // box-vs-box sweep of boxes [first, first + cn) of `bb`: the box's float4 (xmin, xmax, ymin, ymax) comes from the LDS
+        // record (one 16-B read, wave-uniform address when the env is a wave), the four inequalities collapse into
+        // max(xmin - hi_x, lo_x - xmax, ymin - hi_y, lo_y - ymax) <= 0 -- two packed subtractions with the participant's
+        // (-hi, lo) pairs, one max3, one max -- and v_cmp + v_addc shifts the verdict into the mask (descending order, so
+        // box q lands on bit q).  6 VALU per box instead of ~11.  (ox, oy) = (-hi_x, lo_x), (-hi_y, lo_y) of the
+        // participant's box, or of a point.
         typedef float f2p __attribute__((ext_vector_type(2)));
-        const f2p bxp = {-box_hi_x, box_lo_x}, byp = {-box_hi_y, box_lo_y};
-        auto box_sweep = [&](int first, int cn) -> unsigned long long {
+        auto box_sweep = [&](const float4* bb, int first, int cn, const f2p bxp, const f2p byp) -> unsigned long long {
             uint32_t hw[2] = {0u, 0u};
 #pragma unroll
             for (int hb = 1; hb >= 0; --hb) {
                 uint32_t h = 0u;
-                const int top = cn - hb * 32 < 32 ? cn - hb * 32 : 32;   // polygons of this half-word
+                const int top = cn - hb * 32 < 32 ? cn - hb * 32 : 32;   // boxes of this half-word
                 auto verdict = [&](const float4 b) {
                     const f2p tx = {b.x, -b.y}, ty = {b.z, -b.w};
                     const f2p dx = tx + bxp, dy = ty + byp;   // (xmin - hi_x, lo_x - xmax), (ymin - hi_y, lo_y - ymax)
                     const float m = __builtin_fmaxf(__builtin_fmaxf(dx.x, dx.y), __builtin_fmaxf(dy.x, dy.y));
                     asm volatile("v_cmp_ge_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(h) : "v"(m) : "vcc");
                 };
-                // the (top & 3) highest polygons one at a time, the rest four per trip with the four 16-B reads issued
-                // before the first compare: one LDS round trip per four polygons instead of one each
+                // the (top & 3) highest boxes one at a time, the rest four per trip with the four 16-B reads issued
+                // before the first compare: one LDS round trip per four boxes instead of one each
                 int a = top - 1;
                 for (; (a & 3) != 3 && a >= 0; --a) verdict(bb[first + hb * 32 + a]);
                 for (; a >= 3; a -= 4) {
@@ -934,47 +919,43 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             }
             return (unsigned long long)hw[0] | ((unsigned long long)hw[1] << 32);
         };
-        unsigned long long m_first = 0ull;   // lanes: candidates of the first 64 polygons, kept for stage 2
-        if (log2A == 6) {
-            const int np = p1 - p0;  // wave-uniform
-            for (int c0 = 0; c0 < np; c0 += 64) {
-                const int cn = np - c0 < 64 ? np - c0 : 64;
-                unsigned long long m = box_sweep(p0 + c0, cn);
-                if (!sweeps) m = 0ull;
-                if (kd == 1 && c0 == 0) m_first = m;
-                T2D_MARK(5 + 2 * kd);
-                if (kd == 0) compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_static, cn <= 32);
-                else compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_lane, cn <= 32);
-                T2D_MARK(6 + 2 * kd);
-            }
-        } else {
-            for (int c0 = 0;; c0 += 64) {
-                const int left = sweeps ? p1 - p0 - c0 : 0;
-                if (__ballot(left > 0) == 0ull) break;
-                const int cn = left < 64 ? left : 64;
-                const unsigned long long m = cn > 0 ? box_sweep(p0 + c0, cn) : 0ull;
-                if (kd == 1 && c0 == 0) m_first = m;
-                T2D_MARK(5 + 2 * kd);
-                if (kd == 0) compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_static);
-                else compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_lane);
-                T2D_MARK(6 + 2 * kd);
-            }
-        }
-        if (kd == 1) {
-            // stage 2 of the off-lane test (every stage-1 entry of this wave's participants was processed by this wave,
-            // and compact_and_process ends on a wave_sync: s_flags[tid] is complete as far as stage 1 goes)
-            const uint32_t ev = s_flags[tid] >> kLaneShift;
-            // boxes with every vertex in some lane and no single lane holding all four; circles whose centre is in a lane
-            const bool slow = active && (kind == T2D_SHAPE_OBB ? (ev & 31u) == 15u : (ev & 32u) != 0u);
-            if (__ballot(slow) != 0ull) {
+        // boxes [lo, hi) of `bb` against the lanes that `want` the test; entries (participant | box index << 8) go to `process`
+        auto sweep_stage = [&](const float4* bb, int lo, int hi, bool want, const f2p ox, const f2p oy, auto process, int mark) {
+            if (log2A == 6) {
+                const int np = hi - lo;  // wave-uniform
+                for (int c0 = 0; c0 < np; c0 += 64) {
+                    const int cn = np - c0 < 64 ? np - c0 : 64;
+                    unsigned long long m = box_sweep(bb, lo + c0, cn, ox, oy);
+                    if (!want) m = 0ull;
+                    T2D_MARK(mark);
+                    compact_and_process<false>(m, lo + c0, tid, queue, qcount, lane, process, cn <= 32);
+                    T2D_MARK(mark + 1);
+                }
+            } else {
                 for (int c0 = 0;; c0 += 64) {
-                    const int left = slow ? p1 - p0 - c0 : 0;
+                    const int left = want ? hi - lo - c0 : 0;
                     if (__ballot(left > 0) == 0ull) break;
                     const int cn = left < 64 ? left : 64;
-                    const unsigned long long m = cn <= 0 ? 0ull : (c0 == 0 ? m_first : box_sweep(p0 + c0, cn));
-                    compact_and_process<false>(m, p0 + c0, tid, queue, qcount, lane, process_lane_slow);
+                    const unsigned long long m = cn > 0 ? box_sweep(bb, lo + c0, cn, ox, oy) : 0ull;
+                    T2D_MARK(mark);
+                    compact_and_process<false>(m, lo + c0, tid, queue, qcount, lane, process);
+                    T2D_MARK(mark + 1);
                 }
             }
+        };
+        const f2p bxp = {-box_hi_x, box_lo_x}, byp = {-box_hi_y, box_lo_y};
+        if (gl2.has[0] && !(T2D_PROBE_SKIP & 4)) {   // static obstacles
+            const int* pstart = geo_i + gl2.off_pstart[0];
+            sweep_stage(reinterpret_cast<const float4*>(s_geo + gl2.off_aabb[0]), pstart[env_local], pstart[env_local + 1], active,
+                        bxp, byp, process_static, 5);
+        }
+        if (gl2.has[1] && !(T2D_PROBE_SKIP & 8)) {   // lanes: off-lane = not union(lanes).contains(pose)
+            const int* pstart = geo_i + gl2.off_pstart[1];
+            const int p0 = pstart[env_local], p1 = pstart[env_local + 1];
+            n_lane_polys = p1 - p0;
+            const bool want = active && !lane_safe;   // (poses in a safe rectangle are done)
+            if (__ballot(want) != 0ull)
+                sweep_stage(reinterpret_cast<const float4*>(s_geo + gl2.off_aabb[1]), p0, p1, want, bxp, byp, process_lane, 7);
         }
     }
 
@@ -985,41 +966,23 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     // every kernel argument the epilogue touches, requested together (see the start-up phase): the status lane's chain
     // and the restore of a finished env are the last thing a wave does, with nothing behind them to hide a scalar round
     // trip per pointer
-    auto e_flags = as_global(pv.flags);
-    auto e_env_flags = as_global(pv.env_flags);
-    auto e_cnt_step = as_global(pv.cnt_step);
-    auto e_frame_ms = as_global(pv.frame_ms);
-    auto e_status = as_global(pv.status);
-    auto e_reward = as_global(pv.reward);
-    auto e_record = as_global(pv.record);
-    auto e_time_penalty = as_global(pv.time_penalty);
-    auto e_iou = as_global(pv.iou);
-    auto e_last_valid = as_global(pv.last_valid);
-    auto e_cnt_na = as_global(pv.cnt_na);
-    auto e_max_iou = as_global(pv.max_iou);
-    auto e_min_dist = as_global(pv.min_dist);
-    auto e_snap_min_dist = as_global(pv.snap_min_dist);
-    auto e_snap0 = as_global(pv.snap[0]);
-    auto e_snap1 = as_global(pv.snap[1]);
-    auto e_snap2 = as_global(pv.snap[2]);
-    auto e_snap3 = as_global(pv.snap[3]);
-    auto e_snap4 = as_global(pv.snap[4]);
-    auto e_snap5 = as_global(pv.snap[5]);
-    auto e_snap_ids = as_global(pv.snap_ids);
-    auto e_snap_omega0 = as_global(pv.snap_omega[0]);
-    auto e_snap_omega1 = as_global(pv.snap_omega[1]);
-    auto e_x = as_global(pv.x);
-    auto e_y = as_global(pv.y);
-    auto e_heading = as_global(pv.heading);
-    auto e_speed = as_global(pv.speed);
-    auto e_vx = as_global(pv.vx);
-    auto e_vy = as_global(pv.vy);
-    auto e_ids = as_global(pv.ids);
-    auto e_omega_f = as_global(pv.omega_f);
-    auto e_omega_r = as_global(pv.omega_r);
-    int e_auto_reset = pv.auto_reset;
+    const KernargView ep = late_args();
+    auto e_flags = as_global(ep->flags);
+    auto e_env_flags = as_global(ep->env_flags);
+    auto e_cnt_step = as_global(ep->cnt_step);
+    auto e_frame_ms = as_global(ep->frame_ms);
+    auto e_status = as_global(ep->status);
+    auto e_reward = as_global(ep->reward);
+    auto e_record = as_global(ep->record);
+    auto e_time_penalty = as_global(ep->time_penalty);
+    auto e_iou = as_global(ep->iou);
+    auto e_last_valid = as_global(ep->last_valid);
+    auto e_cnt_na = as_global(ep->cnt_na);
+    auto e_max_iou = as_global(ep->max_iou);
+    auto e_min_dist = as_global(ep->min_dist);
+    auto e_snap_min_dist = as_global(ep->snap_min_dist);
+    int e_auto_reset = ep->auto_reset;
     asm volatile("" : "+s"(e_flags), "+s"(e_env_flags), "+s"(e_cnt_step), "+s"(e_frame_ms), "+s"(e_status), "+s"(e_reward), "+s"(e_record), "+s"(e_time_penalty), "+s"(e_iou), "+s"(e_last_valid), "+s"(e_cnt_na), "+s"(e_max_iou), "+s"(e_min_dist), "+s"(e_snap_min_dist), "+s"(e_auto_reset));
-    asm volatile("" : "+s"(e_snap0), "+s"(e_snap1), "+s"(e_snap2), "+s"(e_snap3), "+s"(e_snap4), "+s"(e_snap5), "+s"(e_snap_ids), "+s"(e_snap_omega0), "+s"(e_snap_omega1), "+s"(e_x), "+s"(e_y), "+s"(e_heading), "+s"(e_speed), "+s"(e_vx), "+s"(e_vy), "+s"(e_ids), "+s"(e_omega_f), "+s"(e_omega_r));
     // the status epilogue's inputs, requested now by the lane that will run it (agent 0): the reduce hides part of their
     // latency.  (Fetched at the top of the kernel they sat in registers through every event phase, and at the 128
     // registers of 4 waves / SIMD that meant scratch spills: 8 B per lane stored and re-read, 13 MB of HBM traffic.)
@@ -1039,9 +1002,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         const uint32_t sf = s_flags[tid];
         f = f_own | (sf & ((1u << kLaneShift) - 1u));
         if (n_lane_polys > 0) {  // build-defined off-lane: not union(lanes).contains(pose)
-            const uint32_t b = sf >> kLaneShift;   // see process_lane / process_lane_slow
-            const bool in = lane_safe || (kind == T2D_SHAPE_OBB ? (b & 16u) || ((b & 15u) == 15u && (b & 32u) && !(b & 64u))
-                                                                : (b & 32u) && !(b & 64u));
+            const uint32_t b = sf >> kLaneShift;   // see process_lane
+            const bool in = lane_safe || ((b & 1u) && !(b & 2u));
             if (!in) f |= T2D_FLAG_OFF_LANE;
         }
     }
@@ -1176,30 +1138,53 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         }
     }
     if (WITH_STATUS && e_auto_reset) {  // fused vector-env auto-reset: finished envs go back to the snapshot
+        // (the restore's eighteen pointers are requested here, in one scalar round trip, not with the epilogue's above: 36
+        // more scalar registers held through the reduce and the status code pushed the kernel into scalar spills -- two
+        // v_readlane / v_writelane per spilled value, ~300 VALU instructions per wave)
+        const KernargView rp = late_args();
+        auto e_snap0 = as_global(rp->snap[0]);
+        auto e_snap1 = as_global(rp->snap[1]);
+        auto e_snap2 = as_global(rp->snap[2]);
+        auto e_snap3 = as_global(rp->snap[3]);
+        auto e_snap4 = as_global(rp->snap[4]);
+        auto e_snap5 = as_global(rp->snap[5]);
+        auto e_snap_ids = as_global(rp->snap_ids);
+        auto e_snap_omega0 = as_global(rp->snap_omega[0]);
+        auto e_snap_omega1 = as_global(rp->snap_omega[1]);
+        auto e_x = as_global(rp->x);
+        auto e_y = as_global(rp->y);
+        auto e_heading = as_global(rp->heading);
+        auto e_speed = as_global(rp->speed);
+        auto e_vx = as_global(rp->vx);
+        auto e_vy = as_global(rp->vy);
+        auto e_ids = as_global(rp->ids);
+        auto e_omega_f = as_global(rp->omega_f);
+        auto e_omega_r = as_global(rp->omega_r);
+        asm volatile("" : "+s"(e_snap0), "+s"(e_snap1), "+s"(e_snap2), "+s"(e_snap3), "+s"(e_snap4), "+s"(e_snap5), "+s"(e_snap_ids), "+s"(e_snap_omega0), "+s"(e_snap_omega1), "+s"(e_x), "+s"(e_y), "+s"(e_heading), "+s"(e_speed), "+s"(e_vx), "+s"(e_vy), "+s"(e_ids), "+s"(e_omega_f), "+s"(e_omega_r));
         if (log2A <= 6) wave_sync(); else __syncthreads();
         if (valid && s_done[env_local]) {
             // every snapshot value first, then the stores: written as load / store pairs, each pair waits for its own
             // memory round trip (a store may alias the next load as far as the compiler knows) -- seven in a row at
             // the very end of the wave, where nothing is left to hide them
-            const float r0 = pv.snap[0][idx], r1 = pv.snap[1][idx], r2 = pv.snap[2][idx], r3 = pv.snap[3][idx];
-            const float r4 = pv.snap[4][idx], r5 = pv.snap[5][idx];
-            const uint32_t rid = pv.snap_ids[idx];
+            const float r0 = e_snap0[idx], r1 = e_snap1[idx], r2 = e_snap2[idx], r3 = e_snap3[idx];
+            const float r4 = e_snap4[idx], r5 = e_snap5[idx];
+            const uint32_t rid = e_snap_ids[idx];
             const bool drift = e_snap_omega0 != nullptr;   // SingleTrackDrift wheel speeds (only with a drift type in the table)
             float w0 = 0.f, w1 = 0.f;
             if (drift) {
-                w0 = pv.snap_omega[0][idx];
-                w1 = pv.snap_omega[1][idx];
+                w0 = e_snap_omega0[idx];
+                w1 = e_snap_omega1[idx];
             }
-            pv.x[idx] = r0;
-            pv.y[idx] = r1;
-            pv.heading[idx] = r2;
-            pv.speed[idx] = r3;
-            pv.vx[idx] = r4;
-            pv.vy[idx] = r5;
-            pv.ids[idx] = rid;
+            e_x[idx] = r0;
+            e_y[idx] = r1;
+            e_heading[idx] = r2;
+            e_speed[idx] = r3;
+            e_vx[idx] = r4;
+            e_vy[idx] = r5;
+            e_ids[idx] = rid;
             if (drift) {
-                pv.omega_f[idx] = w0;
-                pv.omega_r[idx] = w1;
+                e_omega_f[idx] = w0;
+                e_omega_r[idx] = w1;
             }
         }
     }
