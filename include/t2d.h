@@ -485,6 +485,13 @@ int t2d_profile_read(t2d_pool* pool, int32_t kernel_id, double* total_ms, int64_
 int t2d_comm_unique_id(uint8_t* id_out);
 int t2d_comm_init(t2d_pool* pool, const uint8_t* id, int32_t rank, int32_t world);
 int t2d_gather(t2d_pool* pool, void* nccl_comm, int32_t n_steps, void* out_dev, void* hip_stream);
+/* What the pool's communicator is: native_rccl = 1 when t2d_comm_init created an RCCL communicator (0: none, or the
+ * RCCL-free world of one), world / rank read back FROM that communicator (ncclCommCount / ncclCommUserRank) -- the proof
+ * a multi-GPU run can print that RCCL saw N ranks.  Any pointer may be NULL.                                        */
+int t2d_comm_info(t2d_pool* pool, int32_t* native_rccl, int32_t* world, int32_t* rank);
+/* t2d_step / t2d_check_status calls so far (t2d_step_n counts n): the step count t2d_gather's n_steps must divide, and the
+ * record-ring slot of the next step (count % T2D_RECORD_RING).  -1 for a null pool.                                   */
+int64_t t2d_step_count(const t2d_pool* pool);
 int t2d_gather_wait(t2d_pool* pool, void* hip_stream, int32_t block_host);
 
 /* Introspection: resident workgroups per CU of the fused step kernel with this pool's geometry, its LDS bytes per

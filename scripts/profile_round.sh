@@ -1,18 +1,33 @@
 #!/bin/bash
-# Round profile: kernel-trace stats of the default bench + HBM traffic counters in separate PMC
-# passes (never combined with sys/hip tracing).  Usage on the GPU box: bash scripts/profile_round.sh r01
-TAG=${1:-r01}
+# Round profile of the headline bench (both step modes): rocprofv3 kernel-trace stats + HBM traffic and SQ counters in
+# separate PMC passes (never combined with sys/hip tracing) + the calibration of FETCH_SIZE / WRITE_SIZE, then kernel-trace
+# summaries of cfg3 / cfg4 / cfg5 and kernel-trace + SQ passes of the next rows' kernels (ego step, lidar, IDM, scene commit).
+# Usage on the GPU box: bash scripts/profile_round.sh r03a     -> gpurun_out/<tag>_*.json / .csv (copy to profiles/)
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-# --groups 1 = the headline configuration only (the default run appends the 4-group pipelined measurement, whose
-# quarter-size launches of the same kernel would otherwise be averaged into the same kernel-stats row)
-BENCH="python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-configs --groups 1"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- $BENCH > $OUT/bench_trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o bench -- $BENCH --no-profile > $OUT/bench_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o bench -- $BENCH --no-profile > $OUT/bench_write.log 2>&1
+COMMON="--steps 1024 --warmup 128 --no-cpu-baseline --no-configs --no-next-rows --no-alternates"
+SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU"
+for MODE in chain step; do
+  BENCH="python bench.py --mode $MODE $COMMON"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$MODE -o bench -- $BENCH > $OUT/bench_trace_$MODE.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_$MODE -o bench -- $BENCH --no-profile > $OUT/bench_fetch_$MODE.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write_$MODE -o bench -- $BENCH --no-profile > $OUT/bench_write_$MODE.log 2>&1
+  # (the SQ_WAIT_* counters slow the kernel by ~20 %: not collected with the ones ratios are taken from)
+  rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/sq_$MODE -o bench -- $BENCH --no-profile > $OUT/bench_sq_$MODE.log 2>&1
+done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -o cal -- python scripts/calib_traffic.py > $OUT/cal_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -o cal -- python scripts/calib_traffic.py > $OUT/cal_write.log 2>&1
-# (the SQ_WAIT_* counters slow the kernel by ~20 %: not collected with the ones ratios are taken from)
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/sq -o bench -- $BENCH --no-profile > $OUT/bench_sq.log 2>&1
+# the other BASELINE.json configurations (per-GPU shards), kernel time per config
+for CFG in cfg2 cfg3 cfg4 cfg5; do
+  for MODE in chain step; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${CFG}_$MODE -o bench -- python bench.py --config $CFG --mode $MODE --steps 512 --warmup 64 --no-cpu-baseline --no-profile --no-alternates > $OUT/${CFG}_$MODE.log 2>&1
+  done
+done
+# next rows: kernel-trace, then an SQ pass (VALU busy, instructions per wave) of the same commands
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/vec -o vec -- python scripts/time_vec_env.py 4096 > $OUT/vec.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/idm -o idm -- python scripts/time_idm.py 4096 > $OUT/idm.log 2>&1
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/vec_sq -o vec -- python scripts/time_vec_env.py 4096 short > $OUT/vec_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/idm_sq -o idm -- python scripts/time_idm.py 4096 short > $OUT/idm_sq.log 2>&1
 python scripts/summarize_profile.py $OUT $TAG

@@ -1,8 +1,12 @@
-"""Condense the rocprofv3 CSVs of scripts/profile_round.sh into profiles/<tag>_summary.{json,md}."""
-import collections, csv, glob, json, os, sys
+"""Condense the rocprofv3 CSVs of scripts/profile_round.sh into gpurun_out/<tag>_summary.json, <tag>_kernel_stats.csv,
+<tag>_configs.json, <tag>_next_rows.json and <tag>_traffic_latest.json (copy to profiles/; bench.py reads
+profiles/traffic_latest.json and trusts it only for the sources whose hash it records)."""
+import collections, csv, glob, json, os, re, sys
 
 out, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from tactics2d_amd import build as B
 
 
 def find(d, suffix):
@@ -11,84 +15,162 @@ def find(d, suffix):
 
 
 def short(name):
-    if "collide_kernel" in name:   # collide_kernel<WITH_STATUS, FUSE, IOU>: FUSE >= 0 is the fused step launch
-        return "collide_kernel" if ",-1" in name.replace(" ", "") else "step_kernel"
-    for k in ("integrate_kernel", "restore_env_kernel", "restore_kernel"):
-        if k in name:
+    """collide_kernel<WITH_STATUS, FUSE, IOU, CHAIN>: FUSE >= 0 is the fused step launch, CHAIN the multi-step launch"""
+    n = name.replace(" ", "")
+    m = re.search(r"collide_kernel<([^>]*)>", n)
+    if m:
+        a = m.group(1).split(",")
+        if a[1] == "-1":
+            return "collide_kernel"
+        return "step_kernel_chained" if len(a) > 3 and a[3] == "true" else "step_kernel"
+    for k in ("ego_step_kernel", "lidar_kernel", "idm_kernel", "parking_scene_kernel", "scene_refill_kernel", "integrate_kernel",
+              "restore_env_kernel", "restore_kernel", "drift_kernel"):
+        if k in n:
             return k
     return name[:40]
 
 
-summary = {"tag": tag, "command": "python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-configs --groups 1"}
-f = find("trace", "kernel_trace.csv")
-if f:
-    d = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        d[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    summary["kernel_trace"] = {k: dict(calls=len(v), avg_us=sum(v) / len(v) / 1e3, min_us=min(v) / 1e3,
-                                       max_us=max(v) / 1e3, total_ms=sum(v) / 1e6) for k, v in d.items()}
-f = find("trace", "kernel_stats.csv")
-if f:
-    summary["kernel_stats_csv"] = open(f).read()
+def steps_of(row, per_step_items):
+    g = int(row.get("Grid_Size", 0) or 0)
+    return max(1, round(g / per_step_items)) if per_step_items else 1
 
 
-def counter(d, name):
-    f = find(d, "counter_collection.csv")
-    res = collections.defaultdict(list)
-    if f:
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == name:
-                res[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in res.items()}
-
-
-fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
-cf, cw = counter("cal_fetch", "FETCH_SIZE"), counter("cal_write", "WRITE_SIZE")
-N = 4096 * 64
-known_r, known_w = 7 * 4 * N, 8 * 4 * N
-cal = {}
-if "restore_kernel" in cf:
-    cal["fetch_kb_reported"] = cf["restore_kernel"]; cal["fetch_factor"] = known_r / (cf["restore_kernel"] * 1024)
-if "restore_kernel" in cw:
-    cal["write_kb_reported"] = cw["restore_kernel"]; cal["write_factor"] = known_w / (cw["restore_kernel"] * 1024)
-summary["traffic_calibration"] = dict(known_read_bytes=known_r, known_write_bytes=known_w, **cal,
-                                      note="restore_kernel (mode 0) streams a known byte count with the "
-                                           "integrator's 4-B/lane pattern; factor = known / (counter KB * 1024)")
-traffic = {}
-for k in set(fetch) | set(write):
-    fb = fetch.get(k, 0) * 1024 * cal.get("fetch_factor", 1.0)
-    wb = write.get(k, 0) * 1024 * cal.get("write_factor", 1.0)
-    traffic[k] = dict(fetch_kb_raw=fetch.get(k), write_kb_raw=write.get(k), hbm_bytes_corrected=fb + wb)
-summary["traffic"] = traffic
-sq = {}
-f = find("sq", "counter_collection.csv")
-if f:
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for r in csv.DictReader(open(f)):
-        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    sq = {k: {c: sum(x) / len(x) for c, x in v.items()} for k, v in agg.items() if "kernel" in k}
-summary["sq_counters_per_dispatch"] = sq
-for log in ("bench_trace.log",):
-    p = os.path.join(out, log)
+bench_json = {}
+for mode in ("chain", "step"):
+    p = os.path.join(out, f"bench_trace_{mode}.log")
     if os.path.exists(p):
         lines = [l for l in open(p) if l.startswith("{")]
         if lines:
-            summary["bench_json"] = json.loads(lines[-1])
+            bench_json[mode] = json.loads(lines[-1])
+cfg = (bench_json.get("chain") or bench_json.get("step") or {}).get("config", {})
+n_env, agents = cfg.get("envs_per_gpu", 4096), cfg.get("participants_per_env", 64)
+log2A = max(1, (agents - 1).bit_length())
+epb = 256 >> log2A
+per_step_items = (((n_env + epb - 1) // epb + 7) & ~7) * 256    # work-items of one step in a chained launch
+
+summary = {"tag": tag, "source_sha256": B.source_hash(),
+           "commands": {m: f"python bench.py --mode {m} --steps 1024 --warmup 128 --no-cpu-baseline --no-configs --no-next-rows --no-alternates" for m in ("chain", "step")}}
+stats_csv = []
+kt = {}
+for mode in ("chain", "step"):
+    f = find(f"trace_{mode}", "kernel_trace.csv")
+    if f:
+        d = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            steps = 1
+            if k == "step_kernel_chained":
+                steps = max(1, int(r["Grid_Size_Y"]) // max(1, int(r["Workgroup_Size_Y"])))
+            d[k].append(((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, steps))
+        kt[mode] = {k: dict(calls=len(v), avg_us=sum(x for x, _ in v) / len(v), steps_per_launch=sum(s for _, s in v) / len(v),
+                            avg_us_per_step=sum(x for x, _ in v) / sum(s for _, s in v), min_us=min(x for x, _ in v),
+                            max_us=max(x for x, _ in v)) for k, v in d.items()}
+    f = find(f"trace_{mode}", "kernel_stats.csv")
+    if f:
+        stats_csv.append(f"# --mode {mode}\n" + open(f).read())
+summary["kernel_trace"] = kt
+
+
+def counters(d, names=None):
+    """per kernel: counter -> average per STEP (a chained launch is divided by the steps it holds)"""
+    f = find(d, "counter_collection.csv")
+    res = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    if f:
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if names and r["Counter_Name"] not in names:
+                continue
+            s = steps_of(r, per_step_items) if k == "step_kernel_chained" else 1
+            a = res[k][r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"]); a[1] += s
+    return {k: {c: v[0] / v[1] for c, v in cs.items() if v[1]} for k, cs in res.items()}
+
+
+cf, cw = counters("cal_fetch").get("restore_kernel", {}).get("FETCH_SIZE"), counters("cal_write").get("restore_kernel", {}).get("WRITE_SIZE")
+N = 4096 * 64
+known_r, known_w = 7 * 4 * N, 8 * 4 * N
+cal = {}
+if cf:
+    cal["fetch_kb_reported"] = cf; cal["fetch_factor"] = known_r / (cf * 1024)
+if cw:
+    cal["write_kb_reported"] = cw; cal["write_factor"] = known_w / (cw * 1024)
+summary["traffic_calibration"] = dict(known_read_bytes=known_r, known_write_bytes=known_w, **cal,
+                                      note="restore_kernel (mode 0) streams a known byte count with the integrator's 4-B/lane "
+                                           "pattern; factor = known / (counter KB * 1024)")
+traffic, sq = {}, {}
+for mode in ("chain", "step"):
+    fe, wr = counters(f"fetch_{mode}"), counters(f"write_{mode}")
+    for k in set(fe) | set(wr):
+        if "step_kernel" not in k:
+            continue
+        fb = fe.get(k, {}).get("FETCH_SIZE", 0) * 1024 * cal.get("fetch_factor", 1.0)
+        wb = wr.get(k, {}).get("WRITE_SIZE", 0) * 1024 * cal.get("write_factor", 1.0)
+        traffic[k] = dict(fetch_bytes_per_step=fb, write_bytes_per_step=wb, hbm_bytes_per_step=fb + wb)
+    for k, v in counters(f"sq_{mode}").items():
+        if "step_kernel" in k:
+            sq[k] = v
+summary["traffic_per_step"] = traffic
+summary["sq_counters_per_step"] = sq
+summary["bench_json"] = bench_json
+for k, v in sq.items():
+    if v.get("SQ_WAVES"):
+        v["_per_wave"] = {c[3:]: v[c] / v["SQ_WAVES"] for c in v if c.startswith("SQ_INSTS")}
+        if v.get("SQ_BUSY_CYCLES"):   # SQ_BUSY_CYCLES is summed over 8 XCDs x 4 SEs; SQ_ACTIVE_INST_* count quad-cycles
+            v["_valu_busy_frac"] = 4.0 * v.get("SQ_ACTIVE_INST_VALU", 0) / (256 * 4 * v["SQ_BUSY_CYCLES"] / 32.0)
 os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
 json.dump(summary, open(os.path.join(root, "gpurun_out", f"{tag}_summary.json"), "w"), indent=1)
-if "kernel_stats_csv" in summary:
-    open(os.path.join(root, "gpurun_out", f"{tag}_kernel_stats.csv"), "w").write(summary["kernel_stats_csv"])
+open(os.path.join(root, "gpurun_out", f"{tag}_kernel_stats.csv"), "w").write("\n".join(stats_csv))
+
+# the other configurations: kernel time per step and per config
+cfgs = {}
+for c in ("cfg2", "cfg3", "cfg4", "cfg5"):
+    for mode in ("chain", "step"):
+        f = find(f"{c}_{mode}", "kernel_trace.csv")
+        if not f:
+            continue
+        d = collections.defaultdict(lambda: [0.0, 0, 0])
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if "kernel" not in k or "rocclr" in k:
+                continue
+            steps = max(1, int(r["Grid_Size_Y"]) // max(1, int(r["Workgroup_Size_Y"]))) if k == "step_kernel_chained" else 1
+            a = d[k]; a[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; a[1] += 1; a[2] += steps
+        line = [l for l in open(os.path.join(out, f"{c}_{mode}.log")) if l.startswith("{")]
+        cfgs.setdefault(c, {})[mode] = dict(kernels={k: dict(calls=v[1], avg_us=v[0] / v[1], avg_us_per_step=v[0] / v[2]) for k, v in d.items()},
+                                            bench_us_per_step=(1e3 * json.loads(line[-1])["ms_per_step"] if line else None))
+json.dump(dict(tag=tag, source_sha256=summary["source_sha256"], note="rocprofv3 --kernel-trace of python bench.py --config <cfg> --mode <mode> "
+               "--steps 512 --warmup 64: kernel time per launch and per step next to the bench's own wall time per step", configs=cfgs),
+          open(os.path.join(root, "gpurun_out", f"{tag}_configs.json"), "w"), indent=1)
+
+# next rows: kernel-trace durations + SQ counters per dispatch
+nxt = {"tag": tag, "source_sha256": summary["source_sha256"],
+       "note": "rocprofv3 --kernel-trace --stats, then an SQ pass of the same command at 4096 envs; durations in us, counters per dispatch"}
+for name, cmd in (("vec", "python scripts/time_vec_env.py 4096"), ("idm", "python scripts/time_idm.py 4096")):
+    rows = {}
+    f = find(name, "kernel_stats.csv")
+    if f:
+        for r in csv.DictReader(open(f)):
+            rows[short(r["Name"])] = dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3, min_us=float(r["MinNs"]) / 1e3, max_us=float(r["MaxNs"]) / 1e3)
+    sqn = {}
+    for k, v in counters(name + "_sq").items():
+        if v.get("SQ_WAVES") and ("kernel" in k) and "rocclr" not in k:
+            sqn[k] = dict(waves=v["SQ_WAVES"], valu_per_wave=v.get("SQ_INSTS_VALU", 0) / v["SQ_WAVES"], salu_per_wave=v.get("SQ_INSTS_SALU", 0) / v["SQ_WAVES"],
+                          lds_per_wave=v.get("SQ_INSTS_LDS", 0) / v["SQ_WAVES"], insts_per_wave=v.get("SQ_INSTS", 0) / v["SQ_WAVES"],
+                          valu_busy_frac=(4.0 * v.get("SQ_ACTIVE_INST_VALU", 0) / (256 * 4 * v["SQ_BUSY_CYCLES"] / 32.0) if v.get("SQ_BUSY_CYCLES") else None))
+    log = os.path.join(out, name + ".log")
+    nxt[name] = dict(command=cmd, kernel_stats=rows, sq=sqn, stdout=open(log).read()[-1200:] if os.path.exists(log) else None)
+json.dump(nxt, open(os.path.join(root, "gpurun_out", f"{tag}_next_rows.json"), "w"), indent=1)
+
 # what bench.py reads for roofline.traffic / the VALU-issue roofline (PMC counters cannot be read in-process)
-bj = summary.get("bench_json", {}).get("config", {})
-latest = dict(tag=tag, config=bj.get("config", "metric"), envs_per_gpu=bj.get("envs_per_gpu", 4096),
-              participants_per_env=bj.get("participants_per_env", 64), groups=bj.get("env_groups", 1),
-              hbm_bytes_per_launch={k: v["hbm_bytes_corrected"] for k, v in traffic.items() if "kernel" in k},
+latest = dict(tag=tag, source_sha256=summary["source_sha256"], config=cfg.get("config", "metric"), envs_per_gpu=n_env, participants_per_env=agents,
+              hbm_bytes_per_step={k: v["hbm_bytes_per_step"] for k, v in traffic.items()},
               fetch_factor=cal.get("fetch_factor"), write_factor=cal.get("write_factor"),
               source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (scripts/profile_round.sh); FETCH_SIZE "
-                     "and WRITE_SIZE scaled by the factors calibrated on restore_kernel's known byte count (same 4-B/lane pattern)",
-              sq_counters_per_dispatch=sq,
-              sq_source="rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES "
-                        "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY pass of the headline command; SQ_ACTIVE_INST_* count quad-cycles",
-              kernel_trace_avg_us={k: v["avg_us"] for k, v in summary.get("kernel_trace", {}).items()})
+                     "and WRITE_SIZE scaled by the factors calibrated on restore_kernel's known byte count (same 4-B/lane pattern); "
+                     "per step: a chained launch's counters are divided by the steps it holds",
+              sq_counters_per_step={k: {c: x for c, x in v.items() if not c.startswith("_")} for k, v in sq.items()},
+              sq_source="rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS SQ_WAVE_CYCLES SQ_BUSY_CYCLES "
+                        "SQ_ACTIVE_INST_VALU pass of the headline command in each step mode; SQ_ACTIVE_INST_* count quad-cycles",
+              kernel_trace_avg_us_per_step={m: {k: v["avg_us_per_step"] for k, v in d.items()} for m, d in kt.items()})
 json.dump(latest, open(os.path.join(root, "gpurun_out", f"{tag}_traffic_latest.json"), "w"), indent=1)
-print(json.dumps({k: summary[k] for k in ("kernel_trace", "traffic_calibration", "traffic") if k in summary}, indent=1)[:3000])
+print(json.dumps(dict(kernel_trace=kt, traffic=traffic, sq={k: v.get("_per_wave") for k, v in sq.items()}, cal=cal), indent=1)[:4000])

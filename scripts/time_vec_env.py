@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tactics2d_amd.envs import VecParkingEnv
 dev = torch.device("cuda", 0)
-for n, source in ((4096, "layout"), (4096, "generator"), (32768, "layout"), (32768, "generator")):
+sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [4096, 32768]
+short = "short" in sys.argv   # counter passes: a few dozen steps are enough
+for n, source in [(n_, s_) for n_ in sizes for s_ in ("layout", "generator")]:
     # "layout": fixed bay layout, finished episodes restart from the snapshot; "generator": ParkingLotGenerator scenes
     # installed on the device, every finished episode continues in a new scene (staged ahead on the pool's stream)
     env = VecParkingEnv(n, max_step=200, auto_reset=True, seed=1, scene_source=source); env.reset()
@@ -13,7 +15,7 @@ for n, source in ((4096, "layout"), (4096, "generator"), (32768, "layout"), (327
     acts = [lo + (hi - lo) * torch.rand((n, 2), device=dev) for _ in range(8)]
     for k in range(50): out = env.step_torch(acts[k & 7])
     torch.cuda.synchronize()
-    t = time.perf_counter(); steps = 500
+    t = time.perf_counter(); steps = 40 if short else 500
     for k in range(steps): out = env.step_torch(acts[k & 7])
     torch.cuda.synchronize()
     el = time.perf_counter() - t

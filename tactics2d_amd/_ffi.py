@@ -87,6 +87,8 @@ SYMBOLS = {
     "t2d_comm_init": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32]),
     "t2d_gather": (C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
     "t2d_gather_wait": (C.c_int, [_vp, _vp, C.c_int32]),
+    "t2d_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "t2d_step_count": (C.c_int64, [_vp]),
     # introspection
     "t2d_debug_set_step_placement": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.c_int32]),
     "t2d_debug_step_occupancy": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

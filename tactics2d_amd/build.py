@@ -19,6 +19,17 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
+def source_hash():
+    """sha256 over the kernel sources, headers and build flags: what a counter pass (profiles/traffic_latest.json) was taken
+    of.  bench.py compares it with the tree it runs from and marks the instruction counts stale when they differ."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True

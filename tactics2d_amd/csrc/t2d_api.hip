@@ -54,6 +54,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;       // optional: t2d_comm_info reads the world back
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
 };
 Rccl& rccl() {
     static Rccl r;
@@ -71,6 +73,8 @@ Rccl& rccl() {
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
     r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    r.CommCount = (decltype(r.CommCount))dlsym(h, "ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(h, "ncclCommUserRank");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.GetErrorString;
     if (!r.ok) r.err = "librccl lacks an expected symbol";
     return r;
@@ -1581,6 +1585,23 @@ int t2d_comm_init(t2d_pool* p, const uint8_t* id, int32_t rank, int32_t world) {
     p->comm = c;
     return T2D_OK;
 }
+
+int t2d_comm_info(t2d_pool* p, int32_t* native_rccl, int32_t* world, int32_t* rank) {
+    if (!p) return T2D_ERR_INVALID;
+    int w = p->comm_world, r = p->comm_rank;
+    if (p->comm) {   // what the communicator itself says, not what the caller passed to t2d_comm_init
+        if (!rccl().CommCount || !rccl().CommUserRank) return fail(p, T2D_ERR_HIP, "librccl lacks ncclCommCount / ncclCommUserRank");
+        ncclResult_t e = rccl().CommCount((ncclComm_t)p->comm, &w);
+        if (e == ncclSuccess) e = rccl().CommUserRank((ncclComm_t)p->comm, &r);
+        if (e != ncclSuccess) return fail(p, T2D_ERR_HIP, std::string("ncclCommCount: ") + rccl().GetErrorString(e));
+    }
+    if (native_rccl) *native_rccl = p->comm != nullptr;
+    if (world) *world = w;
+    if (rank) *rank = r;
+    return T2D_OK;
+}
+
+int64_t t2d_step_count(const t2d_pool* p) { return p ? (int64_t)p->step_count : -1; }
 
 int t2d_gather(t2d_pool* p, void* nccl_comm, int32_t n_steps, void* out_dev, void* hip_stream) {
     if (!p) return T2D_ERR_INVALID;

@@ -704,7 +704,20 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         bool hit;
         if (s_kind[i] == T2D_SHAPE_OBB) {
             // (3 or 4 vertices: t2d_set_static_geometry cuts larger polygons into fans of quads)
+#ifndef T2D_NO_RECT_FILTER
+            // most candidates of the box sweep are clear of the polygon: an edge of the polygon with the whole box beyond it
+            // certifies that, a box whose centre lies inside the polygon is a hit (rect_vs_convex_filter); the rest -- touching, overlapping, or separated only by an edge of the
+            // box -- take the oracle's 32 orientations (both quads are read again there: held across the filter they cost
+            // the kernel 19 spilled registers)
+            const int v = rect_vs_convex_filter(load_obb_lds(&s_v[0][i]), load_quad_f32(xy + 2 * v0, n));
+            hit = v == 1;
+            if (__ballot(v == 2) != 0ull) {
+                asm volatile("" ::: "memory");
+                if (v == 2) hit = sat_quads(load_obb_lds(&s_v[0][i]), load_quad_f32(xy + 2 * v0, n));
+            }
+#else
             hit = sat_quads(load_obb_lds(&s_v[0][i]), load_quad_f32(xy + 2 * v0, n));
+#endif
         } else {
             hit = circle_vs_generic((double)s_cxy[0][i], (double)s_cxy[1][i], rad_of(i),
                                     PolyRef{reinterpret_cast<const float2*>(xy + 2 * v0), nullptr, n});

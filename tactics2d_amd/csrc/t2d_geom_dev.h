@@ -84,6 +84,31 @@ T2D_DEV int rect_pair_filter(const Quad& A, const Quad& B) {
     return g > kRectMargin ? 0 : (g < -kRectMargin ? 1 : 2);
 }
 
+// Certificate of separation in front of sat_quads(A, B) for a RECTANGLE A (participant box) and a convex CCW polygon B:
+// true when some edge of B has the whole of A strictly on its outer side -- A's support along the edge's outward normal
+// n = (ey, -ex) does not reach the edge's line: n.(c - B_j) - (|n.P| + |n.Q|) / 2 > margin (P, Q the box's edge vectors, c its
+// centre; everything below carries the factor 2).  Then orient(B_j, B_k, A_i) < 0 for all four vertices by more than the margin
+// (1e-9 |n|, a nanometre: a thousand times the rounding of either evaluation), which is the oracle's separating-edge rule.
+// Padded vertices (triangles repeat vertex 0) give a zero normal: never certifies.
+// Returns 0: separated (certified), 1: intersecting (certified: the box's centre lies strictly inside B -- inside every edge
+// by the same margin -- so no edge of either polygon can have all of the other's vertices outside), 2: undecided.
+T2D_DEV int rect_vs_convex_filter(const Quad& A, const Quad& B) {
+    const double px = A.x[0] - A.x[3], py = A.y[0] - A.y[3], qx = A.x[1] - A.x[0], qy = A.y[1] - A.y[0];
+    const double c2x = A.x[0] + A.x[2], c2y = A.y[0] + A.y[2];
+    bool out = false, in = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = (j + 1) & 3;
+        const double nx = B.y[k] - B.y[j], ny = B.x[j] - B.x[k];
+        const double s2 = __builtin_fma(nx, c2x - 2.0 * B.x[j], ny * (c2y - 2.0 * B.y[j]));
+        const double e2 = __builtin_fabs(__builtin_fma(nx, px, ny * py)) + __builtin_fabs(__builtin_fma(nx, qx, ny * qy));
+        const double m = 2e-9 * (__builtin_fabs(nx) + __builtin_fabs(ny));
+        out |= s2 - e2 > m;
+        in &= (s2 < -m) | ((nx == 0.0) & (ny == 0.0));   // (the zero-length edge of a padded triangle says nothing)
+    }
+    return out ? 0 : (in ? 1 : 2);
+}
+
 T2D_DEV bool point_in_quad(const Quad& B, double x, double y) {
     bool in = true;
 #pragma unroll

@@ -148,9 +148,13 @@ class NativeGather:
             dist.broadcast_object_list(uid, src=0)
         pool.comm_init(uid[0], rank, world)
 
-    def launch(self, step, stream=None):
-        """Call after (0-based) step `step`, with the stream the steps run on (raw handle or None)."""
-        if (step + 1) % self.every:
+    def launch(self, step=None, stream=None):
+        """Call after every step (or t2d_step_n fragment) with the stream the steps run on (raw handle or None): a gather is
+        issued whenever the POOL's step count (t2d_step_count -- not the caller's index: steps taken before this object
+        existed count too) reaches a multiple of `every`.  Returns the output buffer (0 / 1) the fragment goes to, else None.
+        Buffer k is written again two fragments later, ordered after whatever `stream` holds at that launch: consume
+        result(k) on the steps' stream, or wait(), before launching two more fragments."""
+        if self.pool.step_count() % self.every:
             return None
         k = self._frag & 1
         self._frag += 1
@@ -159,6 +163,7 @@ class NativeGather:
         return k
 
     def wait(self, k=None):
+        """Blocks until every gather issued so far has landed (gathers run in order on one stream: buffer k's is among them)."""
         self.pool.gather_wait(self._stream, block_host=True)
 
     def result(self, k, j=None):

@@ -312,6 +312,17 @@ class ParticipantPool:
     def gather_wait(self, stream=None, block_host=False):
         self._ck(self._lib.t2d_gather_wait(self._h, stream, int(bool(block_host))))
 
+    def comm_info(self):
+        """(native_rccl, world, rank) read back from the pool's communicator (ncclCommCount / ncclCommUserRank when RCCL
+        created one): what a multi-GPU run prints as proof that RCCL saw N ranks."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self._lib.t2d_comm_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return bool(a.value), b.value, c.value
+
+    def step_count(self):
+        """Steps taken so far (t2d_step_count): what t2d_gather's fragment length must divide."""
+        return int(self._lib.t2d_step_count(self._h))
+
     def set_step_placement(self, wgmap=None):
         """Which logical workgroup (and wave rotation << 16) each physical workgroup of the step launch steps; None = identity.
         Never changes a result (t2d.h: t2d_debug_set_step_placement)."""

@@ -511,3 +511,77 @@ def test_rect_pair_filter_is_a_certificate_of_convex_intersects(oracle):
         if v != 2:
             assert bool(v) == oracle.convex_intersects(A, B), (xa, ya, ha, La, Wa, xb, yb, hb, Lb, Wb)
     assert counts[0] > 1000 and counts[1] > 1000 and counts[2] < 600, counts
+
+
+def test_box_outside_a_polygon_edge_certifies_separation(oracle):
+    """rect_vs_convex_filter (t2d_geom_dev.h), restated on the oracle's vertices: a polygon edge with the whole box strictly
+    beyond it certifies `separate`, the box's centre strictly inside the polygon certifies `intersects` -- whenever the
+    filter answers, the oracle's convex_intersects gives the same answer; it answers on most separate pairs, on deep
+    overlaps, and never on touching ones."""
+    rng = np.random.default_rng(5)
+
+    def verdict(A, B):      # 0 separated, 1 intersecting, 2 undecided (rect_vs_convex_filter)
+        p, q, c2 = A[0] - A[3], A[1] - A[0], A[0] + A[2]
+        out, inside = False, True
+        for j in range(len(B)):
+            k = (j + 1) % len(B)
+            n = np.array([B[k][1] - B[j][1], B[j][0] - B[k][0]])
+            s2 = n @ (c2 - 2 * B[j]); m = 2e-9 * np.abs(n).sum()
+            out |= s2 - (abs(n @ p) + abs(n @ q)) > m
+            inside &= s2 < -m
+        return 0 if out else (1 if inside else 2)
+
+    fired = sep = hits = hit_cert = 0
+    for it in range(5000):
+        n = int(rng.integers(3, 5))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+        if np.diff(np.append(ang, ang[0] + 2 * np.pi)).max() > np.pi - 0.2:
+            continue
+        rad = rng.uniform(2, 14)
+        B = np.float64(np.float32(np.stack([rad * np.cos(ang), rad * np.sin(ang)], 1) + rng.uniform(-100, 100, 2)))
+        if not oracle.polygon_is_convex(np.float32(B)):
+            continue
+        L_, W_ = rng.uniform(1.5, 14), rng.uniform(0.6, 2.6)
+        d = rng.uniform(0, 1.4) * (rad + 0.5 * np.hypot(L_, W_)); t = rng.uniform(0, 6.3)
+        cx, cy = np.float32(B.mean(0) + d * np.array([np.cos(t), np.sin(t)]))
+        if it % 5 == 0:      # exact contact: box axis-aligned, its side on the polygon's bounding line
+            h = 0.0; cx = np.float32(B[:, 0].max() + 0.5 * L_)
+        else:
+            h = float(np.float32(rng.uniform(0, 6.3)))
+        A = oracle.pose_obb(float(cx), float(cy), h, L_, W_, trig=1)
+        want = oracle.convex_intersects(A, B)
+        got = verdict(A, B)
+        fired += got == 0; sep += not want; hits += want; hit_cert += got == 1
+        assert got == 2 or bool(got) == want, (A, B, got, want)
+    assert sep > 700 and fired > 0.7 * sep and hits > 400 and hit_cert > 0.3 * hits, (fired, sep, hit_cert, hits)
+
+
+def test_piece_clear_of_the_pose_support_is_a_miss(oracle):
+    """The support test in front of piece_meets_quad_interior (t2d_collide.hip process_lane): when the pose lies on one side of
+    a boundary piece's line, clear of it by the margin, the oracle's predicate says the piece does not meet the pose's interior."""
+    import ctypes as C
+    rng = np.random.default_rng(6)
+    lib = oracle.lib()
+    lib.t2do_piece_meets_quad_interior.restype = C.c_int
+    clear_n = meets_n = 0
+    for it in range(6000):
+        L_, W_ = rng.uniform(1.5, 14), rng.uniform(0.6, 2.6)
+        x, y, h = float(np.float32(rng.uniform(-200, 200))), float(np.float32(rng.uniform(-200, 200))), float(np.float32(rng.uniform(0, 6.3)))
+        P = oracle.pose_obb(x, y, h, L_, W_, trig=1)
+        mid = np.array([x, y]) + rng.uniform(-1.2, 1.2, 2) * np.hypot(L_, W_)
+        th = rng.uniform(0, np.pi); half = rng.uniform(0.05, 30)
+        if it % 4 == 0:   # a piece along the line of one of the pose's edges (touching from outside)
+            e0, e1 = P[it % 3], P[it % 3 + 1]
+            dvec = (e1 - e0) / np.linalg.norm(e1 - e0)
+            a, b = e0 - half * dvec, e1 + half * dvec
+        else:
+            dvec = np.array([np.cos(th), np.sin(th)])
+            a, b = mid - half * dvec, mid + half * dvec
+        piece = np.ascontiguousarray(np.concatenate([a, b]), np.float64)
+        meets = bool(lib.t2do_piece_meets_quad_interior(piece.ctypes.data_as(C.c_void_p), np.ascontiguousarray(P.reshape(8)).ctypes.data_as(C.c_void_p)))
+        p, q, c2 = P[0] - P[3], P[1] - P[0], P[0] + P[2]
+        n = np.array([a[1] - b[1], b[0] - a[0]])
+        clear = abs(n @ (c2 - 2 * a)) > abs(n @ p) + abs(n @ q) + 2e-9 * np.abs(n).sum()
+        clear_n += clear; meets_n += meets
+        assert not (clear and meets), (piece, P)
+    assert clear_n > 1500 and meets_n > 1000, (clear_n, meets_n)
