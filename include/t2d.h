@@ -508,6 +508,11 @@ int t2d_debug_set_step_placement(t2d_pool* pool, const uint32_t* map_host, int32
 int t2d_debug_step_occupancy(t2d_pool* pool, int32_t* blocks_per_cu, int64_t* lds_bytes,
                              int64_t* geometry_bytes_per_launch);
 
+/* Test hook: occupies the pool's gather stream for `microseconds` (one idle wave), so that the gathers enqueued after it
+ * start late -- what a slow peer does to the collective.  tests/test_gpu_dist.py uses it to check that a step about to
+ * overwrite a record slot really waits for the gather that still has to read it.                                       */
+int t2d_debug_delay_gather(t2d_pool* pool, int32_t microseconds);
+
 /* Host-only (no device is touched): the rectangles t2d_set_lane_geometry finds inside the union of each env's lane polygons
  * -- the certificate behind the step kernel's off-lane short cut (a pose whose box lies in one of them is contained in the
  * union).  out = f32 [n_env][T2D_SAFE_RECTS][4] (xmin, xmax, ymin, ymax); unused slots hold (+inf, -inf, +inf, -inf).

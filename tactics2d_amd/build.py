@@ -50,5 +50,24 @@ def build(force=False, verbose=False):
     return LIB
 
 
+# the conservative build tests/test_gpu_soak.py holds the product against (see wave_sync in t2d_collide.hip)
+CHECK_LIB = os.path.join(HERE, "libt2d_hip_waitcnt.so")
+CHECK_FLAGS = ["-DT2D_WAVE_SYNC_WAITCNT"]
+
+
+def build_check_lib(force=False):
+    """libt2d_hip_waitcnt.so: the same sources with every wave-level LDS sync preceded by s_waitcnt lgkmcnt(0)."""
+    if not force and os.path.exists(CHECK_LIB):
+        t = os.path.getmtime(CHECK_LIB)
+        deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+        if all(os.path.getmtime(d) <= t for d in deps):
+            return CHECK_LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc] + FLAGS + CHECK_FLAGS + [os.path.join(CSRC, f) for f in SOURCES] + ["-ldl", "-o", CHECK_LIB])
+    return CHECK_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--check-lib" in sys.argv:
+        print(build_check_lib(force="--force" in sys.argv))

@@ -634,6 +634,11 @@ __global__ __launch_bounds__(256) void restore_kernel(PoolView pv, SnapPtrs sp, 
     // the env record (status, counters) is cleared by restore_env_kernel, launched after this
     // kernel on the same stream, so every participant has read `status` before it changes
 }
+// one wave that does nothing for `ticks` of the 100 MHz real-time counter (t2d_debug_delay_gather)
+__global__ __launch_bounds__(64) void spin_kernel(long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(32);
+}
 __global__ __launch_bounds__(256) void restore_env_kernel(PoolView pv, int mode) {
     const int env = blockIdx.x * 256 + threadIdx.x;
     if (env >= pv.n_env) return;
@@ -648,6 +653,10 @@ __global__ __launch_bounds__(256) void restore_env_kernel(PoolView pv, int mode)
     reinterpret_cast<uchar4*>(pv.status)[env] = st;
 }
 }  // namespace
+hipError_t launch_spin(long long ticks, hipStream_t s) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, ticks);
+    return hipGetLastError();
+}
 hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
                           hipStream_t s) {
     SnapPtrs sp;
@@ -1274,6 +1283,13 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
         v.chain_base = p->chain_count;
         v.chain_real_wgs = (p->v.n_env + p->v.geo_layout.epb - 1) / p->v.geo_layout.epb;
         v.chain_act_step = act_step_stride;
+        // pools whose step launch is at most two workgroups per CU (all resident at once): the workgroups loop over the
+        // steps themselves; larger pools chain one workgroup per (env set, step)
+        {
+            int dev_cus = 0;
+            (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, p->device);
+            v.loop_steps = (p->chain_loop && dev_cus > 0 && v.chain_real_wgs <= 2 * dev_cus) ? n : 0;
+        }
         v.record_ring = (uint2*)p->field_ptr[T2D_F_RECORD];
         v.record_slot0 = slot0;
         if ((rc = record_event(p, 7, s, true))) return rc;
@@ -1290,6 +1306,7 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
 int t2d_set_step_chaining(t2d_pool* p, int32_t on, int32_t priority_rule) {
     if (!p) return T2D_ERR_INVALID;
     p->chain_steps = on != 0;
+    p->chain_loop = on != 2;   // 2: always the chained form, also for small pools (measurements)
     p->chain_priority = priority_rule != 0;
     return T2D_OK;
 }
@@ -1583,6 +1600,16 @@ int t2d_comm_init(t2d_pool* p, const uint8_t* id, int32_t rank, int32_t world) {
     const ncclResult_t r = rccl().CommInitRank(&c, world, u, rank);
     if (r != ncclSuccess) return fail(p, T2D_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
     p->comm = c;
+    return T2D_OK;
+}
+
+int t2d_debug_delay_gather(t2d_pool* p, int32_t microseconds) {
+    if (!p) return T2D_ERR_INVALID;
+    if (microseconds < 0 || microseconds > 200000) return fail(p, T2D_ERR_INVALID, "delay must be 0 .. 200000 us");
+    T2D_HIP(p, hipSetDevice(p->device));
+    int rc;
+    if ((rc = ensure_gather_objects(p))) return rc;
+    T2D_HIP(p, t2d::launch_spin(100ll * microseconds, p->gather_stream));
     return T2D_OK;
 }
 

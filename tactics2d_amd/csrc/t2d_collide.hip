@@ -199,8 +199,14 @@ T2D_DEV uint32_t cell_hash(int cx, int cy) {
 // are used, as always), let alone a workgroup-scope release fence, which would also drain every global store in flight.
 // (Round 1 had the fences: 1-2 k cycles of store round trip at each sync after the state / flag stores; waiting for
 // lgkmcnt(0) at each of the ~25 syncs of a wave still stalled it on every LDS round trip.)
+// -DT2D_WAVE_SYNC_WAITCNT builds the conservative form (every LDS operation of the wave retired before the sync):
+// tests/test_gpu_soak.py steps both builds through thousands of steps and compares every bit.
 T2D_DEV void wave_sync() {
+#ifdef T2D_WAVE_SYNC_WAITCNT
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("" ::: "memory");
+#endif
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -285,6 +291,8 @@ T2D_DEV void compact_and_process(unsigned long long mask, int id_base, int own_i
 // extent is a multiple of 8 and the hardware places linear workgroup id i on XCD i mod 8 -- observed, not promised -- so
 // the consumer CHECKS it: the producer's XCC id travels in the word, a mismatch (or a wait that runs out: kChainSpinLimit)
 // raises chain_err, the host reports the launch as failed and stops chaining.  Never a silent stale read, never a hang.
+// byte offset of the second kernel argument (t2d_status_config) in collide_kernel's argument block: behind the PoolView
+constexpr size_t kCfgArgOffset = (sizeof(PoolView) + alignof(t2d_status_config) - 1) / alignof(t2d_status_config) * alignof(t2d_status_config);
 constexpr int kChainSpinLimit = 1 << 18;   // ~0.2 s of polling: far beyond any step, short enough not to look like a hang
 // The kernel's own argument block (PoolView is the first parameter), through an empty asm: loads of its fields through the
 // returned pointer cannot be moved above this point.  The compiler otherwise hoists every kernel-argument load it can prove
@@ -306,9 +314,28 @@ T2D_DEV T ld_state(const T2D_GLOBAL T* p) {
     if (CHAIN) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return *p;
 }
-template <bool WITH_STATUS, int FUSE, bool IOU = true, bool CHAIN = false>
-__global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv, t2d_status_config cfg,
-                                                                            int interval_ms, int log2A) {
+// LOOP = true (t2d_step_n on pools of at most two workgroups per CU -- every workgroup resident from the start): the
+// workgroup itself walks through the steps, tables and geometry staged once, no hand-off between workgroups at all; its
+// register budget is that of two waves per SIMD (256), which a loop round the step body needs: at the 128 registers of
+// the metric launch's four waves per SIMD it costs 150 spill slots.  A step of these pools is one wave per
+// SIMD walking a dependent chain: the launch boundary, the start-up and the state's round trip through memory are a
+// third of it.
+template <bool WITH_STATUS, int FUSE, bool IOU = true, bool CHAIN = false, bool LOOP = false>
+__global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv_arg, t2d_status_config cfg_arg,
+                                                                                       int interval_ms, int log2A) {
+    static_assert(!(CHAIN && LOOP) && (!LOOP || (FUSE >= 0 && WITH_STATUS)), "LOOP = the fused step, not combined with CHAIN");
+    // `pv` / `cfg` below: the two argument structs -- directly, or (LOOP) through a pointer into the kernel's argument block
+    // that is laundered again at the top of every trip, so that what a trip reads of them cannot be hoisted out of the loop:
+    // left alone the compiler keeps every invariant argument load live across the whole body (225 spilled scalars, 57
+    // spilled vector registers -- at 256 registers).
+    auto pvp = [&]() { if constexpr (LOOP) return late_args(); else return &pv_arg; }();
+    auto cfgp = [&]() {
+        if constexpr (LOOP) return (const __attribute__((address_space(4))) t2d_status_config*)((const __attribute__((address_space(4))) char*)late_args() + kCfgArgOffset);
+        else return &cfg_arg;
+    }();
+#define pv (*pvp)
+#define cfg (*cfgp)
+    constexpr bool MULTI = CHAIN || LOOP;   // the launch holds several steps: per-step action sets, record slots, sc1 state loads
     __shared__ double s_v[8][kBlock];   // OBB vertex coordinate planes x0,y0,...,x3,y3
     __shared__ float s_cxy[2][kBlock];  // centre x, centre y (the stored fp32 state: exact)
     __shared__ unsigned char s_type[kBlock];  // type id: the radius (circle) / bounding radius (OBB) is read from the table
@@ -351,12 +378,11 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     // dropping them and fetching the same arguments again behind the next branch)
     asm volatile("" : "+s"(a_ids), "+s"(a_x), "+s"(a_y), "+s"(a_h), "+s"(a_v), "+s"(a_act0), "+s"(a_act1), "+s"(a_idm),
                       "+s"(a_params), "+s"(a_geo), "+s"(a_n_env), "+s"(a_A), "+s"(a_stride), "+s"(a_epb), "+s"(a_act_stride));
-    const GeoLayout& gl = pv.geo_layout;
     // Placement of the step launch (t2d_debug_set_step_placement): which logical workgroup -- which EPB envs -- this physical
     // workgroup steps, and by how many waves its lane -> participant map is rotated.  Results do not depend on it; the
     // hardware places workgroup b on XCD b mod 8 and its waves on fixed SIMDs, so the map decides which envs share a SIMD.
     int wg = blockIdx.x, wave_rot = 0;
-    const int step_k = CHAIN ? (int)blockIdx.y : 0;
+    int step_k = CHAIN ? (int)blockIdx.y : 0;
     if (CHAIN && wg >= pv.chain_real_wgs) {   // padding of the grid's x extent to a multiple of 8 (see launch_step_chain)
         if (threadIdx.x == 0)
             __hip_atomic_store(&pv.chain_done[wg], chain_word(pv.chain_base + (uint32_t)step_k + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -427,6 +453,40 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         }
         __syncthreads();
     };
+    if constexpr (LOOP) {
+        // tables and the workgroup's geometry record: staged once, ahead of the loop, in the plainest form (kept inside
+        // the loop behind a first-trip test, the staging code's lane masks were hoisted out of it and held in scalar
+        // registers for the whole body: 195 spilled scalars)
+        constexpr int kTab = kTabCols * T2D_MAX_TYPES;
+        const int nthr = a_epb << log2A;
+        for (int q = (int)threadIdx.x; q < kTab; q += nthr) s_partab[q] = a_params[q];
+        if (a_geo) {
+            typedef uint32_t u32x4l __attribute__((ext_vector_type(4)));
+            const T2D_GLOBAL u32x4l* src = (const T2D_GLOBAL u32x4l*)(a_geo + (size_t)wg * a_stride);
+            for (int q = (int)threadIdx.x; q < (a_stride >> 2); q += nthr) reinterpret_cast<u32x4l*>(s_geo)[q] = src[q];
+        }
+    }
+    const int tid_outer = tid;
+    for (;;) {   // (one trip unless LOOP)
+    // LOOP: the lane's coordinates are derived again on every trip from a laundered thread id -- as loop invariants every
+    // lane mask built from them (agent == 0, agent < n_off, valid && ..., one per use) is hoisted and held in a scalar
+    // register pair across the whole body (170 spilled scalars)
+    int tid_l = tid_outer;
+    if constexpr (LOOP) asm volatile("" : "+v"(tid_l));
+    const int tid = tid_l;
+    const int lane = tid & 63;
+    const int env_local = tid >> log2A;
+    const int agent = tid & (A_pad - 1);
+    const int env = wg * EPB + env_local;
+    const bool valid = env < a_n_env && agent < a_A;
+    const int idx = valid ? env * a_A + agent : 0;
+    uint32_t* const queue = s_queue[tid >> 6];
+    int* const qcount = &s_qcount[tid >> 6];
+    if constexpr (LOOP) {
+        pvp = late_args();
+        cfgp = (const __attribute__((address_space(4))) t2d_status_config*)((const __attribute__((address_space(4))) char*)late_args() + kCfgArgOffset);
+    }
+    const auto& gl = pv.geo_layout;
     // ---------------- phase 0: issue every global load, clear LDS tables ------------------
     uint32_t ids = 0;
     float fx = 0, fy = 0, fh = 0;
@@ -438,13 +498,13 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     int pre_cnt = 0, pre_frame = 0;
     if (CHAIN && step_k > 0) chain_wait();
     if (valid) {
-        ids = ld_state<CHAIN>(a_ids + idx);
-        fx = ld_state<CHAIN>(a_x + idx);
-        fy = ld_state<CHAIN>(a_y + idx);
-        fh = ld_state<CHAIN>(a_h + idx);
+        ids = ld_state<MULTI>(a_ids + idx);
+        fx = ld_state<MULTI>(a_x + idx);
+        fy = ld_state<MULTI>(a_y + idx);
+        fh = ld_state<MULTI>(a_h + idx);
         if (FUSE >= 0) {
-            fv = ld_state<CHAIN>(a_v + idx);
-            const size_t ai = (size_t)idx * a_act_stride + (CHAIN ? (size_t)step_k * (size_t)pv.chain_act_step : 0);
+            fv = ld_state<MULTI>(a_v + idx);
+            const size_t ai = (size_t)idx * a_act_stride + (MULTI ? (size_t)step_k * (size_t)pv.chain_act_step : 0);
             fa0 = a_act0[ai];
             fa1 = a_act1[ai];
             if (a_idm && a_idm[idx] != T2D_IDM_NONE) {  // IDM lane while caller actions are bound
@@ -458,7 +518,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             has_boundary = pv.boundary_valid ? pv.boundary_valid[env] != 0 : true;
         }
     }
-    if (FUSE >= 0) {  // full parameter table -> LDS, loads issued together (one exposed latency)
+    constexpr bool stage_tables = !LOOP;   // (a LOOP launch staged them ahead of its loop: they stay in LDS across the steps)
+    if (FUSE >= 0 && stage_tables) {  // full parameter table -> LDS, loads issued together (one exposed latency)
         constexpr int kTab = kTabCols * T2D_MAX_TYPES;
         if (nthreads == kBlock) {   // the usual launch shape: 3 x 8 B per thread, no per-load bounds logic
             static_assert(kTab <= 3 * kBlock && kTab > 2 * kBlock, "staging below assumes 2 full rounds + a partial one");
@@ -495,10 +556,10 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     {
         // rounds of 16-B loads this record needs (wave-uniform): 1 for the metric scenes (<= 4 KiB per workgroup) --
         // the unrolled generic form spends more on its per-load bounds logic than on the loads
-        const int rounds = (n_vec + nthreads - 1) / nthreads;
+        const int rounds = stage_tables ? (n_vec + nthreads - 1) / nthreads : 0;
         u32x4 geo_stage0 = {0u, 0u, 0u, 0u};
         if (rounds <= 1) {
-            if (tid < n_vec) geo_stage0 = gsrc[tid];
+            if (tid < n_vec && rounds == 1) geo_stage0 = gsrc[tid];
         } else {
             // big records (many envs or many polygons per workgroup, e.g. 32 parking lots = 30 KiB for 32 threads):
             // global_load_lds -- 16 B per lane straight into LDS at M0 + lane * 16, no staging registers -- so ALL
@@ -523,7 +584,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             }
         }
         if (rounds <= 1) {
-            if (tid < n_vec) reinterpret_cast<u32x4*>(s_geo)[tid] = geo_stage0;
+            if (tid < n_vec && rounds == 1) reinterpret_cast<u32x4*>(s_geo)[tid] = geo_stage0;
         } else {
             __builtin_amdgcn_s_waitcnt(0);  // the LDS-direct loads are tracked by vmcnt: all landed before the barrier
         }
@@ -540,8 +601,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         auto P = [&](int col) -> double { return s_partab[col * T2D_MAX_TYPES + type]; };
         double pvx = 0.0, pvy = 0.0;
         if (model == T2D_MODEL_POINTMASS) {
-            pvx = (double)ld_state<CHAIN>(as_global(pv.vx) + idx);
-            pvy = (double)ld_state<CHAIN>(as_global(pv.vy) + idx);
+            pvx = (double)ld_state<MULTI>(as_global(pv.vx) + idx);
+            pvy = (double)ld_state<MULTI>(as_global(pv.vy) + idx);
         }
         const integ::StepOut o = integ::step_participant<(FUSE > 0 ? 1 : 0)>(
             model, P, (double)fx, (double)fy, (double)fh, (double)fv, pvx, pvy, (double)fa0, (double)fa1, interval_ms);
@@ -1000,8 +1061,8 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
     // latency.  (Fetched at the top of the kernel they sat in registers through every event phase, and at the 128
     // registers of 4 waves / SIMD that meant scratch spills: 8 B per lane stored and re-read, 13 MB of HBM traffic.)
     if (WITH_STATUS && valid && agent == 0) {
-        pre_cnt = ld_state<CHAIN>(e_cnt_step + env);
-        pre_frame = ld_state<CHAIN>(e_frame_ms + env);
+        pre_cnt = ld_state<MULTI>(e_cnt_step + env);
+        pre_frame = ld_state<MULTI>(e_frame_ms + env);
         if (e_time_penalty && cfg.max_step > 0) {
             const int c = pre_cnt + 1;
             pre_tp = pv.time_penalty[c < cfg.max_step ? c : cfg.max_step];
@@ -1134,7 +1195,7 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
             const uint32_t st = (uint32_t)scen | (uint32_t)traf << 8 | (uint32_t)terminated << 16 | (uint32_t)truncated << 24;
             ((T2D_GLOBAL uint32_t*)e_status)[env] = st;
             pv.reward[env] = r;
-            if (CHAIN) pv.record_ring[(size_t)((pv.record_slot0 + step_k) & (T2D_RECORD_RING - 1)) * (size_t)pv.n_env + env] = make_uint2(__float_as_uint(r), st);
+            if (MULTI) pv.record_ring[(size_t)((pv.record_slot0 + step_k) & (T2D_RECORD_RING - 1)) * (size_t)pv.n_env + env] = make_uint2(__float_as_uint(r), st);
             else pv.record[env] = make_uint2(__float_as_uint(r), st);
             if (e_auto_reset) {
                 const bool done = terminated || truncated;
@@ -1202,12 +1263,21 @@ __global__ __launch_bounds__(kBlock, T2D_COLLIDE_WAVES) void collide_kernel(Pool
         }
     }
     T2D_MARK(12);
+    if (!LOOP) break;
+    // LOOP: this step's stores are in the L2 (the next trip reads them with sc1 loads), and no wave clears the LDS tables
+    // while another still reads them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (++step_k >= pv.loop_steps) break;
+    }
     if (CHAIN) {   // this step of these envs is complete: every store above is in the L2 before the word moves
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0)
             __hip_atomic_store(&pv.chain_done[wg], chain_word(pv.chain_base + (uint32_t)step_k + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#undef pv
+#undef cfg
 }
 
 }  // namespace
@@ -1231,6 +1301,14 @@ hipError_t launch_step_chain(const PoolView& v, const t2d_status_config& cfg, in
     int log2A = 1;
     while ((1 << log2A) < v.A) ++log2A;
     const int EPB = v.geo_layout.epb;
+    if (cfg.check_no_action || cfg.check_arrival) return hipErrorInvalidValue;   // (see below)
+    if (v.loop_steps > 0) {   // small pool: every workgroup resident, each walks through the steps itself
+        const dim3 grid((v.n_env + EPB - 1) / EPB), block(EPB << log2A);
+        const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
+        if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        return hipGetLastError();
+    }
     // x extent rounded up to a multiple of 8: workgroup ids go round the 8 XCDs, so step k + 1 of a set of envs then runs on
     // the XCD that ran their step k and finds their state in that XCD's L2 (the padding workgroups only move their counter)
     const int real = (v.n_env + EPB - 1) / EPB, padded = (real + 7) & ~7;

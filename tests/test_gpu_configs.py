@@ -114,12 +114,30 @@ def test_full_size_config(oracle, name):
     # ---- fast vs exact variant
     fast = _run(sc, acts, "fast")
     from tactics2d_amd import layout as L
-    dyn = sc.rows[sc.type_id, L.P_MODEL] == L.MODEL_DYNAMICS
-    stiff = dyn & (np.abs(sc.speed) < 3.0)        # initial speed: 3 steps cannot leave/enter the band otherwise
-    ok = sc.active.astype(bool) & ~stiff
+    # Every participant is compared; the bound is 2e-5 (the fp32 store of both results: an ulp at |x| >= 128 m is 1.5e-5)
+    # plus what the roll-out's own conditioning allows.  SingleTrackDynamics is the reference's explicit Euler of a stiff
+    # tyre model: at crawling speed an fp32 ulp of the start speed can move the end state by metres.  `sens` = the oracle's
+    # end-state change per fp32 ulp of an input (helpers.rollout_sensitivity); two correct integrators differ by ~1e-7 of
+    # such an ulp per operation, a few hundred operations per step: 1e-4 x sens bounds it with two orders to spare.
+    # Participants whose 3-step roll-out amplifies one ulp to more than 10 m (chaotic by any standard) are reported,
+    # and must be rare; they are covered -- like everything -- by the exact variant's bit-equality with the oracle.
+    dyn = np.nonzero((sc.rows[sc.type_id, L.P_MODEL] == L.MODEL_DYNAMICS) & sc.active.astype(bool))[0]
+    sens = np.zeros(sc.n)
+    if len(dyn):
+        sens[dyn] = H.rollout_sensitivity(oracle, sc, acts, dyn)
+    chaotic = sens > 10.0
+    ok = sc.active.astype(bool) & ~chaotic
+    tol = 2e-5 + 1e-4 * sens
     for c in (0, 1, 3):
-        assert np.abs(fast["state"][c][ok] - big["state"][c][ok]).max() <= 2e-5, c
-    assert H.ang_err(fast["state"][2][ok], big["state"][2][ok]).max() <= 1e-6
+        err = np.abs(fast["state"][c].astype(np.float64) - big["state"][c])
+        assert (err[ok] <= tol[ok]).all(), (c, float((err[ok] / tol[ok]).max()))
+    assert (H.ang_err(fast["state"][2][ok], big["state"][2][ok]) <= 1e-6 + 1e-4 * sens[ok]).all()
+    if len(dyn):
+        errx = np.abs(fast["state"][0].astype(np.float64) - big["state"][0])[dyn]
+        print(f"{name}: dynamics participants {len(dyn)}, sens quantiles (50/90/99/max) "
+              f"{np.quantile(sens[dyn], [0.5, 0.9, 0.99, 1.0])}, chaotic {int(chaotic.sum())}, worst |dx| / bound "
+              f"{float((errx / tol[dyn])[~chaotic[dyn]].max()):.3f}, over 2e-5: {int((errx[~chaotic[dyn]] > 2e-5).sum())}")
+        assert chaotic.sum() <= 0.01 * len(dyn), (int(chaotic.sum()), len(dyn))
     # flags may only differ where a pose moved by an fp32 ulp across a touching configuration: rare
     assert (fast["flags"] != big["flags"]).mean() < 1e-4
 
@@ -165,3 +183,51 @@ def test_agent_permutation_property():
         assert np.array_equal(out["state"][c], base["state"][c][gidx], equal_nan=True)
     assert np.array_equal(out["flags"], base["flags"][gidx])
     assert np.array_equal(out["env_flags"], base["env_flags"]) and np.array_equal(out["status"], base["status"])
+
+
+def test_cfg2_full_size_with_the_iou_events_on(oracle):
+    """cfg2 at its full size (4096 parking envs) with Arrival / NoAction / the shaped reward ON -- the configuration
+    ParkingEnv runs -- every env against the oracle's status chain on the pool's own fp32 states: status bytes, IoU,
+    reward, NoAction counter, step counter, for 8 steps (egos on the bay, egos that never move, egos that drive)."""
+    from tactics2d_amd import layout as L, scenarios as S
+    from tactics2d_amd.pool import ParticipantPool
+    sc = S.parking(4096)
+    n_env = sc.n_env
+    rng = np.random.default_rng(3)
+    tc = sc.target.mean(1)
+    on = np.arange(n_env) % 4 == 0
+    sc.x[on] = tc[on, 0] + rng.normal(0, 0.05, on.sum()).astype(np.float32)
+    sc.y[on] = tc[on, 1] + rng.normal(0, 0.05, on.sum()).astype(np.float32)
+    sc.heading[on] = sc.target_heading[on]
+    still = np.arange(n_env) % 4 == 1
+    sc.status.update(max_step=6, no_action_max_step=3)
+    assert sc.status["check_arrival"] and sc.status["check_no_action"] and sc.status["shaped_reward"]
+    pool = ParticipantPool(n_env, 1)
+    sc.load(pool)
+    pool.set_integrator_variant("exact")
+    cfg = oracle.make_config(**sc.status)
+    ep = oracle.EpisodeState(n_env, sc.target, None, np.stack([sc.x, sc.y], 1))
+    cnt = np.zeros(n_env, np.int32); frame = np.zeros(n_env, np.int32)
+    x, y, h, v = sc.x.copy(), sc.y.copy(), sc.heading.copy(), sc.speed.copy()
+    seen = set()
+    for t in range(8):
+        a0, a1 = sc.sample_actions(rng)
+        a0[still | on] = 0.0
+        pool.set_actions(a0, a1)
+        pool.step(100)
+        oracle.set_trig(1)
+        o = oracle.integrate(sc.rows, x, y, h, v, None, None, a0, a1, sc.type_id, sc.active, 100)
+        oracle.set_trig(0)
+        x, y, h, v = (np.float32(o[:, k]) for k in range(4))
+        assert np.array_equal(pool.download(L.F_X), x) and np.array_equal(pool.download(L.F_HEADING), h)
+        wf, _ = oracle.collide(sc.rows, n_env, 1, x, y, h, sc.type_id, sc.active, sc.static, sc.boundary, sc.boundary_valid, sc.lanes, 0)
+        wst, wrw, wiou = oracle.status_ex(cfg, 1, wf, 100, cnt, frame, sc.rows, x, y, h, sc.type_id, ep)
+        gst, grw, giou = pool.download(L.F_STATUS), pool.download(L.F_REWARD), pool.download(L.F_IOU)
+        assert np.array_equal(pool.download(L.F_FLAGS), wf)
+        assert np.array_equal(gst, wst), (t, np.nonzero((gst != wst).any(1))[0][:5])
+        assert np.array_equal(np.isnan(giou), np.isnan(wiou)) and np.allclose(giou, wiou, rtol=0, atol=1e-7, equal_nan=True)
+        assert np.allclose(grw, wrw, rtol=0, atol=2e-6), float(np.abs(grw - wrw).max())
+        assert np.array_equal(pool.download(L.F_CNT_NO_ACTION), ep.cnt_na) and np.array_equal(pool.download(L.F_CNT_STEP), cnt)
+        seen |= set(map(tuple, gst[:, :2].tolist()))
+    pool.close()
+    assert {(1, 1), (2, 1), (1, 5), (3, 1)} <= seen, seen     # normal, completed, no-action quirk, time exceeded

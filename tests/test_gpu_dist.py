@@ -62,7 +62,7 @@ def test_native_gather_reads_the_record_ring_in_place(with_rccl):
     for t, (a0, a1) in enumerate(acts):
         pool.set_actions(a0, a1)
         pool.step(100, st.cuda_stream)
-        k = g.launch(t, st.cuda_stream)
+        k = g.launch(stream=st.cuda_stream)
         if pending is not None and k is None and (t + 1) % EVERY == 3:   # read a fragment while later steps are in flight
             kk, t_last = pending
             for j in range(EVERY):
@@ -80,6 +80,93 @@ def test_native_gather_reads_the_record_ring_in_place(with_rccl):
     for t in range(STEPS):
         assert np.array_equal(got[t][0], want[t][0]) and np.array_equal(got[t][1], want[t][1]), t
     assert any(w[1][:, 3].any() for w in want)            # some episodes ended: the records are not trivial
+
+
+def _device_action_ring(sc, acts, dev="cuda"):
+    a0 = torch.from_numpy(np.stack([a[0] for a in acts])).to(dev).contiguous()
+    a1 = torch.from_numpy(np.stack([a[1] for a in acts])).to(dev).contiguous()
+    return a0, a1
+
+
+@pytest.mark.parametrize("chained", [False, True])
+def test_gathers_overlap_the_steps_with_no_host_synchronisation(chained):
+    """Actions bound once in device memory, 64 steps and their four gathers enqueued on one stream with no host wait in
+    between (so a step really runs while a gather is in flight, and the slot-event wait is what protects the ring); the
+    fragments are copied out stream-ordered and compared at the end with a single pool stepped one call at a time."""
+    from tactics2d_amd.dist import NativeGather
+    from tactics2d_amd.pool import ParticipantPool
+    sc = _scene()
+    acts = _actions(sc)
+    want = _single_pool_records(sc, acts)
+    a0, a1 = _device_action_ring(sc, acts)
+    pool = ParticipantPool(sc.n_env, sc.A)
+    sc.load(pool)
+    pool.set_auto_reset(True)
+    pool.comm_init(pool.comm_unique_id(), 0, 1)
+    assert pool.comm_info() == (True, 1, 0)               # read back from the RCCL communicator itself
+    g = NativeGather(pool, 1, every=EVERY, device="cuda")
+    st = torch.cuda.Stream()
+    keep = torch.zeros((STEPS // EVERY, EVERY, sc.n_env, 2), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for f in range(STEPS // EVERY):
+        base = f * EVERY
+        if chained:
+            pool.bind_actions(a0.data_ptr() + 4 * sc.n * base, a1.data_ptr() + 4 * sc.n * base)
+            pool.step_n(EVERY, 100, sc.n, st.cuda_stream)
+        else:
+            for j in range(EVERY):
+                pool.bind_actions(a0.data_ptr() + 4 * sc.n * (base + j), a1.data_ptr() + 4 * sc.n * (base + j))
+                pool.step(100, st.cuda_stream)
+        k = g.launch(stream=st.cuda_stream)
+        assert k == f % 2
+        pool.gather_wait(st.cuda_stream, block_host=False)   # the STREAM waits for the gather, the host does not
+        with torch.cuda.stream(st):
+            keep[f].copy_(g.out[k][0])
+    st.synchronize()
+    assert pool.step_count() == STEPS
+    pool.close()
+    from tactics2d_amd.dist import unpack_record
+    for t in range(STEPS):
+        rw, s = unpack_record(keep[t // EVERY, t % EVERY])
+        assert np.array_equal(rw.cpu().numpy(), want[t][0]) and np.array_equal(s.cpu().numpy(), want[t][1]), t
+
+
+def test_a_step_waits_for_the_gather_that_still_reads_its_record_slot():
+    """The record ring has 32 slots.  A gather of steps 0..15 is held back on the pool's gather stream (30 ms behind an idle
+    kernel: a slow peer), while 32 further steps are enqueued at once -- steps 32..47 write the very slots that gather has
+    not read yet.  t2d_step must make the step stream wait for it: the fragment arrives intact.  (Without the wait the
+    fragment would hold the records of steps 32..47.)"""
+    from tactics2d_amd.dist import NativeGather, unpack_record
+    from tactics2d_amd.pool import ParticipantPool
+    sc = _scene()
+    acts = _actions(sc)
+    want = _single_pool_records(sc, acts)
+    a0, a1 = _device_action_ring(sc, acts)
+    pool = ParticipantPool(sc.n_env, sc.A)
+    sc.load(pool)
+    pool.set_auto_reset(True)
+    pool.comm_init(pool.comm_unique_id(), 0, 1)
+    g = NativeGather(pool, 1, every=EVERY, device="cuda")
+    st = torch.cuda.Stream()
+
+    def steps(lo, hi):
+        for t in range(lo, hi):
+            pool.bind_actions(a0.data_ptr() + 4 * sc.n * t, a1.data_ptr() + 4 * sc.n * t)
+            pool.step(100, st.cuda_stream)
+    torch.cuda.synchronize()
+    steps(0, EVERY)
+    pool._ck(pool._lib.t2d_debug_delay_gather(pool._h, 30000))
+    k = g.launch(stream=st.cuda_stream)
+    steps(EVERY, 3 * EVERY)                                   # wraps the ring onto slots 0..15 -- must wait inside t2d_step
+    rw0, s0 = [], []
+    for j in range(EVERY):
+        rw, s = g.result(k, j)
+        rw0.append(rw.cpu().numpy()); s0.append(s.cpu().numpy())
+    st.synchronize()
+    pool.close()
+    for j in range(EVERY):
+        assert np.array_equal(rw0[j], want[j][0]) and np.array_equal(s0[j], want[j][1]), j
+    assert not all(np.array_equal(want[j][0], want[2 * EVERY + j][0]) for j in range(EVERY))   # the two candidates differ
 
 
 def test_gather_argument_checks():
