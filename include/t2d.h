@@ -324,6 +324,9 @@ int t2d_get_field(t2d_pool* pool, int32_t field_id, void** dev_ptr, size_t* nbyt
 /* Synchronous host<->device copies of a whole field (parity tests, small envs).         */
 int t2d_download(t2d_pool* pool, int32_t field_id, void* host_dst, size_t nbytes);
 int t2d_upload(t2d_pool* pool, int32_t field_id, const void* host_src, size_t nbytes);
+/* Waits for THIS pool's work only: the streams it was launched on since the last such call (up to four are tracked; more
+ * distinct streams, or a tracked stream that has been destroyed in the meantime, make the call fall back to a device-wide
+ * synchronise) plus the pool's own internal streams.  The set-up calls and the two copies above wait the same way.       */
 int t2d_sync(t2d_pool* pool);
 
 /* Episode-start snapshot for device-side (auto-)reset -- the vector-env counterpart of

@@ -204,6 +204,7 @@ class BatchedScenarioManager:
         self.pool.reset(x, y, heading, speed, type_id, active, env_mask=env_mask)
         self.pool.snapshot()
         self._flags_cache = None
+        self._ego_velocity_derived = None   # (an env's ego model is fixed until the next reset: see get_observation)
 
     def update(self, act0, act1, stream=None):
         """Physics step of every participant (parking.py:352-359: `physics_model.step` + add_state)."""
@@ -242,8 +243,11 @@ class BatchedScenarioManager:
         # SingleTrackDynamics / SingleTrackDrift return a State without vx, vy (single_track_dynamics.py:220-227) and
         # the pool's VX / VY fields are not written by those models (include/t2d.h): State.velocity then DERIVES
         # (speed cos(heading), speed sin(heading)) (state.py:152-169) -- done here the same way, lazily
-        model = self.pool.download(L.F_IDS).reshape(self.n_env, self.max_agents)[:, self.ego_index] & 0xff
-        derived = (model == L.MODEL_DYNAMICS) | (model == L.MODEL_DRIFT)
+        # (the mask is read once per reset, not per call: an ego's model does not change in between)
+        if getattr(self, "_ego_velocity_derived", None) is None:
+            model = self.pool.download(L.F_IDS).reshape(self.n_env, self.max_agents)[:, self.ego_index] & 0xff
+            self._ego_velocity_derived = (model == L.MODEL_DYNAMICS) | (model == L.MODEL_DRIFT)
+        derived = self._ego_velocity_derived
         if derived.any():
             h, v = cols[2].astype(np.float64), cols[3].astype(np.float64)
             cols[4] = np.where(derived, (v * np.cos(h)).astype(np.float32), cols[4])
