@@ -332,7 +332,7 @@ def main():
     ap.add_argument("--no-reset", action="store_true", help="skip the device-side auto-reset")
     ap.add_argument("--idm", action="store_true", help="non-ego vehicles driven by on-device IDM controllers (row f3); "
                     "adds the idm kernel to every step (not the metric configuration)")
-    ap.add_argument("--clock-warm", type=int, default=500, help="untimed steps of a scratch pool (same scene) before the "
+    ap.add_argument("--clock-warm", type=int, default=3000, help="untimed steps of a scratch pool (same scene) before the "
                     "warm-up steps, so that the GPU has left its idle clocks when the timed region starts (0 = off)")
     args = ap.parse_args()
 
