@@ -323,7 +323,8 @@ def main():
     ap.add_argument("--outputs", default="state", choices=["state", "all"],
                     help="state: x, y, heading, speed (+ a point mass's velocity), flags and the env records; all: also the derived "
                          "vx / vy of the single-track models and the applied action (t2d_set_outputs)")
-    ap.add_argument("--gather-every", type=int, default=16, help="N > 1: steps per all-gather of the result records (1 = every step)")
+    ap.add_argument("--gather-every", type=int, default=32, help="N > 1: steps per all-gather of the result records (1 = every step; "
+                    "it divides the record ring of 64 slots and is at most half of it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP events")
     ap.add_argument("--no-configs", action="store_true", help="skip timing BASELINE.json's other configurations")
@@ -358,7 +359,7 @@ def main():
     agents = args.agents or agents
     scene = build_scene(args.config, n_env, agents, seed=rank)
     N = scene.n
-    frag = max(1, min(args.fragment, L.RECORD_RING))
+    frag = max(1, min(args.fragment, L.RECORD_RING, ACTION_SETS))
     run = Runner(scene, dev, args.variant, auto_reset=not args.no_reset, outputs=args.outputs, seed=1000 + rank, idm=args.idm)
     geo_record_bytes = run.pool.geometry_bytes_per_launch()
     chained_ok = args.mode == "chain" and not args.idm

@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define T2D_ABI_VERSION 6
+#define T2D_ABI_VERSION 7
 
 /* ---- status codes --------------------------------------------------------------- */
 #define T2D_OK            0
@@ -179,7 +179,7 @@ enum {
 
 /* ---- geometry limits ----------------------------------------------------------------- */
 #define T2D_MAX_POLY_VERTS 8      /* static / lane polygons: convex, 3..8 vertices (5..8: evaluated as a fan of quads) */
-#define T2D_RECORD_RING 32      /* slots of the per-env result-record ring (T2D_F_RECORD) */
+#define T2D_RECORD_RING 64      /* slots of the per-env result-record ring (T2D_F_RECORD): two gather fragments of 32 steps */
 #define T2D_MAX_AGENTS 256        /* participants per env                                 */
 
 /* ---- status / reward configuration (t2d_set_status_config) --------------------------- */

@@ -70,7 +70,7 @@ def test_chained_steps_equal_single_steps_on_the_mixed_scene(variant):
 def test_chained_steps_in_several_calls_and_past_the_record_ring():
     from tactics2d_amd import scenarios as S
     sc = S.intersection(64, 32, seed=8)    # A = 32: two envs per wave, eight per workgroup
-    _compare(sc, 70, "exact", calls=(3, 40, 1, 26))   # 40 > the ring of 32 slots: two launches inside one call; 1: plain step
+    _compare(sc, 120, "exact", calls=(3, 90, 1, 26))   # 90 > the ring of 64 slots: two launches inside one call; 1: plain step
 
 
 def test_chained_steps_repeat_one_action_set():

@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-N_ENV, A, STEPS, EVERY = 48, 64, 64, 16
+N_ENV, A, STEPS, EVERY = 48, 64, 128, 16
 
 
 def _scene():
@@ -132,9 +132,9 @@ def test_gathers_overlap_the_steps_with_no_host_synchronisation(chained):
 
 
 def test_a_step_waits_for_the_gather_that_still_reads_its_record_slot():
-    """The record ring has 32 slots.  A gather of steps 0..15 is held back on the pool's gather stream (30 ms behind an idle
-    kernel: a slow peer), while 32 further steps are enqueued at once -- steps 32..47 write the very slots that gather has
-    not read yet.  t2d_step must make the step stream wait for it: the fragment arrives intact.  (Without the wait the
+    """The record ring has RING slots.  A gather of steps 0..15 is held back on the pool's gather stream (30 ms behind an idle
+    kernel: a slow peer), while RING further steps are enqueued at once -- steps RING..RING+15 write the very slots that gather
+    has not read yet.  t2d_step must make the step stream wait for it: the fragment arrives intact.  (Without the wait the
     fragment would hold the records of steps 32..47.)"""
     from tactics2d_amd.dist import NativeGather, unpack_record
     from tactics2d_amd.pool import ParticipantPool
@@ -157,7 +157,8 @@ def test_a_step_waits_for_the_gather_that_still_reads_its_record_slot():
     steps(0, EVERY)
     pool._ck(pool._lib.t2d_debug_delay_gather(pool._h, 30000))
     k = g.launch(stream=st.cuda_stream)
-    steps(EVERY, 3 * EVERY)                                   # wraps the ring onto slots 0..15 -- must wait inside t2d_step
+    from tactics2d_amd import layout as L
+    steps(EVERY, L.RECORD_RING + EVERY)                       # wraps the ring onto slots 0..15 -- must wait inside t2d_step
     rw0, s0 = [], []
     for j in range(EVERY):
         rw, s = g.result(k, j)
@@ -166,7 +167,7 @@ def test_a_step_waits_for_the_gather_that_still_reads_its_record_slot():
     pool.close()
     for j in range(EVERY):
         assert np.array_equal(rw0[j], want[j][0]) and np.array_equal(s0[j], want[j][1]), j
-    assert not all(np.array_equal(want[j][0], want[2 * EVERY + j][0]) for j in range(EVERY))   # the two candidates differ
+    assert not all(np.array_equal(want[j][0], want[L.RECORD_RING + j][0]) for j in range(EVERY))   # the two candidates differ
 
 
 def test_gather_argument_checks():

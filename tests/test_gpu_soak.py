@@ -41,7 +41,7 @@ while done < steps:
             pool.bind_actions(a0.data_ptr() + 4 * sc.n * k, a1.data_ptr() + 4 * sc.n * k)
             pool.step(100)
     done += 32
-    if done %% 256 == 0:   # the record ring holds the last 32 steps' rewards / statuses of every env
+    if done %% 64 == 0:   # the record ring holds the last 64 steps' rewards / statuses of every env
         for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_FLAGS, L.F_RECORD, L.F_CNT_STEP):
             h.update(pool.download(f).tobytes())
 flags = pool.download(L.F_FLAGS)
