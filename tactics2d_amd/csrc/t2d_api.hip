@@ -1251,7 +1251,9 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
     hipStream_t s = (hipStream_t)hip_stream;
     const bool ego = p->ego_kernel && p->v.A == 1 && p->all_boxes && !p->has_drift && !p->hgeo[1].present;
     const bool iou = p->status_cfg.check_no_action || p->status_cfg.check_arrival;   // per-env history read by the epilogue
-    const bool chain = p->chain_steps && n_steps >= 2 && p->fused_step && !p->idm_on && !p->has_drift && !p->scene_regen && !ego && !iou;
+    // (the single-ego kernel has a LOOP form of its own, which reads the history with sc1 loads: IoU events are fine there)
+    const bool chain = p->chain_steps && n_steps >= 2 && p->fused_step && !p->idm_on && !p->has_drift && !p->scene_regen &&
+                       (ego ? p->chain_loop : !iou);
     const float *a0 = p->v.act0, *a1 = p->v.act1;
     int rc = T2D_OK;
     if (!chain) {   // kernels outside the fused step (IDM, drift, scene regeneration, the single-ego kernel): step by step
@@ -1293,7 +1295,12 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
         v.record_ring = (uint2*)p->field_ptr[T2D_F_RECORD];
         v.record_slot0 = slot0;
         if ((rc = record_event(p, 7, s, true))) return rc;
-        T2D_HIP(p, t2d::launch_step_chain(v, p->status_cfg, interval_ms, p->integrator_variant, n, s));
+        if (ego) {   // 16 lanes per env, each group of lanes loops over the steps
+            v.loop_steps = n;
+            T2D_HIP(p, t2d::launch_ego_step(v, p->status_cfg, interval_ms, p->integrator_variant, s));
+        } else {
+            T2D_HIP(p, t2d::launch_step_chain(v, p->status_cfg, interval_ms, p->integrator_variant, n, s));
+        }
         if ((rc = record_event(p, 7, s, false))) return rc;
         p->chain_count += (uint32_t)n;
         p->chain_used = true;

@@ -291,28 +291,14 @@ T2D_DEV void compact_and_process(unsigned long long mask, int id_base, int own_i
 // extent is a multiple of 8 and the hardware places linear workgroup id i on XCD i mod 8 -- observed, not promised -- so
 // the consumer CHECKS it: the producer's XCC id travels in the word, a mismatch (or a wait that runs out: kChainSpinLimit)
 // raises chain_err, the host reports the launch as failed and stops chaining.  Never a silent stale read, never a hang.
-// byte offset of the second kernel argument (t2d_status_config) in collide_kernel's argument block: behind the PoolView
-constexpr size_t kCfgArgOffset = (sizeof(PoolView) + alignof(t2d_status_config) - 1) / alignof(t2d_status_config) * alignof(t2d_status_config);
 constexpr int kChainSpinLimit = 1 << 18;   // ~0.2 s of polling: far beyond any step, short enough not to look like a hang
 // The kernel's own argument block (PoolView is the first parameter), through an empty asm: loads of its fields through the
 // returned pointer cannot be moved above this point.  The compiler otherwise hoists every kernel-argument load it can prove
 // invariant to the entry block -- the epilogue's thirty pointers, the geometry layout -- and, out of scalar registers, parks
 // them in VGPR lanes for the length of the kernel (v_writelane / v_readlane per value: 108 spilled scalars and ~300 extra
 // VALU instructions per wave when the lane stage was rewritten in round 3).
-typedef const __attribute__((address_space(4))) PoolView* KernargView;
-T2D_DEV KernargView late_args() {
-    auto kp = (KernargView)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
-    return kp;
-}
 T2D_DEV unsigned long long chain_word(uint32_t steps_done) {   // {steps done, XCC id of the workgroup that did the last one}
     return (unsigned long long)steps_done | ((unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg(63508) << 32);
-}
-// a load of state the previous step of a chained launch stored: sc1 (through the L2), plain otherwise
-template <bool CHAIN, class T>
-T2D_DEV T ld_state(const T2D_GLOBAL T* p) {
-    if (CHAIN) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
 }
 // LOOP = true (t2d_step_n on pools of at most two workgroups per CU -- every workgroup resident from the start): the
 // workgroup itself walks through the steps, tables and geometry staged once, no hand-off between workgroups at all; its
@@ -394,7 +380,7 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
         wave_rot = (int)(m >> 16);
     }
     const int tid = blockDim.x == kBlock ? (int)((threadIdx.x + 64u * (unsigned)wave_rot) & (kBlock - 1u)) : (int)threadIdx.x;
-    const int lane = tid & 63;
+    [[maybe_unused]] const int lane = tid & 63;   // (the step body derives its own lane coordinates: see the loop below)
     const int A_pad = 1 << log2A;
     const int EPB = a_epb;
     const int nthreads = EPB << log2A;
@@ -402,11 +388,11 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     const int agent = tid & (A_pad - 1);
     const int env = wg * EPB + env_local;
     const bool valid = env < a_n_env && agent < a_A;
-    const int idx = valid ? env * a_A + agent : 0;
+    [[maybe_unused]] const int idx = valid ? env * a_A + agent : 0;
     const bool use_hash_grid = log2A > 6;  // envs larger than a wave use the LDS spatial hash
     const int H = 2 * A_pad;               // buckets per env (power of two)
-    uint32_t* const queue = s_queue[tid >> 6];
-    int* const qcount = &s_qcount[tid >> 6];
+    [[maybe_unused]] uint32_t* const queue = s_queue[tid >> 6];
+    [[maybe_unused]] int* const qcount = &s_qcount[tid >> 6];
 
 #ifdef T2D_TIMING
     unsigned long long t_prev_ = __builtin_readcyclecounter();

@@ -40,8 +40,17 @@ T2D_DEV void ego_wave_sync() {   // LDS writes of this wave -> visible to its ot
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int VARIANT>
-__global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d_status_config cfg, int interval_ms) {
+// LOOP = true (t2d_step_n): the launch holds pv.loop_steps steps and every group of lanes walks through them itself --
+// step k reads action set k of the bound ring and writes record slot (record_slot0 + k) of the ring; what one trip stored
+// (state, counters, detector history) the next reads back with sc1 loads, behind an s_waitcnt vmcnt(0).  An env's chain of
+// steps then pays no launch boundary and no start-up per step: with one wave per SIMD they are a quarter of a step.  The
+// argument structs are read through a kernarg pointer laundered at the top of every trip (see collide_kernel's LOOP form).
+template <int VARIANT, bool LOOP = false>
+__global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv_arg, t2d_status_config cfg_arg, int interval_ms) {
+    auto pvp = [&]() { if constexpr (LOOP) return late_args(); else return &pv_arg; }();
+    auto cfgp = [&]() { if constexpr (LOOP) return late_cfg(); else return &cfg_arg; }();
+#define pv (*pvp)
+#define cfg (*cfgp)
     // the two quads of each IoU, [env of the workgroup][iou][A | B][x0 y0 ... x3 y3]
     __shared__ double s_quad[kEgoPerBlock][2][2][8];
     const int lane = threadIdx.x & 63;
@@ -53,17 +62,25 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d
     const bool live = env_raw < pv.n_env;               // (padding groups of the last workgroup run along on env 0, write nothing)
     const int env = live ? env_raw : 0;
     const int idx = env;                                // max_agents == 1
+    int step_k = 0;
+    for (;;) {   // (one trip unless LOOP)
+    if constexpr (LOOP) {
+        pvp = late_args();
+        cfgp = late_cfg();
+    }
+    auto G = [](auto* q) { return as_global(q); };
 
     // ---------------- loads (group-uniform addresses) -------------------------------------------------------------
-    const uint32_t ids = pv.ids[idx];
-    float fx = pv.x[idx], fy = pv.y[idx], fh = pv.heading[idx];
-    const float fv = pv.speed[idx];
-    float fa0 = pv.act0[(size_t)idx * pv.act_stride], fa1 = pv.act1[(size_t)idx * pv.act_stride];
+    const uint32_t ids = ld_state<LOOP>(G(pv.ids) + idx);
+    float fx = ld_state<LOOP>(G(pv.x) + idx), fy = ld_state<LOOP>(G(pv.y) + idx), fh = ld_state<LOOP>(G(pv.heading) + idx);
+    const float fv = ld_state<LOOP>(G(pv.speed) + idx);
+    const size_t ai = (size_t)idx * pv.act_stride + (LOOP ? (size_t)step_k * (size_t)pv.chain_act_step : 0);
+    float fa0 = pv.act0[ai], fa1 = pv.act1[ai];
     if (pv.idm_ctrl && pv.idm_ctrl[idx] != T2D_IDM_NONE) {
         fa0 = pv.own_act0[idx];
         fa1 = pv.own_act1[idx];
     }
-    const int pre_cnt = pv.cnt_step[env], pre_frame = pv.frame_ms[env];
+    const int pre_cnt = ld_state<LOOP>(G(pv.cnt_step) + env), pre_frame = ld_state<LOOP>(G(pv.frame_ms) + env);
     float bxmin = 0, bxmax = 0, bymin = 0, bymax = 0;
     bool has_boundary = false;
     if (pv.boundary) {
@@ -72,7 +89,7 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d
         has_boundary = pv.boundary_valid ? pv.boundary_valid[env] != 0 : true;
     }
     // this env's obstacle quads in the packed geometry record of its group of envs (t2d_pool.h GeoLayout)
-    const GeoLayout& gl = pv.geo_layout;
+    const auto& gl = pv.geo_layout;
     int p0 = 0, p1 = 0;
     const uint32_t* rec = nullptr;
     if (pv.geo && gl.has[0]) {
@@ -93,17 +110,17 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d
     int pre_cna = 0;
     double pre_max_iou = 0.0, pre_min_dist = 0.0, pre_tcx = 0.0, pre_tcy = 0.0;
     if (iou_on) {
-        pre_last_valid = pv.last_valid[env];
+        pre_last_valid = ld_state<LOOP>(G(pv.last_valid) + env);
         const double* other = iou_k == 0 ? pv.last_pose + 8 * (size_t)env : (pv.target_xy ? pv.target_xy + 8 * (size_t)env : nullptr);
-        if (other) pre_other = other[iou_t];
-        pre_cna = pv.cnt_na[env];
+        if (other) pre_other = ld_state<LOOP>(G(other) + iou_t);   // (the previous pose is written by every trip)
+        pre_cna = ld_state<LOOP>(G(pv.cnt_na) + env);
     }
     if (cfg.shaped_reward) {
-        pre_max_iou = pv.max_iou[env];
+        pre_max_iou = ld_state<LOOP>(G(pv.max_iou) + env);
         if (pv.target_c) {
             pre_tcx = pv.target_c[2 * (size_t)env];
             pre_tcy = pv.target_c[2 * (size_t)env + 1];
-            pre_min_dist = pv.min_dist[env];
+            pre_min_dist = ld_state<LOOP>(G(pv.min_dist) + env);
         }
     }
     const bool active = live && ((ids >> kIdsActiveShift) & 0xffu);
@@ -115,8 +132,8 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d
     if (active && model != T2D_MODEL_DRIFT) {   // (SingleTrackDrift participants are integrated by drift_kernel)
         double pvx = 0.0, pvy = 0.0;
         if (model == T2D_MODEL_POINTMASS) {
-            pvx = (double)pv.vx[idx];
-            pvy = (double)pv.vy[idx];
+            pvx = (double)ld_state<LOOP>(G(pv.vx) + idx);
+            pvy = (double)ld_state<LOOP>(G(pv.vy) + idx);
         }
         const integ::StepOut o = integ::step_participant<VARIANT>(model, P, (double)fx, (double)fy, (double)fh, (double)fv, pvx,
                                                                   pvy, (double)fa0, (double)fa1, interval_ms);
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d
     }
 
     // ---------------- status / reward epilogue (collide_kernel phase 3), the group's first lane --------------------
-    if (!live || l != 0) return;
+    if (live && l == 0) {
     const int cnt = pre_cnt + 1;  // parking.py:353
     pv.cnt_step[env] = cnt;
     pv.frame_ms[env] = pre_frame + interval_ms;
@@ -339,8 +356,10 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d
     st.z = terminated; st.w = truncated;
     reinterpret_cast<uchar4*>(pv.status)[env] = st;
     pv.reward[env] = r;
-    pv.record[env] = make_uint2(__float_as_uint(r), (uint32_t)scen | (uint32_t)traf << 8 |
+    const uint2 recv = make_uint2(__float_as_uint(r), (uint32_t)scen | (uint32_t)traf << 8 |
                                                         (uint32_t)terminated << 16 | (uint32_t)truncated << 24);
+    if (LOOP) pv.record_ring[(size_t)((pv.record_slot0 + step_k) & (T2D_RECORD_RING - 1)) * (size_t)pv.n_env + env] = recv;
+    else pv.record[env] = recv;
     if (pv.auto_reset && (terminated || truncated)) {  // ParkingEnv.reset: state, counters, detector state back to the start
         // (every snapshot value first, then the stores: as load / store pairs each pair waits for its own memory round trip)
         const double smd = pv.snap_min_dist[env];
@@ -371,12 +390,25 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv, t2d
             pv.omega_r[idx] = w1;
         }
     }
+    }   // (the group's first lane)
+    if (!LOOP) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this trip's stores are in the L2 before the next trip's sc1 loads
+    ego_wave_sync();
+    if (++step_k >= pv.loop_steps) break;
+    }
+#undef pv
+#undef cfg
 }
 
 }  // namespace
 
 hipError_t launch_ego_step(const PoolView& v, const t2d_status_config& cfg, int interval_ms, int variant, hipStream_t s) {
     const dim3 grid((v.n_env + kEgoPerBlock - 1) / kEgoPerBlock), block(kEgoBlock);
+    if (v.loop_steps > 0) {   // t2d_step_n: the groups walk through the steps themselves
+        if (variant == 0) hipLaunchKernelGGL((ego_step_kernel<0, true>), grid, block, 0, s, v, cfg, interval_ms);
+        else hipLaunchKernelGGL((ego_step_kernel<1, true>), grid, block, 0, s, v, cfg, interval_ms);
+        return hipGetLastError();
+    }
     if (variant == 0) hipLaunchKernelGGL(ego_step_kernel<0>, grid, block, 0, s, v, cfg, interval_ms);
     else hipLaunchKernelGGL(ego_step_kernel<1>, grid, block, 0, s, v, cfg, interval_ms);
     return hipGetLastError();

@@ -5,6 +5,21 @@
 #include "t2d_pool.h"
 
 namespace t2d {
+
+// The kernel's own argument block (PoolView is the first parameter of the step kernels, t2d_status_config the second),
+// through an empty asm: loads of its fields through the returned pointer cannot be moved above this point (see
+// collide_kernel: hoisted argument loads cost it 108 spilled scalars).
+typedef const __attribute__((address_space(4))) PoolView* KernargView;
+T2D_DEV KernargView late_args() {
+    auto kp = (KernargView)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+}
+// byte offset of the second kernel argument (t2d_status_config) in the argument block: behind the PoolView
+constexpr size_t kCfgArgOffset = (sizeof(PoolView) + alignof(t2d_status_config) - 1) / alignof(t2d_status_config) * alignof(t2d_status_config);
+typedef const __attribute__((address_space(4))) t2d_status_config* KernargCfg;
+T2D_DEV KernargCfg late_cfg() { return (KernargCfg)((const __attribute__((address_space(4))) char*)late_args() + kCfgArgOffset); }
+
 namespace integ {
 
 constexpr double kG = 9.81;  // PhysicsModelBase._G

@@ -14,6 +14,14 @@
 template <class T>
 __device__ __forceinline__ T2D_GLOBAL T* as_global(T* p) { return (T2D_GLOBAL T*)p; }
 
+// a load of state that an earlier step of the SAME launch stored (t2d_step_n): relaxed, agent scope = `sc1`, served by
+// the L2 and never by this CU's L1; a plain load otherwise
+template <bool MULTI, class T>
+__device__ __forceinline__ T ld_state(const T2D_GLOBAL T* p) {
+    if (MULTI) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
 namespace t2d {
 
 constexpr double kTwoPi = 2.0 * 3.141592653589793;
