@@ -4,7 +4,7 @@
 TAG=${1:-deep}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/sqd_$TAG; mkdir -p $OUT
-CMD="python bench.py --steps 60 --warmup 20 --no-cpu-baseline --no-configs --groups 1 --no-profile"
+CMD="python bench.py --mode ${MODE:-step} --steps 64 --warmup 32 --no-cpu-baseline --no-configs --no-next-rows --no-alternates --no-profile"
 i=0
 for SET in "SQ_WAVES SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS" \
            "SQ_WAVES SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_SENDMSG SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \

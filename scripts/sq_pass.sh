@@ -3,7 +3,7 @@
 TAG=${1:-sq}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/sq_$TAG; mkdir -p $OUT
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $OUT -o bench -- python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-profile ${@:2} > $OUT/log.txt 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --output-format csv -d $OUT -o bench -- python bench.py --steps 1000 --warmup 100 --no-cpu-baseline --no-configs --no-next-rows --no-alternates --no-profile ${@:2} > $OUT/log.txt 2>&1
 python - <<PY
 import csv, collections
 rows = list(csv.DictReader(open('$OUT/bench_counter_collection.csv')))

@@ -1288,9 +1288,8 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
         // pools whose step launch is at most two workgroups per CU (all resident at once): the workgroups loop over the
         // steps themselves; larger pools chain one workgroup per (env set, step)
         {
-            int dev_cus = 0;
-            (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, p->device);
-            v.loop_steps = (p->chain_loop && dev_cus > 0 && v.chain_real_wgs <= 2 * dev_cus) ? n : 0;
+            if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
+            v.loop_steps = (p->chain_loop && p->device_cus > 0 && v.chain_real_wgs <= 2 * p->device_cus) ? n : 0;
         }
         v.record_ring = (uint2*)p->field_ptr[T2D_F_RECORD];
         v.record_slot0 = slot0;

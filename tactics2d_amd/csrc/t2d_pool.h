@@ -242,6 +242,7 @@ struct t2d_pool {
     bool chain_loop = true;        // small pools take the LOOP form (t2d_set_step_chaining(pool, 2, *): never)
     bool chain_priority = true;    // wave priorities of a chained launch: 1 = the rule for overlapping work (PoolView::overlapped)
     bool chain_used = false, chain_failed = false;
+    int device_cus = 0;            // compute units of the pool's device (read once)
     // result gather (the one collective of the path): RCCL communicator + a stream of its own, so that the steps that
     // follow a fragment do not wait for its all-gather; slot_event[k] != null = a gather that reads record slot k was
     // enqueued and the step about to overwrite that slot must wait for it first
