@@ -453,6 +453,12 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
         }
     }
     const int tid_outer = tid;
+    // LOOP: what a trip leaves behind for the next one stays in registers -- the state it stored (or restored), the env's
+    // counters, and the next trip's actions, requested a trip ahead: a lone wave hides no load, and each of these was a
+    // round trip to the L2 at the head of its dependent chain
+    [[maybe_unused]] uint32_t c_ids = 0;
+    [[maybe_unused]] float c_x = 0, c_y = 0, c_h = 0, c_v = 0, c_vx = 0, c_vy = 0, n_a0 = 0, n_a1 = 0;
+    [[maybe_unused]] int c_cnt = 0, c_frame = 0;
     for (;;) {   // (one trip unless LOOP)
     // LOOP: the lane's coordinates are derived again on every trip from a laundered thread id -- as loop invariants every
     // lane mask built from them (agent == 0, agent < n_off, valid && ..., one per use) is hoisted and held in a scalar
@@ -483,16 +489,27 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     // would otherwise sit, unhidden, at the very end of the wave
     int pre_cnt = 0, pre_frame = 0;
     if (CHAIN && step_k > 0) chain_wait();
+    const bool carried = LOOP && step_k > 0;   // (LOOP: the second and later trips take their inputs from registers)
     if (valid) {
-        ids = ld_state<MULTI>(a_ids + idx);
-        fx = ld_state<MULTI>(a_x + idx);
-        fy = ld_state<MULTI>(a_y + idx);
-        fh = ld_state<MULTI>(a_h + idx);
+        if (carried) {
+            ids = c_ids; fx = c_x; fy = c_y; fh = c_h; fv = c_v; fa0 = n_a0; fa1 = n_a1;
+        } else {
+            ids = ld_state<MULTI>(a_ids + idx);
+            fx = ld_state<MULTI>(a_x + idx);
+            fy = ld_state<MULTI>(a_y + idx);
+            fh = ld_state<MULTI>(a_h + idx);
+        }
         if (FUSE >= 0) {
-            fv = ld_state<MULTI>(a_v + idx);
             const size_t ai = (size_t)idx * a_act_stride + (MULTI ? (size_t)step_k * (size_t)pv.chain_act_step : 0);
-            fa0 = a_act0[ai];
-            fa1 = a_act1[ai];
+            if (!carried) {
+                fv = ld_state<MULTI>(a_v + idx);
+                fa0 = a_act0[ai];
+                fa1 = a_act1[ai];
+            }
+            if (LOOP && step_k + 1 < pv.loop_steps) {   // the next trip's actions: their latency overlaps this trip
+                n_a0 = a_act0[ai + (size_t)pv.chain_act_step];
+                n_a1 = a_act1[ai + (size_t)pv.chain_act_step];
+            }
             if (a_idm && a_idm[idx] != T2D_IDM_NONE) {  // IDM lane while caller actions are bound
                 fa0 = pv.own_act0[idx];
                 fa1 = pv.own_act1[idx];
@@ -560,7 +577,11 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
         }
         if (use_hash_grid)
             for (int k = tid; k < EPB * H; k += nthreads) s_head[k] = -1;
-        if (tid < kBlock / 2) s_env_or[tid] = 0;
+        if (LOOP) {   // (every wave clears what is its envs' own: the waves of a LOOP launch do not wait for each other)
+            if (agent == 0) s_env_or[env_local] = 0;
+        } else if (tid < kBlock / 2) {
+            s_env_or[tid] = 0;
+        }
         s_flags[tid] = 0;
         if (FUSE < 0) {
 #pragma unroll
@@ -575,7 +596,9 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
             __builtin_amdgcn_s_waitcnt(0);  // the LDS-direct loads are tracked by vmcnt: all landed before the barrier
         }
     }
-    __syncthreads();  // (a) tables cleared, type columns + geometry record staged
+    // (a) tables cleared, type columns + geometry record staged; the later trips of a LOOP launch staged nothing and cleared
+    // only what belongs to their own wave
+    if (carried && log2A <= 6) wave_sync(); else __syncthreads();
     T2D_MARK(0);
 
     const bool active = valid && ((ids >> kIdsActiveShift) & 0xffu);
@@ -587,18 +610,28 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
         auto P = [&](int col) -> double { return s_partab[col * T2D_MAX_TYPES + type]; };
         double pvx = 0.0, pvy = 0.0;
         if (model == T2D_MODEL_POINTMASS) {
-            pvx = (double)ld_state<MULTI>(as_global(pv.vx) + idx);
-            pvy = (double)ld_state<MULTI>(as_global(pv.vy) + idx);
+            if (carried) {
+                pvx = (double)c_vx;
+                pvy = (double)c_vy;
+            } else {
+                pvx = (double)ld_state<MULTI>(as_global(pv.vx) + idx);
+                pvy = (double)ld_state<MULTI>(as_global(pv.vy) + idx);
+            }
         }
         const integ::StepOut o = integ::step_participant<(FUSE > 0 ? 1 : 0)>(
             model, P, (double)fx, (double)fy, (double)fh, (double)fv, pvx, pvy, (double)fa0, (double)fa1, interval_ms);
         fx = (float)o.x;
         fy = (float)o.y;
         fh = (float)o.heading;
+        fv = (float)o.speed;
         pv.x[idx] = fx;
         pv.y[idx] = fy;
         pv.heading[idx] = fh;
-        pv.speed[idx] = (float)o.speed;
+        pv.speed[idx] = fv;
+        if (LOOP && o.has_velocity) {
+            c_vx = (float)o.vx;
+            c_vy = (float)o.vy;
+        }
         if (o.has_velocity && (model == T2D_MODEL_POINTMASS || (pv.out_mask & T2D_OUT_VELOCITY))) {
             pv.vx[idx] = (float)o.vx;
             pv.vy[idx] = (float)o.vy;
@@ -1047,8 +1080,13 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     // latency.  (Fetched at the top of the kernel they sat in registers through every event phase, and at the 128
     // registers of 4 waves / SIMD that meant scratch spills: 8 B per lane stored and re-read, 13 MB of HBM traffic.)
     if (WITH_STATUS && valid && agent == 0) {
-        pre_cnt = ld_state<MULTI>(e_cnt_step + env);
-        pre_frame = ld_state<MULTI>(e_frame_ms + env);
+        if (carried) {
+            pre_cnt = c_cnt;
+            pre_frame = c_frame;
+        } else {
+            pre_cnt = ld_state<MULTI>(e_cnt_step + env);
+            pre_frame = ld_state<MULTI>(e_frame_ms + env);
+        }
         if (e_time_penalty && cfg.max_step > 0) {
             const int c = pre_cnt + 1;
             pre_tp = pv.time_penalty[c < cfg.max_step ? c : cfg.max_step];
@@ -1105,6 +1143,10 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
             const int cnt = pre_cnt + 1;  // parking.py:353
             pv.cnt_step[env] = cnt;
             pv.frame_ms[env] = pre_frame + interval_ms;
+            if (LOOP) {
+                c_cnt = cnt;
+                c_frame = pre_frame + interval_ms;
+            }
             const int ego = (env_local << log2A) + cfg.ego_index;  // workgroup-local lane of the ego
             const uint32_t ef = s_flags[ego];
             int scen = T2D_SCENARIO_NORMAL, traf = T2D_TRAFFIC_NORMAL;
@@ -1189,6 +1231,7 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
                 if (done) {  // ParkingEnv.reset: counters and detector state back to the episode start
                     pv.cnt_step[env] = 0;
                     pv.frame_ms[env] = 0;
+                    if (LOOP) c_cnt = c_frame = 0;
                     pv.last_valid[env] = 0;
                     pv.cnt_na[env] = 0;
                     pv.max_iou[env] = -INFINITY;
@@ -1196,6 +1239,9 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
                 }
             }
         }
+    }
+    if (LOOP) {   // what this trip stored (a pure-output velocity excepted: only a point mass reads c_vx / c_vy back)
+        c_ids = ids; c_x = fx; c_y = fy; c_h = fh; c_v = fv;
     }
     if (WITH_STATUS && e_auto_reset) {  // fused vector-env auto-reset: finished envs go back to the snapshot
         // (the restore's eighteen pointers are requested here, in one scalar round trip, not with the epilogue's above: 36
@@ -1242,6 +1288,9 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
             e_vx[idx] = r4;
             e_vy[idx] = r5;
             e_ids[idx] = rid;
+            if (LOOP) {
+                c_x = r0; c_y = r1; c_h = r2; c_v = r3; c_vx = r4; c_vy = r5; c_ids = rid;
+            }
             if (drift) {
                 e_omega_f[idx] = w0;
                 e_omega_r[idx] = w1;
@@ -1250,10 +1299,9 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     }
     T2D_MARK(12);
     if (!LOOP) break;
-    // LOOP: this step's stores are in the L2 (the next trip reads them with sc1 loads), and no wave clears the LDS tables
-    // while another still reads them
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // LOOP: nothing is read back from memory (see `carried`); what the next trip clears in LDS is the wave's own when an env
+    // fits a wave, else the workgroup meets first
+    if (log2A <= 6) wave_sync(); else __syncthreads();
     if (++step_k >= pv.loop_steps) break;
     }
     if (CHAIN) {   // this step of these envs is complete: every store above is in the L2 before the word moves

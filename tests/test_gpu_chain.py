@@ -122,3 +122,35 @@ def test_chained_steps_at_the_metric_size():
     from tactics2d_amd import scenarios as S
     sc = S.mixed(4096, 64, seed=3)
     _compare(sc, 16, "fast")
+
+
+def test_single_ego_pools_loop_through_arrivals_no_action_and_time_limits():
+    """The single-ego kernel's LOOP form carries the state, the counters and the detector history (previous pose, NoAction
+    counter, _max_iou, _min_dist) in registers from one step to the next: egos parked on the bay (Arrival), egos that never
+    move (NoAction after 3 steps), a 12-step time limit, auto-reset on -- 64 steps as fragments of 1..32 against 64 calls."""
+    from tactics2d_amd import scenarios as S
+    sc = S.parking(777, seed0=5)
+    rng = np.random.default_rng(12)
+    tc = sc.target.mean(1)
+    on = np.arange(sc.n_env) % 3 == 0
+    sc.x[on] = tc[on, 0] + rng.normal(0, 0.03, on.sum()).astype(np.float32)
+    sc.y[on] = tc[on, 1] + rng.normal(0, 0.03, on.sum()).astype(np.float32)
+    sc.heading[on] = sc.target_heading[on]
+    sc.status.update(max_step=12, no_action_max_step=3)
+    still = np.arange(sc.n_env) % 3 == 1
+
+    class Calm:   # an action source whose `still` / `on` egos never accelerate
+        def __init__(self, sc):
+            self.sc = sc
+        def __getattr__(self, k):
+            return getattr(self.sc, k)
+        def sample_actions(self, r):
+            a0, a1 = self.sc.sample_actions(r)
+            a0[still | on] = 0.0
+            return a0, a1
+    want = _compare(Calm(sc), 64, "exact", calls=(1, 2, 29, 32))
+    from tactics2d_amd import layout as L
+    rec = want[_fields().index(L.F_RECORD)].reshape(L.RECORD_RING, sc.n_env, 2)
+    seen = set(map(tuple, np.stack([rec[..., 1] & 0xff, (rec[..., 1] >> 8) & 0xff], -1).reshape(-1, 2).tolist()))
+    assert {(1, 1), (2, 1), (1, 5), (3, 1)} <= seen, seen     # normal, completed, no-action quirk, time exceeded
+    _compare(Calm(sc), 40, "fast", calls=(40,))
