@@ -318,6 +318,24 @@ int t2d_step_groups(t2d_pool* const* pools, const float* const* act0_dev, const 
  * (one "launch" = one chained launch of up to T2D_RECORD_RING steps).                                                    */
 int t2d_step_n(t2d_pool* pool, int32_t interval_ms, int32_t n_steps, int64_t act_step_stride, void* hip_stream);
 int t2d_set_step_chaining(t2d_pool* pool, int32_t on, int32_t priority_rule);
+/* Small pools of envs with 33..64 participants (at most 4 x the device's CUs envs, no IoU events): the fused step gives every
+ * env a workgroup of its own and runs its event stages on four waves side by side (pairs / static polygons / two halves of the
+ * lane polygons) instead of one wave walking through all of them -- same arithmetic, same results, a shorter dependent
+ * chain per env.  Only pools whose envs carry static obstacles AND lanes take it (a pool with nothing to run side by side is
+ * slower that way).  On by default (t2d_step and t2d_step_n alike); 0 keeps one wave per env.                              */
+int t2d_set_split_step(t2d_pool* pool, int32_t on);
+/* Which form of the step kernel a call with n_steps steps takes on this pool now (diagnostics, tests, bench lines):        */
+enum {
+    T2D_FORM_UNFUSED = 0,     /* separate integrate + check_status launches, or helper kernels around the fused step */
+    T2D_FORM_STEP = 1,        /* one fused launch per step, one wave per env (or per 2..64 small envs)                 */
+    T2D_FORM_STEP_SPLIT = 2,  /* one fused launch per step, one workgroup per env                                      */
+    T2D_FORM_EGO = 3,         /* single-ego kernel, one launch per step                                                */
+    T2D_FORM_EGO_LOOP = 4,    /* single-ego kernel, the lanes loop over the steps                                      */
+    T2D_FORM_CHAIN = 5,       /* one launch of (workgroup, step) workgroups ordered by counters                        */
+    T2D_FORM_CHAIN_SPLIT = 6, /* the same with one workgroup per env                                                   */
+    T2D_FORM_LOOP = 7         /* resident workgroups loop over the steps                                               */
+};
+int t2d_step_form(t2d_pool* pool, int32_t n_steps);   /* a T2D_FORM_* value; -1: null pool */
 
 /* Zero-copy device pointer of a field (for wrapping as a torch tensor).                 */
 int t2d_get_field(t2d_pool* pool, int32_t field_id, void** dev_ptr, size_t* nbytes);

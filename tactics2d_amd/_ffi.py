@@ -59,6 +59,8 @@ SYMBOLS = {
     "t2d_step": (C.c_int, [_vp, C.c_int32, _vp]),
     "t2d_step_n": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int64, _vp]),
     "t2d_set_step_chaining": (C.c_int, [_vp, C.c_int32, C.c_int32]),
+    "t2d_set_split_step": (C.c_int, [_vp, C.c_int32]),
+    "t2d_step_form": (C.c_int, [_vp, C.c_int32]),
     "t2d_set_fused_step": (C.c_int, [_vp, C.c_int32]),
     "t2d_set_ego_kernel": (C.c_int, [_vp, C.c_int32]),
     "t2d_step_groups": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, C.c_int32]),

@@ -1147,6 +1147,15 @@ int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     return record_event(p, 0, s, false);
 }
 
+// small pools of 33..64-agent envs: the fused step gives every env a workgroup of its own (collide_kernel<..., SPLIT>)
+static bool use_split(t2d_pool* p) {
+    if (!p->split_steps) return false;
+    if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
+    int log2A = 1;
+    while ((1 << log2A) < p->v.A) ++log2A;
+    return t2d::split_eligible(p->v, p->status_cfg, log2A, p->device_cus);
+}
+
 static int collide_impl(t2d_pool* p, bool with_status, int interval_ms, hipStream_t s, int fuse_variant = -1) {
     int rc;
     touch(p, s);
@@ -1157,8 +1166,11 @@ static int collide_impl(t2d_pool* p, bool with_status, int interval_ms, hipStrea
     // keeps such a pool on the general kernel: the two are held against each other in tests/test_gpu_ego.py)
     if (fuse_variant >= 0 && p->ego_kernel && p->v.A == 1 && p->all_boxes && !p->has_drift && !p->hgeo[1].present)
         T2D_HIP(p, t2d::launch_ego_step(p->v, p->status_cfg, interval_ms, fuse_variant, s));
-    else
-        T2D_HIP(p, t2d::launch_collide(p->v, p->status_cfg, with_status, interval_ms, fuse_variant, s));
+    else {
+        t2d::PoolView v = p->v;
+        v.split_step = fuse_variant >= 0 && use_split(p);
+        T2D_HIP(p, t2d::launch_collide(v, p->status_cfg, with_status, interval_ms, fuse_variant, s));
+    }
     return record_event(p, kid, s, false);
 }
 
@@ -1283,13 +1295,14 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
         v.chain_done = p->d_chain;
         v.chain_err = reinterpret_cast<uint32_t*>(p->d_chain + p->chain_slots);
         v.chain_base = p->chain_count;
-        v.chain_real_wgs = (p->v.n_env + p->v.geo_layout.epb - 1) / p->v.geo_layout.epb;
+        v.split_step = use_split(p);
+        v.chain_real_wgs = v.split_step ? p->v.n_env : (p->v.n_env + p->v.geo_layout.epb - 1) / p->v.geo_layout.epb;
         v.chain_act_step = act_step_stride;
         // pools whose step launch is at most two workgroups per CU (all resident at once): the workgroups loop over the
         // steps themselves; larger pools chain one workgroup per (env set, step)
         {
             if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
-            v.loop_steps = (p->chain_loop && p->device_cus > 0 && v.chain_real_wgs <= 2 * p->device_cus) ? n : 0;
+            v.loop_steps = (!v.split_step && p->chain_loop && p->device_cus > 0 && v.chain_real_wgs <= 2 * p->device_cus) ? n : 0;
         }
         v.record_ring = (uint2*)p->field_ptr[T2D_F_RECORD];
         v.record_slot0 = slot0;
@@ -1307,6 +1320,27 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
     }
     p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] + (size_t)((p->step_count + T2D_RECORD_RING - 1) % T2D_RECORD_RING) * p->v.n_env;
     return rc;
+}
+
+int t2d_step_form(t2d_pool* p, int32_t n_steps) {
+    if (!p) return -1;
+    const bool ego = p->ego_kernel && p->v.A == 1 && p->all_boxes && !p->has_drift && !p->hgeo[1].present;
+    const bool iou = p->status_cfg.check_no_action || p->status_cfg.check_arrival;
+    if (!p->fused_step || p->idm_on || p->has_drift || p->scene_regen) return T2D_FORM_UNFUSED;
+    const bool chain = p->chain_steps && n_steps >= 2 && (ego ? p->chain_loop : !iou);
+    if (ego) return chain ? T2D_FORM_EGO_LOOP : T2D_FORM_EGO;
+    const bool split = use_split(p);
+    if (!chain) return split ? T2D_FORM_STEP_SPLIT : T2D_FORM_STEP;
+    if (split) return T2D_FORM_CHAIN_SPLIT;
+    const int wgs = (p->v.n_env + p->v.geo_layout.epb - 1) / p->v.geo_layout.epb;
+    if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
+    return (p->chain_loop && p->device_cus > 0 && wgs <= 2 * p->device_cus) ? T2D_FORM_LOOP : T2D_FORM_CHAIN;
+}
+
+int t2d_set_split_step(t2d_pool* p, int32_t on) {
+    if (!p) return T2D_ERR_INVALID;
+    p->split_steps = on != 0;
+    return T2D_OK;
 }
 
 int t2d_set_step_chaining(t2d_pool* p, int32_t on, int32_t priority_rule) {

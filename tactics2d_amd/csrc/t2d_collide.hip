@@ -306,10 +306,17 @@ T2D_DEV unsigned long long chain_word(uint32_t steps_done) {   // {steps done, X
 // the metric launch's four waves per SIMD it costs 150 spill slots.  A step of these pools is one wave per
 // SIMD walking a dependent chain: the launch boundary, the start-up and the state's round trip through memory are a
 // third of it.
-template <bool WITH_STATUS, int FUSE, bool IOU = true, bool CHAIN = false, bool LOOP = false>
+// SPLIT = true (pools of at most four waves per SIMD when every env gets a workgroup: <= 4 x CUs envs of 33..64 participants):
+// ONE env per workgroup and its event stages on four waves side by side -- wave 0 integrates, then all four derive the poses
+// (the same instructions four times over, instead of a hand-over), then wave 0 takes the pairs, wave 1 the static polygons,
+// waves 2 and 3 a half of the lane polygons each, and wave 0 reduces and runs the epilogue.  A step of such a pool is one
+// wave per SIMD walking a 3300-instruction dependent chain on an otherwise idle SIMD; this way the chain is the integrator
+// plus the longest stage (~2000 instructions) and the idle SIMDs do the other stages.  Same arithmetic, same flags.
+template <bool WITH_STATUS, int FUSE, bool IOU = true, bool CHAIN = false, bool LOOP = false, bool SPLIT = false>
 __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv_arg, t2d_status_config cfg_arg,
                                                                                        int interval_ms, int log2A) {
     static_assert(!(CHAIN && LOOP) && (!LOOP || (FUSE >= 0 && WITH_STATUS)), "LOOP = the fused step, not combined with CHAIN");
+    static_assert(!SPLIT || (!LOOP && FUSE >= 0 && WITH_STATUS && !IOU), "SPLIT = the fused step of a plain pool, one launch or chained");
     // `pv` / `cfg` below: the two argument structs -- directly, or (LOOP) through a pointer into the kernel's argument block
     // that is laundered again at the top of every trip, so that what a trip reads of them cannot be hoisted out of the loop:
     // left alone the compiler keeps every invariant argument load live across the whole body (225 spilled scalars, 57
@@ -344,6 +351,9 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     // per env: episode finished.  Shares s_env_or: slot env_local is only ever touched by that env's own
     // lanes, and it is consumed (env_flags written) before it is reused
     int* const s_done = reinterpret_cast<int*>(s_env_or);
+    // SPLIT: what wave 0's integrator hands the other three waves -- new x, y, heading and the ids word of every participant
+    __shared__ float s_new[SPLIT ? 3 : 1][SPLIT ? 64 : 1];
+    __shared__ uint32_t s_ids_new[SPLIT ? 64 : 1];
     extern __shared__ __attribute__((aligned(16))) uint32_t s_geo[];  // packed geometry record
 
     // Every kernel argument the start-up phase needs, requested in ONE scalar round trip.  Left to itself the compiler
@@ -367,32 +377,39 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     // Placement of the step launch (t2d_debug_set_step_placement): which logical workgroup -- which EPB envs -- this physical
     // workgroup steps, and by how many waves its lane -> participant map is rotated.  Results do not depend on it; the
     // hardware places workgroup b on XCD b mod 8 and its waves on fixed SIMDs, so the map decides which envs share a SIMD.
-    int wg = blockIdx.x, wave_rot = 0;
+    // what this workgroup stands for: a set of EPB envs = one geometry record -- or (SPLIT) ONE env, whose record it shares
+    const int unit = blockIdx.x;
+    int wg = SPLIT ? unit / a_epb : unit, wave_rot = 0;
     int step_k = CHAIN ? (int)blockIdx.y : 0;
-    if (CHAIN && wg >= pv.chain_real_wgs) {   // padding of the grid's x extent to a multiple of 8 (see launch_step_chain)
+    if (CHAIN && unit >= pv.chain_real_wgs) {   // padding of the grid's x extent to a multiple of 8 (see launch_step_chain)
         if (threadIdx.x == 0)
-            __hip_atomic_store(&pv.chain_done[wg], chain_word(pv.chain_base + (uint32_t)step_k + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&pv.chain_done[unit], chain_word(pv.chain_base + (uint32_t)step_k + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    if (!CHAIN && pv.wgmap) {
+    if (!CHAIN && !SPLIT && pv.wgmap) {
         const uint32_t m = pv.wgmap[blockIdx.x];
         wg = (int)(m & 0xffffu);
         wave_rot = (int)(m >> 16);
     }
-    const int tid = blockDim.x == kBlock ? (int)((threadIdx.x + 64u * (unsigned)wave_rot) & (kBlock - 1u)) : (int)threadIdx.x;
+    // `tid` = the participant's slot in the workgroup's LDS tables.  SPLIT: the four waves all stand for the env's 64 slots;
+    // `role` tells them apart and `ptid` is the thread's own number (what the staging loops stride by)
+    const int role = SPLIT ? (int)(threadIdx.x >> 6) : 0;
+    const int ptid = (int)threadIdx.x;
+    const int tid = SPLIT ? (int)(threadIdx.x & 63u)
+                          : (blockDim.x == kBlock ? (int)((threadIdx.x + 64u * (unsigned)wave_rot) & (kBlock - 1u)) : (int)threadIdx.x);
     [[maybe_unused]] const int lane = tid & 63;   // (the step body derives its own lane coordinates: see the loop below)
     const int A_pad = 1 << log2A;
     const int EPB = a_epb;
     const int nthreads = EPB << log2A;
-    const int env_local = tid >> log2A;
+    const int env_local = SPLIT ? unit % EPB : tid >> log2A;   // the env's place in its geometry record
     const int agent = tid & (A_pad - 1);
-    const int env = wg * EPB + env_local;
+    const int env = SPLIT ? unit : wg * EPB + env_local;
     const bool valid = env < a_n_env && agent < a_A;
     [[maybe_unused]] const int idx = valid ? env * a_A + agent : 0;
     const bool use_hash_grid = log2A > 6;  // envs larger than a wave use the LDS spatial hash
     const int H = 2 * A_pad;               // buckets per env (power of two)
-    [[maybe_unused]] uint32_t* const queue = s_queue[tid >> 6];
-    [[maybe_unused]] int* const qcount = &s_qcount[tid >> 6];
+    [[maybe_unused]] uint32_t* const queue = s_queue[SPLIT ? role : tid >> 6];
+    [[maybe_unused]] int* const qcount = &s_qcount[SPLIT ? role : tid >> 6];
 
 #ifdef T2D_TIMING
     unsigned long long t_prev_ = __builtin_readcyclecounter();
@@ -416,12 +433,12 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     if (behind_first) __builtin_amdgcn_s_setprio(3);
     // chained launch: wait for the step before this one of the same envs (one lane polls, s_sleep between polls)
     auto chain_wait = [&]() {
-        if (tid == 0) {
+        if (ptid == 0) {
             const uint32_t want = pv.chain_base + (uint32_t)step_k;
             int spins = 0;
             unsigned long long w;
             // (a signed difference: the counter may wrap after 2^32 steps of a pool)
-            while ((int32_t)((uint32_t)(w = __hip_atomic_load(&pv.chain_done[wg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - want) < 0) {
+            while ((int32_t)((uint32_t)(w = __hip_atomic_load(&pv.chain_done[unit], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - want) < 0) {
                 __builtin_amdgcn_s_sleep(2);
                 ++spins;
                 // give up when the wait ran out -- or when another workgroup's did (checked now and then): one failure
@@ -467,13 +484,14 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     if constexpr (LOOP) asm volatile("" : "+v"(tid_l));
     const int tid = tid_l;
     const int lane = tid & 63;
-    const int env_local = tid >> log2A;
+    const int env_local = SPLIT ? unit % EPB : tid >> log2A;
+    const int slot0 = SPLIT ? 0 : env_local << log2A;   // first LDS slot of the lane's env
     const int agent = tid & (A_pad - 1);
-    const int env = wg * EPB + env_local;
+    const int env = SPLIT ? unit : wg * EPB + env_local;
     const bool valid = env < a_n_env && agent < a_A;
     const int idx = valid ? env * a_A + agent : 0;
-    uint32_t* const queue = s_queue[tid >> 6];
-    int* const qcount = &s_qcount[tid >> 6];
+    uint32_t* const queue = s_queue[SPLIT ? role : tid >> 6];
+    int* const qcount = &s_qcount[SPLIT ? role : tid >> 6];
     if constexpr (LOOP) {
         pvp = late_args();
         cfgp = (const __attribute__((address_space(4))) t2d_status_config*)((const __attribute__((address_space(4))) char*)late_args() + kCfgArgOffset);
@@ -490,7 +508,7 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     int pre_cnt = 0, pre_frame = 0;
     if (CHAIN && step_k > 0) chain_wait();
     const bool carried = LOOP && step_k > 0;   // (LOOP: the second and later trips take their inputs from registers)
-    if (valid) {
+    if (valid && (!SPLIT || role == 0)) {   // (SPLIT: wave 0 loads and integrates; the others get the new state through LDS)
         if (carried) {
             ids = c_ids; fx = c_x; fy = c_y; fh = c_h; fv = c_v; fa0 = n_a0; fa1 = n_a1;
         } else {
@@ -526,11 +544,11 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
         constexpr int kTab = kTabCols * T2D_MAX_TYPES;
         if (nthreads == kBlock) {   // the usual launch shape: 3 x 8 B per thread, no per-load bounds logic
             static_assert(kTab <= 3 * kBlock && kTab > 2 * kBlock, "staging below assumes 2 full rounds + a partial one");
-            const double t0 = a_params[tid], t1 = a_params[tid + kBlock];
-            const double t2 = tid + 2 * kBlock < kTab ? a_params[tid + 2 * kBlock] : 0.0;
-            s_partab[tid] = t0;
-            s_partab[tid + kBlock] = t1;
-            if (tid + 2 * kBlock < kTab) s_partab[tid + 2 * kBlock] = t2;
+            const double t0 = a_params[ptid], t1 = a_params[ptid + kBlock];
+            const double t2 = ptid + 2 * kBlock < kTab ? a_params[ptid + 2 * kBlock] : 0.0;
+            s_partab[ptid] = t0;
+            s_partab[ptid + kBlock] = t1;
+            if (ptid + 2 * kBlock < kTab) s_partab[ptid + 2 * kBlock] = t2;
         } else {                    // workgroups narrowed by the geometry budget (64 or 128 threads)
             double tstage[12];
 #pragma unroll
@@ -561,28 +579,30 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
         // the unrolled generic form spends more on its per-load bounds logic than on the loads
         const int rounds = stage_tables ? (n_vec + nthreads - 1) / nthreads : 0;
         u32x4 geo_stage0 = {0u, 0u, 0u, 0u};
+        const int gtid = SPLIT ? ptid : tid;   // (the thread's own number: SPLIT's `tid` is the participant slot)
         if (rounds <= 1) {
-            if (tid < n_vec && rounds == 1) geo_stage0 = gsrc[tid];
+            if (gtid < n_vec && rounds == 1) geo_stage0 = gsrc[gtid];
         } else {
             // big records (many envs or many polygons per workgroup, e.g. 32 parking lots = 30 KiB for 32 threads):
             // global_load_lds -- 16 B per lane straight into LDS at M0 + lane * 16, no staging registers -- so ALL
             // rounds are in flight together and one memory latency is exposed instead of one per 8 loads
             for (int k = 0; k < rounds; ++k) {
-                const int q = tid + k * nthreads;
+                const int q = gtid + k * nthreads;
                 if (q < n_vec)
                     __builtin_amdgcn_global_load_lds(
                         (const __attribute__((address_space(1))) void*)(gsrc + q),
-                        (__attribute__((address_space(3))) void*)(s_geo + 4 * (k * nthreads + (tid & ~63))), 16, 0, 0);
+                        (__attribute__((address_space(3))) void*)(s_geo + 4 * (k * nthreads + (gtid & ~63))), 16, 0, 0);
             }
         }
         if (use_hash_grid)
             for (int k = tid; k < EPB * H; k += nthreads) s_head[k] = -1;
         if (LOOP) {   // (every wave clears what is its envs' own: the waves of a LOOP launch do not wait for each other)
             if (agent == 0) s_env_or[env_local] = 0;
-        } else if (tid < kBlock / 2) {
-            s_env_or[tid] = 0;
+        } else if (gtid < kBlock / 2) {
+            s_env_or[gtid] = 0;
         }
         s_flags[tid] = 0;
+        if (SPLIT && role == 0) s_ids_new[tid] = ids;   // (0 for a slot without a participant)
         if (FUSE < 0) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -591,7 +611,7 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
             }
         }
         if (rounds <= 1) {
-            if (tid < n_vec && rounds == 1) reinterpret_cast<u32x4*>(s_geo)[tid] = geo_stage0;
+            if (gtid < n_vec && rounds == 1) reinterpret_cast<u32x4*>(s_geo)[gtid] = geo_stage0;
         } else {
             __builtin_amdgcn_s_waitcnt(0);  // the LDS-direct loads are tracked by vmcnt: all landed before the barrier
         }
@@ -601,10 +621,11 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     if (carried && log2A <= 6) wave_sync(); else __syncthreads();
     T2D_MARK(0);
 
+    if (SPLIT) ids = s_ids_new[tid];
     const bool active = valid && ((ids >> kIdsActiveShift) & 0xffu);
     const int type = (ids >> kIdsTypeShift) & 0xff;
     // (SingleTrackDrift lanes were integrated by drift_kernel, launched before this one)
-    if (FUSE >= 0 && active && ((ids >> kIdsModelShift) & 0xff) != T2D_MODEL_DRIFT) {
+    if (FUSE >= 0 && active && ((ids >> kIdsModelShift) & 0xff) != T2D_MODEL_DRIFT && (!SPLIT || role == 0)) {
         // ---------------- fused physics: one PhysicsModelBase.step in registers ----------------
         const int model = (ids >> kIdsModelShift) & 0xff;
         auto P = [&](int col) -> double { return s_partab[col * T2D_MAX_TYPES + type]; };
@@ -640,6 +661,17 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
             pv.applied0[idx] = (float)o.app0;
             pv.applied1[idx] = (float)o.app1;
         }
+    }
+    if (SPLIT) {   // the new state, from wave 0 to the three waves that take the other event stages
+        if (role == 0) {
+            s_new[0][tid] = fx;
+            s_new[1][tid] = fy;
+            s_new[2][tid] = fh;
+        }
+        __syncthreads();
+        fx = s_new[0][tid];
+        fy = s_new[1][tid];
+        fh = s_new[2][tid];
     }
     T2D_MARK(13);
     double pre_tp = 0.0;
@@ -867,9 +899,14 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     // each): alternating waves and workgroup rounds, as before.
     const bool polys_first = log2A <= 6 && (pv.overlapped ? ((((int)blockIdx.x >> 8) + (tid >> 6)) & 1) != 0
                                                           : (((int)blockIdx.x >> 9) & 1) != 0);
-    for (int stage_it = 0; stage_it < 2; ++stage_it) {
+    if (gl2.has[1] && !(T2D_PROBE_SKIP & 8)) {
+        const int* pstart = geo_i + gl2.off_pstart[1];
+        n_lane_polys = pstart[env_local + 1] - pstart[env_local];
+    }
+    // (SPLIT: one pass -- wave 0 takes the pair stage, the others the polygon stages, each its part: see below)
+    for (int stage_it = 0; stage_it < (SPLIT ? 1 : 2); ++stage_it) {
     if (behind_first && stage_it == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
-    if ((stage_it == 0) != polys_first) {
+    if (SPLIT ? role == 0 : (stage_it == 0) != polys_first) {
     if (T2D_PROBE_SKIP & 1) {
     } else if (!use_hash_grid) {
         // every lane against all agents of its env: fp32 circles, 1 cm margin (strictly
@@ -947,7 +984,7 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
         }
         T2D_MARK(3);
         if (!active || (T2D_PROBE_SKIP & 2)) cand = 0ull;
-        compact_and_process<false, true>(cand, (env_local << log2A), tid, queue, qcount, lane, process_pair, true, A_pad - 1);
+        compact_and_process<false, true>(cand, slot0, tid, queue, qcount, lane, process_pair, true, A_pad - 1);
     } else {
         // spatial-hash walk; pairs go straight to the narrow phase (i < j de-duplicates)
         if (active) {
@@ -1037,17 +1074,20 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
             }
         };
         const f2p bxp = {-box_hi_x, box_lo_x}, byp = {-box_hi_y, box_lo_y};
-        if (gl2.has[0] && !(T2D_PROBE_SKIP & 4)) {   // static obstacles
+        if (gl2.has[0] && !(T2D_PROBE_SKIP & 4) && (!SPLIT || role == 1)) {   // static obstacles
             const int* pstart = geo_i + gl2.off_pstart[0];
             sweep_stage(reinterpret_cast<const float4*>(s_geo + gl2.off_aabb[0]), pstart[env_local], pstart[env_local + 1], active,
                         bxp, byp, process_static, 5);
         }
-        if (gl2.has[1] && !(T2D_PROBE_SKIP & 8)) {   // lanes: off-lane = not union(lanes).contains(pose)
+        if (gl2.has[1] && !(T2D_PROBE_SKIP & 8) && (!SPLIT || role >= 2)) {   // lanes: off-lane = not union(lanes).contains(pose)
             const int* pstart = geo_i + gl2.off_pstart[1];
-            const int p0 = pstart[env_local], p1 = pstart[env_local + 1];
-            n_lane_polys = p1 - p0;
-            const bool want = active && !lane_safe;   // (poses in a safe rectangle are done)
-            if (__ballot(want) != 0ull)
+            int p0 = pstart[env_local], p1 = pstart[env_local + 1];
+            if (SPLIT) {   // waves 2 and 3: the first and the second half of the env's lane polygons
+                const int mid = p0 + ((p1 - p0 + 1) >> 1);
+                if (role == 2) p1 = mid; else p0 = mid;
+            }
+            const bool want = active && !lane_safe && p1 > p0;   // (poses in a safe rectangle are done)
+            if (__ballot(want) != 0ull)   // (wave-uniform: the lanes of a wave may belong to different envs)
                 sweep_stage(reinterpret_cast<const float4*>(s_geo + gl2.off_aabb[1]), p0, p1, want, bxp, byp, process_lane, 7);
         }
     }
@@ -1079,7 +1119,7 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     // the status epilogue's inputs, requested now by the lane that will run it (agent 0): the reduce hides part of their
     // latency.  (Fetched at the top of the kernel they sat in registers through every event phase, and at the 128
     // registers of 4 waves / SIMD that meant scratch spills: 8 B per lane stored and re-read, 13 MB of HBM traffic.)
-    if (WITH_STATUS && valid && agent == 0) {
+    if (WITH_STATUS && valid && agent == 0 && (!SPLIT || role == 0)) {
         if (carried) {
             pre_cnt = c_cnt;
             pre_frame = c_frame;
@@ -1093,8 +1133,9 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
         }
     }
     T2D_MARK(9);
-    if (log2A <= 6) wave_sync(); else __syncthreads();  // (c) every queue drained: s_flags complete
+    if (log2A <= 6 && !SPLIT) wave_sync(); else __syncthreads();  // (c) every queue drained: s_flags complete
     T2D_MARK(10);
+    if (!SPLIT || role == 0) {   // (SPLIT: the reduce, the epilogue and the restore are wave 0's)
     uint32_t f = 0;
     if (active) {
         const uint32_t sf = s_flags[tid];
@@ -1117,7 +1158,7 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     // below exactly as before; an unused value is simply dropped.
     double iou_na = 0.0, iou_ar = 0.0;
     if (WITH_STATUS && IOU && (cfg.check_no_action || cfg.check_arrival)) {
-        const int ego_l = (env_local << log2A) + cfg.ego_index;
+        const int ego_l = slot0 + cfg.ego_index;
         const bool env_ok = env < pv.n_env && agent < 2;
         bool want = false;
         const double* other = nullptr;
@@ -1147,7 +1188,7 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
                 c_cnt = cnt;
                 c_frame = pre_frame + interval_ms;
             }
-            const int ego = (env_local << log2A) + cfg.ego_index;  // workgroup-local lane of the ego
+            const int ego = slot0 + cfg.ego_index;  // workgroup-local lane of the ego
             const uint32_t ef = s_flags[ego];
             int scen = T2D_SCENARIO_NORMAL, traf = T2D_TRAFFIC_NORMAL;
             double iou = 0.0;
@@ -1297,6 +1338,7 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
             }
         }
     }
+    }   // (wave 0 of a SPLIT workgroup)
     T2D_MARK(12);
     if (!LOOP) break;
     // LOOP: nothing is read back from memory (see `carried`); what the next trip clears in LDS is the wave's own when an env
@@ -1307,8 +1349,8 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     if (CHAIN) {   // this step of these envs is complete: every store above is in the L2 before the word moves
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(&pv.chain_done[wg], chain_word(pv.chain_base + (uint32_t)step_k + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ptid == 0)
+            __hip_atomic_store(&pv.chain_done[unit], chain_word(pv.chain_base + (uint32_t)step_k + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #undef pv
 #undef cfg
@@ -1330,12 +1372,30 @@ hipError_t step_occupancy(const PoolView& v, int* blocks_per_cu, size_t* lds_byt
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, collide_kernel<true, 1, false>, block, dyn);
 }
 
+// SPLIT (one env per workgroup, its event stages on four waves): envs of 33..64 participants, workgroups of the full
+// 256 threads, no IoU events, and few enough envs for every workgroup of a step to be resident (four per CU)
+bool split_eligible(const PoolView& v, const t2d_status_config& cfg, int log2A, int device_cus) {
+    // ... and only where there is something to run side by side: envs with static obstacles next to their lanes (measured:
+    // roundabout / intersection pools gain 7-10 %; a highway pool -- pairs and a few lane rectangles, nothing else -- loses 9 %
+    // to the extra barriers and the poses derived four times)
+    return log2A == 6 && v.geo_layout.epb == 4 && !(cfg.check_no_action || cfg.check_arrival) && device_cus > 0 &&
+           v.n_env <= 4 * device_cus && !v.wgmap && v.geo && v.geo_layout.has[0] && v.geo_layout.has[1];
+}
+
 hipError_t launch_step_chain(const PoolView& v, const t2d_status_config& cfg, int interval_ms, int variant, int n_steps,
                              hipStream_t s) {
     int log2A = 1;
     while ((1 << log2A) < v.A) ++log2A;
     const int EPB = v.geo_layout.epb;
     if (cfg.check_no_action || cfg.check_arrival) return hipErrorInvalidValue;   // (see below)
+    if (v.split_step) {   // small pool of 64-agent envs: one env per workgroup, chained per env
+        const int padded = (v.n_env + 7) & ~7;
+        const dim3 grid(padded, n_steps), block(kBlock);
+        const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
+        if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, true, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        else hipLaunchKernelGGL((collide_kernel<true, 1, false, true, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        return hipGetLastError();
+    }
     if (v.loop_steps > 0) {   // small pool: every workgroup resident, each walks through the steps itself
         const dim3 grid((v.n_env + EPB - 1) / EPB), block(EPB << log2A);
         const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
@@ -1364,6 +1424,12 @@ hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool 
     const dim3 grid((v.n_env + EPB - 1) / EPB), block(EPB << log2A);
     const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
     const bool iou = cfg.check_no_action || cfg.check_arrival;
+    if (fuse_variant >= 0 && v.split_step) {
+        const dim3 sgrid(v.n_env), sblock(kBlock);
+        if (fuse_variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, false, true>), sgrid, sblock, dyn, s, v, cfg, interval_ms, log2A);
+        else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, false, true>), sgrid, sblock, dyn, s, v, cfg, interval_ms, log2A);
+        return hipGetLastError();
+    }
     if (fuse_variant >= 0) {  // the fused step always runs the status epilogue
         if (fuse_variant == 0) {
             if (iou) hipLaunchKernelGGL((collide_kernel<true, 0, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);

@@ -102,6 +102,7 @@ struct PoolView {
     uint32_t* chain_err;        // 1: a workgroup's wait ran out, 2: its predecessor ran on another XCD (never expected; the host checks)
     uint32_t chain_base;        // what chain_done[] holds when this launch starts
     int32_t chain_real_wgs;     // workgroups that own envs; the grid's x extent is rounded up to a multiple of 8
+    int32_t split_step;         // the step launch gives every env a workgroup of its own (SPLIT form, small pools of 64-agent envs)
     int32_t loop_steps;         // > 0: the LOOP form -- every workgroup walks through this many steps itself (small pools)
     int64_t chain_act_step;     // elements between the action sets of consecutive steps (0: the same actions every step)
     uint2* record_ring;         // the whole ring of per-env result records; step k writes slot (record_slot0 + k) % ring
@@ -240,6 +241,7 @@ struct t2d_pool {
     uint32_t chain_count = 0;      // what every counter holds once the launches enqueued so far have run
     bool chain_steps = true;       // t2d_set_step_chaining(pool, 0, *): t2d_step_n falls back to one launch per step
     bool chain_loop = true;        // small pools take the LOOP form (t2d_set_step_chaining(pool, 2, *): never)
+    bool split_steps = true;       // small pools of 64-agent envs step with one env per workgroup (t2d_set_split_step)
     bool chain_priority = true;    // wave priorities of a chained launch: 1 = the rule for overlapping work (PoolView::overlapped)
     bool chain_used = false, chain_failed = false;
     int device_cus = 0;            // compute units of the pool's device (read once)
@@ -285,6 +287,7 @@ hipError_t launch_idm(const PoolView& v, const IdmView& iv, const int32_t* force
 hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
                           hipStream_t s);
 hipError_t launch_spin(long long ticks_100mhz, hipStream_t s);
+bool split_eligible(const PoolView& v, const t2d_status_config& cfg, int log2A, int device_cus);
 hipError_t launch_parking_scenes(const PoolView& v, const SceneView& sv, int n_env, int mode, hipStream_t s);
 hipError_t launch_scene_refill(const SceneView& sv, int n_env, hipStream_t s);
 }  // namespace t2d

@@ -263,6 +263,19 @@ class ParticipantPool:
         act[i * stride + k * act_step_stride]; 0 repeats one action set.  Same results as n_steps `step` calls."""
         self._ck(self._lib.t2d_step_n(self._h, int(interval_ms), int(n_steps), int(act_step_stride), stream))
 
+    def set_split_step(self, on=True):
+        """Small pools of 33..64-agent envs: one env per workgroup, its event stages on four waves (t2d_set_split_step)."""
+        self._ck(self._lib.t2d_set_split_step(self._h, int(bool(on))))
+
+    STEP_FORMS = ("unfused", "step", "step_split", "ego", "ego_loop", "chain", "chain_split", "loop")
+
+    def step_form(self, n_steps=1):
+        """Name of the step-kernel form a call of n_steps steps takes on this pool now (t2d_step_form)."""
+        rc = self._lib.t2d_step_form(self._h, int(n_steps))
+        if rc < 0:
+            raise ValueError("t2d_step_form: null pool")
+        return self.STEP_FORMS[rc]
+
     def set_step_chaining(self, on=True, priority_rule=1):
         self._ck(self._lib.t2d_set_step_chaining(self._h, int(bool(on)), int(priority_rule)))
 

@@ -154,3 +154,47 @@ def test_single_ego_pools_loop_through_arrivals_no_action_and_time_limits():
     seen = set(map(tuple, np.stack([rec[..., 1] & 0xff, (rec[..., 1] >> 8) & 0xff], -1).reshape(-1, 2).tolist()))
     assert {(1, 1), (2, 1), (1, 5), (3, 1)} <= seen, seen     # normal, completed, no-action quirk, time exceeded
     _compare(Calm(sc), 40, "fast", calls=(40,))
+
+
+def test_one_workgroup_per_env_form_equals_one_wave_per_env():
+    """Small pools of 64-agent envs with obstacles and lanes run each env's event stages on four waves side by side
+    (collide_kernel<..., SPLIT>): every field after 40 steps -- as single launches and as chained fragments -- equals what the
+    one-wave-per-env form leaves behind, auto-resets included.  A highway pool (no static obstacles) does not take that form."""
+    torch = pytest.importorskip("torch")
+    from tactics2d_amd import layout as L, scenarios as S
+    dev = torch.device("cuda", 0)
+    for sc, A_real in ((S.mixed(150, 64, seed=11), 64), (S.mixed(37, 40, seed=12), 40)):   # 40: 24 empty lanes per env
+        rng = np.random.default_rng(7)
+        sets = [sc.sample_actions(rng) for _ in range(40)]
+        a0 = torch.from_numpy(np.stack([s[0] for s in sets])).to(dev).contiguous()
+        a1 = torch.from_numpy(np.stack([s[1] for s in sets])).to(dev).contiguous()
+        outs = {}
+        for split in (False, True):
+            for chained in (False, True):
+                pool = _pool(sc, "exact")
+                pool.set_split_step(split)
+                assert pool.step_form(1) == ("step_split" if split else "step")
+                assert pool.step_form(8) == ("chain_split" if split else "loop")
+                if chained:
+                    done = 0
+                    for c in (7, 1, 32):
+                        pool.bind_actions(a0.data_ptr() + 4 * sc.n * done, a1.data_ptr() + 4 * sc.n * done)
+                        pool.step_n(c, sc.interval_ms, sc.n)
+                        done += c
+                else:
+                    for k in range(40):
+                        pool.bind_actions(a0.data_ptr() + 4 * sc.n * k, a1.data_ptr() + 4 * sc.n * k)
+                        pool.step(sc.interval_ms)
+                outs[(split, chained)] = [pool.download(f) for f in _fields()]
+                pool.close()
+        want = outs[(False, False)]
+        rec = want[_fields().index(L.F_RECORD)].reshape(L.RECORD_RING, sc.n_env, 2)
+        assert (rec[:40, :, 1] >> 16).astype(bool).any(), "no episode ended: the reset path of the split form was not exercised"
+        fl = want[_fields().index(L.F_FLAGS)]
+        assert (fl & 1).any() and (fl & 8).any(), "no collision / off-lane flag in the comparison"
+        for key, got in outs.items():
+            for f, g, w in zip(_fields(), got, want):
+                assert np.array_equal(g, w, equal_nan=True), (key, f, int((g != w).sum()))
+    hw = _pool(S.highway(64, 64, seed=2), "exact")
+    assert hw.step_form(1) == "step" and hw.step_form(8) == "loop"
+    hw.close()
