@@ -15,19 +15,33 @@ def find(d, suffix):
 
 
 def short(name):
-    """collide_kernel<WITH_STATUS, FUSE, IOU, CHAIN>: FUSE >= 0 is the fused step launch, CHAIN the multi-step launch"""
+    """collide_kernel<WITH_STATUS, FUSE, IOU, CHAIN, LOOP, SPLIT>: FUSE >= 0 is the fused step launch; CHAIN / LOOP are the two
+    multi-step forms (one workgroup per (env set, step) / resident workgroups looping over the steps), SPLIT one workgroup
+    per env; ego_step_kernel<VARIANT, LOOP> likewise"""
     n = name.replace(" ", "")
     m = re.search(r"collide_kernel<([^>]*)>", n)
     if m:
-        a = m.group(1).split(",")
+        a = m.group(1).split(",") + ["false"] * 6
         if a[1] == "-1":
             return "collide_kernel"
-        return "step_kernel_chained" if len(a) > 3 and a[3] == "true" else "step_kernel"
+        return "step_kernel" + ("_chained" if a[3] == "true" else "_loop" if a[4] == "true" else "") + ("_split" if a[5] == "true" else "")
+    m = re.search(r"ego_step_kernel<([^>]*)>", n)
+    if m and m.group(1).split(",")[-1] == "true":
+        return "ego_step_kernel_loop"
     for k in ("ego_step_kernel", "lidar_kernel", "idm_kernel", "parking_scene_kernel", "scene_refill_kernel", "integrate_kernel",
               "restore_env_kernel", "restore_kernel", "drift_kernel"):
         if k in n:
             return k
     return name[:40]
+
+
+def launch_steps(k, row, fragment):
+    """steps one launch of kernel k holds: the grid's y extent for the chained form, the bench's fragment for the loop forms"""
+    if k.startswith("step_kernel_chained"):
+        return max(1, int(row["Grid_Size_Y"]) // max(1, int(row["Workgroup_Size_Y"])))
+    if k.endswith("_loop") or "_loop_" in k:
+        return max(1, int(fragment))
+    return 1
 
 
 def steps_of(row, per_step_items):
@@ -58,9 +72,7 @@ for mode in ("chain", "step"):
         d = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
-            steps = 1
-            if k == "step_kernel_chained":
-                steps = max(1, int(r["Grid_Size_Y"]) // max(1, int(r["Workgroup_Size_Y"])))
+            steps = launch_steps(k, r, cfg.get("fragment", 32))
             d[k].append(((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, steps))
         kt[mode] = {k: dict(calls=len(v), avg_us=sum(x for x, _ in v) / len(v), steps_per_launch=sum(s for _, s in v) / len(v),
                             avg_us_per_step=sum(x for x, _ in v) / sum(s for _, s in v), min_us=min(x for x, _ in v),
@@ -80,7 +92,7 @@ def counters(d, names=None):
             k = short(r["Kernel_Name"])
             if names and r["Counter_Name"] not in names:
                 continue
-            s = steps_of(r, per_step_items) if k == "step_kernel_chained" else 1
+            s = steps_of(r, per_step_items) if k.startswith("step_kernel_chained") else 1
             a = res[k][r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += s
     return {k: {c: v[0] / v[1] for c, v in cs.items() if v[1]} for k, cs in res.items()}
@@ -129,13 +141,14 @@ for c in ("cfg2", "cfg3", "cfg4", "cfg5"):
         if not f:
             continue
         d = collections.defaultdict(lambda: [0.0, 0, 0])
+        line = [l for l in open(os.path.join(out, f"{c}_{mode}.log")) if l.startswith("{")]
+        frag_c = json.loads(line[-1]).get("config", {}).get("fragment", 32) if line else 32
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             if "kernel" not in k or "rocclr" in k:
                 continue
-            steps = max(1, int(r["Grid_Size_Y"]) // max(1, int(r["Workgroup_Size_Y"]))) if k == "step_kernel_chained" else 1
+            steps = launch_steps(k, r, frag_c)
             a = d[k]; a[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; a[1] += 1; a[2] += steps
-        line = [l for l in open(os.path.join(out, f"{c}_{mode}.log")) if l.startswith("{")]
         cfgs.setdefault(c, {})[mode] = dict(kernels={k: dict(calls=v[1], avg_us=v[0] / v[1], avg_us_per_step=v[0] / v[2]) for k, v in d.items()},
                                             bench_us_per_step=(1e3 * json.loads(line[-1])["ms_per_step"] if line else None))
 json.dump(dict(tag=tag, source_sha256=summary["source_sha256"], note="rocprofv3 --kernel-trace of python bench.py --config <cfg> --mode <mode> "
