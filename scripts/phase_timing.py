@@ -5,12 +5,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tactics2d_amd import _ffi, scenarios as S
 from tactics2d_amd.pool import ParticipantPool
 cfg = sys.argv[1] if len(sys.argv) > 1 else "metric"
-sc = {"metric": lambda: S.mixed(4096, 64, 3), "cfg3": lambda: S.highway(1024, 64), "cfg2": lambda: S.parking(4096)}[cfg]()
+sc = {"metric": lambda: S.mixed(4096, 64, 3), "cfg3": lambda: S.highway(1024, 64), "cfg2": lambda: S.parking(4096),
+      "cfg5": lambda: S.mixed(1024, 64, 3), "cfg5nosplit": lambda: S.mixed(1024, 64, 3), "cfg3split": lambda: S.highway(1024, 64)}[cfg]()
 pool = ParticipantPool(sc.n_env, sc.A); sc.load(pool)
+if cfg == "cfg5nosplit":
+    pool.set_split_step(False)
+split = pool.step_form(1) == "step_split"
 rng = np.random.default_rng(0)
 lib = _ffi.lib(); lib.t2d_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 log2A = int(np.ceil(np.log2(sc.A))); epb = 256 >> log2A
-n_blocks = (sc.n_env + epb - 1) // epb
+n_blocks = sc.n_env if split else (sc.n_env + epb - 1) // epb
 n_waves = n_blocks * 4
 buf = np.zeros(n_waves * 16, np.uint64)
 for k in range(60):
@@ -22,7 +26,12 @@ names = ["0 load+stage+barrier(a)", "1 pose", "2 barrier(b)", "3 broad phase", "
          "6 static narrow", "7 lane AABB pass", "8 lane narrow", "9 (loop exit)", "10 barrier(c)", "11 reduce+barrier(d)", "12 epilogue",
          "13 fused integrate"]
 tot = v[:, :14].sum(1)
-print(cfg, "waves", n_waves, "mean ticks/wave", tot.mean(), "max", tot.max())
+print(cfg, "split" if split else "", "waves", n_waves, "mean ticks/wave", tot.mean(), "max", tot.max())
+if split:   # per role (wave of the env's workgroup) and env kind
+    for t in range(3):
+        for role in range(4):
+            sel = ((np.arange(n_waves) // 4) % 3 == t) & (np.arange(n_waves) % 4 == role)
+            print(f" env kind {t} role {role}: total {tot[sel].mean():8.0f} | " + " ".join(f"{k}:{v[sel, k].mean():.0f}" for k in range(14)))
 for t in range(3 if cfg == "metric" else 1):
     sel = (np.arange(n_waves) % 3 == t) if cfg == "metric" else np.ones(n_waves, bool)
     print(" env type", t, "mean total", tot[sel].mean())

@@ -1302,7 +1302,15 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
         // steps themselves; larger pools chain one workgroup per (env set, step)
         {
             if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
-            v.loop_steps = (!v.split_step && p->chain_loop && p->device_cus > 0 && v.chain_real_wgs <= 2 * p->device_cus) ? n : 0;
+            const int loop_wgs = (p->v.n_env + p->v.geo_layout.epb - 1) / p->v.geo_layout.epb;
+            const bool loop_ok = p->chain_loop && p->device_cus > 0 && loop_wgs <= 2 * p->device_cus;
+            // ... and at most one workgroup per CU (envs of up to 64 participants): integrator waves a step ahead (PIPE)
+            v.pipe_step = loop_ok && p->chain_pipe && loop_wgs <= p->device_cus && p->v.A <= 64;
+            if (v.pipe_step) {   // (preferred to the one-workgroup-per-env chain: the whole step overlaps, not only its stages)
+                v.split_step = 0;
+                v.chain_real_wgs = loop_wgs;
+            }
+            v.loop_steps = (!v.split_step && loop_ok) ? n : 0;
         }
         v.record_ring = (uint2*)p->field_ptr[T2D_F_RECORD];
         v.record_slot0 = slot0;
@@ -1331,10 +1339,12 @@ int t2d_step_form(t2d_pool* p, int32_t n_steps) {
     if (ego) return chain ? T2D_FORM_EGO_LOOP : T2D_FORM_EGO;
     const bool split = use_split(p);
     if (!chain) return split ? T2D_FORM_STEP_SPLIT : T2D_FORM_STEP;
-    if (split) return T2D_FORM_CHAIN_SPLIT;
     const int wgs = (p->v.n_env + p->v.geo_layout.epb - 1) / p->v.geo_layout.epb;
     if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
-    return (p->chain_loop && p->device_cus > 0 && wgs <= 2 * p->device_cus) ? T2D_FORM_LOOP : T2D_FORM_CHAIN;
+    const bool loop_ok = p->chain_loop && p->device_cus > 0 && wgs <= 2 * p->device_cus;
+    if (loop_ok && p->chain_pipe && wgs <= p->device_cus && p->v.A <= 64) return T2D_FORM_LOOP_PIPE;
+    if (split) return T2D_FORM_CHAIN_SPLIT;
+    return loop_ok ? T2D_FORM_LOOP : T2D_FORM_CHAIN;
 }
 
 int t2d_set_split_step(t2d_pool* p, int32_t on) {
@@ -1347,6 +1357,7 @@ int t2d_set_step_chaining(t2d_pool* p, int32_t on, int32_t priority_rule) {
     if (!p) return T2D_ERR_INVALID;
     p->chain_steps = on != 0;
     p->chain_loop = on != 2;   // 2: always the chained form, also for small pools (measurements)
+    p->chain_pipe = on == 1;   // 3: small pools loop without the integrator waves (measurements, tests)
     p->chain_priority = priority_rule != 0;
     return T2D_OK;
 }

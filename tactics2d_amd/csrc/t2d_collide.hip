@@ -312,10 +312,21 @@ T2D_DEV unsigned long long chain_word(uint32_t steps_done) {   // {steps done, X
 // waves 2 and 3 a half of the lane polygons each, and wave 0 reduces and runs the epilogue.  A step of such a pool is one
 // wave per SIMD walking a 3300-instruction dependent chain on an otherwise idle SIMD; this way the chain is the integrator
 // plus the longest stage (~2000 instructions) and the idle SIMDs do the other stages.  Same arithmetic, same flags.
-template <bool WITH_STATUS, int FUSE, bool IOU = true, bool CHAIN = false, bool LOOP = false, bool SPLIT = false>
-__global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv_arg, t2d_status_config cfg_arg,
-                                                                                       int interval_ms, int log2A) {
+// PIPE = true (a LOOP launch of at most one workgroup per CU, envs of at most 64 participants): the workgroup carries a second
+// set of waves -- wave 4 + w integrates the participants whose events wave w checks -- and the two run a step apart: while
+// wave w works through the events of step k, wave 4 + w already integrates step k + 1 from the state it committed for step
+// k.  That is speculation on one bit: step k did not end the env's episode.  The event wave publishes that bit with its
+// epilogue; an integrator lane whose env did finish restores the snapshot (the restore is its job here: every store to
+// the state arrays then comes from one wave, in program order), integrates again from there, and only then commits --
+// stores, then the hand-over of (x, y, heading, ids) through LDS.  Nothing of a speculative result is visible anywhere.  A step
+// of such a pool was one wave walking integrator + events on an idle SIMD (~9 k + ~15 k cycles on the highway pool); now it
+// is the longer of the two plus a hand-shake through two LDS words.  Same arithmetic in the same order per participant.
+constexpr int kPipeSpinLimit = 1 << 17;   // polls (s_sleep 1 between them) before a wait is declared lost: > 10 ms
+template <bool WITH_STATUS, int FUSE, bool IOU = true, bool CHAIN = false, bool LOOP = false, bool SPLIT = false, bool PIPE = false>
+__global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv_arg, t2d_status_config cfg_arg,
+                                                                                                         int interval_ms, int log2A) {
     static_assert(!(CHAIN && LOOP) && (!LOOP || (FUSE >= 0 && WITH_STATUS)), "LOOP = the fused step, not combined with CHAIN");
+    static_assert(!PIPE || (LOOP && !IOU && !SPLIT), "PIPE = a LOOP launch with integrator waves");
     static_assert(!SPLIT || (!LOOP && FUSE >= 0 && WITH_STATUS && !IOU), "SPLIT = the fused step of a plain pool, one launch or chained");
     // `pv` / `cfg` below: the two argument structs -- directly, or (LOOP) through a pointer into the kernel's argument block
     // that is laundered again at the top of every trip, so that what a trip reads of them cannot be hoisted out of the loop:
@@ -354,6 +365,12 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     // SPLIT: what wave 0's integrator hands the other three waves -- new x, y, heading and the ids word of every participant
     __shared__ float s_new[SPLIT ? 3 : 1][SPLIT ? 64 : 1];
     __shared__ uint32_t s_ids_new[SPLIT ? 64 : 1];
+    // PIPE: the integrator wave's hand-over (x, y, heading, ids per participant), the event wave's verdict per env (episode
+    // over), and the two progress words of every wave pair: steps committed / steps decided
+    __shared__ float s_hand[PIPE ? 3 : 1][PIPE ? kBlock : 1];
+    __shared__ uint32_t s_hand_ids[PIPE ? kBlock : 1];
+    __shared__ uint32_t s_dec[PIPE ? kBlock / 2 : 1];
+    __shared__ uint32_t s_seq_i[PIPE ? kWaves : 1], s_seq_e[PIPE ? kWaves : 1];
     extern __shared__ __attribute__((aligned(16))) uint32_t s_geo[];  // packed geometry record
 
     // Every kernel argument the start-up phase needs, requested in ONE scalar round trip.  Left to itself the compiler
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
 
 #ifdef T2D_TIMING
     unsigned long long t_prev_ = __builtin_readcyclecounter();
-    const size_t wave_slot_ = ((size_t)blockIdx.x * kWaves + (tid >> 6)) * 16;
+    const size_t wave_slot_ = ((size_t)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 16;
     if (lane == 0) {  // where and when this wave ran: HW_ID | XCC_ID << 32, start tick
         pv.dbg[wave_slot_ + 14] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |
                                   ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
@@ -461,12 +478,151 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
         // the loop behind a first-trip test, the staging code's lane masks were hoisted out of it and held in scalar
         // registers for the whole body: 195 spilled scalars)
         constexpr int kTab = kTabCols * T2D_MAX_TYPES;
-        const int nthr = a_epb << log2A;
+        const int nthr = (int)blockDim.x;
         for (int q = (int)threadIdx.x; q < kTab; q += nthr) s_partab[q] = a_params[q];
         if (a_geo) {
             typedef uint32_t u32x4l __attribute__((ext_vector_type(4)));
             const T2D_GLOBAL u32x4l* src = (const T2D_GLOBAL u32x4l*)(a_geo + (size_t)wg * a_stride);
             for (int q = (int)threadIdx.x; q < (a_stride >> 2); q += nthr) reinterpret_cast<u32x4l*>(s_geo)[q] = src[q];
+        }
+    }
+    // a bounded wait on one of the pair's progress words (every lane reads the same LDS word); a wait that runs out raises
+    // chain_err -- the host then reports the launch as failed -- and the wave goes on: never a hang
+    [[maybe_unused]] auto pipe_wait = [&](uint32_t* word, uint32_t want) {
+        int spins = 0;
+        while ((int32_t)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - want) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kPipeSpinLimit) {
+                __hip_atomic_store(pv.chain_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        asm volatile("" ::: "memory");   // what the other wave wrote before it moved the word is read after this point
+    };
+    [[maybe_unused]] auto pipe_post = [&](uint32_t* word, uint32_t value) {
+        // (a wave's LDS operations complete in order: the plain writes above are in the LDS before the word moves)
+        asm volatile("" ::: "memory");
+        if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    if constexpr (PIPE) {
+        if (threadIdx.x < (unsigned)kWaves) s_seq_i[threadIdx.x] = s_seq_e[threadIdx.x] = 0u;
+        if (threadIdx.x < (unsigned)(kBlock / 2)) s_dec[threadIdx.x] = 0u;
+        if ((int)threadIdx.x >= nthreads) {
+            // ======== integrator waves: thread nthreads + t serves the participant of event thread t ========
+            const int t = (int)threadIdx.x - nthreads;
+            const int w = t >> 6;
+            const int i_env_local = t >> log2A;
+            const int i_env = wg * EPB + i_env_local;
+            const bool i_valid = i_env < a_n_env && (t & (A_pad - 1)) < a_A;
+            const int i_idx = i_valid ? i_env * a_A + (t & (A_pad - 1)) : 0;
+            __syncthreads();   // (a) of the event waves' first trip: tables staged, progress words cleared
+            uint32_t ids = 0;
+            float x = 0, y = 0, h = 0, v = 0, vx = 0, vy = 0;
+            if (i_valid) {
+                ids = ld_state<true>(a_ids + i_idx);
+                x = ld_state<true>(a_x + i_idx);
+                y = ld_state<true>(a_y + i_idx);
+                h = ld_state<true>(a_h + i_idx);
+                v = ld_state<true>(a_v + i_idx);
+                if (((ids >> kIdsModelShift) & 0xff) == T2D_MODEL_POINTMASS) {
+                    vx = ld_state<true>(as_global(pv.vx) + i_idx);
+                    vy = ld_state<true>(as_global(pv.vy) + i_idx);
+                }
+            }
+            const int n_steps = pv.loop_steps;
+            const size_t act_step = (size_t)pv.chain_act_step;
+            const size_t ai0 = (size_t)i_idx * a_act_stride;
+            float a0 = 0, a1 = 0;
+            if (i_valid) {
+                a0 = a_act0[ai0];
+                a1 = a_act1[ai0];
+            }
+            for (int k = 0; k <= n_steps; ++k) {
+                const KernargView ia = late_args();   // (per trip: see the event waves' loop)
+                float na0 = 0, na1 = 0;               // the next step's actions: their latency overlaps this integration
+                if (i_valid && k + 1 < n_steps) {
+                    na0 = a_act0[ai0 + (size_t)(k + 1) * act_step];
+                    na1 = a_act1[ai0 + (size_t)(k + 1) * act_step];
+                }
+                // what this step makes of the lane's state (stays the state itself for lanes the integrator skips)
+                float nx = x, ny = y, nh = h, nv = v, nvx = vx, nvy = vy, app0 = 0, app1 = 0;
+                bool moved = false, has_vel = false;
+                bool todo = k < n_steps;         // lanes to integrate in this round
+                bool decided = k == 0;           // the previous step's verdict is in (nothing precedes step 0)
+                for (;;) {                       // at most two rounds: the speculative one, and one for envs that were reset
+                    const int model = (ids >> kIdsModelShift) & 0xff;
+                    const int type = (ids >> kIdsTypeShift) & 0xff;
+                    if (todo) {
+                        nx = x; ny = y; nh = h; nv = v; nvx = vx; nvy = vy;
+                        moved = false; has_vel = false;
+                    }
+                    if (todo && i_valid && ((ids >> kIdsActiveShift) & 0xffu) && model != T2D_MODEL_DRIFT) {
+                        auto P = [&](int col) -> double { return s_partab[col * T2D_MAX_TYPES + type]; };
+                        const bool pm = model == T2D_MODEL_POINTMASS;
+                        const integ::StepOut o = integ::step_participant<(FUSE > 0 ? 1 : 0)>(
+                            model, P, (double)x, (double)y, (double)h, (double)v, pm ? (double)vx : 0.0, pm ? (double)vy : 0.0,
+                            (double)a0, (double)a1, interval_ms);
+                        nx = (float)o.x; ny = (float)o.y; nh = (float)o.heading; nv = (float)o.speed;
+                        moved = true;
+                        has_vel = o.has_velocity;
+                        if (o.has_velocity) {
+                            nvx = (float)o.vx;
+                            nvy = (float)o.vy;
+                        }
+                        app0 = (float)o.app0;
+                        app1 = (float)o.app1;
+                    }
+                    if (decided) break;
+                    pipe_wait(&s_seq_e[w], (uint32_t)k);
+                    decided = true;
+                    const bool done = i_valid && s_dec[i_env_local] != 0u;
+                    if (__ballot(done) == 0ull) break;
+                    if (done) {   // the env's episode ended with step k - 1: back to the snapshot (t2d_reset's copy)
+                        const float r0 = as_global(ia->snap[0])[i_idx], r1 = as_global(ia->snap[1])[i_idx], r2 = as_global(ia->snap[2])[i_idx];
+                        const float r3 = as_global(ia->snap[3])[i_idx], r4 = as_global(ia->snap[4])[i_idx], r5 = as_global(ia->snap[5])[i_idx];
+                        const uint32_t rid = as_global(ia->snap_ids)[i_idx];
+                        as_global(ia->x)[i_idx] = r0;
+                        as_global(ia->y)[i_idx] = r1;
+                        as_global(ia->heading)[i_idx] = r2;
+                        as_global(ia->speed)[i_idx] = r3;
+                        as_global(ia->vx)[i_idx] = r4;
+                        as_global(ia->vy)[i_idx] = r5;
+                        as_global(ia->ids)[i_idx] = rid;
+                        x = r0; y = r1; h = r2; v = r3; vx = r4; vy = r5; ids = rid;
+                    }
+                    todo = done && k < n_steps;
+                    if (k == n_steps) break;
+                }
+                if (k == n_steps) break;
+                // commit step k: the state arrays, then the hand-over to the event wave
+                if (moved) {
+                    as_global(ia->x)[i_idx] = nx;
+                    as_global(ia->y)[i_idx] = ny;
+                    as_global(ia->heading)[i_idx] = nh;
+                    as_global(ia->speed)[i_idx] = nv;
+                    if (has_vel && (((ids >> kIdsModelShift) & 0xff) == T2D_MODEL_POINTMASS || (ia->out_mask & T2D_OUT_VELOCITY))) {
+                        as_global(ia->vx)[i_idx] = nvx;
+                        as_global(ia->vy)[i_idx] = nvy;
+                    }
+                    if (ia->out_mask & T2D_OUT_APPLIED) {
+                        as_global(ia->applied0)[i_idx] = app0;
+                        as_global(ia->applied1)[i_idx] = app1;
+                    }
+                }
+                x = nx; y = ny; h = nh; v = nv;
+                if (has_vel) {
+                    vx = nvx;
+                    vy = nvy;
+                }
+                s_hand[0][t] = x;
+                s_hand[1][t] = y;
+                s_hand[2][t] = h;
+                s_hand_ids[t] = i_valid ? ids : 0u;
+                pipe_post(&s_seq_i[w], (uint32_t)k + 1u);
+                a0 = na0;
+                a1 = na1;
+            }
+            return;
         }
     }
     const int tid_outer = tid;
@@ -508,7 +664,7 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     int pre_cnt = 0, pre_frame = 0;
     if (CHAIN && step_k > 0) chain_wait();
     const bool carried = LOOP && step_k > 0;   // (LOOP: the second and later trips take their inputs from registers)
-    if (valid && (!SPLIT || role == 0)) {   // (SPLIT: wave 0 loads and integrates; the others get the new state through LDS)
+    if (valid && !PIPE && (!SPLIT || role == 0)) {   // (SPLIT: wave 0 loads and integrates; the others get the new state through LDS)
         if (carried) {
             ids = c_ids; fx = c_x; fy = c_y; fh = c_h; fv = c_v; fa0 = n_a0; fa1 = n_a1;
         } else {
@@ -622,10 +778,17 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     T2D_MARK(0);
 
     if (SPLIT) ids = s_ids_new[tid];
+    if constexpr (PIPE) {   // this step's state, committed by the pair's integrator wave
+        pipe_wait(&s_seq_i[tid >> 6], (uint32_t)step_k + 1u);
+        ids = s_hand_ids[tid];
+        fx = s_hand[0][tid];
+        fy = s_hand[1][tid];
+        fh = s_hand[2][tid];
+    }
     const bool active = valid && ((ids >> kIdsActiveShift) & 0xffu);
     const int type = (ids >> kIdsTypeShift) & 0xff;
     // (SingleTrackDrift lanes were integrated by drift_kernel, launched before this one)
-    if (FUSE >= 0 && active && ((ids >> kIdsModelShift) & 0xff) != T2D_MODEL_DRIFT && (!SPLIT || role == 0)) {
+    if (!PIPE && FUSE >= 0 && active && ((ids >> kIdsModelShift) & 0xff) != T2D_MODEL_DRIFT && (!SPLIT || role == 0)) {
         // ---------------- fused physics: one PhysicsModelBase.step in registers ----------------
         const int model = (ids >> kIdsModelShift) & 0xff;
         auto P = [&](int col) -> double { return s_partab[col * T2D_MAX_TYPES + type]; };
@@ -1269,6 +1432,7 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
             if (e_auto_reset) {
                 const bool done = terminated || truncated;
                 s_done[env_local] = done;
+                if (PIPE) s_dec[env_local] = done;   // (the integrator wave reads it before it commits the next step)
                 if (done) {  // ParkingEnv.reset: counters and detector state back to the episode start
                     pv.cnt_step[env] = 0;
                     pv.frame_ms[env] = 0;
@@ -1284,7 +1448,7 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     if (LOOP) {   // what this trip stored (a pure-output velocity excepted: only a point mass reads c_vx / c_vy back)
         c_ids = ids; c_x = fx; c_y = fy; c_h = fh; c_v = fv;
     }
-    if (WITH_STATUS && e_auto_reset) {  // fused vector-env auto-reset: finished envs go back to the snapshot
+    if (WITH_STATUS && e_auto_reset && !PIPE) {  // fused vector-env auto-reset: finished envs go back to the snapshot (PIPE: by the integrator wave)
         // (the restore's eighteen pointers are requested here, in one scalar round trip, not with the epilogue's above: 36
         // more scalar registers held through the reduce and the status code pushed the kernel into scalar spills -- two
         // v_readlane / v_writelane per spilled value, ~300 VALU instructions per wave)
@@ -1344,6 +1508,7 @@ __global__ __launch_bounds__(kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_
     // LOOP: nothing is read back from memory (see `carried`); what the next trip clears in LDS is the wave's own when an env
     // fits a wave, else the workgroup meets first
     if (log2A <= 6) wave_sync(); else __syncthreads();
+    if constexpr (PIPE) pipe_post(&s_seq_e[tid >> 6], (uint32_t)step_k + 1u);   // this step's verdicts are in s_dec
     if (++step_k >= pv.loop_steps) break;
     }
     if (CHAIN) {   // this step of these envs is complete: every store above is in the L2 before the word moves
@@ -1394,6 +1559,14 @@ hipError_t launch_step_chain(const PoolView& v, const t2d_status_config& cfg, in
         const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
         if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, true, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
         else hipLaunchKernelGGL((collide_kernel<true, 1, false, true, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        return hipGetLastError();
+    }
+    if (v.loop_steps > 0 && v.pipe_step) {   // ... with a second set of waves that integrates a step ahead
+        const dim3 grid((v.n_env + EPB - 1) / EPB), block(2 * (EPB << log2A));
+        const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
+        if (log2A > 6) return hipErrorInvalidValue;
+        if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, true, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, true, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
         return hipGetLastError();
     }
     if (v.loop_steps > 0) {   // small pool: every workgroup resident, each walks through the steps itself

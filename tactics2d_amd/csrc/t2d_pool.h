@@ -104,6 +104,7 @@ struct PoolView {
     int32_t chain_real_wgs;     // workgroups that own envs; the grid's x extent is rounded up to a multiple of 8
     int32_t split_step;         // the step launch gives every env a workgroup of its own (SPLIT form, small pools of 64-agent envs)
     int32_t loop_steps;         // > 0: the LOOP form -- every workgroup walks through this many steps itself (small pools)
+    int32_t pipe_step;          // LOOP form with integrator waves running a step ahead of the event waves (PIPE)
     int64_t chain_act_step;     // elements between the action sets of consecutive steps (0: the same actions every step)
     uint2* record_ring;         // the whole ring of per-env result records; step k writes slot (record_slot0 + k) % ring
     int32_t record_slot0;
@@ -241,6 +242,7 @@ struct t2d_pool {
     uint32_t chain_count = 0;      // what every counter holds once the launches enqueued so far have run
     bool chain_steps = true;       // t2d_set_step_chaining(pool, 0, *): t2d_step_n falls back to one launch per step
     bool chain_loop = true;        // small pools take the LOOP form (t2d_set_step_chaining(pool, 2, *): never)
+    bool chain_pipe = true;        // small pools: the LOOP form carries integrator waves that run a step ahead (PIPE)
     bool split_steps = true;       // small pools of 64-agent envs step with one env per workgroup (t2d_set_split_step)
     bool chain_priority = true;    // wave priorities of a chained launch: 1 = the rule for overlapping work (PoolView::overlapped)
     bool chain_used = false, chain_failed = false;

@@ -267,7 +267,7 @@ class ParticipantPool:
         """Small pools of 33..64-agent envs: one env per workgroup, its event stages on four waves (t2d_set_split_step)."""
         self._ck(self._lib.t2d_set_split_step(self._h, int(bool(on))))
 
-    STEP_FORMS = ("unfused", "step", "step_split", "ego", "ego_loop", "chain", "chain_split", "loop")
+    STEP_FORMS = ("unfused", "step", "step_split", "ego", "ego_loop", "chain", "chain_split", "loop", "loop_pipe")
 
     def step_form(self, n_steps=1):
         """Name of the step-kernel form a call of n_steps steps takes on this pool now (t2d_step_form)."""
@@ -277,7 +277,9 @@ class ParticipantPool:
         return self.STEP_FORMS[rc]
 
     def set_step_chaining(self, on=True, priority_rule=1):
-        self._ck(self._lib.t2d_set_step_chaining(self._h, int(bool(on)), int(priority_rule)))
+        """on: False / True, or (measurements, tests) 2 = always the chained form, 3 = small pools loop without the
+        integrator waves (t2d_set_step_chaining)"""
+        self._ck(self._lib.t2d_set_step_chaining(self._h, int(on), int(priority_rule)))
 
     def snapshot(self):
         """Record the current state as the episode start for device-side resets."""

@@ -25,7 +25,7 @@ def _pool(sc, variant, ego_kernel=True):
     return pool
 
 
-def _compare(sc, n_steps, variant, calls=(None,), ego_kernel=True, same_actions=False):
+def _compare(sc, n_steps, variant, calls=(None,), ego_kernel=True, same_actions=False, chaining=1, form=None, split=True):
     """reference: n_steps t2d_step calls on an action ring; candidate: the same ring through t2d_step_n, split into `calls`"""
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda", 0)
@@ -42,6 +42,10 @@ def _compare(sc, n_steps, variant, calls=(None,), ego_kernel=True, same_actions=
     want = [ref.download(f) for f in _fields()]
     ref.close()
     got_pool = _pool(sc, variant, ego_kernel)
+    got_pool.set_step_chaining(chaining)
+    got_pool.set_split_step(split)
+    if form is not None:
+        assert got_pool.step_form(max(2, n_steps)) == form
     done = 0
     for c in calls:
         c = n_steps - done if c is None else c
@@ -173,8 +177,9 @@ def test_one_workgroup_per_env_form_equals_one_wave_per_env():
             for chained in (False, True):
                 pool = _pool(sc, "exact")
                 pool.set_split_step(split)
+                pool.set_step_chaining(2)    # (the chained form: by default a pool this small loops with integrator waves)
                 assert pool.step_form(1) == ("step_split" if split else "step")
-                assert pool.step_form(8) == ("chain_split" if split else "loop")
+                assert pool.step_form(8) == ("chain_split" if split else "chain")
                 if chained:
                     done = 0
                     for c in (7, 1, 32):
@@ -196,5 +201,27 @@ def test_one_workgroup_per_env_form_equals_one_wave_per_env():
             for f, g, w in zip(_fields(), got, want):
                 assert np.array_equal(g, w, equal_nan=True), (key, f, int((g != w).sum()))
     hw = _pool(S.highway(64, 64, seed=2), "exact")
-    assert hw.step_form(1) == "step" and hw.step_form(8) == "loop"
+    assert hw.step_form(1) == "step" and hw.step_form(8) == "loop_pipe"
+    hw.set_step_chaining(2)
+    assert hw.step_form(8) == "chain"
     hw.close()
+
+
+@pytest.mark.parametrize("chaining,form", [(1, "loop_pipe"), (3, "loop"), (2, "chain")])
+def test_every_multi_step_form_of_a_small_pool_equals_single_steps(chaining, form):
+    """A pool of at most one workgroup per CU has three multi-step forms: workgroups chained per step, resident workgroups
+    looping over the steps, and the loop with integrator waves a step ahead of the event waves (the default).  Each against
+    the same steps as single launches -- auto-resets in most steps (the integrator waves' speculation is wrong there and
+    they integrate again from the snapshot), fragments of 1..33 steps, 64-agent envs (one per wave) and 32-agent envs (two per
+    wave, verdicts of both in one integrator wave)."""
+    from tactics2d_amd import layout as L, scenarios as S
+    for sc, variant, calls in ((S.mixed(203, 64, seed=5), "fast", (1, 2, 33, 4)), (S.intersection(100, 32, seed=8), "exact", (17, 23)),
+                               (S.highway(77, 64, seed=2), "exact", (40,))):
+        if form == "chain" and sc.A == 64 and sc.name != "highway":
+            form_here = "chain_split"     # (pools with static obstacles and lanes chain one workgroup per env)
+        else:
+            form_here = form
+        want = _compare(sc, sum(calls), variant, calls=calls, chaining=chaining, form=form_here, split=chaining != 3)
+        rec = want[_fields().index(L.F_RECORD)].reshape(L.RECORD_RING, sc.n_env, 2)
+        ended = (rec[:sum(calls), :, 1] >> 16).astype(bool)
+        assert ended.any(1).sum() >= sum(calls) // 2, "too few steps with an episode end: the reset path was hardly exercised"
