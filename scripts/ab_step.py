@@ -41,7 +41,7 @@ def child():
             best = min(best, 1e6 * (time.perf_counter() - t) / steps)
         return best
 
-    for name in ("metric", "cfg3", "cfg4", "cfg5"):
+    for name in ("cfg3", "cfg4", "cfg5") if os.environ.get("T2D_AB_SMALL") else ("metric", "cfg3", "cfg4", "cfg5"):
         sc = scene(name)
         rng = np.random.default_rng(5)
         K = 4
@@ -88,6 +88,10 @@ def child():
                 pool.set_step_chaining(True, rule)
                 for frag in (20, 100) if name == "metric" else (20,):
                     r[f"chain{frag}_rule{rule}"] = timed(chained(frag), steps)
+                if name != "metric" and os.environ.get("T2D_AB_SMALL"):   # the looping forms one by one
+                    for mode, key in ((4, "pipe1"), (3, "loop")):
+                        pool.set_step_chaining(mode, rule)
+                        r[f"{key}_rule{rule}"] = timed(chained(20), steps)
         out[name] = r
         pool.close()
     print("AB_RESULT", os.environ.get("T2D_LIB_NAME"), out, flush=True)

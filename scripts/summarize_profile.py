@@ -15,16 +15,17 @@ def find(d, suffix):
 
 
 def short(name):
-    """collide_kernel<WITH_STATUS, FUSE, IOU, CHAIN, LOOP, SPLIT>: FUSE >= 0 is the fused step launch; CHAIN / LOOP are the two
-    multi-step forms (one workgroup per (env set, step) / resident workgroups looping over the steps), SPLIT one workgroup
-    per env; ego_step_kernel<VARIANT, LOOP> likewise"""
+    """collide_kernel<WITH_STATUS, FUSE, IOU, CHAIN, LOOP, SPLIT, PIPE>: FUSE >= 0 is the fused step launch; CHAIN / LOOP are the
+    two multi-step forms (one workgroup per (env set, step) / resident workgroups looping over the steps), SPLIT one workgroup
+    per env, PIPE a loop with integrator waves (1) and lane waves (2); ego_step_kernel<VARIANT, LOOP> likewise"""
     n = name.replace(" ", "")
     m = re.search(r"collide_kernel<([^>]*)>", n)
     if m:
-        a = m.group(1).split(",") + ["false"] * 6
+        a = m.group(1).split(",") + ["false"] * 6 + ["0"]
         if a[1] == "-1":
             return "collide_kernel"
-        return "step_kernel" + ("_chained" if a[3] == "true" else "_loop" if a[4] == "true" else "") + ("_split" if a[5] == "true" else "")
+        pipe = {"0": "", "false": "", "1": "_pipe", "2": "_pipe2"}.get(a[6], "_pipe")
+        return "step_kernel" + ("_chained" if a[3] == "true" else "_loop" if a[4] == "true" else "") + ("_split" if a[5] == "true" else "") + pipe
     m = re.search(r"ego_step_kernel<([^>]*)>", n)
     if m and m.group(1).split(",")[-1] == "true":
         return "ego_step_kernel_loop"
@@ -39,7 +40,7 @@ def launch_steps(k, row, fragment):
     """steps one launch of kernel k holds: the grid's y extent for the chained form, the bench's fragment for the loop forms"""
     if k.startswith("step_kernel_chained"):
         return max(1, int(row["Grid_Size_Y"]) // max(1, int(row["Workgroup_Size_Y"])))
-    if k.endswith("_loop") or "_loop_" in k:
+    if "_loop" in k:
         return max(1, int(fragment))
     return 1
 

@@ -1306,6 +1306,14 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
             const bool loop_ok = p->chain_loop && p->device_cus > 0 && loop_wgs <= 2 * p->device_cus;
             // ... and at most one workgroup per CU (envs of up to 64 participants): integrator waves a step ahead (PIPE)
             v.pipe_step = loop_ok && p->chain_pipe && loop_wgs <= p->device_cus && p->v.A <= 64;
+            // (pools with lane polygons: the lane stage on a wave of its own -- needs three sets of waves in a workgroup)
+            // -- where the lane stage is long enough to pay for the poses derived a second time: five lane polygons per env
+            // and more (measured: 4 per env, the highway pool, 8.8 us per step without lane waves and 10.0 with them; 6 per
+            // env 8.1 / 7.6; 4..16 per env, the mixed pool, 11.0 / 9.2)
+            const size_t lane_polys = p->hgeo[1].present && !p->hgeo[1].env_off.empty() ? (size_t)p->hgeo[1].env_off.back() : 0;
+            if (v.pipe_step && p->chain_pipe2 && p->v.geo && p->v.geo_layout.has[1] && lane_polys >= 5 * (size_t)p->v.n_env &&
+                3 * (p->v.geo_layout.epb << log2_pad(p->v.A)) <= 1024)
+                v.pipe_step = 2;
             if (v.pipe_step) {   // (preferred to the one-workgroup-per-env chain: the whole step overlaps, not only its stages)
                 v.split_step = 0;
                 v.chain_real_wgs = loop_wgs;
@@ -1357,7 +1365,8 @@ int t2d_set_step_chaining(t2d_pool* p, int32_t on, int32_t priority_rule) {
     if (!p) return T2D_ERR_INVALID;
     p->chain_steps = on != 0;
     p->chain_loop = on != 2;   // 2: always the chained form, also for small pools (measurements)
-    p->chain_pipe = on == 1;   // 3: small pools loop without the integrator waves (measurements, tests)
+    p->chain_pipe = on == 1 || on == 4;   // 3: small pools loop without the integrator waves (measurements, tests)
+    p->chain_pipe2 = on == 1;             // 4: integrator waves, but no lane waves
     p->chain_priority = priority_rule != 0;
     return T2D_OK;
 }

@@ -61,6 +61,14 @@ using namespace geom;
 #ifndef T2D_PROBE_SKIP
 #define T2D_PROBE_SKIP 0
 #endif
+// wave priorities of a PIPE launch as three digits: event waves / lane waves / integrator waves (-1: the general rule of the
+// step kernel).  Measured on the 1024 x 64 highway / 512 x 32 intersection / 1024 x 64 mixed pools, us per step with lane
+// waves: flat 9.98 / 7.62 / 9.21; events first (320) 10.31 / 7.85 / 9.40; integrator first (123) 9.03 / 9.06 / 10.38; the
+// general rule 10.14 / 7.83 / 9.38.  The waves of a pair wait for each other: whoever is served first, the other's turn
+// comes, and a rule only adds the s_setprio instructions.
+#ifndef T2D_PIPE_PRIO
+#define T2D_PIPE_PRIO 111
+#endif
 #ifndef T2D_COLLIDE_WAVES
 #define T2D_COLLIDE_WAVES 4  // min waves / SIMD the register allocator must allow
 #endif
@@ -321,10 +329,15 @@ T2D_DEV unsigned long long chain_word(uint32_t steps_done) {   // {steps done, X
 // stores, then the hand-over of (x, y, heading, ids) through LDS.  Nothing of a speculative result is visible anywhere.  A step
 // of such a pool was one wave walking integrator + events on an idle SIMD (~9 k + ~15 k cycles on the highway pool); now it
 // is the longer of the two plus a hand-shake through two LDS words.  Same arithmetic in the same order per participant.
+// PIPE = 2 (pools with lane polygons): a third set of waves -- wave 4 + w takes the lane stage of the participants of wave w,
+// which keeps the pairs, the static polygons, the reduce and the epilogue, and waits for the lane wave's bits (OR-ed into
+// the same s_flags words) before it reduces; the integrator waves are then waves 8 + w.  Both event waves derive the poses
+// from the hand-over, the same instructions twice: the lane stage is the longest event stage of intersection and
+// roundabout envs, and on its own wave the events of a step cost about what the integration of the next one does.
 constexpr int kPipeSpinLimit = 1 << 17;   // polls (s_sleep 1 between them) before a wait is declared lost: > 10 ms
-template <bool WITH_STATUS, int FUSE, bool IOU = true, bool CHAIN = false, bool LOOP = false, bool SPLIT = false, bool PIPE = false>
-__global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv_arg, t2d_status_config cfg_arg,
-                                                                                                         int interval_ms, int log2A) {
+template <bool WITH_STATUS, int FUSE, bool IOU = true, bool CHAIN = false, bool LOOP = false, bool SPLIT = false, int PIPE = 0>
+__global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv_arg, t2d_status_config cfg_arg,
+                                                                                                                   int interval_ms, int log2A) {
     static_assert(!(CHAIN && LOOP) && (!LOOP || (FUSE >= 0 && WITH_STATUS)), "LOOP = the fused step, not combined with CHAIN");
     static_assert(!PIPE || (LOOP && !IOU && !SPLIT), "PIPE = a LOOP launch with integrator waves");
     static_assert(!SPLIT || (!LOOP && FUSE >= 0 && WITH_STATUS && !IOU), "SPLIT = the fused step of a plain pool, one launch or chained");
@@ -352,8 +365,8 @@ __global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_
     // process_lane.  LDS is what decides 4 resident workgroups per CU for the metric scenes: keep this compact.
     __shared__ uint32_t s_flags[kBlock];
     __shared__ uint32_t s_env_or[kBlock / 2];  // per env of the workgroup (an env has at least 2 lanes)
-    __shared__ uint32_t s_queue[kWaves][kQueueCap];
-    __shared__ int s_qcount[kWaves];
+    __shared__ uint32_t s_queue[PIPE == 2 ? 2 * kWaves : kWaves][kQueueCap];   // (PIPE = 2: the lane waves have queues of their own)
+    __shared__ int s_qcount[PIPE == 2 ? 2 * kWaves : kWaves];
     // the spatial-hash lists (envs wider than a wave only) live in the queue storage: they are dead
     // before the polygon stages start using the queues (workgroup barrier in between)
     static_assert(kMaxHeads + kBlock <= kWaves * kQueueCap, "hash grid must fit in the queue storage");
@@ -370,7 +383,7 @@ __global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_
     __shared__ float s_hand[PIPE ? 3 : 1][PIPE ? kBlock : 1];
     __shared__ uint32_t s_hand_ids[PIPE ? kBlock : 1];
     __shared__ uint32_t s_dec[PIPE ? kBlock / 2 : 1];
-    __shared__ uint32_t s_seq_i[PIPE ? kWaves : 1], s_seq_e[PIPE ? kWaves : 1];
+    __shared__ uint32_t s_seq_i[PIPE ? kWaves : 1], s_seq_e[PIPE ? kWaves : 1], s_seq_b[PIPE == 2 ? kWaves : 1];
     extern __shared__ __attribute__((aligned(16))) uint32_t s_geo[];  // packed geometry record
 
     // Every kernel argument the start-up phase needs, requested in ONE scalar round trip.  Left to itself the compiler
@@ -412,7 +425,10 @@ __global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_
     // `role` tells them apart and `ptid` is the thread's own number (what the staging loops stride by)
     const int role = SPLIT ? (int)(threadIdx.x >> 6) : 0;
     const int ptid = (int)threadIdx.x;
+    // PIPE = 2: threads [E, 2E) of the block (E = EPB << log2A) are the lane waves: same slots, same participants as [0, E)
+    const bool role_b = PIPE == 2 && (int)threadIdx.x >= (a_epb << log2A);
     const int tid = SPLIT ? (int)(threadIdx.x & 63u)
+                  : PIPE == 2 ? (int)threadIdx.x - (role_b ? (a_epb << log2A) : 0)
                           : (blockDim.x == kBlock ? (int)((threadIdx.x + 64u * (unsigned)wave_rot) & (kBlock - 1u)) : (int)threadIdx.x);
     [[maybe_unused]] const int lane = tid & 63;   // (the step body derives its own lane coordinates: see the loop below)
     const int A_pad = 1 << log2A;
@@ -425,8 +441,8 @@ __global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_
     [[maybe_unused]] const int idx = valid ? env * a_A + agent : 0;
     const bool use_hash_grid = log2A > 6;  // envs larger than a wave use the LDS spatial hash
     const int H = 2 * A_pad;               // buckets per env (power of two)
-    [[maybe_unused]] uint32_t* const queue = s_queue[SPLIT ? role : tid >> 6];
-    [[maybe_unused]] int* const qcount = &s_qcount[SPLIT ? role : tid >> 6];
+    [[maybe_unused]] uint32_t* const queue = s_queue[SPLIT ? role : (tid >> 6) + (role_b ? kWaves : 0)];
+    [[maybe_unused]] int* const qcount = &s_qcount[SPLIT ? role : (tid >> 6) + (role_b ? kWaves : 0)];
 
 #ifdef T2D_TIMING
     unsigned long long t_prev_ = __builtin_readcyclecounter();
@@ -446,8 +462,14 @@ __global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_
     // When the launches of several env groups overlap (pv.overlapped, t2d_step_groups) the opposite holds: a workgroup
     // that retires makes room for the next launch's, so waves past the integrator go first (0, then 2) -- 4 groups:
     // 20.0 us per step of all envs with that rule, 20.3 without priorities, 23.4 with the single-launch rule.
-    const bool behind_first = pv.overlapped == 0;
+    constexpr bool pipe_prio = PIPE != 0 && T2D_PIPE_PRIO >= 0;
+    const bool behind_first = pv.overlapped == 0 && !pipe_prio;
     if (behind_first) __builtin_amdgcn_s_setprio(3);
+    if constexpr (pipe_prio) {
+        if ((int)threadIdx.x >= PIPE * (a_epb << log2A)) __builtin_amdgcn_s_setprio(T2D_PIPE_PRIO >= 0 ? T2D_PIPE_PRIO % 10 : 0);
+        else if (role_b) __builtin_amdgcn_s_setprio(T2D_PIPE_PRIO >= 0 ? (T2D_PIPE_PRIO / 10) % 10 : 0);
+        else __builtin_amdgcn_s_setprio(T2D_PIPE_PRIO >= 0 ? (T2D_PIPE_PRIO / 100) % 10 : 0);
+    }
     // chained launch: wait for the step before this one of the same envs (one lane polls, s_sleep between polls)
     auto chain_wait = [&]() {
         if (ptid == 0) {
@@ -505,11 +527,14 @@ __global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_
         if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     if constexpr (PIPE) {
-        if (threadIdx.x < (unsigned)kWaves) s_seq_i[threadIdx.x] = s_seq_e[threadIdx.x] = 0u;
+        if (threadIdx.x < (unsigned)kWaves) {
+            s_seq_i[threadIdx.x] = s_seq_e[threadIdx.x] = 0u;
+            if (PIPE == 2) s_seq_b[threadIdx.x] = 0u;
+        }
         if (threadIdx.x < (unsigned)(kBlock / 2)) s_dec[threadIdx.x] = 0u;
-        if ((int)threadIdx.x >= nthreads) {
-            // ======== integrator waves: thread nthreads + t serves the participant of event thread t ========
-            const int t = (int)threadIdx.x - nthreads;
+        if ((int)threadIdx.x >= PIPE * nthreads) {
+            // ======== integrator waves: thread PIPE * nthreads + t serves the participant of event thread t ========
+            const int t = (int)threadIdx.x - PIPE * nthreads;
             const int w = t >> 6;
             const int i_env_local = t >> log2A;
             const int i_env = wg * EPB + i_env_local;
@@ -646,8 +671,8 @@ __global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_
     const int env = SPLIT ? unit : wg * EPB + env_local;
     const bool valid = env < a_n_env && agent < a_A;
     const int idx = valid ? env * a_A + agent : 0;
-    uint32_t* const queue = s_queue[SPLIT ? role : tid >> 6];
-    int* const qcount = &s_qcount[SPLIT ? role : tid >> 6];
+    uint32_t* const queue = s_queue[SPLIT ? role : (tid >> 6) + (role_b ? kWaves : 0)];
+    int* const qcount = &s_qcount[SPLIT ? role : (tid >> 6) + (role_b ? kWaves : 0)];
     if constexpr (LOOP) {
         pvp = late_args();
         cfgp = (const __attribute__((address_space(4))) t2d_status_config*)((const __attribute__((address_space(4))) char*)late_args() + kCfgArgOffset);
@@ -753,11 +778,13 @@ __global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_
         if (use_hash_grid)
             for (int k = tid; k < EPB * H; k += nthreads) s_head[k] = -1;
         if (LOOP) {   // (every wave clears what is its envs' own: the waves of a LOOP launch do not wait for each other)
-            if (agent == 0) s_env_or[env_local] = 0;
+            if (agent == 0 && !role_b) s_env_or[env_local] = 0;
         } else if (gtid < kBlock / 2) {
             s_env_or[gtid] = 0;
         }
-        s_flags[tid] = 0;
+        // (PIPE = 2: two waves OR into a participant's word; its owner clears it at the END of a trip, before the step's
+        // verdict goes out -- the lane wave cannot be in the next step's stage before that -- and here on the first trip only)
+        if (!(PIPE == 2 && (role_b || carried))) s_flags[tid] = 0;
         if (SPLIT && role == 0) s_ids_new[tid] = ids;   // (0 for a slot without a participant)
         if (FUSE < 0) {
 #pragma unroll
@@ -1068,8 +1095,10 @@ __global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_
     }
     // (SPLIT: one pass -- wave 0 takes the pair stage, the others the polygon stages, each its part: see below)
     for (int stage_it = 0; stage_it < (SPLIT ? 1 : 2); ++stage_it) {
-    if (behind_first && stage_it == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
-    if (SPLIT ? role == 0 : (stage_it == 0) != polys_first) {
+    if (!pipe_prio) {
+        if (behind_first && stage_it == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+    }
+    if (SPLIT ? role == 0 : ((stage_it == 0) != polys_first && !role_b)) {
     if (T2D_PROBE_SKIP & 1) {
     } else if (!use_hash_grid) {
         // every lane against all agents of its env: fp32 circles, 1 cm margin (strictly
@@ -1172,7 +1201,7 @@ __global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_
     T2D_MARK(4);
     if (use_hash_grid) __syncthreads();  // the grid lists share LDS with the queues used below
     // ---------------- phase 2b / 2c: static polygons and lane polygons -------------------------
-    } else {
+    } else if (!role_b || (stage_it == 0) == polys_first) {
     {
         // Broad -> narrow stages over boxes kept in the LDS record (static polygons, lane polygons, boundary pieces of the
         // lane union): pass 1 = which (participant, box) pairs meet; pass 2 = the survivors of the whole wave, compacted,
@@ -1237,12 +1266,12 @@ __global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_
             }
         };
         const f2p bxp = {-box_hi_x, box_lo_x}, byp = {-box_hi_y, box_lo_y};
-        if (gl2.has[0] && !(T2D_PROBE_SKIP & 4) && (!SPLIT || role == 1)) {   // static obstacles
+        if (gl2.has[0] && !(T2D_PROBE_SKIP & 4) && (!SPLIT || role == 1) && !role_b) {   // static obstacles
             const int* pstart = geo_i + gl2.off_pstart[0];
             sweep_stage(reinterpret_cast<const float4*>(s_geo + gl2.off_aabb[0]), pstart[env_local], pstart[env_local + 1], active,
                         bxp, byp, process_static, 5);
         }
-        if (gl2.has[1] && !(T2D_PROBE_SKIP & 8) && (!SPLIT || role >= 2)) {   // lanes: off-lane = not union(lanes).contains(pose)
+        if (gl2.has[1] && !(T2D_PROBE_SKIP & 8) && (!SPLIT || role >= 2) && (PIPE != 2 || role_b)) {   // lanes: off-lane = not union(lanes).contains(pose)
             const int* pstart = geo_i + gl2.off_pstart[1];
             int p0 = pstart[env_local], p1 = pstart[env_local + 1];
             if (SPLIT) {   // waves 2 and 3: the first and the second half of the env's lane polygons
@@ -1282,7 +1311,7 @@ __global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_
     // the status epilogue's inputs, requested now by the lane that will run it (agent 0): the reduce hides part of their
     // latency.  (Fetched at the top of the kernel they sat in registers through every event phase, and at the 128
     // registers of 4 waves / SIMD that meant scratch spills: 8 B per lane stored and re-read, 13 MB of HBM traffic.)
-    if (WITH_STATUS && valid && agent == 0 && (!SPLIT || role == 0)) {
+    if (WITH_STATUS && valid && agent == 0 && (!SPLIT || role == 0) && !role_b) {
         if (carried) {
             pre_cnt = c_cnt;
             pre_frame = c_frame;
@@ -1297,8 +1326,12 @@ __global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_
     }
     T2D_MARK(9);
     if (log2A <= 6 && !SPLIT) wave_sync(); else __syncthreads();  // (c) every queue drained: s_flags complete
+    if constexpr (PIPE == 2) {   // ... the lane wave's too
+        if (role_b) pipe_post(&s_seq_b[tid >> 6], (uint32_t)step_k + 1u);
+        else pipe_wait(&s_seq_b[tid >> 6], (uint32_t)step_k + 1u);
+    }
     T2D_MARK(10);
-    if (!SPLIT || role == 0) {   // (SPLIT: the reduce, the epilogue and the restore are wave 0's)
+    if ((!SPLIT || role == 0) && !role_b) {   // (SPLIT: the reduce, the epilogue and the restore are wave 0's)
     uint32_t f = 0;
     if (active) {
         const uint32_t sf = s_flags[tid];
@@ -1508,7 +1541,12 @@ __global__ __launch_bounds__(PIPE ? 2 * kBlock : kBlock, LOOP ? 2 : T2D_COLLIDE_
     // LOOP: nothing is read back from memory (see `carried`); what the next trip clears in LDS is the wave's own when an env
     // fits a wave, else the workgroup meets first
     if (log2A <= 6) wave_sync(); else __syncthreads();
-    if constexpr (PIPE) pipe_post(&s_seq_e[tid >> 6], (uint32_t)step_k + 1u);   // this step's verdicts are in s_dec
+    if constexpr (PIPE == 2) {
+        if (!role_b) s_flags[tid] = 0;   // (see the top of the trip)
+    }
+    if constexpr (PIPE != 0) {
+        if (!role_b) pipe_post(&s_seq_e[tid >> 6], (uint32_t)step_k + 1u);   // this step's verdicts are in s_dec
+    }
     if (++step_k >= pv.loop_steps) break;
     }
     if (CHAIN) {   // this step of these envs is complete: every store above is in the L2 before the word moves
@@ -1565,8 +1603,15 @@ hipError_t launch_step_chain(const PoolView& v, const t2d_status_config& cfg, in
         const dim3 grid((v.n_env + EPB - 1) / EPB), block(2 * (EPB << log2A));
         const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
         if (log2A > 6) return hipErrorInvalidValue;
-        if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, true, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
-        else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, true, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        if (v.pipe_step == 2) {   // ... and a third set that takes the lane stage
+            const dim3 block3(3 * (EPB << log2A));
+            if (block3.x > 1024) return hipErrorInvalidValue;
+            if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, true, false, 2>), grid, block3, dyn, s, v, cfg, interval_ms, log2A);
+            else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, true, false, 2>), grid, block3, dyn, s, v, cfg, interval_ms, log2A);
+            return hipGetLastError();
+        }
+        if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, true, false, 1>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, true, false, 1>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
         return hipGetLastError();
     }
     if (v.loop_steps > 0) {   // small pool: every workgroup resident, each walks through the steps itself

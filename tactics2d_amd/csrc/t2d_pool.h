@@ -242,6 +242,7 @@ struct t2d_pool {
     uint32_t chain_count = 0;      // what every counter holds once the launches enqueued so far have run
     bool chain_steps = true;       // t2d_set_step_chaining(pool, 0, *): t2d_step_n falls back to one launch per step
     bool chain_loop = true;        // small pools take the LOOP form (t2d_set_step_chaining(pool, 2, *): never)
+    bool chain_pipe2 = true;       // ... and lane waves (PIPE = 2) where the pool has lane polygons
     bool chain_pipe = true;        // small pools: the LOOP form carries integrator waves that run a step ahead (PIPE)
     bool split_steps = true;       // small pools of 64-agent envs step with one env per workgroup (t2d_set_split_step)
     bool chain_priority = true;    // wave priorities of a chained launch: 1 = the rule for overlapping work (PoolView::overlapped)

@@ -207,10 +207,11 @@ def test_one_workgroup_per_env_form_equals_one_wave_per_env():
     hw.close()
 
 
-@pytest.mark.parametrize("chaining,form", [(1, "loop_pipe"), (3, "loop"), (2, "chain")])
+@pytest.mark.parametrize("chaining,form", [(1, "loop_pipe"), (4, "loop_pipe"), (3, "loop"), (2, "chain")])
 def test_every_multi_step_form_of_a_small_pool_equals_single_steps(chaining, form):
     """A pool of at most one workgroup per CU has three multi-step forms: workgroups chained per step, resident workgroups
-    looping over the steps, and the loop with integrator waves a step ahead of the event waves (the default).  Each against
+    looping over the steps, and the loop with integrator waves a step ahead of the event waves (the default; with lane
+    polygons in the pool a third set of waves takes the lane stage -- 4 keeps that off).  Each against
     the same steps as single launches -- auto-resets in most steps (the integrator waves' speculation is wrong there and
     they integrate again from the snapshot), fragments of 1..33 steps, 64-agent envs (one per wave) and 32-agent envs (two per
     wave, verdicts of both in one integrator wave)."""
