@@ -256,10 +256,11 @@ def time_config(name, steps, warmup, dev, variant, frag, clock_warm):
     r = Runner(scene, dev, variant)
     us_s, _ = timed(r, "step", steps, warmup, frag, clock_warm)
     us_c, _ = timed(r, "chain", steps, warmup, frag, clock_warm)
+    forms = dict(separate_launches=r.pool.step_form(1), chained=r.pool.step_form(frag))   # which kernel form each took (t2d_step_form)
     r.close()
     best = min(us_s, us_c)
     return dict(envs=n_env, participants_per_env=agents, value=scene.n / (best * 1e-6), unit="participant-steps/s",
-                us_per_step=best, us_per_step_separate_launches=us_s, us_per_step_chained=us_c, steps=steps, warmup=warmup)
+                us_per_step=best, us_per_step_separate_launches=us_s, us_per_step_chained=us_c, kernel_form=forms, steps=steps, warmup=warmup)
 
 
 def next_rows(dev, clock_warm, metric_scene):

@@ -180,6 +180,65 @@ def test_gpu_leader_rule_and_law_match_oracle_on_random_traffic(oracle, A):
         pool.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("A", [2, 7, 32, 64])
+def test_gpu_leader_rule_on_finite_horizons_far_from_the_origin(oracle, A):
+    """Finite horizons, lanes of traffic up to 5 km from the origin (fp32 positions there are good to 0.25-0.5 mm), and
+    candidates placed ON the edges of the follower's corridor -- straight ahead at lon = horizon and one fp32 step either side
+    of it, abreast at |lat| = hw and a step beyond, level with the follower (lon = 0).  Leaders and accelerations bit-equal
+    to the oracle.  (Round 3 tried a packed-fp32 filter in front of the fp64 sweep and dropped it -- DESIGN.md 8.16; this is
+    the test it had to pass.)"""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    rng = np.random.default_rng(100 + A)
+    n_env = 53
+    n = n_env * A
+    ox = np.repeat(rng.uniform(-5000, 5000, n_env), A); oy = np.repeat(rng.uniform(-5000, 5000, n_env), A)
+    lane = rng.integers(0, 4, n)
+    x = np.float32(ox + rng.uniform(-250, 250, n)); y = np.float32(oy + (lane - 1.5) * 3.75 + rng.normal(0, 0.25, n))
+    h = np.float32(np.where(rng.random(n) < 0.85, rng.normal(0, 0.02, n), rng.uniform(0, 2 * np.pi, n)))
+    rows = np.array([[30.0, 1.5, 2.0, 1.0, 3.0, 4.0, 1.875, 120.0], [25.0, 1.2, 3.0, 1.5, 2.0, 2.5, 1.5, 80.0],
+                     [0.0, 1.0, 2.0, 1.0, 3.0, 4.0, 2.0, 35.0]])
+    cid = rng.choice([0, 1, 2, L.IDM_NONE], n, p=[0.45, 0.3, 0.15, 0.1]).astype(np.uint8)
+    # edge cases: in every third env slot 0 heads along +x exactly (lon = dx, lat = dy) and slot 1 sits on an edge of its corridor
+    for e in range(0, n_env, 3):
+        i0, i1 = e * A, e * A + 1
+        h[i0] = 0.0
+        cid[i0] = e % 3 if e % 9 else 1
+        hz, hw = rows[cid[i0], 7], rows[cid[i0], 6]
+        kind = (e // 3) % 6
+        if kind == 0: dx, dy = hz, 0.0
+        elif kind == 1: dx, dy = float(np.nextafter(np.float32(hz), np.float32(1e9))), 0.0
+        elif kind == 2: dx, dy = float(np.nextafter(np.float32(hz), np.float32(0))), 0.0
+        elif kind == 3: dx, dy = 10.0, hw
+        elif kind == 4: dx, dy = 10.0, -float(np.nextafter(np.float32(hw), np.float32(9)))
+        else: dx, dy = 0.0, 0.5
+        # (integers near the env's origin: x0 + dx is then exact in fp32 for the dx above or differs from it by the rounding
+        # the oracle sees as well -- both read the same fp32 positions)
+        x[i0], y[i0] = np.float32(np.round(ox[i0])), np.float32(np.round(oy[i0]))
+        x[i1], y[i1] = np.float32(np.float64(x[i0]) + dx), np.float32(np.float64(y[i0]) + dy)
+    v = np.float32(rng.uniform(0, 35, n)); act = (rng.random(n) < 0.92).astype(np.uint8)
+    act[::A] = 1
+    a0 = np.zeros(n, np.float32); a1 = np.zeros(n, np.float32)
+    row = np.zeros((1, L.PARAM_COLS)); row[0, [L.P_LF, L.P_LR, L.P_WB, L.P_DELTA_T_MS, L.P_LENGTH, L.P_WIDTH]] = 1.2, 1.3, 2.5, 5, 4.5, 1.8
+    pool = ParticipantPool(n_env, A)
+    try:
+        pool.set_param_table(row)
+        pool.reset(x, y, h, v, np.zeros(n, np.uint8), active=act)
+        pool.set_actions(a0, a1)
+        pool.set_idm(rows, cid)
+        pool.idm_actions()
+        g0, gl = pool.download(L.F_ACT0), pool.download(L.F_LEADER)
+        w0, _, wl = oracle.idm(rows, cid, n_env, A, x, y, h, v, act, a0, a1)
+        assert np.array_equal(gl, wl), np.flatnonzero(gl != wl)[:8]
+        assert np.array_equal(g0.view(np.uint32), w0.view(np.uint32))
+        lead0 = wl.reshape(n_env, A)[::3, 0]
+        assert (lead0 == 1).any() and (lead0 != 1).any(), "the edge cases fell on one side only"
+        assert (wl >= 0).mean() > (0.2 if A >= 32 else 0.05)
+    finally:
+        pool.close()
+
+
 def _horizon_edge_scene():
     """ego at the origin heading +x (lon = dx exactly), slots 1 and 2 at 50 m (a tie: the lower index wins), slot 3 at 90 m;
     one env per horizon."""
