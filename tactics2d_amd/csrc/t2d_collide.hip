@@ -272,7 +272,7 @@ T2D_DEV void compact_and_process(unsigned long long mask, int id_base, int own_i
 #define T2D_MARK(k)                                                                     \
     do {                                                                                \
         const unsigned long long now_ = __builtin_readcyclecounter();                   \
-        if (lane == 0) pv.dbg[wave_slot_ + k] = now_ - t_prev_;                         \
+        if (lane == 0) { if (LOOP) pv.dbg[wave_slot_ + k] += now_ - t_prev_; else pv.dbg[wave_slot_ + k] = now_ - t_prev_; } \
         t_prev_ = now_;                                                                 \
     } while (0)
 #else
@@ -380,8 +380,10 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     __shared__ uint32_t s_ids_new[SPLIT ? 64 : 1];
     // PIPE: the integrator wave's hand-over (x, y, heading, ids per participant), the event wave's verdict per env (episode
     // over), and the two progress words of every wave pair: steps committed / steps decided
-    __shared__ float s_hand[PIPE ? 3 : 1][PIPE ? kBlock : 1];
-    __shared__ uint32_t s_hand_ids[PIPE ? kBlock : 1];
+    // (the hand-over has two buffers, by step parity: the integrator fills the next step's while it still waits for this
+    // step's verdict -- a speculative result too, but nobody reads a buffer before the progress word says it is committed)
+    __shared__ float s_hand[PIPE ? 2 : 1][PIPE ? 3 : 1][PIPE ? kBlock : 1];
+    __shared__ uint32_t s_hand_ids[PIPE ? 2 : 1][PIPE ? kBlock : 1];
     __shared__ uint32_t s_dec[PIPE ? kBlock / 2 : 1];
     __shared__ uint32_t s_seq_i[PIPE ? kWaves : 1], s_seq_e[PIPE ? kWaves : 1], s_seq_b[PIPE == 2 ? kWaves : 1];
     extern __shared__ __attribute__((aligned(16))) uint32_t s_geo[];  // packed geometry record
@@ -446,7 +448,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
 
 #ifdef T2D_TIMING
     unsigned long long t_prev_ = __builtin_readcyclecounter();
-    const size_t wave_slot_ = ((size_t)blockIdx.x * kWaves + (threadIdx.x >> 6)) * 16;
+    const size_t wave_slot_ = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
     if (lane == 0) {  // where and when this wave ran: HW_ID | XCC_ID << 32, start tick
         pv.dbg[wave_slot_ + 14] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |
                                   ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
@@ -562,6 +564,18 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                 a0 = a_act0[ai0];
                 a1 = a_act1[ai0];
             }
+#ifdef T2D_TIMING
+            unsigned long long it_prev_ = __builtin_readcyclecounter();
+            const size_t i_slot_ = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
+#define T2D_IMARK(q)                                                                  \
+    do {                                                                              \
+        const unsigned long long now_ = __builtin_readcyclecounter();                 \
+        if ((threadIdx.x & 63u) == 0u) pv.dbg[i_slot_ + q] += now_ - it_prev_;        \
+        it_prev_ = now_;                                                              \
+    } while (0)
+#else
+#define T2D_IMARK(q)
+#endif
             for (int k = 0; k <= n_steps; ++k) {
                 const KernargView ia = late_args();   // (per trip: see the event waves' loop)
                 float na0 = 0, na1 = 0;               // the next step's actions: their latency overlaps this integration
@@ -597,8 +611,19 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                         app0 = (float)o.app0;
                         app1 = (float)o.app1;
                     }
-                    if (decided) break;
+                    if (k < n_steps) {   // the hand-over, written while the verdict is still out (again after a reset)
+                        s_hand[k & 1][0][t] = nx;
+                        s_hand[k & 1][1][t] = ny;
+                        s_hand[k & 1][2][t] = nh;
+                        s_hand_ids[k & 1][t] = i_valid ? ids : 0u;
+                    }
+                    if (decided) {
+                        T2D_IMARK(2);   // (the second round: integrating again after a reset; the first lands on mark 0)
+                        break;
+                    }
+                    T2D_IMARK(0);
                     pipe_wait(&s_seq_e[w], (uint32_t)k);
+                    T2D_IMARK(1);
                     decided = true;
                     const bool done = i_valid && s_dec[i_env_local] != 0u;
                     if (__ballot(done) == 0ull) break;
@@ -619,7 +644,8 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                     if (k == n_steps) break;
                 }
                 if (k == n_steps) break;
-                // commit step k: the state arrays, then the hand-over to the event wave
+                // commit step k: the progress word first -- the event wave reads the hand-over, not memory -- then the state arrays
+                pipe_post(&s_seq_i[w], (uint32_t)k + 1u);
                 if (moved) {
                     as_global(ia->x)[i_idx] = nx;
                     as_global(ia->y)[i_idx] = ny;
@@ -639,11 +665,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                     vx = nvx;
                     vy = nvy;
                 }
-                s_hand[0][t] = x;
-                s_hand[1][t] = y;
-                s_hand[2][t] = h;
-                s_hand_ids[t] = i_valid ? ids : 0u;
-                pipe_post(&s_seq_i[w], (uint32_t)k + 1u);
+                T2D_IMARK(3);
                 a0 = na0;
                 a1 = na1;
             }
@@ -807,10 +829,10 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     if (SPLIT) ids = s_ids_new[tid];
     if constexpr (PIPE) {   // this step's state, committed by the pair's integrator wave
         pipe_wait(&s_seq_i[tid >> 6], (uint32_t)step_k + 1u);
-        ids = s_hand_ids[tid];
-        fx = s_hand[0][tid];
-        fy = s_hand[1][tid];
-        fh = s_hand[2][tid];
+        ids = s_hand_ids[step_k & 1][tid];
+        fx = s_hand[step_k & 1][0][tid];
+        fy = s_hand[step_k & 1][1][tid];
+        fh = s_hand[step_k & 1][2][tid];
     }
     const bool active = valid && ((ids >> kIdsActiveShift) & 0xffu);
     const int type = (ids >> kIdsTypeShift) & 0xff;
@@ -1307,7 +1329,33 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     auto e_min_dist = as_global(ep->min_dist);
     auto e_snap_min_dist = as_global(ep->snap_min_dist);
     int e_auto_reset = ep->auto_reset;
-    asm volatile("" : "+s"(e_flags), "+s"(e_env_flags), "+s"(e_cnt_step), "+s"(e_frame_ms), "+s"(e_status), "+s"(e_reward), "+s"(e_record), "+s"(e_time_penalty), "+s"(e_iou), "+s"(e_last_valid), "+s"(e_cnt_na), "+s"(e_max_iou), "+s"(e_min_dist), "+s"(e_snap_min_dist), "+s"(e_auto_reset));
+    auto e_record_ring = as_global(ep->record_ring);
+    auto e_target_c = as_global(ep->target_c);
+    int e_record_slot0 = ep->record_slot0, e_n_env = ep->n_env;
+    asm volatile("" : "+s"(e_flags), "+s"(e_env_flags), "+s"(e_cnt_step), "+s"(e_frame_ms), "+s"(e_status), "+s"(e_reward), "+s"(e_record), "+s"(e_time_penalty), "+s"(e_iou), "+s"(e_last_valid), "+s"(e_cnt_na), "+s"(e_max_iou), "+s"(e_min_dist), "+s"(e_snap_min_dist), "+s"(e_auto_reset), "+s"(e_record_ring), "+s"(e_target_c), "+s"(e_record_slot0), "+s"(e_n_env));
+    // LOOP: the status configuration as well, all sixteen words in one scalar round trip.  Its fields are read through the
+    // per-trip laundered pointer (see the top of the loop), so left alone every one is fetched where it is first used --
+    // behind its branch of the status logic: eight to ten dependent scalar round trips in a row at the end of the wave's
+    // chain (-DT2D_TIMING: 1.9 k cycles of epilogue per step on the highway pool, most of it these).
+    t2d_status_config lcfg;
+    if constexpr (!LOOP) {
+        lcfg = cfg_arg;
+    } else {   // (field by field: the source sits in the constant address space)
+        lcfg.max_step = cfg.max_step; lcfg.ego_index = cfg.ego_index; lcfg.check_dynamic = cfg.check_dynamic;
+        lcfg.check_off_lane = cfg.check_off_lane; lcfg.reward_collision = cfg.reward_collision;
+        lcfg.reward_time_exceed = cfg.reward_time_exceed; lcfg.reward_out_bound = cfg.reward_out_bound;
+        lcfg.reward_completed = cfg.reward_completed; lcfg.time_penalty_scale = cfg.time_penalty_scale;
+        lcfg.check_arrival = cfg.check_arrival; lcfg.check_no_action = cfg.check_no_action;
+        lcfg.no_action_max_step = cfg.no_action_max_step; lcfg.shaped_reward = cfg.shaped_reward;
+        lcfg.arrival_threshold = cfg.arrival_threshold; lcfg.no_action_iou = cfg.no_action_iou;
+        lcfg.dist_reward_scale = cfg.dist_reward_scale;
+        asm volatile("" : "+s"(lcfg.max_step), "+s"(lcfg.ego_index), "+s"(lcfg.check_dynamic), "+s"(lcfg.check_off_lane),
+                          "+s"(lcfg.reward_collision), "+s"(lcfg.reward_time_exceed), "+s"(lcfg.reward_out_bound),
+                          "+s"(lcfg.reward_completed), "+s"(lcfg.time_penalty_scale), "+s"(lcfg.shaped_reward),
+                          "+s"(lcfg.dist_reward_scale));
+    }
+#undef cfg
+#define cfg lcfg
     // the status epilogue's inputs, requested now by the lane that will run it (agent 0): the reduce hides part of their
     // latency.  (Fetched at the top of the kernel they sat in registers through every event phase, and at the 128
     // registers of 4 waves / SIMD that meant scratch spills: 8 B per lane stored and re-read, 13 MB of HBM traffic.)
@@ -1321,7 +1369,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
         }
         if (e_time_penalty && cfg.max_step > 0) {
             const int c = pre_cnt + 1;
-            pre_tp = pv.time_penalty[c < cfg.max_step ? c : cfg.max_step];
+            pre_tp = e_time_penalty[c < cfg.max_step ? c : cfg.max_step];
         }
     }
     T2D_MARK(9);
@@ -1342,7 +1390,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
             if (!in) f |= T2D_FLAG_OFF_LANE;
         }
     }
-    if (valid) pv.flags[idx] = f;
+    if (valid) e_flags[idx] = f;
     s_flags[tid] = f;
     if (__ballot(f != 0) != 0ull && f != 0) atomicOr(&s_env_or[env_local], f);
     if (log2A <= 6) wave_sync(); else __syncthreads();  // (d)
@@ -1359,7 +1407,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
         bool want = false;
         const double* other = nullptr;
         if (env_ok && s_kind[ego_l] == T2D_SHAPE_OBB) {
-            if (agent == 0 && cfg.check_no_action && pv.last_valid[env]) {
+            if (agent == 0 && cfg.check_no_action && e_last_valid[env]) {
                 want = true;
                 other = pv.last_pose + 8 * (size_t)env;
             } else if (agent == 1 && cfg.check_arrival && pv.target_xy) {
@@ -1375,11 +1423,11 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
         iou_ar = __shfl_down(v, 1);   // lane 0 of the env receives lane 1's value (same wave: 2^log2A >= 2 lanes per env)
     }
     if (valid && agent == 0) {
-        pv.env_flags[env] = s_env_or[env_local];
+        e_env_flags[env] = s_env_or[env_local];
         if (WITH_STATUS) {
             const int cnt = pre_cnt + 1;  // parking.py:353
-            pv.cnt_step[env] = cnt;
-            pv.frame_ms[env] = pre_frame + interval_ms;
+            e_cnt_step[env] = cnt;
+            e_frame_ms[env] = pre_frame + interval_ms;
             if (LOOP) {
                 c_cnt = cnt;
                 c_frame = pre_frame + interval_ms;
@@ -1396,12 +1444,12 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                 bool na = false;
                 if (IOU && cfg.check_no_action && ego_obb) {  // NoAction.update (no_action.py:41-53)
                     double* last = pv.last_pose + 8 * (size_t)env;
-                    int cna = pv.cnt_na[env];
-                    if (!pv.last_valid[env]) {
-                        pv.last_valid[env] = 1;
+                    int cna = e_cnt_na[env];
+                    if (!e_last_valid[env]) {
+                        e_last_valid[env] = 1;
                     } else {
                         cna = iou_na > (double)cfg.no_action_iou ? cna + 1 : 0;
-                        pv.cnt_na[env] = cna;
+                        e_cnt_na[env] = cna;
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -1435,45 +1483,47 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
             else {
                 rd = cfg.max_step > 0 ? (e_time_penalty ? pre_tp : -tanh((double)cnt / (double)cfg.max_step) * (double)cfg.time_penalty_scale) : 0.0;
                 if (cfg.shaped_reward) {
-                    double mi = pv.max_iou[env];
+                    double mi = e_max_iou[env];
                     double iou_reward = 0.0;
                     if (has_iou) iou_reward = mi == -INFINITY ? iou : iou - mi;
                     rd = rd + iou_reward;
-                    if (has_iou) pv.max_iou[env] = mi > iou ? mi : iou;
-                    if (pv.target_c) {
-                        const double dx = (double)s_cxy[0][ego] - pv.target_c[2 * (size_t)env];
-                        const double dy = (double)s_cxy[1][ego] - pv.target_c[2 * (size_t)env + 1];
+                    if (has_iou) e_max_iou[env] = mi > iou ? mi : iou;
+                    if (e_target_c) {
+                        const double dx = (double)s_cxy[0][ego] - e_target_c[2 * (size_t)env];
+                        const double dy = (double)s_cxy[1][ego] - e_target_c[2 * (size_t)env + 1];
                         const double d = __builtin_sqrt(dx * dx + dy * dy);
-                        const double md = pv.min_dist[env];
+                        const double md = e_min_dist[env];
                         if (d < md) {
                             rd += (md - d) * (double)cfg.dist_reward_scale;
-                            pv.min_dist[env] = d;
+                            e_min_dist[env] = d;
                         }
                     }
                 }
             }
             const float r = (float)rd;
-            pv.iou[env] = has_iou ? (float)iou : __builtin_nanf("");
+            e_iou[env] = has_iou ? (float)iou : __builtin_nanf("");
             const bool terminated = scen == T2D_SCENARIO_COMPLETED;
             const bool truncated = !terminated && (scen != T2D_SCENARIO_NORMAL || traf != T2D_TRAFFIC_NORMAL);
             // {scenario, traffic, terminated, truncated}: the four status bytes are also the record's second word
             const uint32_t st = (uint32_t)scen | (uint32_t)traf << 8 | (uint32_t)terminated << 16 | (uint32_t)truncated << 24;
             ((T2D_GLOBAL uint32_t*)e_status)[env] = st;
-            pv.reward[env] = r;
-            if (MULTI) pv.record_ring[(size_t)((pv.record_slot0 + step_k) & (T2D_RECORD_RING - 1)) * (size_t)pv.n_env + env] = make_uint2(__float_as_uint(r), st);
-            else pv.record[env] = make_uint2(__float_as_uint(r), st);
+            e_reward[env] = r;
+            // (the record {reward bits, status word} as one 8-byte store)
+            const unsigned long long rec = (unsigned long long)__float_as_uint(r) | ((unsigned long long)st << 32);
+            if (MULTI) ((T2D_GLOBAL unsigned long long*)e_record_ring)[(size_t)((e_record_slot0 + step_k) & (T2D_RECORD_RING - 1)) * (size_t)e_n_env + env] = rec;
+            else ((T2D_GLOBAL unsigned long long*)e_record)[env] = rec;
             if (e_auto_reset) {
                 const bool done = terminated || truncated;
                 s_done[env_local] = done;
                 if (PIPE) s_dec[env_local] = done;   // (the integrator wave reads it before it commits the next step)
                 if (done) {  // ParkingEnv.reset: counters and detector state back to the episode start
-                    pv.cnt_step[env] = 0;
-                    pv.frame_ms[env] = 0;
+                    e_cnt_step[env] = 0;
+                    e_frame_ms[env] = 0;
                     if (LOOP) c_cnt = c_frame = 0;
-                    pv.last_valid[env] = 0;
-                    pv.cnt_na[env] = 0;
-                    pv.max_iou[env] = -INFINITY;
-                    pv.min_dist[env] = pv.snap_min_dist[env];
+                    e_last_valid[env] = 0;
+                    e_cnt_na[env] = 0;
+                    e_max_iou[env] = -INFINITY;
+                    e_min_dist[env] = e_snap_min_dist[env];
                 }
             }
         }
