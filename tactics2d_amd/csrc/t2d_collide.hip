@@ -524,8 +524,13 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
         asm volatile("" ::: "memory");   // what the other wave wrote before it moved the word is read after this point
     };
     [[maybe_unused]] auto pipe_post = [&](uint32_t* word, uint32_t value) {
-        // (a wave's LDS operations complete in order: the plain writes above are in the LDS before the word moves)
+        // (a wave's LDS operations complete in order: the plain writes above are in the LDS before the word moves; the
+        // conservative build -- tests/test_gpu_soak.py -- waits for them first, and for what it read, like wave_sync)
+#ifdef T2D_WAVE_SYNC_WAITCNT
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         asm volatile("" ::: "memory");
+#endif
         if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     if constexpr (PIPE) {

@@ -23,13 +23,14 @@ from tactics2d_amd import layout as L, scenarios as S
 from tactics2d_amd.pool import ParticipantPool
 steps, chained = int(sys.argv[1]), sys.argv[2] == "chain"
 dev = torch.device("cuda", 0)
-sc = S.mixed(4096, 64, seed=3)
+sc = S.mixed(int(sys.argv[3]), 64, seed=3)
 rng = np.random.default_rng(11)
 sets = [sc.sample_actions(rng) for _ in range(32)]
 a0 = torch.from_numpy(np.stack([s[0] for s in sets])).to(dev).contiguous()
 a1 = torch.from_numpy(np.stack([s[1] for s in sets])).to(dev).contiguous()
 pool = ParticipantPool(sc.n_env, sc.A); sc.load(pool)
 pool.set_integrator_variant("exact"); pool.set_auto_reset(True)
+form = pool.step_form(32 if chained else 1)
 h = hashlib.sha256()
 done = 0
 while done < steps:
@@ -45,13 +46,13 @@ while done < steps:
         for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_FLAGS, L.F_RECORD, L.F_CNT_STEP):
             h.update(pool.download(f).tobytes())
 flags = pool.download(L.F_FLAGS)
-print(json.dumps(dict(sha=h.hexdigest(), steps=done, flagged=float((flags != 0).mean()))))
+print(json.dumps(dict(sha=h.hexdigest(), steps=done, flagged=float((flags != 0).mean()), form=form)))
 """
 
 
-def _run(lib, steps, mode):
+def _run(lib, steps, mode, n_env=4096):
     env = dict(os.environ, T2D_LIB_NAME=lib)
-    out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT), str(steps), mode], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT), str(steps), mode, str(n_env)], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     return json.loads(out.stdout.strip().splitlines()[-1])
 
@@ -66,3 +67,18 @@ def test_waitcnt_free_wave_sync_and_chained_launches_over_thousands_of_steps():
     assert ref["steps"] == steps and ref["flagged"] > 0.05
     assert _run("libt2d_hip_waitcnt.so", steps, "step")["sha"] == ref["sha"], "the waitcnt-free wave_sync changed a result"
     assert _run("libt2d_hip.so", steps, "chain")["sha"] == ref["sha"], "chained launches differ from separate launches"
+
+
+def test_integrator_waves_a_step_ahead_over_thousands_of_steps():
+    """The PIPE form of t2d_step_n (a pool of at most one workgroup per CU: integrator waves, event waves and lane waves hand
+    each other the state and the verdicts through LDS words, t2d_collide.hip) against separate launches, and against the
+    conservative build, in which every hand-shake first waits for the wave's LDS operations: 8192 steps of 768 mixed envs =
+    1.6 M hand-overs, 0.5 M of them after a wrong speculation (an episode ends in about a third of the env-steps).  One hash."""
+    steps, n_env = 8192, 768
+    ref = _run("libt2d_hip.so", steps, "step", n_env)
+    assert ref["steps"] == steps and ref["flagged"] > 0.05 and ref["form"] in ("step", "step_split")
+    got = _run("libt2d_hip.so", steps, "chain", n_env)
+    assert got["form"] == "loop_pipe"
+    assert got["sha"] == ref["sha"], "the PIPE form differs from separate launches"
+    chk = _run("libt2d_hip_waitcnt.so", steps, "chain", n_env)
+    assert chk["form"] == "loop_pipe" and chk["sha"] == ref["sha"], "the conservative build's PIPE form differs"
