@@ -226,3 +226,13 @@ def test_every_multi_step_form_of_a_small_pool_equals_single_steps(chaining, for
         rec = want[_fields().index(L.F_RECORD)].reshape(L.RECORD_RING, sc.n_env, 2)
         ended = (rec[:sum(calls), :, 1] >> 16).astype(bool)
         assert ended.any(1).sum() >= sum(calls) // 2, "too few steps with an episode end: the reset path was hardly exercised"
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg4", "cfg5"])
+def test_baseline_shards_at_full_size_as_fragments(name):
+    """BASELINE.json's configs 3-5 at their per-GPU sizes (1024 x 64 highway, 512 x 32 intersection, 1024 x 64 mixed: one
+    workgroup per CU and fewer) as t2d_step_n fragments -- the form bench.py's `configs` times -- against single launches."""
+    from tactics2d_amd import scenarios as S
+    sc = {"cfg3": lambda: S.highway(1024, 64, seed=1), "cfg4": lambda: S.intersection(512, 32, seed=2),
+          "cfg5": lambda: S.mixed(1024, 64, seed=3)}[name]()
+    _compare(sc, 48, "fast", calls=(32, 16), form="loop_pipe")
