@@ -334,7 +334,8 @@ enum {
     T2D_FORM_CHAIN = 5,       /* one launch of (workgroup, step) workgroups ordered by counters                        */
     T2D_FORM_CHAIN_SPLIT = 6, /* the same with one workgroup per env                                                   */
     T2D_FORM_LOOP = 7,        /* resident workgroups loop over the steps                                               */
-    T2D_FORM_LOOP_PIPE = 8    /* ... with integrator waves running one step ahead of the event waves                   */
+    T2D_FORM_LOOP_PIPE = 8,   /* ... with integrator waves running one step ahead of the event waves                   */
+    T2D_FORM_EGO_LOOP_PIPE = 9 /* the single-ego kernel's loop with integrator waves                                  */
 };
 int t2d_step_form(t2d_pool* pool, int32_t n_steps);   /* a T2D_FORM_* value; -1: null pool */
 

@@ -1325,6 +1325,8 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
         if ((rc = record_event(p, 7, s, true))) return rc;
         if (ego) {   // 16 lanes per env, each group of lanes loops over the steps
             v.loop_steps = n;
+            // (at most one workgroup of 16 envs per CU: integrator waves a step ahead of the event waves, t2d_ego.hip)
+            v.pipe_step = p->chain_pipe && p->device_cus > 0 && (p->v.n_env + 15) / 16 <= p->device_cus;
             T2D_HIP(p, t2d::launch_ego_step(v, p->status_cfg, interval_ms, p->integrator_variant, s));
         } else {
             T2D_HIP(p, t2d::launch_step_chain(v, p->status_cfg, interval_ms, p->integrator_variant, n, s));
@@ -1344,7 +1346,11 @@ int t2d_step_form(t2d_pool* p, int32_t n_steps) {
     const bool iou = p->status_cfg.check_no_action || p->status_cfg.check_arrival;
     if (!p->fused_step || p->idm_on || p->has_drift || p->scene_regen) return T2D_FORM_UNFUSED;
     const bool chain = p->chain_steps && n_steps >= 2 && (ego ? p->chain_loop : !iou);
-    if (ego) return chain ? T2D_FORM_EGO_LOOP : T2D_FORM_EGO;
+    if (ego) {
+        if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
+        if (chain && p->chain_pipe && p->device_cus > 0 && (p->v.n_env + 15) / 16 <= p->device_cus) return T2D_FORM_EGO_LOOP_PIPE;
+        return chain ? T2D_FORM_EGO_LOOP : T2D_FORM_EGO;
+    }
     const bool split = use_split(p);
     if (!chain) return split ? T2D_FORM_STEP_SPLIT : T2D_FORM_STEP;
     const int wgs = (p->v.n_env + p->v.geo_layout.epb - 1) / p->v.geo_layout.epb;

@@ -45,23 +45,148 @@ T2D_DEV void ego_wave_sync() {   // LDS writes of this wave -> visible to its ot
 // (state, counters, detector history) the next reads back with sc1 loads, behind an s_waitcnt vmcnt(0).  An env's chain of
 // steps then pays no launch boundary and no start-up per step: with one wave per SIMD they are a quarter of a step.  The
 // argument structs are read through a kernarg pointer laundered at the top of every trip (see collide_kernel's LOOP form).
-template <int VARIANT, bool LOOP = false>
-__global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv_arg, t2d_status_config cfg_arg, int interval_ms) {
+// PIPE = true (a LOOP launch of at most one workgroup per CU): the workgroup carries a second set of four waves, and wave
+// 4 + w integrates step k + 1 of the envs of wave w while that wave checks the events of step k -- collide_kernel's PIPE
+// form (t2d_collide.hip): speculation on "the episode goes on", integrated again from the snapshot when it did not, nothing
+// visible before the commit; the hand-over (x, y, heading, ids per env) and the verdicts go through LDS.  The detector
+// history (previous pose, NoAction counter, _max_iou, _min_dist) is the event wave's alone and stays where it was.
+constexpr int kEgoSpinLimit = 1 << 17;
+T2D_DEV void ego_pipe_wait(uint32_t* word, uint32_t want, uint32_t* err) {   // bounded: a lost wait raises chain_err, never hangs
+    int spins = 0;
+    while ((int32_t)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - want) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kEgoSpinLimit) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+T2D_DEV void ego_pipe_post(uint32_t* word, uint32_t value) {   // (after the wave's plain LDS writes: they complete in order)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <int VARIANT, bool LOOP = false, bool PIPE = false>
+__global__ __launch_bounds__(PIPE ? 2 * kEgoBlock : kEgoBlock, 2) void ego_step_kernel(PoolView pv_arg, t2d_status_config cfg_arg, int interval_ms) {
+    static_assert(!PIPE || LOOP, "PIPE = a LOOP launch with integrator waves");
     auto pvp = [&]() { if constexpr (LOOP) return late_args(); else return &pv_arg; }();
     auto cfgp = [&]() { if constexpr (LOOP) return late_cfg(); else return &cfg_arg; }();
 #define pv (*pvp)
 #define cfg (*cfgp)
     // the two quads of each IoU, [env of the workgroup][iou][A | B][x0 y0 ... x3 y3]
     __shared__ double s_quad[kEgoPerBlock][2][2][8];
+    // PIPE: the hand-over by step parity, the verdict per env, the progress words of every wave pair
+    __shared__ float s_hand[PIPE ? 2 : 1][3][PIPE ? kEgoPerBlock : 1];
+    __shared__ uint32_t s_hand_ids[PIPE ? 2 : 1][PIPE ? kEgoPerBlock : 1];
+    __shared__ uint32_t s_dec[PIPE ? kEgoPerBlock : 1], s_seq_i[PIPE ? 4 : 1], s_seq_e[PIPE ? 4 : 1];
+    const int etid = (int)(threadIdx.x & (kEgoBlock - 1));   // (PIPE: thread 256 + t serves the env of thread t)
     const int lane = threadIdx.x & 63;
-    const int l = threadIdx.x & (kEgoLanes - 1);        // lane inside the env's group
-    const int grp = threadIdx.x / kEgoLanes;            // env inside the workgroup
+    const int l = etid & (kEgoLanes - 1);               // lane inside the env's group
+    const int grp = etid / kEgoLanes;                   // env inside the workgroup
     const int gbase = lane & ~(kEgoLanes - 1);          // first lane of the group inside the wave
     const unsigned long long gmask = ((1ull << kEgoLanes) - 1ull) << gbase;
     const int env_raw = blockIdx.x * kEgoPerBlock + grp;
     const bool live = env_raw < pv.n_env;               // (padding groups of the last workgroup run along on env 0, write nothing)
     const int env = live ? env_raw : 0;
     const int idx = env;                                // max_agents == 1
+    if constexpr (PIPE) {
+        if (threadIdx.x < 4u) s_seq_i[threadIdx.x] = s_seq_e[threadIdx.x] = 0u;
+        if (threadIdx.x < (unsigned)kEgoPerBlock) s_dec[threadIdx.x] = 0u;
+        __syncthreads();
+        if (threadIdx.x >= (unsigned)kEgoBlock) {
+            // ======== integrator waves ========
+            const int w = etid >> 6;
+            auto G = [](auto* q) { return as_global(q); };
+            uint32_t ids = ld_state<true>(G(pv.ids) + idx);
+            float x = ld_state<true>(G(pv.x) + idx), y = ld_state<true>(G(pv.y) + idx), h = ld_state<true>(G(pv.heading) + idx);
+            float v = ld_state<true>(G(pv.speed) + idx), vx = 0.f, vy = 0.f;
+            if (((ids >> kIdsModelShift) & 0xff) == T2D_MODEL_POINTMASS) {
+                vx = ld_state<true>(G(pv.vx) + idx);
+                vy = ld_state<true>(G(pv.vy) + idx);
+            }
+            const int n_steps = pv.loop_steps;
+            const size_t act_step = (size_t)pv.chain_act_step, ai0 = (size_t)idx * pv.act_stride;
+            float a0 = pv.act0[ai0], a1 = pv.act1[ai0];
+            for (int k = 0; k <= n_steps; ++k) {
+                const KernargView ia = late_args();
+                float na0 = 0.f, na1 = 0.f;   // the next step's actions: their latency overlaps this integration
+                if (k + 1 < n_steps) {
+                    na0 = ia->act0[ai0 + (size_t)(k + 1) * act_step];
+                    na1 = ia->act1[ai0 + (size_t)(k + 1) * act_step];
+                }
+                float nx = x, ny = y, nh = h, nv = v, nvx = vx, nvy = vy, app0 = 0.f, app1 = 0.f;
+                bool moved = false, has_vel = false;
+                bool todo = k < n_steps, decided = k == 0;
+                for (;;) {   // at most two rounds: the speculative one, and one for envs whose episode had ended
+                    const int model = (ids >> kIdsModelShift) & 0xff, type = (ids >> kIdsTypeShift) & 0xff;
+                    if (todo) {
+                        nx = x; ny = y; nh = h; nv = v; nvx = vx; nvy = vy;
+                        moved = false; has_vel = false;
+                    }
+                    if (todo && live && ((ids >> kIdsActiveShift) & 0xffu) && model != T2D_MODEL_DRIFT) {
+                        auto P = [&](int col) -> double { return ia->params[col * T2D_MAX_TYPES + type]; };
+                        const bool pm = model == T2D_MODEL_POINTMASS;
+                        const integ::StepOut o = integ::step_participant<VARIANT>(model, P, (double)x, (double)y, (double)h, (double)v,
+                                                                                  pm ? (double)vx : 0.0, pm ? (double)vy : 0.0,
+                                                                                  (double)a0, (double)a1, interval_ms);
+                        nx = (float)o.x; ny = (float)o.y; nh = (float)o.heading; nv = (float)o.speed;
+                        moved = true;
+                        has_vel = o.has_velocity;
+                        if (o.has_velocity) {
+                            nvx = (float)o.vx;
+                            nvy = (float)o.vy;
+                        }
+                        app0 = (float)o.app0;
+                        app1 = (float)o.app1;
+                    }
+                    if (k < n_steps && l == 0) {   // the hand-over, written while the verdict is still out
+                        s_hand[k & 1][0][grp] = nx;
+                        s_hand[k & 1][1][grp] = ny;
+                        s_hand[k & 1][2][grp] = nh;
+                        s_hand_ids[k & 1][grp] = live ? ids : 0u;
+                    }
+                    if (decided) break;
+                    ego_pipe_wait(&s_seq_e[w], (uint32_t)k, ia->chain_err);
+                    decided = true;
+                    const bool done = live && s_dec[grp] != 0u;
+                    if (__ballot(done) == 0ull) break;
+                    if (done) {   // back to the snapshot (the state arrays are the integrator's to write)
+                        const float r0 = ia->snap[0][idx], r1 = ia->snap[1][idx], r2 = ia->snap[2][idx], r3 = ia->snap[3][idx];
+                        const float r4 = ia->snap[4][idx], r5 = ia->snap[5][idx];
+                        const uint32_t rid = ia->snap_ids[idx];
+                        if (l == 0) {
+                            ia->x[idx] = r0; ia->y[idx] = r1; ia->heading[idx] = r2; ia->speed[idx] = r3;
+                            ia->vx[idx] = r4; ia->vy[idx] = r5; ia->ids[idx] = rid;
+                        }
+                        x = r0; y = r1; h = r2; v = r3; vx = r4; vy = r5; ids = rid;
+                    }
+                    todo = done && k < n_steps;
+                    if (k == n_steps) break;
+                }
+                if (k == n_steps) break;
+                ego_pipe_post(&s_seq_i[w], (uint32_t)k + 1u);   // commit: the progress word, then the state arrays
+                if (moved && l == 0) {
+                    ia->x[idx] = nx; ia->y[idx] = ny; ia->heading[idx] = nh; ia->speed[idx] = nv;
+                    if (has_vel && (((ids >> kIdsModelShift) & 0xff) == T2D_MODEL_POINTMASS || (ia->out_mask & T2D_OUT_VELOCITY))) {
+                        ia->vx[idx] = nvx;
+                        ia->vy[idx] = nvy;
+                    }
+                    if (ia->out_mask & T2D_OUT_APPLIED) {
+                        ia->applied0[idx] = app0;
+                        ia->applied1[idx] = app1;
+                    }
+                }
+                x = nx; y = ny; h = nh; v = nv;
+                if (has_vel) {
+                    vx = nvx;
+                    vy = nvy;
+                }
+                a0 = na0;
+                a1 = na1;
+            }
+            return;
+        }
+    }
     int step_k = 0;
     for (;;) {   // (one trip unless LOOP)
     if constexpr (LOOP) {
@@ -71,14 +196,18 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv_arg,
     auto G = [](auto* q) { return as_global(q); };
 
     // ---------------- loads (group-uniform addresses) -------------------------------------------------------------
-    const uint32_t ids = ld_state<LOOP>(G(pv.ids) + idx);
-    float fx = ld_state<LOOP>(G(pv.x) + idx), fy = ld_state<LOOP>(G(pv.y) + idx), fh = ld_state<LOOP>(G(pv.heading) + idx);
-    const float fv = ld_state<LOOP>(G(pv.speed) + idx);
-    const size_t ai = (size_t)idx * pv.act_stride + (LOOP ? (size_t)step_k * (size_t)pv.chain_act_step : 0);
-    float fa0 = pv.act0[ai], fa1 = pv.act1[ai];
-    if (pv.idm_ctrl && pv.idm_ctrl[idx] != T2D_IDM_NONE) {
-        fa0 = pv.own_act0[idx];
-        fa1 = pv.own_act1[idx];
+    uint32_t ids = 0;
+    float fx = 0.f, fy = 0.f, fh = 0.f, fv = 0.f, fa0 = 0.f, fa1 = 0.f;
+    if constexpr (!PIPE) {
+        ids = ld_state<LOOP>(G(pv.ids) + idx);
+        fx = ld_state<LOOP>(G(pv.x) + idx); fy = ld_state<LOOP>(G(pv.y) + idx); fh = ld_state<LOOP>(G(pv.heading) + idx);
+        fv = ld_state<LOOP>(G(pv.speed) + idx);
+        const size_t ai = (size_t)idx * pv.act_stride + (LOOP ? (size_t)step_k * (size_t)pv.chain_act_step : 0);
+        fa0 = pv.act0[ai]; fa1 = pv.act1[ai];
+        if (pv.idm_ctrl && pv.idm_ctrl[idx] != T2D_IDM_NONE) {
+            fa0 = pv.own_act0[idx];
+            fa1 = pv.own_act1[idx];
+        }
     }
     const int pre_cnt = ld_state<LOOP>(G(pv.cnt_step) + env), pre_frame = ld_state<LOOP>(G(pv.frame_ms) + env);
     float bxmin = 0, bxmax = 0, bymin = 0, bymax = 0;
@@ -123,13 +252,20 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv_arg,
             pre_min_dist = ld_state<LOOP>(G(pv.min_dist) + env);
         }
     }
+    if constexpr (PIPE) {   // this step's state, committed by the pair's integrator wave (the loads above are in flight meanwhile)
+        ego_pipe_wait(&s_seq_i[etid >> 6], (uint32_t)step_k + 1u, pv.chain_err);
+        ids = s_hand_ids[step_k & 1][grp];
+        fx = s_hand[step_k & 1][0][grp];
+        fy = s_hand[step_k & 1][1][grp];
+        fh = s_hand[step_k & 1][2][grp];
+    }
     const bool active = live && ((ids >> kIdsActiveShift) & 0xffu);
     const int type = (ids >> kIdsTypeShift) & 0xff;
     const int model = (ids >> kIdsModelShift) & 0xff;
     auto P = [&](int col) -> double { return pv.params[col * T2D_MAX_TYPES + type]; };
 
     // ---------------- physics: one PhysicsModelBase.step, the group's lanes all the same --------------------------
-    if (active && model != T2D_MODEL_DRIFT) {   // (SingleTrackDrift participants are integrated by drift_kernel)
+    if (!PIPE && active && model != T2D_MODEL_DRIFT) {   // (SingleTrackDrift participants are integrated by drift_kernel)
         double pvx = 0.0, pvy = 0.0;
         if (model == T2D_MODEL_POINTMASS) {
             pvx = (double)ld_state<LOOP>(G(pv.vx) + idx);
@@ -360,6 +496,7 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv_arg,
                                                         (uint32_t)terminated << 16 | (uint32_t)truncated << 24);
     if (LOOP) pv.record_ring[(size_t)((pv.record_slot0 + step_k) & (T2D_RECORD_RING - 1)) * (size_t)pv.n_env + env] = recv;
     else pv.record[env] = recv;
+    if (PIPE && pv.auto_reset) s_dec[grp] = (terminated || truncated) ? 1u : 0u;   // (read by the integrator wave before it commits)
     if (pv.auto_reset && (terminated || truncated)) {  // ParkingEnv.reset: state, counters, detector state back to the start
         // (every snapshot value first, then the stores: as load / store pairs each pair waits for its own memory round trip)
         const double smd = pv.snap_min_dist[env];
@@ -378,20 +515,23 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv_arg,
         pv.cnt_na[env] = 0;
         pv.max_iou[env] = -INFINITY;
         pv.min_dist[env] = smd;
-        pv.x[idx] = r0;
-        pv.y[idx] = r1;
-        pv.heading[idx] = r2;
-        pv.speed[idx] = r3;
-        pv.vx[idx] = r4;
-        pv.vy[idx] = r5;
-        pv.ids[idx] = rid;
-        if (drift) {
-            pv.omega_f[idx] = w0;
-            pv.omega_r[idx] = w1;
+        if (!PIPE) {   // (PIPE: the state arrays are the integrator wave's to write)
+            pv.x[idx] = r0;
+            pv.y[idx] = r1;
+            pv.heading[idx] = r2;
+            pv.speed[idx] = r3;
+            pv.vx[idx] = r4;
+            pv.vy[idx] = r5;
+            pv.ids[idx] = rid;
+            if (drift) {
+                pv.omega_f[idx] = w0;
+                pv.omega_r[idx] = w1;
+            }
         }
     }
     }   // (the group's first lane)
     if (!LOOP) break;
+    if constexpr (PIPE) ego_pipe_post(&s_seq_e[etid >> 6], (uint32_t)step_k + 1u);   // the verdicts first: nobody waits for the stores but this wave
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this trip's stores are in the L2 before the next trip's sc1 loads
     ego_wave_sync();
     if (++step_k >= pv.loop_steps) break;
@@ -404,6 +544,12 @@ __global__ __launch_bounds__(kEgoBlock, 2) void ego_step_kernel(PoolView pv_arg,
 
 hipError_t launch_ego_step(const PoolView& v, const t2d_status_config& cfg, int interval_ms, int variant, hipStream_t s) {
     const dim3 grid((v.n_env + kEgoPerBlock - 1) / kEgoPerBlock), block(kEgoBlock);
+    if (v.loop_steps > 0 && v.pipe_step) {   // ... with integrator waves a step ahead
+        const dim3 block2(2 * kEgoBlock);
+        if (variant == 0) hipLaunchKernelGGL((ego_step_kernel<0, true, true>), grid, block2, 0, s, v, cfg, interval_ms);
+        else hipLaunchKernelGGL((ego_step_kernel<1, true, true>), grid, block2, 0, s, v, cfg, interval_ms);
+        return hipGetLastError();
+    }
     if (v.loop_steps > 0) {   // t2d_step_n: the groups walk through the steps themselves
         if (variant == 0) hipLaunchKernelGGL((ego_step_kernel<0, true>), grid, block, 0, s, v, cfg, interval_ms);
         else hipLaunchKernelGGL((ego_step_kernel<1, true>), grid, block, 0, s, v, cfg, interval_ms);

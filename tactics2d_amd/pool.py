@@ -267,7 +267,7 @@ class ParticipantPool:
         """Small pools of 33..64-agent envs: one env per workgroup, its event stages on four waves (t2d_set_split_step)."""
         self._ck(self._lib.t2d_set_split_step(self._h, int(bool(on))))
 
-    STEP_FORMS = ("unfused", "step", "step_split", "ego", "ego_loop", "chain", "chain_split", "loop", "loop_pipe")
+    STEP_FORMS = ("unfused", "step", "step_split", "ego", "ego_loop", "chain", "chain_split", "loop", "loop_pipe", "ego_loop_pipe")
 
     def step_form(self, n_steps=1):
         """Name of the step-kernel form a call of n_steps steps takes on this pool now (t2d_step_form)."""

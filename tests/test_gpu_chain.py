@@ -152,7 +152,9 @@ def test_single_ego_pools_loop_through_arrivals_no_action_and_time_limits():
             a0, a1 = self.sc.sample_actions(r)
             a0[still | on] = 0.0
             return a0, a1
-    want = _compare(Calm(sc), 64, "exact", calls=(1, 2, 29, 32))
+    # (both multi-step forms of the single-ego kernel: integrator waves a step ahead of the event waves, and the plain loop)
+    _compare(Calm(sc), 64, "exact", calls=(1, 2, 29, 32), chaining=3, form="ego_loop")
+    want = _compare(Calm(sc), 64, "exact", calls=(1, 2, 29, 32), form="ego_loop_pipe")
     from tactics2d_amd import layout as L
     rec = want[_fields().index(L.F_RECORD)].reshape(L.RECORD_RING, sc.n_env, 2)
     seen = set(map(tuple, np.stack([rec[..., 1] & 0xff, (rec[..., 1] >> 8) & 0xff], -1).reshape(-1, 2).tolist()))
