@@ -23,7 +23,9 @@ from tactics2d_amd import layout as L, scenarios as S
 from tactics2d_amd.pool import ParticipantPool
 steps, chained = int(sys.argv[1]), sys.argv[2] == "chain"
 dev = torch.device("cuda", 0)
-sc = S.mixed(int(sys.argv[3]), 64, seed=3)
+sc = S.parking(int(sys.argv[3]), seed0=3) if len(sys.argv) > 4 and sys.argv[4] == "parking" else S.mixed(int(sys.argv[3]), 64, seed=3)
+if sc.name.startswith("parking"):
+    sc.status.update(max_step=40, no_action_max_step=5)   # short episodes: time limits and NoAction verdicts every few steps
 rng = np.random.default_rng(11)
 sets = [sc.sample_actions(rng) for _ in range(32)]
 a0 = torch.from_numpy(np.stack([s[0] for s in sets])).to(dev).contiguous()
@@ -50,9 +52,9 @@ print(json.dumps(dict(sha=h.hexdigest(), steps=done, flagged=float((flags != 0).
 """
 
 
-def _run(lib, steps, mode, n_env=4096):
+def _run(lib, steps, mode, n_env=4096, scene="mixed"):
     env = dict(os.environ, T2D_LIB_NAME=lib)
-    out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT), str(steps), mode, str(n_env)], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT), str(steps), mode, str(n_env), scene], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     return json.loads(out.stdout.strip().splitlines()[-1])
 
@@ -82,3 +84,15 @@ def test_integrator_waves_a_step_ahead_over_thousands_of_steps():
     assert got["sha"] == ref["sha"], "the PIPE form differs from separate launches"
     chk = _run("libt2d_hip_waitcnt.so", steps, "chain", n_env)
     assert chk["form"] == "loop_pipe" and chk["sha"] == ref["sha"], "the conservative build's PIPE form differs"
+
+
+def test_single_ego_integrator_waves_over_thousands_of_steps():
+    """The same for the single-ego kernel's PIPE form (t2d_ego.hip): 2048 parking envs, 4096 steps, IoU events on, episodes of
+    at most 40 steps -- separate launches, fragments, and the fragments of the conservative build: one hash."""
+    steps, n_env = 4096, 2048
+    ref = _run("libt2d_hip.so", steps, "step", n_env, "parking")
+    assert ref["steps"] == steps and ref["form"] == "ego"
+    got = _run("libt2d_hip.so", steps, "chain", n_env, "parking")
+    assert got["form"] == "ego_loop_pipe" and got["sha"] == ref["sha"], "the single-ego PIPE form differs from separate launches"
+    chk = _run("libt2d_hip_waitcnt.so", steps, "chain", n_env, "parking")
+    assert chk["sha"] == ref["sha"], "the conservative build's single-ego PIPE form differs"
