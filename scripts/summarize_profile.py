@@ -26,9 +26,11 @@ def short(name):
             return "collide_kernel"
         pipe = {"0": "", "false": "", "1": "_pipe", "2": "_pipe2"}.get(a[6], "_pipe")
         return "step_kernel" + ("_chained" if a[3] == "true" else "_loop" if a[4] == "true" else "") + ("_split" if a[5] == "true" else "") + pipe
-    m = re.search(r"ego_step_kernel<([^>]*)>", n)
-    if m and m.group(1).split(",")[-1] == "true":
-        return "ego_step_kernel_loop"
+    m = re.search(r"ego_step_kernel<([^>]*)>", n)   # <VARIANT, LOOP, PIPE>
+    if m:
+        a = m.group(1).split(",") + ["false", "false"]
+        if a[1] == "true":
+            return "ego_step_kernel_loop" + ("_pipe" if a[2] == "true" else "")
     for k in ("ego_step_kernel", "lidar_kernel", "idm_kernel", "parking_scene_kernel", "scene_refill_kernel", "integrate_kernel",
               "restore_env_kernel", "restore_kernel", "drift_kernel"):
         if k in n:
