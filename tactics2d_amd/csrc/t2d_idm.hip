@@ -14,54 +14,15 @@
 // conflict free), ~12 fp64 operations per candidate, then evaluates the IDM law once.  Output: accel ->
 // the pool's act0 field, steer 0 -> its act1 field (the reference returns (steering, acceleration); the physics
 // models take (accel, steer)), leader index -> T2D_F_LEADER.  HBM: 17 B read + 12 B written per participant.
-#include <type_traits>
-
-#include "t2d_math.h"
-#include "t2d_pool.h"
+#include "t2d_idm_dev.h"
 
 namespace t2d {
 
 namespace {
 
+using namespace idm;
+
 constexpr int kIdmBlock = 256;
-
-// IDMController.step + _idm_acceleration for one participant (oracle t2do_idm_accel)
-struct IdmRow {
-    double des, T, s0, amax, b, delta, hw, horizon;
-};
-
-T2D_DEV double idm_law(const IdmRow& c, double v, bool has_lead, double dx, double dy, double v_lead) {
-    const double des = c.des, T = c.T, s0 = c.s0, amax = c.amax, b = c.b, delta = c.delta;
-    // (v / v_des)^delta once, ahead of the regimes: a wave with leaders for some lanes and none for others runs both
-    // branches, and the power (deterministic log + exp) is the bulk of either
-    const double pw = des > 0.0 ? pow_det(v / des, delta) : 0.0;
-    double a;
-    if (!has_lead) {  // :75-85
-        if (des > 0.0) a = amax * (1.0 - pw);
-        else a = v > 0.0 ? -b : 0.0;
-    } else {  // :106-141
-        const double dist = __builtin_sqrt(dx * dx + dy * dy);  // np.hypot
-        const double dv = v_lead - v;
-        double s_star = s0 + v * T + (v * dv) / (2.0 * __builtin_sqrt(amax * b));
-        if (s0 > s_star) s_star = s0;  // max(s_star, min_spacing)
-        if (dist > 0.0) {
-            const double term = des > 0.0 ? pw : (v > 0.0 ? 1.0 : 0.0);
-            const double q = s_star / dist;
-            a = amax * (1.0 - term - q * q);
-        } else {
-            a = -b;
-        }
-    }
-    return clipd(a, -b, amax);  // np.clip :90
-}
-
-// the smallest double above h for h >= 0 (h itself when it is +inf or NaN: `lon < h` then equals `lon <= h` for every
-// finite lon); 0 for h < 0, where no offset is both > 0 and <= h
-T2D_DEV double just_above(double h) {
-    if (!(h >= 0.0)) return h != h ? h : 0.0;
-    if (h == __builtin_inf()) return h;
-    return __longlong_as_double(__double_as_longlong(h + 0.0) + 1);   // h + 0.0: -0.0 -> +0.0
-}
 
 // act0_own / act1_own: the POOL's action fields (T2D_F_ACT0 / ACT1) -- never caller-owned memory bound with
 // t2d_bind_actions; while a binding is in effect the integrators take the controlled lanes' actions from there
@@ -106,12 +67,7 @@ __global__ __launch_bounds__(kIdmBlock) void idm_kernel(PoolView pv, IdmView iv,
     const bool controlled = active && ctrl != T2D_IDM_NONE && ctrl < iv.n_ctrl;
     IdmRow c{};
     double sn = 0.0, cs = 1.0;
-    if (controlled) {
-        const T2D_GLOBAL double* r = a_rows + (size_t)ctrl * T2D_IDM_COLS;
-        c.des = r[T2D_IDM_DESIRED_SPEED]; c.T = r[T2D_IDM_TIME_HEADWAY]; c.s0 = r[T2D_IDM_MIN_SPACING];
-        c.amax = r[T2D_IDM_MAX_ACCEL]; c.b = r[T2D_IDM_COMF_DECEL]; c.delta = r[T2D_IDM_DELTA];
-        c.hw = r[T2D_IDM_LANE_HALF_WIDTH]; c.horizon = r[T2D_IDM_HORIZON];
-    }
+    if (controlled) c = load_row(a_rows + (size_t)ctrl * T2D_IDM_COLS);
     const double qnan = __builtin_nan("");
     s_xy[tid] = active ? make_double2((double)fx, (double)fy) : make_double2(qnan, qnan);
     s_v[tid] = fv;
@@ -120,61 +76,12 @@ __global__ __launch_bounds__(kIdmBlock) void idm_kernel(PoolView pv, IdmView iv,
     if (!valid) return;
     int lead = -1;
     if (controlled) {
-        const double hw = c.hw, horizon = c.horizon;
         const int base = env_local << log2A;
-        // `lon <= horizon` rides on the running minimum: it starts at the first double above the horizon and a candidate
-        // must be strictly below it -- one compare and two selects fewer per candidate than testing the horizon apart
-        double best = just_above(horizon);
         const double x0 = (double)fx, y0 = (double)fy;
         const int want = forced ? forced[idx] : T2D_IDM_LEADER_SEARCH;
         if (want >= 0 && want < pv.A && want != agent && s_xy[base + want].x == s_xy[base + want].x)
             lead = want;  // the caller's leading_state
-        if (want == T2D_IDM_LEADER_SEARCH) {
-            auto sweep = [&](int j0, int j1) {
-#pragma unroll 4
-                for (int j = j0; j < j1; ++j) {
-                    const double2 q = s_xy[base + j];
-                    const double dx = q.x - x0, dy = q.y - y0;
-                    const double lon = __builtin_fma(dx, cs, dy * sn);
-                    const double lat = __builtin_fma(dy, cs, -(dx * sn));
-                    const bool take = lon > 0.0 && lon < best && __builtin_fabs(lat) <= hw;   // strict: lowest index on ties
-                    best = take ? lon : best;
-                    lead = take ? j : lead;
-                }
-            };
-            // the same sweep with constant bounds: fully unrolled, the candidate's index is an inline constant of its
-            // select and its LDS address an immediate offset (no loop counter, no index register: ~2.5 of ~16 issued
-            // instructions per candidate)
-            auto sweep_const = [&](auto j0c, auto j1c) {
-#pragma unroll
-                for (int j = decltype(j0c)::value; j < decltype(j1c)::value; ++j) {
-                    const double2 q = s_xy[base + j];
-                    const double dx = q.x - x0, dy = q.y - y0;
-                    const double lon = __builtin_fma(dx, cs, dy * sn);
-                    const double lat = __builtin_fma(dy, cs, -(dx * sn));
-                    const bool take = lon > 0.0 && lon < best && __builtin_fabs(lat) <= hw;
-                    best = take ? lon : best;
-                    lead = take ? j : lead;
-                }
-            };
-            // wave priority by progress (see the step kernel): the launch is one wave-round, a SIMD's waves should finish
-            // together.  The sweep in quarters, the quarter's number is the priority.
-            if (pv.A == 64) {
-                using I0 = std::integral_constant<int, 0>; using I16 = std::integral_constant<int, 16>;
-                using I32 = std::integral_constant<int, 32>; using I48 = std::integral_constant<int, 48>;
-                using I64 = std::integral_constant<int, 64>;
-                __builtin_amdgcn_s_setprio(3); sweep_const(I0{}, I16{});
-                __builtin_amdgcn_s_setprio(2); sweep_const(I16{}, I32{});
-                __builtin_amdgcn_s_setprio(1); sweep_const(I32{}, I48{});
-                __builtin_amdgcn_s_setprio(0); sweep_const(I48{}, I64{});
-            } else {
-                const int q1 = pv.A >> 2, q2 = pv.A >> 1, q3 = q1 + q2;
-                __builtin_amdgcn_s_setprio(3); sweep(0, q1);
-                __builtin_amdgcn_s_setprio(2); sweep(q1, q2);
-                __builtin_amdgcn_s_setprio(1); sweep(q2, q3);
-                __builtin_amdgcn_s_setprio(0); sweep(q3, pv.A);
-            }
-        }
+        if (want == T2D_IDM_LEADER_SEARCH) lead = find_leader<true>(s_xy, base, pv.A, c, x0, y0, sn, cs);
         double dx = 0.0, dy = 0.0, vl = 0.0;
         if (lead >= 0) {
             dx = s_xy[base + lead].x - x0;
