@@ -287,6 +287,17 @@ def next_rows(dev, clock_warm, metric_scene):
     out["idm_note"] = (f"t2d_idm_actions alone, {metric_scene.n_env} x {metric_scene.A}: every vehicle but the ego IDM-controlled "
                        f"(desired speed 25 m/s, horizon 120 m)")
     r.close()
+    # the same controllers on a per-GPU shard of config 3 (1024 x 64 highway, every vehicle but the egos IDM-controlled): one
+    # t2d_step per step = idm_kernel + step launch, against t2d_step_n fragments, whose integrator waves run the controllers
+    hw = build_scene("cfg3", *DEFAULTS["cfg3"], seed=0)
+    r = Runner(hw, dev, "fast", idm=True)
+    r.pool.bind_actions(r.a0.data_ptr(), r.a1.data_ptr())
+    out["idm_pool_step_us_separate_launches"] = loop(lambda: r.pool.step(hw.interval_ms, r.stream.cuda_stream))
+    out["idm_pool_step_us_fragments"] = loop(lambda: r.pool.step_n(20, hw.interval_ms, 0, r.stream.cuda_stream), n=30, warm=6) / 20.0
+    out["idm_pool_note"] = (f"{hw.n_env} x {hw.A} highway envs with 63 IDM agents each, device-resident actions for the egos, auto-reset on: "
+                            f"per step as idm_kernel + step launch ({r.pool.step_form(1)}) and as t2d_step_n fragments of 20 "
+                            f"({r.pool.step_form(20)}: the controllers run inside the step launch)")
+    r.close()
     sc = S.parking(4096)
     r = Runner(sc, dev, "fast")
     r.pool.lidar_config(360, 20.0, False)

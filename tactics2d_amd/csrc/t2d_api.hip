@@ -1252,6 +1252,15 @@ int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     return rc;
 }
 
+// a pool with installed IDM controllers whose t2d_step_n launch can run them itself: the PIPE form (at most one workgroup
+// per CU, envs of 2..64 participants), where the integrator waves have the env's state at hand
+static bool idm_in_step(t2d_pool* p) {
+    if (!p->idm_on || !p->chain_loop || !p->chain_pipe || p->v.A < 2 || p->v.A > 64) return false;
+    if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
+    const int wgs = (p->v.n_env + p->v.geo_layout.epb - 1) / p->v.geo_layout.epb;
+    return p->device_cus > 0 && wgs <= p->device_cus;
+}
+
 int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_step_stride, void* hip_stream) {
     if (!p) return T2D_ERR_INVALID;
     if (n_steps < 1 || act_step_stride < 0) return fail(p, T2D_ERR_INVALID, "n_steps must be >= 1 and act_step_stride >= 0");
@@ -1264,8 +1273,8 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
     const bool ego = p->ego_kernel && p->v.A == 1 && p->all_boxes && !p->has_drift && !p->hgeo[1].present;
     const bool iou = p->status_cfg.check_no_action || p->status_cfg.check_arrival;   // per-env history read by the epilogue
     // (the single-ego kernel has a LOOP form of its own, which reads the history with sc1 loads: IoU events are fine there)
-    const bool chain = p->chain_steps && n_steps >= 2 && p->fused_step && !p->idm_on && !p->has_drift && !p->scene_regen &&
-                       (ego ? p->chain_loop : !iou);
+    const bool chain = p->chain_steps && n_steps >= 2 && p->fused_step && (!p->idm_on || idm_in_step(p)) && !p->has_drift &&
+                       !p->scene_regen && (ego ? p->chain_loop : !iou);
     const float *a0 = p->v.act0, *a1 = p->v.act1;
     int rc = T2D_OK;
     if (!chain) {   // kernels outside the fused step (IDM, drift, scene regeneration, the single-ego kernel): step by step
@@ -1318,6 +1327,15 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
                 v.split_step = 0;
                 v.chain_real_wgs = loop_wgs;
             }
+            if (p->idm_on) {   // (idm_in_step: PIPE-eligible) the integrator waves run the controllers; no lane waves then
+                v.pipe_step = 1;
+                v.idm_rows = p->idm.rows;
+                v.idm_ctrl_all = p->idm.ctrl_id;
+                v.idm_leader = p->idm.leader;
+                v.idm_n_ctrl = p->idm.n_ctrl;
+                v.idm_act0_own = (float*)p->field_ptr[T2D_F_ACT0];
+                v.idm_act1_own = (float*)p->field_ptr[T2D_F_ACT1];
+            }
             v.loop_steps = (!v.split_step && loop_ok) ? n : 0;
         }
         v.record_ring = (uint2*)p->field_ptr[T2D_F_RECORD];
@@ -1344,8 +1362,9 @@ int t2d_step_form(t2d_pool* p, int32_t n_steps) {
     if (!p) return -1;
     const bool ego = p->ego_kernel && p->v.A == 1 && p->all_boxes && !p->has_drift && !p->hgeo[1].present;
     const bool iou = p->status_cfg.check_no_action || p->status_cfg.check_arrival;
-    if (!p->fused_step || p->idm_on || p->has_drift || p->scene_regen) return T2D_FORM_UNFUSED;
+    if (!p->fused_step || p->has_drift || p->scene_regen) return T2D_FORM_UNFUSED;
     const bool chain = p->chain_steps && n_steps >= 2 && (ego ? p->chain_loop : !iou);
+    if (p->idm_on) return (chain && !ego && idm_in_step(p)) ? T2D_FORM_LOOP_PIPE : T2D_FORM_UNFUSED;
     if (ego) {
         if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
         if (chain && p->chain_pipe && p->device_cus > 0 && (p->v.n_env + 15) / 16 <= p->device_cus) return T2D_FORM_EGO_LOOP_PIPE;

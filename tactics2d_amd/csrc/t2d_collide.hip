@@ -47,6 +47,7 @@
 // SIMD and latency-bound, keeps them as literals (+ 4 % with the table).
 #define T2D_TRIG_TABLE 1
 #include "t2d_geom_dev.h"
+#include "t2d_idm_dev.h"
 #include "t2d_integrate_dev.h"
 
 namespace t2d {
@@ -335,11 +336,17 @@ T2D_DEV unsigned long long chain_word(uint32_t steps_done) {   // {steps done, X
 // from the hand-over, the same instructions twice: the lane stage is the longest event stage of intersection and
 // roundabout envs, and on its own wave the events of a step cost about what the integration of the next one does.
 constexpr int kPipeSpinLimit = 1 << 17;   // polls (s_sleep 1 between them) before a wait is declared lost: > 10 ms
-template <bool WITH_STATUS, int FUSE, bool IOU = true, bool CHAIN = false, bool LOOP = false, bool SPLIT = false, int PIPE = 0>
+// IDMF = true (PIPE = 1 launches of pools with installed IDM controllers): the integrator waves run the controller themselves
+// ahead of every step -- what t2d_step does with an idm_kernel launch in front of the step launch: the env's positions go
+// through the integrator waves' own LDS table, every controlled lane sweeps it for its leader and evaluates the law
+// (t2d_idm_dev.h: the kernel's own functions), its acceleration goes to the pool's action field and into the integrator; a
+// lane whose env was reset does it again on the restored positions.  Same leaders, same accelerations, same states.
+template <bool WITH_STATUS, int FUSE, bool IOU = true, bool CHAIN = false, bool LOOP = false, bool SPLIT = false, int PIPE = 0, bool IDMF = false>
 __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv_arg, t2d_status_config cfg_arg,
                                                                                                                    int interval_ms, int log2A) {
     static_assert(!(CHAIN && LOOP) && (!LOOP || (FUSE >= 0 && WITH_STATUS)), "LOOP = the fused step, not combined with CHAIN");
     static_assert(!PIPE || (LOOP && !IOU && !SPLIT), "PIPE = a LOOP launch with integrator waves");
+    static_assert(!IDMF || PIPE == 1, "IDMF = the controller inside the integrator waves of a PIPE = 1 launch");
     static_assert(!SPLIT || (!LOOP && FUSE >= 0 && WITH_STATUS && !IOU), "SPLIT = the fused step of a plain pool, one launch or chained");
     // `pv` / `cfg` below: the two argument structs -- directly, or (LOOP) through a pointer into the kernel's argument block
     // that is laundered again at the top of every trip, so that what a trip reads of them cannot be hoisted out of the loop:
@@ -386,6 +393,9 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     __shared__ uint32_t s_hand_ids[PIPE ? 2 : 1][PIPE ? kBlock : 1];
     __shared__ uint32_t s_dec[PIPE ? kBlock / 2 : 1];
     __shared__ uint32_t s_seq_i[PIPE ? kWaves : 1], s_seq_e[PIPE ? kWaves : 1], s_seq_b[PIPE == 2 ? kWaves : 1];
+    // IDMF: the integrator waves' table of their envs' positions (NaN = inactive slot) and speeds, as in idm_kernel
+    __shared__ double2 s_ixy[IDMF ? kBlock : 1];
+    __shared__ float s_iv[IDMF ? kBlock : 1];
     extern __shared__ __attribute__((aligned(16))) uint32_t s_geo[];  // packed geometry record
 
     // Every kernel argument the start-up phase needs, requested in ONE scalar round trip.  Left to itself the compiler
@@ -561,6 +571,14 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                     vy = ld_state<true>(as_global(pv.vy) + i_idx);
                 }
             }
+            // IDMF: the lane's controller (fixed for the launch) and its row
+            [[maybe_unused]] bool has_ctrl = false;
+            [[maybe_unused]] idm::IdmRow crow{};
+            if constexpr (IDMF) {
+                const int ctrl = i_valid ? (int)as_global(pv.idm_ctrl_all)[i_idx] : T2D_IDM_NONE;
+                has_ctrl = ctrl != T2D_IDM_NONE && ctrl < pv.idm_n_ctrl;
+                if (has_ctrl) crow = idm::load_row(as_global(pv.idm_rows) + (size_t)ctrl * T2D_IDM_COLS);
+            }
             const int n_steps = pv.loop_steps;
             const size_t act_step = (size_t)pv.chain_act_step;
             const size_t ai0 = (size_t)i_idx * a_act_stride;
@@ -599,6 +617,34 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                     if (todo) {
                         nx = x; ny = y; nh = h; nv = v; nvx = vx; nvy = vy;
                         moved = false; has_vel = false;
+                    }
+                    if constexpr (IDMF) {   // IDMController.step for the controlled lanes, on the state this step starts from
+                        if (__ballot(todo) != 0ull) {
+                            const bool act_now = i_valid && ((ids >> kIdsActiveShift) & 0xffu);
+                            const double qnan = __builtin_nan("");
+                            s_ixy[t] = act_now ? make_double2((double)x, (double)y) : make_double2(qnan, qnan);
+                            s_iv[t] = v;
+                            wave_sync();   // (an env's slots are all this wave's)
+                            int lead = -1;
+                            if (todo && act_now && has_ctrl) {
+                                double sn, cs;
+                                sincos_det((double)h, sn, cs);
+                                const int ibase = i_env_local << log2A;
+                                lead = idm::find_leader<false>(s_ixy, ibase, a_A, crow, (double)x, (double)y, sn, cs);
+                                double dx = 0.0, dy = 0.0, vl = 0.0;
+                                if (lead >= 0) {
+                                    dx = s_ixy[ibase + lead].x - (double)x;
+                                    dy = s_ixy[ibase + lead].y - (double)y;
+                                    vl = (double)s_iv[ibase + lead];
+                                }
+                                a0 = (float)idm::idm_law(crow, (double)v, lead >= 0, dx, dy, vl);
+                                a1 = 0.0f;
+                                as_global(ia->idm_act0_own)[i_idx] = a0;
+                                as_global(ia->idm_act1_own)[i_idx] = a1;
+                            }
+                            if (todo && i_valid) as_global(ia->idm_leader)[i_idx] = lead;
+                            wave_sync();   // (the table is rewritten by the next round / step)
+                        }
                     }
                     if (todo && i_valid && ((ids >> kIdsActiveShift) & 0xffu) && model != T2D_MODEL_DRIFT) {
                         auto P = [&](int col) -> double { return s_partab[col * T2D_MAX_TYPES + type]; };
@@ -1663,6 +1709,11 @@ hipError_t launch_step_chain(const PoolView& v, const t2d_status_config& cfg, in
             if (block3.x > 1024) return hipErrorInvalidValue;
             if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, true, false, 2>), grid, block3, dyn, s, v, cfg, interval_ms, log2A);
             else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, true, false, 2>), grid, block3, dyn, s, v, cfg, interval_ms, log2A);
+            return hipGetLastError();
+        }
+        if (v.idm_rows) {   // installed IDM controllers: run by the integrator waves
+            if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, true, false, 1, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+            else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, true, false, 1, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
             return hipGetLastError();
         }
         if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, true, false, 1>), grid, block, dyn, s, v, cfg, interval_ms, log2A);

@@ -108,6 +108,13 @@ struct PoolView {
     int64_t chain_act_step;     // elements between the action sets of consecutive steps (0: the same actions every step)
     uint2* record_ring;         // the whole ring of per-env result records; step k writes slot (record_slot0 + k) % ring
     int32_t record_slot0;
+    // t2d_step_n on a pool with installed IDM controllers (PIPE form): the integrator waves run the controller ahead of every
+    // step themselves (t2d_idm_dev.h) -- its rows, every participant's controller id, and the places t2d_idm_actions writes
+    const double* idm_rows;
+    const uint8_t* idm_ctrl_all;
+    int32_t* idm_leader;
+    float *idm_act0_own, *idm_act1_own;
+    int32_t idm_n_ctrl;
     unsigned long long* dbg;  // phase cycle accumulators (profiling builds with -DT2D_TIMING only)
     double cell;      // spatial-hash cell edge (m) >= max circum-diameter * 1.001
     double inv_cell;

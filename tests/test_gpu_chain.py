@@ -238,3 +238,53 @@ def test_baseline_shards_at_full_size_as_fragments(name):
     sc = {"cfg3": lambda: S.highway(1024, 64, seed=1), "cfg4": lambda: S.intersection(512, 32, seed=2),
           "cfg5": lambda: S.mixed(1024, 64, seed=3)}[name]()
     _compare(sc, 48, "fast", calls=(32, 16), form="loop_pipe")
+
+
+@pytest.mark.parametrize("bound", [False, True])
+def test_idm_pools_run_their_controllers_inside_the_fragment(bound):
+    """A pool with installed IDM controllers (t2d_step = idm_kernel + step launch per step): as t2d_step_n the PIPE form's
+    integrator waves run the controllers themselves ahead of every step -- leaders, accelerations (the pool's action field),
+    states, flags and records equal to the separate launches over 40 steps with auto-resets, with the other participants'
+    actions in the pool's own fields or bound as a device-resident ring."""
+    torch = pytest.importorskip("torch")
+    from tactics2d_amd import layout as L, scenarios as S
+    from tactics2d_amd.controller import IDMController, install
+    dev = torch.device("cuda", 0)
+    for sc in (S.highway(70, 64, seed=4), S.intersection(50, 32, seed=6)):
+        rng = np.random.default_rng(3)
+        n_steps = 40
+        sets = [sc.sample_actions(rng) for _ in range(n_steps)]
+        a0 = torch.from_numpy(np.stack([s[0] for s in sets])).to(dev).contiguous()
+        a1 = torch.from_numpy(np.stack([s[1] for s in sets])).to(dev).contiguous()
+        veh = (sc.rows[sc.type_id, L.P_MODEL] != L.MODEL_POINTMASS).reshape(sc.n_env, sc.A)
+        cid = np.full((sc.n_env, sc.A), L.IDM_NONE, np.uint8)
+        cid[:, 1:] = np.where(veh[:, 1:], np.arange(sc.A - 1)[None, :] % 2, L.IDM_NONE)   # two controllers; slot 0 = the caller's
+        outs = []
+        for mode in ("steps", "fragments"):
+            pool = _pool(sc, "exact")
+            install(pool, [IDMController(desired_speed=25.0, horizon=120.0), IDMController(desired_speed=12.0, horizon=60.0, time_headway=1.0)],
+                    cid.reshape(-1))
+            if not bound:
+                pool.set_actions(sets[0][0], sets[0][1])
+            if mode == "steps":
+                assert pool.step_form(1) == "unfused"
+                for k in range(n_steps):
+                    if bound:
+                        pool.bind_actions(a0.data_ptr() + 4 * sc.n * k, a1.data_ptr() + 4 * sc.n * k)
+                    pool.step(sc.interval_ms)
+            else:
+                assert pool.step_form(8) == "loop_pipe"
+                done = 0
+                for c in (3, 32, 5):
+                    if bound:
+                        pool.bind_actions(a0.data_ptr() + 4 * sc.n * done, a1.data_ptr() + 4 * sc.n * done)
+                    pool.step_n(c, sc.interval_ms, sc.n if bound else 0)
+                    done += c
+            fields = _fields() + (L.F_ACT0, L.F_ACT1, L.F_LEADER)
+            outs.append([pool.download(f) for f in fields])
+            pool.close()
+        for f, g, w in zip(fields, outs[1], outs[0]):
+            assert np.array_equal(g, w, equal_nan=True), (sc.name, bound, f, int((g != w).sum()))
+        lead = outs[0][fields.index(L.F_LEADER)]
+        rec = outs[0][fields.index(L.F_RECORD)].reshape(L.RECORD_RING, sc.n_env, 2)
+        assert (lead >= 0).mean() > 0.2 and (rec[:n_steps, :, 1] >> 16).astype(bool).any()
