@@ -308,12 +308,16 @@ int t2d_step_groups(t2d_pool* const* pools, const float* const* act0_dev, const 
  * action set (frame skip), n_env * max_agents * stride walks an action ring laid out [n_steps][N].  Results are exactly
  * those of n_steps t2d_step calls; per-step rewards / statuses are in the record ring (T2D_F_RECORD), the participant
  * fields hold the last step's values.
- * How: pools whose step is the fused kernel alone (no IDM / drift / regenerated scenes / single-ego kernel) get ONE launch
- * holding all the steps: workgroup (g, k) takes step k of the envs of workgroup g and is ordered after workgroup (g, k - 1)
- * by a per-workgroup counter in device memory (release / acquire at agent scope) -- no launch boundary between steps, so the
- * start-up of step k + 1 overlaps the tail of step k, and small pools stop paying one launch per step.  A wait is bounded:
+ * How: pools whose step is the fused kernel alone (no drift / regenerated scenes; installed IDM controllers only on pools small
+ * enough for the looping form with integrator waves, which then run the controllers themselves) get ONE launch
+ * holding all the steps.  Large pools: workgroup (g, k) takes step k of the envs of workgroup g and is ordered after workgroup
+ * (g, k - 1) by a per-workgroup word in device memory (kept inside one XCD's L2, the placement checked: DESIGN.md 4.10) -- no
+ * launch boundary between steps, so the start-up of step k + 1 overlaps the tail of step k.  Small pools: every workgroup
+ * loops over the steps itself, and where a step's workgroups number at most the device's CUs a second set of waves per
+ * workgroup integrates step k + 1 while the first checks the events of step k (t2d_step_form tells which).  A wait is bounded:
  * if it ever ran out, the next t2d_sync / t2d_download / t2d_step_n returns T2D_ERR_STATE.  Other pools, and every pool after
- * t2d_set_step_chaining(pool, 0, *), take n_steps ordinary launches.  priority_rule: wave priorities inside a chained launch
+ * t2d_set_step_chaining(pool, 0, *), take n_steps ordinary launches (on = 1: automatic, the default; 2 / 3 / 4 pin the chained
+ * form / the plain loop / the loop with integrator but without lane waves -- measurements and tests).  priority_rule: wave priorities inside a chained launch
  * (1, default: the rule for overlapping work; 0: the single-launch rule).  kernel_id 7 in t2d_profile_read
  * (one "launch" = one chained launch of up to T2D_RECORD_RING steps).                                                    */
 int t2d_step_n(t2d_pool* pool, int32_t interval_ms, int32_t n_steps, int64_t act_step_stride, void* hip_stream);
