@@ -288,3 +288,22 @@ def test_idm_pools_run_their_controllers_inside_the_fragment(bound):
         lead = outs[0][fields.index(L.F_LEADER)]
         rec = outs[0][fields.index(L.F_RECORD)].reshape(L.RECORD_RING, sc.n_env, 2)
         assert (lead >= 0).mean() > 0.2 and (rec[:n_steps, :, 1] >> 16).astype(bool).any()
+
+
+@pytest.mark.parametrize("A", [2, 3, 7, 16, 24, 33, 50])
+def test_fragments_of_pools_of_any_env_width(A):
+    """Envs of 2..64 participants map 32..1 envs to a wave (the env's lanes are padded to a power of two), and the last
+    workgroup of a pool is ragged: the looping forms with their integrator / lane waves against single launches for widths
+    that are not powers of two, pools of one env, and env counts that fill no workgroup."""
+    from tactics2d_amd import scenarios as S
+    from tactics2d_amd._ffi import GeometryError
+    ran = 0
+    for n_env, maker in ((1, S.intersection), (5, S.highway), (67, S.intersection), (130, S.highway)):
+        sc = maker(n_env, A, seed=A + n_env)
+        try:
+            for chaining in (1, 3):
+                _compare(sc, 24, "exact", calls=(1, 19, 4), chaining=chaining, form="loop_pipe" if chaining == 1 else "loop", split=False)
+            ran += 1
+        except GeometryError:   # (narrow envs put up to 128 of them into a workgroup: their polygons may not fit its LDS record)
+            assert A < 16
+    assert ran >= 2
