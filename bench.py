@@ -292,11 +292,14 @@ def next_rows(dev, clock_warm, metric_scene):
     hw = build_scene("cfg3", *DEFAULTS["cfg3"], seed=0)
     r = Runner(hw, dev, "fast", idm=True)
     r.pool.bind_actions(r.a0.data_ptr(), r.a1.data_ptr())
+    r.pool.set_step_chaining(0)   # idm_kernel a launch of its own ahead of every step launch
     out["idm_pool_step_us_separate_launches"] = loop(lambda: r.pool.step(hw.interval_ms, r.stream.cuda_stream))
+    r.pool.set_step_chaining(1)
+    out["idm_pool_step_us_one_launch"] = loop(lambda: r.pool.step(hw.interval_ms, r.stream.cuda_stream))
     out["idm_pool_step_us_fragments"] = loop(lambda: r.pool.step_n(20, hw.interval_ms, 0, r.stream.cuda_stream), n=30, warm=6) / 20.0
     out["idm_pool_note"] = (f"{hw.n_env} x {hw.A} highway envs with 63 IDM agents each, device-resident actions for the egos, auto-reset on: "
-                            f"per step as idm_kernel + step launch ({r.pool.step_form(1)}) and as t2d_step_n fragments of 20 "
-                            f"({r.pool.step_form(20)}: the controllers run inside the step launch)")
+                            f"per step as idm_kernel + step launch, as one step launch with the controllers in its front "
+                            f"({r.pool.step_form(1)}) and as t2d_step_n fragments of 20 ({r.pool.step_form(20)}: the integrator waves run them)")
     r.close()
     sc = S.parking(4096)
     r = Runner(sc, dev, "fast")

@@ -1147,6 +1147,30 @@ int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     return record_event(p, 0, s, false);
 }
 
+// a pool with installed IDM controllers whose step launch runs them itself (envs of 2..64 participants: an env's positions
+// then sit in one wave's LDS slots; no IoU events: those pools keep the general instantiations): every workgroup ahead of
+// its integrator (t2d_step, the chained form of t2d_step_n), or the integrator waves of the PIPE form where the pool is
+// small enough for it.  t2d_set_step_chaining(pool, 0, *) keeps idm_kernel a launch of its own (tests hold the two
+// against each other).
+static bool idm_in_step(t2d_pool* p) {
+    return p->idm_on && p->chain_steps && p->fused_step && p->v.A >= 2 && p->v.A <= 64 &&
+           !(p->status_cfg.check_no_action || p->status_cfg.check_arrival);
+}
+static void fill_idm(t2d::PoolView& v, t2d_pool* p) {
+    v.idm_rows = p->idm.rows;
+    v.idm_ctrl_all = p->idm.ctrl_id;
+    v.idm_leader = p->idm.leader;
+    v.idm_n_ctrl = p->idm.n_ctrl;
+    v.idm_act0_own = (float*)p->field_ptr[T2D_F_ACT0];
+    v.idm_act1_own = (float*)p->field_ptr[T2D_F_ACT1];
+}
+static bool idm_in_pipe(t2d_pool* p) {
+    if (!idm_in_step(p) || !p->chain_loop || !p->chain_pipe) return false;
+    if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
+    const int wgs = (p->v.n_env + p->v.geo_layout.epb - 1) / p->v.geo_layout.epb;
+    return p->device_cus > 0 && wgs <= p->device_cus;
+}
+
 // small pools of 33..64-agent envs: the fused step gives every env a workgroup of its own (collide_kernel<..., SPLIT>)
 static bool use_split(t2d_pool* p) {
     if (!p->split_steps) return false;
@@ -1168,7 +1192,9 @@ static int collide_impl(t2d_pool* p, bool with_status, int interval_ms, hipStrea
         T2D_HIP(p, t2d::launch_ego_step(p->v, p->status_cfg, interval_ms, fuse_variant, s));
     else {
         t2d::PoolView v = p->v;
-        v.split_step = fuse_variant >= 0 && use_split(p);
+        const bool idm_fused = fuse_variant >= 0 && idm_in_step(p);
+        v.split_step = fuse_variant >= 0 && !idm_fused && use_split(p);
+        if (idm_fused) fill_idm(v, p);
         T2D_HIP(p, t2d::launch_collide(v, p->status_cfg, with_status, interval_ms, fuse_variant, s));
     }
     return record_event(p, kid, s, false);
@@ -1244,21 +1270,13 @@ int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     if (interval_ms <= 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be positive");
     int rc;
     if ((rc = claim_record_slot(p, (hipStream_t)hip_stream))) return rc;
-    if (p->idm_on && (rc = idm_impl(p, (hipStream_t)hip_stream))) return rc;
+    // (installed IDM controllers: a launch of their own ahead of the step -- or, idm_in_step, the front of the step launch)
+    if (p->idm_on && !idm_in_step(p) && (rc = idm_impl(p, (hipStream_t)hip_stream))) return rc;
     if (p->has_drift && (rc = drift_impl(p, interval_ms, (hipStream_t)hip_stream))) return rc;
     rc = collide_impl(p, true, interval_ms, (hipStream_t)hip_stream, p->integrator_variant);
     if (rc == T2D_OK) p->step_count++;
     if (rc == T2D_OK) rc = regenerate_done_scenes(p, (hipStream_t)hip_stream);
     return rc;
-}
-
-// a pool with installed IDM controllers whose t2d_step_n launch can run them itself: the PIPE form (at most one workgroup
-// per CU, envs of 2..64 participants), where the integrator waves have the env's state at hand
-static bool idm_in_step(t2d_pool* p) {
-    if (!p->idm_on || !p->chain_loop || !p->chain_pipe || p->v.A < 2 || p->v.A > 64) return false;
-    if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
-    const int wgs = (p->v.n_env + p->v.geo_layout.epb - 1) / p->v.geo_layout.epb;
-    return p->device_cus > 0 && wgs <= p->device_cus;
 }
 
 int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_step_stride, void* hip_stream) {
@@ -1327,16 +1345,15 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
                 v.split_step = 0;
                 v.chain_real_wgs = loop_wgs;
             }
-            if (p->idm_on) {   // (idm_in_step: PIPE-eligible) the integrator waves run the controllers; no lane waves then
-                v.pipe_step = 1;
-                v.idm_rows = p->idm.rows;
-                v.idm_ctrl_all = p->idm.ctrl_id;
-                v.idm_leader = p->idm.leader;
-                v.idm_n_ctrl = p->idm.n_ctrl;
-                v.idm_act0_own = (float*)p->field_ptr[T2D_F_ACT0];
-                v.idm_act1_own = (float*)p->field_ptr[T2D_F_ACT1];
+            if (p->idm_on) {   // the integrator waves run the controllers (no lane waves then) -- or every workgroup of the chained form
+                v.pipe_step = idm_in_pipe(p) ? 1 : 0;
+                if (!v.pipe_step) {
+                    v.split_step = 0;
+                    v.chain_real_wgs = loop_wgs;
+                }
+                fill_idm(v, p);
             }
-            v.loop_steps = (!v.split_step && loop_ok) ? n : 0;
+            v.loop_steps = (!v.split_step && loop_ok && !(p->idm_on && !v.pipe_step)) ? n : 0;
         }
         v.record_ring = (uint2*)p->field_ptr[T2D_F_RECORD];
         v.record_slot0 = slot0;
@@ -1364,7 +1381,10 @@ int t2d_step_form(t2d_pool* p, int32_t n_steps) {
     const bool iou = p->status_cfg.check_no_action || p->status_cfg.check_arrival;
     if (!p->fused_step || p->has_drift || p->scene_regen) return T2D_FORM_UNFUSED;
     const bool chain = p->chain_steps && n_steps >= 2 && (ego ? p->chain_loop : !iou);
-    if (p->idm_on) return (chain && !ego && idm_in_step(p)) ? T2D_FORM_LOOP_PIPE : T2D_FORM_UNFUSED;
+    if (p->idm_on) {
+        if (ego || !idm_in_step(p)) return T2D_FORM_UNFUSED;
+        return !chain ? T2D_FORM_STEP : idm_in_pipe(p) ? T2D_FORM_LOOP_PIPE : T2D_FORM_CHAIN;
+    }
     if (ego) {
         if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
         if (chain && p->chain_pipe && p->device_cus > 0 && (p->v.n_env + 15) / 16 <= p->device_cus) return T2D_FORM_EGO_LOOP_PIPE;

@@ -346,7 +346,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                                                                                                                    int interval_ms, int log2A) {
     static_assert(!(CHAIN && LOOP) && (!LOOP || (FUSE >= 0 && WITH_STATUS)), "LOOP = the fused step, not combined with CHAIN");
     static_assert(!PIPE || (LOOP && !IOU && !SPLIT), "PIPE = a LOOP launch with integrator waves");
-    static_assert(!IDMF || PIPE == 1, "IDMF = the controller inside the integrator waves of a PIPE = 1 launch");
+    static_assert(!IDMF || PIPE == 1 || (PIPE == 0 && !LOOP && !SPLIT && FUSE >= 0), "IDMF = the controller inside a PIPE = 1 launch, or ahead of the integrator of a chained one");
     static_assert(!SPLIT || (!LOOP && FUSE >= 0 && WITH_STATUS && !IOU), "SPLIT = the fused step of a plain pool, one launch or chained");
     // `pv` / `cfg` below: the two argument structs -- directly, or (LOOP) through a pointer into the kernel's argument block
     // that is laundered again at the top of every trip, so that what a trip reads of them cannot be hoisted out of the loop:
@@ -394,8 +394,8 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     __shared__ uint32_t s_dec[PIPE ? kBlock / 2 : 1];
     __shared__ uint32_t s_seq_i[PIPE ? kWaves : 1], s_seq_e[PIPE ? kWaves : 1], s_seq_b[PIPE == 2 ? kWaves : 1];
     // IDMF: the integrator waves' table of their envs' positions (NaN = inactive slot) and speeds, as in idm_kernel
-    __shared__ double2 s_ixy[IDMF ? kBlock : 1];
-    __shared__ float s_iv[IDMF ? kBlock : 1];
+    __shared__ double2 s_ixy[IDMF && PIPE ? kBlock : 1];
+    __shared__ float s_iv[IDMF && PIPE ? kBlock : 1];
     extern __shared__ __attribute__((aligned(16))) uint32_t s_geo[];  // packed geometry record
 
     // Every kernel argument the start-up phase needs, requested in ONE scalar round trip.  Left to itself the compiler
@@ -630,7 +630,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                                 double sn, cs;
                                 sincos_det((double)h, sn, cs);
                                 const int ibase = i_env_local << log2A;
-                                lead = idm::find_leader<false>(s_ixy, ibase, a_A, crow, (double)x, (double)y, sn, cs);
+                                lead = idm::find_leader<false>([&](int j) { return s_ixy[ibase + j]; }, a_A, crow, (double)x, (double)y, sn, cs);
                                 double dx = 0.0, dy = 0.0, vl = 0.0;
                                 if (lead >= 0) {
                                     dx = s_ixy[ibase + lead].x - (double)x;
@@ -755,6 +755,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     uint32_t ids = 0;
     float fx = 0, fy = 0, fh = 0;
     float fv = 0, fa0 = 0, fa1 = 0;  // fused: speed and actions
+    [[maybe_unused]] int i_ctrl = T2D_IDM_NONE;   // IDMF: the participant's controller
     float bxmin = 0, bxmax = 0, bymin = 0, bymax = 0;
     bool has_boundary = false;
     // the status epilogue's inputs, fetched now by the lane that will run it (agent 0): their latency
@@ -782,10 +783,11 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                 n_a0 = a_act0[ai + (size_t)pv.chain_act_step];
                 n_a1 = a_act1[ai + (size_t)pv.chain_act_step];
             }
-            if (a_idm && a_idm[idx] != T2D_IDM_NONE) {  // IDM lane while caller actions are bound
+            if (!(IDMF && !PIPE) && a_idm && a_idm[idx] != T2D_IDM_NONE) {  // IDM lane while caller actions are bound
                 fa0 = pv.own_act0[idx];
                 fa1 = pv.own_act1[idx];
             }
+            if constexpr (IDMF && !PIPE) i_ctrl = (int)as_global(pv.idm_ctrl_all)[idx];   // (its row is fetched behind the barrier)
         }
         if (FUSE < 0 && pv.boundary) {  // fused: fetched after the integrator (register pressure)
             const float4 b = reinterpret_cast<const float4*>(pv.boundary)[env];
@@ -887,6 +889,37 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     }
     const bool active = valid && ((ids >> kIdsActiveShift) & 0xffu);
     const int type = (ids >> kIdsTypeShift) & 0xff;
+    if constexpr (IDMF && !PIPE) {
+        // IDMController.step ahead of the integrator (what t2d_step does with an idm_kernel launch in front of this one): the
+        // env's positions and speeds go through LDS -- the vertex planes and the centre table, dead until the pose phase --
+        // every controlled lane sweeps its env for the leader and evaluates the law (t2d_idm_dev.h)
+        const double qnan = __builtin_nan("");
+        s_v[0][tid] = active ? (double)fx : qnan;
+        s_v[1][tid] = active ? (double)fy : qnan;
+        s_cxy[0][tid] = fv;
+        const bool has_ctrl = active && i_ctrl != T2D_IDM_NONE && i_ctrl < pv.idm_n_ctrl;
+        if (log2A <= 6) wave_sync(); else __syncthreads();
+        int lead = -1;
+        if (has_ctrl) {
+            const idm::IdmRow crow = idm::load_row(as_global(pv.idm_rows) + (size_t)i_ctrl * T2D_IDM_COLS);
+            double sn, cs;
+            sincos_det((double)fh, sn, cs);
+            lead = idm::find_leader<false>([&](int j) { return make_double2(s_v[0][slot0 + j], s_v[1][slot0 + j]); }, a_A, crow,
+                                           (double)fx, (double)fy, sn, cs);
+            double dx = 0.0, dy = 0.0, vl = 0.0;
+            if (lead >= 0) {
+                dx = s_v[0][slot0 + lead] - (double)fx;
+                dy = s_v[1][slot0 + lead] - (double)fy;
+                vl = (double)s_cxy[0][slot0 + lead];
+            }
+            fa0 = (float)idm::idm_law(crow, (double)fv, lead >= 0, dx, dy, vl);
+            fa1 = 0.0f;
+            as_global(pv.idm_act0_own)[idx] = fa0;
+            as_global(pv.idm_act1_own)[idx] = fa1;
+        }
+        if (valid) as_global(pv.idm_leader)[idx] = lead;
+        if (log2A <= 6) wave_sync(); else __syncthreads();   // (the planes are the pose phase's from here on)
+    }
     // (SingleTrackDrift lanes were integrated by drift_kernel, launched before this one)
     if (!PIPE && FUSE >= 0 && active && ((ids >> kIdsModelShift) & 0xff) != T2D_MODEL_DRIFT && (!SPLIT || role == 0)) {
         // ---------------- fused physics: one PhysicsModelBase.step in registers ----------------
@@ -1735,6 +1768,11 @@ hipError_t launch_step_chain(const PoolView& v, const t2d_status_config& cfg, in
     // (pools with IoU events keep per-env history -- last pose, counters -- that the epilogue reads through plain pointers:
     // the caller steps those one launch at a time)
     if (cfg.check_no_action || cfg.check_arrival) return hipErrorInvalidValue;
+    if (v.idm_rows) {   // installed IDM controllers: run by every workgroup ahead of its integrator
+        if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, true, false, false, 0, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        else hipLaunchKernelGGL((collide_kernel<true, 1, false, true, false, false, 0, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        return hipGetLastError();
+    }
     if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
     else hipLaunchKernelGGL((collide_kernel<true, 1, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
     return hipGetLastError();
@@ -1752,6 +1790,11 @@ hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool 
         const dim3 sgrid(v.n_env), sblock(kBlock);
         if (fuse_variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, false, true>), sgrid, sblock, dyn, s, v, cfg, interval_ms, log2A);
         else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, false, true>), sgrid, sblock, dyn, s, v, cfg, interval_ms, log2A);
+        return hipGetLastError();
+    }
+    if (fuse_variant >= 0 && v.idm_rows && !iou) {   // installed IDM controllers, run ahead of the integrator
+        if (fuse_variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, false, false, 0, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, false, false, 0, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
         return hipGetLastError();
     }
     if (fuse_variant >= 0) {  // the fused step always runs the status epilogue

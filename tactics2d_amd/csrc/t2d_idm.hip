@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kIdmBlock) void idm_kernel(PoolView pv, IdmView iv,
         const int want = forced ? forced[idx] : T2D_IDM_LEADER_SEARCH;
         if (want >= 0 && want < pv.A && want != agent && s_xy[base + want].x == s_xy[base + want].x)
             lead = want;  // the caller's leading_state
-        if (want == T2D_IDM_LEADER_SEARCH) lead = find_leader<true>(s_xy, base, pv.A, c, x0, y0, sn, cs);
+        if (want == T2D_IDM_LEADER_SEARCH) lead = find_leader<true>([&](int j) { return s_xy[base + j]; }, pv.A, c, x0, y0, sn, cs);
         double dx = 0.0, dy = 0.0, vl = 0.0;
         if (lead >= 0) {
             dx = s_xy[base + lead].x - x0;

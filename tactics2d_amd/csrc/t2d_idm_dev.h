@@ -62,12 +62,12 @@ T2D_DEV IdmRow load_row(const T2D_GLOBAL double* r) {
     return c;
 }
 
-// The leader rule for one controlled participant: among slots [0, A) of its env -- (x, y) pairs at s_xy[base + j], NaN for
+// The leader rule for one controlled participant: among slots [0, A) of its env -- get(j) = the (x, y) of slot j, NaN for
 // inactive slots -- those ahead (0 < lon <= horizon along the own heading, sn / cs its sine / cosine) inside the own corridor
 // (|lat| <= hw), the one with the smallest lon, lowest index on ties.  PRIO: the sweep in quarters with the wave priority
 // falling 3 -> 0 (idm_kernel: the launch is one wave-round, a SIMD's waves should finish together).
-template <bool PRIO>
-T2D_DEV int find_leader(const double2* s_xy, int base, int A, const IdmRow& c, double x0, double y0, double sn, double cs) {
+template <bool PRIO, class Get>
+T2D_DEV int find_leader(Get get, int A, const IdmRow& c, double x0, double y0, double sn, double cs) {
     const double hw = c.hw;
     // `lon <= horizon` rides on the running minimum: it starts at the first double above the horizon and a candidate
     // must be strictly below it -- one compare and two selects fewer per candidate than testing the horizon apart
@@ -76,7 +76,7 @@ T2D_DEV int find_leader(const double2* s_xy, int base, int A, const IdmRow& c, d
     auto sweep = [&](int j0, int j1) {
 #pragma unroll 4
         for (int j = j0; j < j1; ++j) {
-            const double2 q = s_xy[base + j];
+            const double2 q = get(j);
             const double dx = q.x - x0, dy = q.y - y0;
             const double lon = __builtin_fma(dx, cs, dy * sn);
             const double lat = __builtin_fma(dy, cs, -(dx * sn));
@@ -91,7 +91,7 @@ T2D_DEV int find_leader(const double2* s_xy, int base, int A, const IdmRow& c, d
     auto sweep_const = [&](auto j0c, auto j1c) {
 #pragma unroll
         for (int j = decltype(j0c)::value; j < decltype(j1c)::value; ++j) {
-            const double2 q = s_xy[base + j];
+            const double2 q = get(j);
             const double dx = q.x - x0, dy = q.y - y0;
             const double lon = __builtin_fma(dx, cs, dy * sn);
             const double lat = __builtin_fma(dy, cs, -(dx * sn));

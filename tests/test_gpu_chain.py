@@ -240,12 +240,13 @@ def test_baseline_shards_at_full_size_as_fragments(name):
     _compare(sc, 48, "fast", calls=(32, 16), form="loop_pipe")
 
 
-@pytest.mark.parametrize("bound", [False, True])
-def test_idm_pools_run_their_controllers_inside_the_fragment(bound):
+@pytest.mark.parametrize("bound,chaining,form", [(False, 1, "loop_pipe"), (True, 1, "loop_pipe"), (True, 2, "chain")])
+def test_idm_pools_run_their_controllers_inside_the_fragment(bound, chaining, form):
     """A pool with installed IDM controllers (t2d_step = idm_kernel + step launch per step): as t2d_step_n the PIPE form's
-    integrator waves run the controllers themselves ahead of every step -- leaders, accelerations (the pool's action field),
-    states, flags and records equal to the separate launches over 40 steps with auto-resets, with the other participants'
-    actions in the pool's own fields or bound as a device-resident ring."""
+    integrator waves run the controllers themselves ahead of every step, and so does every workgroup of the chained form
+    (larger pools) ahead of its integrator -- leaders, accelerations (the pool's action field), states, flags and records
+    equal to the separate launches over 40 steps with auto-resets, with the other participants' actions in the pool's own
+    fields or bound as a device-resident ring."""
     torch = pytest.importorskip("torch")
     from tactics2d_amd import layout as L, scenarios as S
     from tactics2d_amd.controller import IDMController, install
@@ -260,20 +261,21 @@ def test_idm_pools_run_their_controllers_inside_the_fragment(bound):
         cid = np.full((sc.n_env, sc.A), L.IDM_NONE, np.uint8)
         cid[:, 1:] = np.where(veh[:, 1:], np.arange(sc.A - 1)[None, :] % 2, L.IDM_NONE)   # two controllers; slot 0 = the caller's
         outs = []
-        for mode in ("steps", "fragments"):
+        for mode in ("steps", "fragments", "fused_steps"):
             pool = _pool(sc, "exact")
+            pool.set_step_chaining(0 if mode == "steps" else chaining)   # 0: idm_kernel stays a launch of its own
             install(pool, [IDMController(desired_speed=25.0, horizon=120.0), IDMController(desired_speed=12.0, horizon=60.0, time_headway=1.0)],
                     cid.reshape(-1))
             if not bound:
                 pool.set_actions(sets[0][0], sets[0][1])
-            if mode == "steps":
-                assert pool.step_form(1) == "unfused"
+            if mode != "fragments":
+                assert pool.step_form(1) == ("unfused" if mode == "steps" else "step")
                 for k in range(n_steps):
                     if bound:
                         pool.bind_actions(a0.data_ptr() + 4 * sc.n * k, a1.data_ptr() + 4 * sc.n * k)
                     pool.step(sc.interval_ms)
             else:
-                assert pool.step_form(8) == "loop_pipe"
+                assert pool.step_form(8) == form
                 done = 0
                 for c in (3, 32, 5):
                     if bound:
@@ -283,8 +285,9 @@ def test_idm_pools_run_their_controllers_inside_the_fragment(bound):
             fields = _fields() + (L.F_ACT0, L.F_ACT1, L.F_LEADER)
             outs.append([pool.download(f) for f in fields])
             pool.close()
-        for f, g, w in zip(fields, outs[1], outs[0]):
-            assert np.array_equal(g, w, equal_nan=True), (sc.name, bound, f, int((g != w).sum()))
+        for got in outs[1:]:
+            for f, g, w in zip(fields, got, outs[0]):
+                assert np.array_equal(g, w, equal_nan=True), (sc.name, bound, f, int((g != w).sum()))
         lead = outs[0][fields.index(L.F_LEADER)]
         rec = outs[0][fields.index(L.F_RECORD)].reshape(L.RECORD_RING, sc.n_env, 2)
         assert (lead >= 0).mean() > 0.2 and (rec[:n_steps, :, 1] >> 16).astype(bool).any()
@@ -307,3 +310,35 @@ def test_fragments_of_pools_of_any_env_width(A):
         except GeometryError:   # (narrow envs put up to 128 of them into a workgroup: their polygons may not fit its LDS record)
             assert A < 16
     assert ran >= 2
+
+
+def test_idm_pool_of_more_workgroups_than_cus_chains_with_its_controllers():
+    """1100 x 64 = 275 workgroups: too many for the looping forms with integrator waves; the chained form runs the controllers"""
+    torch = pytest.importorskip("torch")
+    from tactics2d_amd import layout as L, scenarios as S
+    from tactics2d_amd.controller import IDMController, install
+    sc = S.mixed(1100, 64, seed=9)
+    rng = np.random.default_rng(1)
+    a0, a1 = sc.sample_actions(rng)
+    veh = (sc.rows[sc.type_id, L.P_MODEL] != L.MODEL_POINTMASS).reshape(sc.n_env, sc.A)
+    cid = np.full((sc.n_env, sc.A), L.IDM_NONE, np.uint8)
+    cid[:, 1:] = np.where(veh[:, 1:], 0, L.IDM_NONE)
+    outs = []
+    fields = _fields() + (L.F_ACT0, L.F_ACT1, L.F_LEADER)
+    for mode in ("steps", "fragments"):
+        pool = _pool(sc, "fast")
+        install(pool, [IDMController(desired_speed=20.0, horizon=100.0)], cid.reshape(-1))
+        pool.set_actions(a0, a1)
+        if mode == "steps":
+            pool.set_step_chaining(0)   # idm_kernel + step launch per step
+            assert pool.step_form(1) == "unfused"
+            for _ in range(24):
+                pool.step(sc.interval_ms)
+        else:
+            assert pool.step_form(1) == "step"   # (a single t2d_step runs the controllers in its launch as well)
+            assert pool.step_form(24) == "chain"
+            pool.step_n(24, sc.interval_ms, 0)
+        outs.append([pool.download(f) for f in fields])
+        pool.close()
+    for f, g, w in zip(fields, outs[1], outs[0]):
+        assert np.array_equal(g, w, equal_nan=True), (f, int((g != w).sum()))
