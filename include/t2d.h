@@ -308,8 +308,8 @@ int t2d_step_groups(t2d_pool* const* pools, const float* const* act0_dev, const 
  * action set (frame skip), n_env * max_agents * stride walks an action ring laid out [n_steps][N].  Results are exactly
  * those of n_steps t2d_step calls; per-step rewards / statuses are in the record ring (T2D_F_RECORD), the participant
  * fields hold the last step's values.
- * How: pools whose step is the fused kernel alone (no drift / regenerated scenes; installed IDM controllers only on pools small
- * enough for the looping form with integrator waves, which then run the controllers themselves) get ONE launch
+ * How: pools whose step is the fused kernel alone (no drift / regenerated scenes; installed IDM controllers are run by the
+ * step launch itself, here as in t2d_step, for envs of 2..64 participants) get ONE launch
  * holding all the steps.  Large pools: workgroup (g, k) takes step k of the envs of workgroup g and is ordered after workgroup
  * (g, k - 1) by a per-workgroup word in device memory (kept inside one XCD's L2, the placement checked: DESIGN.md 4.10) -- no
  * launch boundary between steps, so the start-up of step k + 1 overlaps the tail of step k.  Small pools: every workgroup
