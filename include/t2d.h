@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define T2D_ABI_VERSION 7
+#define T2D_ABI_VERSION 8
 
 /* ---- status codes --------------------------------------------------------------- */
 #define T2D_OK            0

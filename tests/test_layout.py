@@ -122,3 +122,16 @@ def test_only_tests_smoke_and_the_cpu_baseline_touch_the_oracle():
     lo = bench.index("def _cpu_leg")          # the two functions of the cpu_baseline leg
     hi = bench.index("\ndef ", bench.index("def cpu_baseline") + 1)
     assert all(lo < u < hi for u in uses), "the oracle may only be imported inside the cpu_baseline leg"
+
+
+def test_step_form_names_follow_the_header():
+    """pool.step_form() turns t2d_step_form's T2D_FORM_* value into a name: one name per enumerator, in the header's order"""
+    import re
+    from tactics2d_amd.pool import ParticipantPool
+    vals = _enum_values()
+    forms = sorted((v, k) for k, v in vals.items() if k.startswith("T2D_FORM_"))
+    assert [v for v, _ in forms] == list(range(len(forms)))
+    assert len(ParticipantPool.STEP_FORMS) == len(forms)
+    for (v, k), name in zip(forms, ParticipantPool.STEP_FORMS):
+        want = k[len("T2D_FORM_"):].lower()
+        assert name == want or name == {"step": "step", "unfused": "unfused"}.get(want), (k, name)
