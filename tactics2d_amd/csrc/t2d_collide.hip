@@ -280,6 +280,18 @@ T2D_DEV void compact_and_process(unsigned long long mask, int id_base, int own_i
 #define T2D_MARK(k)
 #endif
 
+// collide_kernel<WITH_STATUS, FUSE, IOU, CHAIN, LOOP, SPLIT, PIPE, IDMF>: ONE step body, instantiated in these forms (the flags
+// are explained one by one below; `launch_collide` / `launch_step_chain` pick, t2d_step_form names the choice):
+//   events only          <*, -1, *>                t2d_collide / t2d_check_status after a separate integrate launch
+//   step                 <1, V, IOU>               t2d_step: integrator + events + status in one launch, one wave per env
+//   step, split          <1, V, 0, 0, 0, SPLIT>    t2d_step of small pools: one workgroup per env, stages on four waves
+//   chained              <1, V, 0, CHAIN>          t2d_step_n of large pools: workgroup (g, k) = step k of env set g
+//   chained, split       <1, V, 0, CHAIN, 0, SPLIT>
+//   loop                 <1, V, 0, 0, LOOP>        t2d_step_n of pools of <= 2 workgroups per CU: each walks the steps itself
+//   loop + PIPE 1 / 2    <1, V, 0, 0, LOOP, 0, P>  ... <= 1 workgroup per CU: integrator waves a step ahead (2: + lane waves)
+//   ... + IDMF           <.., IDMF>                step / chained / PIPE 1 with the pool's IDM controllers run inside the launch
+// V = 0 / 1: exact / fast integrator.  Every form is held against the plain step launch bit for bit (tests/test_gpu_chain.py).
+//
 // FUSE = -1: events only (poses read from the pool).  FUSE = 0 / 1: the whole ScenarioManager step in
 // one launch -- the participant is first integrated in registers (exact / fast variant, the same
 // device functions as integrate_kernel), written back, and its new pose goes straight into the event
