@@ -316,7 +316,8 @@ int t2d_step_groups(t2d_pool* const* pools, const float* const* act0_dev, const 
  * loops over the steps itself, and where a step's workgroups number at most the device's CUs a second set of waves per
  * workgroup integrates step k + 1 while the first checks the events of step k (t2d_step_form tells which).  A wait is bounded:
  * if it ever ran out, the next t2d_sync / t2d_download / t2d_step_n returns T2D_ERR_STATE.  Other pools, and every pool after
- * t2d_set_step_chaining(pool, 0, *), take n_steps ordinary launches (on = 1: automatic, the default; 2 / 3 / 4 pin the chained
+ * t2d_set_step_chaining(pool, 0, *), take n_steps ordinary launches -- and t2d_step its plainest form: installed IDM
+ * controllers as a launch of their own (on = 1: automatic, the default; 2 / 3 / 4 pin the chained
  * form / the plain loop / the loop with integrator but without lane waves -- measurements and tests).  priority_rule: wave priorities inside a chained launch
  * (1, default: the rule for overlapping work; 0: the single-launch rule).  kernel_id 7 in t2d_profile_read
  * (one "launch" = one chained launch of up to T2D_RECORD_RING steps).                                                    */
@@ -391,8 +392,10 @@ int t2d_lidar_scan(t2d_pool* pool, float* out_dev, void* hip_stream);
  * T2D_F_LEADER.  The reference takes `leading_state` from its caller; here the leader is the nearest active
  * participant ahead (0 < longitudinal offset <= horizon along the own heading) inside the own corridor
  * (|lateral offset| <= lane_half_width), lowest index on ties; none -> free-flow branch.  Distance is
- * centre to centre (np.hypot), as in :111-113.  While installed, t2d_step and t2d_integrate run it first
- * on the same stream.  kernel_id 4 in t2d_profile_read.                                               */
+ * centre to centre (np.hypot), as in :111-113.  While installed, t2d_step, t2d_step_n and t2d_integrate run it
+ * first: t2d_integrate as a launch of its own on the same stream (kernel_id 4 in t2d_profile_read); the step launches
+ * -- for envs of 2..64 participants without IoU events -- in their own front, same leaders and accelerations
+ * (t2d_set_step_chaining(pool, 0, *) keeps the separate launch there as well).                */
 enum t2d_idm_col {
     T2D_IDM_DESIRED_SPEED = 0,
     T2D_IDM_TIME_HEADWAY = 1,
