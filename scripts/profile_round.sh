@@ -25,6 +25,10 @@ for CFG in cfg2 cfg3 cfg4 cfg5; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${CFG}_$MODE -o bench -- python bench.py --config $CFG --mode $MODE --steps 512 --warmup 64 --no-cpu-baseline --no-profile --no-alternates > $OUT/${CFG}_$MODE.log 2>&1
   done
 done
+# SQ pass of the small pools' t2d_step_n launches (VALU issue per SIMD and step, VALU busy: DESIGN.md 8.16)
+for CFG in cfg2 cfg3 cfg4 cfg5; do
+  rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/${CFG}_chain_sq -o bench -- python bench.py --config $CFG --mode chain --steps 512 --warmup 64 --no-cpu-baseline --no-profile --no-alternates > $OUT/${CFG}_chain_sq.log 2>&1
+done
 # next rows: kernel-trace, then an SQ pass (VALU busy, instructions per wave) of the same commands
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/vec -o vec -- python scripts/time_vec_env.py 4096 > $OUT/vec.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/idm -o idm -- python scripts/time_idm.py 4096 > $OUT/idm.log 2>&1

@@ -154,6 +154,32 @@ for c in ("cfg2", "cfg3", "cfg4", "cfg5"):
             a = d[k]; a[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; a[1] += 1; a[2] += steps
         cfgs.setdefault(c, {})[mode] = dict(kernels={k: dict(calls=v[1], avg_us=v[0] / v[1], avg_us_per_step=v[0] / v[2]) for k, v in d.items()},
                                             bench_us_per_step=(1e3 * json.loads(line[-1])["ms_per_step"] if line else None))
+# ... and the SQ pass of each config's multi-step launches: VALU instructions per SIMD and step, VALU busy
+for c in ("cfg2", "cfg3", "cfg4", "cfg5"):
+    f = find(f"{c}_chain_sq", "counter_collection.csv")
+    if not f or c not in cfgs:
+        continue
+    line = [l for l in open(os.path.join(out, f"{c}_chain_sq.log")) if l.startswith("{")]
+    frag_c = json.loads(line[-1]).get("config", {}).get("fragment", 32) if line else 32
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.defaultdict(int)
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if "_loop" not in k and "_chained" not in k:
+            continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "SQ_WAVES":
+            launches[k] += 1
+    sqc = {}
+    for k, v in acc.items():
+        steps = launches[k] * (frag_c if "_loop" in k else 1)   # (chained launches of the small configs are not expected here)
+        if not steps or not v.get("SQ_BUSY_CYCLES"):
+            continue
+        sqc[k] = dict(launches=launches[k], steps_per_launch=frag_c, waves_per_launch=v["SQ_WAVES"] / launches[k],
+                      valu_insts_per_simd_and_step=v.get("SQ_INSTS_VALU", 0) / steps / 1024.0,
+                      insts_per_simd_and_step=v.get("SQ_INSTS", 0) / steps / 1024.0,
+                      valu_busy_frac=4.0 * v.get("SQ_ACTIVE_INST_VALU", 0) / (256 * 4 * v["SQ_BUSY_CYCLES"] / 32.0))
+    cfgs[c]["chain_sq"] = sqc
 json.dump(dict(tag=tag, source_sha256=summary["source_sha256"], note="rocprofv3 --kernel-trace of python bench.py --config <cfg> --mode <mode> "
                "--steps 512 --warmup 64: kernel time per launch and per step next to the bench's own wall time per step", configs=cfgs),
           open(os.path.join(root, "gpurun_out", f"{tag}_configs.json"), "w"), indent=1)
