@@ -406,11 +406,23 @@ void fill_layout(t2d::GeoLayout& gl, int epb, const int mp[2], const int mv[2], 
     gl.epb = epb;
 }
 
+// Envs per workgroup of the step launch: as many as 256 lanes hold -- fewer while that leaves compute units without a
+// workgroup (a pool of 512 envs x 32 participants is 64 workgroups of 8 envs, or 256 workgroups of 2: one per CU instead of
+// three CUs in four idle), down to one wave per workgroup.
+int envs_per_workgroup(t2d_pool* p, int log2A) {
+    if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
+    int epb = 256 >> log2A;
+    // (halved only while the narrower workgroups still number at most the CUs: the looping forms of t2d_step_n with their
+    // extra sets of waves want one workgroup per CU, not two)
+    while (epb > 1 && (epb << log2A) > 64 && (p->v.n_env + (epb >> 1) - 1) / (epb >> 1) <= p->device_cus) epb >>= 1;
+    return epb;
+}
+
 // (Re)build the packed per-workgroup geometry records from the host CSR copies and upload them.
 int rebuild_geo(t2d_pool* p) {
     const int E = p->v.n_env;
     const int log2A = log2_pad(p->v.A);
-    const int epb_max = 256 >> log2A;
+    const int epb_max = envs_per_workgroup(p, log2A);
     constexpr int kBudgetDwords = 8192;  // 32 KiB of dynamic LDS for the record
     t2d::GeoLayout gl{};
     gl.epb = epb_max;
@@ -780,7 +792,8 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
 #endif
     v.geo = nullptr;
     v.geo_layout = t2d::GeoLayout{};
-    v.geo_layout.epb = 256 >> log2_pad(max_agents);
+    p->v.n_env = n_env;   // (envs_per_workgroup reads it)
+    v.geo_layout.epb = envs_per_workgroup(p, log2_pad(max_agents));
     // ParkingEnv defaults: envs/parking.py:106 (max_step 2e4), :151-163 (reward table)
     p->status_cfg = t2d_status_config{20000, 0, 0, 0, -5.0f, -1.0f, -5.0f, 5.0f, 0.001f,
                                       0, 0, 100, 0, 0.95f, 0.999f, 0.1f};

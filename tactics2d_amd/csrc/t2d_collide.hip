@@ -457,7 +457,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     [[maybe_unused]] const int lane = tid & 63;   // (the step body derives its own lane coordinates: see the loop below)
     const int A_pad = 1 << log2A;
     const int EPB = a_epb;
-    const int nthreads = EPB << log2A;
+    const int nthreads = SPLIT ? kBlock : EPB << log2A;   // (SPLIT: four waves per env whatever the record holds)
     const int env_local = SPLIT ? unit % EPB : tid >> log2A;   // the env's place in its geometry record
     const int agent = tid & (A_pad - 1);
     const int env = SPLIT ? unit : wg * EPB + env_local;
@@ -1727,7 +1727,7 @@ bool split_eligible(const PoolView& v, const t2d_status_config& cfg, int log2A, 
     // ... and only where there is something to run side by side: envs with static obstacles next to their lanes (measured:
     // roundabout / intersection pools gain 7-10 %; a highway pool -- pairs and a few lane rectangles, nothing else -- loses 9 %
     // to the extra barriers and the poses derived four times)
-    return log2A == 6 && v.geo_layout.epb == 4 && !(cfg.check_no_action || cfg.check_arrival) && device_cus > 0 &&
+    return log2A == 6 && !(cfg.check_no_action || cfg.check_arrival) && device_cus > 0 &&
            v.n_env <= 4 * device_cus && !v.wgmap && v.geo && v.geo_layout.has[0] && v.geo_layout.has[1];
 }
 

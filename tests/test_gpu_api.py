@@ -267,34 +267,37 @@ def test_step_placement_never_changes_a_result():
     from tactics2d_amd import scenarios as S, layout as L
     from tactics2d_amd.pool import ParticipantPool
     from tactics2d_amd._ffi import T2DError
-    sc = S.mixed(96, 64, 5)                       # 24 workgroups of 4 envs
     rng = np.random.default_rng(3)
-    acts = [sc.sample_actions(rng) for _ in range(6)]
+    # 1060 envs: 265 workgroups of 4 envs (four waves each: rotations apply); 96 envs: fewer workgroups than compute units at
+    # four envs each, so the pool steps with one env -- one wave -- per workgroup (t2d_api.hip envs_per_workgroup)
+    for n_env, n_wg, max_rot in ((1060, 265, 4), (96, 96, 1)):
+        sc = S.mixed(n_env, 64, 5)
+        acts = [sc.sample_actions(rng) for _ in range(6)]
 
-    def rollout(wgmap):
-        pool = ParticipantPool(sc.n_env, sc.A); sc.load(pool); pool.set_auto_reset(True)
-        if wgmap is not None:
-            pool.set_step_placement(wgmap)
-        out = []
-        for a0, a1 in acts:
-            pool.set_actions(a0, a1); pool.step(100)
-            out.append([pool.download(f).copy() for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_FLAGS, L.F_STATUS, L.F_REWARD)])
+        def rollout(wgmap):
+            pool = ParticipantPool(sc.n_env, sc.A); sc.load(pool); pool.set_auto_reset(True)
+            if wgmap is not None:
+                pool.set_step_placement(wgmap)
+            out = []
+            for a0, a1 in acts:
+                pool.set_actions(a0, a1); pool.step(100)
+                out.append([pool.download(f).copy() for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_FLAGS, L.F_STATUS, L.F_REWARD)])
+            pool.close()
+            return out
+        want = rollout(None)
+        perm = rng.permutation(n_wg).astype(np.uint32)
+        rot = rng.integers(0, max_rot, n_wg).astype(np.uint32)
+        got = rollout(perm | (rot << 16))
+        for w, g in zip(want, got):
+            for a, b in zip(w, g):
+                assert np.array_equal(a, b, equal_nan=True)
+        pool = ParticipantPool(sc.n_env, sc.A); sc.load(pool)
+        bad = perm.copy(); bad[0] = bad[1]
+        for m in (bad, perm[:-1], perm | np.uint32(4 << 16)):
+            with pytest.raises(T2DError):
+                pool.set_step_placement(m)
+        pool.set_step_placement(None)
         pool.close()
-        return out
-    want = rollout(None)
-    perm = rng.permutation(24).astype(np.uint32)
-    rot = rng.integers(0, 4, 24).astype(np.uint32)
-    got = rollout(perm | (rot << 16))
-    for w, g in zip(want, got):
-        for a, b in zip(w, g):
-            assert np.array_equal(a, b, equal_nan=True)
-    pool = ParticipantPool(sc.n_env, sc.A); sc.load(pool)
-    bad = perm.copy(); bad[0] = bad[1]
-    for m in (bad, perm[:-1], perm | np.uint32(4 << 16)):
-        with pytest.raises(T2DError):
-            pool.set_step_placement(m)
-    pool.set_step_placement(None)
-    pool.close()
 
 
 @pytest.mark.gpu
