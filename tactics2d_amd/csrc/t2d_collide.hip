@@ -50,6 +50,12 @@
 #include "t2d_idm_dev.h"
 #include "t2d_integrate_dev.h"
 
+// s_sleep between two polls of a PIPE progress word, in units of 64 cycles.  A waiting wave shares its SIMD with the wave it
+// waits for: measured on cfg3 / cfg4 / cfg5 / cfg2 (us per step) 0: 8.9 / 6.4 / 9.4 / -; 1: 8.8 / 6.4 / 9.2 / 4.9; 4: 8.6 / 6.5 /
+// 8.7 / 4.9; 8: 8.6 / 6.6 / 8.6 / 4.9; 16: 8.5 / 6.9 / 8.7; 32: 8.6 / 7.6 / 9.1.
+#ifndef T2D_POLL_SLEEP
+#define T2D_POLL_SLEEP 4
+#endif
 namespace t2d {
 
 namespace {
@@ -537,7 +543,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     [[maybe_unused]] auto pipe_wait = [&](uint32_t* word, uint32_t want) {
         int spins = 0;
         while ((int32_t)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - want) < 0) {
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(T2D_POLL_SLEEP);
             if (++spins > kPipeSpinLimit) {
                 __hip_atomic_store(pv.chain_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;

@@ -25,6 +25,12 @@
 #include "t2d_geom_dev.h"
 #include "t2d_integrate_dev.h"
 
+// s_sleep between two polls of a PIPE progress word, in units of 64 cycles.  A waiting wave shares its SIMD with the wave it
+// waits for: measured on cfg3 / cfg4 / cfg5 / cfg2 (us per step) 0: 8.9 / 6.4 / 9.4 / -; 1: 8.8 / 6.4 / 9.2 / 4.9; 4: 8.6 / 6.5 /
+// 8.7 / 4.9; 8: 8.6 / 6.6 / 8.6 / 4.9; 16: 8.5 / 6.9 / 8.7; 32: 8.6 / 7.6 / 9.1.
+#ifndef T2D_POLL_SLEEP
+#define T2D_POLL_SLEEP 4
+#endif
 namespace t2d {
 
 namespace {
@@ -54,7 +60,7 @@ constexpr int kEgoSpinLimit = 1 << 17;
 T2D_DEV void ego_pipe_wait(uint32_t* word, uint32_t want, uint32_t* err) {   // bounded: a lost wait raises chain_err, never hangs
     int spins = 0;
     while ((int32_t)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - want) < 0) {
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(T2D_POLL_SLEEP);
         if (++spins > kEgoSpinLimit) {
             __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
