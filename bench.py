@@ -193,6 +193,7 @@ class Runner:
         self.a1 = torch.from_numpy(np.stack([s[1] for s in sets])).to(dev).contiguous()
         self.stream = torch.cuda.Stream(device=dev)
         self.k = 0
+        self.align = False
 
     def steps_single(self, n, after_step=None):
         N = self.scene.n
@@ -210,6 +211,8 @@ class Runner:
         done = 0
         while done < n:
             f = min(frag, n - done)
+            if self.align:   # fragments end where the pool's step count reaches a multiple of `frag` (where a gather is due)
+                f = min(frag - self.pool.step_count() % frag, n - done)
             self.pool.step_n(f, self.scene.interval_ms, self.scene.n, self.stream.cuda_stream)
             done += f
             self.k += f
@@ -386,6 +389,8 @@ def main():
     gather, gather_note = None, None
     use_gather = world > 1 or bool(os.environ.get("T2D_FORCE_GATHER"))
     every = max(1, args.gather_every)
+    if use_gather:   # at least one gather inside the timed region, whatever --steps is (fragments end at multiples of `every`)
+        every = max(e for e in (1, 2, 4, 8, 16, 32) if e <= max(1, min(every, args.steps, L.RECORD_RING // 2)))
     native_gather = backend == "nccl" and not os.environ.get("T2D_GATHER_TORCH")
     if use_gather:
         if L.RECORD_RING % every or every > L.RECORD_RING // 2:
@@ -412,6 +417,7 @@ def main():
         else:
             rec = torch.as_tensor(run.pool.device_array(L.F_RECORD), device=dev).view(torch.int32)
             gather = D.ResultGather(rec, world, every=every)
+    run.align = gather is not None
     n_gathers = [0]
 
     def hook():   # after every step (step mode) or fragment (chain mode)
@@ -594,7 +600,7 @@ def main():
                         note="no instruction counts for these sources: re-run scripts/profile_round.sh; the HBM figure stands")
         gather_obj = None
         if gather is not None:
-            gather_obj = dict(native=bool(native_gather), every=every, gathers_in_timed_region=gathers_timed,
+            gather_obj = dict(native=bool(native_gather), every=every, every_requested=args.gather_every, gathers_in_timed_region=gathers_timed,
                               rccl_world=(comm[1] if comm else None), rccl_rank0=(comm[2] if comm else None),
                               rccl_communicator=(bool(comm[0]) if comm else False),
                               ms_per_step_by_rank=per_rank, ms_per_step_min=(min(per_rank) if per_rank else rank_ms),

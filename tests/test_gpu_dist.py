@@ -249,3 +249,21 @@ def test_two_ranks_with_real_pools_gather_what_one_pool_computes(tmp_path):
         assert rw.shape == (STEPS, N_ENV) and st.shape == (STEPS, N_ENV, 4)
         for t in range(STEPS):
             assert np.array_equal(rw[t], want[t][0]) and np.array_equal(st[t], want[t][1]), (rank, t)
+
+
+def test_bench_line_holds_a_gather_inside_the_timed_region_whatever_the_step_count():
+    """bench.py with the gather forced on one rank (what N > 1 runs per rank), at a driver-like `--steps 20 --warmup 5`: the
+    cadence is cut to what fits the run and the fragments end where the pool's step count reaches a multiple of it, so the
+    timed region holds its gather (and the wait for it) -- not a region the collective happens to fall outside of."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, T2D_FORCE_GATHER="1")
+    for extra, want_every, want_gathers in ((["--steps", "20", "--warmup", "5"], 16, 1), (["--steps", "64", "--warmup", "7"], 32, 2),
+                                            (["--steps", "20", "--warmup", "5", "--mode", "step"], 16, 1)):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--envs", "512", "--no-cpu-baseline", "--no-configs",
+                              "--no-next-rows", "--no-alternates", "--no-profile", "--clock-warm", "0"] + extra,
+                             env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-1500:]
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        g = line["gather"]
+        assert g["every"] == want_every and g["gathers_in_timed_region"] >= want_gathers, g
