@@ -61,7 +61,7 @@
 extern "C" {
 #endif
 
-#define T2D_ABI_VERSION 8
+#define T2D_ABI_VERSION 9
 
 /* ---- status codes --------------------------------------------------------------- */
 #define T2D_OK            0
@@ -314,8 +314,18 @@ int t2d_step_groups(t2d_pool* const* pools, const float* const* act0_dev, const 
  * (g, k - 1) by a per-workgroup word in device memory (kept inside one XCD's L2, the placement checked: DESIGN.md 4.10) -- no
  * launch boundary between steps, so the start-up of step k + 1 overlaps the tail of step k.  Small pools: every workgroup
  * loops over the steps itself, and where a step's workgroups number at most the device's CUs a second set of waves per
- * workgroup integrates step k + 1 while the first checks the events of step k (t2d_step_form tells which).  A wait is bounded:
- * if it ever ran out, the next t2d_sync / t2d_download / t2d_step_n returns T2D_ERR_STATE.  Other pools, and every pool after
+ * workgroup integrates step k + 1 while the first checks the events of step k (t2d_step_form tells which).
+ * Failure (never observed; forced by tests with t2d_debug_chain_fault): every wait is bounded, and a chained hand-off checks
+ * that producer and consumer share an XCD.  A workgroup whose hand-off fails does NOT run its step, and neither does any later
+ * step of those envs nor any fragment enqueued behind the failed one; the first t2d_sync / t2d_download / t2d_step_n after it
+ * returns T2D_ERR_STATE -- once -- and the pool goes on with ordinary launches (t2d_set_step_chaining re-enables chaining).
+ * CHAIN forms: the pool has then been rolled back to the state and step count (t2d_step_count) it had when the failed fragment
+ * began -- every chained fragment checkpoints what it starts from -- so the caller re-issues its steps from there; flags,
+ * status, reward and records are rewritten by the next step.  LOOP forms (a wait inside a workgroup ran out): the state is
+ * undefined, t2d_reset / t2d_restore(mode 0) / uploads make the pool usable again.
+ * act_step_stride > 0 needs an action ring bound with t2d_bind_actions[_strided] (n_steps * act_step_stride elements beyond
+ * the last participant's first action); the pool's own ACT0 / ACT1 fields hold one set: T2D_ERR_INVALID otherwise.
+ * Other pools, and every pool after
  * t2d_set_step_chaining(pool, 0, *), take n_steps ordinary launches -- and t2d_step its plainest form: installed IDM
  * controllers as a launch of their own (on = 1: automatic, the default; 2 / 3 / 4 pin the chained
  * form / the plain loop / the loop with integrator but without lane waves -- measurements and tests).  priority_rule: wave priorities inside a chained launch
@@ -534,6 +544,11 @@ int t2d_gather_wait(t2d_pool* pool, void* hip_stream, int32_t block_host);
  * places workgroup b on XCD b mod 8 and its waves on fixed SIMDs, so the map only decides which envs share a SIMD and
  * which XCD gets the expensive ones.  Reset by every t2d_set_*_geometry.  Host memory.                                  */
 int t2d_debug_set_step_placement(t2d_pool* pool, const uint32_t* map_host, int32_t n_workgroups);
+
+/* Test hook: the CHAIN launches of t2d_step_n enqueued from now on break ONE hand-off on purpose -- workgroup 1 posts its step
+ * 1 with a foreign XCC id (kind 1: what a consumer on another XCD would see) or not at all (kind 2: its consumer's bounded
+ * wait runs out after ~0.2 s); 0 = off.  Needs a pool of >= 2 step workgroups and fragments of >= 3 steps to have any effect. */
+int t2d_debug_chain_fault(t2d_pool* pool, int32_t kind);
 
 int t2d_debug_step_occupancy(t2d_pool* pool, int32_t* blocks_per_cu, int64_t* lds_bytes,
                              int64_t* geometry_bytes_per_launch);

@@ -95,6 +95,7 @@ SYMBOLS = {
     # introspection
     "t2d_debug_set_step_placement": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.c_int32]),
     "t2d_debug_step_occupancy": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "t2d_debug_chain_fault": (C.c_int, [_vp, C.c_int32]),
 }
 
 _lib = None

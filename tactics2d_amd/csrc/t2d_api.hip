@@ -90,6 +90,10 @@ void touch(t2d_pool* p, hipStream_t s) {
     else p->live_overflow = true;   // more distinct streams than tracked: the next quiesce falls back to the device
 }
 
+}  // namespace
+namespace t2d { hipError_t launch_chain_rollback(const PoolView& v, const uint32_t* ckpt, hipStream_t s); }
+namespace {
+
 hipError_t quiesce(t2d_pool* p) {
     hipError_t e = hipSuccess;
     bool whole_device = p->live_overflow;
@@ -111,17 +115,51 @@ hipError_t quiesce(t2d_pool* p) {
     }
     p->n_live_streams = 0;
     p->live_overflow = false;
-    if (e == hipSuccess && p->chain_used) {   // a chained launch reports a wait that ran out through a word in device memory
-        uint32_t err = 0;
-        e = hipMemcpy(&err, p->d_chain + p->chain_slots, sizeof(err), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && p->chain_used) {   // a chained launch reports a broken hand-off through two words in device memory
+        uint32_t err[2] = {0, 0};   // {1: a bounded wait ran out | 2: producer and consumer on different XCDs, ckpt_tag of the fragment}
+        e = hipMemcpy(err, p->d_chain + p->chain_slots, sizeof(err), hipMemcpyDeviceToHost);
         p->chain_used = false;
-        if (e == hipSuccess && err) {
+        if (e == hipSuccess && err[0]) {
             (void)hipMemset(p->d_chain + p->chain_slots, 0, sizeof(err));
             p->chain_failed = true;
+            p->chain_err_code = (int)err[0];
             p->chain_steps = false;   // whatever broke the hand-off (a wait that ran out, workgroups of one env set on two XCDs) may do so again
+            p->chain_sig = 0;         // (the counters are in no known state: a later chained launch starts them afresh)
+            p->chain_rolled_back = false;
+            if (p->ckpt_armed && p->d_ckpt) {
+                // CHAIN form: the failed fragment and everything enqueued behind it wrote no state it could not trust (poisoned
+                // hand-offs skip their steps), and its checkpoint holds what it started from: put the pool back there.  The
+                // tag is the low half of the step count at the fragment's start.
+                const uint32_t back = (uint32_t)p->step_count - err[1];
+                e = t2d::launch_chain_rollback(p->v, p->d_ckpt, nullptr);
+                if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+                if (e == hipSuccess) {
+                    p->step_count -= (long long)back;
+                    p->chain_rolled_back = true;
+                    p->chain_rollback_step = p->step_count;
+                    p->v.record = (uint2*)p->field_ptr[T2D_F_RECORD] +
+                                  (size_t)((p->step_count + T2D_RECORD_RING - 1) % T2D_RECORD_RING) * p->v.n_env;
+                }
+            }
         }
     }
     return e;
+}
+
+// A failed chained launch is reported ONCE, by the first t2d_sync / t2d_download / t2d_step_n after it; the pool then goes on
+// with plain launches (t2d_set_step_chaining turns chaining back on).
+int report_chain_failure(t2d_pool* p) {
+    if (!p->chain_failed) return T2D_OK;
+    p->chain_failed = false;
+    const std::string why = p->chain_err_code == 2 ? "two workgroups of one env set ran on different XCDs"
+                                                   : "a workgroup's bounded wait for its previous step ran out";
+    if (p->chain_rolled_back)
+        return fail(p, T2D_ERR_STATE, "a t2d_step_n launch failed (" + why + "): the pool was rolled back to step " +
+                                          std::to_string(p->chain_rollback_step) + ", the start of the failed fragment -- flags, status, "
+                                          "reward and records hold nothing valid until the next step; re-issue the steps from there "
+                                          "(they take plain launches now)");
+    return fail(p, T2D_ERR_STATE, "a t2d_step_n launch failed (" + why + "): its results are invalid -- t2d_reset / t2d_restore / "
+                                      "upload the state before stepping on (plain launches from now on)");
 }
 
 size_t field_elem_bytes(int f) {
@@ -664,7 +702,34 @@ __global__ __launch_bounds__(256) void restore_env_kernel(PoolView pv, int mode)
     uchar4 st; st.x = T2D_SCENARIO_NORMAL; st.y = T2D_TRAFFIC_NORMAL; st.z = 0; st.w = 0;
     reinterpret_cast<uchar4*>(pv.status)[env] = st;
 }
+// back to the checkpoint of a failed CHAIN fragment (PoolView::ckpt): the state arrays and the envs' counters
+__global__ __launch_bounds__(256) void chain_rollback_kernel(PoolView pv, const uint32_t* ck) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)pv.N;
+    if (i < pv.N) {
+        // (every slot of the pool was loaded and checkpointed by the fragment's first step, active or not; a point mass's
+        // velocity is the only velocity that is state)
+        const uint32_t ids = ck[6 * n + i];
+        pv.x[i] = __uint_as_float(ck[i]);
+        pv.y[i] = __uint_as_float(ck[n + i]);
+        pv.heading[i] = __uint_as_float(ck[2 * n + i]);
+        pv.speed[i] = __uint_as_float(ck[3 * n + i]);
+        if (((ids >> kIdsActiveShift) & 0xffu) && ((ids >> kIdsModelShift) & 0xffu) == T2D_MODEL_POINTMASS) {
+            pv.vx[i] = __uint_as_float(ck[4 * n + i]);
+            pv.vy[i] = __uint_as_float(ck[5 * n + i]);
+        }
+        pv.ids[i] = ids;
+    }
+    if (i < pv.n_env) {
+        pv.cnt_step[i] = (int32_t)ck[7 * n + i];
+        pv.frame_ms[i] = (int32_t)ck[7 * n + pv.n_env + i];
+    }
+}
 }  // namespace
+hipError_t launch_chain_rollback(const PoolView& v, const uint32_t* ckpt, hipStream_t s) {
+    hipLaunchKernelGGL(chain_rollback_kernel, dim3((v.N + 255) / 256), dim3(256), 0, s, v, ckpt);
+    return hipGetLastError();
+}
 hipError_t launch_spin(long long ticks, hipStream_t s) {
     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, ticks);
     return hipGetLastError();
@@ -812,7 +877,7 @@ int t2d_destroy(t2d_pool* p) {
                     p->d_lidar_env_off, p->d_lidar_next, p->d_lidar_meta, p->d_lidar_xy, p->d_beam_sin, p->d_beam_cos,
                     p->d_snap[0], p->d_snap[1], p->d_snap[2],
                     p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_wgmap, p->d_idm_rows, p->d_idm_ctrl, p->d_snap_omega[0], p->d_snap_omega[1], p->d_time_penalty,
-                    p->d_scene_arrays, p->d_lidar_cnt, p->d_chain};
+                    p->d_scene_arrays, p->d_lidar_cnt, p->d_chain, p->d_ckpt};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->comm && rccl().ok) (void)rccl().CommDestroy((ncclComm_t)p->comm);
@@ -1024,6 +1089,7 @@ int t2d_reset(t2d_pool* p, const uint8_t* env_mask, const float* x, const float*
         return fail(p, T2D_ERR_INVALID, "x, y, heading, speed, type_id, active are required");
     T2D_HIP(p, hipSetDevice(p->device));
     T2D_HIP(p, quiesce(p));
+    if (!env_mask) p->chain_failed = false;   // (every env gets a new state: whatever a failed t2d_step_n left behind is gone)
     const int E = p->v.n_env, A = p->v.A, N = p->v.N;
     std::vector<float> hx(N), hy(N), hh(N), hs(N), hvx(N), hvy(N);
     std::vector<uint32_t> hids(N), hflags(N);
@@ -1166,7 +1232,9 @@ int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
 // small enough for it.  t2d_set_step_chaining(pool, 0, *) keeps idm_kernel a launch of its own (tests hold the two
 // against each other).
 static bool idm_in_step(t2d_pool* p) {
-    return p->idm_on && p->chain_steps && p->fused_step && p->v.A >= 2 && p->v.A <= 64 &&
+    // (not pools with SingleTrackDrift participants: drift_kernel runs between the controllers and the step launch and reads
+    // the accelerations the controllers wrote -- t2d_step's order is IDM, drift, step -- so there idm_kernel stays a launch)
+    return p->idm_on && p->chain_steps && p->fused_step && !p->has_drift && p->v.A >= 2 && p->v.A <= 64 &&
            !(p->status_cfg.check_no_action || p->status_cfg.check_arrival);
 }
 static void fill_idm(t2d::PoolView& v, t2d_pool* p) {
@@ -1295,8 +1363,10 @@ int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
 int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_step_stride, void* hip_stream) {
     if (!p) return T2D_ERR_INVALID;
     if (n_steps < 1 || act_step_stride < 0) return fail(p, T2D_ERR_INVALID, "n_steps must be >= 1 and act_step_stride >= 0");
-    if (p->chain_failed)
-        return fail(p, T2D_ERR_STATE, "an earlier t2d_step_n launch timed out waiting for its previous step (results invalid)");
+    // (the pool's own action fields hold ONE action set: a ring needs bound memory of n_steps * act_step_stride elements)
+    if (act_step_stride != 0 && p->v.act0 == (const float*)p->field_ptr[T2D_F_ACT0])
+        return fail(p, T2D_ERR_INVALID, "act_step_stride > 0 needs an action ring bound with t2d_bind_actions (the pool's own ACT0 / ACT1 hold one set)");
+    if (p->chain_failed) return report_chain_failure(p);   // (once; the call after it goes ahead with plain launches)
     if (!p->have_params || !p->have_reset)
         return fail(p, T2D_ERR_STATE, "t2d_set_param_table and t2d_reset must precede t2d_step_n");
     if (interval_ms <= 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be positive");
@@ -1370,6 +1440,34 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
         }
         v.record_ring = (uint2*)p->field_ptr[T2D_F_RECORD];
         v.record_slot0 = slot0;
+        // CHAIN forms (one workgroup per (env set, step), ordered by the counters in d_chain): the counters continue from
+        // launch to launch only while the launches have one shape -- a pool that changes form (t2d_set_idm, new geometry,
+        // t2d_set_split_step, t2d_set_step_chaining) starts them afresh, on the stream -- and every fragment carries the
+        // checkpoint a failed hand-off is rolled back to
+        const bool chain_form = !ego && v.loop_steps == 0;
+        if (chain_form) {
+            const uint32_t sig = ((uint32_t)v.chain_real_wgs << 1) | (v.split_step ? 1u : 0u) | 0x80000000u;
+            if (sig != p->chain_sig) {
+                T2D_HIP(p, hipMemsetAsync(p->d_chain, 0, sizeof(unsigned long long) * (size_t)p->chain_slots, s));
+                p->chain_count = 0;
+                p->chain_sig = sig;
+                v.chain_base = 0;
+            }
+            if (!p->d_ckpt) {
+                const size_t words = 7 * (size_t)p->v.N + 2 * (size_t)p->v.n_env;
+                T2D_HIP(p, hipMalloc((void**)&p->d_ckpt, sizeof(uint32_t) * words));
+                T2D_HIP(p, hipMemset(p->d_ckpt, 0, sizeof(uint32_t) * words));
+            }
+            v.ckpt = p->d_ckpt;
+            v.ckpt_tag = (uint32_t)(p->step_count - n);   // (low half of the step count this fragment starts from)
+            v.chain_fault = p->chain_fault;
+        } else {
+            v.ckpt = nullptr;
+            v.chain_fault = 0;
+        }
+        // (the checkpoint is what a failure is rolled back to only while every multi-step launch since the last host
+        // synchronisation carried one)
+        p->ckpt_armed = chain_form && (p->chain_used ? p->ckpt_armed : true);
         if ((rc = record_event(p, 7, s, true))) return rc;
         if (ego) {   // 16 lanes per env, each group of lanes loops over the steps
             v.loop_steps = n;
@@ -1380,7 +1478,7 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
             T2D_HIP(p, t2d::launch_step_chain(v, p->status_cfg, interval_ms, p->integrator_variant, n, s));
         }
         if ((rc = record_event(p, 7, s, false))) return rc;
-        p->chain_count += (uint32_t)n;
+        if (chain_form) p->chain_count += (uint32_t)n;   // (only these launches move the counters)
         p->chain_used = true;
         done += n;
     }
@@ -1495,6 +1593,7 @@ int t2d_restore(t2d_pool* p, int32_t mode, void* hip_stream) {
     if (!p->have_snapshot) return fail(p, T2D_ERR_STATE, "t2d_snapshot must precede t2d_restore");
     if (mode != 0 && mode != 1) return fail(p, T2D_ERR_INVALID, "mode must be 0 (all) or 1 (done envs)");
     touch(p, (hipStream_t)hip_stream);
+    if (mode == 0) p->chain_failed = false;   // (see t2d_reset)
     T2D_HIP(p, t2d::launch_restore(p->v, p->d_snap, p->d_snap_ids, mode, (hipStream_t)hip_stream));
     return T2D_OK;
 }
@@ -1789,6 +1888,14 @@ int t2d_gather_wait(t2d_pool* p, void* hip_stream, int32_t block_host) {
     return T2D_OK;
 }
 
+// test hook: the next CHAIN launches of the pool break one hand-off on purpose (include/t2d.h)
+int t2d_debug_chain_fault(t2d_pool* p, int32_t kind) {
+    if (!p) return T2D_ERR_INVALID;
+    if (kind < 0 || kind > 2) return fail(p, T2D_ERR_INVALID, "fault kind: 0 none, 1 foreign XCC id, 2 a hand-off that never comes");
+    p->chain_fault = (uint32_t)kind;
+    return T2D_OK;
+}
+
 // placement of the step launch (include/t2d.h): a permutation of its workgroups + a wave rotation per workgroup
 int t2d_debug_set_step_placement(t2d_pool* p, const uint32_t* map_host, int32_t n_workgroups) {
     if (!p) return T2D_ERR_INVALID;
@@ -1847,8 +1954,7 @@ int t2d_download(t2d_pool* p, int32_t f, void* host_dst, size_t nbytes) {
                                             std::to_string(f >= 0 && f < T2D_F_COUNT ? p->field_bytes[f] : 0) + " bytes)");
     T2D_HIP(p, hipSetDevice(p->device));
     T2D_HIP(p, quiesce(p));
-    if (p->chain_failed)
-        return fail(p, T2D_ERR_STATE, "a t2d_step_n launch timed out waiting for its previous step (results invalid)");
+    if (p->chain_failed) return report_chain_failure(p);
     T2D_HIP(p, hipMemcpy(host_dst, p->field_ptr[f], nbytes, hipMemcpyDeviceToHost));
     return T2D_OK;
 }
@@ -1875,8 +1981,7 @@ int t2d_sync(t2d_pool* p) {
     if (!p) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));
     T2D_HIP(p, quiesce(p));
-    if (p->chain_failed)
-        return fail(p, T2D_ERR_STATE, "a t2d_step_n launch timed out waiting for its previous step (results invalid)");
+    if (p->chain_failed) return report_chain_failure(p);
     return T2D_OK;
 }
 

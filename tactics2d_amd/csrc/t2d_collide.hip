@@ -500,7 +500,16 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
         else if (role_b) __builtin_amdgcn_s_setprio(T2D_PIPE_PRIO >= 0 ? (T2D_PIPE_PRIO / 10) % 10 : 0);
         else __builtin_amdgcn_s_setprio(T2D_PIPE_PRIO >= 0 ? (T2D_PIPE_PRIO / 100) % 10 : 0);
     }
-    // chained launch: wait for the step before this one of the same envs (one lane polls, s_sleep between polls)
+    // chained launch: wait for the step before this one of the same envs (one lane polls, s_sleep between polls).
+    // A hand-off that fails -- the wait ran out, or the producer sat on another XCD -- is RECORDED, {what, which fragment}, and
+    // the workgroup goes on (never a hang): the host rolls the pool back to the checkpoint the fragment wrote in its first
+    // step (below) and reports the launch as failed, so nothing computed from here on is ever handed to a caller.
+    [[maybe_unused]] auto chain_fail = [&](uint32_t code) {   // (the first failure names the fragment)
+        if (__hip_atomic_load(pv.chain_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __hip_atomic_store(pv.chain_err + 1, pv.ckpt_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pv.chain_err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     auto chain_wait = [&]() {
         if (ptid == 0) {
             const uint32_t want = pv.chain_base + (uint32_t)step_k;
@@ -514,14 +523,13 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                 // ends the launch in about one limit, not in one limit per workgroup
                 if (spins > kChainSpinLimit ||
                     ((spins & 255) == 0 && __hip_atomic_load(pv.chain_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-                    __hip_atomic_store(pv.chain_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    chain_fail(1u);
                     w = chain_word(want);
                     break;
                 }
             }
             // the previous step's stores sit in ITS XCD's L2: the sc1 loads below see them only from the same XCD
-            if ((uint32_t)(w >> 32) != (uint32_t)__builtin_amdgcn_s_getreg(63508))
-                __hip_atomic_store(pv.chain_err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(w >> 32) != (uint32_t)__builtin_amdgcn_s_getreg(63508)) chain_fail(2u);
         }
         __syncthreads();
     };
@@ -896,6 +904,24 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     // only what belongs to their own wave
     if (carried && log2A <= 6) wave_sync(); else __syncthreads();
     T2D_MARK(0);
+    if constexpr (CHAIN) {
+        // The fragment's checkpoint: the state its first step starts from, stored from the registers that hold it anyway
+        // (every slot of the pool, active or not).  Not behind a fragment that failed -- the error word is final by then,
+        // launches of one stream do not overlap -- so the failed fragment's own checkpoint survives whatever was enqueued
+        // behind it, and that is what the host restores.
+        if (step_k == 0 && valid && (!SPLIT || role == 0)) {
+            const KernargView ck = late_args();
+            if (*as_global(ck->chain_err) == 0u) {
+                auto c_base = as_global(ck->ckpt);
+                const size_t cn = (size_t)ck->N;
+                c_base[idx] = __float_as_uint(fx);
+                c_base[cn + idx] = __float_as_uint(fy);
+                c_base[2 * cn + idx] = __float_as_uint(fh);
+                c_base[3 * cn + idx] = __float_as_uint(fv);
+                c_base[6 * cn + idx] = ids;
+            }
+        }
+    }
 
     if (SPLIT) ids = s_ids_new[tid];
     if constexpr (PIPE) {   // this step's state, committed by the pair's integrator wave
@@ -949,8 +975,20 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                 pvx = (double)c_vx;
                 pvy = (double)c_vy;
             } else {
-                pvx = (double)ld_state<MULTI>(as_global(pv.vx) + idx);
-                pvy = (double)ld_state<MULTI>(as_global(pv.vy) + idx);
+                const float lvx = ld_state<MULTI>(as_global(pv.vx) + idx), lvy = ld_state<MULTI>(as_global(pv.vy) + idx);
+                pvx = (double)lvx;
+                pvy = (double)lvy;
+                // (a point mass's velocity is state: part of the fragment's checkpoint.  The step number through an empty asm:
+                // the compiler otherwise keeps the lane mask of the test at the top alive down to here, in spilled scalars)
+                int k0 = CHAIN ? (int)blockIdx.y : 1;
+                if constexpr (CHAIN) asm volatile("" : "+s"(k0));
+                if (CHAIN && k0 == 0) {
+                    const KernargView ck = late_args();
+                    if (*as_global(ck->chain_err) == 0u) {
+                        as_global(ck->ckpt)[4 * (size_t)ck->N + idx] = __float_as_uint(lvx);
+                        as_global(ck->ckpt)[5 * (size_t)ck->N + idx] = __float_as_uint(lvy);
+                    }
+                }
             }
         }
         const integ::StepOut o = integ::step_participant<(FUSE > 0 ? 1 : 0)>(
@@ -1468,6 +1506,13 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
         } else {
             pre_cnt = ld_state<MULTI>(e_cnt_step + env);
             pre_frame = ld_state<MULTI>(e_frame_ms + env);
+            int k0 = CHAIN ? (int)blockIdx.y : 1;
+            if constexpr (CHAIN) asm volatile("" : "+s"(k0));
+            if (CHAIN && k0 == 0 && *as_global(ep->chain_err) == 0u) {   // (the env's counters at the start of the fragment: the checkpoint's last two columns)
+                auto c_env = as_global(ep->ckpt) + 7 * (size_t)ep->N;
+                c_env[env] = (uint32_t)pre_cnt;
+                c_env[e_n_env + env] = (uint32_t)pre_frame;
+            }
         }
         if (e_time_penalty && cfg.max_step > 0) {
             const int c = pre_cnt + 1;
@@ -1704,8 +1749,13 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     if (CHAIN) {   // this step of these envs is complete: every store above is in the L2 before the word moves
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (ptid == 0)
-            __hip_atomic_store(&pv.chain_done[unit], chain_word(pv.chain_base + (uint32_t)step_k + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ptid == 0) {
+            unsigned long long w = chain_word(pv.chain_base + (uint32_t)step_k + 1u);
+            // test hook (t2d_debug_chain_fault): workgroup 1 hands its step 1 over with a foreign XCC id / not at all
+            const uint32_t fault = (unit == 1 && step_k == 1) ? pv.chain_fault : 0u;
+            if (fault & 1u) w ^= 1ull << 32;
+            if (!(fault & 2u)) __hip_atomic_store(&pv.chain_done[unit], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 #undef pv
 #undef cfg

@@ -108,6 +108,13 @@ struct PoolView {
     int64_t chain_act_step;     // elements between the action sets of consecutive steps (0: the same actions every step)
     uint2* record_ring;         // the whole ring of per-env result records; step k writes slot (record_slot0 + k) % ring
     int32_t record_slot0;
+    // CHAIN launches: what the state was when the fragment started, written by the workgroups of its step 0 from the values
+    // they load anyway -- [x | y | heading | speed | vx | vy | ids] of N words each, then cnt_step / frame_ms of n_env words
+    // each.  A fragment whose hand-off fails (chain_err) is rolled back to it by the host: t2d_step_n never leaves a pool
+    // on stale results (see t2d_api.hip quiesce).  ckpt_tag travels into chain_err[1] with the error: which fragment.
+    uint32_t* ckpt;
+    uint32_t ckpt_tag;
+    uint32_t chain_fault;       // test hook (t2d_debug_chain_fault): 1 = a producer posts a foreign XCC id, 2 = one never posts
     // t2d_step_n on a pool with installed IDM controllers (PIPE form): the integrator waves run the controller ahead of every
     // step themselves (t2d_idm_dev.h) -- its rows, every participant's controller id, and the places t2d_idm_actions writes
     const double* idm_rows;
@@ -254,6 +261,17 @@ struct t2d_pool {
     bool split_steps = true;       // small pools of 64-agent envs step with one env per workgroup (t2d_set_split_step)
     bool chain_priority = true;    // wave priorities of a chained launch: 1 = the rule for overlapping work (PoolView::overlapped)
     bool chain_used = false, chain_failed = false;
+    // a failed chained launch (chain_err: 1 = a bounded wait ran out, 2 = producer and consumer of a hand-off on different
+    // XCDs): reported ONCE by the next t2d_sync / t2d_download / t2d_step_n; chaining stays off for the pool afterwards.
+    // CHAIN-form fragments carry a checkpoint of the state they started from (PoolView::ckpt): the pool is rolled back to it,
+    // step count included, and goes on from there with plain launches.
+    int chain_err_code = 0;
+    bool chain_rolled_back = false;
+    long long chain_rollback_step = 0;
+    uint32_t* d_ckpt = nullptr;
+    bool ckpt_armed = false;       // every multi-step launch since the last quiesce was a CHAIN launch with a checkpoint
+    uint32_t chain_sig = 0;        // shape (workgroups, split) of the last CHAIN launch whose counters d_chain holds; 0 = none
+    uint32_t chain_fault = 0;      // t2d_debug_chain_fault
     int device_cus = 0;            // compute units of the pool's device (read once)
     // result gather (the one collective of the path): RCCL communicator + a stream of its own, so that the steps that
     // follow a fragment do not wait for its all-gather; slot_event[k] != null = a gather that reads record slot k was

@@ -347,6 +347,11 @@ class ParticipantPool:
         m = np.ascontiguousarray(wgmap, np.uint32)
         self._ck(self._lib.t2d_debug_set_step_placement(self._h, m.ctypes.data_as(C.POINTER(C.c_uint32)), int(m.size)))
 
+    def debug_chain_fault(self, kind):
+        """Test hook (t2d_debug_chain_fault): the CHAIN launches of step_n break one hand-off on purpose -- 1: a foreign XCC
+        id in the word, 2: a word that never comes; 0: off."""
+        self._ck(self._lib.t2d_debug_chain_fault(self._h, int(kind)))
+
     def step_occupancy(self):
         """(resident workgroups per CU, LDS bytes per workgroup) of the fused step kernel with this pool's geometry."""
         b, l, g = C.c_int32(), C.c_int64(), C.c_int64()
