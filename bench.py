@@ -348,6 +348,7 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip timing BASELINE.json's other configurations")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the IDM / lidar / ParkingEnv timings")
     ap.add_argument("--no-alternates", action="store_true", help="skip timing the other step mode and the all-outputs form")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip timing the closed loop (policy kernel -> t2d_step per env group)")
     ap.add_argument("--no-reset", action="store_true", help="skip the device-side auto-reset")
     ap.add_argument("--idm", action="store_true", help="non-ego vehicles driven by on-device IDM controllers (row f3); "
                     "adds the idm kernel to every step (not the metric configuration)")

@@ -115,7 +115,12 @@ enum {
     T2D_P_DRIFT_TSB = 15,    /* T_sb, brake-torque split   (single_track_drift.py:102) */
     T2D_P_DRIFT_TSE = 16,    /* T_se, engine-torque split  (:103)                      */
     T2D_P_DRIFT_RADIUS = 22, /* effective wheel radius (m) (:101)                      */
-    T2D_P_DRIFT_IYW = 23     /* wheel inertia I_yw         (:106)                      */
+    T2D_P_DRIFT_IYW = 23,    /* wheel inertia I_yw         (:106)                      */
+    /* ... and rows of the other models carry two DERIVED values there, written by the library (whatever the caller put
+     * into the reserved columns is ignored): */
+    T2D_P_DT_S = 22,         /* (double)delta_t_ms / 1000: the Euler sub-step in seconds (_step's `dt`)            */
+    T2D_P_SUBSTEPS = 23      /* (interval_ms / delta_t_ms) * 65536 + interval_ms % delta_t_ms for the interval of the
+                              * launch in flight (a 32-thread kernel refreshes it when the interval changes)        */
 };
 #define T2D_RANGE_STEER 1
 #define T2D_RANGE_SPEED 2
@@ -274,6 +279,7 @@ int t2d_bind_actions_strided(t2d_pool* pool, const float* act0_dev, const float*
 /* Physics only: one PhysicsModelBase.step(interval_ms) for every active participant,
  * actions taken from fields ACT0/ACT1.                                                  */
 int t2d_integrate(t2d_pool* pool, int32_t interval_ms, void* hip_stream);
+#define T2D_MAX_INTERVAL_MS 32767   /* interval_ms of every stepping call: 1 .. 32767 (the sub-step count travels in 15 bits) */
 /* Events only: recompute FLAGS / ENV_FLAGS from the current poses.                      */
 int t2d_collide(t2d_pool* pool, void* hip_stream);
 /* ScenarioManager.check_status alone (envs/parking.py:361-392): events + the status / reward /
@@ -320,8 +326,8 @@ int t2d_step_groups(t2d_pool* const* pools, const float* const* act0_dev, const 
  * step of those envs nor any fragment enqueued behind the failed one; the first t2d_sync / t2d_download / t2d_step_n after it
  * returns T2D_ERR_STATE -- once -- and the pool goes on with ordinary launches (t2d_set_step_chaining re-enables chaining).
  * CHAIN forms: the pool has then been rolled back to the state and step count (t2d_step_count) it had when the failed fragment
- * began -- every chained fragment checkpoints what it starts from -- so the caller re-issues its steps from there; flags,
- * status, reward and records are rewritten by the next step.  LOOP forms (a wait inside a workgroup ran out): the state is
+ * began -- every chained fragment checkpoints what it starts from -- so the caller re-issues its steps from there; the pure
+ * outputs (flags, status, reward, records, vx / vy of the single-track models, the applied action) are rewritten by the next step.  LOOP forms (a wait inside a workgroup ran out): the state is
  * undefined, t2d_reset / t2d_restore(mode 0) / uploads make the pool usable again.
  * act_step_stride > 0 needs an action ring bound with t2d_bind_actions[_strided] (n_steps * act_step_stride elements beyond
  * the last participant's first action); the pool's own ACT0 / ACT1 fields hold one set: T2D_ERR_INVALID otherwise.
@@ -557,6 +563,31 @@ int t2d_debug_step_occupancy(t2d_pool* pool, int32_t* blocks_per_cu, int64_t* ld
  * start late -- what a slow peer does to the collective.  tests/test_gpu_dist.py uses it to check that a step about to
  * overwrite a record slot really waits for the gather that still has to read it.                                       */
 int t2d_debug_delay_gather(t2d_pool* pool, int32_t microseconds);
+
+/* ---- the closed loop (measurement / test helpers; tactics2d_amd/csrc/t2d_loop.hip) -----------------------------------------
+ * The reference's callers run  action = policy(obs); obs, reward, ... = env.step(action)  (envs/parking.py:219-256 inside the
+ * tutorial's training loop).  On the device that is: a policy kernel that reads the state the previous step left behind and
+ * writes an [N, 2] (steering, accel) tensor -> t2d_step reading it in place (t2d_bind_actions_strided) -> the policy again,
+ * with no host synchronisation; the envs cut into groups -- one pool and one stream each -- so that one group's policy,
+ * start-up and tail overlap the other groups' busy middle (env groups: tactics2d_amd/pipeline.py, t2d_step_groups).
+ *   t2d_debug_feedback_policy   a STAND-IN policy, one launch: per participant accel = clip(k_speed (v_target - speed), -3, 2),
+ *                               steering = k_steer sin(0.05 x + 0.08 y + heading); act_out_dev = f32 [N][2] (steering, accel).
+ *   t2d_debug_closed_loop_*     n iterations of (that policy, t2d_step) per group enqueued by ONE host call -- launcher 0: from
+ *                               the calling thread, round the groups step by step; 1: one host thread per group; 2: one captured
+ *                               hipGraph per group holding graph_steps iterations, replayed (a replay rewrites the record-ring
+ *                               slots of the capture: pick graph_steps = a multiple of T2D_RECORD_RING, or read T2D_F_STATUS /
+ *                               T2D_F_REWARD).  create binds each pool's actions to its act_out_dev[g]; run returns when
+ *                               everything is enqueued (t2d_sync / stream synchronisation waits for it); results are those of
+ *                               the same policy and t2d_step calls on one pool holding all the envs. */
+typedef struct t2d_closed_loop t2d_closed_loop;
+/* a hipStreamNonBlocking stream created by the library (priority as hipStreamCreateWithPriority: 0 default, negative higher) */
+int t2d_debug_stream_create(int32_t device_id, int32_t priority, void** out_stream);
+int t2d_debug_stream_destroy(void* stream);
+int t2d_debug_feedback_policy(t2d_pool* pool, float* act_out_dev, float v_target, float k_speed, float k_steer, void* hip_stream);
+int t2d_debug_closed_loop_create(t2d_pool* const* pools, void* const* hip_streams, float* const* act_out_dev, int32_t n_groups,
+                                 int32_t interval_ms, int32_t launcher, int32_t graph_steps, t2d_closed_loop** out);
+int t2d_debug_closed_loop_run(t2d_closed_loop* loop, int32_t n_steps);
+int t2d_debug_closed_loop_destroy(t2d_closed_loop* loop);
 
 /* Host-only (no device is touched): the rectangles t2d_set_lane_geometry finds inside the union of each env's lane polygons
  * -- the certificate behind the step kernel's off-lane short cut (a pose whose box lies in one of them is contained in the

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
+#include <map>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -49,7 +51,7 @@ constexpr int kIters = 1024;
                          : "vcc");                                                                                    \
         const unsigned long long t1 = __builtin_readcyclecounter();                                                   \
         asm volatile("" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));                     \
-        if ((threadIdx.x & 63u) == 0u) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;                    \
+        if ((threadIdx.x & 63u) == 0u) { unsigned long long* o_ = out + 4 * (size_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); o_[0] = t0; o_[1] = t1; o_[2] = __builtin_amdgcn_s_getreg(63492); o_[3] = __builtin_amdgcn_s_getreg(63508); }                    \
     }
 
 #define OP_FMA64(d, a, b) "v_fma_f64 " d ", " d ", " a ", " b "\n\t"
@@ -89,6 +91,52 @@ constexpr int kIters = 1024;
 #define OP_MIX_LDS(d, a, b) "v_fma_f64 " d ", " d ", " a ", " b "\n\tds_read_b32 v40, v42\n\t"
 #define OP_SALU_ONLY(d, a, b) "s_add_u32 s20, s20, 1\n\t"
 
+// (v_cndmask reads a lane mask: VCC as left by whatever ran before / VCC set to a pattern / an SGPR pair / VCC written by a
+// v_cmp right before it -- the usual select idiom)
+#define KERNEL_PRE(NAME, TYPE, INIT, PRE, OP)                                                                          \
+    __global__ __launch_bounds__(256) void NAME(unsigned long long* out, TYPE seed) {                                 \
+        TYPE a0 = seed, a1 = seed, a2 = seed, a3 = seed, a4 = seed, a5 = seed, a6 = seed, a7 = seed;                  \
+        TYPE x = INIT, y = seed;                                                                                      \
+        asm volatile("" : "+v"(x), "+v"(y));                                                                          \
+        asm volatile(PRE ::: "vcc", "s20", "s21");                                                                    \
+        const unsigned long long t0 = __builtin_readcyclecounter();                                                   \
+        for (int i = 0; i < kIters; ++i)                                                                              \
+            asm volatile(BLOCK16(OP)                                                                                  \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)             \
+                         : "v"(x), "v"(y)                                                                             \
+                         : "vcc", "s20", "s21");                                                                      \
+        const unsigned long long t1 = __builtin_readcyclecounter();                                                   \
+        asm volatile("" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));                     \
+        if ((threadIdx.x & 63u) == 0u) { unsigned long long* o_ = out + 4 * (size_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); o_[0] = t0; o_[1] = t1; o_[2] = __builtin_amdgcn_s_getreg(63492); o_[3] = __builtin_amdgcn_s_getreg(63508); } \
+    }
+#define OP_CNDMASK_S(d, a, b) "v_cndmask_b32_e64 " d ", " d ", " a ", s[20:21]\n\t"
+#define OP_CMP_CNDMASK(d, a, b) "v_cmp_lt_u32 vcc, " d ", " a "\n\tv_cndmask_b32 " d ", " d ", " a ", vcc\n\t"
+#define OP_CMP_CNDMASK_S(d, a, b) "v_cmp_lt_u32_e64 s[20:21], " d ", " a "\n\tv_cndmask_b32_e64 " d ", " d ", " a ", s[20:21]\n\t"
+#define OP_CMP64_S(d, a, b) "v_cmp_lt_u32_e64 s[20:21], " d ", " a "\n\t"
+#define OP_MINU32(d, a, b) "v_min_u32 " d ", " d ", " a "\n\t"
+#define OP_MAD_U32(d, a, b) "v_mad_u32_u24 " d ", " d ", " a ", " b "\n\t"
+#define OP_OR3(d, a, b) "v_or3_b32 " d ", " d ", " a ", " b "\n\t"
+#define OP_LSHLADD(d, a, b) "v_lshl_add_u32 " d ", " d ", 2, " a "\n\t"
+#define OP_BFE(d, a, b) "v_bfe_u32 " d ", " d ", 3, 5\n\t"
+#define OP_READLANE(d, a, b) "v_readlane_b32 s20, " d ", 3\n\t"
+#define OP_WRITELANE(d, a, b) "v_writelane_b32 " d ", s20, 3\n\t"
+#define OP_CMP_2CND(d, a, b) "v_cmp_lt_u32 vcc, " d ", " a "\n\tv_cndmask_b32 " d ", " d ", " a ", vcc\n\tv_cndmask_b32 " d ", " d ", " b ", vcc\n\t"
+#define OP_CMP_2CND_S(d, a, b) "v_cmp_lt_u32_e64 s[20:21], " d ", " a "\n\tv_cndmask_b32_e64 " d ", " d ", " a ", s[20:21]\n\tv_cndmask_b32_e64 " d ", " d ", " b ", s[20:21]\n\t"
+#define OP_CMP64_2CND(d, a, b) "v_cmp_lt_f64 vcc, %8, %9\n\tv_cndmask_b32 " d ", " d ", " a ", vcc\n\tv_cndmask_b32 " d ", " d ", " b ", vcc\n\t"
+KERNEL_PRE(k_cmp_2cnd, unsigned, 3u, "s_mov_b64 vcc, 0", OP_CMP_2CND)
+KERNEL_PRE(k_cmp_2cnd_s, unsigned, 3u, "s_mov_b64 s[20:21], 0", OP_CMP_2CND_S)
+KERNEL_PRE(k_cndmask_vccset, unsigned, 3u, "s_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555", OP_CNDMASK)
+KERNEL_PRE(k_cndmask_s, unsigned, 3u, "s_mov_b32 s20, 0x55555555\n\ts_mov_b32 s21, 0x55555555", OP_CNDMASK_S)
+KERNEL_PRE(k_cmp_cndmask, unsigned, 3u, "s_mov_b64 vcc, 0", OP_CMP_CNDMASK)
+KERNEL_PRE(k_cmp_cndmask_s, unsigned, 3u, "s_mov_b64 s[20:21], 0", OP_CMP_CNDMASK_S)
+KERNEL_PRE(k_cmp_s, unsigned, 3u, "s_mov_b64 s[20:21], 0", OP_CMP64_S)
+KERNEL_PRE(k_minu32, unsigned, 3u, "s_mov_b64 vcc, 0", OP_MINU32)
+KERNEL_PRE(k_mad_u32, unsigned, 3u, "s_mov_b64 vcc, 0", OP_MAD_U32)
+KERNEL_PRE(k_or3, unsigned, 3u, "s_mov_b64 vcc, 0", OP_OR3)
+KERNEL_PRE(k_lshladd, unsigned, 3u, "s_mov_b64 vcc, 0", OP_LSHLADD)
+KERNEL_PRE(k_bfe, unsigned, 3u, "s_mov_b64 vcc, 0", OP_BFE)
+KERNEL_PRE(k_readlane, unsigned, 3u, "s_mov_b32 s20, 0", OP_READLANE)
+KERNEL_PRE(k_writelane, unsigned, 3u, "s_mov_b32 s20, 7", OP_WRITELANE)
 KERNEL(k_fma64, double, 1.0000001, OP_FMA64)
 KERNEL(k_add64, double, 1.0000001, OP_ADD64)
 KERNEL(k_mul64, double, 1.0000001, OP_MUL64)
@@ -135,7 +183,7 @@ KERNEL(k_pkmul, double, 1.0000001, OP_PKMUL)
                          : "vcc", "v40", "v41", "v42", "v43", "s20", "s21", "scc", "memory");                             \
         const unsigned long long t1 = __builtin_readcyclecounter();                                                   \
         asm volatile("" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));                     \
-        if ((threadIdx.x & 63u) == 0u) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;                    \
+        if ((threadIdx.x & 63u) == 0u) { unsigned long long* o_ = out + 4 * (size_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); o_[0] = t0; o_[1] = t1; o_[2] = __builtin_amdgcn_s_getreg(63492); o_[3] = __builtin_amdgcn_s_getreg(63508); }                    \
     }
 KERNEL_MIX(k_mix_fma64_salu, OP_MIX_SALU)
 KERNEL_MIX(k_mix_fma64_2salu, OP_MIX_SALU2)
@@ -160,7 +208,7 @@ KERNEL_MIX(k_cvt_i32_f64, OP_CVT_I32_F64)
         for (int i = 0; i < kIters; ++i) asm volatile(DEP16(OP) : "+v"(a0) : "v"(x), "v"(y) : "vcc");                  \
         const unsigned long long t1 = __builtin_readcyclecounter();                                                   \
         asm volatile("" ::"v"(a0));                                                                                   \
-        if ((threadIdx.x & 63u) == 0u) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;                    \
+        if ((threadIdx.x & 63u) == 0u) { unsigned long long* o_ = out + 4 * (size_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); o_[0] = t0; o_[1] = t1; o_[2] = __builtin_amdgcn_s_getreg(63492); o_[3] = __builtin_amdgcn_s_getreg(63508); }                    \
     }
 KERNEL_DEP(k_dep_fma64, double, 1.0000001, OP_FMA64)
 KERNEL_DEP(k_dep_add64, double, 1.0000001, OP_ADD64)
@@ -186,7 +234,7 @@ int main() {
     const int cus = prop.multiProcessorCount;
     unsigned long long* d_out;
     const int max_waves = cus * 4 * 8;
-    CHECK(hipMalloc(&d_out, sizeof(unsigned long long) * max_waves));
+    CHECK(hipMalloc(&d_out, sizeof(unsigned long long) * 4 * max_waves));
     hipStream_t s;
     CHECK(hipStreamCreate(&s));
     hipEvent_t e0, e1;
@@ -214,6 +262,20 @@ int main() {
         ROW("v_cmp_lt_f32", "fp32", 16, 0, float, k_cmp32),
         ROW("v_rcp_f32", "trans32", 16, 0, float, k_rcp32),
         ROW("v_cndmask_b32", "b32", 16, 0, unsigned, k_cndmask),
+        ROW("v_cndmask_b32 (vcc set before the loop)", "b32", 16, 0, unsigned, k_cndmask_vccset),
+        ROW("v_cndmask_b32_e64 (sgpr-pair mask)", "b32", 16, 0, unsigned, k_cndmask_s),
+        ROW("v_cmp_lt_u32 vcc + v_cndmask_b32", "cmp+select", 32, 0, unsigned, k_cmp_cndmask),
+        ROW("v_cmp_lt_u32_e64 sgpr + v_cndmask_b32_e64", "cmp+select", 32, 0, unsigned, k_cmp_cndmask_s),
+        ROW("v_cmp_lt_u32 vcc + 2 v_cndmask_b32 (one mask, two selects: an fp64 select)", "cmp+2 selects", 48, 0, unsigned, k_cmp_2cnd),
+        ROW("v_cmp_lt_u32_e64 sgpr + 2 v_cndmask_b32_e64", "cmp+2 selects", 48, 0, unsigned, k_cmp_2cnd_s),
+        ROW("v_cmp_lt_u32_e64 sgpr", "int32", 16, 0, unsigned, k_cmp_s),
+        ROW("v_min_u32", "int32", 16, 0, unsigned, k_minu32),
+        ROW("v_mad_u32_u24", "int32", 16, 0, unsigned, k_mad_u32),
+        ROW("v_or3_b32", "int32", 16, 0, unsigned, k_or3),
+        ROW("v_lshl_add_u32", "int32", 16, 0, unsigned, k_lshladd),
+        ROW("v_bfe_u32", "int32", 16, 0, unsigned, k_bfe),
+        ROW("v_readlane_b32", "lane", 16, 0, unsigned, k_readlane),
+        ROW("v_writelane_b32", "lane", 16, 0, unsigned, k_writelane),
         ROW("v_mov_b32", "b32", 16, 0, unsigned, k_mov32),
         ROW("v_add_u32", "int32", 16, 0, unsigned, k_addu32),
         ROW("v_and_b32", "int32", 16, 0, unsigned, k_and32),
@@ -238,11 +300,10 @@ int main() {
     // clock ramp: half a second of fp64 FMAs
     for (int i = 0; i < 400; ++i) rows[0].launch(cus * 4, d_out, s);
     CHECK(hipStreamSynchronize(s));
-    printf("{\"device\": \"%s\", \"cus\": %d, \"clock_rate_khz\": %d, \"iters\": %d,\n \"what\": \"SIMD cycles per wave64 instruction = "
-           "median over waves of (s_memtime span) / (k * instructions per wave), k waves resident per SIMD; wall = the same from "
-           "HIP-event time of 20 back-to-back launches at the clock implied by the counter\",\n \"rows\": [\n",
+    printf("{\"device\": \"%s\", \"cus\": %d, \"clock_rate_khz\": %d, \"iters\": %d,\n \"what\": \"cycles_per_inst_simd = median over SIMDs of (last end - first start of the SIMD's waves, s_memtime) / (instructions its waves issued); "
+           "waves are assigned to SIMDs by HW_ID; simds_by_wave_count[i] = SIMDs that held i + 1 waves; launch_us = HIP-event time per launch\",\n \"rows\": [\n",
            prop.name, cus, prop.clockRate, kIters);
-    std::vector<unsigned long long> h(max_waves);
+    std::vector<unsigned long long> h(4 * (size_t)max_waves);
     bool first = true;
     for (const Row& r : rows) {
         for (int k : {1, 2, 4}) {
@@ -257,14 +318,37 @@ int main() {
             CHECK(hipGetLastError());
             float ms = 0;
             CHECK(hipEventElapsedTime(&ms, e0, e1));
-            CHECK(hipMemcpy(h.data(), d_out, sizeof(unsigned long long) * waves, hipMemcpyDeviceToHost));
-            std::sort(h.begin(), h.begin() + waves);
+            CHECK(hipMemcpy(h.data(), d_out, sizeof(unsigned long long) * 4 * waves, hipMemcpyDeviceToHost));
+            // per SIMD (XCC, SE, SH, CU, SIMD of HW_ID): instructions issued by its waves / (last end - first start)
+            std::map<unsigned long long, std::array<double, 4>> simd;   // first start, last end, waves, sum of wave spans
+            std::vector<double> per_wave;
             const double n_class = (double)kIters * r.per_block;
-            const double med = (double)h[waves / 2], lo = (double)h[0], hi = (double)h[waves - 1];
-            printf("%s  {\"inst\": \"%s\", \"class\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_inst_simd\": %.3f, "
-                   "\"cycles_per_inst_wave_min\": %.3f, \"cycles_per_inst_wave_max\": %.3f, \"other_insts_per_inst\": %.2f, "
-                   "\"launch_us\": %.2f}",
-                   first ? "" : ",\n", r.name.c_str(), r.klass.c_str(), k, med / (k * n_class), lo / n_class, hi / n_class,
+            for (int w = 0; w < waves; ++w) {
+                const unsigned long long t0 = h[4 * w], t1 = h[4 * w + 1], hw = h[4 * w + 2], xcc = h[4 * w + 3];
+                const unsigned long long key = (xcc << 32) | (hw & 0xfff0u);   // (drop the wave slot)
+                auto it = simd.find(key);
+                if (it == simd.end()) simd[key] = {(double)t0, (double)t1, 1.0, (double)(t1 - t0)};
+                else {
+                    it->second[0] = std::min(it->second[0], (double)t0);
+                    it->second[1] = std::max(it->second[1], (double)t1);
+                    it->second[2] += 1.0;
+                    it->second[3] += (double)(t1 - t0);
+                }
+                per_wave.push_back((double)(t1 - t0) / n_class);
+            }
+            std::vector<double> thr;
+            int hist[10] = {0};
+            for (auto& kv : simd) {
+                thr.push_back((kv.second[1] - kv.second[0]) / (kv.second[2] * n_class));
+                hist[std::min(9, (int)kv.second[2])]++;
+            }
+            std::sort(thr.begin(), thr.end());
+            std::sort(per_wave.begin(), per_wave.end());
+            printf("%s  {\"inst\": \"%s\", \"class\": \"%s\", \"waves_per_simd_target\": %d, \"cycles_per_inst_simd\": %.3f, "
+                   "\"cycles_per_inst_simd_min\": %.3f, \"cycles_per_inst_simd_max\": %.3f, \"cycles_per_inst_wave_median\": %.3f, "
+                   "\"simds\": %d, \"simds_by_wave_count\": [%d, %d, %d, %d, %d, %d, %d, %d, %d], \"other_insts_per_inst\": %.2f, \"launch_us\": %.2f}",
+                   first ? "" : ",\n", r.name.c_str(), r.klass.c_str(), k, thr[thr.size() / 2], thr.front(), thr.back(),
+                   per_wave[per_wave.size() / 2], (int)simd.size(), hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8], hist[9],
                    (double)r.extra / r.per_block, 1e3 * ms / reps);
             first = false;
         }

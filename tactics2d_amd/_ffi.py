@@ -96,6 +96,13 @@ SYMBOLS = {
     "t2d_debug_set_step_placement": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.c_int32]),
     "t2d_debug_step_occupancy": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "t2d_debug_chain_fault": (C.c_int, [_vp, C.c_int32]),
+    # the closed loop (measurement / test helpers)
+    "t2d_debug_feedback_policy": (C.c_int, [_vp, _vp, C.c_float, C.c_float, C.c_float, _vp]),
+    "t2d_debug_closed_loop_create": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "t2d_debug_closed_loop_run": (C.c_int, [_vp, C.c_int32]),
+    "t2d_debug_closed_loop_destroy": (C.c_int, [_vp]),
+    "t2d_debug_stream_create": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "t2d_debug_stream_destroy": (C.c_int, [_vp]),
 }
 
 _lib = None

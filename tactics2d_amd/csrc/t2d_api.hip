@@ -726,6 +726,7 @@ __global__ __launch_bounds__(256) void chain_rollback_kernel(PoolView pv, const 
     }
 }
 }  // namespace
+void pool_touch(t2d_pool* p, hipStream_t s) { touch(p, s); }
 hipError_t launch_chain_rollback(const PoolView& v, const uint32_t* ckpt, hipStream_t s) {
     hipLaunchKernelGGL(chain_rollback_kernel, dim3((v.N + 255) / 256), dim3(256), 0, s, v, ckpt);
     return hipGetLastError();
@@ -927,6 +928,10 @@ int t2d_set_param_table(t2d_pool* p, const double* rows, int32_t n_types, int32_
         const double L = r[T2D_P_LENGTH], W = r[T2D_P_WIDTH];
         const double br = (int)r[T2D_P_SHAPE] == T2D_SHAPE_CIRCLE ? 0.5 * W : 0.5 * sqrt(L * L + W * W);
         t[(size_t)T2D_P_RESERVED0 * T2D_MAX_TYPES + ty] = br;  // bounding radius for the reject test
+        if (model != T2D_MODEL_DRIFT) {   // the two derived columns (include/t2d.h): the sub-step in seconds now, its counts per launch interval
+            t[(size_t)T2D_P_DT_S * T2D_MAX_TYPES + ty] = (double)dt / 1000;
+            t[(size_t)T2D_P_SUBSTEPS * T2D_MAX_TYPES + ty] = 0.0;
+        }
         dmax = std::max(dmax, 2.0 * br);
     }
     p->v.n_types = n_types;
@@ -936,7 +941,9 @@ int t2d_set_param_table(t2d_pool* p, const double* rows, int32_t n_types, int32_
         if ((int)p->host_params[ty][T2D_P_SHAPE] != T2D_SHAPE_OBB) p->all_boxes = false;
     p->v.cell = dmax * 1.001 + 1e-3;  // 3x3 cell neighbourhood is then provably sufficient
     p->v.inv_cell = 1.0 / p->v.cell;
+    T2D_HIP(p, quiesce(p));
     T2D_HIP(p, hipMemcpy(p->d_params, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+    p->derived_interval = -1;
     p->have_params = true;
     return T2D_OK;
 }
@@ -1211,6 +1218,19 @@ static int idm_impl(t2d_pool* p, hipStream_t s, const int32_t* forced_leader = n
     return record_event(p, 4, s, false);
 }
 
+// what a stepping launch needs of its interval beside the integer: interval_ms / 1000 (PointMass's dt) in the view, and the
+// sub-step counts per type in the device table (one 32-thread launch on the step's stream whenever the interval changes)
+static int prepare_interval(t2d_pool* p, int interval_ms, hipStream_t s) {
+    if (interval_ms > T2D_MAX_INTERVAL_MS) return fail(p, T2D_ERR_INVALID, "interval_ms must be <= 32767");
+    p->v.interval_s = (double)interval_ms / 1000;
+    if (p->derived_interval != interval_ms) {
+        touch(p, s);
+        T2D_HIP(p, t2d::launch_derive(p->d_params, p->v.n_types, interval_ms, s));
+        p->derived_interval = interval_ms;
+    }
+    return T2D_OK;
+}
+
 int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     if (!p) return T2D_ERR_INVALID;
     if (!p->have_params || !p->have_reset)
@@ -1219,6 +1239,7 @@ int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     hipStream_t s = (hipStream_t)hip_stream;
     int rc;
     touch(p, s);
+    if ((rc = prepare_interval(p, interval_ms, s))) return rc;
     if (p->idm_on && (rc = idm_impl(p, s))) return rc;
     if (p->has_drift && (rc = drift_impl(p, interval_ms, s))) return rc;
     if ((rc = record_event(p, 0, s, true))) return rc;
@@ -1274,7 +1295,10 @@ static int collide_impl(t2d_pool* p, bool with_status, int interval_ms, hipStrea
     else {
         t2d::PoolView v = p->v;
         const bool idm_fused = fuse_variant >= 0 && idm_in_step(p);
-        v.split_step = fuse_variant >= 0 && !idm_fused && use_split(p);
+        // (one workgroup per env fills the GPU with a quarter of the envs: for a pool that has the GPU to itself, not for env
+        // groups whose launches are meant to overlap -- round 4: a group of 1024 envs took every workgroup slot and the groups
+        // ran one after the other, 44 us per step of 4 groups)
+        v.split_step = fuse_variant >= 0 && !idm_fused && !p->v.overlapped && use_split(p);
         if (idm_fused) fill_idm(v, p);
         T2D_HIP(p, t2d::launch_collide(v, p->status_cfg, with_status, interval_ms, fuse_variant, s));
     }
@@ -1350,6 +1374,7 @@ int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
         return fail(p, T2D_ERR_STATE, "t2d_set_param_table and t2d_reset must precede t2d_step");
     if (interval_ms <= 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be positive");
     int rc;
+    if ((rc = prepare_interval(p, interval_ms, (hipStream_t)hip_stream))) return rc;
     if ((rc = claim_record_slot(p, (hipStream_t)hip_stream))) return rc;
     // (installed IDM controllers: a launch of their own ahead of the step -- or, idm_in_step, the front of the step launch)
     if (p->idm_on && !idm_in_step(p) && (rc = idm_impl(p, (hipStream_t)hip_stream))) return rc;
@@ -1389,6 +1414,7 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
         return rc;
     }
     touch(p, s);
+    if ((rc = prepare_interval(p, interval_ms, s))) return rc;
     for (int done = 0; done < n_steps && rc == T2D_OK;) {
         // one launch covers at most a ring of record slots (and a gather that still reads any of them is waited for first)
         const int n = std::min(n_steps - done, (int)T2D_RECORD_RING);

@@ -64,7 +64,8 @@ using namespace geom;
 
 // -DT2D_PROBE_SKIP=<bits>: measurement builds that leave a phase out (the flags are then wrong; instruction counts and
 // timings of such a build against the full one say what the phase costs): 1 pair stage, 2 pair narrow phase only,
-// 4 static polygons, 8 lane polygons, 16 off-lane stage 2 only, 32 pair broad phase only (every pair a candidate: never use)
+// 4 static polygons, 8 lane polygons, 16 off-lane stage 2 only, 32 pair broad phase only (every pair a candidate: never use),
+// 64 the fused integrator (the state stays what it was)
 #ifndef T2D_PROBE_SKIP
 #define T2D_PROBE_SKIP 0
 #endif
@@ -383,7 +384,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     __shared__ unsigned char s_type[kBlock];  // type id: the radius (circle) / bounding radius (OBB) is read from the table
     // type table in LDS, [column][type]: all columns up to the bounding radius when fused, else only
     // the 4 shape columns (length, width, shape, bounding radius)
-    constexpr int kTabCols = T2D_P_RESERVED0 + 1;
+    constexpr int kTabCols = T2D_PARAM_COLS;   // (all of them: the last two carry the sub-step and its counts, T2D_P_DT_S / T2D_P_SUBSTEPS)
     __shared__ double s_partab[FUSE >= 0 ? kTabCols * T2D_MAX_TYPES : 4 * T2D_MAX_TYPES];
     __shared__ signed char s_kind[kBlock];  // T2D_SHAPE_* or -1 = inactive
     // event bits OR-ed by the narrow phases (T2D_FLAG_*), and above them (<< kLaneShift) the off-lane evidence of
@@ -677,7 +678,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                         const bool pm = model == T2D_MODEL_POINTMASS;
                         const integ::StepOut o = integ::step_participant<(FUSE > 0 ? 1 : 0)>(
                             model, P, (double)x, (double)y, (double)h, (double)v, pm ? (double)vx : 0.0, pm ? (double)vy : 0.0,
-                            (double)a0, (double)a1, interval_ms);
+                            (double)a0, (double)a1, interval_ms, ia->interval_s);
                         nx = (float)o.x; ny = (float)o.y; nh = (float)o.heading; nv = (float)o.speed;
                         moved = true;
                         has_vel = o.has_velocity;
@@ -825,7 +826,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     if (FUSE >= 0 && stage_tables) {  // full parameter table -> LDS, loads issued together (one exposed latency)
         constexpr int kTab = kTabCols * T2D_MAX_TYPES;
         if (nthreads == kBlock) {   // the usual launch shape: 3 x 8 B per thread, no per-load bounds logic
-            static_assert(kTab <= 3 * kBlock && kTab > 2 * kBlock, "staging below assumes 2 full rounds + a partial one");
+            static_assert(kTab <= 3 * kBlock && kTab > 2 * kBlock, "staging below assumes 2 full rounds + a (possibly full) third one");
             const double t0 = a_params[ptid], t1 = a_params[ptid + kBlock];
             const double t2 = ptid + 2 * kBlock < kTab ? a_params[ptid + 2 * kBlock] : 0.0;
             s_partab[ptid] = t0;
@@ -965,7 +966,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
         if (log2A <= 6) wave_sync(); else __syncthreads();   // (the planes are the pose phase's from here on)
     }
     // (SingleTrackDrift lanes were integrated by drift_kernel, launched before this one)
-    if (!PIPE && FUSE >= 0 && active && ((ids >> kIdsModelShift) & 0xff) != T2D_MODEL_DRIFT && (!SPLIT || role == 0)) {
+    if (!PIPE && FUSE >= 0 && active && ((ids >> kIdsModelShift) & 0xff) != T2D_MODEL_DRIFT && (!SPLIT || role == 0) && !(T2D_PROBE_SKIP & 64)) {
         // ---------------- fused physics: one PhysicsModelBase.step in registers ----------------
         const int model = (ids >> kIdsModelShift) & 0xff;
         auto P = [&](int col) -> double { return s_partab[col * T2D_MAX_TYPES + type]; };
@@ -992,7 +993,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
             }
         }
         const integ::StepOut o = integ::step_participant<(FUSE > 0 ? 1 : 0)>(
-            model, P, (double)fx, (double)fy, (double)fh, (double)fv, pvx, pvy, (double)fa0, (double)fa1, interval_ms);
+            model, P, (double)fx, (double)fy, (double)fh, (double)fv, pvx, pvy, (double)fa0, (double)fa1, interval_ms, pv.interval_s);
         fx = (float)o.x;
         fy = (float)o.y;
         fh = (float)o.heading;
@@ -1055,23 +1056,25 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
             double s, c;
             sincos_det((double)fh, s, c);
             const double hl = 0.5 * L, hw = 0.5 * W;
-            const double lx[4] = {hl, hl, -hl, -hl};
-            const double ly[4] = {-hw, hw, hw, -hw};
-            double ax[4], ay[4];
+            // The oracle's vertex k is  c * lx[k] - s * ly[k] + cx,  s * lx[k] + c * ly[k] + cy  with (lx, ly) = (hl, -hw),
+            // (hl, hw), (-hl, hw), (-hl, -hw).  Rounding is symmetric in sign, so its eight products are +-(c hl), +-(s hw),
+            // +-(s hl), +-(c hw) and its eight first sums +-u, +-w, +-p, +-q below: the same sixteen results from half the
+            // operations.  The pose box likewise: fl(cx + t) is monotonic in t, so the smallest of the four x is
+            // fl(cx - max(|u|, |w|)), bit for bit the minimum the comparisons found.
+            const double chl = c * hl, shw = s * hw, shl = s * hl, chw = c * hw;
+            const double u = chl + shw, w = chl - shw;      // vertex 0 / 1 minus the centre, x
+            const double pp = shl - chw, qq = shl + chw;    // ... y
+            const double ax[4] = {u + cx, w + cx, cx - u, cx - w};
+            const double ay[4] = {pp + cy, qq + cy, cy - pp, cy - qq};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                ax[k] = c * lx[k] - s * ly[k] + cx;
-                ay[k] = s * lx[k] + c * ly[k] + cy;
                 s_v[2 * k][tid] = ax[k];
                 s_v[2 * k + 1][tid] = ay[k];
             }
-            lo_x = hi_x = ax[0];
-            lo_y = hi_y = ay[0];
-#pragma unroll
-            for (int k = 1; k < 4; ++k) {
-                lo_x = ax[k] < lo_x ? ax[k] : lo_x; hi_x = ax[k] > hi_x ? ax[k] : hi_x;
-                lo_y = ay[k] < lo_y ? ay[k] : lo_y; hi_y = ay[k] > hi_y ? ay[k] : hi_y;
-            }
+            const double mx = __builtin_fmax(__builtin_fabs(u), __builtin_fabs(w));
+            const double my = __builtin_fmax(__builtin_fabs(pp), __builtin_fabs(qq));
+            lo_x = cx - mx; hi_x = cx + mx;
+            lo_y = cy - my; hi_y = cy + my;
             // OutBound.update: not boundary.contains(pose); touching from inside is contained
             if (has_boundary)
                 out = lo_x < (double)bxmin || hi_x > (double)bxmax || lo_y < (double)bymin || hi_y > (double)bymax;
@@ -1095,11 +1098,16 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
         // lane stages below never see it.  A certificate, not an approximation: poses it does not cover take the exact path.
         if (gl.has[1]) {
             const float4* sr = reinterpret_cast<const float4*>(s_geo + gl.off_safe) + env_local * kSafeRects;
+            // box inside rectangle: max(xmin - lo_x, hi_x - xmax, ymin - lo_y, hi_y - ymax) <= 0, two packed additions
+            // with the box's (-lo, hi) pairs, a max3 and a max per rectangle (the form of the box sweeps below)
+            typedef float f2s __attribute__((ext_vector_type(2)));
+            const f2s cxp = {-box_lo_x, box_hi_x}, cyp = {-box_lo_y, box_hi_y};
 #pragma unroll
             for (int k = 0; k < kSafeRects; ++k) {
                 const float4 r = sr[k];
-                const float m = __builtin_fmaxf(__builtin_fmaxf(r.x - box_lo_x, box_hi_x - r.y),
-                                                __builtin_fmaxf(r.z - box_lo_y, box_hi_y - r.w));
+                const f2s tx = {r.x, -r.y}, ty = {r.z, -r.w};
+                const f2s dx = tx + cxp, dy = ty + cyp;
+                const float m = __builtin_fmaxf(__builtin_fmaxf(dx.x, dx.y), __builtin_fmaxf(dy.x, dy.y));
                 lane_safe |= m <= 0.0f;
             }
         }

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(PIPE ? 2 * kEgoBlock : kEgoBlock, 2) void ego_step_
                         const bool pm = model == T2D_MODEL_POINTMASS;
                         const integ::StepOut o = integ::step_participant<VARIANT>(model, P, (double)x, (double)y, (double)h, (double)v,
                                                                                   pm ? (double)vx : 0.0, pm ? (double)vy : 0.0,
-                                                                                  (double)a0, (double)a1, interval_ms);
+                                                                                  (double)a0, (double)a1, interval_ms, ia->interval_s);
                         nx = (float)o.x; ny = (float)o.y; nh = (float)o.heading; nv = (float)o.speed;
                         moved = true;
                         has_vel = o.has_velocity;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(PIPE ? 2 * kEgoBlock : kEgoBlock, 2) void ego_step_
             pvy = (double)ld_state<LOOP>(G(pv.vy) + idx);
         }
         const integ::StepOut o = integ::step_participant<VARIANT>(model, P, (double)fx, (double)fy, (double)fh, (double)fv, pvx,
-                                                                  pvy, (double)fa0, (double)fa1, interval_ms);
+                                                                  pvy, (double)fa0, (double)fa1, interval_ms, pv.interval_s);
         fx = (float)o.x;
         fy = (float)o.y;
         fh = (float)o.heading;

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(PoolView pv, int inte
                                    (double)fa1, interval_ms);
     } else {
         o = step_pointmass(P, (double)fx, (double)fy, (double)pv.vx[i], (double)pv.vy[i],
-                           (double)fa0, (double)fa1, interval_ms);
+                           (double)fa0, (double)fa1, pv.interval_s);
     }
     pv.x[i] = (float)o.x;
     pv.y[i] = (float)o.y;
@@ -159,6 +159,23 @@ hipError_t launch_verify(const PoolView& v, const float* x, const float* y, cons
                          int interval_ms, uint8_t* valid, hipStream_t s) {
     VerifyArgs a{x, y, heading, speed, valid, interval_ms};
     hipLaunchKernelGGL(verify_kernel, dim3((v.N + kBlock - 1) / kBlock), dim3(kBlock), 0, s, v, a);
+    return hipGetLastError();
+}
+
+// Column T2D_P_SUBSTEPS of the device table: (interval // delta_t) << 16 | interval % delta_t per type, for the interval of the
+// launches that follow on this stream (t2d_api.hip launches it when the interval changes; rows of the drift model own the
+// column).  The integrators read it instead of dividing per lane.
+namespace {
+__global__ void derive_kernel(double* params, int n_types, int interval_ms) {
+    const int t = threadIdx.x;
+    if (t >= n_types || (int)params[T2D_P_MODEL * T2D_MAX_TYPES + t] == T2D_MODEL_DRIFT) return;
+    const int delta_t = (int)params[T2D_P_DELTA_T_MS * T2D_MAX_TYPES + t];
+    const int n = interval_ms / delta_t, rem = interval_ms - n * delta_t;
+    params[T2D_P_SUBSTEPS * T2D_MAX_TYPES + t] = (double)(n * 65536 + rem);
+}
+}  // namespace
+hipError_t launch_derive(double* params, int n_types, int interval_ms, hipStream_t s) {
+    hipLaunchKernelGGL(derive_kernel, dim3(1), dim3(T2D_MAX_TYPES), 0, s, params, n_types, interval_ms);
     return hipGetLastError();
 }
 

@@ -101,10 +101,13 @@ T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, 
     const bool clip_v = flags & T2D_RANGE_SPEED;
     const double vlo = P(T2D_P_SPEED_LO), vhi = P(T2D_P_SPEED_HI);
     const double lr = P(T2D_P_LR), wb = P(T2D_P_WB);
-    const int delta_t = (int)P(T2D_P_DELTA_T_MS);
-    const double dt = (double)delta_t / 1000;
-    const int n_steps = interval / delta_t;
-    const int rem = interval - n_steps * delta_t;
+    // the sub-step (double)delta_t / 1000 and the counts interval // delta_t, interval % delta_t depend on the TYPE and the
+    // launch only: the host keeps them in two columns of the table (t2d_api.hip derive_kernel) -- per lane they were a
+    // 32-bit integer division and an IEEE fp64 division, ~50 instructions per wave and step
+    const double dt = P(T2D_P_DT_S);
+    const int sub = (int)P(T2D_P_SUBSTEPS);
+    const int n_steps = sub >> 16;
+    const int rem = sub & 0xffff;
     const int total = n_steps + (rem > 0 ? 1 : 0);
     double ovx, ovy;  // (all StepOut fields are assembled in ONE place per model: stores into a
                       // struct from several branches get sunk into pointer-phis and cost scratch)
@@ -132,15 +135,13 @@ T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, 
         ovx = v * cp;
         ovy = v * sp;
     } else {
-        double sd, cd;
-        sincos_det_steer(delta, sd, cd);
+        double sd, cd, sp, cp;
+        sincos_det_steer_and(delta, phi, sd, cd, sp, cp);
         const double tw = sd * rcp_nr(cd * wb);  // tan(delta) / wb
         const double t = lr * tw;                // tan(beta)
         // cos(beta) = 1/sqrt(1+t^2), sin(beta) = t*cos(beta): no atan needed
         const double cb = rsq_nr(__builtin_fma(t, t, 1.0));
         const double sb = t * cb;
-        double sp, cp;
-        sincos_det(phi, sp, cp);
         double c = cp * cb - sp * sb;  // cos(phi + beta)
         double s = sp * cb + cp * sb;
         const double kk = tw * cb;  // d(phi)/dt = v * kk
@@ -292,9 +293,8 @@ T2D_DEV StepOut step_dynamics(PF P, double x, double y, double phi, double v, do
     const double lf = P(T2D_P_LF), lr = P(T2D_P_LR), wb = P(T2D_P_WB);
     const double mass = P(T2D_P_MASS), hcg = P(T2D_P_MASS_HEIGHT), mu = P(T2D_P_MU);
     const double Iz = P(T2D_P_IZ), cf = P(T2D_P_CF), cr = P(T2D_P_CR);
-    const int delta_t = (int)P(T2D_P_DELTA_T_MS);
-    const double dt = (double)delta_t / 1000;
-    const int n_steps = interval / delta_t;  // the remainder is never integrated (:143)
+    const double dt = P(T2D_P_DT_S);                      // (double)delta_t / 1000, per type (see step_kinematics)
+    const int n_steps = (int)P(T2D_P_SUBSTEPS) >> 16;     // interval // delta_t; the remainder is never integrated (:143)
 
     // the exact variant keeps the reference's IEEE divisions; the fast one multiplies by Newton reciprocals of the
     // per-type constants (wb, lf, Iz) -- ~1e-16 relative, far inside the contract wherever the model is well conditioned
@@ -445,10 +445,9 @@ T2D_DEV StepOut step_dynamics(PF P, double x, double y, double phi, double v, do
 
 template <typename PF>
 T2D_DEV StepOut step_pointmass(PF P, double x, double y, double vx, double vy, double ax,
-                               double ay, int interval) {
+                               double ay, double dt /* (double)interval_ms / 1000, divided once by the host */) {
     int flags = (int)P(T2D_P_RANGE_FLAGS);
     const double lo = P(T2D_P_SPEED_LO), hi = P(T2D_P_SPEED_HI);
-    const double dt = (double)interval / 1000;
     double nvx = vx + ax * dt;
     double nvy = vy + ay * dt;
     double ns = __builtin_sqrt(nvx * nvx + nvy * nvy);
@@ -487,10 +486,10 @@ T2D_DEV StepOut step_pointmass(PF P, double x, double y, double vx, double vy, d
 // one PhysicsModelBase.step for the participant held in registers
 template <int VARIANT, typename PF>
 T2D_DEV StepOut step_participant(int model, PF P, double x, double y, double heading, double speed, double vx,
-                                 double vy, double a0, double a1, int interval_ms) {
+                                 double vy, double a0, double a1, int interval_ms, double interval_s) {
     if (model == T2D_MODEL_KINEMATICS) return step_kinematics<VARIANT>(P, x, y, heading, speed, a0, a1, interval_ms);
     if (model == T2D_MODEL_DYNAMICS) return step_dynamics<VARIANT>(P, x, y, heading, speed, a0, a1, interval_ms);
-    return step_pointmass(P, x, y, vx, vy, a0, a1, interval_ms);
+    return step_pointmass(P, x, y, vx, vy, a0, a1, interval_s);
 }
 
 }  // namespace integ

@@ -91,8 +91,11 @@ T2D_DEV void sincos_det(double x, double& s_out, double& c_out) {
     pc = __builtin_fma(pc, z, 4.16666666666666019037e-02);
 #endif
     double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
-    long long q = (long long)k;
-    int quad = (int)(q & 3);
+    // the quadrant = k mod 4: through the one-instruction 32-bit conversion when every lane's quotient fits (|x| < 3e9:
+    // always, short of an integrator that has blown up), the 64-bit one -- four instructions -- otherwise; same bits
+    int quad;
+    if (__ballot(!(__builtin_fabs(k) < 2147483000.0)) == 0ull) quad = (int)k & 3;
+    else quad = (int)((long long)k & 3);
     double s = (quad & 1) ? cr : sr;
     double c = (quad & 1) ? sr : cr;
     s_out = (quad & 2) ? -s : s;
@@ -139,6 +142,68 @@ T2D_DEV void sincos_det_small(double r, double& s_out, double& c_out) {
 T2D_DEV void sincos_det_steer(double x, double& s_out, double& c_out) {
     if (__ballot(!(__builtin_fabs(x) <= 0.78)) == 0ull) sincos_det_small(x, s_out, c_out);
     else sincos_det(x, s_out, c_out);
+}
+
+// sincos_det of TWO angles in one pass -- the steering angle (small in every lane: see sincos_det_steer; else the general
+// reduction) and the heading: the two polynomial evaluations interleaved, so that each table constant is an operand of both
+// while it sits in its scalar register.  Evaluated one after the other the compiler parks the sixteen constants in vector
+// registers between the two calls: sixteen 64-bit moves per wave and call site.  Same operations per angle, same bits.
+T2D_DEV void sincos_det_steer_and(double xa, double xb, double& sa_out, double& ca_out, double& sb_out, double& cb_out) {
+#ifdef T2D_TRIG_TABLE
+    const double* T = kSinCosTab;
+    const double t0 = T[0], t1 = T[1], t2 = T[2], t3 = T[3], p0 = T[4], p1 = T[5], p2 = T[6], p3 = T[7], p4 = T[8], p5 = T[9],
+                 q0 = T[10], q1 = T[11], q2 = T[12], q3 = T[13], q4 = T[14], q5 = T[15];
+#else
+    const double t0 = kTwoOverPi, t1 = kPio2Hi, t2 = kPio2Mid, t3 = kPio2Lo;
+    const double p0 = 1.58969099521155010221e-10, p1 = -2.50507602534068634195e-08, p2 = 2.75573137070700676789e-06,
+                 p3 = -1.98412698298579493134e-04, p4 = 8.33333333332248946124e-03, p5 = -1.66666666666666324348e-01;
+    const double q0 = -1.13596475577881948265e-11, q1 = 2.08757232129817482790e-09, q2 = -2.75573143513906633035e-07,
+                 q3 = 2.48015872894767294178e-05, q4 = -1.38888888888741095749e-03, q5 = 4.16666666666666019037e-02;
+#endif
+    const bool small_a = __ballot(!(__builtin_fabs(xa) <= 0.78)) == 0ull;   // wave-uniform
+    double ka = 0.0, ra = xa;
+    if (!small_a) {
+        ka = __builtin_rint(xa * t0);
+        ra = __builtin_fma(-ka, t1, xa);
+        ra = __builtin_fma(-ka, t2, ra);
+        ra = __builtin_fma(-ka, t3, ra);
+    }
+    const double kb = __builtin_rint(xb * t0);
+    double rb = __builtin_fma(-kb, t1, xb);
+    rb = __builtin_fma(-kb, t2, rb);
+    rb = __builtin_fma(-kb, t3, rb);
+    const double za = ra * ra, zb = rb * rb;
+    double psa = p0, psb = p0;
+    psa = __builtin_fma(psa, za, p1); psb = __builtin_fma(psb, zb, p1);
+    psa = __builtin_fma(psa, za, p2); psb = __builtin_fma(psb, zb, p2);
+    psa = __builtin_fma(psa, za, p3); psb = __builtin_fma(psb, zb, p3);
+    psa = __builtin_fma(psa, za, p4); psb = __builtin_fma(psb, zb, p4);
+    psa = __builtin_fma(psa, za, p5); psb = __builtin_fma(psb, zb, p5);
+    const double sra = __builtin_fma(ra * za, psa, ra), srb = __builtin_fma(rb * zb, psb, rb);
+    double pca = q0, pcb = q0;
+    pca = __builtin_fma(pca, za, q1); pcb = __builtin_fma(pcb, zb, q1);
+    pca = __builtin_fma(pca, za, q2); pcb = __builtin_fma(pcb, zb, q2);
+    pca = __builtin_fma(pca, za, q3); pcb = __builtin_fma(pcb, zb, q3);
+    pca = __builtin_fma(pca, za, q4); pcb = __builtin_fma(pcb, zb, q4);
+    pca = __builtin_fma(pca, za, q5); pcb = __builtin_fma(pcb, zb, q5);
+    const double cra = __builtin_fma(za * za, pca, __builtin_fma(-0.5, za, 1.0));
+    const double crb = __builtin_fma(zb * zb, pcb, __builtin_fma(-0.5, zb, 1.0));
+    auto finish = [](double k, double sr, double cr, double& s_out, double& c_out) {
+        int quad;
+        if (__ballot(!(__builtin_fabs(k) < 2147483000.0)) == 0ull) quad = (int)k & 3;
+        else quad = (int)((long long)k & 3);
+        const double s = (quad & 1) ? cr : sr;
+        const double c = (quad & 1) ? sr : cr;
+        s_out = (quad & 2) ? -s : s;
+        c_out = ((quad + 1) & 2) ? -c : c;
+    };
+    if (small_a) {   // (quotient 0: the kernels alone are sincos_det's result)
+        sa_out = sra;
+        ca_out = cra;
+    } else {
+        finish(ka, sra, cra, sa_out, ca_out);
+    }
+    finish(kb, srb, crb, sb_out, cb_out);
 }
 
 T2D_DEV double tan_det(double x) {

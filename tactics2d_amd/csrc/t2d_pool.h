@@ -122,6 +122,7 @@ struct PoolView {
     int32_t* idm_leader;
     float *idm_act0_own, *idm_act1_own;
     int32_t idm_n_ctrl;
+    double interval_s;        // (double)interval_ms / 1000 of this launch (PointMass's dt), divided once by the host
     unsigned long long* dbg;  // phase cycle accumulators (profiling builds with -DT2D_TIMING only)
     double cell;      // spatial-hash cell edge (m) >= max circum-diameter * 1.001
     double inv_cell;
@@ -250,6 +251,7 @@ struct t2d_pool {
     bool scene_refill_pending = false;
     int32_t* d_lidar_cnt = nullptr;
     long long step_count = 0;  // t2d_step calls so far (selects the record ring slot)
+    int derived_interval = -1; // the interval_ms column T2D_P_SUBSTEPS of the device table was derived for (-1: none yet)
     // chained multi-step launches (t2d_step_n): per-workgroup step counters + one error word behind them
     unsigned long long* d_chain = nullptr;   // chain_slots words, then the error word
     int chain_slots = 0;
@@ -299,6 +301,8 @@ struct t2d_pool {
 // kernel launchers (defined in t2d_integrate.hip / t2d_collide.hip)
 namespace t2d {
 hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hipStream_t s);
+// column T2D_P_SUBSTEPS of the device table for `interval_ms` (rows of the drift model keep their own column 23)
+hipError_t launch_derive(double* params, int n_types, int interval_ms, hipStream_t s);
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
                           int interval_ms, int fuse_variant, hipStream_t s);
 // n_steps fused steps in one launch (v.chain_* set by the caller); see PoolView::chain_done
@@ -315,6 +319,8 @@ hipError_t launch_idm(const PoolView& v, const IdmView& iv, const int32_t* force
 hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
                           hipStream_t s);
 hipError_t launch_spin(long long ticks_100mhz, hipStream_t s);
+// note that work of this pool was enqueued on `s` by code outside t2d_api.hip (a replayed graph): t2d_sync waits for it
+void pool_touch(t2d_pool* p, hipStream_t s);
 bool split_eligible(const PoolView& v, const t2d_status_config& cfg, int log2A, int device_cus);
 hipError_t launch_parking_scenes(const PoolView& v, const SceneView& sv, int n_env, int mode, hipStream_t s);
 hipError_t launch_scene_refill(const SceneView& sv, int n_env, hipStream_t s);

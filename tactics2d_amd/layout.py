@@ -11,6 +11,8 @@ MAX_TYPES = 32
 RANGE_STEER, RANGE_SPEED, RANGE_ACCEL = 1, 2, 4
 MODEL_KINEMATICS, MODEL_DYNAMICS, MODEL_POINTMASS, MODEL_DRIFT = 0, 1, 2, 3
 P_DRIFT_TSB, P_DRIFT_TSE, P_DRIFT_RADIUS, P_DRIFT_IYW = 15, 16, 22, 23   # SingleTrackDrift rows only
+P_DT_S, P_SUBSTEPS = 22, 23   # rows of the other models: derived by the library (sub-step in s, sub-step counts of the launch)
+MAX_INTERVAL_MS = 32767
 SHAPE_OBB, SHAPE_CIRCLE = 0, 1
 # fields
 F_X, F_Y, F_HEADING, F_SPEED, F_VX, F_VY, F_ACT0, F_ACT1, F_IDS, F_FLAGS = range(10)

@@ -123,6 +123,80 @@ def test_gpu_drift_inside_step_with_other_models_and_auto_reset(oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_idm_controlled_drift_participants_keep_the_documented_order(oracle):
+    """IDM controllers on SingleTrackDrift participants (and a drift leader ahead of a kinematic follower): t2d_step's order is
+    IDM, then drift, then the fused step.  Round 3 moved the controllers into the front of the step launch -- BEHIND
+    drift_kernel, which then integrated the controlled drift lanes with the previous step's acceleration (0 on the first
+    step) and showed followers a leader already advanced to t + 1 (round-3 advisor, high).  Drift pools keep idm_kernel a
+    launch of its own; held here against the oracle (idm -> drift) and against t2d_set_step_chaining(0), t2d_step and
+    t2d_step_n alike, three steps so that a stale action could not hide."""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.controller import IDMController, install
+    from tactics2d_amd.pool import ParticipantPool
+    g = H.load_npz("drift.npz")
+    kin = np.zeros(L.PARAM_COLS); kin[[L.P_LF, L.P_LR, L.P_WB, L.P_DELTA_T_MS, L.P_LENGTH, L.P_WIDTH]] = 1.2, 1.3, 2.5, 5, 4.5, 1.8
+    rows = np.stack([kin, g["rows"][0]])
+    n_env, A = 24, 4
+    n = n_env * A
+    rng = np.random.default_rng(11)
+    tid = np.tile([0, 1, 1, 0], n_env).astype(np.uint8)     # kin ego, drift follower, drift leader, kin vehicle far ahead
+    x = np.float32(np.tile([0, 14, 30, 60], n_env) + rng.normal(0, 0.2, n)); y = np.float32(rng.normal(0, 0.05, n))
+    h = np.float32(rng.normal(0, 0.01, n) % (2 * np.pi)); v = np.float32(rng.uniform(6, 14, n))
+    om = np.float32(v / 0.344)
+    a0 = np.float32(rng.uniform(-1, 1, n)); a1 = np.float32(rng.normal(0, 0.02, n))
+    ctrl = IDMController(desired_speed=20.0, horizon=80.0)
+    cid = np.full(n, L.IDM_NONE, np.uint8)
+    cid[np.arange(n) % A == 1] = 0      # the drift follower of every env is IDM-controlled (leader: the drift vehicle ahead)
+    cid[np.arange(n) % A == 0] = 0      # ... and so is the kinematic ego (leader: the drift follower)
+    outs = {}
+    for mode in ("step", "step_unchained", "step_n"):
+        pool = ParticipantPool(n_env, A)
+        try:
+            pool.set_param_table(rows)
+            pool.set_status_config(max_step=100)
+            pool.reset(x, y, h, v, tid)
+            pool.upload(L.F_OMEGA_F, om); pool.upload(L.F_OMEGA_R, om)
+            pool.set_integrator_variant("exact")
+            install(pool, [ctrl], cid)
+            pool.set_actions(a0, a1)
+            if mode == "step_unchained":
+                pool.set_step_chaining(0)
+            if mode == "step_n":
+                pool.step_n(3, 100, 0)
+            else:
+                for _ in range(3):
+                    pool.step(100)
+            outs[mode] = [pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_OMEGA_F, L.F_OMEGA_R, L.F_ACT0,
+                                                     L.F_LEADER, L.F_FLAGS)]
+        finally:
+            pool.close()
+    for mode in ("step_unchained", "step_n"):
+        for a, b in zip(outs["step"], outs[mode]):
+            assert np.array_equal(a, b), mode
+    # the first step against the oracle: IDM on the start state, THEN the drift model with that acceleration
+    pool = ParticipantPool(n_env, A)
+    try:
+        pool.set_param_table(rows)
+        pool.reset(x, y, h, v, tid)
+        pool.upload(L.F_OMEGA_F, om); pool.upload(L.F_OMEGA_R, om)
+        pool.set_integrator_variant("exact")
+        install(pool, [ctrl], cid)
+        pool.set_actions(a0, a1)
+        pool.step(100)
+        got = np.stack([pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_OMEGA_F, L.F_OMEGA_R)], 1)
+        gacc, glead = pool.download(L.F_ACT0), pool.download(L.F_LEADER)
+    finally:
+        pool.close()
+    wa0, wa1, wlead = oracle.idm(np.stack([ctrl.row()]), cid, n_env, A, x, y, h, v, np.ones(n, np.uint8), a0, a1)
+    ctl = cid != L.IDM_NONE
+    assert np.array_equal(glead[ctl], wlead[ctl]) and np.array_equal(gacc[ctl], np.float32(wa0)[ctl])
+    assert (glead[np.arange(n) % A == 1] == 2).all() and (glead[np.arange(n) % A == 0] == 1).all()
+    dr = tid == 1
+    want = oracle.drift(rows, tid, np.stack([x, y, h, v, om, om], 1), np.stack([np.float32(wa0), np.float32(wa1)], 1), 100, trig=1)
+    assert np.array_equal(got[dr], np.float32(want[dr][:, :6]))
+
+
+@pytest.mark.gpu
 def test_gpu_mirror_class_runs_the_reference_rollout():
     from tactics2d_amd.physics import BatchedState, SingleTrackDrift
     g = H.load_npz("drift.npz")

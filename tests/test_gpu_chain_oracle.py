@@ -244,6 +244,7 @@ def test_a_broken_hand_off_is_reported_once_rolled_back_and_survived(kind, code)
 
     pool = fresh()
     pool.set_step_chaining(2)           # CHAIN form whatever the pool's size
+    pool.set_split_step(False)
     assert pool.step_form(6) == "chain"
 
     def frag(k0, n):
@@ -261,8 +262,12 @@ def test_a_broken_hand_off_is_reported_once_rolled_back_and_survived(kind, code)
     assert ei.value.code == _ffi.ERR_STATE and code in str(ei.value) and "rolled back to step 6" in str(ei.value), str(ei.value)
     pool.sync()                         # reported once
     assert pool.step_count() == 6
+    pm = sc.rows[sc.type_id, L.P_MODEL] == L.MODEL_POINTMASS
     for f, w in zip(fields, after6):
-        assert np.array_equal(pool.download(f), w, equal_nan=True), f
+        g = pool.download(f)
+        if f in (L.F_VX, L.F_VY):   # (state only for a point mass; the single-track models' vx / vy are outputs of the next step)
+            g, w = g[pm], w[pm]
+        assert np.array_equal(g, w, equal_nan=True), f
     assert pool.step_form(6) == "step"  # chaining is off for this pool now
     frag(6, 12)                         # ... so this is twelve plain launches
     got = [pool.download(f) for f in fields + (L.F_FLAGS, L.F_STATUS, L.F_REWARD)]
@@ -305,7 +310,7 @@ def test_a_pool_that_changes_its_chained_shape_restarts_the_counters():
     ref.close()
     pool = fresh(3)
     forms = []
-    for k0, chaining, split in ((0, 3, True), (6, 2, False), (12, 2, True), (18, 2, False)):
+    for k0, chaining, split in ((0, 3, False), (6, 2, False), (12, 2, True), (18, 2, False)):
         pool.set_step_chaining(chaining)
         pool.set_split_step(split)
         forms.append(pool.step_form(6))

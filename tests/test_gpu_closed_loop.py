@@ -1,0 +1,76 @@
+"""The closed loop on the device (t2d_loop.hip): per env group and step, a policy kernel that reads the state the previous
+step left behind -> t2d_step reading its [N, 2] action tensor in place, no host synchronisation -- the loop of the
+reference's callers (envs/parking.py:219-256 under `action = policy(obs)`).  Whatever the number of groups and whoever
+enqueues the launches (the calling thread, one host thread per group, replayed hipGraphs), every env must end where it ends
+when ONE pool holds all the envs and the host calls policy and t2d_step one after the other."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+STEPS = 70   # (more than the record ring, not a multiple of the graphs' 16 steps: replays + a remainder)
+
+
+def _fields():
+    from tactics2d_amd import layout as L
+    return (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_VX, L.F_VY, L.F_FLAGS, L.F_ENV_FLAGS, L.F_CNT_STEP, L.F_FRAME_MS,
+            L.F_STATUS, L.F_REWARD)
+
+
+def _reference(sc, steps):
+    """one pool, one stream, the host calling the policy and the step in turn"""
+    torch = pytest.importorskip("torch")
+    from tactics2d_amd.pool import ParticipantPool
+    dev = torch.device("cuda", 0)
+    pool = ParticipantPool(sc.n_env, sc.A)
+    sc.load(pool)
+    pool.set_integrator_variant("exact")
+    pool.set_auto_reset(True)
+    act = torch.zeros((sc.n, 2), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    pool.bind_actions(act.data_ptr() + 4, act.data_ptr(), 2)
+    for _ in range(steps):
+        pool._ck(pool._lib.t2d_debug_feedback_policy(pool._h, act.data_ptr(), 12.0, 0.5, 0.04, None))
+        pool.step(sc.interval_ms)
+    out = [pool.download(f) for f in _fields()]
+    pool.close()
+    return out
+
+
+@pytest.mark.parametrize("groups,launcher", [(1, "thread"), (2, "thread"), (4, "threads"), (8, "threads"), (4, "graph"), (1, "graph")])
+def test_closed_loop_of_env_groups_equals_one_pool_stepped_by_the_host(groups, launcher):
+    from tactics2d_amd import scenarios as S
+    from tactics2d_amd.pipeline import ClosedLoop, EnvGroups
+    sc = S.mixed(96, 64, seed=23)
+    want = _reference(sc, STEPS)
+    eg = EnvGroups(sc, groups)
+    eg.configure(lambda p: (p.set_integrator_variant("exact"), p.set_auto_reset(True)))
+    loop = ClosedLoop(eg, launcher, sc.interval_ms, graph_steps=16)
+    loop.run(STEPS // 2)
+    loop.run(STEPS - STEPS // 2)
+    got = [eg.download(f) for f in _fields()]
+    assert all(p.step_count() == STEPS for p in eg.pools)
+    loop.close()
+    eg.close()
+    for f, g, w in zip(_fields(), got, want):
+        assert np.array_equal(g, w, equal_nan=True), (f, int((g != w).sum()))
+    from tactics2d_amd import layout as L
+    st = want[_fields().index(L.F_STATUS)]
+    assert st[:, 2:].any() or want[_fields().index(L.F_CNT_STEP)].min() < STEPS, "no episode ended: auto-reset not exercised"
+
+
+def test_closed_loop_at_the_metric_size_runs_and_matches_a_single_pool_sample():
+    """4096 x 64 in 4 groups on 4 host threads, 24 steps: the first group's envs against a single pool holding just them"""
+    from tactics2d_amd import scenarios as S
+    from tactics2d_amd.pipeline import ClosedLoop, EnvGroups
+    sc = S.mixed(4096, 64, seed=3)
+    eg = EnvGroups(sc, 4)
+    eg.configure(lambda p: (p.set_integrator_variant("exact"), p.set_auto_reset(True)))
+    loop = ClosedLoop(eg, "threads", sc.interval_ms)
+    loop.run(24)
+    got = [eg.pools[0].download(f) for f in _fields()]
+    loop.close()
+    eg.close()
+    want = _reference(sc.shard(0, 1024), 24)
+    for f, g, w in zip(_fields(), got, want):
+        assert np.array_equal(g, w, equal_nan=True), f
