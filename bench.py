@@ -44,6 +44,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 # VALU issue roof: a SIMD issues one wave64 VALU instruction (fp64 included: full rate on CDNA4) per 4 cycles;
 # 256 CUs x 4 SIMDs at the 2.4 GHz peak clock of the same guide
 VALU_ISSUE_PEAK_GINST = 256 * 4 * 2.4 / 4.0
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9   # SIMD-cycles per second at the 2.4 GHz peak clock
 INTEGRATOR_BYTES = 44          # algorithmic bytes per participant-step
 COLLIDE_BYTES = 20             # + per-env geometry (computed from the scene)
 ACTION_SETS = 32               # action ring resident in HBM (one set per step of a chained fragment)
@@ -169,7 +170,7 @@ def cpu_baseline(scene, target_seconds=10.0):
 class Runner:
     """One pool + a resident action ring + the two ways of enqueuing steps."""
 
-    def __init__(self, scene, dev, variant, auto_reset=True, outputs="state", seed=5, idm=False):
+    def __init__(self, scene, dev, variant, auto_reset=True, outputs="all", seed=5, idm=False):
         import torch
         from tactics2d_amd import layout as L
         from tactics2d_amd.pool import ParticipantPool
@@ -266,6 +267,64 @@ def time_config(name, steps, warmup, dev, variant, frag, clock_warm):
                 us_per_step=best, us_per_step_separate_launches=us_s, us_per_step_chained=us_c, kernel_form=forms, steps=steps, warmup=warmup)
 
 
+def closed_loop(scene, dev, variant, steps, warmup, clock_warm, outputs):
+    """The loop the reference's callers run -- action = policy(obs); env.step(action), envs/parking.py:219-256 -- kept on the
+    device: per env group and step a policy kernel that reads the state the previous step left behind and writes an [n, 2]
+    (steering, accel) tensor -> t2d_step reading it in place, nothing synchronising with the host (tactics2d_amd/csrc/
+    t2d_loop.hip: a stand-in policy of a few flops per participant, so what is timed is the step path under the real
+    dependency).  One pool on one stream first (the plain closed loop), then G env groups on G streams -- their launches
+    overlap: what gives a closed-loop caller part of the overlap t2d_step_n gives an open-loop one.  Same results whatever G
+    (tests/test_gpu_closed_loop.py)."""
+    import torch
+    from tactics2d_amd.pipeline import ClosedLoop, EnvGroups
+    N = scene.n
+    rows = []
+    long_steps = max(steps, 400)
+
+    def measure(loop, n):
+        clock_warm()
+        loop.run(max(warmup, 32))
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        loop.run(n)
+        torch.cuda.synchronize()
+        return 1e6 * (time.perf_counter() - t) / n
+
+    for G, launcher in ((1, "thread"), (2, "threads"), (4, "threads")):
+        if scene.n_env % G:
+            continue
+        eg = EnvGroups(scene, G, dev.index)
+        eg.configure(lambda p: (p.set_integrator_variant(variant), p.set_auto_reset(True),
+                                p.set_outputs(velocity=outputs == "all", applied=outputs == "all")))
+        try:
+            loop = ClosedLoop(eg, launcher, scene.interval_ms)
+            us = min(measure(loop, steps) for _ in range(2))
+            us_long = measure(loop, long_steps)
+            loop.close()
+            rows.append(dict(groups=G, launcher=launcher, us_per_step=us, us_per_step_long_run=us_long, long_run_steps=long_steps))
+        except Exception as e:   # noqa: BLE001 -- reported in the line, never fatal for it
+            rows.append(dict(groups=G, launcher=launcher, error=str(e)))
+        eg.close()
+    ok = [r for r in rows if "us_per_step" in r]
+    if not ok:
+        return dict(error="no closed-loop configuration ran", candidates=rows)
+    best = min(ok, key=lambda r: r["us_per_step"])
+    single = next((r for r in ok if r["groups"] == 1), None)
+    return dict(us_per_step=best["us_per_step"], value=N / (best["us_per_step"] * 1e-6), unit="participant-steps/s", groups=best["groups"],
+                launcher=best["launcher"], steps=steps, warmup=max(warmup, 32),
+                us_per_step_long_run=best["us_per_step_long_run"], long_run_steps=long_steps,
+                us_per_step_one_pool_one_stream=(single or {}).get("us_per_step"),
+                form="per env group and step: policy kernel -> t2d_step (one fused launch), the group's own stream, no host synchronisation; "
+                     "the groups' launches overlap (GPU_MAX_HW_QUEUES=%s)" % os.environ.get("GPU_MAX_HW_QUEUES"),
+                producer="t2d_debug_feedback_policy: a stand-in policy, one launch per group and step -- reads x, y, heading, speed of step "
+                         "k - 1, writes [n, 2] (steering, accel) in the reference's action layout, bound with t2d_bind_actions_strided",
+                bit_identical_to="the same policy and t2d_step calls on one pool holding all the envs (tests/test_gpu_closed_loop.py)",
+                candidates=rows,
+                note="us_per_step = wall time of `steps` iterations of all groups incl. the final synchronise, best of 2 after the clock ramp; "
+                     "which group count wins depends on how the runtime maps streams to hardware queues on the box (profiles/r04_closed_loop_sweep_*.json: "
+                     "2 groups overlap with 8 queues, 4 groups with 4; the others serialise)")
+
+
 def next_rows(dev, clock_warm, metric_scene):
     """The rows SURVEY 8f adds around the step (IDM, lidar, the ParkingEnv vector step): >= 200 back-to-back launches each
     after the clock ramp, wall time including the final synchronise."""
@@ -338,9 +397,9 @@ def main():
     ap.add_argument("--mode", default="chain", choices=["chain", "step"],
                     help="chain: t2d_step_n fragments (one launch per fragment); step: one t2d_step launch per step")
     ap.add_argument("--fragment", type=int, default=32, help="steps per t2d_step_n call in chain mode (<= 32)")
-    ap.add_argument("--outputs", default="state", choices=["state", "all"],
-                    help="state: x, y, heading, speed (+ a point mass's velocity), flags and the env records; all: also the derived "
-                         "vx / vy of the single-track models and the applied action (t2d_set_outputs)")
+    ap.add_argument("--outputs", default="all", choices=["state", "all"],
+                    help="all (default): the reference's State -- x, y, heading, speed, vx / vy, the applied action -- plus flags and the env "
+                         "records; state: without the derived vx / vy of the single-track models and the applied action (t2d_set_outputs)")
     ap.add_argument("--gather-every", type=int, default=32, help="N > 1: steps per all-gather of the result records (1 = every step; "
                     "it divides the record ring of 64 slots and is at most half of it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -538,6 +597,15 @@ def main():
                  ("stored as well (t2d_set_outputs(T2D_OUT_ALL): the reference's State)" if args.outputs != "all" else "not stored"))
         run.pool.set_outputs(velocity=args.outputs == "all", applied=args.outputs == "all")
 
+    # ---- the same timed region once more WITHOUT the clock ramp: the GPU left idle for 0.4 s, then --warmup steps, then the
+    # timed steps -- what the ramp contributes is driver-timed here, not quoted ---------------------------------------------
+    no_ramp = None
+    if world == 1 and gather is None and args.clock_warm:
+        time.sleep(0.4)
+        us, span = timed(run, mode, args.steps, args.warmup, frag, None)
+        no_ramp = dict(value=N / (us * 1e-6), us_per_step=us, event_span_us_per_step=span,
+                       note=f"same {args.steps} steps after 0.4 s of idle GPU and {args.warmup} warm-up steps, no untimed clock ramp")
+
     # state sanity after the run (not timed): flags/status distribution
     flags = run.pool.download(L.F_FLAGS)
     status = run.pool.download(L.F_STATUS)
@@ -557,6 +625,9 @@ def main():
                                f"of {frag} steps; us_per_step = the better of the two; wall time incl. the final synchronise")
         if not args.no_next_rows:
             nrows = next_rows(dev, clock_warm, scene)
+    cloop = None
+    if world == 1 and rank == 0 and not args.no_closed_loop and not args.idm:
+        cloop = closed_loop(scene, dev, args.variant, args.steps, args.warmup, clock_warm, args.outputs)
     if warm is not None:
         warm.close()
 
@@ -595,10 +666,57 @@ def main():
             insts = float(sq["SQ_INSTS_VALU"])
             roof.update(achieved=insts / (step_us * 1e-6) / 1e9, valu_insts_per_step=insts,
                         valu_insts_per_wave=insts / sq["SQ_WAVES"], insts_per_wave=sq.get("SQ_INSTS", 0) / sq["SQ_WAVES"])
-            roof["frac"] = roof["achieved"] / VALU_ISSUE_PEAK_GINST
+            roof["frac_at_4_cycles_per_instruction"] = roof["achieved"] / VALU_ISSUE_PEAK_GINST
+            roof["frac"] = roof["frac_at_4_cycles_per_instruction"]
+            # class-resolved: what the step's VALU instructions cost a SIMD by the MEASURED issue cost of their class
+            # (profiles/valu_issue_cycles.json <- scripts/valu_roof.hip on this GPU) over the SIMD-cycles of the step
+            cyc_f = os.path.join(ROOT, "profiles", "valu_issue_cycles.json")
+            if os.path.exists(cyc_f) and "SQ_INSTS_VALU_FMA_F64" in sq:
+                cyc = json.load(open(cyc_f))["cycles"]
+                g = lambda k: float(sq.get(k, 0.0))
+                fp64 = g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_ADD_F64")
+                tr64, tr32 = g("SQ_INSTS_VALU_TRANS_F64"), g("SQ_INSTS_VALU_TRANS_F32")
+                cvt, i64 = g("SQ_INSTS_VALU_CVT"), g("SQ_INSTS_VALU_INT64")
+                i32 = g("SQ_INSTS_VALU_INT32")
+                f32 = g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32")
+                fma32 = g("SQ_INSTS_VALU_FMA_F32")
+                other = max(0.0, insts - (fp64 + tr64 + tr32 + cvt + i64 + i32 + f32 + fma32))   # moves, selects, compares, lane ops
+                fixed = (fp64 * cyc["fp64_add_mul_fma"] + tr64 * cyc["trans_f64"] + tr32 * cyc["trans_f32"] + cvt * cyc["cvt"] +
+                         i64 * cyc["int64"] + fma32 * cyc["f32_fma"])
+                simple = i32 + f32 + other
+                simd_cycles = step_us * 1e-6 * SIMD_CYCLES_PER_S
+                hi = (fixed + simple * cyc["simple_32bit_between_fp64"]) / simd_cycles
+                lo = (fixed + simple * cyc["int32_simple_back_to_back"]) / simd_cycles
+                roof.update(frac=hi, frac_lower_bound=lo,
+                            issue_cycles_per_class=dict(source="profiles/valu_issue_cycles.json", **{k: cyc[k] for k in (
+                                "fp64_add_mul_fma", "trans_f64", "trans_f32", "cvt", "int64", "f32_fma", "simple_32bit_between_fp64",
+                                "int32_simple_back_to_back", "int32_other", "f32_other", "pk_f32", "salu")}),
+                            valu_insts_per_wave_by_class={k: v / sq["SQ_WAVES"] for k, v in dict(
+                                fp64_add_mul_fma=fp64, trans_f64=tr64, trans_f32=tr32, cvt=cvt, int64=i64, int32=i32, f32_add_mul=f32,
+                                f32_fma=fma32, other_moves_selects_compares=other).items()},
+                            frac_is="sum over classes of (instructions per step x measured SIMD cycles per wave64 instruction of the class, 4 waves "
+                                    "per SIMD) / (256 CUs x 4 SIMDs x 2.4 GHz x step_us); 32-bit integer / fp32 add-mul / move-select-compare "
+                                    "instructions at the 4.0 cycles one of them costs BETWEEN fp64 instructions (the stream of this kernel); "
+                                    "frac_lower_bound prices all of them at the 2.19 cycles of an unbroken run of plain 32-bit operations")
         else:   # never print a numerator that belongs to another binary
             roof.update(achieved=None, frac=None,
                         note="no instruction counts for these sources: re-run scripts/profile_round.sh; the HBM figure stands")
+        # north_star's own roofline kernel: the stand-alone integrator (t2d_integrate), algorithmic 44 B per participant over its
+        # launch duration (HIP events of the per-kernel pass) against the 8 TB/s peak -- the target there is >= 0.40
+        integ = None
+        if kern.get("integrate_kernel"):
+            iu = kern["integrate_kernel"]["avg_us"]
+            integ = dict(kernel="integrate_kernel<fast>", bound="hbm", avg_us=iu, algorithmic_bytes=INTEGRATOR_BYTES * N,
+                         achieved=INTEGRATOR_BYTES * N / (iu * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                         north_star_target_frac=0.40,
+                         note="20 fp64 Euler sub-steps per participant for 44 B: VALU-issue bound (DESIGN.md 4.1); avg_us includes the "
+                              "~2 us of the HIP-event pair around each launch")
+            integ["frac"] = integ["achieved"] / HBM_PEAK_GBS
+            isq = tj.get("integrator_sq_per_launch") if same_cfg and not stale else None
+            if isq and isq.get("SQ_WAVES"):
+                integ.update(valu_insts_per_wave=isq["SQ_INSTS_VALU"] / isq["SQ_WAVES"],
+                             valu_busy_frac=isq.get("_valu_busy_frac"), rocprofv3_avg_us=tj.get("kernel_trace_avg_us_per_step", {}).get("step", {}).get("integrate_kernel"))
+        roof["integrator"] = integ
         gather_obj = None
         if gather is not None:
             gather_obj = dict(native=bool(native_gather), every=every, every_requested=args.gather_every, gathers_in_timed_region=gathers_timed,
@@ -619,23 +737,32 @@ def main():
                                         f"integrator variant {args.variant}, fused step kernel, auto-reset "
                                         f"{'off' if args.no_reset else 'on'}" + (", IDM agents on" if args.idm else "") +
                                         f"; steps enqueued as {how_steps}; outputs stored: {args.outputs}",
-                               config=args.config, envs_per_gpu=n_env, participants_per_env=agents, mode=mode, fragment=frag,
+                               config=args.config, envs_per_gpu=n_env, participants_per_env=agents, mode=mode,
+                               fragment=(min(frag, args.steps) if mode == "chain" else 1), fragment_max=frag,
                                outputs=args.outputs, host_enqueue_us_per_step=host_enqueue_us,
                                untimed_prewarm=f"{args.clock_warm} steps of a scratch pool with the same scene before every timed region (GPU clock "
                                                f"ramp, the measured pool untouched), then {args.warmup} warm-up steps; per-kernel pass: "
                                                f"{PREWARM} untimed steps of each kernel form, then up to {n_prof} timed ones",
                                parallelism=(f"env-sharded x{world}, one async all-gather of the 8 B/env result records per {every} steps"
                                             if world > 1 else "single GPU")),
-                   roofline=roof, alternates=alternates, gather=gather_obj, configs=configs, next_rows=nrows,
+                   roofline=roof, closed_loop=cloop, value_without_clock_ramp=no_ramp, alternates=alternates, gather=gather_obj,
+                   configs=configs, next_rows=nrows,
                    check=dict(state_finite=finite,
                               flag_rates=[float((flags & b).astype(bool).mean()) for b in (1, 2, 4, 8)],
                               truncated_frac=float(status[:, 3].mean())))
         if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only (the other ranks would sit in the barrier)
             out["cpu_baseline"] = cpu_baseline(scene)
         print(json.dumps(out))
+    bad_world = (world > 1 and backend == "nccl" and not os.environ.get("T2D_GATHER_TORCH") and
+                 (not native_gather or comm is None or comm[1] != world))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if bad_world:   # a multi-GPU run whose records did not travel through the library's own RCCL communicator of N ranks is not
+        # the path this bench claims to measure: fail loudly (T2D_GATHER_TORCH=1 asks for the torch.distributed path on purpose)
+        print(f"error: rank {rank}: the native RCCL gather is not in place (native={native_gather}, communicator={comm}); "
+              f"expected a communicator of {world} ranks", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

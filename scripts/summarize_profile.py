@@ -66,7 +66,7 @@ epb = 256 >> log2A
 per_step_items = (((n_env + epb - 1) // epb + 7) & ~7) * 256    # work-items of one step in a chained launch
 
 summary = {"tag": tag, "source_sha256": B.source_hash(),
-           "commands": {m: f"python bench.py --mode {m} --steps 1024 --warmup 128 --no-cpu-baseline --no-configs --no-next-rows --no-alternates" for m in ("chain", "step")}}
+           "commands": {m: f"python bench.py --mode {m} --steps 1024 --warmup 128 --no-cpu-baseline --no-configs --no-next-rows --no-alternates --no-closed-loop" for m in ("chain", "step")}}
 stats_csv = []
 kt = {}
 for mode in ("chain", "step"):
@@ -124,6 +124,15 @@ for mode in ("chain", "step"):
     for k, v in counters(f"sq_{mode}").items():
         if "step_kernel" in k:
             sq[k] = v
+    for d in (f"sqc1_{mode}", f"sqc2_{mode}"):   # the class-resolved passes: merged into the kernel's counter set
+        for k, v in counters(d).items():
+            if "step_kernel" in k and k in sq:
+                for c, x in v.items():
+                    sq[k].setdefault(c, x)
+integ_sq = counters("sq_integ").get("integrate_kernel")
+if integ_sq and integ_sq.get("SQ_BUSY_CYCLES"):
+    integ_sq["_valu_busy_frac"] = 4.0 * integ_sq.get("SQ_ACTIVE_INST_VALU", 0) / (256 * 4 * integ_sq["SQ_BUSY_CYCLES"] / 32.0)
+summary["integrator_sq_per_launch"] = integ_sq
 summary["traffic_per_step"] = traffic
 summary["sq_counters_per_step"] = sq
 summary["bench_json"] = bench_json
@@ -211,6 +220,7 @@ latest = dict(tag=tag, source_sha256=summary["source_sha256"], config=cfg.get("c
                      "and WRITE_SIZE scaled by the factors calibrated on restore_kernel's known byte count (same 4-B/lane pattern); "
                      "per step: a chained launch's counters are divided by the steps it holds",
               sq_counters_per_step={k: {c: x for c, x in v.items() if not c.startswith("_")} for k, v in sq.items()},
+              integrator_sq_per_launch=integ_sq,
               sq_source="rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS SQ_WAVE_CYCLES SQ_BUSY_CYCLES "
                         "SQ_ACTIVE_INST_VALU pass of the headline command in each step mode; SQ_ACTIVE_INST_* count quad-cycles",
               kernel_trace_avg_us_per_step={m: {k: v["avg_us_per_step"] for k, v in d.items()} for m, d in kt.items()})

@@ -65,7 +65,7 @@ using namespace geom;
 // -DT2D_PROBE_SKIP=<bits>: measurement builds that leave a phase out (the flags are then wrong; instruction counts and
 // timings of such a build against the full one say what the phase costs): 1 pair stage, 2 pair narrow phase only,
 // 4 static polygons, 8 lane polygons, 16 off-lane stage 2 only, 32 pair broad phase only (every pair a candidate: never use),
-// 64 the fused integrator (the state stays what it was)
+// 64 the fused integrator (the state stays what it was), 128 the status epilogue, 256 the auto-reset restore
 #ifndef T2D_PROBE_SKIP
 #define T2D_PROBE_SKIP 0
 #endif
@@ -1577,7 +1577,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
         iou_na = v;
         iou_ar = __shfl_down(v, 1);   // lane 0 of the env receives lane 1's value (same wave: 2^log2A >= 2 lanes per env)
     }
-    if (valid && agent == 0) {
+    if (valid && agent == 0 && !(T2D_PROBE_SKIP & 128)) {
         e_env_flags[env] = s_env_or[env_local];
         if (WITH_STATUS) {
             const int cnt = pre_cnt + 1;  // parking.py:353
@@ -1686,7 +1686,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     if (LOOP) {   // what this trip stored (a pure-output velocity excepted: only a point mass reads c_vx / c_vy back)
         c_ids = ids; c_x = fx; c_y = fy; c_h = fh; c_v = fv;
     }
-    if (WITH_STATUS && e_auto_reset && !PIPE) {  // fused vector-env auto-reset: finished envs go back to the snapshot (PIPE: by the integrator wave)
+    if (WITH_STATUS && e_auto_reset && !PIPE && !(T2D_PROBE_SKIP & 256)) {  // fused vector-env auto-reset: finished envs go back to the snapshot (PIPE: by the integrator wave)
         // (the restore's eighteen pointers are requested here, in one scalar round trip, not with the epilogue's above: 36
         // more scalar registers held through the reduce and the status code pushed the kernel into scalar spills -- two
         // v_readlane / v_writelane per spilled value, ~300 VALU instructions per wave)
