@@ -205,6 +205,22 @@ __device__ __noinline__ double quad_iou(const double* a_planes, const double* b_
     return inter / uni;
 }
 
+// A store of per-participant output by a launch that holds ONE step (STREAM): the value is not read again inside the launch, and
+// what sits dirty in the L2 when the kernel ends is written back behind its last wave -- on the path to the next launch.
+// -DT2D_STORE_MODE: 0 plain, 1 nontemporal (streaming; the default), 2 relaxed agent-scope (sc1: written through).  Measured
+// at 4096 x 64, one launch per step (scripts/ab_step.py, same box, same checksum): 21.93 / 21.47 / 21.77 us per step; the small
+// pools do not care (14.4 / 13.0 / 14.9 either way).  Launches that hold several steps keep plain stores: the next step reads
+// them from this XCD's L2.
+#ifndef T2D_STORE_MODE
+#define T2D_STORE_MODE 1
+#endif
+template <bool STREAM, class P, class T>
+T2D_DEV void st_out(P p, T v) {   // (P: a plain or an address-space-qualified pointer to T)
+    if (STREAM && T2D_STORE_MODE == 1) __builtin_nontemporal_store(v, p);
+    else if (STREAM && T2D_STORE_MODE == 2) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 T2D_DEV uint32_t cell_hash(int cx, int cy) {
     return ((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u);
 }
@@ -998,21 +1014,21 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
         fy = (float)o.y;
         fh = (float)o.heading;
         fv = (float)o.speed;
-        pv.x[idx] = fx;
-        pv.y[idx] = fy;
-        pv.heading[idx] = fh;
-        pv.speed[idx] = fv;
+        st_out<!MULTI>(pv.x + idx, fx);
+        st_out<!MULTI>(pv.y + idx, fy);
+        st_out<!MULTI>(pv.heading + idx, fh);
+        st_out<!MULTI>(pv.speed + idx, fv);
         if (LOOP && o.has_velocity) {
             c_vx = (float)o.vx;
             c_vy = (float)o.vy;
         }
         if (o.has_velocity && (model == T2D_MODEL_POINTMASS || (pv.out_mask & T2D_OUT_VELOCITY))) {
-            pv.vx[idx] = (float)o.vx;
-            pv.vy[idx] = (float)o.vy;
+            st_out<!MULTI>(pv.vx + idx, (float)o.vx);
+            st_out<!MULTI>(pv.vy + idx, (float)o.vy);
         }
         if (pv.out_mask & T2D_OUT_APPLIED) {
-            pv.applied0[idx] = (float)o.app0;
-            pv.applied1[idx] = (float)o.app1;
+            st_out<!MULTI>(pv.applied0 + idx, (float)o.app0);
+            st_out<!MULTI>(pv.applied1 + idx, (float)o.app1);
         }
     }
     if (SPLIT) {   // the new state, from wave 0 to the three waves that take the other event stages
@@ -1545,7 +1561,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
             if (!in) f |= T2D_FLAG_OFF_LANE;
         }
     }
-    if (valid) e_flags[idx] = f;
+    if (valid) st_out<!MULTI>(e_flags + idx, f);
     s_flags[tid] = f;
     if (__ballot(f != 0) != 0ull && f != 0) atomicOr(&s_env_or[env_local], f);
     if (log2A <= 6) wave_sync(); else __syncthreads();  // (d)
@@ -1577,7 +1593,75 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
         iou_na = v;
         iou_ar = __shfl_down(v, 1);   // lane 0 of the env receives lane 1's value (same wave: 2^log2A >= 2 lanes per env)
     }
-    if (valid && agent == 0 && !(T2D_PROBE_SKIP & 128)) {
+    // One env per wave (64-participant envs) without IoU events, shaped reward or the tanh fall-back: everything the status
+    // epilogue works on is ONE value per wave.  Made wave-uniform by v_readfirstlane, the ordered early-return logic of
+    // check_status, the reward table and the counters compile to SCALAR instructions -- the scalar pipe has slack (4.2
+    // cycles per instruction beside the VALU work of other waves, profiles/valu_issue_cycles.json) while the VALU is what
+    // bounds the launch: the wave issued ~100 VALU instructions here for the sake of one lane, now ~20 (the stores' data).
+    // Same decisions, same bits: the generic path below, instruction for instruction, on the same inputs.
+    bool epilogue_done = false;
+    if constexpr (WITH_STATUS && !IOU && !SPLIT) {
+        if (log2A == 6 && !cfg.shaped_reward && (cfg.max_step <= 0 || e_time_penalty) && !(T2D_PROBE_SKIP & 128)) {
+            epilogue_done = true;
+            if (valid && agent == 0 && !role_b) {
+                const int env_s = __builtin_amdgcn_readfirstlane(env);
+                const uint32_t env_or = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_env_or[env_local]);
+                const uint32_t ef = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_flags[slot0 + cfg.ego_index]);
+                const int cnt = __builtin_amdgcn_readfirstlane(pre_cnt) + 1;  // parking.py:353
+                const int frame = __builtin_amdgcn_readfirstlane(pre_frame) + interval_ms;
+                const uint32_t tp_bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint((float)pre_tp));
+                int scen = T2D_SCENARIO_NORMAL, traf = T2D_TRAFFIC_NORMAL;
+                if (cfg.max_step > 0 && cnt > cfg.max_step) {
+                    scen = T2D_SCENARIO_TIME_EXCEEDED;  // later detectors are not updated (parking.py:366-369)
+                } else if (ef & T2D_FLAG_OUT_BOUND) {
+                    scen = T2D_SCENARIO_OUT_BOUND;
+                } else if (ef & T2D_FLAG_COLLISION_STATIC) {
+                    scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_COLLISION_STATIC;
+                } else if (cfg.check_dynamic && (ef & T2D_FLAG_COLLISION_DYNAMIC)) {
+                    scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_COLLISION_DYNAMIC;
+                } else if (cfg.check_off_lane && (ef & T2D_FLAG_OFF_LANE)) {
+                    scen = T2D_SCENARIO_FAILED; traf = T2D_TRAFFIC_OFF_LANE;
+                }
+                // ParkingEnv._get_reward (envs/parking.py:148-190) on bit patterns: every value is one of the configuration's
+                // floats or the time penalty of the table, rounded to fp32 once, exactly as (float)(double) does below
+                uint32_t rb;
+                if (traf == T2D_TRAFFIC_COLLISION_STATIC) rb = __float_as_uint(cfg.reward_collision);
+                else if (scen == T2D_SCENARIO_TIME_EXCEEDED || scen == T2D_SCENARIO_NO_ACTION) rb = __float_as_uint(cfg.reward_time_exceed);
+                else if (scen == T2D_SCENARIO_OUT_BOUND) rb = __float_as_uint(cfg.reward_out_bound);
+                else if (scen == T2D_SCENARIO_COMPLETED) rb = __float_as_uint(cfg.reward_completed);
+                else if (traf == T2D_TRAFFIC_COLLISION_DYNAMIC || traf == T2D_TRAFFIC_OFF_LANE) rb = __float_as_uint(cfg.reward_collision);
+                else rb = cfg.max_step > 0 ? tp_bits : 0u;
+                const bool terminated = scen == T2D_SCENARIO_COMPLETED;
+                const bool truncated = !terminated && (scen != T2D_SCENARIO_NORMAL || traf != T2D_TRAFFIC_NORMAL);
+                const uint32_t st = (uint32_t)scen | (uint32_t)traf << 8 | (uint32_t)terminated << 16 | (uint32_t)truncated << 24;
+                const bool done = e_auto_reset && (terminated || truncated);
+                e_env_flags[env_s] = env_or;
+                e_cnt_step[env_s] = done ? 0 : cnt;
+                e_frame_ms[env_s] = done ? 0 : frame;
+                if (LOOP) {
+                    c_cnt = done ? 0 : cnt;
+                    c_frame = done ? 0 : frame;
+                }
+                ((T2D_GLOBAL uint32_t*)e_status)[env_s] = st;
+                ((T2D_GLOBAL uint32_t*)e_reward)[env_s] = rb;
+                ((T2D_GLOBAL uint32_t*)e_iou)[env_s] = 0x7fc00000u;   // NaN: not evaluated
+                const unsigned long long rec = (unsigned long long)rb | ((unsigned long long)st << 32);
+                if (MULTI) ((T2D_GLOBAL unsigned long long*)e_record_ring)[(size_t)((e_record_slot0 + step_k) & (T2D_RECORD_RING - 1)) * (size_t)e_n_env + env_s] = rec;
+                else ((T2D_GLOBAL unsigned long long*)e_record)[env_s] = rec;
+                if (e_auto_reset) {
+                    s_done[env_local] = done;
+                    if (PIPE) s_dec[env_local] = done;   // (the integrator wave reads it before it commits the next step)
+                    if (done) {  // ParkingEnv.reset: detector state back to the episode start (the counters: above)
+                        e_last_valid[env_s] = 0;
+                        e_cnt_na[env_s] = 0;
+                        e_max_iou[env_s] = -INFINITY;
+                        e_min_dist[env_s] = e_snap_min_dist[env_s];
+                    }
+                }
+            }
+        }
+    }
+    if (!epilogue_done && valid && agent == 0 && !(T2D_PROBE_SKIP & 128)) {
         e_env_flags[env] = s_env_or[env_local];
         if (WITH_STATUS) {
             const int cnt = pre_cnt + 1;  // parking.py:353
