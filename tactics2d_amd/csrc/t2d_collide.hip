@@ -1601,6 +1601,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     // Same decisions, same bits: the generic path below, instruction for instruction, on the same inputs.
     bool epilogue_done = false;
     if constexpr (WITH_STATUS && !IOU && !SPLIT) {
+#ifndef T2D_NO_SCALAR_EPILOGUE
         if (log2A == 6 && !cfg.shaped_reward && (cfg.max_step <= 0 || e_time_penalty) && !(T2D_PROBE_SKIP & 128)) {
             epilogue_done = true;
             if (valid && agent == 0 && !role_b) {
@@ -1660,6 +1661,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                 }
             }
         }
+#endif
     }
     if (!epilogue_done && valid && agent == 0 && !(T2D_PROBE_SKIP & 128)) {
         e_env_flags[env] = s_env_or[env_local];

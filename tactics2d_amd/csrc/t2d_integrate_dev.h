@@ -388,6 +388,9 @@ T2D_DEV StepOut step_dynamics(PF P, double x, double y, double phi, double v, do
                 beta = __builtin_fma(d_beta, dt, beta);
                 const double eps = (d_phi + d_beta) * dt;
                 const double aeps = __builtin_fabs(eps);
+                // (one wave-uniform test per sub-step.  Round 4 tried the tiny-angle formula without asking, the largest sub-step
+                // angle tested once per step and the step redone when it was too large: the eight start values kept alive for
+                // the redo made the loop slower -- cfg3 fragments 8.4 -> 10.1 us per step, scripts/ab_step.py)
                 if (__ballot(aeps > kEpsTiny) == 0ull) rotate_tiny(eps, c, s);
                 else if (aeps <= kEpsMax) rotate_small(eps, c, s);
                 else sincos_det(phi + beta, s, c);

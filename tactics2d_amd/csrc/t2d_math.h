@@ -47,15 +47,12 @@ __constant__ double kAtanTab[12] = {
     9.09088713343650656196e-02, -7.69187620504482999495e-02, 6.66107313738753120669e-02, -5.83357013379057348645e-02,
     4.97687799461593236017e-02, -3.65315727442169155270e-02, 1.62858201153657823623e-02, 0.0};
 #endif
-// k mod 4 of an integral-valued double (the quadrant of the Cody-Waite quotient): through the one-instruction 32-bit
-// conversion when every lane's quotient fits (|x| < 3e9: always, short of an integrator that has blown up), through the
-// 64-bit one (trunc, ldexp, floor, fma, cvt) otherwise -- the same bits.  The empty asm keeps the rare side a real branch: left
-// alone the compiler evaluates both conversions and selects.
-T2D_DEV int quadrant_of(double k) {
-    if (__builtin_expect(__ballot(!(__builtin_fabs(k) < 2147483000.0)) == 0ull, 1)) return (int)k & 3;
-    asm volatile("" : "+v"(k));
-    return (int)((long long)k & 3);
-}
+// k mod 4 of an integral-valued double (the quadrant of the Cody-Waite quotient), through the 64-bit conversion (trunc, ldexp,
+// floor, fma, cvt: five instructions).  Round 4 tried the one-instruction 32-bit conversion behind a wave-uniform test of
+// |k| < 2^31: four instructions fewer, and 6 % SLOWER on the pools that run one or two waves per SIMD (cfg3 as t2d_step_n
+// fragments 8.4 -> 9.2 us per step, scripts/ab_step.py) -- a ballot and a branch on a lone wave's dependent chain cost more
+// than the instructions they skip.
+T2D_DEV int quadrant_of(double k) { return (int)((long long)k & 3); }
 
 // sin/cos of x: 3-term Cody-Waite reduction by pi/2 (fma), minimax kernels on [-pi/4, pi/4].
 // <= 1 ulp against libm for |x| < ~1e5 (tests/test_oracle_geometry.py, tests/test_gpu_math.py).
@@ -171,7 +168,7 @@ T2D_DEV void sincos_det_steer_and(double xa, double xb, double& sa_out, double& 
     const bool small_a = __ballot(!(__builtin_fabs(xa) <= 0.78)) == 0ull;   // wave-uniform
     double ka = 0.0, ra = xa;
     if (__builtin_expect(!small_a, 0)) {
-        asm volatile("" : "+v"(xa));   // (a real branch: see quadrant_of)
+        asm volatile("" : "+v"(xa));   // (keeps the rare side a real branch: left alone the compiler evaluates the reduction and selects)
         ka = __builtin_rint(xa * t0);
         ra = __builtin_fma(-ka, t1, xa);
         ra = __builtin_fma(-ka, t2, ra);
