@@ -1,0 +1,15 @@
+#!/bin/bash
+# end-of-round evidence run: GPU test suite, the profile round (rocprofv3 kernel traces + PMC passes -> summaries), the
+# driver-like default bench line and a long-run one.  Usage on the GPU box: bash scripts/gpu_final.sh TAG
+TAG=${1:-r04}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export PYTHONUNBUFFERED=1
+mkdir -p gpurun_out/${TAG}_logs
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_logs/pytest_gpu.log 2>&1; echo "gpu tests rc $?"; tail -3 gpurun_out/${TAG}_logs/pytest_gpu.log
+bash scripts/profile_round.sh $TAG > gpurun_out/${TAG}_logs/profile_round.log 2>&1; echo "profile round rc $?"
+cp gpurun_out/prof_$TAG/*.log gpurun_out/${TAG}_logs/ 2>/dev/null; rm -rf gpurun_out/prof_$TAG
+# (the bench reads profiles/traffic_latest.json: the fresh one is put in place for the two lines below)
+cp gpurun_out/${TAG}_traffic_latest.json profiles/traffic_latest.json
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_like.json 2> gpurun_out/${TAG}_logs/bench_driver_like.err; echo "bench (20 steps) rc $?"
+timeout 900 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline > gpurun_out/${TAG}_bench_1000.json 2> gpurun_out/${TAG}_logs/bench_1000.err; echo "bench (1000 steps) rc $?"
+du -sh gpurun_out
