@@ -115,6 +115,15 @@ hipError_t quiesce(t2d_pool* p) {
     }
     p->n_live_streams = 0;
     p->live_overflow = false;
+    if (e == hipSuccess && p->scene_commit_used && p->scene.commit_err) {
+        uint32_t err = 0;
+        e = hipMemcpy(&err, p->scene.commit_err, sizeof(err), hipMemcpyDeviceToHost);
+        p->scene_commit_used = false;
+        if (e == hipSuccess && err) {
+            (void)hipMemset(p->scene.commit_err, 0, sizeof(err));
+            p->scene_commit_failed = true;
+        }
+    }
     if (e == hipSuccess && p->chain_used) {   // a chained launch reports a broken hand-off through two words in device memory
         uint32_t err[2] = {0, 0};   // {1: a bounded wait ran out | 2: producer and consumer on different XCDs, ckpt_tag of the fragment}
         e = hipMemcpy(err, p->d_chain + p->chain_slots, sizeof(err), hipMemcpyDeviceToHost);
@@ -149,6 +158,11 @@ hipError_t quiesce(t2d_pool* p) {
 // A failed chained launch is reported ONCE, by the first t2d_sync / t2d_download / t2d_step_n after it; the pool then goes on
 // with plain launches (t2d_set_step_chaining turns chaining back on).
 int report_chain_failure(t2d_pool* p) {
+    if (p->scene_commit_failed) {   // (scene_commit_kernel: cannot happen while the refill cadence below holds)
+        p->scene_commit_failed = false;
+        return fail(p, T2D_ERR_STATE, "scene regeneration: an env whose episode ended found no staged scene for its next episode and "
+                                      "kept its old one -- call t2d_parking_scenes again before stepping on");
+    }
     if (!p->chain_failed) return T2D_OK;
     p->chain_failed = false;
     const std::string why = p->chain_err_code == 2 ? "two workgroups of one env set ran on different XCDs"
@@ -597,6 +611,7 @@ int rebuild_lidar_geo(t2d_pool* p) {
         if ((rc = dev_replace(p, &p->d_lidar_env_off, evo.data(), evo.size()))) return rc;
         p->lidar.max_static_verts = VS;
         p->lidar.env_vert_cnt = p->d_lidar_cnt;
+        p->lidar.edge_meta = p->d_lidar_meta;   // (ring slots < 16 and <= 48 edges per env by construction)
     } else if (!g.present || g.ring_env_off[E] == 0) {
         if ((rc = dev_replace<int32_t>(p, &p->d_lidar_env_off, nullptr, 0))) return rc;
         if ((rc = dev_replace<float>(p, &p->d_lidar_xy, nullptr, 0))) return rc;
@@ -613,11 +628,11 @@ int rebuild_lidar_geo(t2d_pool* p) {
             }
         for (int e = 0; e < E; ++e) p->lidar.max_static_verts = std::max(p->lidar.max_static_verts, evo[e + 1] - evo[e]);
         // which rings may take part in the scan's occlusion culling (t2d_lidar.hip): well-shaped rings (the chord bound of
-        // the culling argument needs sin(interior angle) >= 0.05 at every vertex) of envs with <= 16 rings and <= 32 edges
+        // the culling argument needs sin(interior angle) >= 0.05 at every vertex) of envs with <= 16 rings and <= 48 edges
         std::vector<uint8_t> meta((size_t)V, 0xff);
         for (int e = 0; e < E; ++e) {
             const int q0 = g.ring_env_off[e], q1 = g.ring_env_off[e + 1];
-            if (q1 - q0 > 16 || evo[e + 1] - evo[e] > 32) continue;
+            if (q1 - q0 > 16 || evo[e + 1] - evo[e] > 48) continue;
             for (int q = q0; q < q1; ++q) {
                 const int a = g.ring_vert_off[q], n = g.ring_vert_off[q + 1] - a;
                 bool ok = true;
@@ -878,7 +893,7 @@ int t2d_destroy(t2d_pool* p) {
                     p->d_lidar_env_off, p->d_lidar_next, p->d_lidar_meta, p->d_lidar_xy, p->d_beam_sin, p->d_beam_cos,
                     p->d_snap[0], p->d_snap[1], p->d_snap[2],
                     p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_wgmap, p->d_idm_rows, p->d_idm_ctrl, p->d_snap_omega[0], p->d_snap_omega[1], p->d_time_penalty,
-                    p->d_scene_arrays, p->d_lidar_cnt, p->d_chain, p->d_ckpt};
+                    p->d_scene_arrays, p->d_lidar_cnt, p->d_chain, p->d_ckpt, p->d_scene_view};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->comm && rccl().ok) (void)rccl().CommDestroy((ncclComm_t)p->comm);
@@ -1290,9 +1305,16 @@ static int collide_impl(t2d_pool* p, bool with_status, int interval_ms, hipStrea
     // single-ego pools (ParkingEnv: one box-shaped participant per env, no lanes) step with one WAVE per env
     // (t2d_ego.hip) instead of one lane per participant; same arithmetic, same results (t2d_set_ego_kernel(pool, 0)
     // keeps such a pool on the general kernel: the two are held against each other in tests/test_gpu_ego.py)
-    if (fuse_variant >= 0 && p->ego_kernel && p->v.A == 1 && p->all_boxes && !p->has_drift && !p->hgeo[1].present)
-        T2D_HIP(p, t2d::launch_ego_step(p->v, p->status_cfg, interval_ms, fuse_variant, s));
-    else {
+    p->scene_committed_in_step = false;
+    if (fuse_variant >= 0 && p->ego_kernel && p->v.A == 1 && p->all_boxes && !p->has_drift && !p->hgeo[1].present) {
+        t2d::PoolView v = p->v;
+        // staged scene regeneration: the step's own epilogue moves finished envs into their next lot (no launch behind it)
+        if (with_status && p->scene_regen && p->scene.ring > 0 && p->d_scene_view) {
+            v.regen = p->d_scene_view;
+            p->scene_committed_in_step = p->scene_commit_used = true;
+        }
+        T2D_HIP(p, t2d::launch_ego_step(v, p->status_cfg, interval_ms, fuse_variant, s));
+    } else {
         t2d::PoolView v = p->v;
         const bool idm_fused = fuse_variant >= 0 && idm_in_step(p);
         // (one workgroup per env fills the GPU with a quarter of the envs: for a pool that has the GPU to itself, not for env
@@ -1324,9 +1346,16 @@ static int regenerate_done_scenes(t2d_pool* p, hipStream_t s) {
     int rc;
     const bool refill = p->scene.ring > 0 && p->step_count % kSceneRefillPeriod == 0;
     if (refill && p->scene_refill_pending) T2D_HIP(p, hipStreamWaitEvent(s, p->ev_scene_refill, 0));
-    if ((rc = record_event(p, 6, s, true))) return rc;
-    T2D_HIP(p, t2d::launch_parking_scenes(p->v, p->scene, p->v.n_env, 2, s));
-    if ((rc = record_event(p, 6, s, false))) return rc;
+    if (!p->scene_committed_in_step) {   // (the ego step kernel has done it in its epilogue otherwise)
+        if ((rc = record_event(p, 6, s, true))) return rc;
+        if (p->scene.ring > 0) {   // staged scenes: sixteen lanes per env copy the prepared scene in
+            T2D_HIP(p, t2d::launch_scene_commit(p->v, p->scene, p->v.n_env, s));
+            p->scene_commit_used = true;
+        } else {
+            T2D_HIP(p, t2d::launch_parking_scenes(p->v, p->scene, p->v.n_env, 2, s));
+        }
+        if ((rc = record_event(p, 6, s, false))) return rc;
+    }
     if (refill) {
         T2D_HIP(p, hipEventRecord(p->ev_scene_commit, s));
         T2D_HIP(p, hipStreamWaitEvent(p->scene_stream, p->ev_scene_commit, 0));
@@ -1391,7 +1420,7 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
     // (the pool's own action fields hold ONE action set: a ring needs bound memory of n_steps * act_step_stride elements)
     if (act_step_stride != 0 && p->v.act0 == (const float*)p->field_ptr[T2D_F_ACT0])
         return fail(p, T2D_ERR_INVALID, "act_step_stride > 0 needs an action ring bound with t2d_bind_actions (the pool's own ACT0 / ACT1 hold one set)");
-    if (p->chain_failed) return report_chain_failure(p);   // (once; the call after it goes ahead with plain launches)
+    if (p->chain_failed || p->scene_commit_failed) return report_chain_failure(p);   // (once; the call after it goes ahead with plain launches)
     if (!p->have_params || !p->have_reset)
         return fail(p, T2D_ERR_STATE, "t2d_set_param_table and t2d_reset must precede t2d_step_n");
     if (interval_ms <= 0) return fail(p, T2D_ERR_INVALID, "interval_ms must be positive");
@@ -1687,6 +1716,8 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
         std::vector<int32_t> zi(E, 0);
         if ((rc = dev_replace(p, &p->d_lidar_xy, zl.data(), zl.size()))) return rc;
         if ((rc = dev_replace(p, &p->d_lidar_cnt, zi.data(), zi.size()))) return rc;
+        std::vector<uint8_t> zm(4 * (size_t)K * E, 0xff);   // per edge: its ring's slot if the ring may cull (install_quad_slot)
+        if ((rc = dev_replace(p, &p->d_lidar_meta, zm.data(), zm.size()))) return rc;
     }
     p->v.boundary = p->d_boundary;
     p->v.boundary_valid = nullptr;
@@ -1703,7 +1734,7 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
     const size_t per[8] = {(size_t)K * 8 * sizeof(float), (size_t)K * sizeof(int32_t), sizeof(int32_t), 3 * sizeof(double),
                            8 * sizeof(float), sizeof(double), 4 * sizeof(float), sizeof(uint32_t)};
     const size_t counts[2] = {(size_t)E, (size_t)E * ring};
-    size_t off[18], total = 0;
+    size_t off[19], total = 0;
     for (int set = 0; set < 2; ++set)
         for (int k = 0; k < 8; ++k) {
             off[8 * set + k] = total;
@@ -1711,6 +1742,7 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
         }
     off[16] = total; total += ((size_t)E * sizeof(int32_t) + 255) & ~(size_t)255;          // episode
     off[17] = total; total += ((size_t)E * ring * sizeof(int32_t) + 255) & ~(size_t)255;   // staged_ep
+    off[18] = total; total += 256;                                                         // commit_err
     if (p->scene_stream) T2D_HIP(p, hipStreamSynchronize(p->scene_stream));
     if (p->d_scene_arrays) {
         T2D_HIP(p, hipFree(p->d_scene_arrays));
@@ -1732,6 +1764,8 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
     }
     sv.episode = (int32_t*)(base + off[16]);
     sv.staged_ep = (int32_t*)(base + off[17]);
+    sv.commit_err = (uint32_t*)(base + off[18]);
+    p->scene_commit_used = p->scene_commit_failed = false;
     sv.ring = ring;
     if (ring > 0) {
         T2D_HIP(p, hipMemset(sv.staged_ep, 0xff, (size_t)E * ring * sizeof(int32_t)));   // -1 = empty slot
@@ -1741,7 +1775,7 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
     }
     p->scene_refill_pending = false;
     sv.geo = p->d_geo; sv.gl = gl;
-    sv.lidar_xy = p->d_lidar_xy; sv.lidar_cnt = p->d_lidar_cnt;
+    sv.lidar_xy = p->d_lidar_xy; sv.lidar_cnt = p->d_lidar_cnt; sv.lidar_meta = p->d_lidar_meta;
     sv.boundary = p->d_boundary; sv.target_xy = p->d_target_xy; sv.target_c = p->d_target_c;
     for (int k = 0; k < 6; ++k) sv.snap[k] = p->d_snap[k];
     sv.snap_ids = p->d_snap_ids;
@@ -1750,6 +1784,8 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
                   (1u << t2d::kIdsActiveShift);
     p->scene_mode = true;
     p->scene_regen = regenerate != 0;
+    if (!p->d_scene_view) T2D_HIP(p, hipMalloc((void**)&p->d_scene_view, sizeof(t2d::SceneView)));
+    T2D_HIP(p, hipMemcpy(p->d_scene_view, &sv, sizeof(sv), hipMemcpyHostToDevice));   // (what the ego step kernel's epilogue reads)
     if ((rc = rebuild_lidar_geo(p))) return rc;
     {  // t2d_reset's remaining columns: wheel speeds start at zero
         for (int f : {T2D_F_OMEGA_F, T2D_F_OMEGA_R}) T2D_HIP(p, hipMemset(p->field_ptr[f], 0, nbytes));
@@ -1980,7 +2016,7 @@ int t2d_download(t2d_pool* p, int32_t f, void* host_dst, size_t nbytes) {
                                             std::to_string(f >= 0 && f < T2D_F_COUNT ? p->field_bytes[f] : 0) + " bytes)");
     T2D_HIP(p, hipSetDevice(p->device));
     T2D_HIP(p, quiesce(p));
-    if (p->chain_failed) return report_chain_failure(p);
+    if (p->chain_failed || p->scene_commit_failed) return report_chain_failure(p);
     T2D_HIP(p, hipMemcpy(host_dst, p->field_ptr[f], nbytes, hipMemcpyDeviceToHost));
     return T2D_OK;
 }
@@ -2007,7 +2043,7 @@ int t2d_sync(t2d_pool* p) {
     if (!p) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));
     T2D_HIP(p, quiesce(p));
-    if (p->chain_failed) return report_chain_failure(p);
+    if (p->chain_failed || p->scene_commit_failed) return report_chain_failure(p);
     return T2D_OK;
 }
 

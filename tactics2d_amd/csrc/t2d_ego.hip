@@ -24,6 +24,7 @@
 // with the exact integrator the two agree bit for bit (tests/test_gpu_ego.py), and with the oracle.
 #include "t2d_geom_dev.h"
 #include "t2d_integrate_dev.h"
+#include "t2d_scene_dev.h"
 
 // s_sleep between two polls of a PIPE progress word, in units of 64 cycles.  A waiting wave shares its SIMD with the wave it
 // waits for: measured on cfg3 / cfg4 / cfg5 / cfg2 (us per step) 0: 8.9 / 6.4 / 9.4 / -; 1: 8.8 / 6.4 / 9.2 / 4.9; 4: 8.6 / 6.5 /
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(PIPE ? 2 * kEgoBlock : kEgoBlock, 2) void ego_step_
     }
 
     // ---------------- status / reward epilogue (collide_kernel phase 3), the group's first lane --------------------
+    bool ended = false;   // (first lane: this step ended the env's episode)
     if (live && l == 0) {
     const int cnt = pre_cnt + 1;  // parking.py:353
     pv.cnt_step[env] = cnt;
@@ -503,7 +505,9 @@ __global__ __launch_bounds__(PIPE ? 2 * kEgoBlock : kEgoBlock, 2) void ego_step_
     if (LOOP) pv.record_ring[(size_t)((pv.record_slot0 + step_k) & (T2D_RECORD_RING - 1)) * (size_t)pv.n_env + env] = recv;
     else pv.record[env] = recv;
     if (PIPE && pv.auto_reset) s_dec[grp] = (terminated || truncated) ? 1u : 0u;   // (read by the integrator wave before it commits)
-    if (pv.auto_reset && (terminated || truncated)) {  // ParkingEnv.reset: state, counters, detector state back to the start
+    ended = terminated || truncated;
+    // (a regenerating pool: the episode continues in another lot -- below, by all the group's lanes -- not at this lot's start)
+    if (pv.auto_reset && ended && (LOOP || !pv.regen)) {  // ParkingEnv.reset: state, counters, detector state back to the start
         // (every snapshot value first, then the stores: as load / store pairs each pair waits for its own memory round trip)
         const double smd = pv.snap_min_dist[env];
         const float r0 = pv.snap[0][idx], r1 = pv.snap[1][idx], r2 = pv.snap[2][idx], r3 = pv.snap[3][idx];
@@ -536,6 +540,15 @@ __global__ __launch_bounds__(PIPE ? 2 * kEgoBlock : kEgoBlock, 2) void ego_step_
         }
     }
     }   // (the group's first lane)
+    if constexpr (!LOOP) {
+        // t2d_parking_scenes(regenerate = 1): an env whose episode ended moves into the lot staged for its next episode, here
+        // instead of in a launch of its own behind the step -- the group's sixteen lanes are the sixteen of
+        // scene::commit_staged (t2d_scene_dev.h); its fence between the loads and the stores also puts the first lane's
+        // epilogue stores (counters, detector state) ahead of the ones that start the new episode
+        if (pv.regen) {   // (uniform)
+            if (__shfl((int)ended, gbase)) scene::commit_staged(pv, *pv.regen, env, l);
+        }
+    }
     if (!LOOP) break;
     if constexpr (PIPE) ego_pipe_post(&s_seq_e[etid >> 6], (uint32_t)step_k + 1u);   // the verdicts first: nobody waits for the stores but this wave
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this trip's stores are in the L2 before the next trip's sc1 loads

@@ -21,6 +21,7 @@
 
 #include "t2d_math.h"
 #include "t2d_pool.h"
+#include "t2d_scene_dev.h"
 
 namespace t2d {
 
@@ -472,14 +473,6 @@ T2D_DEV void store_rec(const SceneArrays& A, size_t at, const SceneRec& r) {
     A.info[at] = r.info;
 }
 
-// fp32 ring -> counter-clockwise fp32 ring, decided like prepare_polys (t2d_api.hip): shoelace of the fp32 values in fp64
-T2D_DEV void ring_ccw_f32(const float* q, float* o) {
-    Quad r;
-    for (int c = 0; c < 8; ++c) r.v[c] = (double)q[c];
-    const Quad n = counter_clockwise(r);
-    for (int c = 0; c < 8; ++c) o[c] = (float)n.v[c];
-}
-
 // What t2d_set_static_geometry / t2d_set_target_areas / t2d_reset / t2d_snapshot would do for env e, written in place:
 // the env's K polygon slots of the workgroup geometry record (dead slots get a box nothing can meet), its lidar ring
 // slots, boundary, target area + area centroid, the ego's state and episode snapshot, the IoU / shaping state.
@@ -492,54 +485,11 @@ T2D_DEV void install_scene(const PoolView& pv, const SceneView& sv, int e, const
     float4* bb = reinterpret_cast<float4*>(rec + gl.off_aabb[0]) + K * el;
     float* xy = reinterpret_cast<float*>(rec + gl.off_xy[0]) + 8 * K * el;
     float4* ledge = reinterpret_cast<float4*>(sv.lidar_xy) + (size_t)e * 4 * K;   // one record per edge
-    for (int k = 0; k < K; ++k) {
-        float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float4 box = make_float4(INFINITY, -INFINITY, INFINITY, -INFINITY);
-        if (k < n_areas) {
-            const float raw[8] = {R.quad[2 * k].x, R.quad[2 * k].y, R.quad[2 * k].z, R.quad[2 * k].w,
-                                  R.quad[2 * k + 1].x, R.quad[2 * k + 1].y, R.quad[2 * k + 1].z, R.quad[2 * k + 1].w};
-            ring_ccw_f32(raw, r);
-            box = make_float4(r[0], r[0], r[1], r[1]);
-            for (int v = 1; v < 4; ++v) {
-                box.x = __builtin_fminf(box.x, r[2 * v]);
-                box.y = __builtin_fmaxf(box.y, r[2 * v]);
-                box.z = __builtin_fminf(box.z, r[2 * v + 1]);
-                box.w = __builtin_fmaxf(box.w, r[2 * v + 1]);
-            }
-        }
-        bb[k] = box;
-        const float4 lo = make_float4(r[0], r[1], r[2], r[3]), hi = make_float4(r[4], r[5], r[6], r[7]);
-        reinterpret_cast<float4*>(xy)[2 * k] = lo;
-        reinterpret_cast<float4*>(xy)[2 * k + 1] = hi;
-        ledge[4 * k] = lo;                                   // (v0, v1)
-        ledge[4 * k + 1] = make_float4(r[2], r[3], r[4], r[5]);   // (v1, v2)
-        ledge[4 * k + 2] = hi;                                   // (v2, v3)
-        ledge[4 * k + 3] = make_float4(r[6], r[7], r[0], r[1]);   // (v3, v0)
-    }
+    for (int k = 0; k < K; ++k) scene::install_quad_slot(bb, xy, ledge, sv.lidar_meta ? sv.lidar_meta + (size_t)e * 4 * K : nullptr, k, k < n_areas, R.quad[2 * k], R.quad[2 * k + 1]);
     sv.lidar_cnt[e] = 4 * n_areas;
     reinterpret_cast<float4*>(sv.boundary)[e] = R.bound;
-    // target area (t2d_set_target_areas): fp32 ring as doubles, counter-clockwise, area centroid
-    float tr[8];
-    const float traw[8] = {R.target[0].x, R.target[0].y, R.target[0].z, R.target[0].w,
-                           R.target[1].x, R.target[1].y, R.target[1].z, R.target[1].w};
-    ring_ccw_f32(traw, tr);
-    double tq[8], area = 0.0, cx = 0.0, cy = 0.0;
-    for (int c = 0; c < 8; ++c) tq[c] = (double)tr[c];
-    for (int i = 0; i < 4; ++i) {
-        const int j = (i + 1) & 3;
-        area += tq[2 * i] * tq[2 * j + 1] - tq[2 * j] * tq[2 * i + 1];
-    }
-    for (int i = 0; i < 4; ++i) {
-        const int j = (i + 1) & 3;
-        const double w = tq[2 * i] * tq[2 * j + 1] - tq[2 * j] * tq[2 * i + 1];
-        cx += (tq[2 * i] + tq[2 * j]) * w;
-        cy += (tq[2 * i + 1] + tq[2 * j + 1]) * w;
-    }
-    cx = cx / (3.0 * area);
-    cy = cy / (3.0 * area);
-    for (int c = 0; c < 8; ++c) sv.target_xy[8 * (size_t)e + c] = tq[c];
-    sv.target_c[2 * (size_t)e] = cx;
-    sv.target_c[2 * (size_t)e + 1] = cy;
+    double cx, cy;
+    scene::install_target(sv, e, R.target[0], R.target[1], cx, cy);
     // ego state + episode snapshot (t2d_reset with speed 0, then t2d_snapshot); one participant per env
     const float fx = (float)R.start[0], fy = (float)R.start[1], fh = (float)R.start[2];
     const float st[6] = {fx, fy, fh, 0.f, 0.f, 0.f};
@@ -605,6 +555,17 @@ __global__ __launch_bounds__(kGenBlock) void parking_scene_kernel(PoolView pv, S
     }
 }
 
+// regenerate = 1 on a pool whose step is not the ego kernel (which commits in its own epilogue): a launch of its own after
+// the step, sixteen lanes per env (scene::commit_staged, t2d_scene_dev.h)
+__global__ __launch_bounds__(256) void scene_commit_kernel(PoolView pv, SceneView sv, int n_env) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int e = gid / scene::kCommitLanes, lane = gid & (scene::kCommitLanes - 1);
+    if (e >= n_env) return;
+    const uchar4 st = reinterpret_cast<const uchar4*>(pv.status)[e];
+    if (!(st.z | st.w)) return;
+    scene::commit_staged(pv, sv, e, lane);
+}
+
 // One lane per env, walking its ring: slot j must hold the episode in (k, k + ring] that is congruent to j, k = the
 // env's current episode; a slot holding anything else was consumed and is generated anew (usually none or one per
 // refill).  Runs on the pool's own stream while the env keeps stepping: `episode` may advance meanwhile, a stale
@@ -635,6 +596,13 @@ __global__ __launch_bounds__(kGenBlock) void scene_refill_kernel(SceneView sv, i
 hipError_t launch_scene_refill(const SceneView& sv, int n_env, hipStream_t s) {
     if (n_env <= 0 || sv.ring <= 0) return hipSuccess;
     hipLaunchKernelGGL(scene_refill_kernel, dim3((n_env + kGenBlock - 1) / kGenBlock), dim3(kGenBlock), 0, s, sv, n_env);
+    return hipGetLastError();
+}
+
+hipError_t launch_scene_commit(const PoolView& v, const SceneView& sv, int n_env, hipStream_t s) {
+    if (n_env <= 0 || sv.ring <= 0) return hipSuccess;
+    const long long threads = (long long)n_env * scene::kCommitLanes;
+    hipLaunchKernelGGL(scene_commit_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, v, sv, n_env);
     return hipGetLastError();
 }
 

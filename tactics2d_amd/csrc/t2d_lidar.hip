@@ -25,7 +25,12 @@ namespace t2d {
 namespace {
 
 constexpr int kLidarBlock = 128;
-constexpr int kLidarQueue = 256;  // (beam, edge) candidates per wave per round
+constexpr int kLidarQueue = 256;  // (beam, edge) candidates per wave per round (LidarView::queue_len: 128 where that buys a workgroup per CU)
+// An edge's beam span in LDS, one word: first beam (12 bits, < n_beams <= 4096) | length + 1 (13 bits, -1 .. n_beams) |
+// "16 + ring" of a front edge with a core (5 bits, else 0: see the occlusion culling below).  0 = nothing to scatter.
+T2D_DEV uint32_t pack_span(int2 sp, int core = 0) { return (uint32_t)sp.x | (uint32_t)(sp.y + 1) << 12 | (uint32_t)core << 25; }
+constexpr int kLidarStaticLds = 104;      // the kernel's __shared__ arrays (culling tables + queue counters)
+constexpr int kLidarLdsPerCu16 = 10240;   // 160 KB / 16 workgroups (8 waves per SIMD of two-wave workgroups)
 
 // What the determinant solve needs of an edge, computed once per edge instead of once per (beam, edge) candidate:
 // d, e, f of the edge's line and the segment's coordinate bounds with the reference's 1e-8 slack already applied --
@@ -164,11 +169,11 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
         const double* e = s_edge_raw + 4 * (size_t)slot;
         return edge_pre(e[0], e[1], e[2], e[3]);
     };
-    int2* const s_span = reinterpret_cast<int2*>(s_edge_raw + (size_t)kSlotDoubles * lv.max_slots);  // [slots] beam span per edge
+    uint32_t* const s_span = reinterpret_cast<uint32_t*>(s_edge_raw + (size_t)kSlotDoubles * lv.max_slots);  // [slots] beam span per edge (pack_span)
     // [n_beams] running minimum per beam as the bit pattern of a non-negative double (monotone), then the wave queues
-    unsigned long long* const s_best = reinterpret_cast<unsigned long long*>(s_span + lv.max_slots);
+    unsigned long long* const s_best = reinterpret_cast<unsigned long long*>(s_span + ((lv.max_slots + 1) & ~1));
     unsigned long long* const s_mask = s_best + lv.n_beams;   // [n_beams] candidate edges (bit q) of the current 64-edge chunk
-    uint32_t* const s_queue = reinterpret_cast<uint32_t*>(s_mask + lv.n_beams);       // [kLidarBlock / 64][kLidarQueue]
+    uint32_t* const s_queue = reinterpret_cast<uint32_t*>(s_mask + lv.n_beams);       // [kLidarBlock / 64][queue_len]
     __shared__ int s_qcount[kLidarBlock / 64];
     // Occlusion culling (short static lists, rings described by lv.edge_meta): per edge q its ring | facing, per ring the
     // bits of its back edges.  A beam that passes through the CORE of a front edge of a ring -- its span less one beam at
@@ -177,10 +182,15 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     // least r_V sin(0.85 beam) sin(gamma) >= 2e-6 m further out (1024 beams) (r_V >= 1 cm the nearer end point's distance, gamma the
     // ring's interior angle there, sin >= 0.05 by the host's choice of rings): the front edge's hit is accepted whenever the
     // back edge's would be, and it is strictly the smaller one -- the back edge's candidate cannot be the beam's minimum
-    // and is dropped before the exact arithmetic.  Bits 32..47 of a beam's candidate word name the rings whose core covers it.
+    // and is dropped before the exact arithmetic.  Lists of <= 48 edges (a generated parking lot's 12 quads): bits 0..47 of a
+    // beam's candidate word are the edges, bits 48..63 name the rings whose core covers it.
     constexpr bool kCull = kPre && !PARTS;
-    __shared__ uint32_t s_back[kCull ? 16 : 1];
-    __shared__ uint8_t s_core[kCull ? 32 : 1];     // per edge of the (single) chunk: 16 + its ring when it is a front edge with a core, else 0
+    constexpr int kCullEdges = 48;
+    // (96 bytes: with 32 slots and 360 beams a workgroup's LDS is within 100 bytes of 160 KB / 16 -- 4096 envs in one round
+    // of workgroups; 80 bytes more here made it 14 per CU and 17.3 -> 22.4 us.)  A front edge's "16 + ring" travels in its
+    // span word instead of a table of its own.
+    __shared__ uint32_t s_back[kCull ? 16 : 1];      // per ring: its back edges among edges 0..31
+    __shared__ uint32_t s_back_hi[kCull ? 8 : 1];    // ... among edges 32..47, two rings per word
     const int env = blockIdx.x;
     const int tid = threadIdx.x;
     const int A = pv.A;
@@ -224,8 +234,9 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     T2D_LMARK(0);
 
     // ---- phase 1a: static polygon edges (vertex v -> next vertex of its ring) ------------------------
-    const bool cull_on = kCull && lv.edge_meta != nullptr && n_static <= 32;   // (workgroup-uniform)
+    const bool cull_on = kCull && lv.edge_meta != nullptr && n_static <= kCullEdges;   // (workgroup-uniform)
     if (kCull && tid < 16) s_back[tid] = 0u;
+    if (kCull && tid < 8) s_back_hi[tid] = 0u;
     uint8_t meta_first = 0xff;
     if (cull_on && tid < n_static) meta_first = lv.edge_meta[v0 + tid];
     for (int q = tid; q < n_static; q += kLidarBlock) {
@@ -235,20 +246,22 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
         const double x2 = cs * (double)ed.z + sn * (double)ed.w + x_off;
         const double y2 = -sn * (double)ed.z + cs * (double)ed.w + y_off;
         put_edge(q, x1, y1, x2, y2);
-        if (cull_on) {   // (n_static <= 32: q == tid)
+        if (cull_on) {   // (n_static <= 48 < kLidarBlock: q == tid)
             int facing = 0;
             const int2 sp = edge_span(x1, y1, x2, y2, lv.max_range, lv.n_beams, &facing);
-            s_span[q] = sp;
             const int ring = meta_first;
-            uint8_t core = 0;
+            int core = 0;
             if (ring != 0xff) {
                 // a front edge has a core when its span is a proper arc of at least three beams
-                if (facing > 0 && sp.y >= 2 && sp.y < lv.n_beams) core = (uint8_t)(16 + ring);
-                if (facing < 0) atomicOr(&s_back[ring], 1u << q);
+                if (facing > 0 && sp.y >= 2 && sp.y < lv.n_beams) core = 16 + ring;
+                if (facing < 0) {
+                    if (q < 32) atomicOr(&s_back[ring], 1u << q);
+                    else atomicOr(&s_back_hi[ring >> 1], 1u << ((q - 32) + 16 * (ring & 1)));
+                }
             }
-            s_core[q] = core;
+            s_span[q] = pack_span(sp, core);
         } else {
-            s_span[q] = edge_span(x1, y1, x2, y2, lv.max_range, lv.n_beams);
+            s_span[q] = pack_span(edge_span(x1, y1, x2, y2, lv.max_range, lv.n_beams));
         }
     }
     // ---- phase 1b: the other participants' boxes (4 edges each; skipped slots get the far edge) -------
@@ -283,8 +296,8 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
                 const double e0 = use ? vx[k] : kFar, e1 = use ? vy[k] : kFar;
                 const double e2 = use ? vx[(k + 1) & 3] : kFar, e3 = use ? vy[(k + 1) & 3] : kFar + 1.0;
                 put_edge(n_static + 4 * j + k, e0, e1, e2, e3);
-                s_span[n_static + 4 * j + k] = use ? edge_span(e0, e1, e2, e3, lv.max_range, lv.n_beams)
-                                                   : make_int2(0, -1);
+                s_span[n_static + 4 * j + k] = pack_span(use ? edge_span(e0, e1, e2, e3, lv.max_range, lv.n_beams)
+                                                             : make_int2(0, -1));
             }
         }
     }
@@ -305,7 +318,8 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     // values).  min over the same set of values: the result does not depend on the evaluation order.
     const double R = lv.max_range;
     const int lane = tid & 63, wave = tid >> 6;
-    uint32_t* const queue = s_queue + wave * kLidarQueue;
+    const int queue_len = lv.queue_len;
+    uint32_t* const queue = s_queue + wave * queue_len;
     int* const qcount = &s_qcount[wave];
     auto wave_sync = [] {   // LDS traffic of this wave only: its LDS operations complete in order (see t2d_collide.hip)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -328,16 +342,15 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
             // phase is bound by its longest dependent chain, not by the number of atomics.)
             constexpr int kLongSpan = 24;
             const int q = tid >> 1;
-            int2 sp = make_int2(0, -1);
-            if (c0 + q < n_slots) sp = s_span[c0 + q];
+            uint32_t spw = 0u;
+            if (c0 + q < n_slots) spw = s_span[c0 + q];
+            const int2 sp = make_int2((int)(spw & 0xfffu), (int)((spw >> 12) & 0x1fffu) - 1);
+            const int cr = cull_on ? (int)(spw >> 25) : 0;   // (see s_back: a front edge's ring rides in its span word)
             const int last = sp.y < lv.n_beams ? sp.y : lv.n_beams - 1;   // sp.y = -1: invisible
             const bool is_long = last >= kLongSpan;
             // beams i = 1 .. last - 1 of a front edge's span are its core: they also get the bit of its ring
             unsigned long long core_bit = 0ull;
-            if (cull_on && c0 + q < n_slots) {
-                const int cr = s_core[q];
-                if (cr) core_bit = 1ull << (32 + (cr & 15));
-            }
+            if (cr) core_bit = 1ull << (kCullEdges + (cr & 15));
             if (!is_long) {
                 for (int i = tid & 1; i <= last; i += 2) {
                     int kb = sp.x + i;
@@ -366,21 +379,22 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
             const int k = tid + it * kLidarBlock;
             unsigned long long m = k < lv.n_beams ? s_mask[k] : 0ull;
             if (cull_on) {   // drop the back edges of every ring whose core covers this beam (see s_back above)
-                uint32_t cov = (uint32_t)(m >> 32) & 0xffffu, cull = 0u;
+                uint32_t cov = (uint32_t)(m >> kCullEdges);
+                unsigned long long cull = ~((1ull << kCullEdges) - 1ull);
                 while (cov) {
                     const int r = __ffs((int)cov) - 1;
                     cov &= cov - 1u;
-                    cull |= s_back[r];
+                    cull |= (unsigned long long)s_back[r] | (unsigned long long)((s_back_hi[r >> 1] >> (16 * (r & 1))) & 0xffffu) << 32;
                 }
-                m = (unsigned long long)((uint32_t)m & ~cull);
+                m &= ~cull;
             }
             for (;;) {  // compaction rounds (all 64 lanes take part)
                 const int cnt = __popcll(m);
                 if (__ballot(cnt > 0) == 0ull) break;
                 if (lane == 0) *qcount = 0;
                 wave_sync();
-                const int off = cnt > 0 ? atomicAdd(qcount, cnt) : kLidarQueue;
-                const int room = kLidarQueue - off;
+                const int off = cnt > 0 ? atomicAdd(qcount, cnt) : queue_len;
+                const int room = queue_len - off;
                 const int n_emit = room <= 0 ? 0 : (cnt < room ? cnt : room);
                 for (int e = 0; e < n_emit; ++e) {
                     const int q = __ffsll((long long)m) - 1;
@@ -389,7 +403,7 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
                 }
                 wave_sync();
                 const int total = *qcount;
-                const int n_round = total < kLidarQueue ? total : kLidarQueue;
+                const int n_round = total < queue_len ? total : queue_len;
                 for (int j = lane; j < n_round; j += 64) {
                     const uint32_t en = queue[j];
                     const int kb = (int)(en & 0xffffu), q = (int)(en >> 16);
@@ -421,10 +435,19 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
 
 }  // namespace
 
-hipError_t launch_lidar(const PoolView& v, const LidarView& lv, float* out, hipStream_t s) {
+hipError_t launch_lidar(const PoolView& v, const LidarView& lv_in, float* out, hipStream_t s) {
+    LidarView lv = lv_in;
     const bool short_list = lv.max_slots <= 64;   // EdgePre records (64 B) for short lists, end points (32 B) otherwise
-    const size_t dyn = ((short_list ? sizeof(EdgePre) : 4 * sizeof(double)) + sizeof(int2)) * (size_t)lv.max_slots +
-                       16 * (size_t)lv.n_beams + 4 * (size_t)kLidarQueue * (kLidarBlock / 64);
+    auto lds = [&](int queue_len) {
+        return (short_list ? sizeof(EdgePre) : 4 * sizeof(double)) * (size_t)lv.max_slots + 4 * (size_t)((lv.max_slots + 1) & ~1) +
+               16 * (size_t)lv.n_beams + 4 * (size_t)queue_len * (kLidarBlock / 64);
+    };
+    // a generated parking lot's 48 edge slots: half the queue (one more compaction round now and then) keeps the workgroup
+    // within a sixteenth of the CU's LDS -- 4096 envs resident at once instead of 3584 and a second round
+    lv.queue_len = kLidarQueue;
+    if (short_list && lds(kLidarQueue) + kLidarStaticLds > kLidarLdsPerCu16 && lds(kLidarQueue / 2) + kLidarStaticLds <= kLidarLdsPerCu16)
+        lv.queue_len = kLidarQueue / 2;
+    const size_t dyn = lds(lv.queue_len);
     // (the scan of static obstacles only -- ParkingEnv -- is compiled without the participants' phase: at the 64
     // registers of 8 waves / SIMD that code cost the whole kernel 27 spilled registers, reloaded in the evaluation loop)
     if (short_list && !lv.include_participants)

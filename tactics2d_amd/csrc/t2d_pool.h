@@ -48,6 +48,7 @@ constexpr int kSafeRects = 4;   // per env
 
 // What kernels receive by value.
 struct LidarView;
+struct SceneView;
 struct PoolView {
     int32_t n_env, A, N;
     float *x, *y, *heading, *speed, *vx, *vy, *applied0, *applied1;
@@ -122,6 +123,7 @@ struct PoolView {
     int32_t* idm_leader;
     float *idm_act0_own, *idm_act1_own;
     int32_t idm_n_ctrl;
+    const SceneView* regen;   // ego step kernel, regenerating pool: the device copy of the pool's SceneView, else null
     double interval_s;        // (double)interval_ms / 1000 of this launch (PointMass's dt), divided once by the host
     unsigned long long* dbg;  // phase cycle accumulators (profiling builds with -DT2D_TIMING only)
     double cell;      // spatial-hash cell edge (m) >= max circum-diameter * 1.001
@@ -134,13 +136,14 @@ struct LidarView {
     const int32_t* env_vert_cnt;  // null, or [E] vertices in use when envs own fixed-capacity ranges (generated scenes)
     const float* xy;              // [V][4] one record per polygon EDGE: x1, y1, x2, y2 (vertex v -> next vertex of its ring)
     // [V] per edge: index (0..15) of its ring among its env's rings when the ring may take part in the occlusion culling of
-    // the scan (CCW, convex, every interior angle with sin >= 0.05, <= 16 rings and <= 32 edges in the env), else 0xff; or null
+    // the scan (CCW, convex, every interior angle with sin >= 0.05, <= 16 rings and <= 48 edges in the env), else 0xff; or null
     const uint8_t* edge_meta;
     const double* beam_pre;       // [n_beams][6] per beam: a = sin, b = -cos of linspace(0, 2pi, n, endpoint=False)[k]
                                   // (lidar.py:161-162) and the four slack-widened bounds of its end point (x hi / lo, y hi / lo)
     double max_range;
     int32_t n_beams, include_participants, ego_index, max_static_verts;
     int32_t max_slots;  // LDS edge slots per env: max_static_verts + 4 * max_agents (when participants are scanned)
+    int32_t queue_len;  // (set by launch_lidar) candidates per wave and compaction round
 };
 
 // Device-side ParkingLotGenerator (t2d_generate.hip): stream parameters, the per-scene output arrays and -- when the
@@ -162,6 +165,8 @@ struct SceneView {
     uint32_t* geo;        // the pool's geometry records (capacity layout)
     GeoLayout gl;
     float* lidar_xy; int32_t* lidar_cnt;
+    uint8_t* lidar_meta;  // [n_env][4 * T2D_GEN_MAX_QUADS] per edge: its ring's slot when the ring may take part in the scan's occlusion culling, else 0xff
+    uint32_t* commit_err; // sticky: an env whose episode ended found no staged scene (scene_commit_kernel)
     float* boundary; double* target_xy; double* target_c;
     float* snap[6]; uint32_t* snap_ids; uint32_t ids_word;
     double* snap_min_dist;
@@ -249,6 +254,10 @@ struct t2d_pool {
     hipStream_t scene_stream = nullptr;   // staged scenes are refilled here, off the step's stream
     hipEvent_t ev_scene_commit = nullptr, ev_scene_refill = nullptr;
     bool scene_refill_pending = false;
+    bool scene_commit_failed = false;
+    bool scene_committed_in_step = false;   // the last step launch was the ego kernel with the commit in its epilogue
+    t2d::SceneView* d_scene_view = nullptr;
+    bool scene_commit_used = false;   // a commit launch since the last host synchronisation (its sticky error word is read then)
     int32_t* d_lidar_cnt = nullptr;
     long long step_count = 0;  // t2d_step calls so far (selects the record ring slot)
     int derived_interval = -1; // the interval_ms column T2D_P_SUBSTEPS of the device table was derived for (-1: none yet)
@@ -324,4 +333,6 @@ void pool_touch(t2d_pool* p, hipStream_t s);
 bool split_eligible(const PoolView& v, const t2d_status_config& cfg, int log2A, int device_cus);
 hipError_t launch_parking_scenes(const PoolView& v, const SceneView& sv, int n_env, int mode, hipStream_t s);
 hipError_t launch_scene_refill(const SceneView& sv, int n_env, hipStream_t s);
+// regenerate = 1: envs whose episode just ended take the scene staged for their next one, sixteen lanes per env
+hipError_t launch_scene_commit(const PoolView& v, const SceneView& sv, int n_env, hipStream_t s);
 }  // namespace t2d

@@ -365,6 +365,50 @@ def test_scene_regeneration_follows_the_episode_streams(oracle, auto_reset, mode
     pool.close()
 
 
+@pytest.mark.gpu
+def test_staged_scenes_survive_the_shortest_episodes_in_a_row(oracle):
+    """The staging ring holds 16 episodes per env and is topped up every 4 steps (t2d_api.hip regenerate_done_scenes).  The
+    shortest episode the status rules allow in a generated lot is two steps (max_step = 1: cnt_step > max_step at the second
+    step, parking.py:271; the no-action detector needs a previous pose as well, and the generator rules out a start in
+    collision): EVERY env ends an episode at EVERY second step, for three times round the ring, with host synchronisation
+    only now and then (the refill stream runs behind the steps).  Every commit (sixteen lanes per env, scene_commit_kernel)
+    is checked field for field against the oracle's scene of that episode's stream, the lidar edges and their culling bytes
+    through a scan against the oracle's on the same lot."""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.generator import ParkingLotGenerator
+    n_env, seed, size, first, stride = 96, 5, (4.284, 1.81), 40, 1000
+    scenes = ParkingLotGenerator(size, 0.5).generate(n_env, seed, first_env=first)
+    sc = scenes.scene(max_step=1)
+    pool = _pool_for(sc, n_env)
+    pool.parking_scenes(seed, 0.5, size, regenerate=True, first_env=first, env_stride=stride)
+    pool.lidar_config(120, 20.0, False)
+    parked = np.zeros(n_env, np.float32)
+    for step in range(1, 101):
+        pool.set_actions(parked, parked)
+        pool.step(100)
+        if step % 14 and step < 96:
+            continue
+        status = pool.download(L.F_STATUS)
+        assert (status[:, 2] | status[:, 3]).astype(bool).all() == (step % 2 == 0)
+        cur = pool.get_parking_scenes()
+        assert (cur.episode == step // 2).all()
+        for e in range(n_env):
+            want = oracle.generate_parking(seed, 1, 0.5, size, first_env=first + e + (step // 2) * stride, trig=1)
+            for key in ("start", "quads", "quad_id", "n_quads", "target", "target_heading", "boundary", "info"):
+                assert np.array_equal(getattr(cur, key)[e], want[key][0]), (step, e, key)
+        gx, gy, gh = (pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING))
+        assert np.array_equal(gx, cur.start[:, 0].astype(np.float32)) and np.array_equal(gy, cur.start[:, 1].astype(np.float32))
+        if step % 2 == 0:                               # (a stepped heading is wrapped into [0, 2 pi), the start's is as generated)
+            assert np.array_equal(gh, cur.start[:, 2].astype(np.float32))
+        assert (pool.download(L.F_CNT_STEP) == step % 2).all() and (pool.download(L.F_SPEED) == 0).all()
+        # the lidar edges (and their culling bytes) the commit wrote: the scan equals the oracle's brute force on the same lots
+        pool.lidar_scan()
+        got = pool.download(L.F_LIDAR)
+        ref = oracle.lidar(sc.rows, n_env, 1, 0, gx, gy, gh, sc.type_id, sc.active, cur.static_csr(), 0, 120, 20.0, trig=0)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), step
+    pool.close()
+
+
 class ParkingScenesSubset:
     """Rows `idx` of a ParkingScenes as the CSR / boundary arguments of the oracle."""
 

@@ -101,9 +101,10 @@ def test_gpu_lidar_is_bit_identical_to_the_oracle(oracle, scene, part):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("extent,n_static,beams,rng_max", [((24.0, 16.0), 8, 360, 20.0), ((5.0, 4.0), 7, 360, 20.0),
-                                                          ((2.0, 2.0), 6, 1024, 12.0), ((40.0, 24.0), 5, 90, 35.0)])
+                                                          ((2.0, 2.0), 6, 1024, 12.0), ((40.0, 24.0), 5, 90, 35.0),
+                                                          ((24.0, 16.0), 12, 360, 20.0), ((6.0, 5.0), 11, 1024, 15.0)])
 def test_gpu_lidar_occlusion_culling_is_bit_identical(oracle, extent, n_static, beams, rng_max):
-    """Static-only scans of <= 32 edges drop the back edges of a ring for the beams that pass through the core of one of
+    """Static-only scans of <= 48 edges (a generated parking lot's 12 quads) drop the back edges of a ring for the beams that pass through the core of one of
     its front edges (t2d_lidar.hip): same bits as the oracle's brute force -- quads and 3..8-gons of either winding, cramped
     scenes with vertices centimetres from the sensor (edges then count as neither front nor back), sensors inside obstacles."""
     import helpers as H
