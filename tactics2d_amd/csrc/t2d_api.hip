@@ -1734,7 +1734,7 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
     const size_t per[8] = {(size_t)K * 8 * sizeof(float), (size_t)K * sizeof(int32_t), sizeof(int32_t), 3 * sizeof(double),
                            8 * sizeof(float), sizeof(double), 4 * sizeof(float), sizeof(uint32_t)};
     const size_t counts[2] = {(size_t)E, (size_t)E * ring};
-    size_t off[19], total = 0;
+    size_t off[21], total = 0;
     for (int set = 0; set < 2; ++set)
         for (int k = 0; k < 8; ++k) {
             off[8 * set + k] = total;
@@ -1743,6 +1743,8 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
     off[16] = total; total += ((size_t)E * sizeof(int32_t) + 255) & ~(size_t)255;          // episode
     off[17] = total; total += ((size_t)E * ring * sizeof(int32_t) + 255) & ~(size_t)255;   // staged_ep
     off[18] = total; total += 256;                                                         // commit_err
+    off[19] = total; total += 256;                                                         // refill_count
+    off[20] = total; total += ((size_t)E * ring * sizeof(uint2) + 255) & ~(size_t)255;     // refill_list
     if (p->scene_stream) T2D_HIP(p, hipStreamSynchronize(p->scene_stream));
     if (p->d_scene_arrays) {
         T2D_HIP(p, hipFree(p->d_scene_arrays));
@@ -1765,6 +1767,8 @@ int t2d_parking_scenes(t2d_pool* p, uint64_t seed, int64_t first_env, int64_t en
     sv.episode = (int32_t*)(base + off[16]);
     sv.staged_ep = (int32_t*)(base + off[17]);
     sv.commit_err = (uint32_t*)(base + off[18]);
+    sv.refill_count = (uint32_t*)(base + off[19]);
+    sv.refill_list = (uint2*)(base + off[20]);
     p->scene_commit_used = p->scene_commit_failed = false;
     sv.ring = ring;
     if (ring > 0) {

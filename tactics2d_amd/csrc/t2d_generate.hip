@@ -566,28 +566,40 @@ __global__ __launch_bounds__(256) void scene_commit_kernel(PoolView pv, SceneVie
     scene::commit_staged(pv, sv, e, lane);
 }
 
-// One lane per env, walking its ring: slot j must hold the episode in (k, k + ring] that is congruent to j, k = the
-// env's current episode; a slot holding anything else was consumed and is generated anew (usually none or one per
-// refill).  Runs on the pool's own stream while the env keeps stepping: `episode` may advance meanwhile, a stale
-// (smaller) k only postpones a slot to the next refill, and a slot rewritten here is `ring` episodes away from the one
-// the step stream reads next.  n_env / 64 waves: next to nothing beside the step kernel it overlaps with.
-__global__ __launch_bounds__(kGenBlock) void scene_refill_kernel(SceneView sv, int n_env) {
-    const int e = blockIdx.x * kGenBlock + threadIdx.x;
-    if (e >= n_env) return;
+// Topping up the staging ring, on the pool's own stream while the env keeps stepping.  Slot j of env e must hold the
+// episode in (k, k + ring] that is congruent to j, k = the env's current episode; a slot holding anything else was consumed
+// and is generated anew.  `episode` may advance meanwhile: a stale (smaller) k only postpones a slot to the next refill, and
+// a slot rewritten here is `ring` episodes away from the one the step stream reads next.
+// Two launches: the SCAN (one lane per slot, a few loads) appends the slots that need a scene to a list; the GENERATOR walks
+// the list, one lane per scene.  In the steady state a few per cent of the envs finish an episode between two refills: one
+// lane per ENV kept all n_env / 64 workgroups busy for a whole scene (46 us, 110 KB of LDS each: a quarter of the CUs with
+// room for 4 instead of 16 lidar workgroups while the steps went on beside it) for two or three useful lanes per wave; the
+// list fills whole waves instead, and the workgroups without work leave at once.
+__global__ __launch_bounds__(256) void scene_refill_scan_kernel(SceneView sv, int n_env) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n_env * sv.ring) return;
+    const int e = gid / sv.ring, j = gid - e * sv.ring;
+    const int k = sv.episode[e];
+    const int want = k + 1 + ((j - (k + 1)) % sv.ring + sv.ring) % sv.ring;
+    if (sv.staged_ep[gid] == want) return;
+    sv.refill_list[atomicAdd(sv.refill_count, 1u)] = make_uint2((uint32_t)gid, (uint32_t)want);
+}
+
+__global__ __launch_bounds__(kGenBlock) void scene_refill_kernel(SceneView sv) {
+    const uint32_t n = *sv.refill_count;
+    if (blockIdx.x * kGenBlock >= n) return;
     __shared__ double s_q[kListCap * 8 * kGenBlock];
     __shared__ int s_i[(kListCap + 2 * T2D_GEN_MAX_QUADS) * kGenBlock];
     const LaneMem m{s_q + threadIdx.x, s_i + threadIdx.x, s_i + kListCap * kGenBlock + threadIdx.x,
                     s_i + (kListCap + T2D_GEN_MAX_QUADS) * kGenBlock + threadIdx.x};
-    const int k = sv.episode[e];
-    for (int j = 0; j < sv.ring; ++j) {
-        const size_t i = (size_t)e * sv.ring + j;
-        const int want = k + 1 + ((j - (k + 1)) % sv.ring + sv.ring) % sv.ring;
-        if (sv.staged_ep[i] == want) continue;
+    for (uint32_t i = blockIdx.x * kGenBlock + threadIdx.x; i < n; i += gridDim.x * kGenBlock) {
+        const uint2 item = sv.refill_list[i];
+        const int e = (int)item.x / sv.ring, want = (int)item.y;
         SceneHead sc;
         make_scene(sv.seed, sv.first_env + e + (int64_t)want * sv.env_stride, sv.type_proportion, sv.len, sv.wid, m, sc);
-        store_scene(sv.staged, i, m, sc);
+        store_scene(sv.staged, item.x, m, sc);
         __threadfence();
-        sv.staged_ep[i] = want;
+        sv.staged_ep[item.x] = want;
     }
 }
 
@@ -595,7 +607,12 @@ __global__ __launch_bounds__(kGenBlock) void scene_refill_kernel(SceneView sv, i
 
 hipError_t launch_scene_refill(const SceneView& sv, int n_env, hipStream_t s) {
     if (n_env <= 0 || sv.ring <= 0) return hipSuccess;
-    hipLaunchKernelGGL(scene_refill_kernel, dim3((n_env + kGenBlock - 1) / kGenBlock), dim3(kGenBlock), 0, s, sv, n_env);
+    hipError_t e = hipMemsetAsync(sv.refill_count, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    const long long slots = (long long)n_env * sv.ring;
+    hipLaunchKernelGGL(scene_refill_scan_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, sv, n_env);
+    // (as many workgroups as one scene per env needs: more work than that -- the first fill -- goes round in the kernel's loop)
+    hipLaunchKernelGGL(scene_refill_kernel, dim3((n_env + kGenBlock - 1) / kGenBlock), dim3(kGenBlock), 0, s, sv);
     return hipGetLastError();
 }
 

@@ -379,14 +379,14 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
             const int k = tid + it * kLidarBlock;
             unsigned long long m = k < lv.n_beams ? s_mask[k] : 0ull;
             if (cull_on) {   // drop the back edges of every ring whose core covers this beam (see s_back above)
-                uint32_t cov = (uint32_t)(m >> kCullEdges);
-                unsigned long long cull = ~((1ull << kCullEdges) - 1ull);
+                uint32_t cov = (uint32_t)(m >> kCullEdges), cull_lo = 0u, cull_hi = 0xffff0000u;   // (the ring bits go in any case)
                 while (cov) {
                     const int r = __ffs((int)cov) - 1;
                     cov &= cov - 1u;
-                    cull |= (unsigned long long)s_back[r] | (unsigned long long)((s_back_hi[r >> 1] >> (16 * (r & 1))) & 0xffffu) << 32;
+                    cull_lo |= s_back[r];
+                    if (n_static > 32) cull_hi |= (s_back_hi[r >> 1] >> (16 * (r & 1))) & 0xffffu;   // (workgroup-uniform)
                 }
-                m &= ~cull;
+                m &= ~((unsigned long long)cull_hi << 32 | cull_lo);
             }
             for (;;) {  // compaction rounds (all 64 lanes take part)
                 const int cnt = __popcll(m);

@@ -161,6 +161,8 @@ struct SceneView {
     SceneArrays staged;   // [n_env * ring] scenes of coming episodes (episode k of env e in slot k % ring), or nulls
     int32_t ring;         // staged scenes per env (0 = none: regeneration generates on the step's stream)
     int32_t* staged_ep;   // [n_env * ring] episode number held by each staged slot (-1 = empty)
+    uint2* refill_list;   // [n_env * ring] {staged slot, episode to generate for it} found by a refill's scan; refill_count[0] of them
+    uint32_t* refill_count;
     int32_t* episode;     // [n_env]
     uint32_t* geo;        // the pool's geometry records (capacity layout)
     GeoLayout gl;
