@@ -480,9 +480,13 @@ int t2d_generate_parking(int32_t device_id, uint64_t seed, int64_t first_env, in
  * t2d_check_status is followed, on the same stream, by a launch that gives each env whose episode just ended
  * (terminated | truncated) the scene of its next episode -- the reference's reset() per episode -- while the terminal
  * status / reward stay readable until the next step; kernel_id 6 in t2d_profile_read.  regenerate = 1: the scenes of
- * the next 16 episodes of every env are kept staged in HBM and topped up every 4 steps on a stream owned by the pool,
- * so the launch on the step's stream only copies (a scene is a ~46 us single-lane chain; an env that outruns its
- * staging ring falls back to generating in place -- results never depend on timing); regenerate = 2: no staging,
+ * the next 16 episodes of every env are kept staged in HBM and topped up every 4 steps on a stream owned by the pool
+ * (a scene is a ~46 us single-lane chain), so the step's stream only copies: sixteen lanes per finished env, in the
+ * epilogue of the ego step kernel itself when that is the pool's step (no launch behind it, no kernel_id 6 then),
+ * else in a launch of their own.  The shortest episode the status rules allow is two steps, the ring holds sixteen and
+ * the step stream waits for the refill before last: an env cannot outrun its ring.  Should one ever find its slot
+ * unstaged it keeps its lot, and the next t2d_sync / t2d_download / t2d_step_n returns T2D_ERR_STATE (once; call
+ * t2d_parking_scenes again) -- results never depend on timing.  regenerate = 2: no staging,
  * scenes are generated on the step's stream.  Geometry lives in a
  * fixed-capacity layout (T2D_GEN_MAX_QUADS polygon slots per env); t2d_set_static_geometry leaves this mode.
  * t2d_get_parking_scenes copies the current scenes (arrays as in t2d_generate_parking, any pointer may be NULL) and
