@@ -366,20 +366,23 @@ def test_scene_regeneration_follows_the_episode_streams(oracle, auto_reset, mode
 
 
 @pytest.mark.gpu
-def test_staged_scenes_survive_the_shortest_episodes_in_a_row(oracle):
+@pytest.mark.parametrize("ego_kernel", [True, False])
+def test_staged_scenes_survive_the_shortest_episodes_in_a_row(oracle, ego_kernel):
     """The staging ring holds 16 episodes per env and is topped up every 4 steps (t2d_api.hip regenerate_done_scenes).  The
     shortest episode the status rules allow in a generated lot is two steps (max_step = 1: cnt_step > max_step at the second
     step, parking.py:271; the no-action detector needs a previous pose as well, and the generator rules out a start in
     collision): EVERY env ends an episode at EVERY second step, for three times round the ring, with host synchronisation
     only now and then (the refill stream runs behind the steps).  Every commit (sixteen lanes per env, scene_commit_kernel)
     is checked field for field against the oracle's scene of that episode's stream, the lidar edges and their culling bytes
-    through a scan against the oracle's on the same lot."""
+    through a scan against the oracle's on the same lot.  ego_kernel: the commit in the ego step kernel's epilogue, or -- the
+    pool kept on the general step kernel -- the same device function in a launch of its own behind the step."""
     from tactics2d_amd import layout as L
     from tactics2d_amd.generator import ParkingLotGenerator
     n_env, seed, size, first, stride = 96, 5, (4.284, 1.81), 40, 1000
     scenes = ParkingLotGenerator(size, 0.5).generate(n_env, seed, first_env=first)
     sc = scenes.scene(max_step=1)
     pool = _pool_for(sc, n_env)
+    pool.set_ego_kernel(ego_kernel)
     pool.parking_scenes(seed, 0.5, size, regenerate=True, first_env=first, env_stride=stride)
     pool.lidar_config(120, 20.0, False)
     parked = np.zeros(n_env, np.float32)
