@@ -22,7 +22,11 @@ for seed in range(n_seeds):
             # <= 32 edges, static only: the scan drops back edges behind a front edge of their ring (occlusion culling)
             (48, 1, (24.0, 16.0), dict(n_static=8, n_lanes=0), 360, 20.0, False),
             (36, 1, (5.0, 4.0), dict(n_static=7, n_lanes=0), 360, 20.0, False),
-            (36, 1, (2.0, 2.0), dict(n_static=6, n_lanes=0), 1024, 12.0, False)]:
+            (36, 1, (2.0, 2.0), dict(n_static=6, n_lanes=0), 1024, 12.0, False),
+            # 33 .. 48 edges (a generated parking lot's 9 .. 12 quads): culled since round 4, edge bits 0..47 + ring bits 48..63
+            (36, 1, (24.0, 16.0), dict(n_static=11, n_lanes=0), 360, 20.0, False),
+            (36, 1, (4.0, 3.0), dict(n_static=12, n_lanes=0), 1024, 12.0, False),
+            (36, 1, (8.0, 6.0), dict(n_static=9, n_lanes=0), 720, 20.0, False)]:
         rng = np.random.default_rng(7000 * seed + n_env * 100 + A)
         sc = H.random_scene(rng, n_env, A, extent, **kw)
         pool = ParticipantPool(n_env, A)
