@@ -217,10 +217,25 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     // ego's loads + sincos instead of following them (one record per edge: no vertex -> next-vertex indirection)
     int n_static = 0, v0 = 0;
     float4 first_edge = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lv.env_vert_off) {
+    const bool cull_maybe = kPre && !PARTS && lv.edge_meta != nullptr;
+    uint8_t meta_first = 0xff;
+    if (lv.env_vert_cnt) {
+        // capacity layout (generated parking lots): env e owns slots [e * max_static_verts, ...), unused ones hold zeros --
+        // the edge and its culling byte are fetched beside the count, not behind it (one dependent load less at the front
+        // of a chain every workgroup of the launch waits through at the same time)
+        v0 = env * lv.max_static_verts;
+        if (tid < lv.max_static_verts) {
+            first_edge = reinterpret_cast<const float4*>(lv.xy)[v0 + tid];
+            if (cull_maybe) meta_first = lv.edge_meta[v0 + tid];
+        }
+        n_static = lv.env_vert_cnt[env];
+    } else if (lv.env_vert_off) {
         v0 = lv.env_vert_off[env];
-        n_static = lv.env_vert_cnt ? lv.env_vert_cnt[env] : lv.env_vert_off[env + 1] - v0;
-        if (tid < n_static) first_edge = reinterpret_cast<const float4*>(lv.xy)[v0 + tid];
+        n_static = lv.env_vert_off[env + 1] - v0;
+        if (tid < n_static) {
+            first_edge = reinterpret_cast<const float4*>(lv.xy)[v0 + tid];
+            if (cull_maybe) meta_first = lv.edge_meta[v0 + tid];
+        }
     }
     // the ego transform, by every lane for itself: the same instructions whether one lane or sixty-four execute them, and
     // no LDS hand-over + workgroup barrier before the first edge can be transformed
@@ -237,8 +252,6 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     const bool cull_on = kCull && lv.edge_meta != nullptr && n_static <= kCullEdges;   // (workgroup-uniform)
     if (kCull && tid < 16) s_back[tid] = 0u;
     if (kCull && tid < 8) s_back_hi[tid] = 0u;
-    uint8_t meta_first = 0xff;
-    if (cull_on && tid < n_static) meta_first = lv.edge_meta[v0 + tid];
     for (int q = tid; q < n_static; q += kLidarBlock) {
         const float4 ed = q == tid ? first_edge : reinterpret_cast<const float4*>(lv.xy)[v0 + q];
         const double x1 = cs * (double)ed.x + sn * (double)ed.y + x_off;
