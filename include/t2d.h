@@ -480,7 +480,7 @@ int t2d_generate_parking(int32_t device_id, uint64_t seed, int64_t first_env, in
  * t2d_check_status is followed, on the same stream, by a launch that gives each env whose episode just ended
  * (terminated | truncated) the scene of its next episode -- the reference's reset() per episode -- while the terminal
  * status / reward stay readable until the next step; kernel_id 6 in t2d_profile_read.  regenerate = 1: the scenes of
- * the next 16 episodes of every env are kept staged in HBM and topped up every 4 steps on a stream owned by the pool
+ * the next 16 episodes of every env are kept staged in HBM and topped up every 8 steps on a stream owned by the pool
  * (a scene is a ~46 us single-lane chain), so the step's stream only copies: sixteen lanes per finished env, in the
  * epilogue of the ego step kernel itself when that is the pool's step (no launch behind it, no kernel_id 6 then),
  * else in a launch of their own.  The shortest episode the status rules allow is two steps, the ring holds sixteen and

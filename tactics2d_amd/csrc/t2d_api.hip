@@ -1334,13 +1334,16 @@ int t2d_collide(t2d_pool* p, void* hip_stream) {
     return collide_impl(p, false, 0, (hipStream_t)hip_stream);
 }
 
-// generated parking scenes with regeneration on: envs whose episode ended in the launch just enqueued move on to
-// their next scene (one cheap launch on the step's stream: staged scenes are copied in); every kSceneRefillPeriod
-// steps the staging ring is topped up on the pool's own stream, off the critical path -- one scene is a ~46 us
-// single-lane chain.  A slot rewritten by a refill is not read by the step stream before `ring` - 1 further episodes of
-// that env (>= 2 steps each), and the step stream waits for the previous refill before the next one is launched.
+// generated parking scenes with regeneration on: envs whose episode ended in the launch just enqueued move on to their next
+// scene -- in that launch's own epilogue (ego step kernel) or in one cheap launch on the step's stream: staged scenes are
+// copied in; every kSceneRefillPeriod steps the staging ring is topped up on the pool's own stream, off the critical path
+// (one scene is a ~46 us single-lane chain).  The step stream waits for refill j before it launches refill j + 1, so the
+// commits of steps [8 j, 8 j + 8) rely on refill j - 1 alone: it staged the 16 episodes past what it read at step >= 8 j - 8,
+// and an env ends at most one episode in two steps -- 8 episodes by step 8 j + 8: half the ring is margin.  A slot a refill
+// rewrites held an episode the env has left.  (Period 4 until round 4: the event wait + the side stream's three launches
+// cost the step stream ~1 us per step on average, 36.2 -> 35.0 us per ParkingEnv vector step with period 8.)
 constexpr int kSceneRing = 16;
-constexpr int kSceneRefillPeriod = 4;
+constexpr int kSceneRefillPeriod = 8;
 static int regenerate_done_scenes(t2d_pool* p, hipStream_t s) {
     if (!p->scene_regen) return T2D_OK;
     int rc;

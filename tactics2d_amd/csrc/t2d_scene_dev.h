@@ -99,7 +99,7 @@ T2D_DEV void install_target(const SceneView& sv, int e, float4 t_lo, float4 t_hi
 // same values), as two memory round trips of plain copies instead of one lane's chain of four dependent round trips and
 // twelve serial quads -- and without the in-place generator next to it: that path (make_scene: 402 registers, 110 KB of LDS
 // per 64 lanes) held parking_scene_kernel to one block per CU.  An env that finds no staged scene for its episode -- by
-// construction of the ring impossible (16 slots, topped up every 4 steps, at most one episode per step: t2d_api.hip
+// construction of the ring impossible (16 slots, topped up every 8 steps, at most one episode per two steps: t2d_api.hip
 // regenerate_done_scenes) -- raises a sticky error word the host reports at its next synchronisation, and keeps its scene.
 constexpr int kCommitLanes = 16;
 // lane = 0 .. 15 of env e's group, called by all sixteen (the caller has established that e's episode just ended)

@@ -368,7 +368,7 @@ def test_scene_regeneration_follows_the_episode_streams(oracle, auto_reset, mode
 @pytest.mark.gpu
 @pytest.mark.parametrize("ego_kernel", [True, False])
 def test_staged_scenes_survive_the_shortest_episodes_in_a_row(oracle, ego_kernel):
-    """The staging ring holds 16 episodes per env and is topped up every 4 steps (t2d_api.hip regenerate_done_scenes).  The
+    """The staging ring holds 16 episodes per env and is topped up every 8 steps (t2d_api.hip regenerate_done_scenes).  The
     shortest episode the status rules allow in a generated lot is two steps (max_step = 1: cnt_step > max_step at the second
     step, parking.py:271; the no-action detector needs a previous pose as well, and the generator rules out a start in
     collision): EVERY env ends an episode at EVERY second step, for three times round the ring, with host synchronisation
