@@ -7,7 +7,8 @@ from tactics2d_amd.envs import VecParkingEnv
 dev = torch.device("cuda", 0)
 sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [4096, 32768]
 short = "short" in sys.argv   # counter passes: a few dozen steps are enough
-for n, source in [(n_, s_) for n_ in sizes for s_ in ("layout", "generator")]:
+sources = [a for a in sys.argv[1:] if a in ("layout", "generator")] or ["layout", "generator"]   # (one source: a per-source kernel trace)
+for n, source in [(n_, s_) for n_ in sizes for s_ in sources]:
     # "layout": fixed bay layout, finished episodes restart from the snapshot; "generator": ParkingLotGenerator scenes
     # installed on the device, every finished episode continues in a new scene (staged ahead on the pool's stream)
     env = VecParkingEnv(n, max_step=200, auto_reset=True, seed=1, scene_source=source); env.reset()
