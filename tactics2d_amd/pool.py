@@ -158,7 +158,11 @@ class ParticipantPool:
                        env_stride=None):
         """Device-side ParkingLotGenerator writing straight into this pool (one participant per env): obstacles,
         boundary, target, start pose, snapshot, IoU state -- nothing crosses PCIe.  regenerate=True: after every
-        step, envs whose episode ended get the scene of their next episode (stream first_env + e + k * env_stride);
+        step, envs whose episode ended get the scene of their next episode (stream first_env + e + k * env_stride) --
+        from a ring of 16 lots per env staged ahead on a stream of the pool's own, copied in by the step launch itself
+        (single-ego pools) or by one small launch behind it.  An env cannot outrun its ring (an episode lasts at least
+        two steps, the ring is topped up every 8); should a slot ever be found unstaged the env keeps its lot and the
+        next sync() / download() raises StateError once (include/t2d.h, t2d_parking_scenes).
         regenerate="inline" generates them on the step's stream instead of staging them ahead (C ABI value 2)."""
         stride = self.n_env if env_stride is None else int(env_stride)
         self._ck(self._lib.t2d_parking_scenes(self._h, int(seed) & (2**64 - 1), int(first_env), stride,
