@@ -162,7 +162,7 @@ class ParticipantPool:
         from a ring of 16 lots per env staged ahead on a stream of the pool's own, copied in by the step launch itself
         (single-ego pools) or by one small launch behind it.  An env cannot outrun its ring (an episode lasts at least
         two steps, the ring is topped up every 8); should a slot ever be found unstaged the env keeps its lot and the
-        next sync() / download() raises StateError once (include/t2d.h, t2d_parking_scenes).
+        next sync() / download() raises T2DError(ERR_STATE) once (include/t2d.h, t2d_parking_scenes).
         regenerate="inline" generates them on the step's stream instead of staging them ahead (C ABI value 2)."""
         stride = self.n_env if env_stride is None else int(env_stride)
         self._ck(self._lib.t2d_parking_scenes(self._h, int(seed) & (2**64 - 1), int(first_env), stride,
