@@ -259,6 +259,10 @@ __global__ __launch_bounds__(PIPE ? 2 * kEgoBlock : kEgoBlock, 2) void ego_step_
             pre_min_dist = ld_state<LOOP>(G(pv.min_dist) + env);
         }
     }
+    [[maybe_unused]] scene::StagedPart staged{};   // regenerating pool: the lane's share of the env's next lot (t2d_scene_dev.h)
+    if constexpr (!LOOP) {
+        if (pv.regen) staged = scene::fetch_staged(*pv.regen, env, l);
+    }
     if constexpr (PIPE) {   // this step's state, committed by the pair's integrator wave (the loads above are in flight meanwhile)
         ego_pipe_wait(&s_seq_i[etid >> 6], (uint32_t)step_k + 1u, pv.chain_err);
         ids = s_hand_ids[step_k & 1][grp];
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(PIPE ? 2 * kEgoBlock : kEgoBlock, 2) void ego_step_
         // scene::commit_staged (t2d_scene_dev.h); its fence between the loads and the stores also puts the first lane's
         // epilogue stores (counters, detector state) ahead of the ones that start the new episode
         if (pv.regen) {   // (uniform)
-            if (__shfl((int)ended, gbase)) scene::commit_staged(pv, *pv.regen, env, l);
+            if (__shfl((int)ended, gbase)) scene::commit_staged(pv, *pv.regen, env, l, staged);
         }
     }
     if (!LOOP) break;

@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256) void scene_commit_kernel(PoolView pv, SceneVie
     if (e >= n_env) return;
     const uchar4 st = reinterpret_cast<const uchar4*>(pv.status)[e];
     if (!(st.z | st.w)) return;
-    scene::commit_staged(pv, sv, e, lane);
+    scene::commit_staged(pv, sv, e, lane, scene::fetch_staged(sv, e, lane));
 }
 
 // Topping up the staging ring, on the pool's own stream while the env keeps stepping.  Slot j of env e must hold the

@@ -102,39 +102,66 @@ T2D_DEV void install_target(const SceneView& sv, int e, float4 t_lo, float4 t_hi
 // construction of the ring impossible (16 slots, topped up every 8 steps, at most one episode per two steps: t2d_api.hip
 // regenerate_done_scenes) -- raises a sticky error word the host reports at its next synchronisation, and keeps its scene.
 constexpr int kCommitLanes = 16;
-// lane = 0 .. 15 of env e's group, called by all sixteen (the caller has established that e's episode just ended)
-T2D_DEV void commit_staged(const PoolView& pv, const SceneView& sv, int e, int lane) {
-    static_assert(T2D_GEN_MAX_QUADS <= 12, "lanes 0..11 take the polygon slots");
-    const int episode = sv.episode[e] + 1;
-    const size_t slot = (size_t)e * sv.ring + (size_t)(episode % sv.ring);
-    if (sv.staged_ep[slot] != episode) {
+// What a lane of env e's group fetches from the staging ring for its part of the commit: the env's next episode, the tag of
+// the slot that episode lives in, and the lane's share of the staged record.  The ego step kernel calls this at its very start
+// -- for every env, whether or not its episode will end: 600 B per env and step, and the three dependent round trips (episode
+// -> tag + record) hide behind the integrator instead of standing, cold, between the step's verdict and the copy.  A staged
+// slot stays as it is until its episode has been consumed (scene_refill_scan_kernel), so the values are good whenever they
+// were read since the env's previous commit.
+struct StagedPart {
+    float4 a, b;          // lanes 0..11: the quad of polygon slot `lane`; lane 12: the target quad
+    float4 bound;         // lane 12
+    double s0, s1, s2;    // lanes 12, 13: start x, y, heading
+    double th;            // lane 12: target heading
+    int32_t episode, tag, qid, n_areas;
+    uint32_t info;
+};
+T2D_DEV StagedPart fetch_staged(const SceneView& sv, int e, int lane) {
+    constexpr int K = T2D_GEN_MAX_QUADS;
+    static_assert(K <= 12, "lanes 0..11 take the polygon slots");
+    const SceneArrays& S = sv.staged;
+    StagedPart r;
+    r.a = r.b = r.bound = make_float4(0.f, 0.f, 0.f, 0.f);
+    r.s0 = r.s1 = r.s2 = r.th = 0.0;
+    r.qid = -1; r.info = 0u;
+    r.episode = sv.episode[e] + 1;
+    const size_t slot = (size_t)e * sv.ring + (size_t)(r.episode % sv.ring);
+    r.tag = sv.staged_ep[slot];
+    r.n_areas = S.n_quads[slot];
+    if (lane < K) {
+        r.a = reinterpret_cast<const float4*>(S.quads + slot * K * 8)[2 * lane];
+        r.b = reinterpret_cast<const float4*>(S.quads + slot * K * 8)[2 * lane + 1];
+        r.qid = S.quad_id[slot * K + lane];
+    }
+    if (lane == 12 || lane == 13) {
+        r.s0 = S.start[3 * slot]; r.s1 = S.start[3 * slot + 1]; r.s2 = S.start[3 * slot + 2];
+    }
+    if (lane == 12) {
+        r.a = reinterpret_cast<const float4*>(S.target + slot * 8)[0];
+        r.b = reinterpret_cast<const float4*>(S.target + slot * 8)[1];
+        r.th = S.target_heading[slot];
+        r.bound = reinterpret_cast<const float4*>(S.boundary)[slot];
+        r.info = S.info[slot];
+    }
+    return r;
+}
+
+// lane = 0 .. 15 of env e's group, called by all sixteen (the caller has established that e's episode just ended);
+// P = fetch_staged(sv, e, lane)
+T2D_DEV void commit_staged(const PoolView& pv, const SceneView& sv, int e, int lane, const StagedPart& P) {
+    constexpr int K = T2D_GEN_MAX_QUADS;
+    const int episode = P.episode;
+    if (P.tag != episode) {
         if (lane == 0) atomicOr(sv.commit_err, 1u);
         return;
     }
-    constexpr int K = T2D_GEN_MAX_QUADS;
-    const SceneArrays& S = sv.staged;
     const SceneArrays& Lv = sv.live;
-    // ---- every lane's loads first (one memory latency), then a fence, then the stores: the staged slot is free for the
-    // refill stream once `episode` has moved, and that store comes last
-    float4 q_lo = make_float4(0.f, 0.f, 0.f, 0.f), q_hi = q_lo, t_lo = q_lo, t_hi = q_lo, bound = q_lo;
-    int32_t qid = -1, n_areas = S.n_quads[slot];
-    double sx = 0.0, sy = 0.0, sh = 0.0, th = 0.0;
-    uint32_t info = 0u;
-    if (lane < K) {
-        q_lo = reinterpret_cast<const float4*>(S.quads + slot * K * 8)[2 * lane];
-        q_hi = reinterpret_cast<const float4*>(S.quads + slot * K * 8)[2 * lane + 1];
-        qid = S.quad_id[slot * K + lane];
-    }
-    if (lane == 12 || lane == 13) {
-        sx = S.start[3 * slot]; sy = S.start[3 * slot + 1]; sh = S.start[3 * slot + 2];
-        t_lo = reinterpret_cast<const float4*>(S.target + slot * 8)[0];
-        t_hi = reinterpret_cast<const float4*>(S.target + slot * 8)[1];
-    }
-    if (lane == 12) {
-        th = S.target_heading[slot];
-        bound = reinterpret_cast<const float4*>(S.boundary)[slot];
-        info = S.info[slot];
-    }
+    const float4 q_lo = P.a, q_hi = P.b, t_lo = P.a, t_hi = P.b, bound = P.bound;
+    const int32_t qid = P.qid, n_areas = P.n_areas;
+    const double sx = P.s0, sy = P.s1, sh = P.s2, th = P.th;
+    const uint32_t info = P.info;
+    // every earlier store of this wave -- the step epilogue's, to words the lanes below write again -- is in the L2 before the
+    // stores below are issued (and so is every load of the staged slot, whose refill may start once `episode` has moved)
     __threadfence();
     if (lane < K) {   // polygon slot `lane`: the live copy of the record, then what install_scene writes for it
         reinterpret_cast<float4*>(Lv.quads + (size_t)e * K * 8)[2 * lane] = q_lo;
