@@ -31,7 +31,8 @@ def short(name):
         a = m.group(1).split(",") + ["false", "false"]
         if a[1] == "true":
             return "ego_step_kernel_loop" + ("_pipe" if a[2] == "true" else "")
-    for k in ("ego_step_kernel", "lidar_kernel", "idm_kernel", "parking_scene_kernel", "scene_refill_kernel", "integrate_kernel",
+    for k in ("ego_step_kernel", "lidar_kernel", "idm_kernel", "parking_scene_kernel", "scene_refill_scan_kernel", "scene_refill_kernel",
+              "scene_commit_kernel", "derive_kernel", "feedback_policy_kernel", "chain_rollback_kernel", "integrate_kernel",
               "restore_env_kernel", "restore_kernel", "drift_kernel"):
         if k in n:
             return k
