@@ -135,3 +135,13 @@ def test_step_form_names_follow_the_header():
     for (v, k), name in zip(forms, ParticipantPool.STEP_FORMS):
         want = k[len("T2D_FORM_"):].lower()
         assert name == want or name == {"step": "step", "unfused": "unfused"}.get(want), (k, name)
+
+
+def test_the_build_tracks_every_kernel_source_and_header():
+    """tactics2d_amd.build.SOURCES / HEADERS decide when the library is rebuilt and what source_hash() -- the key the committed
+    counter passes (profiles/traffic_latest.json) are valid for -- covers: every .hip / .h under csrc/ must be listed."""
+    import os
+    from tactics2d_amd import build as B
+    on_disk = set(os.listdir(B.CSRC))
+    assert {f for f in on_disk if f.endswith(".hip")} == set(B.SOURCES)
+    assert {f for f in on_disk if f.endswith(".h")} == {h for h in B.HEADERS if os.sep not in h and "/" not in h}
