@@ -38,6 +38,8 @@
  *   t2d_step              <- _ParkingScenarioManager.update + check_status  envs/parking.py:352-392
  *                            ParkingEnv.step terminated/truncated/reward    envs/parking.py:219-256,148-161
  *                            TimeExceed.update               traffic/event_detection/time_exceed.py:26-33
+ *   t2d_step_host         <- ParkingEnv.step as its caller sees it: host action in, host 5-tuple out
+ *                            envs/parking.py:219-256, _get_infos / _get_relative_pose :190-217
  *
  * Threading: one host thread per pool.  t2d_integrate / t2d_collide / t2d_step are
  * asynchronous on the supplied hipStream_t (passed as void*; NULL = the null stream).
@@ -61,7 +63,7 @@
 extern "C" {
 #endif
 
-#define T2D_ABI_VERSION 9
+#define T2D_ABI_VERSION 10
 
 /* ---- status codes --------------------------------------------------------------- */
 #define T2D_OK            0
@@ -369,6 +371,51 @@ int t2d_upload(t2d_pool* pool, int32_t field_id, const void* host_src, size_t nb
  * distinct streams, or a tracked stream that has been destroyed in the meantime, make the call fall back to a device-wide
  * synchronise) plus the pool's own internal streams.  The set-up calls and the two copies above wait the same way.       */
 int t2d_sync(t2d_pool* pool);
+
+/* ---- the Gym-API host path: host actions in, ONE packed host frame out ------------------------------------------------
+ * What the reference's caller gets from ParkingEnv.step (envs/parking.py:219-256) is host values: the observation, the reward,
+ * terminated / truncated and the info dict of _get_infos (:203-217: lidar, state, target area / heading, the two statuses and
+ * the relative pose of _get_relative_pose :190-201).  t2d_step_host is that call for every env of the pool: it takes the
+ * actions from HOST memory, runs t2d_step (and, when the frame carries a lidar section, t2d_lidar_scan writing straight into
+ * the frame), packs everything the 5-tuple needs of the ego of every env into one contiguous FRAME and brings it to pinned host
+ * memory with one asynchronous copy and one stream synchronisation -- instead of one blocking copy per field.
+ *   t2d_frame_config   chooses the sections (T2D_FRAME_*), allocates the device frame and two pinned host frames, and fills
+ *                      *layout with the byte offsets of the sections inside a frame (-1 = section absent).  Call it again after
+ *                      t2d_lidar_config changed the beam count.  T2D_FRAME_ZEROCOPY: no copy commands at all -- the step kernel
+ *                      reads the actions from mapped host memory and the pack / lidar kernels write the mapped host frame
+ *                      (lowest latency for small pools; a large pool's 8 B per participant would cross PCIe inside the step).
+ *   t2d_set_target_headings  target_heading of every env (envs/parking.py:401), host fp64 [n_env]; generated scenes
+ *                      (t2d_parking_scenes) bring their own.  Without it diff_heading is NaN.
+ *   t2d_step_host      actions_host = f32 [n_env * max_agents][2] in the reference's action layout (steering, accel)
+ *                      (envs/parking.py:239; a point mass: (ay, ax)), or NULL = the actions already in / bound to the pool.
+ *                      Ends any t2d_bind_actions binding (the pool reads a buffer of its own from then on).  Returns with
+ *                      *frame_host pointing at the filled host frame: valid until the call after the next one (two frames
+ *                      alternate).  Reports a failed scene regeneration / chained launch like t2d_sync does.
+ *   t2d_frame_fetch    the frame of the CURRENT state without stepping (what reset() returns; the lidar section is scanned
+ *                      from the current poses).
+ * Frame sections (E = n_env; every offset a multiple of 256 B):
+ *   header     u32 [16]: {step count (low half), scene-regeneration error word, 0 ...}
+ *   obs        f32 [E][6]   x, y, heading, speed, vx, vy of the ego (vx / vy as stored: see T2D_F_VX)
+ *   rel        f64 [E][3]   diff_position, diff_angle, diff_heading of _get_relative_pose: |centroid - (x, y)|,
+ *                           atan2(cy - y, cx - x) - heading, target_heading - heading, in fp64 from the stored fp32 state
+ *                           (NaN without target areas / headings)
+ *   reward     f32 [E]      status  u8 [E][4]   iou f32 [E]   frame_ms i32 [E]   cnt_step i32 [E]
+ *   episode    i32 [E]      generated scenes: episode number of the env (0 otherwise)
+ *   target     f32 [E][8] + f64 [E] target_heading   (T2D_FRAME_TARGET: the target area the env is in NOW; generated scenes)
+ *   lidar      f32 [E][n_beams]                      (T2D_FRAME_LIDAR)                                                      */
+#define T2D_FRAME_LIDAR    1u
+#define T2D_FRAME_TARGET   2u
+#define T2D_FRAME_ZEROCOPY 4u
+typedef struct t2d_frame_layout {
+    int64_t bytes;          /* size of one frame */
+    int64_t off_obs, off_rel, off_reward, off_status, off_iou, off_frame_ms, off_cnt_step, off_episode;
+    int64_t off_target, off_target_heading, off_lidar;   /* -1 = absent */
+    int32_t n_env, n_beams;
+} t2d_frame_layout;
+int t2d_frame_config(t2d_pool* pool, uint32_t sections, t2d_frame_layout* layout);
+int t2d_set_target_headings(t2d_pool* pool, const double* heading_host);
+int t2d_step_host(t2d_pool* pool, const float* actions_host, int32_t interval_ms, void* hip_stream, const void** frame_host);
+int t2d_frame_fetch(t2d_pool* pool, void* hip_stream, const void** frame_host);
 
 /* Episode-start snapshot for device-side (auto-)reset -- the vector-env counterpart of
  * ParkingEnv.reset (envs/parking.py:262-298) without a host round trip.

@@ -38,6 +38,13 @@ class StatusConfig(C.Structure):
                 ("dist_reward_scale", C.c_float)]
 
 
+class FrameLayout(C.Structure):
+    """t2d_frame_layout (include/t2d.h): byte offsets of the sections of one host frame, -1 = absent."""
+    _fields_ = [(k, C.c_int64) for k in ("bytes", "off_obs", "off_rel", "off_reward", "off_status", "off_iou", "off_frame_ms",
+                                         "off_cnt_step", "off_episode", "off_target", "off_target_heading", "off_lidar")] + \
+               [("n_env", C.c_int32), ("n_beams", C.c_int32)]
+
+
 # every symbol include/t2d.h declares: name -> (restype, argtypes)
 _vp = C.c_void_p
 SYMBOLS = {
@@ -68,6 +75,10 @@ SYMBOLS = {
     "t2d_download": (C.c_int, [_vp, C.c_int32, _vp, C.c_size_t]),
     "t2d_upload": (C.c_int, [_vp, C.c_int32, _vp, C.c_size_t]),
     "t2d_sync": (C.c_int, [_vp]),
+    "t2d_frame_config": (C.c_int, [_vp, C.c_uint32, C.POINTER(FrameLayout)]),
+    "t2d_set_target_headings": (C.c_int, [_vp, _vp]),
+    "t2d_step_host": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.POINTER(_vp)]),
+    "t2d_frame_fetch": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "t2d_snapshot": (C.c_int, [_vp]),
     "t2d_restore": (C.c_int, [_vp, C.c_int32, _vp]),
     "t2d_set_auto_reset": (C.c_int, [_vp, C.c_int32]),

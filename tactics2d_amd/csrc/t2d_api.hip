@@ -763,6 +763,9 @@ hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t*
 
 extern "C" {
 
+static void frame_release(t2d_pool* p);
+static void refresh_idm_view(t2d_pool* p);
+
 const char* t2d_last_error(const t2d_pool* pool) {
     return pool ? pool->err.c_str() : g_create_err.c_str();
 }
@@ -896,6 +899,8 @@ int t2d_destroy(t2d_pool* p) {
                     p->d_scene_arrays, p->d_lidar_cnt, p->d_chain, p->d_ckpt, p->d_scene_view};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    frame_release(p);
+    if (p->d_target_heading) (void)hipFree(p->d_target_heading);
     if (p->comm && rccl().ok) (void)rccl().CommDestroy((ncclComm_t)p->comm);
     if (p->gather_stream) (void)hipStreamDestroy(p->gather_stream);
     if (p->ev_frag_ready) (void)hipEventDestroy(p->ev_frag_ready);
@@ -2052,6 +2057,163 @@ int t2d_sync(t2d_pool* p) {
     T2D_HIP(p, quiesce(p));
     if (p->chain_failed || p->scene_commit_failed) return report_chain_failure(p);
     return T2D_OK;
+}
+
+// ---- the Gym-API host path (include/t2d.h: t2d_frame_config / t2d_step_host / t2d_frame_fetch) -------------------------------
+static void frame_release(t2d_pool* p) {
+    if (p->d_frame) (void)hipFree(p->d_frame);
+    if (p->d_actions) (void)hipFree(p->d_actions);
+    for (char*& h : p->h_frame) {
+        if (h) (void)hipHostFree(h);
+        h = nullptr;
+    }
+    if (p->h_actions) (void)hipHostFree(p->h_actions);
+    p->d_frame = nullptr;
+    p->d_actions = nullptr;
+    p->h_actions = nullptr;
+    p->frame_sections = 0;
+    p->frame_layout = t2d_frame_layout{};
+}
+
+int t2d_frame_config(t2d_pool* p, uint32_t sections, t2d_frame_layout* layout) {
+    if (!p) return T2D_ERR_INVALID;
+    if (sections & ~(T2D_FRAME_LIDAR | T2D_FRAME_TARGET | T2D_FRAME_ZEROCOPY)) return fail(p, T2D_ERR_INVALID, "unknown frame section bits");
+    if ((sections & T2D_FRAME_LIDAR) && !p->lidar_on)
+        return fail(p, T2D_ERR_STATE, "t2d_lidar_config must precede a frame with a lidar section");
+    T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, quiesce(p));
+    const size_t E = (size_t)p->v.n_env;
+    t2d_frame_layout L{};
+    size_t total = 256;   // header
+    auto section = [&](size_t bytes) {
+        const size_t off = total;
+        total += (bytes + 255) & ~(size_t)255;
+        return (int64_t)off;
+    };
+    L.off_rel = section(E * 3 * sizeof(double));
+    L.off_obs = section(E * 6 * sizeof(float));
+    L.off_reward = section(E * 4);
+    L.off_status = section(E * 4);
+    L.off_iou = section(E * 4);
+    L.off_frame_ms = section(E * 4);
+    L.off_cnt_step = section(E * 4);
+    L.off_episode = section(E * 4);
+    L.off_target = L.off_target_heading = L.off_lidar = -1;
+    if (sections & T2D_FRAME_TARGET) {
+        L.off_target_heading = section(E * sizeof(double));
+        L.off_target = section(E * 8 * sizeof(float));
+    }
+    L.n_env = p->v.n_env;
+    L.n_beams = 0;
+    if (sections & T2D_FRAME_LIDAR) {
+        L.n_beams = p->lidar.n_beams;
+        L.off_lidar = section(E * (size_t)L.n_beams * sizeof(float));
+    }
+    L.bytes = (int64_t)total;
+    frame_release(p);
+    const unsigned host_flags = hipHostMallocMapped | hipHostMallocCoherent;
+    for (char*& h : p->h_frame) {
+        T2D_HIP(p, hipHostMalloc((void**)&h, total, host_flags));
+        memset(h, 0, total);
+    }
+    const size_t act_bytes = (size_t)p->v.N * 2 * sizeof(float);
+    T2D_HIP(p, hipHostMalloc((void**)&p->h_actions, act_bytes, host_flags));
+    memset(p->h_actions, 0, act_bytes);
+    if (!(sections & T2D_FRAME_ZEROCOPY)) {
+        T2D_HIP(p, hipMalloc((void**)&p->d_frame, total));
+        T2D_HIP(p, hipMemset(p->d_frame, 0, total));
+        T2D_HIP(p, hipMalloc((void**)&p->d_actions, act_bytes));
+        T2D_HIP(p, hipMemset(p->d_actions, 0, act_bytes));
+    }
+    p->frame_sections = sections | 0x80000000u;   // (configured, whatever the section bits)
+    p->frame_layout = L;
+    p->frame_turn = 0;
+    if (layout) *layout = L;
+    return T2D_OK;
+}
+
+int t2d_set_target_headings(t2d_pool* p, const double* heading_host) {
+    if (!p) return T2D_ERR_INVALID;
+    T2D_HIP(p, hipSetDevice(p->device));
+    T2D_HIP(p, quiesce(p));
+    return dev_replace(p, &p->d_target_heading, heading_host, heading_host ? (size_t)p->v.n_env : 0);
+}
+
+// scan (optional) + pack + fetch of the current state on `s`; returns with the host frame filled
+static int frame_finish(t2d_pool* p, hipStream_t s, const void** frame_host) {
+    const t2d_frame_layout& L = p->frame_layout;
+    const bool zero_copy = (p->frame_sections & T2D_FRAME_ZEROCOPY) != 0;
+    char* host = p->h_frame[p->frame_turn];
+    p->frame_turn ^= 1;
+    char* dev_out = p->d_frame;
+    if (zero_copy) T2D_HIP(p, hipHostGetDevicePointer((void**)&dev_out, host, 0));
+    int rc;
+    if (L.off_lidar >= 0) {
+        if (!p->lidar_on || p->lidar.n_beams != L.n_beams)
+            return fail(p, T2D_ERR_STATE, "the lidar configuration changed: call t2d_frame_config again");
+        if ((rc = t2d_lidar_scan(p, reinterpret_cast<float*>(dev_out + L.off_lidar), s))) return rc;
+    }
+    t2d::FrameView fv{};
+    fv.out = dev_out;
+    fv.lay = L;
+    fv.target_heading = p->scene_mode ? p->scene.live.target_heading : p->d_target_heading;
+    fv.target_quads = p->scene_mode ? p->scene.live.target : nullptr;
+    fv.episode = p->scene_mode ? p->scene.episode : nullptr;
+    fv.commit_err = p->scene_mode && p->scene_regen ? p->scene.commit_err : nullptr;
+    fv.step_count = (uint32_t)p->step_count;
+    fv.ego_index = p->status_cfg.ego_index;
+    touch(p, s);
+    T2D_HIP(p, t2d::launch_frame_pack(p->v, fv, s));
+    if (!zero_copy) T2D_HIP(p, hipMemcpyAsync(host, p->d_frame, (size_t)L.bytes, hipMemcpyDeviceToHost, s));
+    T2D_HIP(p, hipStreamSynchronize(s));
+    // `s` is drained: drop it from the streams a later quiesce has to wait for
+    for (int k = 0; k < p->n_live_streams; ++k)
+        if (p->live_streams[k] == s) {
+            p->live_streams[k] = p->live_streams[--p->n_live_streams];
+            break;
+        }
+    if (frame_host) *frame_host = host;
+    if (fv.commit_err && reinterpret_cast<const uint32_t*>(host)[1]) {   // (what quiesce would have found with a blocking copy)
+        (void)hipMemset(p->scene.commit_err, 0, sizeof(uint32_t));
+        p->scene_commit_failed = true;
+    }
+    if (p->n_live_streams == 0 && !p->live_overflow && !p->chain_used) p->scene_commit_used = false;
+    if (p->scene_commit_failed) return report_chain_failure(p);
+    return T2D_OK;
+}
+
+int t2d_step_host(t2d_pool* p, const float* actions_host, int32_t interval_ms, void* hip_stream, const void** frame_host) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!p->frame_sections) return fail(p, T2D_ERR_STATE, "t2d_frame_config must precede t2d_step_host");
+    T2D_HIP(p, hipSetDevice(p->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (actions_host) {
+        const size_t act_bytes = (size_t)p->v.N * 2 * sizeof(float);
+        memcpy(p->h_actions, actions_host, act_bytes);
+        const float* dev_act = p->d_actions;
+        if (p->frame_sections & T2D_FRAME_ZEROCOPY) {
+            T2D_HIP(p, hipHostGetDevicePointer((void**)&dev_act, p->h_actions, 0));
+        } else {
+            touch(p, s);
+            T2D_HIP(p, hipMemcpyAsync(p->d_actions, p->h_actions, act_bytes, hipMemcpyHostToDevice, s));
+        }
+        // (steering, accel) per participant: act0 (accel) = element 1, act1 (steering) = element 0, stride 2
+        p->v.act0 = dev_act + 1;
+        p->v.act1 = dev_act;
+        p->v.act_stride = 2;
+        refresh_idm_view(p);
+    }
+    int rc = t2d_step(p, interval_ms, hip_stream);
+    if (rc != T2D_OK) return rc;
+    return frame_finish(p, s, frame_host);
+}
+
+int t2d_frame_fetch(t2d_pool* p, void* hip_stream, const void** frame_host) {
+    if (!p) return T2D_ERR_INVALID;
+    if (!p->frame_sections) return fail(p, T2D_ERR_STATE, "t2d_frame_config must precede t2d_frame_fetch");
+    if (!p->have_params || !p->have_reset) return fail(p, T2D_ERR_STATE, "t2d_reset must precede t2d_frame_fetch");
+    T2D_HIP(p, hipSetDevice(p->device));
+    return frame_finish(p, (hipStream_t)hip_stream, frame_host);
 }
 
 int t2d_lidar_config(t2d_pool* p, int32_t n_beams, float max_range, int32_t include_participants,

@@ -182,6 +182,19 @@ struct IdmView {
     int32_t n_ctrl;
 };
 
+// The Gym-API host frame (t2d_step_host): where the pack kernel writes what ParkingEnv.step hands its caller, one frame per
+// step -- `out` is the device frame (then copied to pinned host memory) or the mapped host frame itself (T2D_FRAME_ZEROCOPY).
+struct FrameView {
+    char* out;
+    t2d_frame_layout lay;
+    const double* target_heading;   // [E] or null (diff_heading = NaN)
+    const float* target_quads;      // [E][8] scene mode: the live target areas; else null
+    const int32_t* episode;         // [E] scene mode, else null
+    const uint32_t* commit_err;     // scene regeneration's sticky error word, or null
+    uint32_t step_count;
+    int32_t ego_index;
+};
+
 constexpr int kIdsModelShift = 0;
 constexpr int kIdsTypeShift = 8;
 constexpr int kIdsActiveShift = 16;
@@ -301,6 +314,15 @@ struct t2d_pool {
     hipStream_t live_streams[kMaxLiveStreams]{};
     int n_live_streams = 0;
     bool live_overflow = false;
+    // the Gym-API host frame (t2d_frame_config / t2d_step_host)
+    uint32_t frame_sections = 0;
+    t2d_frame_layout frame_layout{};
+    char* d_frame = nullptr;          // device frame (copy mode)
+    char* h_frame[2]{};               // pinned (and mapped) host frames, alternating
+    int frame_turn = 0;
+    float* h_actions = nullptr;       // pinned (and mapped) staging of the host actions, [N][2]
+    float* d_actions = nullptr;       // device copy of them (copy mode)
+    double* d_target_heading = nullptr;
     // profiling
     bool profiling = false;
     static constexpr int kMaxProfSteps = 4096;
@@ -330,6 +352,7 @@ hipError_t launch_idm(const PoolView& v, const IdmView& iv, const int32_t* force
 hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
                           hipStream_t s);
 hipError_t launch_spin(long long ticks_100mhz, hipStream_t s);
+hipError_t launch_frame_pack(const PoolView& v, const FrameView& fv, hipStream_t s);
 // note that work of this pool was enqueued on `s` by code outside t2d_api.hip (a replayed graph): t2d_sync waits for it
 void pool_touch(t2d_pool* p, hipStream_t s);
 bool split_eligible(const PoolView& v, const t2d_status_config& cfg, int log2A, int device_cus);

@@ -51,10 +51,15 @@ class VecParkingEnv:
     _discrete_actions = {1: (0, 0), 2: (-0.5, 0), 3: (0.5, 0), 4: (0, 1), 5: (0, -1)}  # parking.py:95
 
     def __init__(self, n_envs, max_step=int(2e4), continuous=True, auto_reset=False, seed=0, device_id=0,
-                 scene_source="layout", type_proportion=0.5):
+                 scene_source="layout", type_proportion=0.5, info_lidar=True, copy=True, zero_copy=None):
         """scene_source: "generator" = the device-side ParkingLotGenerator (tactics2d_amd.generator; bay and
         parallel scenes with the reference's rejection sampler, `type_proportion` as in envs/parking.py:331-333),
-        "layout" = the fixed bay layout of scenarios.parking (BASELINE config 2)."""
+        "layout" = the fixed bay layout of scenarios.parking (BASELINE config 2).
+        The host path (`step`) is ONE library call per step (t2d_step_host): actions up, step + 360-beam scan + pack, one
+        frame back (pool.HostFrame).  info_lidar=False leaves the scan out of the host path (info["lidar"] is None: at 4096
+        envs the 360 floats per env are 5.9 MB per step over PCIe); copy=False hands out views of the library's pinned
+        frames instead of copies (valid until the step after next); zero_copy: the kernels read the actions from / write
+        the frame to mapped host memory instead of copy commands (None = for pools of at most 64 envs)."""
         if scene_source not in ("layout", "generator"):
             raise ValueError(f"unknown scene_source {scene_source!r}")
         self.scene_source = scene_source
@@ -64,6 +69,9 @@ class VecParkingEnv:
         self.max_step = max_step
         self.continuous = continuous
         self.auto_reset = auto_reset
+        self.info_lidar = bool(info_lidar)
+        self.copy = bool(copy)
+        self.zero_copy = self.n_envs <= 64 if zero_copy is None else bool(zero_copy)
         self.observation_space = Box(np.full(6, -np.inf), np.full(6, np.inf))
         self.action_space = Box([-self._max_steer, -self._max_accel], [self._max_steer, self._max_accel])
         # ScenarioManager(max_step, step_size=100, ...)  envs/parking.py:144-146
@@ -98,6 +106,7 @@ class VecParkingEnv:
             sc = scenarios.parking(self.n_envs, seed0=self._seed * self.n_envs)
             self._scene = sc
             m.pool.set_target_areas(sc.target)
+            m.pool.set_target_headings(sc.target_heading)
             m.configure(sc.rows, check_dynamic=False, check_off_lane=False, check_arrival=1, check_no_action=1,
                         no_action_max_step=100, shaped_reward=1)
             m.status_checklist["collision"].reset(_csr_to_lists(sc.static))
@@ -107,14 +116,17 @@ class VecParkingEnv:
         m.pool.set_auto_reset(self.auto_reset)
         # SingleLineLidar(perception_range=20, freq_detect=360 * 10)  envs/parking.py:303-304,422-431
         m.pool.lidar_config(360, 20.0, include_participants=False)
-        obs = m.get_observation()
-        n = self.n_envs
-        return obs, self._infos(obs, np.full(n, ScenarioStatus.NORMAL, np.uint8), np.full(n, TrafficStatus.NORMAL, np.uint8))
+        # the target area changes under the caller only when scenes are regenerated on the device: the frame carries it then
+        self._moving_targets = self.scene_source == "generator" and self.auto_reset
+        m.pool.frame_config(lidar=self.info_lidar, target=self._moving_targets, zero_copy=self.zero_copy)
+        self._target_area, self._target_heading = self._scene.target, self._scene.target_heading
+        fr = self._take(m.pool.frame_fetch())
+        return fr.obs, self._infos(fr)
 
     # ------------------------------------------------------------------ step
     def _to_continuous(self, actions):
         if self.continuous:
-            a = np.asarray(actions, np.float32).reshape(self.n_envs, 2)
+            a = np.ascontiguousarray(actions, np.float32).reshape(self.n_envs, 2)
             if not (np.all(a >= self.action_space.low) and np.all(a <= self.action_space.high)):
                 raise InvalidAction(f"Action {actions} is not in the action space.")
             return a
@@ -123,20 +135,19 @@ class VecParkingEnv:
             raise InvalidAction(f"Action {actions} is not in the action space.")
         return np.array([self._discrete_actions[int(i)] for i in idx], np.float32)
 
+    def _take(self, frame):
+        return frame.copy() if self.copy else frame
+
     def step(self, actions):
+        """(obs[n, 6], reward[n], terminated[n], truncated[n], infos) -- envs/parking.py:219-256 for every env: one
+        t2d_step_host call (physics_model.step(state, accel, steering) parking.py:355 + check_status + scan + pack)."""
         if self._scene is None:
             raise RuntimeError("call reset() first")
         a = self._to_continuous(actions)
-        m = self.scenario_manager
-        # (set_actions uploads into the pool's own action fields, which also ends a step_torch binding)
-        m.step(a[:, 1], a[:, 0])  # physics_model.step(state, accel, steering)  parking.py:355
-        pool = m.pool
-        status = pool.download(L.F_STATUS)
-        reward = pool.download(L.F_REWARD)
-        obs = m.get_observation()
-        terminated = status[:, 2].astype(bool)
-        truncated = status[:, 3].astype(bool)
-        return obs, reward, terminated, truncated, self._infos(obs, status[:, 0], status[:, 1])
+        fr = self._take(self.scenario_manager.pool.step_host(a, 100))
+        self.scenario_manager._flags_cache = None
+        st = fr.status
+        return fr.obs, fr.reward, st[:, 2].view(np.bool_), st[:, 3].view(np.bool_), self._infos(fr)
 
     def step_torch(self, actions, stream=None):
         """The device-resident step: `actions` is a float32 CUDA tensor [n_envs, 2] in the reference's layout (steering,
@@ -175,27 +186,21 @@ class VecParkingEnv:
         out["lidar"] = self._t_lidar
         return out
 
-    def _infos(self, obs, scenario_status, traffic_status):
-        return dict(state=dict(x=obs[:, 0], y=obs[:, 1], heading=obs[:, 2], speed=obs[:, 3], vx=obs[:, 4],
-                               vy=obs[:, 5], frame=self.scenario_manager.pool.download(L.F_FRAME_MS)),
-                    scenario_status=scenario_status, traffic_status=traffic_status,
-                    target_area=None if self._scene is None else self._targets()[0],
-                    target_heading=None if self._scene is None else self._targets()[1],
-                    iou=self.scenario_manager.pool.download(L.F_IOU), lidar=self._lidar())
+    def _infos(self, fr):
+        """_get_infos (envs/parking.py:203-217) for every env, as views of the frame."""
+        obs, st = fr.obs, fr.status
+        if self._moving_targets:
+            self._target_area, self._target_heading = fr.target, fr.target_heading
+        return dict(state=dict(x=obs[:, 0], y=obs[:, 1], heading=obs[:, 2], speed=obs[:, 3], vx=obs[:, 4], vy=obs[:, 5],
+                               frame=fr.frame_ms),
+                    scenario_status=st[:, 0], traffic_status=st[:, 1],
+                    target_area=self._target_area, target_heading=self._target_heading,
+                    diff_position=fr.rel[:, 0], diff_angle=fr.rel[:, 1], diff_heading=fr.rel[:, 2],
+                    iou=fr.iou, lidar=fr.lidar, episode=fr.episode)
 
     def _targets(self):
-        """Target areas / headings of the scenes the envs are in NOW (they change per episode when generated scenes
-        are regenerated on the device)."""
-        if self.scene_source == "generator" and self.auto_reset:
-            self.generated = self.scenario_manager.pool.get_parking_scenes()
-            return self.generated.target, np.float32(self.generated.target_heading)
-        return self._scene.target, self._scene.target_heading
-
-    def _lidar(self):
-        """info["lidar"]: 360 ranges per env, +inf = no return (the reference's scan_result)."""
-        pool = self.scenario_manager.pool
-        pool.lidar_scan()
-        return pool.download(L.F_LIDAR)
+        """Target areas / headings of the scenes the envs are in NOW (as of the last step / reset)."""
+        return self._target_area, self._target_heading
 
     def render(self):
         raise NotImplementedError("rendering is outside the accelerated path")
@@ -208,29 +213,60 @@ class ParkingEnv:
     """Single-scene adapter with the reference's 5-tuple (envs/parking.py:256)."""
 
     def __init__(self, type_proportion=0.5, render_mode="rgb_array", render_fps=60, max_step=int(2e4),
-                 continuous=True, seed=0, scene_source="layout"):
+                 continuous=True, seed=0, scene_source="layout", info_lidar=True, zero_copy=True):
         if render_mode not in ("human", "rgb_array"):
             raise NotImplementedError(f"Render mode {render_mode} is not supported.")  # parking.py:119-120
         self.max_step = max_step
         self.continuous = continuous
         self._vec = VecParkingEnv(1, max_step, continuous, seed=seed, scene_source=scene_source,
-                                  type_proportion=type_proportion)
+                                  type_proportion=type_proportion, info_lidar=info_lidar, copy=False, zero_copy=zero_copy)
         self.observation_space = self._vec.observation_space
         self.action_space = self._vec.action_space
         self.scenario_manager = self._vec.scenario_manager
 
     def reset(self, seed=None, options=None):
         obs, infos = self._vec.reset(seed, options)
-        return obs[0], _first(infos)
-
-    def step(self, action):
-        if self.continuous and not self.action_space.contains(np.asarray(action, np.float32)):
-            raise InvalidAction(f"Action {action} is not in the action space.")
-        obs, reward, terminated, truncated, infos = self._vec.step([action])
+        self._abuf = np.zeros((1, 2), np.float32)
+        lo, hi = self.action_space.low, self.action_space.high
+        self._bounds = (float(lo[0]), float(hi[0]), float(lo[1]), float(hi[1]))
         infos = _first(infos)
         infos["scenario_status"] = ScenarioStatus(int(infos["scenario_status"]))
         infos["traffic_status"] = TrafficStatus(int(infos["traffic_status"]))
-        return obs[0], float(reward[0]), bool(terminated[0]), bool(truncated[0]), infos
+        return obs[0], infos
+
+    def step(self, action):
+        """envs/parking.py:219-256: (observation, reward, terminated, truncated, infos) as host values -- one library call
+        (t2d_step_host on a zero-copy frame: the kernels read the action from and write the results to mapped host memory)."""
+        v = self._vec
+        if v._scene is None:
+            raise RuntimeError("call reset() first")
+        a = self._abuf
+        if self.continuous:
+            try:
+                a[0] = action
+            except (ValueError, TypeError):
+                raise InvalidAction(f"Action {action} is not in the action space.") from None
+            lo0, hi0, lo1, hi1 = self._bounds
+            if not (lo0 <= a[0, 0] <= hi0 and lo1 <= a[0, 1] <= hi1):   # (NaN fails both, like Box.contains)
+                raise InvalidAction(f"Action {action} is not in the action space.")
+        else:
+            try:
+                a[0] = v._discrete_actions[int(action)]
+            except (KeyError, ValueError, TypeError):
+                raise InvalidAction(f"Action {action} is not in the action space.") from None
+        fr = v.scenario_manager.pool.step_host(a, 100)
+        v.scenario_manager._flags_cache = None
+        o = fr.obs[0].copy()
+        st = fr.status[0]
+        rel = fr.rel[0]
+        if v._moving_targets:
+            v._target_area, v._target_heading = fr.target.copy(), fr.target_heading.copy()
+        infos = dict(state=dict(x=o[0], y=o[1], heading=o[2], speed=o[3], vx=o[4], vy=o[5], frame=fr.frame_ms[0]),
+                     scenario_status=ScenarioStatus(int(st[0])), traffic_status=TrafficStatus(int(st[1])),
+                     target_area=v._target_area[0], target_heading=v._target_heading[0],
+                     diff_position=rel[0], diff_angle=rel[1], diff_heading=rel[2],
+                     iou=fr.iou[0], lidar=None if fr.lidar is None else fr.lidar[0].copy(), episode=fr.episode[0])
+        return o, float(fr.reward[0]), bool(st[2]), bool(st[3]), infos
 
     def close(self):
         self._vec.close()

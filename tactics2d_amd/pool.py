@@ -32,6 +32,39 @@ class _DevArray:
         self._owner = owner
 
 
+class HostFrame:
+    """numpy views of one host frame of t2d_step_host (include/t2d.h): what ParkingEnv.step hands its caller, for the ego of
+    every env.  Views of the library's pinned frames are valid until the step after next; `copy()` returns a frame that owns
+    its memory."""
+    _SECTIONS = (("rel", "off_rel", np.float64, 3), ("obs", "off_obs", np.float32, 6), ("reward", "off_reward", np.float32, 0),
+                 ("status", "off_status", np.uint8, 4), ("iou", "off_iou", np.float32, 0),
+                 ("frame_ms", "off_frame_ms", np.int32, 0), ("cnt_step", "off_cnt_step", np.int32, 0),
+                 ("episode", "off_episode", np.int32, 0), ("target_heading", "off_target_heading", np.float64, 0),
+                 ("target", "off_target", np.float32, 8), ("lidar", "off_lidar", np.float32, -1))
+
+    def __init__(self, base, lay):
+        """base: uint8 array holding the frame (or its front part up to the lidar section)."""
+        self.base, self.lay = base, lay
+        n = lay.n_env
+        self.header = base[:64].view(np.uint32)
+        for name, off_name, dt, cols in self._SECTIONS:
+            off = getattr(lay, off_name)
+            cols = lay.n_beams if cols < 0 else cols
+            nb = n * max(cols, 1) * np.dtype(dt).itemsize
+            if off < 0 or off + nb > base.size:
+                setattr(self, name, None)
+                continue
+            v = base[off:off + nb].view(dt)
+            setattr(self, name, v.reshape(n, cols) if cols else v)
+        if self.target is not None:
+            self.target = self.target.reshape(n, 4, 2)
+
+    def copy(self, lidar=True):
+        """A frame that owns its memory (one memcpy); lidar=False leaves the lidar section out (its views become None)."""
+        end = self.lay.bytes if lidar or self.lay.off_lidar < 0 else self.lay.off_lidar
+        return HostFrame(self.base[:end].copy(), self.lay)
+
+
 class ParticipantPool:
     """n_env environments x max_agents participants resident on one MI355X."""
 
@@ -183,6 +216,46 @@ class ParticipantPool:
                                                   ptr(out.boundary), ptr(out.info), ptr(episode)))
         out.episode = episode
         return out
+
+    # ---------------------------------------------------------------- the Gym-API host path
+    def frame_config(self, lidar=False, target=False, zero_copy=False):
+        """Sections of the host frame t2d_step_host fills (t2d_frame_config); returns the layout."""
+        lay = _ffi.FrameLayout()
+        mask = (L.FRAME_LIDAR if lidar else 0) | (L.FRAME_TARGET if target else 0) | (L.FRAME_ZEROCOPY if zero_copy else 0)
+        self._ck(self._lib.t2d_frame_config(self._h, mask, C.byref(lay)))
+        self.frame_layout = lay
+        self._frames = {}
+        self._frame_ptr = C.c_void_p()
+        return lay
+
+    def set_target_headings(self, heading):
+        h = _arr(heading, np.float64, self.n_env, "target_heading")
+        self._ck(self._lib.t2d_set_target_headings(self._h, _p(h)))
+
+    def _frame(self):
+        ptr = self._frame_ptr.value
+        fr = self._frames.get(ptr)
+        if fr is None:   # (two pinned frames alternate: their views are built once)
+            buf = (C.c_uint8 * self.frame_layout.bytes).from_address(ptr)
+            fr = self._frames[ptr] = HostFrame(np.frombuffer(buf, np.uint8), self.frame_layout)
+        return fr
+
+    def step_host(self, actions, interval_ms=100, stream=None):
+        """ParkingEnv.step for every env, host to host (t2d_step_host): actions float32 [n, 2] (steering, accel) C-contiguous or
+        None (the actions already in the pool); returns the HostFrame -- views of pinned memory valid until the step after next."""
+        if actions is not None:
+            if actions.dtype != np.float32 or actions.size != 2 * self.n or not actions.flags.c_contiguous:
+                raise ValueError(f"actions must be C-contiguous float32 [{self.n}, 2]")
+            actions = actions.ctypes.data
+        rc = self._lib.t2d_step_host(self._h, actions, interval_ms, stream, C.byref(self._frame_ptr))
+        if rc:
+            self._ck(rc)
+        return self._frame()
+
+    def frame_fetch(self, stream=None):
+        """The frame of the current state without stepping (t2d_frame_fetch)."""
+        self._ck(self._lib.t2d_frame_fetch(self._h, stream, C.byref(self._frame_ptr)))
+        return self._frame()
 
     def set_integrator_variant(self, variant):
         v = {"exact": 0, "fast": 1}.get(variant, variant)

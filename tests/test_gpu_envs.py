@@ -199,3 +199,85 @@ def test_vec_parking_env_device_resident_step_equals_the_host_step():
         assert np.array_equal(out["lidar"].cpu().numpy().view(np.uint32), infos["lidar"].view(np.uint32))
         assert np.array_equal(out["iou"].cpu().numpy(), infos["iou"], equal_nan=True)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("source,zero_copy", [("layout", False), ("layout", True), ("generator", False), ("generator", True)])
+def test_host_frame_equals_the_per_field_copies(source, zero_copy):
+    """t2d_step_host's ONE packed frame against the per-field path it replaces (t2d_download of every column, a lidar scan
+    into the pool's own buffer, t2d_get_parking_scenes): bit-identical, with copy commands and with the kernels
+    reading / writing mapped host memory; the relative pose of _get_relative_pose (envs/parking.py:190-201) against numpy
+    on the same fp32 state."""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.envs import VecParkingEnv
+    n = 257
+    env = VecParkingEnv(n, max_step=25, seed=3, auto_reset=True, scene_source=source, zero_copy=zero_copy)
+    obs, infos = env.reset()
+    pool = env.scenario_manager.pool
+    rng = np.random.default_rng(4)
+    n_done = 0
+    for t in range(60):
+        if t:
+            act = env.action_space.sample(rng, n)
+            if t % 7 == 0:
+                act[::3] = 0.0
+            obs, reward, term, trunc, infos = env.step(act)
+            assert np.array_equal(pool.download(L.F_ACT0)[:0], np.zeros(0, np.float32))   # (a download in between is harmless)
+            st = pool.download(L.F_STATUS)
+            assert np.array_equal(reward.view(np.uint32), pool.download(L.F_REWARD).view(np.uint32))
+            assert np.array_equal(term, st[:, 2].astype(bool)) and np.array_equal(trunc, st[:, 3].astype(bool))
+            assert np.array_equal(infos["scenario_status"], st[:, 0]) and np.array_equal(infos["traffic_status"], st[:, 1])
+            n_done += int((term | trunc).sum())
+        for k, f in enumerate((L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_VX, L.F_VY)):
+            assert np.array_equal(obs[:, k].view(np.uint32), pool.download(f).view(np.uint32)), (t, k)
+        assert np.array_equal(infos["state"]["frame"], pool.download(L.F_FRAME_MS))
+        assert np.array_equal(infos["iou"].view(np.uint32), pool.download(L.F_IOU).view(np.uint32))
+        pool.lidar_scan()
+        assert np.array_equal(infos["lidar"].view(np.uint32), pool.download(L.F_LIDAR).view(np.uint32)), t
+        if source == "generator":
+            g = pool.get_parking_scenes()
+            assert np.array_equal(infos["target_area"], g.target) and np.array_equal(infos["target_heading"], g.target_heading)
+            assert np.array_equal(infos["episode"], g.episode)
+            tc = _area_centroid(g.target)
+            th = g.target_heading
+        else:
+            tc = _area_centroid(env._scene.target)
+            th = np.float64(env._scene.target_heading)
+            assert np.array_equal(infos["target_area"], env._scene.target)
+        x, y, h = (obs[:, k].astype(np.float64) for k in range(3))
+        assert np.allclose(infos["diff_position"], np.hypot(tc[:, 0] - x, tc[:, 1] - y), rtol=1e-12, atol=1e-12)
+        assert np.allclose(infos["diff_angle"], np.arctan2(tc[:, 1] - y, tc[:, 0] - x) - h, rtol=1e-12, atol=1e-12)
+        assert np.array_equal(infos["diff_heading"], th - h)
+    assert n_done > n   # episodes ended and restarted under the frame
+    env.close()
+
+
+def _area_centroid(quads):
+    """shapely Polygon.centroid of a batch of quads (n, 4, 2), fp64 -- what t2d_set_target_areas computes."""
+    q = np.asarray(quads, np.float64)
+    nxt = np.roll(q, -1, 1)
+    w = q[:, :, 0] * nxt[:, :, 1] - nxt[:, :, 0] * q[:, :, 1]
+    a = w.sum(1) / 2
+    return np.stack([((q[:, :, 0] + nxt[:, :, 0]) * w).sum(1), ((q[:, :, 1] + nxt[:, :, 1]) * w).sum(1)], 1) / (6 * a[:, None])
+
+
+def test_host_frame_views_without_copy_and_without_lidar():
+    """copy=False hands out views of the two alternating pinned frames (valid until the step after next); info_lidar=False
+    leaves the scan out of the host path."""
+    from tactics2d_amd.envs import VecParkingEnv
+    n = 64
+    a = VecParkingEnv(n, max_step=30, seed=5, auto_reset=True)
+    b = VecParkingEnv(n, max_step=30, seed=5, auto_reset=True, copy=False, info_lidar=False)
+    a.reset(); obs_b0, infos_b = b.reset()
+    assert infos_b["lidar"] is None
+    rng = np.random.default_rng(2)
+    prev = None
+    for t in range(12):
+        act = a.action_space.sample(rng, n)
+        oa, ra, ta, ua, ia = a.step(act)
+        ob, rb, tb, ub, ib = b.step(act)
+        assert np.array_equal(oa, ob) and np.array_equal(ra, rb) and np.array_equal(ta, tb) and np.array_equal(ua, ub)
+        assert np.array_equal(ia["iou"], ib["iou"], equal_nan=True) and ib["lidar"] is None
+        if prev is not None:   # the previous step's views are still intact (two frames alternate)
+            assert np.array_equal(prev[0], prev[1])
+        prev = (ob, oa.copy())
+    a.close(); b.close()
