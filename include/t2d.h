@@ -72,6 +72,7 @@ extern "C" {
 #define T2D_ERR_NOMEM     3
 #define T2D_ERR_STATE     4   /* call order violated (e.g. step before param table)      */
 #define T2D_ERR_GEOMETRY  5   /* polygon not convex / degenerate / too many vertices     */
+#define T2D_ERR_ACTION    6   /* t2d_step_host: an action outside the caller's action box (InvalidAction, envs/parking.py:235-236); nothing was stepped */
 
 /* ---- physics model ids (column T2D_P_MODEL of a parameter row) --------------------- */
 #define T2D_MODEL_KINEMATICS 0   /* SingleTrackKinematics */
@@ -379,7 +380,8 @@ int t2d_sync(t2d_pool* pool);
  * actions from HOST memory, runs t2d_step (and, when the frame carries a lidar section, t2d_lidar_scan writing straight into
  * the frame), packs everything the 5-tuple needs of the ego of every env into one contiguous FRAME and brings it to pinned host
  * memory with one asynchronous copy and one stream synchronisation -- instead of one blocking copy per field.
- *   t2d_frame_config   chooses the sections (T2D_FRAME_*), allocates the device frame and two pinned host frames, and fills
+ *   t2d_frame_config   chooses the sections (T2D_FRAME_*), allocates the device frame and n_host_frames (1..T2D_MAX_HOST_FRAMES)
+ *                      pinned host frames, and fills
  *                      *layout with the byte offsets of the sections inside a frame (-1 = section absent).  Call it again after
  *                      t2d_lidar_config changed the beam count.  T2D_FRAME_ZEROCOPY: no copy commands at all -- the step kernel
  *                      reads the actions from mapped host memory and the pack / lidar kernels write the mapped host frame
@@ -389,8 +391,13 @@ int t2d_sync(t2d_pool* pool);
  *   t2d_step_host      actions_host = f32 [n_env * max_agents][2] in the reference's action layout (steering, accel)
  *                      (envs/parking.py:239; a point mass: (ay, ax)), or NULL = the actions already in / bound to the pool.
  *                      Ends any t2d_bind_actions binding (the pool reads a buffer of its own from then on).  Returns with
- *                      *frame_host pointing at the filled host frame: valid until the call after the next one (two frames
- *                      alternate).  Reports a failed scene regeneration / chained launch like t2d_sync does.
+ *                      *frame_host pointing at the filled host frame: frame_index (0 .. n_host_frames - 1) names the pinned
+ *                      frame to fill -- a caller that hands the frame's memory on (numpy views) picks one nobody holds any
+ *                      more, and no copy is needed -- or -1 = the frames in turn.  Reports a failed scene regeneration like
+ *                      t2d_sync does.
+ *                      action_box = {steering lo, steering hi, accel lo, accel hi} or NULL: `action_space.contains(action)`
+ *                      of envs/parking.py:235-236 for every row, checked while the actions are staged (closed bounds, a NaN
+ *                      is outside) -- T2D_ERR_ACTION, nothing stepped, the message names the first offending row.
  *   t2d_frame_fetch    the frame of the CURRENT state without stepping (what reset() returns; the lidar section is scanned
  *                      from the current poses).
  * Frame sections (E = n_env; every offset a multiple of 256 B):
@@ -406,16 +413,18 @@ int t2d_sync(t2d_pool* pool);
 #define T2D_FRAME_LIDAR    1u
 #define T2D_FRAME_TARGET   2u
 #define T2D_FRAME_ZEROCOPY 4u
+#define T2D_MAX_HOST_FRAMES 16
 typedef struct t2d_frame_layout {
     int64_t bytes;          /* size of one frame */
     int64_t off_obs, off_rel, off_reward, off_status, off_iou, off_frame_ms, off_cnt_step, off_episode;
     int64_t off_target, off_target_heading, off_lidar;   /* -1 = absent */
     int32_t n_env, n_beams;
 } t2d_frame_layout;
-int t2d_frame_config(t2d_pool* pool, uint32_t sections, t2d_frame_layout* layout);
+int t2d_frame_config(t2d_pool* pool, uint32_t sections, int32_t n_host_frames, t2d_frame_layout* layout);
 int t2d_set_target_headings(t2d_pool* pool, const double* heading_host);
-int t2d_step_host(t2d_pool* pool, const float* actions_host, int32_t interval_ms, void* hip_stream, const void** frame_host);
-int t2d_frame_fetch(t2d_pool* pool, void* hip_stream, const void** frame_host);
+int t2d_step_host(t2d_pool* pool, const float* actions_host, const float* action_box, int32_t interval_ms, void* hip_stream,
+                  int32_t frame_index, const void** frame_host);
+int t2d_frame_fetch(t2d_pool* pool, void* hip_stream, int32_t frame_index, const void** frame_host);
 
 /* Episode-start snapshot for device-side (auto-)reset -- the vector-env counterpart of
  * ParkingEnv.reset (envs/parking.py:262-298) without a host round trip.

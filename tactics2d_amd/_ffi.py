@@ -11,7 +11,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.environ.get("T2D_LIB_NAME", "libt2d_hip.so"))
 
-OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_GEOMETRY = 0, 1, 2, 3, 4, 5
+OK, ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_GEOMETRY, ERR_ACTION = 0, 1, 2, 3, 4, 5, 6
 
 
 class T2DError(RuntimeError):
@@ -75,10 +75,10 @@ SYMBOLS = {
     "t2d_download": (C.c_int, [_vp, C.c_int32, _vp, C.c_size_t]),
     "t2d_upload": (C.c_int, [_vp, C.c_int32, _vp, C.c_size_t]),
     "t2d_sync": (C.c_int, [_vp]),
-    "t2d_frame_config": (C.c_int, [_vp, C.c_uint32, C.POINTER(FrameLayout)]),
+    "t2d_frame_config": (C.c_int, [_vp, C.c_uint32, C.c_int32, C.POINTER(FrameLayout)]),
     "t2d_set_target_headings": (C.c_int, [_vp, _vp]),
-    "t2d_step_host": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.POINTER(_vp)]),
-    "t2d_frame_fetch": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
+    "t2d_step_host": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, C.c_int32, C.POINTER(_vp)]),
+    "t2d_frame_fetch": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(_vp)]),
     "t2d_snapshot": (C.c_int, [_vp]),
     "t2d_restore": (C.c_int, [_vp, C.c_int32, _vp]),
     "t2d_set_auto_reset": (C.c_int, [_vp, C.c_int32]),

@@ -2072,11 +2072,13 @@ static void frame_release(t2d_pool* p) {
     p->d_actions = nullptr;
     p->h_actions = nullptr;
     p->frame_sections = 0;
+    p->n_host_frames = 0;
     p->frame_layout = t2d_frame_layout{};
 }
 
-int t2d_frame_config(t2d_pool* p, uint32_t sections, t2d_frame_layout* layout) {
+int t2d_frame_config(t2d_pool* p, uint32_t sections, int32_t n_host_frames, t2d_frame_layout* layout) {
     if (!p) return T2D_ERR_INVALID;
+    if (n_host_frames < 1 || n_host_frames > T2D_MAX_HOST_FRAMES) return fail(p, T2D_ERR_INVALID, "need 1..16 host frames");
     if (sections & ~(T2D_FRAME_LIDAR | T2D_FRAME_TARGET | T2D_FRAME_ZEROCOPY)) return fail(p, T2D_ERR_INVALID, "unknown frame section bits");
     if ((sections & T2D_FRAME_LIDAR) && !p->lidar_on)
         return fail(p, T2D_ERR_STATE, "t2d_lidar_config must precede a frame with a lidar section");
@@ -2112,10 +2114,11 @@ int t2d_frame_config(t2d_pool* p, uint32_t sections, t2d_frame_layout* layout) {
     L.bytes = (int64_t)total;
     frame_release(p);
     const unsigned host_flags = hipHostMallocMapped | hipHostMallocCoherent;
-    for (char*& h : p->h_frame) {
-        T2D_HIP(p, hipHostMalloc((void**)&h, total, host_flags));
-        memset(h, 0, total);
+    for (int k = 0; k < n_host_frames; ++k) {
+        T2D_HIP(p, hipHostMalloc((void**)&p->h_frame[k], total, host_flags));
+        memset(p->h_frame[k], 0, total);
     }
+    p->n_host_frames = n_host_frames;
     const size_t act_bytes = (size_t)p->v.N * 2 * sizeof(float);
     T2D_HIP(p, hipHostMalloc((void**)&p->h_actions, act_bytes, host_flags));
     memset(p->h_actions, 0, act_bytes);
@@ -2140,11 +2143,14 @@ int t2d_set_target_headings(t2d_pool* p, const double* heading_host) {
 }
 
 // scan (optional) + pack + fetch of the current state on `s`; returns with the host frame filled
-static int frame_finish(t2d_pool* p, hipStream_t s, const void** frame_host) {
+static int frame_finish(t2d_pool* p, hipStream_t s, int frame_index, const void** frame_host) {
     const t2d_frame_layout& L = p->frame_layout;
     const bool zero_copy = (p->frame_sections & T2D_FRAME_ZEROCOPY) != 0;
-    char* host = p->h_frame[p->frame_turn];
-    p->frame_turn ^= 1;
+    if (frame_index < 0) {
+        frame_index = p->frame_turn;
+        p->frame_turn = (p->frame_turn + 1) % p->n_host_frames;
+    }
+    char* host = p->h_frame[frame_index];
     char* dev_out = p->d_frame;
     if (zero_copy) T2D_HIP(p, hipHostGetDevicePointer((void**)&dev_out, host, 0));
     int rc;
@@ -2182,14 +2188,36 @@ static int frame_finish(t2d_pool* p, hipStream_t s, const void** frame_host) {
     return T2D_OK;
 }
 
-int t2d_step_host(t2d_pool* p, const float* actions_host, int32_t interval_ms, void* hip_stream, const void** frame_host) {
+int t2d_step_host(t2d_pool* p, const float* actions_host, const float* action_box, int32_t interval_ms, void* hip_stream,
+                  int32_t frame_index, const void** frame_host) {
     if (!p) return T2D_ERR_INVALID;
     if (!p->frame_sections) return fail(p, T2D_ERR_STATE, "t2d_frame_config must precede t2d_step_host");
+    if (frame_index >= p->n_host_frames) return fail(p, T2D_ERR_INVALID, "frame_index out of range");
     T2D_HIP(p, hipSetDevice(p->device));
     hipStream_t s = (hipStream_t)hip_stream;
     if (actions_host) {
         const size_t act_bytes = (size_t)p->v.N * 2 * sizeof(float);
-        memcpy(p->h_actions, actions_host, act_bytes);
+        if (action_box) {   // Box.contains for every row, in the pass that stages the actions
+            const float lo0 = action_box[0], hi0 = action_box[1], lo1 = action_box[2], hi1 = action_box[3];
+            float* dst = p->h_actions;
+            int ok = 1;
+            for (size_t i = 0, n = (size_t)p->v.N; i < n; ++i) {
+                const float a = actions_host[2 * i], b = actions_host[2 * i + 1];
+                ok &= (int)(a >= lo0) & (int)(a <= hi0) & (int)(b >= lo1) & (int)(b <= hi1);
+                dst[2 * i] = a;
+                dst[2 * i + 1] = b;
+            }
+            if (!ok) {
+                size_t bad = 0;
+                for (size_t n = (size_t)p->v.N; bad < n; ++bad) {
+                    const float a = actions_host[2 * bad], b = actions_host[2 * bad + 1];
+                    if (!(a >= lo0 && a <= hi0 && b >= lo1 && b <= hi1)) break;
+                }
+                return fail(p, T2D_ERR_ACTION, "action row " + std::to_string(bad) + " is not in the action space");
+            }
+        } else {
+            memcpy(p->h_actions, actions_host, act_bytes);
+        }
         const float* dev_act = p->d_actions;
         if (p->frame_sections & T2D_FRAME_ZEROCOPY) {
             T2D_HIP(p, hipHostGetDevicePointer((void**)&dev_act, p->h_actions, 0));
@@ -2205,15 +2233,16 @@ int t2d_step_host(t2d_pool* p, const float* actions_host, int32_t interval_ms, v
     }
     int rc = t2d_step(p, interval_ms, hip_stream);
     if (rc != T2D_OK) return rc;
-    return frame_finish(p, s, frame_host);
+    return frame_finish(p, s, frame_index, frame_host);
 }
 
-int t2d_frame_fetch(t2d_pool* p, void* hip_stream, const void** frame_host) {
+int t2d_frame_fetch(t2d_pool* p, void* hip_stream, int32_t frame_index, const void** frame_host) {
     if (!p) return T2D_ERR_INVALID;
     if (!p->frame_sections) return fail(p, T2D_ERR_STATE, "t2d_frame_config must precede t2d_frame_fetch");
+    if (frame_index >= p->n_host_frames) return fail(p, T2D_ERR_INVALID, "frame_index out of range");
     if (!p->have_params || !p->have_reset) return fail(p, T2D_ERR_STATE, "t2d_reset must precede t2d_frame_fetch");
     T2D_HIP(p, hipSetDevice(p->device));
-    return frame_finish(p, (hipStream_t)hip_stream, frame_host);
+    return frame_finish(p, (hipStream_t)hip_stream, frame_index, frame_host);
 }
 
 int t2d_lidar_config(t2d_pool* p, int32_t n_beams, float max_range, int32_t include_participants,

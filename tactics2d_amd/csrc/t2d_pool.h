@@ -318,8 +318,8 @@ struct t2d_pool {
     uint32_t frame_sections = 0;
     t2d_frame_layout frame_layout{};
     char* d_frame = nullptr;          // device frame (copy mode)
-    char* h_frame[2]{};               // pinned (and mapped) host frames, alternating
-    int frame_turn = 0;
+    char* h_frame[T2D_MAX_HOST_FRAMES]{};   // pinned (and mapped) host frames
+    int n_host_frames = 0, frame_turn = 0;
     float* h_actions = nullptr;       // pinned (and mapped) staging of the host actions, [N][2]
     float* d_actions = nullptr;       // device copy of them (copy mode)
     double* d_target_heading = nullptr;

@@ -14,6 +14,7 @@ gymnasium is not a dependency: `Box` below is the minimal stand-in for `spaces.B
 import numpy as np
 
 from . import layout as L, scenarios
+from ._ffi import ERR_ACTION, T2DError
 from .traffic import BatchedScenarioManager, ScenarioStatus, TrafficStatus
 
 MAX_STEER = 0.524  # envs/parking.py:30
@@ -57,9 +58,12 @@ class VecParkingEnv:
         "layout" = the fixed bay layout of scenarios.parking (BASELINE config 2).
         The host path (`step`) is ONE library call per step (t2d_step_host): actions up, step + 360-beam scan + pack, one
         frame back (pool.HostFrame).  info_lidar=False leaves the scan out of the host path (info["lidar"] is None: at 4096
-        envs the 360 floats per env are 5.9 MB per step over PCIe); copy=False hands out views of the library's pinned
-        frames instead of copies (valid until the step after next); zero_copy: the kernels read the actions from / write
-        the frame to mapped host memory instead of copy commands (None = for pools of at most 64 envs)."""
+        envs the 360 floats per env are 5.9 MB per step over PCIe).  The arrays handed out are views of pinned host frames:
+        copy=True (default) fills a frame nobody holds a view of any more -- as good as fresh arrays, without a memcpy (a
+        caller that keeps many steps' results by reference gets real copies once the four frames are held); copy=False
+        takes the frames in turn (valid for three further steps).  zero_copy: the kernels read the actions from / write
+        the frame to mapped host memory instead of copy commands (None = for pools of at most 16384 envs; beyond, the
+        8 B per env of the actions would cross PCIe inside the step kernel)."""
         if scene_source not in ("layout", "generator"):
             raise ValueError(f"unknown scene_source {scene_source!r}")
         self.scene_source = scene_source
@@ -71,9 +75,11 @@ class VecParkingEnv:
         self.auto_reset = auto_reset
         self.info_lidar = bool(info_lidar)
         self.copy = bool(copy)
-        self.zero_copy = self.n_envs <= 64 if zero_copy is None else bool(zero_copy)
+        self.zero_copy = self.n_envs <= 16384 if zero_copy is None else bool(zero_copy)
         self.observation_space = Box(np.full(6, -np.inf), np.full(6, np.inf))
         self.action_space = Box([-self._max_steer, -self._max_accel], [self._max_steer, self._max_accel])
+        lo, hi = self.action_space.low, self.action_space.high
+        self._action_box = np.float32([lo[0], hi[0], lo[1], hi[1]]) if continuous else None
         # ScenarioManager(max_step, step_size=100, ...)  envs/parking.py:144-146
         self.scenario_manager = BatchedScenarioManager(self.n_envs, 1, max_step, 100, device_id=device_id)
         self._seed = seed
@@ -120,23 +126,21 @@ class VecParkingEnv:
         self._moving_targets = self.scene_source == "generator" and self.auto_reset
         m.pool.frame_config(lidar=self.info_lidar, target=self._moving_targets, zero_copy=self.zero_copy)
         self._target_area, self._target_heading = self._scene.target, self._scene.target_heading
-        fr = self._take(m.pool.frame_fetch())
+        fr = self._last = m.pool.frame_fetch(fresh=self.copy)
         return fr.obs, self._infos(fr)
 
     # ------------------------------------------------------------------ step
     def _to_continuous(self, actions):
         if self.continuous:
-            a = np.ascontiguousarray(actions, np.float32).reshape(self.n_envs, 2)
-            if not (np.all(a >= self.action_space.low) and np.all(a <= self.action_space.high)):
-                raise InvalidAction(f"Action {actions} is not in the action space.")
-            return a
+            # (`action_space.contains` runs inside t2d_step_host, in the pass that stages the actions: 50 us of numpy at 4096 envs)
+            try:
+                return np.ascontiguousarray(actions, np.float32).reshape(self.n_envs, 2)
+            except (ValueError, TypeError):
+                raise InvalidAction(f"Action {actions} is not in the action space.") from None
         idx = np.asarray(actions).reshape(self.n_envs)
         if not np.all(np.isin(idx, list(self._discrete_actions))):
             raise InvalidAction(f"Action {actions} is not in the action space.")
         return np.array([self._discrete_actions[int(i)] for i in idx], np.float32)
-
-    def _take(self, frame):
-        return frame.copy() if self.copy else frame
 
     def step(self, actions):
         """(obs[n, 6], reward[n], terminated[n], truncated[n], infos) -- envs/parking.py:219-256 for every env: one
@@ -144,10 +148,14 @@ class VecParkingEnv:
         if self._scene is None:
             raise RuntimeError("call reset() first")
         a = self._to_continuous(actions)
-        fr = self._take(self.scenario_manager.pool.step_host(a, 100))
+        try:
+            fr = self._last = self.scenario_manager.pool.step_host(a, 100, action_box=self._action_box, fresh=self.copy)
+        except T2DError as exc:
+            if exc.code == ERR_ACTION:
+                raise InvalidAction(f"Action {actions} is not in the action space.") from None
+            raise
         self.scenario_manager._flags_cache = None
-        st = fr.status
-        return fr.obs, fr.reward, st[:, 2].view(np.bool_), st[:, 3].view(np.bool_), self._infos(fr)
+        return fr.obs, fr.reward, fr.terminated, fr.truncated, self._infos(fr)
 
     def step_torch(self, actions, stream=None):
         """The device-resident step: `actions` is a float32 CUDA tensor [n_envs, 2] in the reference's layout (steering,
@@ -189,17 +197,18 @@ class VecParkingEnv:
     def _infos(self, fr):
         """_get_infos (envs/parking.py:203-217) for every env, as views of the frame."""
         obs, st = fr.obs, fr.status
-        if self._moving_targets:
-            self._target_area, self._target_heading = fr.target, fr.target_heading
+        ta, th = (fr.target, fr.target_heading) if self._moving_targets else (self._target_area, self._target_heading)
         return dict(state=dict(x=obs[:, 0], y=obs[:, 1], heading=obs[:, 2], speed=obs[:, 3], vx=obs[:, 4], vy=obs[:, 5],
                                frame=fr.frame_ms),
                     scenario_status=st[:, 0], traffic_status=st[:, 1],
-                    target_area=self._target_area, target_heading=self._target_heading,
+                    target_area=ta, target_heading=th,
                     diff_position=fr.rel[:, 0], diff_angle=fr.rel[:, 1], diff_heading=fr.rel[:, 2],
                     iou=fr.iou, lidar=fr.lidar, episode=fr.episode)
 
     def _targets(self):
         """Target areas / headings of the scenes the envs are in NOW (as of the last step / reset)."""
+        if self._moving_targets:   # (the env keeps the HostFrame object, not views of it: the frame stays free to be refilled)
+            return self._last.target.copy(), self._last.target_heading.copy()
         return self._target_area, self._target_heading
 
     def render(self):
@@ -227,8 +236,6 @@ class ParkingEnv:
     def reset(self, seed=None, options=None):
         obs, infos = self._vec.reset(seed, options)
         self._abuf = np.zeros((1, 2), np.float32)
-        lo, hi = self.action_space.low, self.action_space.high
-        self._bounds = (float(lo[0]), float(hi[0]), float(lo[1]), float(hi[1]))
         infos = _first(infos)
         infos["scenario_status"] = ScenarioStatus(int(infos["scenario_status"]))
         infos["traffic_status"] = TrafficStatus(int(infos["traffic_status"]))
@@ -246,24 +253,25 @@ class ParkingEnv:
                 a[0] = action
             except (ValueError, TypeError):
                 raise InvalidAction(f"Action {action} is not in the action space.") from None
-            lo0, hi0, lo1, hi1 = self._bounds
-            if not (lo0 <= a[0, 0] <= hi0 and lo1 <= a[0, 1] <= hi1):   # (NaN fails both, like Box.contains)
-                raise InvalidAction(f"Action {action} is not in the action space.")
         else:
             try:
                 a[0] = v._discrete_actions[int(action)]
             except (KeyError, ValueError, TypeError):
                 raise InvalidAction(f"Action {action} is not in the action space.") from None
-        fr = v.scenario_manager.pool.step_host(a, 100)
+        try:   # (`action_space.contains`: checked by the library while it stages the action -- a NaN is outside, like Box.contains)
+            fr = v.scenario_manager.pool.step_host(a, 100, action_box=v._action_box)
+        except T2DError as exc:
+            if exc.code == ERR_ACTION:
+                raise InvalidAction(f"Action {action} is not in the action space.") from None
+            raise
         v.scenario_manager._flags_cache = None
         o = fr.obs[0].copy()
         st = fr.status[0]
         rel = fr.rel[0]
-        if v._moving_targets:
-            v._target_area, v._target_heading = fr.target.copy(), fr.target_heading.copy()
+        ta, th = (fr.target[0].copy(), fr.target_heading[0]) if v._moving_targets else (v._target_area[0], v._target_heading[0])
         infos = dict(state=dict(x=o[0], y=o[1], heading=o[2], speed=o[3], vx=o[4], vy=o[5], frame=fr.frame_ms[0]),
                      scenario_status=ScenarioStatus(int(st[0])), traffic_status=TrafficStatus(int(st[1])),
-                     target_area=v._target_area[0], target_heading=v._target_heading[0],
+                     target_area=ta, target_heading=th,
                      diff_position=rel[0], diff_angle=rel[1], diff_heading=rel[2],
                      iou=fr.iou[0], lidar=None if fr.lidar is None else fr.lidar[0].copy(), episode=fr.episode[0])
         return o, float(fr.reward[0]), bool(st[2]), bool(st[3]), infos

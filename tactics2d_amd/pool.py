@@ -4,6 +4,7 @@ Host logic only: argument marshalling and error translation.  All compute happen
 HIP kernels behind libt2d_hip.so.
 """
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -34,8 +35,8 @@ class _DevArray:
 
 class HostFrame:
     """numpy views of one host frame of t2d_step_host (include/t2d.h): what ParkingEnv.step hands its caller, for the ego of
-    every env.  Views of the library's pinned frames are valid until the step after next; `copy()` returns a frame that owns
-    its memory."""
+    every env.  `copy()` returns a frame that owns its memory; `in_use()` tells whether anything outside this object still
+    holds a view of the frame (so that the pinned frame can be handed out again without a copy)."""
     _SECTIONS = (("rel", "off_rel", np.float64, 3), ("obs", "off_obs", np.float32, 6), ("reward", "off_reward", np.float32, 0),
                  ("status", "off_status", np.uint8, 4), ("iou", "off_iou", np.float32, 0),
                  ("frame_ms", "off_frame_ms", np.int32, 0), ("cnt_step", "off_cnt_step", np.int32, 0),
@@ -55,9 +56,22 @@ class HostFrame:
                 setattr(self, name, None)
                 continue
             v = base[off:off + nb].view(dt)
-            setattr(self, name, v.reshape(n, cols) if cols else v)
-        if self.target is not None:
-            self.target = self.target.reshape(n, 4, 2)
+            setattr(self, name, v.reshape(n, 4, 2) if name == "target" else v.reshape(n, cols) if cols else v)
+        st = self.status
+        self.terminated, self.truncated = st[:, 2].view(np.bool_), st[:, 3].view(np.bool_)
+        del st, v
+        # everything a caller can get hold of is one of these objects or a view whose .base is one of them (numpy collapses
+        # the base chain of a view to the array that exposes the memory): their reference counts tell whether the frame is held
+        self._tracked = [self.base] + [v for v in self.__dict__.values() if isinstance(v, np.ndarray) and v is not self.base]
+        # idle: a view is held by its attribute, the list above, _refs' loop variable and getrefcount's own argument; the
+        # frame's memory by the same four and by every view (as its .base)  (tests/test_host.py holds this against CPython)
+        self._idle_refs = [len(self._tracked) + 3] + [4] * (len(self._tracked) - 1)
+
+    def _refs(self):
+        return [sys.getrefcount(v) for v in self._tracked]
+
+    def in_use(self):
+        return self._refs() != self._idle_refs
 
     def copy(self, lidar=True):
         """A frame that owns its memory (one memcpy); lidar=False leaves the lidar section out (its views become None)."""
@@ -218,44 +232,70 @@ class ParticipantPool:
         return out
 
     # ---------------------------------------------------------------- the Gym-API host path
-    def frame_config(self, lidar=False, target=False, zero_copy=False):
-        """Sections of the host frame t2d_step_host fills (t2d_frame_config); returns the layout."""
+    def frame_config(self, lidar=False, target=False, zero_copy=False, n_frames=4):
+        """Sections of the host frame t2d_step_host fills (t2d_frame_config) and the number of pinned host frames; returns
+        the layout."""
         lay = _ffi.FrameLayout()
         mask = (L.FRAME_LIDAR if lidar else 0) | (L.FRAME_TARGET if target else 0) | (L.FRAME_ZEROCOPY if zero_copy else 0)
-        self._ck(self._lib.t2d_frame_config(self._h, mask, C.byref(lay)))
+        self._ck(self._lib.t2d_frame_config(self._h, mask, int(n_frames), C.byref(lay)))
         self.frame_layout = lay
-        self._frames = {}
+        self.n_frames = int(n_frames)
+        self._frames = [None] * self.n_frames
         self._frame_ptr = C.c_void_p()
+        self._frame_turn = 0
         return lay
 
     def set_target_headings(self, heading):
         h = _arr(heading, np.float64, self.n_env, "target_heading")
         self._ck(self._lib.t2d_set_target_headings(self._h, _p(h)))
 
-    def _frame(self):
-        ptr = self._frame_ptr.value
-        fr = self._frames.get(ptr)
-        if fr is None:   # (two pinned frames alternate: their views are built once)
-            buf = (C.c_uint8 * self.frame_layout.bytes).from_address(ptr)
-            fr = self._frames[ptr] = HostFrame(np.frombuffer(buf, np.uint8), self.frame_layout)
+    def _pick_frame(self, fresh):
+        """Index of the pinned frame the next call fills and whether its contents must be copied out.  fresh=False: the frames
+        in turn (views valid until n_frames - 1 further calls).  fresh=True: a frame nobody holds a view of any more -- what the
+        caller gets is then as good as a new array, without a copy; should every frame but the last still be held (a caller
+        that keeps the results of many steps by reference), the last one is filled and copied out."""
+        if not fresh:
+            k = self._frame_turn
+            self._frame_turn = (k + 1) % self.n_frames
+            return k, False
+        last = self.n_frames - 1
+        for k in range(last):
+            fr = self._frames[k]
+            if fr is None or not fr.in_use():
+                return k, False
+        return last, True
+
+    def _frame(self, k):
+        fr = self._frames[k]
+        if fr is None:   # (the views of a pinned frame are built once)
+            buf = (C.c_uint8 * self.frame_layout.bytes).from_address(self._frame_ptr.value)
+            fr = self._frames[k] = HostFrame(np.frombuffer(buf, np.uint8), self.frame_layout)
         return fr
 
-    def step_host(self, actions, interval_ms=100, stream=None):
+    def step_host(self, actions, interval_ms=100, stream=None, action_box=None, fresh=False):
         """ParkingEnv.step for every env, host to host (t2d_step_host): actions float32 [n, 2] (steering, accel) C-contiguous or
-        None (the actions already in the pool); returns the HostFrame -- views of pinned memory valid until the step after next."""
+        None (the actions already in the pool); returns the HostFrame -- views of pinned memory (see _pick_frame for how long
+        they stay valid).  action_box: float32 [4] (steering lo, hi, accel lo, hi) = `action_space.contains` for every row,
+        checked by the library while it stages the actions (T2DError with code ERR_ACTION, nothing stepped)."""
         if actions is not None:
             if actions.dtype != np.float32 or actions.size != 2 * self.n or not actions.flags.c_contiguous:
                 raise ValueError(f"actions must be C-contiguous float32 [{self.n}, 2]")
             actions = actions.ctypes.data
-        rc = self._lib.t2d_step_host(self._h, actions, interval_ms, stream, C.byref(self._frame_ptr))
+        if action_box is not None:
+            action_box = action_box.ctypes.data
+        k, must_copy = self._pick_frame(fresh)
+        rc = self._lib.t2d_step_host(self._h, actions, action_box, interval_ms, stream, k, C.byref(self._frame_ptr))
         if rc:
             self._ck(rc)
-        return self._frame()
+        fr = self._frame(k)
+        return fr.copy() if must_copy else fr
 
-    def frame_fetch(self, stream=None):
+    def frame_fetch(self, stream=None, fresh=False):
         """The frame of the current state without stepping (t2d_frame_fetch)."""
-        self._ck(self._lib.t2d_frame_fetch(self._h, stream, C.byref(self._frame_ptr)))
-        return self._frame()
+        k, must_copy = self._pick_frame(fresh)
+        self._ck(self._lib.t2d_frame_fetch(self._h, stream, k, C.byref(self._frame_ptr)))
+        fr = self._frame(k)
+        return fr.copy() if must_copy else fr
 
     def set_integrator_variant(self, variant):
         v = {"exact": 0, "fast": 1}.get(variant, variant)

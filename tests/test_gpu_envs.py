@@ -281,3 +281,31 @@ def test_host_frame_views_without_copy_and_without_lidar():
             assert np.array_equal(prev[0], prev[1])
         prev = (ob, oa.copy())
     a.close(); b.close()
+
+
+def test_default_step_results_are_never_overwritten():
+    """copy=True (default): what step() returns behaves like fresh arrays although no memcpy happens while pinned frames are
+    free -- a caller that keeps EVERY step's results by reference still finds them intact later."""
+    from tactics2d_amd.envs import VecParkingEnv
+    n = 33
+    env = VecParkingEnv(n, max_step=30, seed=7, auto_reset=True)
+    env.reset()
+    rng = np.random.default_rng(1)
+    kept, saved = [], []
+    for t in range(12):
+        out = env.step(env.action_space.sample(rng, n))
+        kept.append(out)
+        saved.append((out[0].copy(), out[1].copy(), out[4]["lidar"].copy(), out[4]["state"]["x"].copy()))
+    for (obs, rew, term, trunc, infos), (o, r, l, x) in zip(kept, saved):
+        assert np.array_equal(obs, o) and np.array_equal(rew, r) and np.array_equal(infos["lidar"], l)
+        assert np.array_equal(infos["state"]["x"], x)
+    # ... and once the caller lets go, the pinned frames are handed out again (no copies: the arrays are views of them)
+    del kept, out, obs, rew, term, trunc, infos
+    pool = env.scenario_manager.pool
+    bases = set()
+    for t in range(6):
+        o = env.step(env.action_space.sample(rng, n))[0]
+        bases.add(o.base.__array_interface__["data"][0])
+        del o
+    assert len(bases) <= 2 and bases <= {fr.base.__array_interface__["data"][0] for fr in pool._frames if fr is not None}
+    env.close()

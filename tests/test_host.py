@@ -223,3 +223,45 @@ def test_batched_state_keeps_the_reference_state_semantics():
     s3.set_velocity([1.0], [1.0])
     assert [float(v[0]) for v in s3.velocity] == k["setters"]["velocity_after_set_velocity"]
     assert float(s3.speed[0]) == k["setters"]["speed_after_set_velocity"] == 3.0
+
+
+def test_host_frame_views_and_in_use_tracking():
+    """pool.HostFrame (the Gym-API host path): section views of a frame laid out by t2d_frame_config, and the reference-count
+    test that lets a pinned frame be handed out again without a copy only when nobody holds a view of it."""
+    from tactics2d_amd._ffi import FrameLayout
+    from tactics2d_amd.pool import HostFrame
+    n, beams = 5, 7
+    lay = FrameLayout()
+    off = 256
+    for name, nb in (("off_rel", 24 * n), ("off_obs", 24 * n), ("off_reward", 4 * n), ("off_status", 4 * n), ("off_iou", 4 * n),
+                     ("off_frame_ms", 4 * n), ("off_cnt_step", 4 * n), ("off_episode", 4 * n), ("off_target_heading", 8 * n),
+                     ("off_target", 32 * n), ("off_lidar", 4 * n * beams)):
+        setattr(lay, name, off)
+        off += (nb + 255) & ~255
+    lay.bytes, lay.n_env, lay.n_beams = off, n, beams
+    base = np.zeros(off, np.uint8)
+    fr = HostFrame(base, lay)
+    del base
+    assert fr.obs.shape == (n, 6) and fr.rel.shape == (n, 3) and fr.target.shape == (n, 4, 2) and fr.lidar.shape == (n, beams)
+    assert fr.status.shape == (n, 4) and fr.terminated.dtype == np.bool_ and fr.reward.shape == (n,)
+    fr.status[2, 2] = 1
+    assert fr.terminated.tolist() == [False, False, True, False, False]
+    assert not fr.in_use()
+    held = fr.obs                      # the section view itself
+    assert fr.in_use()
+    del held
+    assert not fr.in_use()
+    col = fr.obs[:, 0]                 # a view of a view: its .base is the frame's memory
+    assert fr.in_use()
+    del col
+    info = {"state": {"x": fr.obs[:, 0]}, "lidar": fr.lidar}
+    assert fr.in_use()
+    del info
+    t = fr.terminated
+    assert fr.in_use()
+    del t
+    assert not fr.in_use()
+    own = fr.copy(lidar=False)         # owns its memory, no lidar section
+    assert own.lidar is None and own.obs.base is not fr.base and np.array_equal(own.status, fr.status)
+    x = float(fr.obs[0, 0])            # scalars do not hold the frame
+    assert not fr.in_use() and x == 0.0
