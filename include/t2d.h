@@ -552,8 +552,12 @@ int t2d_parking_scenes(t2d_pool* pool, uint64_t seed, int64_t first_env, int64_t
 int t2d_get_parking_scenes(t2d_pool* pool, float* quads, int32_t* quad_id, int32_t* n_quads, double* start,
                            float* target, double* target_heading, float* boundary, uint32_t* info, int32_t* episode);
 
-/* Kernel variants: 0 = exact (library-grade fp64 trig every sub-step), 1 = fast
- * (rotation recurrence, default).  Both satisfy the 1e-5 contract; see DESIGN.md.       */
+/* Kernel variants: 0 = exact (library-grade fp64 trig every sub-step), 1 = fast (default: SingleTrackKinematics steps whose
+ * speed stays inside its bounds are RESUMMED -- the Euler sum of the step's sub-steps evaluated as a series instead of
+ * iterated, truncation < 1e-9 m --, everything else advances cos / sin by a rotation recurrence), 2 = fast with the kinematic
+ * steps iterated as well (rounds 1-4's form; A/B measurements and tests).  Pools of fewer than two waves per SIMD of the device
+ * (< 131072 participants on an MI355X) iterate under variant 1 too -- a lone wave is a latency chain the series' table fetch
+ * lengthens --; 3 = variant 1 with the series whatever the pool size (tests).  All satisfy the 1e-5 contract; see DESIGN.md. */
 int t2d_set_integrator_variant(t2d_pool* pool, int32_t variant);
 
 /* Which pure OUTPUT columns the integrators store.  The reference's step() returns a State carrying vx / vy and the

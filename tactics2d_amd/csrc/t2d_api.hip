@@ -1240,10 +1240,64 @@ static int idm_impl(t2d_pool* p, hipStream_t s, const int32_t* forced_leader = n
 
 // what a stepping launch needs of its interval beside the integer: interval_ms / 1000 (PointMass's dt) in the view, and the
 // sub-step counts per type in the device table (one 32-thread launch on the step's stream whenever the interval changes)
+// Coefficients of the resummed kinematic step (PoolView::kin_coef) for n sub-steps.  With u = k - m the centred sub-step
+// index, w = u / M, the step's Euler sum  sum_k v_k (cos, sin)(theta_k),  theta_k = Theta + a w + b w^2,  v_k = V + ah M w,
+// needs the means over k of cos / sin / w cos / w sin of (a w + b w^2); expanding in a (to a^(2 D + 1)) and b (to b^3) and
+// using that the odd moments of w vanish leaves eight polynomials in a^2 whose coefficients are moments mu_p = mean(w^p)
+// over factorials (SingleTrackKinematics._step, physics/single_track_kinematics.py:126-176, is the sum being restated).
+static void kinematics_resum_table(t2d::PoolView& v, int n) {
+    v.kin_n = 0;
+    if (n < 1) return;
+    constexpr int D = t2d::kKinDegree;
+    const long double m = ((long double)n - 1) / 2, M = (long double)n / 2;
+    long double mu[2 * D + 9];
+    for (int q = 0; q <= 2 * D + 8; ++q) mu[q] = 0;
+    for (int k = 0; k < n; ++k) {
+        const long double w = ((long double)k - m) / M;
+        long double pw = 1;
+        for (int q = 0; q <= 2 * D + 8; ++q) {
+            mu[q] += pw;
+            pw *= w;
+        }
+    }
+    for (int q = 0; q <= 2 * D + 8; ++q) mu[q] /= (long double)n;
+    long double fact[2 * D + 3];
+    fact[0] = 1;
+    for (int q = 1; q <= 2 * D + 2; ++q) fact[q] = fact[q - 1] * q;
+    for (int i = 0; i <= D; ++i) {
+        const long double sg = (i & 1) ? -1.0L : 1.0L;
+        const long double qe = sg / fact[2 * i], ro = sg / fact[2 * i + 1];
+        v.kin_coef[i][t2d::KIN_Q0] = (double)(qe * mu[2 * i]);                  // E cos:   Q0 + b^2 Q4
+        v.kin_coef[i][t2d::KIN_Q4] = (double)(-0.5L * qe * mu[2 * i + 4]);
+        v.kin_coef[i][t2d::KIN_Q2] = (double)(qe * mu[2 * i + 2]);              // E sin:   b (Q2 + b^2 Q6)
+        v.kin_coef[i][t2d::KIN_Q6] = (double)(-qe * mu[2 * i + 6] / 6);
+        v.kin_coef[i][t2d::KIN_R4] = (double)(-ro * mu[2 * i + 4]);             // E w cos: a b (R4 + b^2 R8)
+        v.kin_coef[i][t2d::KIN_R8] = (double)(ro * mu[2 * i + 8] / 6);
+        v.kin_coef[i][t2d::KIN_R2] = (double)(ro * mu[2 * i + 2]);              // E w sin: a (R2 + b^2 R6)
+        v.kin_coef[i][t2d::KIN_R6] = (double)(-0.5L * ro * mu[2 * i + 6]);
+    }
+    const double g[8] = {(double)m, (double)M, (double)(m - 0.5L), (double)(m * (m - 1) / 2), (double)(M * M / 2),
+                         (double)(m + 1), (double)((m + 1) * (m + 1) / 2), (double)n};
+    memcpy(v.kin_geo, g, sizeof g);
+    v.kin_n = n;
+}
+
 static int prepare_interval(t2d_pool* p, int interval_ms, hipStream_t s) {
     if (interval_ms > T2D_MAX_INTERVAL_MS) return fail(p, T2D_ERR_INVALID, "interval_ms must be <= 32767");
     p->v.interval_s = (double)interval_ms / 1000;
     if (p->derived_interval != interval_ms) {
+        // the resummed kinematic step is built for ONE sub-step count: that of the first SingleTrackKinematics row (every
+        // type shares delta_t = 5 ms unless a caller says otherwise); lanes of a type with another count take the loop
+        int kn = 0;
+        for (int t = 0; t < p->v.n_types && !kn; ++t)
+            if ((int)p->host_params[t][T2D_P_MODEL] == T2D_MODEL_KINEMATICS && p->host_params[t][T2D_P_DELTA_T_MS] >= 1.0)
+                kn = interval_ms / (int)p->host_params[t][T2D_P_DELTA_T_MS];
+        // ... and only pools that put at least two waves on every SIMD: a lone wave is a latency chain, and the table's scalar
+        // loads (cache misses on first touch) lengthen it by more than the twenty loop trips they replace (same-box A/B,
+        // 512 x 32 envs one launch per step: 12.8 -> 13.4 us with the series)
+        if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
+        const bool fills = (long long)p->v.N >= 2LL * 64 * 4 * (p->device_cus > 0 ? p->device_cus : 256);
+        kinematics_resum_table(p->v, p->kin_resum && (fills || p->kin_resum_forced) ? kn : 0);
         touch(p, s);
         T2D_HIP(p, t2d::launch_derive(p->d_params, p->v.n_types, interval_ms, s));
         p->derived_interval = interval_ms;
@@ -2397,8 +2451,11 @@ int t2d_debug_lane_safe_rects(int32_t n_env, const int32_t* env_lane_offsets, co
 
 int t2d_set_integrator_variant(t2d_pool* p, int32_t variant) {
     if (!p) return T2D_ERR_INVALID;
-    if (variant != 0 && variant != 1) return fail(p, T2D_ERR_INVALID, "variant must be 0 (exact) or 1 (fast)");
-    p->integrator_variant = variant;
+    if (variant < 0 || variant > 3) return fail(p, T2D_ERR_INVALID, "variant must be 0 (exact), 1 (fast), 2 (fast, kinematic steps iterated) or 3 (fast, resummed whatever the pool size)");
+    p->integrator_variant = variant ? 1 : 0;
+    p->kin_resum = variant != 2;
+    p->kin_resum_forced = variant == 3;
+    p->derived_interval = -1;   // (the resummation table travels with the interval's derived values)
     return T2D_OK;
 }
 

@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                 }
             }
         }
-        const integ::StepOut o = integ::step_participant<(FUSE > 0 ? 1 : 0)>(
+        const integ::StepOut o = integ::step_participant<(FUSE > 0 ? 1 : 0), !LOOP>(
             model, P, (double)fx, (double)fy, (double)fh, (double)fv, pvx, pvy, (double)fa0, (double)fa1, interval_ms, pv.interval_s);
         fx = (float)o.x;
         fy = (float)o.y;

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(PoolView pv, int inte
 
     StepOut o;
     if (model == T2D_MODEL_KINEMATICS) {
-        o = step_kinematics<VARIANT>(P, (double)fx, (double)fy, (double)fh, (double)fv, (double)fa0,
+        o = step_kinematics<VARIANT, true>(P, (double)fx, (double)fy, (double)fh, (double)fv, (double)fa0,
                                      (double)fa1, interval_ms);
     } else if (model == T2D_MODEL_DYNAMICS) {
         o = step_dynamics<VARIANT>(P, (double)fx, (double)fy, (double)fh, (double)fv, (double)fa0,

@@ -61,6 +61,79 @@ T2D_DEV void rotate_tiny(double eps, double& c, double& s) {
     s = sn;
 }
 
+// rotate (c, s) by |eps| <= 0.6: sin to e^13, cos to e^14 (truncation < 4e-16) -- the two rotations of a resummed step
+T2D_DEV void rotate_mid(double eps, double& c, double& s) {
+    const double e2 = eps * eps;
+    double ps = __builtin_fma(e2, 1.0 / 6227020800.0, -1.0 / 39916800.0);
+    ps = __builtin_fma(e2, ps, 1.0 / 362880.0);
+    ps = __builtin_fma(e2, ps, -1.0 / 5040.0);
+    ps = __builtin_fma(e2, ps, 1.0 / 120.0);
+    ps = __builtin_fma(e2, ps, -1.0 / 6.0);
+    ps = __builtin_fma(e2, ps, 1.0);
+    const double se = eps * ps;
+    double pc = __builtin_fma(e2, -1.0 / 87178291200.0, 1.0 / 479001600.0);
+    pc = __builtin_fma(e2, pc, -1.0 / 3628800.0);
+    pc = __builtin_fma(e2, pc, 1.0 / 40320.0);
+    pc = __builtin_fma(e2, pc, -1.0 / 720.0);
+    pc = __builtin_fma(e2, pc, 1.0 / 24.0);
+    pc = __builtin_fma(e2, pc, -0.5);
+    const double ce = __builtin_fma(e2, pc, 1.0);
+    const double cn = __builtin_fma(c, ce, -(s * se));
+    const double sn = __builtin_fma(s, ce, c * se);
+    c = cn;
+    s = sn;
+}
+
+// The resummed kinematic step.  With constant (clipped) acceleration and steering angle and the speed inside its bounds for
+// the whole step -- the linear case below -- the reference's n Euler sub-steps (single_track_kinematics.py:149-160) are
+//     x_n = x_0 + dt sum_k v_k cos(theta_k),   v_k = v_0 + k ah,   theta_k = theta_0 + k eps_0 + dlt k (k - 1) / 2
+// (theta = phi + beta, eps_0 = v_0 kh, dlt = ah kh).  Centred on u = k - m, m = (n - 1) / 2, and scaled by M = n / 2:
+//     theta_k = Theta + a w + b w^2,  v_k = V + (ah M) w,  w = u / M in (-1, 1),  a = (eps_0 + dlt (m - 1/2)) M,  b = dlt M^2 / 2
+// so the sum is  n [ (cos, sin)(Theta) rotated by (P, Q) ],  P = V E[cos f] + ah M E[w cos f],  Q = V E[sin f] + ah M E[w sin f],
+// f = a w + b w^2, E = the mean over the n sub-steps.  Expanding in a and b and dropping the odd moments of w (zero by
+// symmetry) leaves eight polynomials in a^2 whose coefficients depend on n alone (PoolView::kin_coef, built by the host):
+// one centre rotation + ~45 fma replace n x 11 operations.  |a| <= kResumAmax (half the heading change of the step),
+// |b| <= kResumBmax: truncation a^10 / 10!, b^4 / 24 of the path -- < 2e-10 m; outside, the recurrence loop runs.
+constexpr double kResumAmax = 0.5;
+constexpr double kResumBmax = 5e-3;
+struct ResumIn { double a, b, ahM, V; };
+// fp64 operations with ONE operand in scalar registers, spelled out: the table's coefficients arrive by scalar loads from the
+// argument block, and left to itself the compiler copies every one of them into vector registers first (two v_mov_b32 per
+// coefficient: 64 moves around 32 fma -- the resummed step then issued as many instructions as the loop it replaces)
+T2D_DEV double fma_vvs(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+T2D_DEV double mul_vs(double a, double c) {
+    double r;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c));
+    return r;
+}
+T2D_DEV double add_vs(double a, double c) {
+    double r;
+    asm("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(c));
+    return r;
+}
+T2D_DEV void resum_sums(const KernargView ka, const ResumIn& r, double& P, double& Q) {
+    const double a2 = r.a * r.a, b2 = r.b * r.b;
+    double q[8];
+    // (the first Horner step has two scalar operands -- one more than an instruction may read: multiply, then add)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) q[p] = add_vs(mul_vs(a2, ka->kin_coef[kKinDegree][p]), ka->kin_coef[kKinDegree - 1][p]);
+#pragma unroll
+    for (int i = kKinDegree - 2; i >= 0; --i) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) q[p] = fma_vvs(q[p], a2, ka->kin_coef[i][p]);
+    }
+    const double ec = __builtin_fma(b2, q[KIN_Q4], q[KIN_Q0]);
+    const double es = r.b * __builtin_fma(b2, q[KIN_Q6], q[KIN_Q2]);
+    const double ewc = (r.a * r.b) * __builtin_fma(b2, q[KIN_R8], q[KIN_R4]);
+    const double ews = r.a * __builtin_fma(b2, q[KIN_R6], q[KIN_R2]);
+    P = __builtin_fma(r.ahM, ewc, r.V * ec);
+    Q = __builtin_fma(r.ahM, ews, r.V * es);
+}
+
 // 1/x to ~1 ulp: hardware estimate + two Newton steps (fast variant only; the exact variant
 // uses IEEE division).  x must be normal and finite.
 T2D_DEV double rcp_nr(double x) {
@@ -92,7 +165,12 @@ T2D_DEV double div_r(double a, double b, double r) {
     return __builtin_fma(rem, r, q);
 }
 
-template <int VARIANT, typename PF>
+// RESUM: compile the resummed step in (the stand-alone integrator and the fused step of pools that fill the GPU; the looping
+// forms of small pools and the single-ego kernel keep the recurrence loop alone: their lone waves are latency chains that a
+// wave-uniform table fetch lengthens, and their register allocation is at its limit as it is -- measured, DESIGN.md 8.20;
+// touching the table's cache lines early, in the start-up phase, cost every launch ~1 us: six more scalar-cache misses while
+// all waves start together)
+template <int VARIANT, bool RESUM = false, typename PF>
 T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, double accel,
                                 double delta, int interval) {
     int flags = (int)P(T2D_P_RANGE_FLAGS);
@@ -178,7 +256,34 @@ T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, 
         const double eps0 = v * kh, eps_end = v_end * kh, dlt = ah_l * kh;
         const bool lane_linear = (!clip_v || (v >= vlo && v <= vhi && v_end >= vlo && v_end <= vhi)) &&
                                  __builtin_fabs(eps0) <= kEpsMax && __builtin_fabs(eps_end) <= kEpsMax;
-        if (__ballot(!lane_linear) == 0ull) {
+        // the resummed step (see resum_sums): every lane of the wave linear, of the sub-step count the table was built for,
+        // and inside the series' range
+        bool wave_resum = false;
+        KernargView ka = nullptr;
+        double ra = 0.0, rb = 0.0;
+        if constexpr (RESUM) {
+            ka = late_args();
+            const int kn = ka->kin_n;   // (0: no table -- pools too small for it, variant 2 -- and nothing else of it is fetched)
+            if (kn > 0) {
+                ra = __builtin_fma(dlt, ka->kin_geo[2], eps0) * ka->kin_geo[1];   // a = (eps_0 + dlt (m - 1/2)) M
+                rb = dlt * ka->kin_geo[4];                                        // b = dlt M^2 / 2
+                const bool lane_resum = lane_linear && n_steps == kn && __builtin_fabs(ra) <= kResumAmax && __builtin_fabs(rb) <= kResumBmax;
+                wave_resum = __ballot(!lane_resum) == 0ull;
+            }
+        }
+        if (RESUM && wave_resum) {
+            const double gm = ka->kin_geo[0], gM = ka->kin_geo[1];
+            double Ps, Qs;
+            resum_sums(ka, ResumIn{ra, rb, ah_l * gM, __builtin_fma(gm, ah_l, v)}, Ps, Qs);
+            rotate_mid(__builtin_fma(dlt, ka->kin_geo[3], gm * eps0), c, s);   // theta_0 -> Theta: m eps_0 + dlt m (m - 1) / 2
+            const double fn = ka->kin_geo[7], ndt = fn * dt;
+            x = __builtin_fma(ndt, __builtin_fma(c, Ps, -(s * Qs)), x);
+            y = __builtin_fma(ndt, __builtin_fma(s, Ps, c * Qs), y);
+            // Theta -> theta_n: A (m + 1) + B (m + 1)^2 with A = a / M, B = dlt / 2
+            rotate_mid(__builtin_fma(dlt, ka->kin_geo[6], (__builtin_fma(dlt, ka->kin_geo[2], eps0)) * ka->kin_geo[5]), c, s);
+            phi += __builtin_fma(fn, eps0, dlt * (0.5 * (fn * (fn - 1.0))));
+            v = v_end;
+        } else if (__ballot(!lane_linear) == 0ull) {
             double ce = 1.0, se = 0.0, cD = 1.0, sD = 0.0;
             const double amax = __builtin_fmax(__builtin_fabs(eps0), __builtin_fabs(eps_end));
             if (__ballot(amax > kEpsTiny) == 0ull) {  // the usual case: |sub-step angle| <= 0.01 rad in the whole wave
@@ -487,10 +592,10 @@ T2D_DEV StepOut step_pointmass(PF P, double x, double y, double vx, double vy, d
 
 
 // one PhysicsModelBase.step for the participant held in registers
-template <int VARIANT, typename PF>
+template <int VARIANT, bool RESUM = false, typename PF>
 T2D_DEV StepOut step_participant(int model, PF P, double x, double y, double heading, double speed, double vx,
                                  double vy, double a0, double a1, int interval_ms, double interval_s) {
-    if (model == T2D_MODEL_KINEMATICS) return step_kinematics<VARIANT>(P, x, y, heading, speed, a0, a1, interval_ms);
+    if (model == T2D_MODEL_KINEMATICS) return step_kinematics<VARIANT, RESUM>(P, x, y, heading, speed, a0, a1, interval_ms);
     if (model == T2D_MODEL_DYNAMICS) return step_dynamics<VARIANT>(P, x, y, heading, speed, a0, a1, interval_ms);
     return step_pointmass(P, x, y, vx, vy, a0, a1, interval_s);
 }

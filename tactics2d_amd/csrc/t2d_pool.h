@@ -45,6 +45,8 @@ struct GeoLayout {
     int32_t off_safe;                                              // lanes: rectangles inside the union (dword offset)
 };
 constexpr int kSafeRects = 4;   // per env
+constexpr int kKinDegree = 4;   // resummed kinematics: polynomials of degree 4 in a^2 (truncation < 2e-10 m at |a| <= 0.5)
+enum { KIN_Q0 = 0, KIN_Q4, KIN_Q2, KIN_Q6, KIN_R4, KIN_R8, KIN_R2, KIN_R6 };
 
 // What kernels receive by value.
 struct LidarView;
@@ -125,6 +127,15 @@ struct PoolView {
     int32_t idm_n_ctrl;
     const SceneView* regen;   // ego step kernel, regenerating pool: the device copy of the pool's SceneView, else null
     double interval_s;        // (double)interval_ms / 1000 of this launch (PointMass's dt), divided once by the host
+    // SingleTrackKinematics, fast variant: the Euler sum of a step RESUMMED instead of iterated (t2d_integrate_dev.h
+    // resum_kinematics).  kin_n = the sub-step count the table below was built for (0: none; lanes whose type has another
+    // count keep the recurrence loop); kin_coef[i][p] = coefficient of a^(2 i) of polynomial p (KIN_Q0 ...), each the moment
+    // of the centred sub-step index it multiplies, divided by its factorial, times the sign / the 1/2, 1/6 of its b-term;
+    // kin_geo = {m, M, m - 1/2, m (m - 1) / 2, M^2 / 2, m + 1, (m + 1)^2 / 2, n} with m = (n - 1) / 2, M = n / 2.  Computed by
+    // the host (long double) whenever the interval changes; read by the kernels as scalar loads from their argument block.
+    double kin_coef[kKinDegree + 1][8];
+    double kin_geo[8];
+    int32_t kin_n;
     unsigned long long* dbg;  // phase cycle accumulators (profiling builds with -DT2D_TIMING only)
     double cell;      // spatial-hash cell edge (m) >= max circum-diameter * 1.001
     double inv_cell;
@@ -207,6 +218,8 @@ struct t2d_pool {
     bool have_params = false;
     bool have_reset = false;
     int integrator_variant = 1;
+    bool kin_resum = true;   // fast variant: resummed kinematic steps (t2d_set_integrator_variant(pool, 2) keeps the recurrence loop)
+    bool kin_resum_forced = false;   // ... also on pools too small to fill the GPU (variant 3: tests)
     bool fused_step = true;  // t2d_step = one launch (integrate + events + status)
     bool ego_kernel = true;  // single-ego pools step with one wave per env (t2d_ego.hip) when they qualify
     bool all_boxes = false;  // every row of the parameter table is T2D_SHAPE_OBB

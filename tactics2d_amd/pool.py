@@ -298,7 +298,7 @@ class ParticipantPool:
         return fr.copy() if must_copy else fr
 
     def set_integrator_variant(self, variant):
-        v = {"exact": 0, "fast": 1}.get(variant, variant)
+        v = {"exact": 0, "fast": 1, "fast_iterated": 2, "fast_resummed": 3}.get(variant, variant)
         self._ck(self._lib.t2d_set_integrator_variant(self._h, int(v)))
 
     def set_outputs(self, velocity=True, applied=True):

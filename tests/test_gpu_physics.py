@@ -39,7 +39,7 @@ def test_exact_variant_is_bit_identical_to_oracle(oracle, name, model):
     assert mism == 0
 
 
-@pytest.mark.parametrize("variant", ["fast", "exact"])
+@pytest.mark.parametrize("variant", ["fast", "exact", "fast_resummed", "fast_iterated"])
 def test_kinematics_within_1e5_of_reference(variant):
     d = H.load_npz("kin_random.npz")
     worst = np.zeros(6)
@@ -210,3 +210,45 @@ def test_fast_kinematics_speed_clipping_paths(oracle, interval, delta_t):
     # the closed-form speed v0 + n*ah may round to the neighbouring fp32 of the iterated sum
     assert (e[:, 3] <= np.spacing(np.abs(exact[:, 3]).astype(np.float32)) + 1e-7).all(), e.max(0)
     print("clip paths", interval, delta_t, "max err", e.max(0), "flipped-ulp cases", int((e[:, :2].max(1) > 2e-6).sum()))
+
+
+@pytest.mark.parametrize("interval,delta_t", [(100, 5), (50, 3), (100, 1), (5, 5), (9, 5)])
+def test_resummed_kinematics_against_the_iterated_and_the_exact_step(oracle, interval, delta_t):
+    """The fast variant evaluates a kinematic step whose speed stays inside its bounds as a SERIES (the Euler sum resummed,
+    t2d_integrate_dev.h resum_sums) instead of iterating it.  Tiny vehicles at walking speed make the test sharp: wheel base
+    0.1 m turns 1 m/s into the step's full heading range (|a| up to and beyond the series' limit 0.5, |b| up to and beyond
+    5e-3) while the fp32 store of a coordinate < 0.3 m resolves 3e-8 m -- against the exact variant (== the oracle, bit for
+    bit) and against variant 2 (the same step iterated, rounds 1-4's form).  Waves are homogeneous (sorted by |a|), so that
+    the wave-uniform path choice really takes the series for the small angles and the loop beyond."""
+    from tactics2d_amd import layout as L
+    rng = np.random.default_rng(7 + interval)
+    k = [q for q in H.load_json("physics_kats.json") if q["ctor"] == "parking" and q["model"] == "kinematics"][0]
+    r = np.array(k["row"], np.float64)
+    r[L.P_LF], r[L.P_LR], r[L.P_WB] = 0.04, 0.06, 0.1
+    r[L.P_RANGE_FLAGS] = int(r[L.P_RANGE_FLAGS]) & ~2          # speed unbounded: every lane linear
+    r[L.P_ACCEL_LO], r[L.P_ACCEL_HI] = -6.0, 6.0
+    r[L.P_DELTA_T_MS] = delta_t
+    rows = r[None]
+    n = 64 * 300
+    tid = np.zeros(n, np.uint8)
+    v = rng.uniform(-2.5, 2.5, n)
+    steer = rng.uniform(-0.524, 0.524, n)
+    order = np.argsort(np.abs(v * np.tan(steer)))              # |a| grows along the pool: homogeneous waves
+    v, steer = v[order], steer[order]
+    acc = rng.uniform(-6, 6, n) * rng.choice([0.0, 0.05, 1.0], n)
+    st = np.stack([rng.uniform(-0.01, 0.01, n), rng.uniform(-0.01, 0.01, n), rng.uniform(0, 6.28, n), v], 1).astype(np.float32)
+    act = np.stack([acc, steer], 1).astype(np.float32)
+    ref = H.oracle_physics(oracle, rows, tid, st, act, interval, "kin", trig=1)
+    exact = H.gpu_physics(rows, tid, st, act, interval, "exact", "kin")
+    fast = H.gpu_physics(rows, tid, st, act, interval, "fast_resummed", "kin")   # (the series whatever the pool size)
+    loop = H.gpu_physics(rows, tid, st, act, interval, "fast_iterated", "kin")
+    assert np.array_equal(exact[:, :4], np.float32(ref[:, :4]))
+    for name, got in (("resummed", fast), ("iterated", loop)):
+        e = np.abs(got[:, :6].astype(np.float64) - ref[:, :6])
+        ulp = np.spacing(np.abs(np.float32(ref[:, :6])))
+        # half an ulp of the fp32 store + 2e-9 of arithmetic (the series' truncation bound is 2e-10 m)
+        assert (e[:, :2] <= 0.5 * ulp[:, :2] + 2e-9).all(), (name, e.max(0))
+        assert (e[:, 2:] <= 0.5 * ulp[:, 2:] + 1e-7).all(), (name, e.max(0))
+    d = np.abs(fast[:, :2].astype(np.float64) - loop[:, :2]).max(1)
+    print(f"resummed vs iterated ({interval}, {delta_t}): max |dx| {d.max():.2e}, {int((d > 0).sum())} of {n} stores differ by an ulp")
+    assert d.max() <= 6e-8

@@ -157,3 +157,59 @@ def test_python_loop_baseline_is_the_same_algorithm():
         e = np.abs(np.array(o[:4]) - d["out"][k][:4]); e[2] = min(e[2], 2 * np.pi - e[2])
         worst = max(worst, e.max())
     assert worst <= 1e-12, worst
+
+
+@pytest.mark.parametrize("n,dt", [(20, 0.005), (16, 0.003), (100, 0.001), (1, 0.005), (2, 0.005), (33, 0.003)])
+def test_resummed_kinematic_step_is_the_euler_sum(n, dt):
+    """The series the fast kernel variant evaluates instead of iterating SingleTrackKinematics._step's sub-steps
+    (single_track_kinematics.py:149-160 with the speed inside its bounds), restated in numpy with the table
+    t2d_api.hip's kinematics_resum_table builds: x_n = x_0 + dt sum_k v_k cos(theta_k) to < 1e-9 m inside the range the
+    kernel accepts (|a| <= 0.5, |b| <= 5e-3), against the iterated sum in extended precision."""
+    from math import factorial
+    D = 4
+    M, m = n / 2, (n - 1) / 2
+    kk = np.arange(n, dtype=np.longdouble)
+    w = (kk - np.longdouble(m)) / np.longdouble(M)
+    mu = [float(np.mean(w ** q)) for q in range(2 * D + 9)]
+    qe = lambda i: (-1) ** i / factorial(2 * i)
+    ro = lambda i: (-1) ** i / factorial(2 * i + 1)
+    T = {"Q0": [qe(i) * mu[2 * i] for i in range(D + 1)], "Q4": [-0.5 * qe(i) * mu[2 * i + 4] for i in range(D + 1)],
+         "Q2": [qe(i) * mu[2 * i + 2] for i in range(D + 1)], "Q6": [-qe(i) * mu[2 * i + 6] / 6 for i in range(D + 1)],
+         "R4": [-ro(i) * mu[2 * i + 4] for i in range(D + 1)], "R8": [ro(i) * mu[2 * i + 8] / 6 for i in range(D + 1)],
+         "R2": [ro(i) * mu[2 * i + 2] for i in range(D + 1)], "R6": [-0.5 * ro(i) * mu[2 * i + 6] for i in range(D + 1)]}
+
+    def horner(c, x):
+        acc = np.full_like(x, c[-1])
+        for ci in c[-2::-1]:
+            acc = acc * x + ci
+        return acc
+
+    rng = np.random.default_rng(n)
+    N = 20000
+    v0 = rng.uniform(-16.67, 69.44, N); acc = rng.uniform(-11, 3.2, N); delta = rng.uniform(-0.524, 0.524, N)
+    lr, wb = 1.375, 2.637
+    t = lr / wb * np.tan(delta); cb = 1 / np.sqrt(1 + t * t)
+    ah, kh = acc * dt, np.tan(delta) / wb * cb * dt
+    x0, y0, th0 = rng.uniform(-200, 200, N), rng.uniform(-200, 200, N), rng.uniform(0, 2 * np.pi, N)
+    eps0, dlt = v0 * kh, ah * kh
+    a = (eps0 + dlt * (m - 0.5)) * M
+    b = dlt * (M * M / 2)
+    a2, b2 = a * a, b * b
+    ec = horner(T["Q4"], a2) * b2 + horner(T["Q0"], a2)
+    es = b * (horner(T["Q6"], a2) * b2 + horner(T["Q2"], a2))
+    ewc = a * b * (horner(T["R8"], a2) * b2 + horner(T["R4"], a2))
+    ews = a * (horner(T["R6"], a2) * b2 + horner(T["R2"], a2))
+    V = v0 + m * ah
+    P, Q = V * ec + ah * M * ewc, V * es + ah * M * ews
+    Th = th0 + m * eps0 + dlt * (m * (m - 1) / 2)
+    xr = x0 + n * dt * (np.cos(Th) * P - np.sin(Th) * Q)
+    yr = y0 + n * dt * (np.sin(Th) * P + np.cos(Th) * Q)
+    th_end = Th + (eps0 + dlt * (m - 0.5)) * (m + 1) + dlt * ((m + 1) ** 2 / 2)
+    x = x0.astype(np.longdouble); y = y0.astype(np.longdouble); th = th0.astype(np.longdouble); v = v0.astype(np.longdouble)
+    for _ in range(n):
+        x, y, th, v = x + v * dt * np.cos(th), y + v * dt * np.sin(th), th + v * kh, v + ah
+    ok = (np.abs(a) <= 0.5) & (np.abs(b) <= 5e-3)
+    assert ok.sum() > N // 3
+    err = np.maximum(np.abs(xr - x), np.abs(yr - y)).astype(np.float64)
+    assert err[ok].max() < 1e-9, err[ok].max()
+    assert np.abs(th_end - th).astype(np.float64).max() < 1e-12   # the second rotation lands on theta_n
