@@ -49,6 +49,15 @@
  * internal streams -- never for the whole device: other pools (env groups) and a policy
  * running on other streams keep going.
  *
+ * Non-finite values.  The integrators follow the reference: np.clip(nan, lo, hi) is nan (single_track_kinematics.py:192-193),
+ * np.clip(+-inf) the bound, np.mod(+-inf, 2 pi) nan -- a NaN action or state makes the participant's state NaN exactly where
+ * numpy would (tests/golden/nonfinite.npz, made by importing the reference).  What the reference leaves to GEOS is BUILD-DEFINED
+ * here: a participant whose pose (x, y or heading) is not finite takes no part in event detection -- its flags are 0 and nobody
+ * collides with it --, its IoU events are not evaluated (T2D_F_IOU = NaN), as a lidar ego it sees nothing (+inf on every beam)
+ * and as a lidar obstacle it is skipped; an IDM participant with a non-finite pose leads nobody (comparisons with NaN are
+ * false).  Nothing hangs and no other participant's result changes (tests/test_gpu_nonfinite.py).  t2d_step_host rejects
+ * non-finite actions when given an action box (T2D_ERR_ACTION), as `action_space.contains` does.
+ *
  * Ownership: the pool owns every device buffer.  Host pointers passed in are read
  * during the call and never retained.  Device pointers handed out by t2d_get_field
  * stay valid until t2d_destroy.

@@ -423,7 +423,8 @@ void t2do_ego_poses(const double* rows, int row_stride, int n_env, int A, int eg
         xy[2 * e + 1] = y[i];
         is_obb[e] = 0;
         for (int k = 0; k < 8; ++k) pose8[8 * (size_t)e + k] = 0.0;
-        if ((int)p[T2D_P_SHAPE] == T2D_SHAPE_OBB) {
+        /* (an ego whose pose is not finite takes no part in the IoU events either: t2do_collide) */
+        if ((int)p[T2D_P_SHAPE] == T2D_SHAPE_OBB && isfinite(x[i]) && isfinite(y[i]) && isfinite(heading[i])) {
             t2do_pose_obb(x[i], y[i], heading[i], p[T2D_P_LENGTH], p[T2D_P_WIDTH], trig, pose8 + 8 * (size_t)e);
             is_obb[e] = 1;
         }
@@ -803,6 +804,7 @@ void t2do_collide(const double* rows, int row_stride, int n_env, int A, const fl
     double* V = (double*)malloc(sizeof(double) * 8 * (size_t)A);
     double* C = (double*)malloc(sizeof(double) * 3 * (size_t)A);
     int* kind = (int*)malloc(sizeof(int) * (size_t)A);
+    int* present = (int*)malloc(sizeof(int) * (size_t)A);
 #pragma omp for schedule(dynamic, 4)
     for (int e = 0; e < n_env; ++e) {
         size_t base = (size_t)e * A;
@@ -819,7 +821,11 @@ void t2do_collide(const double* rows, int row_stride, int n_env, int A, const fl
         }
         for (int i = 0; i < A; ++i) {
             flags[base + i] = 0;
-            if (!active[base + i]) continue;
+            /* build-defined: a participant whose pose is not finite (a NaN action went through np.clip, an overflow) takes no
+             * part in event detection -- it raises no flag and nobody collides with it -- exactly like an inactive one (the
+             * reference hands such a pose to GEOS, whose answer is not defined) */
+            present[i] = active[base + i] && isfinite(x[base + i]) && isfinite(y[base + i]) && isfinite(heading[base + i]);
+            if (!present[i]) continue;
             const double* p = rows + (size_t)type_id[base + i] * row_stride;
             kind[i] = (int)p[T2D_P_SHAPE];
             C[3 * i] = x[base + i];
@@ -830,11 +836,11 @@ void t2do_collide(const double* rows, int row_stride, int n_env, int A, const fl
                               p[T2D_P_WIDTH], trig, V + 8 * i);
         }
         for (int i = 0; i < A; ++i) {
-            if (!active[base + i]) continue;
+            if (!present[i]) continue;
             uint32_t f = 0;
             /* participant vs participant */
             for (int j = 0; j < A && !(f & T2D_FLAG_COLLISION_DYNAMIC); ++j) {
-                if (j == i || !active[base + j]) continue;
+                if (j == i || !present[j]) continue;
                 int hit;
                 if (kind[i] == T2D_SHAPE_OBB && kind[j] == T2D_SHAPE_OBB)
                     hit = t2do_convex_intersects(V + 8 * i, 4, V + 8 * j, 4);
@@ -891,7 +897,7 @@ void t2do_collide(const double* rows, int row_stride, int n_env, int A, const fl
         env_flags[e] = ef;
         free(pieces); free(lvo); free(lxy);
     }
-    free(V); free(C); free(kind);
+    free(V); free(C); free(kind); free(present);
     }
 }
 
@@ -1103,7 +1109,11 @@ void t2do_lidar(const double* rows, int row_stride, int n_env, int A, int ego_in
         const size_t base = (size_t)env * A;
         const size_t ie = base + ego_index;
         float* o = out + (size_t)env * n_beams;
-        if (!active[ie]) { for (int k = 0; k < n_beams; ++k) o[k] = INFINITY; continue; }
+        /* (build-defined: an ego whose pose is not finite scans nothing, a participant whose pose is not finite is no obstacle) */
+        if (!active[ie] || !isfinite(x[ie]) || !isfinite(y[ie]) || !isfinite(heading[ie])) {
+            for (int k = 0; k < n_beams; ++k) o[k] = INFINITY;
+            continue;
+        }
         double sn, cs;
         if (trig == 0) t2do_sincos((double)heading[ie], &sn, &cs);
         else { sn = sin((double)heading[ie]); cs = cos((double)heading[ie]); }
@@ -1132,6 +1142,7 @@ void t2do_lidar(const double* rows, int row_stride, int n_env, int A, int ego_in
         if (include_participants) {
             for (int j = 0; j < A; ++j) {
                 if (j == ego_index || !active[base + j]) continue;
+                if (!isfinite(x[base + j]) || !isfinite(y[base + j]) || !isfinite(heading[base + j])) continue;
                 const double* p = rows + (size_t)type_id[base + j] * row_stride;
                 if ((int)p[T2D_P_SHAPE] != T2D_SHAPE_OBB) continue;
                 t2do_pose_obb(x[base + j], y[base + j], heading[base + j], p[T2D_P_LENGTH], p[T2D_P_WIDTH], trig, ring);

@@ -314,7 +314,8 @@ __global__ __launch_bounds__(PIPE ? 2 * kEgoBlock : kEgoBlock, 2) void ego_step_
     uint32_t f = 0;
     float box_lo_x = 0, box_hi_x = 0, box_lo_y = 0, box_hi_y = 0;
     const double cx = (double)fx, cy = (double)fy;
-    if (active) {
+    // (an ego whose pose is not finite takes no part in event detection -- no flag, no IoU -- like the general kernel's)
+    if (active && __builtin_isfinite(fx) && __builtin_isfinite(fy) && __builtin_isfinite(fh)) {
         const int kind = (int)P(T2D_P_SHAPE);
         const double L = P(T2D_P_LENGTH), W = P(T2D_P_WIDTH);
         double lo_x, hi_x, lo_y, hi_y;

@@ -230,7 +230,7 @@ T2D_DEV StepOut step_kinematics(PF P, double x, double y, double phi, double v, 
             y = __builtin_fma(vh, s, y);
             phi += eps;
             v += ah;
-            if (clip_v) v = __builtin_fmin(__builtin_fmax(v, vlo), vhi);
+            if (clip_v) v = clipd(v, vlo, vhi);   // (np.clip: a NaN speed stays NaN -- fmin / fmax would turn it into a bound)
             if (__builtin_fabs(eps) <= kEpsMax) {
                 rotate_small(eps, c, s);
             } else {  // absurd yaw rates (unbounded speed): re-seed from phi
@@ -539,7 +539,7 @@ T2D_DEV StepOut step_dynamics(PF P, double x, double y, double phi, double v, do
             const double e2 = d_beta * dt;
             phi += e1;
             beta += e2;
-            if (clip_v) v = __builtin_fmin(__builtin_fmax(v, vlo), vhi);
+            if (clip_v) v = clipd(v, vlo, vhi);   // (np.clip: NaN stays NaN)
             const double eps = e1 + e2;
             const double aeps = __builtin_fabs(eps);
             if (__ballot(aeps > kEpsTiny) == 0ull) rotate_tiny(eps, c, s);   // wave-uniform: usual case

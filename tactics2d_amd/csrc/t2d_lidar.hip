@@ -240,10 +240,14 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     // the ego transform, by every lane for itself: the same instructions whether one lane or sixty-four execute them, and
     // no LDS hand-over + workgroup barrier before the first edge can be transformed
     const size_t ie = base + lv.ego_index;
-    const bool ego_active = ((pv.ids[ie] >> kIdsActiveShift) & 0xff) != 0;
+    // (an ego whose pose is not finite scans nothing -- every beam +inf -- and a participant whose pose is not finite is no
+    // obstacle: build-defined, like the event kernels and the oracle)
+    const float ego_hf = pv.heading[ie], ego_xf = pv.x[ie], ego_yf = pv.y[ie];
+    const bool ego_active = ((pv.ids[ie] >> kIdsActiveShift) & 0xff) != 0 && __builtin_isfinite(ego_hf) &&
+                            __builtin_isfinite(ego_xf) && __builtin_isfinite(ego_yf);
     double sn, cs;
-    sincos_det((double)pv.heading[ie], sn, cs);
-    const double ego_x = pv.x[ie], ego_y = pv.y[ie];
+    sincos_det((double)ego_hf, sn, cs);
+    const double ego_x = ego_xf, ego_y = ego_yf;
     const double x_off = -ego_x * cs - ego_y * sn;   // lidar.py:112-113
     const double y_off = ego_x * sn - ego_y * cs;
     T2D_LMARK(0);
@@ -285,7 +289,9 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
             const uint32_t ids = pv.ids[base + j];
             const int type = (ids >> kIdsTypeShift) & 0xff;
             const bool use = j != lv.ego_index && ((ids >> kIdsActiveShift) & 0xff) &&
-                             (int)pv.params[T2D_P_SHAPE * T2D_MAX_TYPES + type] == T2D_SHAPE_OBB;
+                             (int)pv.params[T2D_P_SHAPE * T2D_MAX_TYPES + type] == T2D_SHAPE_OBB &&
+                             __builtin_isfinite(pv.heading[base + j]) && __builtin_isfinite(pv.x[base + j]) &&
+                             __builtin_isfinite(pv.y[base + j]);
             double vx[4], vy[4];
             if (use) {
                 const double L = pv.params[T2D_P_LENGTH * T2D_MAX_TYPES + type];

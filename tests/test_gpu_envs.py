@@ -309,3 +309,32 @@ def test_default_step_results_are_never_overwritten():
         del o
     assert len(bases) <= 2 and bases <= {fr.base.__array_interface__["data"][0] for fr in pool._frames if fr is not None}
     env.close()
+
+
+def test_nan_actions_are_invalid_actions_and_step_nothing():
+    """`action_space.contains(nan)` is False in the reference (envs/parking.py:235-236): the host path raises InvalidAction
+    from the staging pass of t2d_step_host and nothing is stepped -- vector env and single env alike."""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.envs import InvalidAction, ParkingEnv, VecParkingEnv
+    env = VecParkingEnv(16, max_step=30, seed=2)
+    env.reset()
+    pool = env.scenario_manager.pool
+    a = env.action_space.sample(np.random.default_rng(0), 16)
+    env.step(a)
+    x0, cnt0 = pool.download(L.F_X), pool.download(L.F_CNT_STEP)
+    for bad in (np.nan, np.inf, -np.inf, 0.6):
+        b = a.copy(); b[7, 0] = bad
+        with pytest.raises(InvalidAction):
+            env.step(b)
+    assert np.array_equal(pool.download(L.F_X), x0) and np.array_equal(pool.download(L.F_CNT_STEP), cnt0)
+    env.step(a)
+    assert (pool.download(L.F_CNT_STEP) == cnt0 + 1).all()
+    env.close()
+    one = ParkingEnv(seed=1)
+    one.reset()
+    for bad in ([np.nan, 0.0], [0.0, np.nan], [0.0, 2.5], [0.0], "x"):
+        with pytest.raises(InvalidAction):
+            one.step(bad)
+    obs, reward, term, trunc, info = one.step(np.float32([0.1, 0.5]))
+    assert np.isfinite(obs).all() and info["state"]["frame"] == 100
+    one.close()

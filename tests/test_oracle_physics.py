@@ -213,3 +213,36 @@ def test_resummed_kinematic_step_is_the_euler_sum(n, dt):
     err = np.maximum(np.abs(xr - x), np.abs(yr - y)).astype(np.float64)
     assert err[ok].max() < 1e-9, err[ok].max()
     assert np.abs(th_end - th).astype(np.float64).max() < 1e-12   # the second rotation lands on theta_n
+
+
+def _same_nonfinite(got, want, tol):
+    """NaN exactly where `want` has NaN, +-inf equal, finite values within tol"""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    if not np.array_equal(np.isnan(got), np.isnan(want)):
+        return False
+    fin = np.isfinite(want)
+    if not np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)]):
+        return False
+    return bool(np.all(np.abs(got[fin] - want[fin]) <= tol))
+
+
+def test_nonfinite_inputs_propagate_like_the_reference(oracle):
+    """tests/golden/nonfinite.npz (oracle/gen_golden_nonfinite.py, by importing the reference): one input of a step -- a
+    state field or an action component -- is nan / +inf / -inf.  np.clip(nan) is nan (single_track_kinematics.py:192-193),
+    np.clip(+-inf) the bound, np.mod(+-inf, 2 pi) nan: the oracle must put NaN exactly where the reference does and agree
+    everywhere else, in both trig modes."""
+    d = H.load_npz("nonfinite.npz")
+    names = {0: "kin", 1: "dyn", 2: "pm"}
+    n_nan = 0
+    for t in np.unique(d["type_id"]):
+        m = np.nonzero(d["type_id"] == t)[0]
+        model = names[int(d["model"][m[0]])]
+        cols = 4 if model == "dyn" else 6
+        for trig in (0, 1):
+            got = H.oracle_physics(oracle, d["rows"], d["type_id"][m], d["state"][m], d["action"][m], int(d["interval"][m[0]]), model, trig=trig)
+            for i, k in enumerate(m):
+                # (the crawling-speed dynamics case is ill-conditioned in the reference itself: 1e-9 between the trig modes)
+                assert _same_nonfinite(got[i, :cols], d["out"][k, :cols], 1e-6 if model == "dyn" else 1e-9), \
+                    (model, trig, d["state"][k], d["action"][k], got[i, :cols], d["out"][k, :cols])
+                n_nan += int(np.isnan(d["out"][k, :cols]).any())
+    assert n_nan > 100   # the fixture does exercise the propagation
