@@ -103,11 +103,11 @@ class VecParkingEnv:
             m.configure(rows, check_dynamic=False, check_off_lane=False, check_arrival=1, check_no_action=1,
                         no_action_max_step=100, shaped_reward=1)
             m.pool.parking_scenes(self._seed, self.type_proportion, size, regenerate=self.auto_reset)
-            self.generated = m.pool.get_parking_scenes()
-            bad = self.generated.info & 0x1e
+            self._generated = m.pool.get_parking_scenes()
+            bad = self._generated.info & 0x1e
             if bad.any():
                 raise RuntimeError(f"{int((bad != 0).sum())} generated scenes are flagged; use another seed")
-            self._scene = self.generated.scene(max_step=self.max_step)
+            self._scene = self._generated.scene(max_step=self.max_step)
         else:
             sc = scenarios.parking(self.n_envs, seed0=self._seed * self.n_envs)
             self._scene = sc
@@ -128,6 +128,14 @@ class VecParkingEnv:
         self._target_area, self._target_heading = self._scene.target, self._scene.target_heading
         fr = self._last = m.pool.frame_fetch(fresh=self.copy)
         return fr.obs, self._infos(fr)
+
+    @property
+    def generated(self):
+        """The generated scenes the envs are in NOW (a generator.ParkingScenes + .episode): fetched from the device on demand
+        when scenes are regenerated there (nothing on the step path reads it: the frame carries the target areas)."""
+        if getattr(self, "_moving_targets", False):
+            self._generated = self.scenario_manager.pool.get_parking_scenes()
+        return self._generated
 
     # ------------------------------------------------------------------ step
     def _to_continuous(self, actions):
@@ -250,7 +258,7 @@ class ParkingEnv:
         a = self._abuf
         if self.continuous:
             try:
-                a[0] = action
+                a[0, 0], a[0, 1] = action   # (exactly two scalars: Box.contains checks the shape as well)
             except (ValueError, TypeError):
                 raise InvalidAction(f"Action {action} is not in the action space.") from None
         else:

@@ -66,7 +66,7 @@ def test_invalid_arguments_are_rejected_with_messages():
     with pytest.raises(_ffi.T2DError):
         p.set_status_config(ego_index=2)                      # >= max_agents
     with pytest.raises(_ffi.T2DError):
-        p.set_integrator_variant(3)
+        p.set_integrator_variant(4)
     lib = _ffi.lib()
     buf = np.zeros(3, np.float32)                             # wrong size for a field
     assert lib.t2d_download(p._h, 0, buf.ctypes.data_as(C.c_void_p), buf.nbytes) == _ffi.ERR_INVALID
