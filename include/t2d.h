@@ -334,8 +334,9 @@ int t2d_step_groups(t2d_pool* const* pools, const float* const* act0_dev, const 
  * loops over the steps itself, and where a step's workgroups number at most the device's CUs a second set of waves per
  * workgroup integrates step k + 1 while the first checks the events of step k (t2d_step_form tells which).
  * Failure (never observed; forced by tests with t2d_debug_chain_fault): every wait is bounded, and a chained hand-off checks
- * that producer and consumer share an XCD.  A workgroup whose hand-off fails does NOT run its step, and neither does any later
- * step of those envs nor any fragment enqueued behind the failed one; the first t2d_sync / t2d_download / t2d_step_n after it
+ * that producer and consumer share an XCD.  A workgroup whose hand-off fails records the failure and goes on (never a hang):
+ * what it and everything enqueued behind it on the device computes from then on -- state, flags, records, a t2d_gather of those
+ * records, a lidar scan -- is INVALID until the host has noticed: the first t2d_sync / t2d_download / t2d_step_n after it
  * returns T2D_ERR_STATE -- once -- and the pool goes on with ordinary launches (t2d_set_step_chaining re-enables chaining).
  * CHAIN forms: the pool has then been rolled back to the state and step count (t2d_step_count) it had when the failed fragment
  * began -- every chained fragment checkpoints what it starts from -- so the caller re-issues its steps from there; the pure
@@ -626,7 +627,9 @@ int t2d_debug_set_step_placement(t2d_pool* pool, const uint32_t* map_host, int32
 
 /* Test hook: the CHAIN launches of t2d_step_n enqueued from now on break ONE hand-off on purpose -- workgroup 1 posts its step
  * 1 with a foreign XCC id (kind 1: what a consumer on another XCD would see) or not at all (kind 2: its consumer's bounded
- * wait runs out after ~0.2 s); 0 = off.  Needs a pool of >= 2 step workgroups and fragments of >= 3 steps to have any effect. */
+ * wait runs out after ~0.2 s); kind 3: it posts its step 0 with a foreign XCC id, so that the failure is on record while the
+ * fragment's first step is still being dispatched (a grid larger than the device holds: the checkpoint must still be complete);
+ * 0 = off.  Needs a pool of >= 2 step workgroups and fragments of >= 3 steps to have any effect. */
 int t2d_debug_chain_fault(t2d_pool* pool, int32_t kind);
 
 int t2d_debug_step_occupancy(t2d_pool* pool, int32_t* blocks_per_cu, int64_t* lds_bytes,

@@ -136,9 +136,10 @@ hipError_t quiesce(t2d_pool* p) {
             p->chain_sig = 0;         // (the counters are in no known state: a later chained launch starts them afresh)
             p->chain_rolled_back = false;
             if (p->ckpt_armed && p->d_ckpt) {
-                // CHAIN form: the failed fragment and everything enqueued behind it wrote no state it could not trust (poisoned
-                // hand-offs skip their steps), and its checkpoint holds what it started from: put the pool back there.  The
-                // tag is the low half of the step count at the fragment's start.
+                // CHAIN form: whatever the failed fragment and the fragments enqueued behind it computed is discarded -- its
+                // checkpoint holds what it started from (complete: its own failure never stops its step-0 stores, a later
+                // fragment never overwrites it): put the pool back there.  The tag is the low half of the step count at
+                // the fragment's start.
                 const uint32_t back = (uint32_t)p->step_count - err[1];
                 e = t2d::launch_chain_rollback(p->v, p->d_ckpt, nullptr);
                 if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
@@ -963,7 +964,15 @@ int t2d_set_param_table(t2d_pool* p, const double* rows, int32_t n_types, int32_
     p->v.inv_cell = 1.0 / p->v.cell;
     T2D_HIP(p, quiesce(p));
     T2D_HIP(p, hipMemcpy(p->d_params, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
-    p->derived_interval = -1;
+    // the derived column (T2D_P_SUBSTEPS) of the new table, for the interval the pool was last stepped with, at once: a
+    // captured graph of step launches does not hold the derive launch and would otherwise replay on a column of zeros
+    // (no sub-steps at all, silently) after a new table
+    const int prev_interval = p->derived_interval;
+    p->derived_interval = -1;   // (the next stepping call derives again: the host-side values travel with it)
+    if (prev_interval > 0) {
+        T2D_HIP(p, t2d::launch_derive(p->d_params, n_types, prev_interval, nullptr));
+        T2D_HIP(p, hipStreamSynchronize(nullptr));
+    }
     p->have_params = true;
     return T2D_OK;
 }
@@ -2019,7 +2028,8 @@ int t2d_gather_wait(t2d_pool* p, void* hip_stream, int32_t block_host) {
 // test hook: the next CHAIN launches of the pool break one hand-off on purpose (include/t2d.h)
 int t2d_debug_chain_fault(t2d_pool* p, int32_t kind) {
     if (!p) return T2D_ERR_INVALID;
-    if (kind < 0 || kind > 2) return fail(p, T2D_ERR_INVALID, "fault kind: 0 none, 1 foreign XCC id, 2 a hand-off that never comes");
+    if (kind < 0 || kind > 3)
+        return fail(p, T2D_ERR_INVALID, "fault kind: 0 none, 1 foreign XCC id at step 1, 2 a hand-off that never comes, 3 foreign XCC id at step 0");
     p->chain_fault = (uint32_t)kind;
     return T2D_OK;
 }

@@ -341,6 +341,13 @@ constexpr int kChainSpinLimit = 1 << 18;   // ~0.2 s of polling: far beyond any 
 // invariant to the entry block -- the epilogue's thirty pointers, the geometry layout -- and, out of scalar registers, parks
 // them in VGPR lanes for the length of the kernel (v_writelane / v_readlane per value: 108 spilled scalars and ~300 extra
 // VALU instructions per wave when the lane stage was rewritten in round 3).
+// may this fragment's step 0 store its checkpoint?  Yes unless a failure of an EARLIER fragment is on record (its checkpoint
+// is what the host restores): the error word is {code, ckpt_tag of the failing fragment}, written once, as one word
+T2D_DEV bool ckpt_open(const KernargView ck) {
+    const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(ck->chain_err), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+    return w == 0ull || (uint32_t)(w >> 32) == ck->ckpt_tag;
+}
 T2D_DEV unsigned long long chain_word(uint32_t steps_done) {   // {steps done, XCC id of the workgroup that did the last one}
     return (unsigned long long)steps_done | ((unsigned long long)(uint32_t)__builtin_amdgcn_s_getreg(63508) << 32);
 }
@@ -521,11 +528,12 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     // A hand-off that fails -- the wait ran out, or the producer sat on another XCD -- is RECORDED, {what, which fragment}, and
     // the workgroup goes on (never a hang): the host rolls the pool back to the checkpoint the fragment wrote in its first
     // step (below) and reports the launch as failed, so nothing computed from here on is ever handed to a caller.
-    [[maybe_unused]] auto chain_fail = [&](uint32_t code) {   // (the first failure names the fragment)
-        if (__hip_atomic_load(pv.chain_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            __hip_atomic_store(pv.chain_err + 1, pv.ckpt_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(pv.chain_err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    [[maybe_unused]] auto chain_fail = [&](uint32_t code) {   // (the first failure names the fragment; {code, tag} is ONE word:
+        // a reader never sees the code of one failure with the tag of another, or a code whose tag has not landed yet)
+        unsigned long long none = 0ull;
+        (void)__hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long*>(pv.chain_err), &none,
+                                                   (unsigned long long)code | ((unsigned long long)pv.ckpt_tag << 32),
+                                                   __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     auto chain_wait = [&]() {
         if (ptid == 0) {
@@ -925,10 +933,12 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
         // The fragment's checkpoint: the state its first step starts from, stored from the registers that hold it anyway
         // (every slot of the pool, active or not).  Not behind a fragment that failed -- the error word is final by then,
         // launches of one stream do not overlap -- so the failed fragment's own checkpoint survives whatever was enqueued
-        // behind it, and that is what the host restores.
+        // behind it, and that is what the host restores.  A failure of THIS fragment must not stop its own checkpoint: on a
+        // grid larger than the device holds, a consumer of step 1 can post its failure while the last workgroups of step 0
+        // have not stored theirs yet (ckpt_open: the recorded failure, if any, carries this fragment's tag).
         if (step_k == 0 && valid && (!SPLIT || role == 0)) {
             const KernargView ck = late_args();
-            if (*as_global(ck->chain_err) == 0u) {
+            if (ckpt_open(ck)) {
                 auto c_base = as_global(ck->ckpt);
                 const size_t cn = (size_t)ck->N;
                 c_base[idx] = __float_as_uint(fx);
@@ -1001,7 +1011,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                 if constexpr (CHAIN) asm volatile("" : "+s"(k0));
                 if (CHAIN && k0 == 0) {
                     const KernargView ck = late_args();
-                    if (*as_global(ck->chain_err) == 0u) {
+                    if (ckpt_open(ck)) {
                         as_global(ck->ckpt)[4 * (size_t)ck->N + idx] = __float_as_uint(lvx);
                         as_global(ck->ckpt)[5 * (size_t)ck->N + idx] = __float_as_uint(lvy);
                     }
@@ -1535,7 +1545,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
             pre_frame = ld_state<MULTI>(e_frame_ms + env);
             int k0 = CHAIN ? (int)blockIdx.y : 1;
             if constexpr (CHAIN) asm volatile("" : "+s"(k0));
-            if (CHAIN && k0 == 0 && *as_global(ep->chain_err) == 0u) {   // (the env's counters at the start of the fragment: the checkpoint's last two columns)
+            if (CHAIN && k0 == 0 && ckpt_open(ep)) {   // (the env's counters at the start of the fragment: the checkpoint's last two columns)
                 auto c_env = as_global(ep->ckpt) + 7 * (size_t)ep->N;
                 c_env[env] = (uint32_t)pre_cnt;
                 c_env[e_n_env + env] = (uint32_t)pre_frame;
@@ -1848,8 +1858,11 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
         __syncthreads();
         if (ptid == 0) {
             unsigned long long w = chain_word(pv.chain_base + (uint32_t)step_k + 1u);
-            // test hook (t2d_debug_chain_fault): workgroup 1 hands its step 1 over with a foreign XCC id / not at all
-            const uint32_t fault = (unit == 1 && step_k == 1) ? pv.chain_fault : 0u;
+            // test hook (t2d_debug_chain_fault): workgroup 1 hands its step 1 over with a foreign XCC id (1) / not at all (2);
+            // 3: it hands its step 0 over with a foreign XCC id -- the failure is then posted while the fragment's first
+            // step is still being dispatched on a grid larger than the device holds
+            const uint32_t cf = pv.chain_fault;
+            const uint32_t fault = unit != 1 ? 0u : (cf == 3u ? (step_k == 0 ? 1u : 0u) : (step_k == 1 ? cf : 0u));
             if (fault & 1u) w ^= 1ull << 32;
             if (!(fault & 2u)) __hip_atomic_store(&pv.chain_done[unit], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -22,6 +22,17 @@
 #include <vector>
 
 #include "t2d_pool.h"
+#include <thread>
+
+// a spin-wait hint that exists on every host (the x86 pause instruction where there is one)
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+
 
 namespace t2d {
 namespace {
@@ -96,7 +107,7 @@ void worker_main(t2d_closed_loop* L, int g) {
         int polls = 0;
         while ((cur = L->go.load(std::memory_order_acquire)) == seen) {
             if (L->quit.load(std::memory_order_acquire)) return;
-            __builtin_ia32_pause();
+            cpu_relax();
             if ((++polls & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
                 std::unique_lock<std::mutex> lk(L->mu);
                 L->cv.wait(lk, [&] { return L->go.load(std::memory_order_acquire) != seen || L->quit.load(std::memory_order_acquire); });
@@ -212,7 +223,15 @@ int t2d_debug_closed_loop_run(t2d_closed_loop* L, int32_t n_steps) {
             L->go.fetch_add(1, std::memory_order_release);
         }
         L->cv.notify_all();
-        while (L->done.load(std::memory_order_acquire) < G) __builtin_ia32_pause();
+        // (bounded: a worker whose t2d_step blocks for good -- a wedged device -- must not hang the caller as well)
+        const auto t_wait = std::chrono::steady_clock::now();
+        for (long polls = 0; L->done.load(std::memory_order_acquire) < G; ++polls) {
+            cpu_relax();
+            if ((polls & 0xffff) == 0xffff && std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(60)) {
+                L->pools[0]->err = "closed loop: a group's host thread did not finish enqueuing within 60 s";
+                return T2D_ERR_HIP;
+            }
+        }
         for (int g = 0; g < G; ++g)
             if (L->rc[g] != T2D_OK) return L->rc[g];
         return T2D_OK;

@@ -338,3 +338,46 @@ def test_an_action_ring_needs_bound_memory():
     pool.step_n(4, 100, 0)   # one action set repeated: fine
     pool.sync()
     pool.close()
+
+
+def test_a_failure_during_the_first_step_leaves_a_complete_checkpoint():
+    """Fault kind 3: workgroup 1 posts its step 0 with a foreign XCC id, on a grid larger than the device holds (8192 x 64:
+    2048 step workgroups per step, 1024 resident) -- its consumer fails while the last step-0 workgroups have not started.
+    The fragment's own failure must not keep them from storing their checkpoint: after the rollback EVERY env is exactly
+    where the fragment began (round 4 skipped the checkpoint whenever any failure was on record: stale or zero state for
+    the late workgroups' envs)."""
+    torch = pytest.importorskip("torch")
+    from tactics2d_amd import _ffi, layout as L, scenarios as S
+    from tactics2d_amd.pool import ParticipantPool
+    dev = torch.device("cuda", 0)
+    sc = S.mixed(8192, 64, seed=4)
+    r0, r1 = _ring(sc, 12, seed=3)
+    a0 = torch.from_numpy(r0).to(dev).contiguous(); a1 = torch.from_numpy(r1).to(dev).contiguous()
+    fields = (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_IDS, L.F_CNT_STEP, L.F_FRAME_MS)
+    pool = ParticipantPool(sc.n_env, sc.A)
+    sc.load(pool)
+    pool.set_auto_reset(True)
+    pool.set_step_chaining(2)
+    pool.set_split_step(False)
+    assert pool.step_form(6) == "chain"
+
+    def frag(k0, n):
+        pool.bind_actions(a0.data_ptr() + 4 * sc.n * k0, a1.data_ptr() + 4 * sc.n * k0)
+        pool.step_n(n, sc.interval_ms, sc.n)
+
+    frag(0, 6)
+    pool.sync()
+    after6 = [pool.download(f) for f in fields]
+    for rep in range(3):
+        pool.set_step_chaining(2)
+        pool.debug_chain_fault(3)
+        frag(6, 6)
+        pool.debug_chain_fault(0)
+        with pytest.raises(_ffi.T2DError) as ei:
+            pool.sync()
+        assert ei.value.code == _ffi.ERR_STATE and "rolled back to step 6" in str(ei.value), str(ei.value)
+        assert pool.step_count() == 6
+        for f, w in zip(fields, after6):
+            g = pool.download(f)
+            assert np.array_equal(g, w, equal_nan=True), (rep, f, int((g != w).sum()))
+    pool.close()
