@@ -673,6 +673,17 @@ int t2d_debug_closed_loop_destroy(t2d_closed_loop* loop);
 int t2d_debug_lane_safe_rects(int32_t n_env, const int32_t* env_lane_offsets, const int32_t* lane_vert_offsets,
                               const float* verts_xy, float* out);
 
+/* Host-only (no device is touched): the LDS budget of a scene before it is installed.  The step kernels keep the static and
+ * lane geometry of one workgroup's envs in ONE packed record of at most 32 KiB; t2d_set_static_geometry / t2d_set_lane_geometry
+ * narrow the workgroup down to one wave (64 / padded max_agents envs) before they give up with T2D_ERR_GEOMETRY.  This call runs
+ * the same preparation (convexity checks, fans of quads for 5..8-gons, the boundary pieces of each env's lane union) on host
+ * CSR arrays (as in t2d_set_*_geometry; either pair may be NULL) and reports the dwords the fullest such workgroup needs and
+ * the budget (8192): what tactics2d_amd/mapgeom.py uses to say how many lane / obstacle polygons of a reference map
+ * (map/element/lane.py:125-130, map/element/area.py) an env can carry.                                                      */
+int t2d_debug_geometry_budget(int32_t n_env, int32_t max_agents, const int32_t* env_poly_offsets, const int32_t* poly_vert_offsets,
+                              const float* poly_xy, const int32_t* env_lane_offsets, const int32_t* lane_vert_offsets,
+                              const float* lane_xy, int32_t* dwords_needed, int32_t* dwords_budget, int32_t* envs_per_workgroup);
+
 #ifdef __cplusplus
 }
 #endif

@@ -95,6 +95,8 @@ SYMBOLS = {
     "t2d_set_outputs": (C.c_int, [_vp, C.c_uint32]),
     "t2d_debug_delay_gather": (C.c_int, [_vp, C.c_int32]),
     "t2d_debug_lane_safe_rects": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
+    "t2d_debug_geometry_budget": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "t2d_profile_enable": (C.c_int, [_vp, C.c_int32]),
     "t2d_profile_read": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "t2d_comm_unique_id": (C.c_int, [_vp]),

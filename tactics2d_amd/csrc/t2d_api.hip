@@ -2459,6 +2459,48 @@ int t2d_debug_lane_safe_rects(int32_t n_env, const int32_t* env_lane_offsets, co
     return T2D_OK;
 }
 
+// Host-only: what t2d_set_static_geometry + t2d_set_lane_geometry would make of these polygons -- the dwords of the packed
+// record of the fullest workgroup at the narrowest workgroup the step kernels accept (one wave: 64 / padded max_agents envs)
+// against the 32 KiB budget; T2D_ERR_GEOMETRY (with the message t2d_set_*_geometry would give) for polygons it rejects.
+int t2d_debug_geometry_budget(int32_t n_env, int32_t max_agents, const int32_t* env_poly_offsets, const int32_t* poly_vert_offsets,
+                              const float* poly_xy, const int32_t* env_lane_offsets, const int32_t* lane_vert_offsets,
+                              const float* lane_xy, int32_t* dwords_needed, int32_t* dwords_budget, int32_t* envs_per_workgroup_out) {
+    if (n_env <= 0 || max_agents <= 0 || max_agents > T2D_MAX_AGENTS || !dwords_needed) return T2D_ERR_INVALID;
+    std::unique_ptr<t2d_pool> tmp(new (std::nothrow) t2d_pool());   // host bookkeeping only: no device call below
+    if (!tmp) return T2D_ERR_NOMEM;
+    tmp->v.n_env = n_env;
+    tmp->v.A = max_agents;
+    int rc;
+    if (env_poly_offsets) {
+        if ((rc = prepare_polys(tmp.get(), env_poly_offsets, poly_vert_offsets, poly_xy, tmp->hgeo[0])) != T2D_OK) return fail(nullptr, rc, tmp->err);
+    }
+    if (env_lane_offsets) {
+        if ((rc = prepare_polys(tmp.get(), env_lane_offsets, lane_vert_offsets, lane_xy, tmp->hgeo[1])) != T2D_OK) return fail(nullptr, rc, tmp->err);
+        build_lane_boundary(n_env, tmp->hgeo[1]);
+    }
+    const int log2A = log2_pad(max_agents);
+    const int epb = std::max(1, 64 >> log2A);
+    const int nb = (n_env + epb - 1) / epb;
+    int mp[2] = {0, 0}, mv[2] = {0, 0}, mb = 0;
+    for (int k = 0; k < 2; ++k) {
+        const auto& g = tmp->hgeo[k];
+        if (!g.present) continue;
+        for (int b = 0; b < nb; ++b) {
+            const int e0 = b * epb, e1 = std::min((int)n_env, e0 + epb);
+            const int p0 = g.env_off[e0], p1 = g.env_off[e1];
+            mp[k] = std::max(mp[k], p1 - p0);
+            mv[k] = std::max(mv[k], g.vert_off[p1] - g.vert_off[p0]);
+            if (k == 1) mb = std::max(mb, g.bnd_off[p1] - g.bnd_off[p0]);
+        }
+    }
+    t2d::GeoLayout gl{};
+    fill_layout(gl, epb, mp, mv, mb);
+    *dwords_needed = gl.stride;
+    if (dwords_budget) *dwords_budget = 8192;
+    if (envs_per_workgroup_out) *envs_per_workgroup_out = epb;
+    return T2D_OK;
+}
+
 int t2d_set_integrator_variant(t2d_pool* p, int32_t variant) {
     if (!p) return T2D_ERR_INVALID;
     if (variant < 0 || variant > 3) return fail(p, T2D_ERR_INVALID, "variant must be 0 (exact), 1 (fast), 2 (fast, kinematic steps iterated) or 3 (fast, resummed whatever the pool size)");

@@ -1,0 +1,267 @@
+"""From the reference's map elements to the geometry the event kernels take.
+
+The reference keeps a lane as a ring -- `Lane.geometry = LinearRing(left_side + reversed(right_side))`
+(map/element/lane.py:125-130): many vertices, not convex -- an area as an arbitrary polygon (map/element/area.py) and the map
+boundary as floor / ceil of the extreme coordinates (map/element/map.py:92-167).  The kernels take, per env, CONVEX polygons of
+3..8 vertices in one packed LDS record (include/t2d.h: t2d_set_static_geometry / t2d_set_lane_geometry), and the off-lane flag
+is `not union(lane polygons).contains(pose)` with the rule that polygons which abut share their vertices exactly.
+
+This module cuts the reference's rings into such polygons WITHOUT inventing a coordinate: every piece is made of the ring's
+own (fp32-rounded) vertices and every cut runs from one of them to another, so neighbouring pieces share whole edges bit for
+bit, and the union of the pieces is the ring.  Host-side numpy only (runs once per reset, like `OffLane.reset`).
+
+    lanes_from_sides(left_xy, right_xy)   one lane -> a strip of abutting convex quads / triangles
+    ring_to_convex(ring_xy, max_verts)    any simple ring -> convex pieces of <= max_verts vertices (ear clipping + merging)
+    areas_to_convex(polys, max_verts)     the same for a list of polygons
+    map_boundary(point sets)              Map.boundary's floor / ceil rule
+    from_reference_map(map_)              duck-typed: lanes / obstacle areas / boundary of a tactics2d `Map`
+    geometry_budget(...)                  how much of the 32 KiB record a scene takes, before it is installed
+"""
+import ctypes as C
+
+import numpy as np
+
+
+# ---------------------------------------------------------------------------------------------------------------- predicates
+def _f32(xy):
+    """the coordinates as the pool stores them: fp32, kept as fp64 values (products of their differences are then exact)"""
+    a = np.asarray(xy, np.float64).reshape(-1, 2)
+    return a.astype(np.float32).astype(np.float64)
+
+
+def _orient(a, b, c):
+    return (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0])
+
+
+def _area2(P):
+    x, y = P[:, 0], P[:, 1]
+    return float(np.dot(x, np.roll(y, -1)) - np.dot(np.roll(x, -1), y))
+
+
+def _is_convex(P, idx):
+    """every turn of the CCW index polygon is left or straight, and it has area (what t2d_set_*_geometry accepts)"""
+    n = len(idx)
+    if n < 3:
+        return False
+    for i in range(n):
+        if _orient(P[idx[i]], P[idx[(i + 1) % n]], P[idx[(i + 2) % n]]) < 0.0:
+            return False
+    return _area2(P[list(idx)]) > 0.0
+
+
+def _in_triangle(p, a, b, c):
+    return _orient(a, b, p) >= 0.0 and _orient(b, c, p) >= 0.0 and _orient(c, a, p) >= 0.0
+
+
+def _dedup(P):
+    keep = [0]
+    for i in range(1, len(P)):
+        if not np.array_equal(P[i], P[keep[-1]]):
+            keep.append(i)
+    if len(keep) > 1 and np.array_equal(P[keep[-1]], P[keep[0]]):   # a closed ring repeats its first vertex
+        keep.pop()
+    return P[keep]
+
+
+# ---------------------------------------------------------------------------------------------------------------- ear clipping
+def _ear_clip(P):
+    """triangles (index triples, CCW) of the simple CCW ring P; collinear vertices are dropped (they add no area)"""
+    idx = list(range(len(P)))
+    tris = []
+    guard = 0
+    while len(idx) > 3:
+        n = len(idx)
+        clipped = False
+        for k in range(n):
+            i0, i1, i2 = idx[(k - 1) % n], idx[k], idx[(k + 1) % n]
+            o = _orient(P[i0], P[i1], P[i2])
+            if o == 0.0:               # collinear: the vertex lies on the chord, remove it without a triangle
+                idx.pop(k)
+                clipped = True
+                break
+            if o < 0.0:
+                continue               # reflex corner
+            a, b, c = P[i0], P[i1], P[i2]
+            if any(j not in (i0, i1, i2) and _in_triangle(P[j], a, b, c) and not (np.array_equal(P[j], a) or np.array_equal(P[j], b) or np.array_equal(P[j], c))
+                   for j in idx):
+                continue
+            tris.append((i0, i1, i2))
+            idx.pop(k)
+            clipped = True
+            break
+        guard += 1
+        if not clipped or guard > 4 * len(P) + 16:
+            raise ValueError("ring is not a simple polygon (self-intersecting or degenerate): cannot be cut into convex pieces")
+    if len(idx) == 3 and _orient(P[idx[0]], P[idx[1]], P[idx[2]]) > 0.0:
+        tris.append(tuple(idx))
+    return tris
+
+
+def _merge(P, polys, max_verts):
+    """Hertel-Mehlhorn style: join two pieces across a shared edge while the result stays convex and small enough"""
+    polys = [list(p) for p in polys]
+    changed = True
+    while changed:
+        changed = False
+        edges = {}
+        for pi, p in enumerate(polys):
+            for k in range(len(p)):
+                edges[(p[k], p[(k + 1) % len(p)])] = (pi, k)
+        for (a, b), (pi, ka) in list(edges.items()):
+            other = edges.get((b, a))
+            if other is None:
+                continue
+            pj, kb = other
+            if pi == pj or len(polys[pi]) + len(polys[pj]) - 2 > max_verts:
+                continue
+            p, q = polys[pi], polys[pj]
+            # p runs ... a, b ...; q runs ... b, a ...: walk p from b round to a, then q from a round to b (ends dropped)
+            m = [p[(ka + 1 + t) % len(p)] for t in range(len(p))] + [q[(kb + 2 + t) % len(q)] for t in range(len(q) - 2)]
+            # straight corners at the two joints are kept (shared vertices stay shared); the piece must be convex
+            if _is_convex(P, m):
+                polys[pi] = m
+                polys.pop(pj)
+                changed = True
+                break
+    return polys
+
+
+def ring_to_convex(ring_xy, max_verts=8):
+    """A simple ring (closed or not, either winding) -> list of convex CCW polygons, float32 (n, 2), 3 <= n <= max_verts, made
+    of the ring's own vertices; their union is the ring's polygon and neighbours share whole edges."""
+    if not 3 <= max_verts <= 8:
+        raise ValueError("max_verts must be 3..8 (T2D_MAX_POLY_VERTS)")
+    P = _dedup(_f32(ring_xy))
+    if len(P) < 3:
+        raise ValueError("a ring needs at least 3 distinct vertices")
+    a2 = _area2(P)
+    if a2 == 0.0:
+        raise ValueError("ring has no area")
+    if a2 < 0.0:
+        P = P[::-1].copy()
+    polys = _merge(P, _ear_clip(P), max_verts)
+    return [np.float32(P[list(p)]) for p in polys]
+
+
+def areas_to_convex(polys, max_verts=8):
+    """[ring (n, 2), ...] -> flat list of convex pieces (map/element/area.py geometries: `area.geometry.exterior.coords`)"""
+    out = []
+    for ring in polys:
+        out.extend(ring_to_convex(ring, max_verts))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- lanes
+def lanes_from_sides(left_xy, right_xy, max_verts=4):
+    """One lane of the reference -- its two side polylines, same direction of travel (Lane.left_side / right_side,
+    map/element/lane.py:117-130) -- as a strip of exactly-abutting convex polygons (quads where the sides allow, triangles where
+    one side has more points than the other): consecutive cross cuts L[i] - R[j] advance along whichever side keeps the cut
+    short, so the pieces follow the lane instead of fanning out from one corner.  Falls back to ear clipping of the ring
+    left + reversed(right) when a cut would leave the lane (sides that fold back).  Returns float32 arrays (n, 2), CCW."""
+    Lp, Rp = _dedup(_f32(left_xy)), _dedup(_f32(right_xy))
+    if len(Lp) < 2 or len(Rp) < 2:
+        raise ValueError("each side needs at least 2 distinct points")
+    ring = np.concatenate([Lp, Rp[::-1]])
+    sign = np.sign(_area2(ring))
+    if sign == 0.0:
+        raise ValueError("lane has no area")
+    nL, nR = len(Lp), len(Rp)
+    P = np.concatenate([Lp, Rp])           # indices: left i, right nL + j
+    tris, i, j, ok = [], 0, 0, True
+    while i < nL - 1 or j < nR - 1:
+        adv_left = j == nR - 1 or (i < nL - 1 and np.sum((Lp[i + 1] - Rp[j]) ** 2) <= np.sum((Lp[i] - Rp[j + 1]) ** 2))
+        t = (i, nL + j, i + 1) if adv_left else (i, nL + j, nL + j + 1)
+        o = _orient(P[t[0]], P[t[1]], P[t[2]])
+        if o * sign > 0.0:                 # (the ring runs left forward, right backward: a valid piece turns the other way round)
+            ok = False
+            break
+        if o != 0.0:
+            tris.append(t if o > 0.0 else (t[0], t[2], t[1]))
+        if adv_left:
+            i += 1
+        else:
+            j += 1
+    # (pieces that all turn the right way tile the lane iff their areas add up to the ring's: a cut that crossed the far side
+    # would count some ground twice)
+    if ok and tris:
+        total = sum(_orient(P[a], P[b], P[c]) for a, b, c in tris)
+        ok = abs(total - abs(_area2(ring))) <= 1e-9 * abs(_area2(ring))
+    if not ok or not tris:
+        return ring_to_convex(ring, max(max_verts, 3))
+    return [np.float32(P[list(p)]) for p in _merge(P, tris, max_verts)]
+
+
+# ---------------------------------------------------------------------------------------------------------------- boundary
+def map_boundary(*point_sets):
+    """Map.boundary (map/element/map.py:92-167): (floor(min x), ceil(max x), floor(min y), ceil(max y)) over every coordinate
+    given -- nodes, lane rings, area exteriors, road lines; (0, 0, 0, 0) for an empty map.  Tuple order = OutBound's."""
+    pts = [np.asarray(p, np.float64).reshape(-1, 2) for p in point_sets if p is not None and len(p)]
+    if not pts:
+        return (0.0, 0.0, 0.0, 0.0)
+    a = np.concatenate(pts)
+    return (float(np.floor(a[:, 0].min())), float(np.ceil(a[:, 0].max())), float(np.floor(a[:, 1].min())), float(np.ceil(a[:, 1].max())))
+
+
+def _coords(geom):
+    if geom is None:
+        return None
+    ext = getattr(geom, "exterior", None)
+    c = getattr(ext if ext is not None else geom, "coords", geom)
+    a = np.asarray(list(c), np.float64)
+    return a[:, :2] if a.size else None
+
+
+def from_reference_map(map_, origin=(0.0, 0.0), obstacle_subtypes=("obstacle",), max_lane_verts=4, max_area_verts=8):
+    """Flatten a tactics2d `Map` (duck-typed: `.lanes`, `.areas`, optionally `.nodes` / `.roadlines`, dicts of elements with the
+    reference's attributes) for ONE env: returns dict(lanes=[convex polys], static=[convex polys], boundary=(xmin, xmax, ymin,
+    ymax)).  `origin` is subtracted first: the pool stores env-local fp32 coordinates and wants |x|, |y| < 256 m.
+    Lanes with both sides use lanes_from_sides, the others their `geometry` ring; areas whose subtype is in
+    `obstacle_subtypes` become static obstacles (envs/parking.py:416-420 passes exactly those to StaticCollision)."""
+    o = np.asarray(origin, np.float64)
+    lanes, static, pts = [], [], []
+    for lane in getattr(map_, "lanes", {}).values():
+        left, right = _coords(getattr(lane, "left_side", None)), _coords(getattr(lane, "right_side", None))
+        if left is not None and right is not None:
+            lanes.extend(lanes_from_sides(left - o, right - o, max_lane_verts))
+            pts += [left - o, right - o]
+        else:
+            ring = _coords(getattr(lane, "geometry", None))
+            if ring is not None:
+                lanes.extend(ring_to_convex(ring - o, max(max_lane_verts, 3)))
+                pts.append(ring - o)
+    for area in getattr(map_, "areas", {}).values():
+        ring = _coords(getattr(area, "geometry", None))
+        if ring is None:
+            continue
+        pts.append(ring - o)
+        if getattr(area, "subtype", None) in obstacle_subtypes:
+            static.extend(ring_to_convex(ring - o, max_area_verts))
+    for node in getattr(map_, "nodes", {}).values():
+        pts.append(np.array([[node.x, node.y]], np.float64) - o)
+    for line in getattr(map_, "roadlines", {}).values():
+        c = _coords(getattr(line, "geometry", None))
+        if c is not None:
+            pts.append(c - o)
+    return dict(lanes=lanes, static=static, boundary=map_boundary(*pts))
+
+
+# ---------------------------------------------------------------------------------------------------------------- capacity
+def geometry_budget(n_env, max_agents, static=None, lanes=None):
+    """What t2d_set_static_geometry + t2d_set_lane_geometry would need of the 32 KiB per-workgroup record for these scenes
+    (per-env lists of convex polygons, or CSR triples), WITHOUT a device: dict(dwords_needed, dwords_budget, envs_per_workgroup,
+    fits).  Raises GeometryError for polygons the library rejects (not convex, degenerate, > 8 vertices)."""
+    from . import _ffi
+    from .traffic import polygons_to_csr
+
+    def csr(t):
+        if t is None:
+            return None, None, None
+        eo, vo, xy = t if isinstance(t, tuple) else polygons_to_csr(t)
+        return (np.ascontiguousarray(eo, np.int32), np.ascontiguousarray(vo, np.int32), np.ascontiguousarray(xy, np.float32))
+
+    p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    s, l = csr(static), csr(lanes)
+    need, budget, epb = C.c_int32(), C.c_int32(), C.c_int32()
+    _ffi.check(_ffi.lib().t2d_debug_geometry_budget(int(n_env), int(max_agents), p(s[0]), p(s[1]), p(s[2]), p(l[0]), p(l[1]), p(l[2]),
+                                                   C.byref(need), C.byref(budget), C.byref(epb)))
+    return dict(dwords_needed=need.value, dwords_budget=budget.value, envs_per_workgroup=epb.value, fits=need.value <= budget.value)

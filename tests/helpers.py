@@ -45,6 +45,11 @@ SENS_CHAOTIC = 1e-3
 SENS_SCALE = 600.0   # the worst observed |error| / (1e-5 + SENS_SCALE x sens) over the 221 scaled cases of dyn_random.npz is 0.9
 
 
+def dyn_chaotic_bound(sens, tol=1e-5):
+    """the bound held even where the reference is chaotic (sens >= SENS_CHAOTIC): the same K x sens as the scaled cases"""
+    return tol + SENS_SCALE * np.asarray(sens, np.float64)
+
+
 def dyn_tolerance(sens, tol=1e-5):
     """per-case tolerance (np.inf where the reference is chaotic) and the mask of the strictly asserted cases"""
     sens = np.asarray(sens, np.float64)

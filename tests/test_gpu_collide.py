@@ -204,3 +204,51 @@ def test_fused_step_equals_two_kernel_step(variant, n_env, A):
         pool.close()
     for a, b in zip(*outs):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_reference_lane_rings_through_the_map_adapter(oracle):
+    """A curved two-lane road given the way the reference holds it (two side polylines per lane, 40 points each:
+    map/element/lane.py:125-130) cut by tactics2d_amd.mapgeom into abutting convex quads, installed, and stepped over: the
+    kernel's off-lane flags equal the oracle's on the pieces AND `ring polygon contains pose` on the UNDIVIDED outline in exact
+    rational arithmetic; the budget query agrees with what t2d_set_lane_geometry accepts."""
+    import test_mapgeom as TM
+    from tactics2d_amd import _ffi, layout as L, mapgeom as MG
+    from tactics2d_amd.pool import ParticipantPool
+    road = TM._curved_road(wiggle=1.5, seed=4)
+    pieces = [q for left, right in road for q in MG.lanes_from_sides(left, right)]
+    outline = np.concatenate([road[0][0], road[1][1][::-1]])
+    n_env, A = 24, 16
+    rng = np.random.default_rng(12)
+    rows = H.shape_rows(with_peds=False)
+    n = n_env * A
+    ang = rng.uniform(-0.02, 1.32, n); rr = 60.0 + rng.uniform(-5.5, 5.5, n)
+    x, y = np.float32(rr * np.cos(ang)), np.float32(rr * np.sin(ang))
+    h = np.float32(ang + np.pi / 2 + rng.normal(0, 0.25, n))
+    tid = rng.integers(0, len(rows), n).astype(np.uint8)
+    act = np.ones(n, np.uint8)
+    lanes = [pieces] * n_env
+    budget = MG.geometry_budget(n_env, A, lanes=lanes)
+    assert budget["fits"], budget
+    pool = ParticipantPool(n_env, A)
+    pool.set_param_table(rows)
+    from tactics2d_amd.traffic import polygons_to_csr
+    csr = polygons_to_csr(lanes)
+    pool.set_lane_geometry(csr)
+    pool.reset(x, y, h, np.zeros(n, np.float32), tid, act)
+    pool.collide()
+    got = pool.download(L.F_FLAGS)
+    want, _ = oracle.collide(rows, n_env, A, x, y, h, tid, act, None, None, None, csr, 0)
+    assert np.array_equal(got & L.FLAG_OFF_LANE, want & L.FLAG_OFF_LANE)
+    n_in = 0
+    for i in range(0, n, 3):
+        pose = oracle.pose_obb(float(x[i]), float(y[i]), float(h[i]), rows[tid[i], L.P_LENGTH], rows[tid[i], L.P_WIDTH], trig=0)
+        inside = TM._exact_box_in_ring(pose, outline)
+        assert bool(got[i] & L.FLAG_OFF_LANE) == (not inside), i
+        n_in += inside
+    assert 20 < n_in < n // 3 - 20
+    # a scene that does not fit: the budget query says so, and so does the library
+    too_many = [pieces * 8] * n_env
+    assert not MG.geometry_budget(n_env, A, lanes=too_many)["fits"]
+    with pytest.raises(_ffi.GeometryError):
+        pool.set_lane_geometry(polygons_to_csr(too_many))
+    pool.close()

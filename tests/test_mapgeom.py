@@ -1,0 +1,177 @@
+"""tactics2d_amd.mapgeom: the reference's lane rings / area polygons cut into the convex polygons the event kernels take
+(map/element/lane.py:125-130, map/element/map.py:92-167).  CPU tests: the pieces are convex, made of
+the ring's own vertices, abut exactly -- and the off-lane predicate on the pieces (the oracle's union rule) equals `ring polygon
+contains box` evaluated on the UNDIVIDED ring in exact rational arithmetic."""
+from fractions import Fraction as Fr
+
+import numpy as np
+import pytest
+
+from tactics2d_amd import mapgeom as MG
+
+
+def _area2(P):
+    P = np.asarray(P, np.float64)
+    return float(np.dot(P[:, 0], np.roll(P[:, 1], -1)) - np.dot(np.roll(P[:, 0], -1), P[:, 1]))
+
+
+def _convex_ccw(P):
+    P = np.asarray(P, np.float64)
+    n = len(P)
+    return n >= 3 and _area2(P) > 0 and all(
+        (P[(i + 1) % n, 0] - P[i, 0]) * (P[(i + 2) % n, 1] - P[i, 1]) - (P[(i + 1) % n, 1] - P[i, 1]) * (P[(i + 2) % n, 0] - P[i, 0]) >= 0
+        for i in range(n))
+
+
+def _curved_road(n_pts=40, radius=60.0, width=3.75, arc=1.3, wiggle=0.0, seed=0):
+    """two lanes side by side along an arc, their shared rail sampled ONCE (so the lanes abut exactly); sides of a lane may
+    carry different numbers of points (the outer rail is resampled)"""
+    rng = np.random.default_rng(seed)
+    t = np.linspace(0, arc, n_pts)
+    r = radius + wiggle * np.sin(7 * t)
+    rail = lambda off, tt=t: np.stack([(np.interp(tt, t, r) + off) * np.cos(tt), (np.interp(tt, t, r) + off) * np.sin(tt)], 1)
+    mid = rail(0.0)
+    inner = rail(-width, np.sort(np.concatenate([[0, arc], rng.uniform(0, arc, n_pts - 9)])))   # fewer points than the middle rail
+    outer = rail(+width, np.linspace(0, arc, n_pts + 7))
+    # direction of travel = increasing angle (counter-clockwise): the LEFT side is the inner rail
+    return [(inner, mid), (mid, outer)]
+
+
+def _exact_box_in_ring(box, ring):
+    """closed polygon(ring) contains the convex box  <=>  area(box clipped to ... ) -- here: clip the RING by the box's four
+    half-planes (Sutherland-Hodgman, exact rationals) and compare areas"""
+    F = lambda P: [(Fr(float(x)), Fr(float(y))) for x, y in P]
+    a2 = lambda P: sum(P[i][0] * P[(i + 1) % len(P)][1] - P[(i + 1) % len(P)][0] * P[i][1] for i in range(len(P)))
+    B, R = F(box), F(np.float32(ring))
+    if a2(B) < 0:
+        B = B[::-1]
+    if a2(R) < 0:
+        R = R[::-1]
+    out = R
+    for k in range(4):
+        a, b = B[k], B[(k + 1) % 4]
+        side = lambda p: (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0])
+        nxt = []
+        for i in range(len(out)):
+            p, q = out[i], out[(i + 1) % len(out)]
+            sp, sq = side(p), side(q)
+            if sp >= 0:
+                nxt.append(p)
+            if (sp > 0 and sq < 0) or (sp < 0 and sq > 0):
+                t = sp / (sp - sq)
+                nxt.append((p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1])))
+        out = nxt
+        if len(out) < 3:
+            return False
+    return a2(out) == a2(B)
+
+
+def test_lane_strip_pieces_are_convex_made_of_the_sides_own_points_and_tile_the_lane():
+    for seed, wiggle in ((0, 0.0), (1, 1.5), (2, 3.0)):
+        for left, right in _curved_road(wiggle=wiggle, seed=seed):
+            pieces = MG.lanes_from_sides(left, right)
+            pts = {tuple(p) for p in np.float32(np.concatenate([left, right]))}
+            ring = np.float32(np.concatenate([left, right[::-1]]))
+            assert len(pieces) >= 30
+            for q in pieces:
+                assert q.dtype == np.float32 and 3 <= len(q) <= 4 and _convex_ccw(q)
+                assert all(tuple(v) in pts for v in q)
+            assert abs(sum(_area2(q) for q in pieces) - abs(_area2(ring))) < 1e-6 * abs(_area2(ring))
+            assert sum(len(q) == 4 for q in pieces) >= 0.6 * len(pieces)    # mostly quads: the strip follows the lane
+            # every cut is shared by exactly two pieces, edge for edge (no T-junction): the outline left over is the ring
+            edges = {}
+            for q in pieces:
+                for k in range(len(q)):
+                    e = (tuple(q[k]), tuple(q[(k + 1) % len(q)]))
+                    edges[e] = edges.get(e, 0) + 1
+            open_edges = [e for e in edges if (e[1], e[0]) not in edges]
+            ring_edges = {(tuple(ring[k]), tuple(ring[(k + 1) % len(ring)])) for k in range(len(ring))}
+            ring_edges |= {(b, a) for a, b in ring_edges}
+            assert all(e in ring_edges for e in open_edges) and all(v == 1 for v in edges.values())
+
+
+def test_off_lane_on_the_pieces_equals_contains_on_the_undivided_ring(oracle):
+    """a curved two-lane road with 40-point sides: `not union(pieces).contains(pose)` (the oracle's predicate, what the kernels
+    evaluate) against exact `polygon(ring of both lanes).contains(pose)` on the undivided outline"""
+    rng = np.random.default_rng(5)
+    n = inside = 0
+    for seed, wiggle in ((0, 0.0), (3, 2.0)):
+        road = _curved_road(wiggle=wiggle, seed=seed)
+        pieces = [q for left, right in road for q in MG.lanes_from_sides(left, right)]
+        outline = np.concatenate([road[0][0], road[1][1][::-1]])     # inner rail forward, outer rail backward: both lanes
+        for _ in range(140):
+            ang = rng.uniform(-0.05, 1.35); rr = 60.0 + rng.uniform(-5.5, 5.5)
+            x, y = np.float32(rr * np.cos(ang)), np.float32(rr * np.sin(ang))
+            h = np.float32(ang + np.pi / 2 + rng.normal(0, 0.25))
+            pose = oracle.pose_obb(float(x), float(y), float(h), rng.uniform(3.5, 5.0), rng.uniform(1.6, 2.0), trig=0)
+            got = oracle.pose_in_lane_union(pose, (float(x), float(y)), pieces)
+            want = _exact_box_in_ring(pose, outline)
+            assert got == want, (seed, float(x), float(y), float(h), got, want)
+            n += 1; inside += want
+    assert n == 280 and 0.2 < inside / n < 0.8, (n, inside)
+
+
+def test_ring_to_convex_on_non_convex_areas():
+    comb = [(0, 0), (10, 0), (10, 6), (8, 6), (8, 2), (6, 2), (6, 6), (4, 6), (4, 2), (2, 2), (2, 6), (0, 6)]
+    ell = [(0, 0), (6, 0), (6, 2), (2, 2), (2, 7), (0, 7)]
+    star = [(np.cos(a) * (4 if k % 2 else 9), np.sin(a) * (4 if k % 2 else 9)) for k, a in enumerate(np.linspace(0, 2 * np.pi, 14, endpoint=False))]
+    for ring in (comb, ell, star, comb[::-1], ell + [ell[0]]):
+        for mv in (3, 4, 8):
+            pieces = MG.ring_to_convex(ring, mv)
+            assert all(_convex_ccw(q) and len(q) <= mv for q in pieces)
+            assert abs(sum(_area2(q) for q in pieces) - abs(_area2(np.float32(ring)))) < 1e-4
+        assert len(MG.ring_to_convex(ring, 8)) <= len(MG.ring_to_convex(ring, 3))
+    sq = MG.ring_to_convex([(0, 0), (2, 0), (4, 0), (4, 3), (0, 3)], 8)   # a collinear vertex adds nothing
+    assert len(sq) == 1 and abs(_area2(sq[0]) - 24.0) < 1e-6
+    with pytest.raises(ValueError):
+        MG.ring_to_convex([(0, 0), (4, 4), (4, 0), (0, 4)], 8)             # a bow tie is not a simple ring
+    with pytest.raises(ValueError):
+        MG.ring_to_convex([(0, 0), (1, 1), (2, 2)], 8)
+    assert len(MG.areas_to_convex([ell, comb], 8)) == len(MG.ring_to_convex(ell, 8)) + len(MG.ring_to_convex(comb, 8))
+
+
+def test_map_boundary_and_the_duck_typed_map_adapter():
+    assert MG.map_boundary() == (0.0, 0.0, 0.0, 0.0)
+    assert MG.map_boundary([(0.2, -1.5), (3.7, 2.01)], [(-0.1, 0.0)]) == (-1.0, 4.0, -2.0, 3.0)   # floor / ceil, map.py:149-160
+
+    class Geo:
+        def __init__(self, c): self.coords = c
+    class Poly:
+        def __init__(self, c): self.exterior = Geo(c)
+    class Lane:
+        def __init__(self, left=None, right=None, ring=None):
+            self.left_side = None if left is None else Geo(left)
+            self.right_side = None if right is None else Geo(right)
+            self.geometry = None if ring is None else Geo(ring)
+    class Area:
+        def __init__(self, c, subtype): self.geometry, self.subtype = Poly(c), subtype
+    class Map:
+        pass
+    road = _curved_road(n_pts=12)
+    m = Map()
+    m.lanes = {"1": Lane(road[0][0] + [1000, 2000], road[0][1] + [1000, 2000]),
+               "2": Lane(ring=np.concatenate([road[1][0], road[1][1][::-1]]) + [1000, 2000])}
+    m.areas = {"a": Area([(1050, 2010), (1056, 2010), (1056, 2012), (1052, 2012), (1052, 2017), (1050, 2017), (1050, 2010)], "obstacle"),
+               "b": Area([(1000, 2000), (1001, 2000), (1001, 2001)], "freespace")}
+    out = MG.from_reference_map(m, origin=(1000, 2000))
+    assert len(out["static"]) == len(MG.ring_to_convex([(50, 10), (56, 10), (56, 12), (52, 12), (52, 17), (50, 17)], 8))
+    assert all(_convex_ccw(q) for q in out["lanes"] + out["static"]) and len(out["lanes"]) > 12
+    assert np.abs(np.concatenate(out["lanes"])).max() < 256
+    b = out["boundary"]
+    assert b[0] <= 0.0 and b[2] <= 0.0 and b[1] >= 56.0 and all(float(v).is_integer() for v in b)
+
+
+def test_geometry_budget_says_how_many_polygons_an_env_can_carry():
+    road = _curved_road(n_pts=40)
+    pieces = [q for left, right in road for q in MG.lanes_from_sides(left, right)]
+    small = MG.geometry_budget(8, 64, lanes=[pieces[:40]] * 8)
+    big = MG.geometry_budget(8, 64, lanes=[pieces] * 8)
+    assert small["envs_per_workgroup"] == 1 and small["dwords_budget"] == 8192
+    assert small["fits"] and small["dwords_needed"] < big["dwords_needed"]
+    # the more envs share a workgroup (smaller max_agents), the less each can carry
+    assert MG.geometry_budget(8, 8, lanes=[pieces[:40]] * 8)["dwords_needed"] > small["dwords_needed"]
+    huge = MG.geometry_budget(2, 64, lanes=[pieces * 6] * 2)
+    assert not huge["fits"]
+    from tactics2d_amd._ffi import GeometryError
+    with pytest.raises(GeometryError):
+        MG.geometry_budget(1, 64, static=[[np.float32([(0, 0), (4, 4), (4, 0), (0, 4)])]])   # not convex
