@@ -33,7 +33,7 @@ def short(name):
             return "ego_step_kernel_loop" + ("_pipe" if a[2] == "true" else "")
     for k in ("ego_step_kernel", "lidar_kernel", "idm_kernel", "parking_scene_kernel", "scene_refill_scan_kernel", "scene_refill_kernel",
               "scene_commit_kernel", "derive_kernel", "feedback_policy_kernel", "chain_rollback_kernel", "integrate_kernel",
-              "restore_env_kernel", "restore_kernel", "drift_kernel"):
+              "restore_env_kernel", "restore_kernel", "drift_kernel", "frame_pack_kernel"):
         if k in n:
             return k
     return name[:40]
