@@ -41,5 +41,5 @@ rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/vec_sq -o vec -- 
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $OUT/idm_sq -o idm -- python scripts/time_idm.py 4096 short > $OUT/idm_sq.log 2>&1
 # the Gym-API host path (round 5): kernels of one VecParkingEnv.step at 4096 envs (ego step, lidar, frame pack) and its wall time
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/host -o host -- python scripts/time_host_path.py 4096 200 > $OUT/host.log 2>&1
-cp $OUT/host.log gpurun_out/${TAG}_host_path.json 2>/dev/null
+grep '^{' $OUT/host.log > gpurun_out/${TAG}_host_path.json 2>/dev/null
 python scripts/summarize_profile.py $OUT $TAG

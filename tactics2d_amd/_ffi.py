@@ -150,7 +150,13 @@ def lib():
                 "(hipcc, gfx950). tactics2d_amd has no CPU fallback.")
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
-            fn = getattr(handle, name)
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                # (A/B measurements against a library built from older sources of the same ABI version: scripts/ab_step.py)
+                if os.environ.get("T2D_ALLOW_MISSING_SYMBOLS"):
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         from . import layout

@@ -958,7 +958,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
         fy = s_hand[step_k & 1][1][tid];
         fh = s_hand[step_k & 1][2][tid];
     }
-    const bool active = valid && ((ids >> kIdsActiveShift) & 0xffu);
+    bool active = valid && ((ids >> kIdsActiveShift) & 0xffu);
     const int type = (ids >> kIdsTypeShift) & 0xff;
     if constexpr (IDMF && !PIPE) {
         // IDMController.step ahead of the integrator (what t2d_step does with an idm_kernel launch in front of this one): the
@@ -1062,14 +1062,16 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     // ---------------- phase 1: pose, out-of-bound, conservative fp32 box ------------------------
     // (build-defined, as in the oracle's t2do_collide: a participant whose pose is not finite -- a NaN action that went through
     // np.clip, an overflow -- takes no part in event detection: no flag of its own, and nobody collides with it)
-    const bool present = active && __builtin_isfinite(fx) && __builtin_isfinite(fy) && __builtin_isfinite(fh);
+    // (`active` itself from here on -- nothing below asks whether the slot holds a participant, only whether it takes part:
+    // a second lane mask kept alive through the event phases cost the looping forms 2 % on the highway pool)
+    active = active && __builtin_isfinite(fx) && __builtin_isfinite(fy) && __builtin_isfinite(fh);
     int kind = -1;
     float R32 = -1.0f;                                  // bounding radius + 5 mm; < 0 = inactive
     float box_lo_x = 0, box_hi_x = 0, box_lo_y = 0, box_hi_y = 0;  // encloses the pose (outward rounded)
     uint32_t f_own = 0;                                 // flags this lane decides alone
     bool lane_safe = false;                             // pose certified inside the union of the env's lanes
     int gcx = 0, gcy = 0;
-    if (present) {
+    if (active) {
         const double cx = (double)fx, cy = (double)fy;
         // columns SHAPE, LENGTH, WIDTH, RESERVED0 (bounding radius) are consecutive in the table
         constexpr int c0 = FUSE >= 0 ? T2D_P_SHAPE : 0;
@@ -1317,7 +1319,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
             static_assert(3 * 96 <= kQueueCap, "broad-phase staging must fit in the wave's queue");
             // (the centre comes back from LDS: carried in registers since the pose phase it cost the kernel a spill)
             const float fx_b = s_cxy[0][tid], fy = s_cxy[1][tid];
-            const float px = present ? fx_b : 1e30f;
+            const float px = active ? fx_b : 1e30f;
             // every env of the wave gets a segment of 1.5 * A_pad entries: its agents, then its first half again, so
             // that the ring sweep below reads agent + offset without wrapping (64 / A_pad segments: 96 entries in all)
             const int n_off = A_pad >> 1;                           // partners per lane: agent + 1 .. agent + A_pad / 2
@@ -1374,11 +1376,11 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
             cand = h;
         }
         T2D_MARK(3);
-        if (!present || (T2D_PROBE_SKIP & 2)) cand = 0ull;
+        if (!active || (T2D_PROBE_SKIP & 2)) cand = 0ull;
         compact_and_process<false, true>(cand, slot0, tid, queue, qcount, lane, process_pair, true, A_pad - 1);
     } else {
         // spatial-hash walk; pairs go straight to the narrow phase (i < j de-duplicates)
-        if (present) {
+        if (active) {
             const double cx = (double)s_cxy[0][tid], cy = (double)s_cxy[1][tid];
             for (int oy_ = -1; oy_ <= 1; ++oy_)
                 for (int ox_ = -1; ox_ <= 1; ++ox_) {
@@ -1467,7 +1469,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
         const f2p bxp = {-box_hi_x, box_lo_x}, byp = {-box_hi_y, box_lo_y};
         if (gl2.has[0] && !(T2D_PROBE_SKIP & 4) && (!SPLIT || role == 1) && !role_b) {   // static obstacles
             const int* pstart = geo_i + gl2.off_pstart[0];
-            sweep_stage(reinterpret_cast<const float4*>(s_geo + gl2.off_aabb[0]), pstart[env_local], pstart[env_local + 1], present,
+            sweep_stage(reinterpret_cast<const float4*>(s_geo + gl2.off_aabb[0]), pstart[env_local], pstart[env_local + 1], active,
                         bxp, byp, process_static, 5);
         }
         if (gl2.has[1] && !(T2D_PROBE_SKIP & 8) && (!SPLIT || role >= 2) && (PIPE != 2 || role_b)) {   // lanes: off-lane = not union(lanes).contains(pose)
@@ -1477,7 +1479,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                 const int mid = p0 + ((p1 - p0 + 1) >> 1);
                 if (role == 2) p1 = mid; else p0 = mid;
             }
-            const bool want = present && !lane_safe && p1 > p0;   // (poses in a safe rectangle are done)
+            const bool want = active && !lane_safe && p1 > p0;   // (poses in a safe rectangle are done)
             if (__ballot(want) != 0ull)   // (wave-uniform: the lanes of a wave may belong to different envs)
                 sweep_stage(reinterpret_cast<const float4*>(s_geo + gl2.off_aabb[1]), p0, p1, want, bxp, byp, process_lane, 7);
         }
@@ -1565,7 +1567,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     T2D_MARK(10);
     if ((!SPLIT || role == 0) && !role_b) {   // (SPLIT: the reduce, the epilogue and the restore are wave 0's)
     uint32_t f = 0;
-    if (present) {
+    if (active) {
         const uint32_t sf = s_flags[tid];
         f = f_own | (sf & ((1u << kLaneShift) - 1u));
         if (n_lane_polys > 0) {  // build-defined off-lane: not union(lanes).contains(pose)

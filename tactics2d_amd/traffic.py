@@ -226,6 +226,19 @@ class BatchedScenarioManager:
         self.pool.step(self.step_size, stream)
         self._flags_cache = None
 
+    def step_host(self, actions, lidar=False, fresh=True):
+        """update + check_status for every scene, host to host, in ONE library call (t2d_step_host): `actions` float32
+        [n_env * max_agents, 2] in the reference's action layout (steering, accel) -- (ay, ax) for a point mass -- in, a
+        pool.HostFrame out: the ego's state, reward, status bytes, IoU, frame, counters (and the 360-beam scan with lidar=True,
+        after lidar_config) of every scene as numpy views of one pinned frame, instead of one blocking copy per field."""
+        want = (bool(lidar),)
+        if getattr(self, "_frame_cfg", None) != want:
+            self.pool.frame_config(lidar=bool(lidar))
+            self._frame_cfg = want
+        a = np.ascontiguousarray(actions, np.float32).reshape(self.n_env * self.max_agents, 2)
+        self._flags_cache = None
+        return self.pool.step_host(a, self.step_size, fresh=fresh)
+
     def render(self):
         raise NotImplementedError("rendering is outside the accelerated path (DESIGN.md section 9)")
 

@@ -50,6 +50,37 @@ def dyn_chaotic_bound(sens, tol=1e-5):
     return tol + SENS_SCALE * np.asarray(sens, np.float64)
 
 
+def dyn_max_trig_argument(d, k):
+    """The largest |phi + beta| SingleTrackDynamics._step (single_track_dynamics.py:140-229) feeds to cos / sin while it
+    integrates case k of dyn_random.npz: where the reference's own slip angle explodes (crawling speed, tyre-force branch)
+    it reaches 1e14 .. 1e18 rad -- outside the domain the deterministic sincos is specified for (|x| < 1e9)."""
+    from tactics2d_amd import layout as L
+    row = d["rows"][d["type_id"][k]]
+    iv, dt_ms = (int(v) for v in d["timing"][k])
+    lf, lr, wb = row[L.P_LF], row[L.P_LR], row[L.P_WB]
+    mass, hcg, mu, Iz, cf, cr = (row[c] for c in (L.P_MASS, L.P_MASS_HEIGHT, L.P_MU, L.P_IZ, L.P_CF, L.P_CR))
+    _, _, phi, v = (float(np.float32(q)) for q in d["state"][k])
+    accel = float(np.clip(np.float32(d["action"][k][0]), row[L.P_ACCEL_LO], row[L.P_ACCEL_HI]))
+    delta = float(np.clip(np.float32(d["action"][k][1]), row[L.P_STEER_LO], row[L.P_STEER_HI]))
+    dt, g = dt_ms / 1000, 9.81
+    ff, fr = (g * lr - accel * hcg) / wb, (g * lf + accel * hcg) / wb
+    d_phi, beta, worst = v / wb * np.tan(delta), np.arctan(lr / lf * np.tan(delta)), 0.0
+    for _ in range(iv // dt_ms):
+        worst = max(worst, abs(phi + beta))
+        vs = v if abs(v) > 1e-6 else (1e-6 if v >= 0 else -1e-6)
+        if abs(v) >= 0.1:
+            dd_phi = mu * mass / Iz * (lf * cf * ff * delta + (lr * cr * fr - lf * cf * ff) * beta - (lf * lf * cf * ff + lr * lr * cr * fr) * d_phi / vs)
+            d_beta = mu / vs * (cf * ff * delta - (cr * fr + cf * ff) * beta + (lr * cr * fr - lf * cf * ff) * d_phi / vs) - d_phi
+            d_phi += dd_phi * dt
+        else:
+            d_beta = lr / (1 + np.tan(delta) * lr / wb) ** 2 / wb / np.cos(delta) ** 2 * delta
+            d_phi += v * np.cos(beta) / wb * np.tan(delta) * dt
+        v = float(np.clip(v + accel * dt, row[L.P_SPEED_LO], row[L.P_SPEED_HI]))
+        phi += d_phi * dt
+        beta += d_beta * dt
+    return worst
+
+
 def dyn_tolerance(sens, tol=1e-5):
     """per-case tolerance (np.inf where the reference is chaotic) and the mask of the strictly asserted cases"""
     sens = np.asarray(sens, np.float64)

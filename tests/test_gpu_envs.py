@@ -338,3 +338,33 @@ def test_nan_actions_are_invalid_actions_and_step_nothing():
     obs, reward, term, trunc, info = one.step(np.float32([0.1, 0.5]))
     assert np.isfinite(obs).all() and info["state"]["frame"] == 100
     one.close()
+
+
+def test_scenario_manager_step_host_equals_step_plus_downloads():
+    """BatchedScenarioManager.step_host on a multi-agent pool (mixed scene, ego = agent 0): the frame of ONE call against
+    set_actions + step + one download per field."""
+    from tactics2d_amd import layout as L, scenarios as S
+    from tactics2d_amd.traffic import BatchedScenarioManager
+    sc = S.mixed(48, 64, seed=9)
+    rng = np.random.default_rng(3)
+
+    def make():
+        m = BatchedScenarioManager(sc.n_env, sc.A, max_step=20, step_size=sc.interval_ms)
+        sc.load(m.pool)
+        m.pool.set_status_config(**{**sc.status, "max_step": 20})
+        m.pool.set_auto_reset(True)
+        return m
+
+    a, b = make(), make()
+    for t in range(25):
+        a0, a1 = sc.sample_actions(rng)
+        fr = a.step_host(np.stack([a1, a0], 1))          # (steering, accel) per participant
+        b.step(a0, a1)
+        obs = b.get_observation()
+        assert np.array_equal(fr.obs[:, :4], obs[:, :4]), t
+        st = b.pool.download(L.F_STATUS)
+        assert np.array_equal(fr.status, st) and np.array_equal(fr.reward, b.pool.download(L.F_REWARD))
+        assert np.array_equal(fr.cnt_step, b.pool.download(L.F_CNT_STEP)) and np.array_equal(fr.frame_ms, b.pool.download(L.F_FRAME_MS))
+        assert np.array_equal(a.flags(), b.flags())
+    assert (st[:, 2] | st[:, 3]).any() or t > 20
+    a.close(); b.close()

@@ -85,14 +85,19 @@ def test_dynamics_within_1e5_of_reference_wherever_it_is_conditioned(variant):
     assert (err[strict] <= TOL).all(), err[strict].max()
     assert (err[~chaotic] <= tol[~chaotic]).all(), (err / tol)[~chaotic].max()
     # the chaotic cases (one fp64 ulp of an input moves the reference's own result by >= 1 mm) are BOUNDED too, by the same
-    # K x sens: heading and speed of every one of them, and the position of all but the one case whose slip angle the
-    # reference itself drives to 9.5e17 rad inside the step (dyn_random case 4461, by replaying its recurrence) -- the
-    # deterministic sincos is specified for |x| < 1e9 rad, the position built from it is garbage there, in kernel and
-    # oracle alike (bit-equal: test_exact_variant_is_bit_identical_to_oracle), where numpy's stays bounded
+    # K x sens: heading and speed of every one of them, and the position of every one whose trig arguments stay inside the
+    # domain the deterministic sincos is specified for (|x| < 1e9 rad).  In a handful the reference drives its own slip angle
+    # to 1e14 .. 1e18 rad inside the step (helpers.dyn_max_trig_argument replays its recurrence): there cos / sin of kernel
+    # and oracle (bit-equal to each other: test_exact_variant_is_bit_identical_to_oracle) are not those of numpy, and the
+    # position built from them is reported, not bounded
     cb = H.dyn_chaotic_bound(d["sens"], TOL)
     assert (err4[chaotic, 2:] <= cb[chaotic, None]).all(), (err4[chaotic, 2:] / cb[chaotic, None]).max()
-    beyond = chaotic & (err4[:, :2].max(1) > cb)
-    assert beyond.sum() <= 1 and set(np.nonzero(beyond)[0]) <= {4461}, np.nonzero(beyond)[0]
+    beyond = np.nonzero(chaotic & (err4[:, :2].max(1) > cb))[0]
+    for k in beyond:
+        assert H.dyn_max_trig_argument(d, int(k)) > 1e9, (int(k), err4[k], cb[k])
+    assert len(beyond) <= 4, beyond
+    print(f"   chaotic cases: all {int(chaotic.sum())} headings / speeds within 1e-5 + {H.SENS_SCALE:g} x sens; positions beyond it "
+          f"(trig argument > 1e9 rad in the reference itself): {beyond.tolist()}")
 
 
 def test_known_answers():
