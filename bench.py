@@ -423,6 +423,45 @@ def next_rows(dev, clock_warm, metric_scene):
     env.close()
     out["parking_env_single_step_us"] = us
     out["parking_env_single_steps_per_s"] = 1e6 / us
+    # the PCIe-inclusive rate of the METRIC scene: actions of all 262 144 participants from host memory (2 MB per step), the
+    # ego records back, through BatchedScenarioManager.step_host (copy commands: the pool is far too large for mapped memory)
+    from tactics2d_amd.traffic import BatchedScenarioManager
+    m = BatchedScenarioManager(metric_scene.n_env, metric_scene.A, max_step=metric_scene.status.get("max_step", 2000),
+                               step_size=metric_scene.interval_ms)
+    metric_scene.load(m.pool)
+    m.pool.set_auto_reset(True)
+    rng = np.random.default_rng(1)
+    hacts = []
+    for _ in range(4):
+        a0, a1 = metric_scene.sample_actions(rng)
+        hacts.append(np.ascontiguousarray(np.stack([a1, a0], 1), np.float32))
+    clock_warm()
+    for k in range(20):
+        m.step_host(hacts[k & 3], fresh=False)
+    t = time.perf_counter()
+    for k in range(200):
+        m.step_host(hacts[k & 3], fresh=False)
+    us = 1e6 * (time.perf_counter() - t) / 200
+    # ... and with the actions written straight into the pool's pinned staging buffer (what a policy running on the host
+    # would do): no staging copy
+    buf = m.pool.host_action_buffer()
+    for k in range(20):
+        buf[:] = hacts[k & 3]
+        m.step_host(buf, fresh=False)
+    t_fill = t_all = 0.0
+    for k in range(200):
+        t0 = time.perf_counter()
+        buf[:] = hacts[k & 3]           # (stands for the policy writing its output: not part of the step)
+        t1 = time.perf_counter()
+        m.step_host(buf, fresh=False)
+        t_all += time.perf_counter() - t1
+    out["metric_step_host_us_actions_in_pinned_buffer"] = 1e6 * t_all / 200
+    m.close()
+    out["metric_step_host_us"] = us
+    out["metric_step_host_value"] = metric_scene.n / (us * 1e-6)
+    out["metric_step_host_note"] = (f"the metric scene ({metric_scene.n_env} x {metric_scene.A}) stepped from HOST actions: 2 MB of actions up "
+                                    "per step (pinned staging + one async copy), one t2d_step launch, the egos' packed frame down, one "
+                                    "synchronisation per step -- the PCIe-inclusive rate of the path (never `value`)")
     out["host_path_note"] = ("VecParkingEnv.step at 4096 envs, host to host: numpy actions in (Box.contains checked while they are staged), "
                              "(obs, reward, terminated, truncated, infos) out as views of a pinned frame nobody holds any more -- one "
                              "library call, no per-field copies; '_with_lidar_in_info' adds the 360-beam scan to the frame (5.9 MB per "

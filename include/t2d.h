@@ -408,6 +408,9 @@ int t2d_sync(t2d_pool* pool);
  *                      action_box = {steering lo, steering hi, accel lo, accel hi} or NULL: `action_space.contains(action)`
  *                      of envs/parking.py:235-236 for every row, checked while the actions are staged (closed bounds, a NaN
  *                      is outside) -- T2D_ERR_ACTION, nothing stepped, the message names the first offending row.
+ *   t2d_host_action_buffer  the pool's own pinned staging buffer, f32 [n_env * max_agents][2] (valid until the next
+ *                      t2d_frame_config): a caller that writes its actions THERE and passes that pointer to t2d_step_host saves the
+ *                      staging copy (2 MB per step at 4096 x 64: ~ 70 us of host memcpy); the box check still reads every row.
  *   t2d_frame_fetch    the frame of the CURRENT state without stepping (what reset() returns; the lidar section is scanned
  *                      from the current poses).
  * Frame sections (E = n_env; every offset a multiple of 256 B):
@@ -435,6 +438,7 @@ int t2d_set_target_headings(t2d_pool* pool, const double* heading_host);
 int t2d_step_host(t2d_pool* pool, const float* actions_host, const float* action_box, int32_t interval_ms, void* hip_stream,
                   int32_t frame_index, const void** frame_host);
 int t2d_frame_fetch(t2d_pool* pool, void* hip_stream, int32_t frame_index, const void** frame_host);
+int t2d_host_action_buffer(t2d_pool* pool, float** actions_host);
 
 /* Episode-start snapshot for device-side (auto-)reset -- the vector-env counterpart of
  * ParkingEnv.reset (envs/parking.py:262-298) without a host round trip.

@@ -79,6 +79,7 @@ SYMBOLS = {
     "t2d_set_target_headings": (C.c_int, [_vp, _vp]),
     "t2d_step_host": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, C.c_int32, C.POINTER(_vp)]),
     "t2d_frame_fetch": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(_vp)]),
+    "t2d_host_action_buffer": (C.c_int, [_vp, C.POINTER(_vp)]),
     "t2d_snapshot": (C.c_int, [_vp]),
     "t2d_restore": (C.c_int, [_vp, C.c_int32, _vp]),
     "t2d_set_auto_reset": (C.c_int, [_vp, C.c_int32]),

@@ -2261,15 +2261,23 @@ int t2d_step_host(t2d_pool* p, const float* actions_host, const float* action_bo
     hipStream_t s = (hipStream_t)hip_stream;
     if (actions_host) {
         const size_t act_bytes = (size_t)p->v.N * 2 * sizeof(float);
+        const bool in_place = actions_host == p->h_actions;   // the caller filled the pool's own pinned buffer (t2d_host_action_buffer)
         if (action_box) {   // Box.contains for every row, in the pass that stages the actions
             const float lo0 = action_box[0], hi0 = action_box[1], lo1 = action_box[2], hi1 = action_box[3];
             float* dst = p->h_actions;
             int ok = 1;
-            for (size_t i = 0, n = (size_t)p->v.N; i < n; ++i) {
-                const float a = actions_host[2 * i], b = actions_host[2 * i + 1];
-                ok &= (int)(a >= lo0) & (int)(a <= hi0) & (int)(b >= lo1) & (int)(b <= hi1);
-                dst[2 * i] = a;
-                dst[2 * i + 1] = b;
+            if (in_place) {
+                for (size_t i = 0, n = (size_t)p->v.N; i < n; ++i) {
+                    const float a = actions_host[2 * i], b = actions_host[2 * i + 1];
+                    ok &= (int)(a >= lo0) & (int)(a <= hi0) & (int)(b >= lo1) & (int)(b <= hi1);
+                }
+            } else {
+                for (size_t i = 0, n = (size_t)p->v.N; i < n; ++i) {
+                    const float a = actions_host[2 * i], b = actions_host[2 * i + 1];
+                    ok &= (int)(a >= lo0) & (int)(a <= hi0) & (int)(b >= lo1) & (int)(b <= hi1);
+                    dst[2 * i] = a;
+                    dst[2 * i + 1] = b;
+                }
             }
             if (!ok) {
                 size_t bad = 0;
@@ -2279,7 +2287,7 @@ int t2d_step_host(t2d_pool* p, const float* actions_host, const float* action_bo
                 }
                 return fail(p, T2D_ERR_ACTION, "action row " + std::to_string(bad) + " is not in the action space");
             }
-        } else {
+        } else if (!in_place) {
             memcpy(p->h_actions, actions_host, act_bytes);
         }
         const float* dev_act = p->d_actions;
@@ -2298,6 +2306,13 @@ int t2d_step_host(t2d_pool* p, const float* actions_host, const float* action_bo
     int rc = t2d_step(p, interval_ms, hip_stream);
     if (rc != T2D_OK) return rc;
     return frame_finish(p, s, frame_index, frame_host);
+}
+
+int t2d_host_action_buffer(t2d_pool* p, float** actions_host) {
+    if (!p || !actions_host) return T2D_ERR_INVALID;
+    if (!p->frame_sections) return fail(p, T2D_ERR_STATE, "t2d_frame_config must precede t2d_host_action_buffer");
+    *actions_host = p->h_actions;
+    return T2D_OK;
 }
 
 int t2d_frame_fetch(t2d_pool* p, void* hip_stream, int32_t frame_index, const void** frame_host) {

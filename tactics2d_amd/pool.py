@@ -245,6 +245,14 @@ class ParticipantPool:
         self._frame_turn = 0
         return lay
 
+    def host_action_buffer(self):
+        """float32 [n, 2] numpy view of the pool's own pinned action staging buffer (t2d_host_action_buffer): actions written
+        there and passed to step_host as this very array are not copied again (valid until the next frame_config)."""
+        ptr = C.c_void_p()
+        self._ck(self._lib.t2d_host_action_buffer(self._h, C.byref(ptr)))
+        buf = (C.c_float * (2 * self.n)).from_address(ptr.value)
+        return np.frombuffer(buf, np.float32).reshape(self.n, 2)
+
     def set_target_headings(self, heading):
         h = _arr(heading, np.float64, self.n_env, "target_heading")
         self._ck(self._lib.t2d_set_target_headings(self._h, _p(h)))

@@ -358,7 +358,12 @@ def test_scenario_manager_step_host_equals_step_plus_downloads():
     a, b = make(), make()
     for t in range(25):
         a0, a1 = sc.sample_actions(rng)
-        fr = a.step_host(np.stack([a1, a0], 1))          # (steering, accel) per participant
+        acts = np.stack([a1, a0], 1)                     # (steering, accel) per participant
+        if t >= 5 and t % 2:                             # ... written straight into the pool's pinned staging buffer: no copy
+            buf = a.pool.host_action_buffer()
+            buf[:] = acts
+            acts = buf
+        fr = a.step_host(acts)
         b.step(a0, a1)
         obs = b.get_observation()
         assert np.array_equal(fr.obs[:, :4], obs[:, :4]), t
