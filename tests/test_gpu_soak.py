@@ -96,3 +96,33 @@ def test_single_ego_integrator_waves_over_thousands_of_steps():
     assert got["form"] == "ego_loop_pipe" and got["sha"] == ref["sha"], "the single-ego PIPE form differs from separate launches"
     chk = _run("libt2d_hip_waitcnt.so", steps, "chain", n_env, "parking")
     assert chk["sha"] == ref["sha"], "the conservative build's single-ego PIPE form differs"
+
+
+def test_host_frames_through_mapped_memory_over_thousands_of_steps():
+    """The Gym-API host path's mapped-memory mode (T2D_FRAME_ZEROCOPY: the step kernel reads the actions from, the pack and
+    lidar kernels write the frame to, pinned host memory -- no copy commands) relies on one thing: what a kernel wrote to
+    mapped host memory is visible to the host once the stream has been synchronised.  3000 steps of 512 regenerating parking
+    envs (episodes end and restart all the time), frame by frame against a second env driven through copy commands: every
+    section of every frame bit-identical, lidar included."""
+    import numpy as np
+    from tactics2d_amd.envs import VecParkingEnv
+    n = 512
+    a = VecParkingEnv(n, max_step=40, seed=11, auto_reset=True, scene_source="generator", zero_copy=True, copy=False)
+    b = VecParkingEnv(n, max_step=40, seed=11, auto_reset=True, scene_source="generator", zero_copy=False, copy=False)
+    oa, ia = a.reset(); ob, ib = b.reset()
+    assert np.array_equal(oa, ob)
+    rng = np.random.default_rng(0)
+    acts = [a.action_space.sample(rng, n) for _ in range(16)]
+    ended = 0
+    for t in range(3000):
+        x = acts[t & 15]
+        if t % 97 == 0:
+            x = np.zeros_like(x)
+        ra, rb = a.step(x), b.step(x)
+        for u, v in zip(ra[:4], rb[:4]):
+            assert np.array_equal(np.ascontiguousarray(u).view(np.uint8), np.ascontiguousarray(v).view(np.uint8)), t
+        for k in ("iou", "lidar", "episode", "target_area", "target_heading", "diff_position", "diff_angle", "diff_heading"):
+            assert np.array_equal(np.ascontiguousarray(ra[4][k]).view(np.uint8), np.ascontiguousarray(rb[4][k]).view(np.uint8)), (t, k)
+        ended += int((ra[2] | ra[3]).sum())
+    assert ended > 20 * n   # every env went through dozens of episodes
+    a.close(); b.close()
