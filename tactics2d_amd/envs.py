@@ -11,12 +11,16 @@ accelerated path: the observation returned here is the ego
 
 gymnasium is not a dependency: `Box` below is the minimal stand-in for `spaces.Box`.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import layout as L, scenarios
 from ._ffi import ERR_ACTION, T2DError
 from .traffic import BatchedScenarioManager, ScenarioStatus, TrafficStatus
 
+_SCENARIO = {int(v): v for v in ScenarioStatus}
+_TRAFFIC = {int(v): v for v in TrafficStatus}
 MAX_STEER = 0.524  # envs/parking.py:30
 MAX_ACCEL = 2.0    # envs/parking.py:31
 
@@ -247,11 +251,20 @@ class ParkingEnv:
         infos = _first(infos)
         infos["scenario_status"] = ScenarioStatus(int(infos["scenario_status"]))
         infos["traffic_status"] = TrafficStatus(int(infos["traffic_status"]))
+        # the step's fast path: everything a step needs of the library and of frame 0, looked up once (one env: the results
+        # are copied out of the frame anyway, so every step fills the same pinned frame)
+        pool = self.scenario_manager.pool
+        fr = pool._frames[0]                  # (built by the reset's frame_fetch: the first frame handed out)
+        self._vec._last = fr
+        self._fast = (pool._lib.t2d_step_host, pool._h, self._abuf.ctypes.data,
+                      None if self._vec._action_box is None else self._vec._action_box.ctypes.data, C.byref(pool._frame_ptr), pool,
+                      fr, fr.obs[0], fr.status[0], fr.rel[0], None if fr.lidar is None else fr.lidar[0])
         return obs[0], infos
 
     def step(self, action):
         """envs/parking.py:219-256: (observation, reward, terminated, truncated, infos) as host values -- one library call
-        (t2d_step_host on a zero-copy frame: the kernels read the action from and write the results to mapped host memory)."""
+        (t2d_step_host on a zero-copy frame: the kernels read the action from and write the results to mapped host memory).
+        `infos["state"]` holds Python floats (the stored fp32 values, exactly), the statuses are the reference's enums."""
         v = self._vec
         if v._scene is None:
             raise RuntimeError("call reset() first")
@@ -266,23 +279,24 @@ class ParkingEnv:
                 a[0] = v._discrete_actions[int(action)]
             except (KeyError, ValueError, TypeError):
                 raise InvalidAction(f"Action {action} is not in the action space.") from None
-        try:   # (`action_space.contains`: checked by the library while it stages the action -- a NaN is outside, like Box.contains)
-            fr = v.scenario_manager.pool.step_host(a, 100, action_box=v._action_box)
-        except T2DError as exc:
-            if exc.code == ERR_ACTION:
-                raise InvalidAction(f"Action {action} is not in the action space.") from None
-            raise
+        step_host, h, a_ptr, box_ptr, frame_ref, pool, fr, obs_row, st_row, rel_row, lidar_row = self._fast
+        # (`action_space.contains`: checked by the library while it stages the action -- a NaN is outside, like Box.contains)
+        rc = step_host(h, a_ptr, box_ptr, 100, None, 0, frame_ref)
+        if rc:
+            if rc == ERR_ACTION:
+                raise InvalidAction(f"Action {action} is not in the action space.")
+            pool._ck(rc)
         v.scenario_manager._flags_cache = None
-        o = fr.obs[0].copy()
-        st = fr.status[0]
-        rel = fr.rel[0]
-        ta, th = (fr.target[0].copy(), fr.target_heading[0]) if v._moving_targets else (v._target_area[0], v._target_heading[0])
-        infos = dict(state=dict(x=o[0], y=o[1], heading=o[2], speed=o[3], vx=o[4], vy=o[5], frame=fr.frame_ms[0]),
-                     scenario_status=ScenarioStatus(int(st[0])), traffic_status=TrafficStatus(int(st[1])),
-                     target_area=ta, target_heading=th,
-                     diff_position=rel[0], diff_angle=rel[1], diff_heading=rel[2],
-                     iou=fr.iou[0], lidar=None if fr.lidar is None else fr.lidar[0].copy(), episode=fr.episode[0])
-        return o, float(fr.reward[0]), bool(st[2]), bool(st[3]), infos
+        o = obs_row.copy()
+        x, y, heading, speed, vx, vy = o.tolist()
+        s0, s1, s2, s3 = st_row.tolist()
+        d0, d1, d2 = rel_row.tolist()
+        ta, th = (fr.target[0].copy(), float(fr.target_heading[0])) if v._moving_targets else (v._target_area[0], v._target_heading[0])
+        infos = {"state": {"x": x, "y": y, "heading": heading, "speed": speed, "vx": vx, "vy": vy, "frame": int(fr.frame_ms[0])},
+                 "scenario_status": _SCENARIO[s0], "traffic_status": _TRAFFIC[s1], "target_area": ta, "target_heading": th,
+                 "diff_position": d0, "diff_angle": d1, "diff_heading": d2, "iou": float(fr.iou[0]),
+                 "lidar": None if lidar_row is None else lidar_row.copy(), "episode": int(fr.episode[0])}
+        return o, float(fr.reward[0]), s2 != 0, s3 != 0, infos
 
     def close(self):
         self._vec.close()
