@@ -24,7 +24,9 @@ import numpy as np
 
 # ---------------------------------------------------------------------------------------------------------------- predicates
 def _f32(xy):
-    """the coordinates as the pool stores them: fp32, kept as fp64 values (products of their differences are then exact)"""
+    """the coordinates as the pool stores them: fp32, kept as fp64 values (their differences are then exact and an orientation
+    is two products and one subtraction, each rounded once: the same evaluation -- and the same sign, down to areas of ~1e-13 m^2
+    -- as the convexity check of t2d_set_*_geometry, which is what decides whether a piece is accepted)"""
     a = np.asarray(xy, np.float64).reshape(-1, 2)
     return a.astype(np.float32).astype(np.float64)
 
