@@ -211,6 +211,7 @@ def test_random_lanes_tile_exactly_and_agree_with_the_undivided_ring(oracle):
         pts = {tuple(p) for p in ring}
         assert all(_convex_ccw(q) and 3 <= len(q) <= 4 and all(tuple(v) in pts for v in q) for q in pieces), case
         assert abs(sum(_area2(q) for q in pieces) - abs(_area2(ring))) < 1e-5 * abs(_area2(ring)), case
+        assert MG.geometry_budget(1, 8, lanes=[pieces])["dwords_needed"] > 0      # the library's own checks accept every piece
         for _ in range(6):
             i = int(rng.integers(0, len(left)))
             c = 0.5 * (left[i] + right[min(i * len(right) // len(left), len(right) - 1)]) + rng.normal(0, width * 0.4, 2)
