@@ -231,3 +231,39 @@ def test_cfg2_full_size_with_the_iou_events_on(oracle):
         seen |= set(map(tuple, gst[:, :2].tolist()))
     pool.close()
     assert {(1, 1), (2, 1), (1, 5), (3, 1)} <= seen, seen     # normal, completed, no-action quirk, time exceeded
+
+
+def test_fast_fused_step_at_metric_size_against_the_exact_one():
+    """The default (fast) integrator inside the FUSED step at the metric size -- where the resummed kinematic step is on
+    (>= two waves per SIMD) -- one step from the same state as the exact variant (== the oracle, test above): kinematic and
+    point-mass participants within half an fp32 ulp + 1e-8 of it in x, y (the series' truncation bound is 2e-10 m), 1e-6 in
+    heading and speed; dynamics participants within the 1e-5 contract wherever they are well conditioned (|v| >= 1 m/s);
+    and the event flags of all but a handful (an ulp of a pose can flip a touching predicate) identical."""
+    from tactics2d_amd import layout as L
+    sc = _scene("metric")
+    rng = np.random.default_rng(23)
+    acts = [sc.sample_actions(rng)]
+    ex = _run(sc, acts, "exact")
+    fa = _run(sc, acts, "fast")
+    it = _run(sc, acts, "fast_iterated")
+    model = sc.rows[sc.type_id, L.P_MODEL].astype(int)
+    act = sc.active.astype(bool)
+    kin = act & (model != L.MODEL_DYNAMICS)
+    dyn = act & (model == L.MODEL_DYNAMICS) & (np.abs(sc.speed) >= 1.0)
+    assert kin.sum() > 100000 and dyn.sum() > 50000
+    for name, got in (("fast", fa), ("fast_iterated", it)):
+        for c in (0, 1):
+            d = np.abs(got["state"][c].astype(np.float64) - ex["state"][c])
+            ulp = np.spacing(np.abs(ex["state"][c]))
+            assert (d[kin] <= 0.5 * ulp[kin] + 1e-8).all(), (name, c, d[kin].max())
+            assert (d[dyn] <= 1e-5).all(), (name, c, d[dyn].max())
+        for c in (2, 3):
+            d = np.abs(got["state"][c].astype(np.float64) - ex["state"][c])
+            if c == 2:
+                d = np.minimum(d, 2 * np.pi - d)
+            assert (d[kin] <= 1e-6).all() and (d[dyn] <= 1e-5).all(), (name, c, d[kin].max(), d[dyn].max())
+        assert (got["flags"] != ex["flags"]).sum() <= 20, (name, int((got["flags"] != ex["flags"]).sum()))
+    # the resummed and the iterated fast step differ by the series' truncation only: almost every fp32 store identical
+    same = np.mean([(fa["state"][c][kin] == it["state"][c][kin]).mean() for c in (0, 1)])
+    print(f"fast (resummed) vs fast_iterated: {100 * same:.3f} % of the kinematic x / y stores identical")
+    assert same > 0.995
