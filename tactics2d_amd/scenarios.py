@@ -11,6 +11,8 @@ Every builder returns a Scene; `Scene.load(pool)` pushes it through the C ABI.
 """
 from dataclasses import dataclass, field
 
+import os
+
 import numpy as np
 
 from . import layout as L
@@ -215,11 +217,14 @@ def _intersection_env(rng, A, rows_by_name, ped_frac=0.0):
 def _roundabout_env(rng, A, rows_by_name):
     names = list(VEHICLE_TEMPLATE)
     cyc = list(CYCLIST_TEMPLATE)
-    r_in, r_out, nseg = 12.0, 20.0, 12
+    # ("16-gon annulus r in [12, 20] m with 4 arms".  Rounds 1-4 built it from 12 trapezoids to keep an env at 16 lane
+    # polygons; with 16 + 4 = 20 the packed record still leaves four workgroups per CU -- 38.5 KB of LDS -- and the chained
+    # step is no slower (16.8 against 17.0 us on one box: smaller trapezoids, fewer candidates), so the scene is the survey's)
+    r_in, r_out, nseg = 12.0, 20.0, int(os.environ.get("T2D_ROUNDABOUT_SEGS", "16"))
     n_ring = max(1, A // 4)
     arm_len = 26.0 + ((A - n_ring + 3) // 4) * 7.5 + 6.0
     lanes = []
-    for k in range(nseg):                                          # annulus as 12 convex trapezoids
+    for k in range(nseg):                                          # annulus as 16 convex trapezoids
         # the last trapezoid closes on the first one's vertices exactly (sin(2 pi) is not 0 in floating point, and a
         # 3e-15 m sliver between two lanes is a real gap of the union for `contains`)
         a0, a1 = TWO_PI * k / nseg, TWO_PI * ((k + 1) % nseg) / nseg
