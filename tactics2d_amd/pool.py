@@ -63,15 +63,20 @@ class HostFrame:
         # everything a caller can get hold of is one of these objects or a view whose .base is one of them (numpy collapses
         # the base chain of a view to the array that exposes the memory): their reference counts tell whether the frame is held
         self._tracked = [self.base] + [v for v in self.__dict__.values() if isinstance(v, np.ndarray) and v is not self.base]
-        # idle: a view is held by its attribute, the list above, _refs' loop variable and getrefcount's own argument; the
-        # frame's memory by the same four and by every view (as its .base)  (tests/test_host.py holds this against CPython)
-        self._idle_refs = [len(self._tracked) + 3] + [4] * (len(self._tracked) - 1)
+        self._idle_refs = None   # set by calibrate(); until then the frame counts as in use (the safe answer)
+
+    def calibrate(self):
+        """Record the reference counts of the frame's arrays in the IDLE state -- call once, right after construction, when
+        nothing outside this object holds a view yet (ParticipantPool._frame does).  Measured, not derived: whatever
+        temporaries the interpreter keeps while counting are the same then and later."""
+        self._idle_refs = self._refs()
+        return self
 
     def _refs(self):
         return [sys.getrefcount(v) for v in self._tracked]
 
     def in_use(self):
-        return self._refs() != self._idle_refs
+        return self._idle_refs is None or self._refs() != self._idle_refs
 
     def copy(self, lidar=True):
         """A frame that owns its memory (one memcpy); lidar=False leaves the lidar section out (its views become None)."""
@@ -277,7 +282,10 @@ class ParticipantPool:
         fr = self._frames[k]
         if fr is None:   # (the views of a pinned frame are built once)
             buf = (C.c_uint8 * self.frame_layout.bytes).from_address(self._frame_ptr.value)
-            fr = self._frames[k] = HostFrame(np.frombuffer(buf, np.uint8), self.frame_layout)
+            arr = np.frombuffer(buf, np.uint8)
+            fr = HostFrame(arr, self.frame_layout)
+            del arr, buf
+            self._frames[k] = fr.calibrate()
         return fr
 
     def step_host(self, actions, interval_ms=100, stream=None, action_box=None, fresh=False):

@@ -241,7 +241,9 @@ def test_host_frame_views_and_in_use_tracking():
     lay.bytes, lay.n_env, lay.n_beams = off, n, beams
     base = np.zeros(off, np.uint8)
     fr = HostFrame(base, lay)
+    assert fr.in_use()                 # not calibrated yet: the safe answer
     del base
+    fr.calibrate()
     assert fr.obs.shape == (n, 6) and fr.rel.shape == (n, 3) and fr.target.shape == (n, 4, 2) and fr.lidar.shape == (n, beams)
     assert fr.status.shape == (n, 4) and fr.terminated.dtype == np.bool_ and fr.reward.shape == (n,)
     fr.status[2, 2] = 1
