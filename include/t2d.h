@@ -392,7 +392,9 @@ int t2d_sync(t2d_pool* pool);
  * memory with one asynchronous copy and one stream synchronisation -- instead of one blocking copy per field.
  *   t2d_frame_config   chooses the sections (T2D_FRAME_*), allocates the device frame and n_host_frames (1..T2D_MAX_HOST_FRAMES)
  *                      pinned host frames, and fills
- *                      *layout with the byte offsets of the sections inside a frame (-1 = section absent).  Call it again after
+ *                      *layout with the byte offsets of the sections inside a frame (-1 = section absent).  Asking for the
+ *                      configuration already in place keeps the frames (and what a caller still holds of them); a DIFFERENT one
+ *                      frees them: views of earlier frames are invalid from then on, as after t2d_destroy.  Call it again after
  *                      t2d_lidar_config changed the beam count.  T2D_FRAME_ZEROCOPY: no copy commands at all -- the step kernel
  *                      reads the actions from mapped host memory and the pack / lidar kernels write the mapped host frame
  *                      (lowest latency for small pools; a large pool's 8 B per participant would cross PCIe inside the step).

@@ -2176,6 +2176,12 @@ int t2d_frame_config(t2d_pool* p, uint32_t sections, int32_t n_host_frames, t2d_
         L.off_lidar = section(E * (size_t)L.n_beams * sizeof(float));
     }
     L.bytes = (int64_t)total;
+    // the same configuration again (every VecParkingEnv.reset asks): keep the frames -- a caller may still hold views of them
+    if ((p->frame_sections & 0x7fffffffu) == sections && (p->frame_sections & 0x80000000u) && p->n_host_frames == n_host_frames &&
+        memcmp(&p->frame_layout, &L, sizeof L) == 0) {
+        if (layout) *layout = L;
+        return T2D_OK;
+    }
     frame_release(p);
     const unsigned host_flags = hipHostMallocMapped | hipHostMallocCoherent;
     for (int k = 0; k < n_host_frames; ++k) {

@@ -251,6 +251,9 @@ class ParkingEnv:
         infos = _first(infos)
         infos["scenario_status"] = ScenarioStatus(int(infos["scenario_status"]))
         infos["traffic_status"] = TrafficStatus(int(infos["traffic_status"]))
+        # (what reset hands out must not alias the pinned frame the steps fill: copies, like the step's own results)
+        obs = obs.copy()
+        infos = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in infos.items()}
         # the step's fast path: everything a step needs of the library and of frame 0, looked up once (one env: the results
         # are copied out of the frame anyway, so every step fills the same pinned frame)
         pool = self.scenario_manager.pool

@@ -243,6 +243,12 @@ class ParticipantPool:
         lay = _ffi.FrameLayout()
         mask = (L.FRAME_LIDAR if lidar else 0) | (L.FRAME_TARGET if target else 0) | (L.FRAME_ZEROCOPY if zero_copy else 0)
         self._ck(self._lib.t2d_frame_config(self._h, mask, int(n_frames), C.byref(lay)))
+        key = (mask, int(n_frames), bytes(lay))
+        if getattr(self, "_frame_key", None) == key:
+            # the configuration already in place (every env reset asks): the library kept the pinned frames, and so do we --
+            # HostFrame objects, their views and what callers still hold of them stay valid and tracked
+            return self.frame_layout
+        self._frame_key = key
         self.frame_layout = lay
         self.n_frames = int(n_frames)
         self._frames = [None] * self.n_frames

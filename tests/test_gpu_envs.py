@@ -373,3 +373,26 @@ def test_scenario_manager_step_host_equals_step_plus_downloads():
         assert np.array_equal(a.flags(), b.flags())
     assert (st[:, 2] | st[:, 3]).any() or t > 20
     a.close(); b.close()
+
+
+def test_single_env_results_survive_later_steps_and_resets():
+    """What ParkingEnv.reset / step hand out never aliases the pinned frame later calls fill: a reset's observation and lidar
+    are intact after the next steps, a step's after the following ones and after a reset (which keeps the frames: the same
+    frame configuration is asked for again)."""
+    from tactics2d_amd.envs import ParkingEnv
+    env = ParkingEnv(seed=4, max_step=30)
+    obs0, info0 = env.reset()
+    keep0 = (obs0.copy(), info0["lidar"].copy())
+    rng = np.random.default_rng(0)
+    kept = []
+    for t in range(8):
+        o, r, te, tr, info = env.step(env.action_space.sample(rng))
+        kept.append((o, o.copy(), info["lidar"], info["lidar"].copy()))
+    assert np.array_equal(obs0, keep0[0]) and np.array_equal(info0["lidar"], keep0[1])
+    obs1, info1 = env.reset()
+    for _ in range(3):
+        env.step(env.action_space.sample(rng))
+    for o, oc, l, lc in kept:
+        assert np.array_equal(o, oc) and np.array_equal(l, lc)
+    assert np.array_equal(obs1, obs0)          # the same scene, the same start
+    env.close()
