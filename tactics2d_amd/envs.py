@@ -227,6 +227,8 @@ class VecParkingEnv:
         raise NotImplementedError("rendering is outside the accelerated path")
 
     def close(self):
+        """Frees the pool -- and with it the pinned frames: arrays handed out by reset() / step() are views of that memory
+        (DESIGN.md 5a), so copy what has to outlive the env before closing it."""
         self.scenario_manager.close()
 
 
