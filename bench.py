@@ -279,7 +279,7 @@ def closed_loop(scene, dev, variant, steps, warmup, clock_warm, outputs):
     overlap: what gives a closed-loop caller part of the overlap t2d_step_n gives an open-loop one.  Same results whatever G
     (tests/test_gpu_closed_loop.py)."""
     import torch
-    from tactics2d_amd.pipeline import ClosedLoop, EnvGroups
+    from tactics2d_amd.debug import ClosedLoop, env_groups   # (the stand-in policy + its runner: libt2d_hip_debug.so, include/t2d_debug.h)
     N = scene.n
     rows = []
     long_steps = max(steps, 400)
@@ -296,7 +296,7 @@ def closed_loop(scene, dev, variant, steps, warmup, clock_warm, outputs):
     for G, launcher in ((1, "thread"), (2, "threads"), (4, "threads")):
         if scene.n_env % G:
             continue
-        eg = EnvGroups(scene, G, dev.index)
+        eg = env_groups(scene, G, dev.index)
         eg.configure(lambda p: (p.set_integrator_variant(variant), p.set_auto_reset(True),
                                 p.set_outputs(velocity=outputs == "all", applied=outputs == "all")))
         try:

@@ -72,7 +72,7 @@
 extern "C" {
 #endif
 
-#define T2D_ABI_VERSION 10
+#define T2D_ABI_VERSION 11
 
 /* ---- status codes --------------------------------------------------------------- */
 #define T2D_OK            0
@@ -306,7 +306,11 @@ int t2d_set_fused_step(t2d_pool* pool, int32_t on);
 /* Pools with ONE participant per env (ParkingEnv, BASELINE config 2) whose parameter table holds box-shaped types only
  * and that have no lane geometry take their fused step with one WAVE per env instead of one lane per participant (the
  * quads of the lot, the constraints of the two IoUs spread over the wave's lanes: ~2.5x faster at 4096 envs).  Same
- * arithmetic, same results bit for bit; on by default, t2d_set_ego_kernel(pool, 0) keeps the pool on the general kernel. */
+ * arithmetic, same results bit for bit -- with ONE exception: the single-ego kernel always ITERATES a kinematic step, so on
+ * pools large enough for the general kernel to resum it (integrator variant 1 at >= 131072 participants on an MI355X, or
+ * variant 3: t2d_set_integrator_variant) the two agree to the series' truncation (< 1e-9 m; the last bit of the fp32 state may
+ * differ), and bit for bit again under variants 0 and 2.  On by default, t2d_set_ego_kernel(pool, 0) keeps the pool on the
+ * general kernel. */
 int t2d_set_ego_kernel(t2d_pool* pool, int32_t on);
 /* One step of n pools in a single call -- env groups on separate streams (independent environments cut into
  * groups whose launches overlap: one group's start-up latency and tail hide behind the others' busy middle,
@@ -394,7 +398,9 @@ int t2d_sync(t2d_pool* pool);
  *                      pinned host frames, and fills
  *                      *layout with the byte offsets of the sections inside a frame (-1 = section absent).  Asking for the
  *                      configuration already in place keeps the frames (and what a caller still holds of them); a DIFFERENT one
- *                      frees them: views of earlier frames are invalid from then on, as after t2d_destroy.  Call it again after
+ *                      frees them: views of earlier frames are invalid from then on, as after t2d_destroy, and a pool whose
+ *                      actions are the ones t2d_step_host last staged reads its OWN action fields (T2D_F_ACT0 / ACT1) again
+ *                      until the next t2d_step_host / t2d_bind_actions / upload.  Call it again after
  *                      t2d_lidar_config changed the beam count.  T2D_FRAME_ZEROCOPY: no copy commands at all -- the step kernel
  *                      reads the actions from mapped host memory and the pack / lidar kernels write the mapped host frame
  *                      (lowest latency for small pools; a large pool's 8 B per participant would cross PCIe inside the step).
@@ -409,7 +415,8 @@ int t2d_sync(t2d_pool* pool);
  *                      t2d_sync does.
  *                      action_box = {steering lo, steering hi, accel lo, accel hi} or NULL: `action_space.contains(action)`
  *                      of envs/parking.py:235-236 for every row, checked while the actions are staged (closed bounds, a NaN
- *                      is outside) -- T2D_ERR_ACTION, nothing stepped, the message names the first offending row.
+ *                      is outside) -- T2D_ERR_ACTION, nothing stepped AND nothing staged (the verdict precedes the copy: the
+ *                      actions of the last accepted call stay in place), the message names the first offending row.
  *   t2d_host_action_buffer  the pool's own pinned staging buffer, f32 [n_env * max_agents][2] (valid until the next
  *                      t2d_frame_config): a caller that writes its actions THERE and passes that pointer to t2d_step_host saves the
  *                      staging copy (2 MB per step at 4096 x 64: ~ 70 us of host memcpy); the box check still reads every row.
@@ -573,7 +580,9 @@ int t2d_get_parking_scenes(t2d_pool* pool, float* quads, int32_t* quad_id, int32
  * iterated, truncation < 1e-9 m --, everything else advances cos / sin by a rotation recurrence), 2 = fast with the kinematic
  * steps iterated as well (rounds 1-4's form; A/B measurements and tests).  Pools of fewer than two waves per SIMD of the device
  * (< 131072 participants on an MI355X) iterate under variant 1 too -- a lone wave is a latency chain the series' table fetch
- * lengthens --; 3 = variant 1 with the series whatever the pool size (tests).  All satisfy the 1e-5 contract; see DESIGN.md. */
+ * lengthens --; 3 = variant 1 with the series whatever the pool size (tests).  The single-ego kernel (t2d_set_ego_kernel) and
+ * the looping forms of t2d_step_n (pools of <= 2 workgroups per CU) iterate under every variant.  All satisfy the 1e-5
+ * contract; see DESIGN.md. */
 int t2d_set_integrator_variant(t2d_pool* pool, int32_t variant);
 
 /* Which pure OUTPUT columns the integrators store.  The reference's step() returns a State carrying vx / vy and the
@@ -620,64 +629,26 @@ int t2d_comm_info(t2d_pool* pool, int32_t* native_rccl, int32_t* world, int32_t*
 int64_t t2d_step_count(const t2d_pool* pool);
 int t2d_gather_wait(t2d_pool* pool, void* hip_stream, int32_t block_host);
 
-/* Introspection: resident workgroups per CU of the fused step kernel with this pool's geometry, its LDS bytes per
+/* Capacity planning: resident workgroups per CU of the fused step kernel with this pool's geometry, its LDS bytes per
  * workgroup (static tables + the workgroup's geometry record), and (may be NULL) the bytes of packed geometry records
  * the workgroups of one step launch stage into LDS.  The 4096 x 64 metric launch is one wave-round of 1024 workgroups
  * on 256 CUs and needs 4; a scene whose record grows past the LDS budget halves the rate.                          */
-/* Placement of the step launch: entry b = logical workgroup (the envs [g * epb, (g + 1) * epb), epb = 256 / padded
- * max_agents unless the geometry budget narrowed it) | wave rotation 0..3 << 16 that physical workgroup b steps.  Must be a
- * permutation of the launch's workgroups; NULL / 0 restores the identity.  Results never depend on it -- the hardware
- * places workgroup b on XCD b mod 8 and its waves on fixed SIMDs, so the map only decides which envs share a SIMD and
- * which XCD gets the expensive ones.  Reset by every t2d_set_*_geometry.  Host memory.                                  */
-int t2d_debug_set_step_placement(t2d_pool* pool, const uint32_t* map_host, int32_t n_workgroups);
+int t2d_step_occupancy(t2d_pool* pool, int32_t* blocks_per_cu, int64_t* lds_bytes,
+                       int64_t* geometry_bytes_per_launch);
 
-/* Test hook: the CHAIN launches of t2d_step_n enqueued from now on break ONE hand-off on purpose -- workgroup 1 posts its step
- * 1 with a foreign XCC id (kind 1: what a consumer on another XCD would see) or not at all (kind 2: its consumer's bounded
- * wait runs out after ~0.2 s); kind 3: it posts its step 0 with a foreign XCC id, so that the failure is on record while the
- * fragment's first step is still being dispatched (a grid larger than the device holds: the checkpoint must still be complete);
- * 0 = off.  Needs a pool of >= 2 step workgroups and fragments of >= 3 steps to have any effect. */
-int t2d_debug_chain_fault(t2d_pool* pool, int32_t kind);
-
-int t2d_debug_step_occupancy(t2d_pool* pool, int32_t* blocks_per_cu, int64_t* lds_bytes,
-                             int64_t* geometry_bytes_per_launch);
-
-/* Test hook: occupies the pool's gather stream for `microseconds` (one idle wave), so that the gathers enqueued after it
- * start late -- what a slow peer does to the collective.  tests/test_gpu_dist.py uses it to check that a step about to
- * overwrite a record slot really waits for the gather that still has to read it.                                       */
-int t2d_debug_delay_gather(t2d_pool* pool, int32_t microseconds);
-
-/* ---- the closed loop (measurement / test helpers; tactics2d_amd/csrc/t2d_loop.hip) -----------------------------------------
- * The reference's callers run  action = policy(obs); obs, reward, ... = env.step(action)  (envs/parking.py:219-256 inside the
- * tutorial's training loop).  On the device that is: a policy kernel that reads the state the previous step left behind and
- * writes an [N, 2] (steering, accel) tensor -> t2d_step reading it in place (t2d_bind_actions_strided) -> the policy again,
- * with no host synchronisation; the envs cut into groups -- one pool and one stream each -- so that one group's policy,
- * start-up and tail overlap the other groups' busy middle (env groups: tactics2d_amd/pipeline.py, t2d_step_groups).
- *   t2d_debug_feedback_policy   a STAND-IN policy, one launch: per participant accel = clip(k_speed (v_target - speed), -3, 2),
- *                               steering = k_steer sin(0.05 x + 0.08 y + heading); act_out_dev = f32 [N][2] (steering, accel).
- *   t2d_debug_closed_loop_*     n iterations of (that policy, t2d_step) per group enqueued by ONE host call -- launcher 0: from
- *                               the calling thread, round the groups step by step; 1: one host thread per group; 2: one captured
- *                               hipGraph per group holding graph_steps iterations, replayed (a replay rewrites the record-ring
- *                               slots of the capture: pick graph_steps = a multiple of T2D_RECORD_RING, or read T2D_F_STATUS /
- *                               T2D_F_REWARD).  create binds each pool's actions to its act_out_dev[g]; run returns when
- *                               everything is enqueued (t2d_sync / stream synchronisation waits for it); results are those of
- *                               the same policy and t2d_step calls on one pool holding all the envs. */
-typedef struct t2d_closed_loop t2d_closed_loop;
-/* a hipStreamNonBlocking stream created by the library (priority as hipStreamCreateWithPriority: 0 default, negative higher) */
-int t2d_debug_stream_create(int32_t device_id, int32_t priority, void** out_stream);
-int t2d_debug_stream_destroy(void* stream);
-int t2d_debug_feedback_policy(t2d_pool* pool, float* act_out_dev, float v_target, float k_speed, float k_steer, void* hip_stream);
-int t2d_debug_closed_loop_create(t2d_pool* const* pools, void* const* hip_streams, float* const* act_out_dev, int32_t n_groups,
-                                 int32_t interval_ms, int32_t launcher, int32_t graph_steps, t2d_closed_loop** out);
-int t2d_debug_closed_loop_run(t2d_closed_loop* loop, int32_t n_steps);
-int t2d_debug_closed_loop_destroy(t2d_closed_loop* loop);
+/* A hipStreamNonBlocking stream created by the library (priority as hipStreamCreateWithPriority: 0 default, negative
+ * higher) -- for hosts that step env groups on streams of their own (t2d_step_groups) without another HIP binding.      */
+int t2d_stream_create(int32_t device_id, int32_t priority, void** out_stream);
+int t2d_stream_destroy(void* stream);
 
 /* Host-only (no device is touched): the rectangles t2d_set_lane_geometry finds inside the union of each env's lane polygons
  * -- the certificate behind the step kernel's off-lane short cut (a pose whose box lies in one of them is contained in the
  * union).  out = f32 [n_env][T2D_SAFE_RECTS][4] (xmin, xmax, ymin, ymax); unused slots hold (+inf, -inf, +inf, -inf).
- * Same CSR arguments as t2d_set_lane_geometry.  Lets the CPU tests hold the certificate against the oracle's predicate. */
+ * Same CSR arguments as t2d_set_lane_geometry.  Lets a caller (and the CPU tests) hold the certificate against its own
+ * predicate (map/element/map.py:242-329 answers the same "what is near this pose" question with an STRtree).            */
 #define T2D_SAFE_RECTS 4
-int t2d_debug_lane_safe_rects(int32_t n_env, const int32_t* env_lane_offsets, const int32_t* lane_vert_offsets,
-                              const float* verts_xy, float* out);
+int t2d_lane_safe_rects(int32_t n_env, const int32_t* env_lane_offsets, const int32_t* lane_vert_offsets,
+                        const float* verts_xy, float* out);
 
 /* Host-only (no device is touched): the LDS budget of a scene before it is installed.  The step kernels keep the static and
  * lane geometry of one workgroup's envs in ONE packed record of at most 32 KiB; t2d_set_static_geometry / t2d_set_lane_geometry
@@ -686,9 +657,13 @@ int t2d_debug_lane_safe_rects(int32_t n_env, const int32_t* env_lane_offsets, co
  * CSR arrays (as in t2d_set_*_geometry; either pair may be NULL) and reports the dwords the fullest such workgroup needs and
  * the budget (8192): what tactics2d_amd/mapgeom.py uses to say how many lane / obstacle polygons of a reference map
  * (map/element/lane.py:125-130, map/element/area.py) an env can carry.                                                      */
-int t2d_debug_geometry_budget(int32_t n_env, int32_t max_agents, const int32_t* env_poly_offsets, const int32_t* poly_vert_offsets,
-                              const float* poly_xy, const int32_t* env_lane_offsets, const int32_t* lane_vert_offsets,
-                              const float* lane_xy, int32_t* dwords_needed, int32_t* dwords_budget, int32_t* envs_per_workgroup);
+int t2d_geometry_budget(int32_t n_env, int32_t max_agents, const int32_t* env_poly_offsets, const int32_t* poly_vert_offsets,
+                        const float* poly_xy, const int32_t* env_lane_offsets, const int32_t* lane_vert_offsets,
+                        const float* lane_xy, int32_t* dwords_needed, int32_t* dwords_budget, int32_t* envs_per_workgroup);
+
+/* Test and measurement hooks (fault injection, a gather delay, a stand-in policy and closed-loop runner, placement maps) are
+ * NOT part of this library: include/t2d_debug.h, exported only by libt2d_hip_debug.so (the same sources built with
+ * -DT2D_DEBUG_HOOKS), which tests/, bench.py's closed_loop leg and scripts/ load.                                          */
 
 #ifdef __cplusplus
 }

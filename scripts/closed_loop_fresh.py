@@ -16,7 +16,7 @@ raw = len(sys.argv) > 3 and sys.argv[3] == "raw"
 import torch  # noqa: E402
 
 from tactics2d_amd import scenarios as S  # noqa: E402
-from tactics2d_amd.pipeline import ClosedLoop, EnvGroups  # noqa: E402
+from tactics2d_amd.debug import ClosedLoop, env_groups as EnvGroups  # noqa: E402
 
 sc = S.mixed(4096, 64, seed=3)
 eg = EnvGroups(sc, G, raw_streams=raw)

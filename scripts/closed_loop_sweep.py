@@ -18,7 +18,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from tactics2d_amd import scenarios as S  # noqa: E402
-from tactics2d_amd.pipeline import ClosedLoop, EnvGroups  # noqa: E402
+from tactics2d_amd.debug import ClosedLoop, env_groups as EnvGroups  # noqa: E402
 from tactics2d_amd.pool import ParticipantPool  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
@@ -61,7 +61,7 @@ def single_open(n):
 
 def single_closed(n):
     pool.bind_actions(act.data_ptr() + 4, act.data_ptr(), 2)
-    f = pool._lib.t2d_debug_feedback_policy
+    f = pool._lib.t2d_debug_feedback_policy   # (pools of debug.env_groups live in libt2d_hip_debug.so)
     for _ in range(n):
         f(pool._h, act.data_ptr(), 12.0, 0.5, 0.04, st.cuda_stream)
         pool.step(100, st.cuda_stream)

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from tactics2d_amd import scenarios as S  # noqa: E402
-from tactics2d_amd.pipeline import ClosedLoop, EnvGroups  # noqa: E402
+from tactics2d_amd.debug import ClosedLoop, env_groups as EnvGroups  # noqa: E402
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 launcher = sys.argv[2] if len(sys.argv) > 2 else "thread"

@@ -5,7 +5,7 @@ import itertools, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from tactics2d_amd import scenarios as S, layout as L
-from tactics2d_amd.pool import ParticipantPool
+from tactics2d_amd import debug as D
 
 sc = S.mixed(4096, 64, 3)
 rng = np.random.default_rng(0)
@@ -44,8 +44,8 @@ def build_map(cost_env, skew=True, rotate=True, a=0.343, cycles_per_us=2200.0):
 
 
 def run(wgmap, n=2000):
-    pool = ParticipantPool(sc.n_env, sc.A); sc.load(pool); pool.set_auto_reset(True)
-    if wgmap is not None: pool.set_step_placement(wgmap)
+    pool = D.pool(sc.n_env, sc.A); sc.load(pool); pool.set_auto_reset(True)
+    if wgmap is not None: D.set_step_placement(pool, wgmap)
     import torch
     dev = torch.device("cuda", 0)
     ring = [(torch.from_numpy(a0).to(dev), torch.from_numpy(a1).to(dev)) for a0, a1 in acts]

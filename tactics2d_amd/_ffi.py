@@ -94,10 +94,9 @@ SYMBOLS = {
     "t2d_get_parking_scenes": (C.c_int, [_vp] * 10),
     "t2d_set_integrator_variant": (C.c_int, [_vp, C.c_int32]),
     "t2d_set_outputs": (C.c_int, [_vp, C.c_uint32]),
-    "t2d_debug_delay_gather": (C.c_int, [_vp, C.c_int32]),
-    "t2d_debug_lane_safe_rects": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
-    "t2d_debug_geometry_budget": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32),
-                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "t2d_lane_safe_rects": (C.c_int, [C.c_int32, _vp, _vp, _vp, _vp]),
+    "t2d_geometry_budget": (C.c_int, [C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "t2d_profile_enable": (C.c_int, [_vp, C.c_int32]),
     "t2d_profile_read": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "t2d_comm_unique_id": (C.c_int, [_vp]),
@@ -106,17 +105,9 @@ SYMBOLS = {
     "t2d_gather_wait": (C.c_int, [_vp, _vp, C.c_int32]),
     "t2d_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "t2d_step_count": (C.c_int64, [_vp]),
-    # introspection
-    "t2d_debug_set_step_placement": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.c_int32]),
-    "t2d_debug_step_occupancy": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
-    "t2d_debug_chain_fault": (C.c_int, [_vp, C.c_int32]),
-    # the closed loop (measurement / test helpers)
-    "t2d_debug_feedback_policy": (C.c_int, [_vp, _vp, C.c_float, C.c_float, C.c_float, _vp]),
-    "t2d_debug_closed_loop_create": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
-    "t2d_debug_closed_loop_run": (C.c_int, [_vp, C.c_int32]),
-    "t2d_debug_closed_loop_destroy": (C.c_int, [_vp]),
-    "t2d_debug_stream_create": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(_vp)]),
-    "t2d_debug_stream_destroy": (C.c_int, [_vp]),
+    "t2d_step_occupancy": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "t2d_stream_create": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "t2d_stream_destroy": (C.c_int, [_vp]),
 }
 
 _lib = None
@@ -140,38 +131,42 @@ def _share_torch_hip_runtime():
         C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
+def _load(path, symbols, what):
+    _share_torch_hip_runtime()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build it with `python -m tactics2d_amd.build{what}` "
+            "(hipcc, gfx950). tactics2d_amd has no CPU fallback.")
+    handle = C.CDLL(path)
+    for name, (res, args) in symbols.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            # (A/B measurements against a library built from older sources of the same ABI version: scripts/ab_step.py)
+            if os.environ.get("T2D_ALLOW_MISSING_SYMBOLS"):
+                continue
+            raise
+        fn.restype = res
+        fn.argtypes = args
+    from . import layout
+    have = handle.t2d_abi_version()
+    if have != layout.ABI_VERSION:   # e.g. a stale .so whose record ring is sized differently
+        raise ImportError(f"{path} has ABI version {have}, this package expects {layout.ABI_VERSION}: "
+                          "rebuild it with `python -m tactics2d_amd.build --force`")
+    return handle
+
+
 def lib():
     """Load libt2d_hip.so (raises if it has not been built -- no fallback)."""
     global _lib
     if _lib is None:
-        _share_torch_hip_runtime()
-        if not os.path.exists(LIB_PATH):
-            raise ImportError(
-                f"{LIB_PATH} not found: build it with `python -m tactics2d_amd.build` "
-                "(hipcc, gfx950). tactics2d_amd has no CPU fallback.")
-        handle = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
-            try:
-                fn = getattr(handle, name)
-            except AttributeError:
-                # (A/B measurements against a library built from older sources of the same ABI version: scripts/ab_step.py)
-                if os.environ.get("T2D_ALLOW_MISSING_SYMBOLS"):
-                    continue
-                raise
-            fn.restype = res
-            fn.argtypes = args
-        from . import layout
-        have = handle.t2d_abi_version()
-        if have != layout.ABI_VERSION:   # e.g. a stale .so whose record ring is sized differently
-            raise ImportError(f"{LIB_PATH} has ABI version {have}, this package expects {layout.ABI_VERSION}: "
-                              "rebuild it with `python -m tactics2d_amd.build --force`")
-        _lib = handle
+        _lib = _load(LIB_PATH, SYMBOLS, "")
     return _lib
 
 
-def check(rc, pool=None):
+def check(rc, pool=None, library=None):
     if rc == OK:
         return
-    msg = lib().t2d_last_error(pool)
+    msg = (library or lib()).t2d_last_error(pool)
     msg = msg.decode() if msg else ""
     raise (GeometryError if rc == ERR_GEOMETRY else T2DError)(rc, msg)

@@ -3,6 +3,7 @@
 // returns T2D_ERR_HIP with the HIP error text when the device / runtime is unavailable.
 #include <dlfcn.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 // RCCL: types and enums only -- the library is opened with dlopen when a communicator is asked for.  A single-GPU
@@ -26,6 +27,12 @@ typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3 } nccl
 #include <vector>
 
 #include "t2d_pool.h"
+#ifndef T2D_LOOP_MAX_WGS_PER_CU
+#define T2D_LOOP_MAX_WGS_PER_CU 2
+#endif
+#ifdef T2D_DEBUG_HOOKS
+#include "../../include/t2d_debug.h"
+#endif
 
 namespace {
 
@@ -872,8 +879,12 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
     v.overlapped = 0;
     v.wgmap = nullptr;
 #ifdef T2D_TIMING
-    (void)hipMalloc((void**)&v.dbg, (size_t)(n_env + 64) * 16 * 4 * sizeof(unsigned long long));
-    (void)hipMemset(v.dbg, 0, (size_t)(n_env + 64) * 16 * 4 * sizeof(unsigned long long));
+    {   // (T2D_TIMING_WORDS: room for the chained form's record per wave AND step, scripts/chain_timing.py)
+        size_t words = (size_t)(n_env + 64) * 16 * 4;
+        if (const char* e = getenv("T2D_TIMING_WORDS")) words = std::max(words, (size_t)strtoull(e, nullptr, 10));
+        (void)hipMalloc((void**)&v.dbg, words * sizeof(unsigned long long));
+        (void)hipMemset(v.dbg, 0, words * sizeof(unsigned long long));
+    }
 #endif
     v.geo = nullptr;
     v.geo_layout = t2d::GeoLayout{};
@@ -1222,6 +1233,7 @@ int t2d_bind_actions_strided(t2d_pool* p, const float* act0_dev, const float* ac
     p->v.act0 = act0_dev ? act0_dev : (const float*)p->field_ptr[T2D_F_ACT0];
     p->v.act1 = act1_dev ? act1_dev : (const float*)p->field_ptr[T2D_F_ACT1];
     p->v.act_stride = act0_dev ? stride : 1;
+    p->act_in_frame = false;
     refresh_idm_view(p);
     return T2D_OK;
 }
@@ -1539,7 +1551,7 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
         {
             if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
             const int loop_wgs = (p->v.n_env + p->v.geo_layout.epb - 1) / p->v.geo_layout.epb;
-            const bool loop_ok = p->chain_loop && p->device_cus > 0 && loop_wgs <= 2 * p->device_cus;
+            const bool loop_ok = p->chain_loop && p->device_cus > 0 && loop_wgs <= T2D_LOOP_MAX_WGS_PER_CU * p->device_cus;
             // ... and at most one workgroup per CU (envs of up to 64 participants): integrator waves a step ahead (PIPE)
             v.pipe_step = loop_ok && p->chain_pipe && loop_wgs <= p->device_cus && p->v.A <= 64;
             // (pools with lane polygons: the lane stage on a wave of its own -- needs three sets of waves in a workgroup)
@@ -1631,7 +1643,7 @@ int t2d_step_form(t2d_pool* p, int32_t n_steps) {
     if (!chain) return split ? T2D_FORM_STEP_SPLIT : T2D_FORM_STEP;
     const int wgs = (p->v.n_env + p->v.geo_layout.epb - 1) / p->v.geo_layout.epb;
     if (p->device_cus == 0) (void)hipDeviceGetAttribute(&p->device_cus, hipDeviceAttributeMultiprocessorCount, p->device);
-    const bool loop_ok = p->chain_loop && p->device_cus > 0 && wgs <= 2 * p->device_cus;
+    const bool loop_ok = p->chain_loop && p->device_cus > 0 && wgs <= T2D_LOOP_MAX_WGS_PER_CU * p->device_cus;
     if (loop_ok && p->chain_pipe && wgs <= p->device_cus && p->v.A <= 64) return T2D_FORM_LOOP_PIPE;
     if (split) return T2D_FORM_CHAIN_SPLIT;
     return loop_ok ? T2D_FORM_LOOP : T2D_FORM_CHAIN;
@@ -1957,6 +1969,7 @@ int t2d_comm_init(t2d_pool* p, const uint8_t* id, int32_t rank, int32_t world) {
     return T2D_OK;
 }
 
+#ifdef T2D_DEBUG_HOOKS   // include/t2d_debug.h: libt2d_hip_debug.so only
 int t2d_debug_delay_gather(t2d_pool* p, int32_t microseconds) {
     if (!p) return T2D_ERR_INVALID;
     if (microseconds < 0 || microseconds > 200000) return fail(p, T2D_ERR_INVALID, "delay must be 0 .. 200000 us");
@@ -1966,6 +1979,7 @@ int t2d_debug_delay_gather(t2d_pool* p, int32_t microseconds) {
     T2D_HIP(p, t2d::launch_spin(100ll * microseconds, p->gather_stream));
     return T2D_OK;
 }
+#endif
 
 int t2d_comm_info(t2d_pool* p, int32_t* native_rccl, int32_t* world, int32_t* rank) {
     if (!p) return T2D_ERR_INVALID;
@@ -2026,6 +2040,7 @@ int t2d_gather_wait(t2d_pool* p, void* hip_stream, int32_t block_host) {
 }
 
 // test hook: the next CHAIN launches of the pool break one hand-off on purpose (include/t2d.h)
+#ifdef T2D_DEBUG_HOOKS   // include/t2d_debug.h: libt2d_hip_debug.so only
 int t2d_debug_chain_fault(t2d_pool* p, int32_t kind) {
     if (!p) return T2D_ERR_INVALID;
     if (kind < 0 || kind > 3)
@@ -2033,8 +2048,10 @@ int t2d_debug_chain_fault(t2d_pool* p, int32_t kind) {
     p->chain_fault = (uint32_t)kind;
     return T2D_OK;
 }
+#endif
 
-// placement of the step launch (include/t2d.h): a permutation of its workgroups + a wave rotation per workgroup
+#ifdef T2D_DEBUG_HOOKS   // include/t2d_debug.h: libt2d_hip_debug.so only
+// placement of the step launch (include/t2d_debug.h): a permutation of its workgroups + a wave rotation per workgroup
 int t2d_debug_set_step_placement(t2d_pool* p, const uint32_t* map_host, int32_t n_workgroups) {
     if (!p) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));
@@ -2058,10 +2075,11 @@ int t2d_debug_set_step_placement(t2d_pool* p, const uint32_t* map_host, int32_t 
     p->v.wgmap = p->d_wgmap;
     return T2D_OK;
 }
+#endif
 
-// introspection: resident workgroups per CU of the fused step kernel for this pool's geometry, and its LDS bytes per
+// capacity planning: resident workgroups per CU of the fused step kernel for this pool's geometry, and its LDS bytes per
 // workgroup -- the regression guard of tests/test_gpu_api.py
-int t2d_debug_step_occupancy(t2d_pool* p, int32_t* blocks_per_cu, int64_t* lds_bytes, int64_t* geometry_bytes_per_launch) {
+int t2d_step_occupancy(t2d_pool* p, int32_t* blocks_per_cu, int64_t* lds_bytes, int64_t* geometry_bytes_per_launch) {
     if (!p || !blocks_per_cu || !lds_bytes) return T2D_ERR_INVALID;
     T2D_HIP(p, hipSetDevice(p->device));
     int b = 0;
@@ -2075,6 +2093,22 @@ int t2d_debug_step_occupancy(t2d_pool* p, int32_t* blocks_per_cu, int64_t* lds_b
         *geometry_bytes_per_launch = p->v.geo ? n_blocks * (int64_t)p->v.geo_layout.stride * 4 : 0;
     }
     return T2D_OK;
+}
+
+// a HIP stream of the library's own making (hipStreamNonBlocking, given priority: 0 = default, negative = higher): env groups
+// on streams that do not come out of the caller's framework pool
+int t2d_stream_create(int32_t device_id, int32_t priority, void** out_stream) {
+    if (!out_stream) return T2D_ERR_INVALID;
+    hipStream_t s = nullptr;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority) != hipSuccess) {
+        (void)hipGetLastError();
+        return T2D_ERR_HIP;
+    }
+    *out_stream = s;
+    return T2D_OK;
+}
+int t2d_stream_destroy(void* stream) {
+    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? T2D_OK : T2D_ERR_HIP;
 }
 
 int t2d_get_field(t2d_pool* p, int32_t f, void** dev_ptr, size_t* nbytes) {
@@ -2110,6 +2144,7 @@ int t2d_upload(t2d_pool* p, int32_t f, const void* host_src, size_t nbytes) {
         p->v.act0 = (const float*)p->field_ptr[T2D_F_ACT0];
         p->v.act1 = (const float*)p->field_ptr[T2D_F_ACT1];
         p->v.act_stride = 1;
+        p->act_in_frame = false;
         refresh_idm_view(p);
     }
     return T2D_OK;
@@ -2125,6 +2160,15 @@ int t2d_sync(t2d_pool* p) {
 
 // ---- the Gym-API host path (include/t2d.h: t2d_frame_config / t2d_step_host / t2d_frame_fetch) -------------------------------
 static void frame_release(t2d_pool* p) {
+    // the staging buffers go: a pool whose actions are the ones t2d_step_host staged there falls back to its own action
+    // fields (what t2d_step / t2d_step_n / t2d_step_host(NULL) read from now on), never to freed memory
+    if (p->act_in_frame) {
+        p->v.act0 = (const float*)p->field_ptr[T2D_F_ACT0];
+        p->v.act1 = (const float*)p->field_ptr[T2D_F_ACT1];
+        p->v.act_stride = 1;
+        p->act_in_frame = false;
+        refresh_idm_view(p);
+    }
     if (p->d_frame) (void)hipFree(p->d_frame);
     if (p->d_actions) (void)hipFree(p->d_actions);
     for (char*& h : p->h_frame) {
@@ -2272,19 +2316,14 @@ int t2d_step_host(t2d_pool* p, const float* actions_host, const float* action_bo
             const float lo0 = action_box[0], hi0 = action_box[1], lo1 = action_box[2], hi1 = action_box[3];
             float* dst = p->h_actions;
             int ok = 1;
-            if (in_place) {
-                for (size_t i = 0, n = (size_t)p->v.N; i < n; ++i) {
-                    const float a = actions_host[2 * i], b = actions_host[2 * i + 1];
-                    ok &= (int)(a >= lo0) & (int)(a <= hi0) & (int)(b >= lo1) & (int)(b <= hi1);
-                }
-            } else {
-                for (size_t i = 0, n = (size_t)p->v.N; i < n; ++i) {
-                    const float a = actions_host[2 * i], b = actions_host[2 * i + 1];
-                    ok &= (int)(a >= lo0) & (int)(a <= hi0) & (int)(b >= lo1) & (int)(b <= hi1);
-                    dst[2 * i] = a;
-                    dst[2 * i + 1] = b;
-                }
+            // the verdict first, the copy only behind it: rejected rows (NaN included) never reach the staging buffer, which
+            // in zero-copy mode IS what the previous call's binding reads -- a t2d_step after an InvalidAction steps with the
+            // last accepted actions (a caller that filled the pool's own buffer in place has overwritten them itself)
+            for (size_t i = 0, n = (size_t)p->v.N; i < n; ++i) {
+                const float a = actions_host[2 * i], b = actions_host[2 * i + 1];
+                ok &= (int)(a >= lo0) & (int)(a <= hi0) & (int)(b >= lo1) & (int)(b <= hi1);
             }
+            if (ok && !in_place) memcpy(dst, actions_host, act_bytes);
             if (!ok) {
                 size_t bad = 0;
                 for (size_t n = (size_t)p->v.N; bad < n; ++bad) {
@@ -2307,6 +2346,7 @@ int t2d_step_host(t2d_pool* p, const float* actions_host, const float* action_bo
         p->v.act0 = dev_act + 1;
         p->v.act1 = dev_act;
         p->v.act_stride = 2;
+        p->act_in_frame = true;
         refresh_idm_view(p);
     }
     int rc = t2d_step(p, interval_ms, hip_stream);
@@ -2466,7 +2506,7 @@ int t2d_set_outputs(t2d_pool* p, uint32_t mask) {
     return T2D_OK;
 }
 
-int t2d_debug_lane_safe_rects(int32_t n_env, const int32_t* env_lane_offsets, const int32_t* lane_vert_offsets,
+int t2d_lane_safe_rects(int32_t n_env, const int32_t* env_lane_offsets, const int32_t* lane_vert_offsets,
                               const float* verts_xy, float* out) {
     if (n_env <= 0 || !env_lane_offsets || !lane_vert_offsets || !out) return T2D_ERR_INVALID;
     std::unique_ptr<t2d_pool> tmp(new (std::nothrow) t2d_pool());   // host bookkeeping only: no device call below
@@ -2483,7 +2523,7 @@ int t2d_debug_lane_safe_rects(int32_t n_env, const int32_t* env_lane_offsets, co
 // Host-only: what t2d_set_static_geometry + t2d_set_lane_geometry would make of these polygons -- the dwords of the packed
 // record of the fullest workgroup at the narrowest workgroup the step kernels accept (one wave: 64 / padded max_agents envs)
 // against the 32 KiB budget; T2D_ERR_GEOMETRY (with the message t2d_set_*_geometry would give) for polygons it rejects.
-int t2d_debug_geometry_budget(int32_t n_env, int32_t max_agents, const int32_t* env_poly_offsets, const int32_t* poly_vert_offsets,
+int t2d_geometry_budget(int32_t n_env, int32_t max_agents, const int32_t* env_poly_offsets, const int32_t* poly_vert_offsets,
                               const float* poly_xy, const int32_t* env_lane_offsets, const int32_t* lane_vert_offsets,
                               const float* lane_xy, int32_t* dwords_needed, int32_t* dwords_budget, int32_t* envs_per_workgroup_out) {
     if (n_env <= 0 || max_agents <= 0 || max_agents > T2D_MAX_AGENTS || !dwords_needed) return T2D_ERR_INVALID;

@@ -80,6 +80,12 @@ using namespace geom;
 #ifndef T2D_COLLIDE_WAVES
 #define T2D_COLLIDE_WAVES 4  // min waves / SIMD the register allocator must allow
 #endif
+#ifndef T2D_LOOP_WAVES
+#define T2D_LOOP_WAVES 2     // ... of the LOOP forms (a workgroup walks through the steps itself)
+#endif
+#ifndef T2D_LOOP_RESUM
+#define T2D_LOOP_RESUM 0
+#endif
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kQueueCap = 288;  // queue entries per wave per round (also holds the broad phase's 3 x 96 staging floats)
@@ -384,7 +390,7 @@ constexpr int kPipeSpinLimit = 1 << 17;   // polls (s_sleep 1 between them) befo
 // (t2d_idm_dev.h: the kernel's own functions), its acceleration goes to the pool's action field and into the integrator; a
 // lane whose env was reset does it again on the restored positions.  Same leaders, same accelerations, same states.
 template <bool WITH_STATUS, int FUSE, bool IOU = true, bool CHAIN = false, bool LOOP = false, bool SPLIT = false, int PIPE = 0, bool IDMF = false>
-__global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv_arg, t2d_status_config cfg_arg,
+__global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOOP_WAVES : T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv_arg, t2d_status_config cfg_arg,
                                                                                                                    int interval_ms, int log2A) {
     static_assert(!(CHAIN && LOOP) && (!LOOP || (FUSE >= 0 && WITH_STATUS)), "LOOP = the fused step, not combined with CHAIN");
     static_assert(!PIPE || (LOOP && !IOU && !SPLIT), "PIPE = a LOOP launch with integrator waves");
@@ -470,11 +476,13 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
             __hip_atomic_store(&pv.chain_done[unit], chain_word(pv.chain_base + (uint32_t)step_k + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
+#ifdef T2D_DEBUG_HOOKS   // (libt2d_hip_debug.so: t2d_debug_set_step_placement)
     if (!CHAIN && !SPLIT && pv.wgmap) {
         const uint32_t m = pv.wgmap[blockIdx.x];
         wg = (int)(m & 0xffffu);
         wave_rot = (int)(m >> 16);
     }
+#endif
     // `tid` = the participant's slot in the workgroup's LDS tables.  SPLIT: the four waves all stand for the env's 64 slots;
     // `role` tells them apart and `ptid` is the thread's own number (what the staging loops stride by)
     const int role = SPLIT ? (int)(threadIdx.x >> 6) : 0;
@@ -500,11 +508,16 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
 
 #ifdef T2D_TIMING
     unsigned long long t_prev_ = __builtin_readcyclecounter();
-    const size_t wave_slot_ = ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
+    // CHAIN: one record of 32 words per wave AND step (scripts/chain_timing.py): words 0-15 as below, 16 / 17 = the constant
+    // 100 MHz clock (s_memrealtime) at the wave's start / end, 18 = cycles waiting for the hand-off, 19 = cycles of the tail
+    // (store drain + barrier + the word), 20 = the cycle counter at the end
+    const size_t wave_slot_ = CHAIN ? ((((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6)) + (threadIdx.x >> 6)) * 32
+                                    : ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16;
     if (lane == 0) {  // where and when this wave ran: HW_ID | XCC_ID << 32, start tick
         pv.dbg[wave_slot_ + 14] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |
                                   ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
         pv.dbg[wave_slot_ + 15] = t_prev_;
+        if (CHAIN) pv.dbg[wave_slot_ + 16] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
     // Wave priority = how far BEHIND a wave is: 3 through the integrator and the pose phase, 2 in the first event stage,
@@ -813,6 +826,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     // would otherwise sit, unhidden, at the very end of the wave
     int pre_cnt = 0, pre_frame = 0;
     if (CHAIN && step_k > 0) chain_wait();
+    if constexpr (CHAIN) { T2D_MARK(18); }
     const bool carried = LOOP && step_k > 0;   // (LOOP: the second and later trips take their inputs from registers)
     if (valid && !PIPE && (!SPLIT || role == 0)) {   // (SPLIT: wave 0 loads and integrates; the others get the new state through LDS)
         if (carried) {
@@ -1018,7 +1032,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
                 }
             }
         }
-        const integ::StepOut o = integ::step_participant<(FUSE > 0 ? 1 : 0), !LOOP>(
+        const integ::StepOut o = integ::step_participant<(FUSE > 0 ? 1 : 0), (!LOOP || T2D_LOOP_RESUM)>(
             model, P, (double)fx, (double)fy, (double)fh, (double)fv, pvx, pvy, (double)fa0, (double)fa1, interval_ms, pv.interval_s);
         fx = (float)o.x;
         fy = (float)o.y;
@@ -1856,6 +1870,9 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
     if (++step_k >= pv.loop_steps) break;
     }
     if (CHAIN) {   // this step of these envs is complete: every store above is in the L2 before the word moves
+#ifdef T2D_TIMING
+        t_prev_ = __builtin_readcyclecounter();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (ptid == 0) {
@@ -1863,11 +1880,23 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? 2 : T2D
             // test hook (t2d_debug_chain_fault): workgroup 1 hands its step 1 over with a foreign XCC id (1) / not at all (2);
             // 3: it hands its step 0 over with a foreign XCC id -- the failure is then posted while the fragment's first
             // step is still being dispatched on a grid larger than the device holds
+#ifdef T2D_DEBUG_HOOKS   // (libt2d_hip_debug.so only; the product posts the word as it is)
             const uint32_t cf = pv.chain_fault;
             const uint32_t fault = unit != 1 ? 0u : (cf == 3u ? (step_k == 0 ? 1u : 0u) : (step_k == 1 ? cf : 0u));
             if (fault & 1u) w ^= 1ull << 32;
-            if (!(fault & 2u)) __hip_atomic_store(&pv.chain_done[unit], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(fault & 2u))
+#endif
+            __hip_atomic_store(&pv.chain_done[unit], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#ifdef T2D_TIMING
+        if constexpr (CHAIN) {
+            T2D_MARK(19);
+            if (lane == 0) {
+                pv.dbg[wave_slot_ + 17] = __builtin_amdgcn_s_memrealtime();
+                pv.dbg[wave_slot_ + 20] = t_prev_;
+            }
+        }
+#endif
     }
 #undef pv
 #undef cfg

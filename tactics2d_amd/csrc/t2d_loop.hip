@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "t2d_pool.h"
+#include "../../include/t2d_debug.h"
 #include <thread>
 
 // a spin-wait hint that exists on every host (the x86 pause instruction where there is one)
@@ -134,22 +135,6 @@ int t2d_debug_feedback_policy(t2d_pool* p, float* act_out_dev, float v_target, f
         return T2D_ERR_HIP;
     }
     return T2D_OK;
-}
-
-// a HIP stream of the library's own making (hipStreamNonBlocking, given priority: 0 = default, negative = higher): env groups
-// on streams that do not come out of the caller's framework pool
-int t2d_debug_stream_create(int32_t device_id, int32_t priority, void** out_stream) {
-    if (!out_stream) return T2D_ERR_INVALID;
-    hipStream_t s = nullptr;
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority) != hipSuccess) {
-        (void)hipGetLastError();
-        return T2D_ERR_HIP;
-    }
-    *out_stream = s;
-    return T2D_OK;
-}
-int t2d_debug_stream_destroy(void* stream) {
-    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? T2D_OK : T2D_ERR_HIP;
 }
 
 int t2d_debug_closed_loop_create(t2d_pool* const* pools, void* const* hip_streams, float* const* act_out_dev, int32_t n_groups,

@@ -338,6 +338,7 @@ struct t2d_pool {
     int n_host_frames = 0, frame_turn = 0;
     float* h_actions = nullptr;       // pinned (and mapped) staging of the host actions, [N][2]
     float* d_actions = nullptr;       // device copy of them (copy mode)
+    bool act_in_frame = false;        // v.act0 / v.act1 point into d_actions / the mapped h_actions (set by t2d_step_host)
     double* d_target_heading = nullptr;
     // profiling
     bool profiling = false;

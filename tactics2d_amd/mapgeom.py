@@ -67,17 +67,25 @@ def _dedup(P):
 
 # ---------------------------------------------------------------------------------------------------------------- ear clipping
 def _ear_clip(P):
-    """triangles (index triples, CCW) of the simple CCW ring P; collinear vertices are dropped (they add no area)"""
+    """convex pieces (index tuples, CCW) of the simple CCW ring P: its ear triangles, each with the ring's COLLINEAR vertices
+    that lie on its edges kept as straight corners -- a vertex on a straight run adds no area, but a neighbouring ring that
+    shares the polyline still uses it, and pieces that abut must share their vertices exactly (no T-junctions)"""
     idx = list(range(len(P)))
     tris = []
+    on_chord = {}          # (u, v), neighbours in the shrinking ring -> the collinear vertices dropped between them, in order
     guard = 0
+
+    def run(u, v):         # u, the straight corners between u and v, (v excluded)
+        return [u] + on_chord.pop((u, v), [])
+
     while len(idx) > 3:
         n = len(idx)
         clipped = False
         for k in range(n):
             i0, i1, i2 = idx[(k - 1) % n], idx[k], idx[(k + 1) % n]
             o = _orient(P[i0], P[i1], P[i2])
-            if o == 0.0:               # collinear: the vertex lies on the chord, remove it without a triangle
+            if o == 0.0:               # collinear: the vertex lies on the chord; it stays a corner of the piece that gets the chord
+                on_chord[(i0, i2)] = on_chord.pop((i0, i1), []) + [i1] + on_chord.pop((i1, i2), [])
                 idx.pop(k)
                 clipped = True
                 break
@@ -87,7 +95,7 @@ def _ear_clip(P):
             if any(j not in (i0, i1, i2) and _in_triangle(P[j], a, b, c) and not (np.array_equal(P[j], a) or np.array_equal(P[j], b) or np.array_equal(P[j], c))
                    for j in idx):
                 continue
-            tris.append((i0, i1, i2))
+            tris.append(tuple(run(i0, i1) + run(i1, i2) + [i2]))   # (the new chord i2 -> i0 is a cut: nothing lies on it)
             idx.pop(k)
             clipped = True
             break
@@ -95,8 +103,29 @@ def _ear_clip(P):
         if not clipped or guard > 4 * len(P) + 16:
             raise ValueError("ring is not a simple polygon (self-intersecting or degenerate): cannot be cut into convex pieces")
     if len(idx) == 3 and _orient(P[idx[0]], P[idx[1]], P[idx[2]]) > 0.0:
-        tris.append(tuple(idx))
+        tris.append(tuple(run(idx[0], idx[1]) + run(idx[1], idx[2]) + run(idx[2], idx[0])))
     return tris
+
+
+def _split_large(P, poly, max_verts):
+    """a convex piece with more than max_verts vertices (straight corners count) -> pieces of <= max_verts, cut along chords
+    between its own vertices; both sides of every cut keep an area"""
+    poly = list(poly)
+    n = len(poly)
+    if n <= max_verts:
+        return [poly]
+    best = None
+    for i in range(n):
+        for d in range(2, n - 1):
+            a = [poly[(i + t) % n] for t in range(d + 1)]
+            b = [poly[(i + d + t) % n] for t in range(n - d + 1)]
+            if _area2(P[a]) > 0.0 and _area2(P[b]) > 0.0:
+                score = max(len(a), len(b))
+                if best is None or score < best[0]:
+                    best = (score, a, b)
+    if best is None:
+        raise ValueError("cannot cut a piece of %d vertices down to %d" % (n, max_verts))
+    return _split_large(P, best[1], max_verts) + _split_large(P, best[2], max_verts)
 
 
 def _merge(P, polys, max_verts):
@@ -141,7 +170,10 @@ def ring_to_convex(ring_xy, max_verts=8):
         raise ValueError("ring has no area")
     if a2 < 0.0:
         P = P[::-1].copy()
-    polys = _merge(P, _ear_clip(P), max_verts)
+    pieces = []
+    for t in _ear_clip(P):              # (an ear with many straight corners on its edges is cut down first)
+        pieces.extend(_split_large(P, t, max_verts))
+    polys = _merge(P, pieces, max_verts)
     return [np.float32(P[list(p)]) for p in polys]
 
 
@@ -264,6 +296,6 @@ def geometry_budget(n_env, max_agents, static=None, lanes=None):
     p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
     s, l = csr(static), csr(lanes)
     need, budget, epb = C.c_int32(), C.c_int32(), C.c_int32()
-    _ffi.check(_ffi.lib().t2d_debug_geometry_budget(int(n_env), int(max_agents), p(s[0]), p(s[1]), p(s[2]), p(l[0]), p(l[1]), p(l[2]),
+    _ffi.check(_ffi.lib().t2d_geometry_budget(int(n_env), int(max_agents), p(s[0]), p(s[1]), p(s[2]), p(l[0]), p(l[1]), p(l[2]),
                                                    C.byref(need), C.byref(budget), C.byref(epb)))
     return dict(dwords_needed=need.value, dwords_budget=budget.value, envs_per_workgroup=epb.value, fits=need.value <= budget.value)

@@ -29,7 +29,9 @@ from .pool import ParticipantPool
 
 
 class EnvGroups:
-    def __init__(self, scene, groups, device_id=0, raw_streams=False):
+    def __init__(self, scene, groups, device_id=0, raw_streams=False, library=None):
+        """library: the loaded C library the groups' pools live in (default libt2d_hip.so; tactics2d_amd.debug passes
+        libt2d_hip_debug.so for the closed-loop measurement)"""
         import torch
         if groups < 1 or scene.n_env % groups:
             raise ValueError(f"{groups} groups must divide {scene.n_env} envs")
@@ -39,19 +41,19 @@ class EnvGroups:
         self.pools, self.streams, self._raw = [], [], []
         dev = torch.device("cuda", device_id)
         for lo, hi in self.bounds:
-            pool = ParticipantPool(hi - lo, scene.A, device_id)
+            pool = ParticipantPool(hi - lo, scene.A, device_id, library=library)
             scene.shard(lo, hi).load(pool)
             self.pools.append(pool)
             if raw_streams:   # streams of the library's own making, wrapped for torch's stream API (wait_stream, synchronize)
                 h = C.c_void_p()
-                _ffi.check(_ffi.lib().t2d_debug_stream_create(device_id, 0, C.byref(h)))
+                _ffi.check((library or _ffi.lib()).t2d_stream_create(device_id, 0, C.byref(h)))
                 self._raw.append(h)
                 self.streams.append(torch.cuda.ExternalStream(h.value, device=dev))
             else:
                 self.streams.append(torch.cuda.Stream(device=dev))
         self.n_env, self.A, self.n = scene.n_env, scene.A, scene.n
         # one C call steps every group (t2d_step_groups): handle / stream / action-pointer arrays built once
-        self._lib = _ffi.lib()
+        self._lib = library if library is not None else _ffi.lib()
         vp = C.c_void_p * groups
         self._handles = vp(*[p._h for p in self.pools])
         self._streams = vp(*[s.cuda_stream for s in self.streams])
@@ -84,8 +86,8 @@ class EnvGroups:
             for p in self.pools:
                 msg = self._lib.t2d_last_error(p._h)
                 if msg:
-                    _ffi.check(rc, p._h)
-            _ffi.check(rc, None)
+                    _ffi.check(rc, p._h, self._lib)
+            _ffi.check(rc, None, self._lib)
 
     def join(self, stream=None):
         """Make `stream` (a torch stream; default: the current one) wait for everything launched so far."""
@@ -118,52 +120,5 @@ class EnvGroups:
             p.close()
         self.pools = []
         for h in self._raw:
-            _ffi.lib().t2d_debug_stream_destroy(h)
+            self._lib.t2d_stream_destroy(h)
         self._raw = []
-
-
-class ClosedLoop:
-    """The closed loop a policy-driven caller runs -- per env group and step: policy kernel -> t2d_step, no host
-    synchronisation -- enqueued `n` iterations at a time by one C call (t2d_debug_closed_loop_*, t2d_loop.hip).  The policy is
-    the library's stand-in (per-participant state feedback, a few flops): what is timed is the step path under a real
-    dependency -- step k + 1 of a group cannot start before its policy has read step k's state -- not a network.
-
-    launcher: "thread" (the calling thread goes round the groups), "threads" (one host thread per group) or "graph" (one
-    captured hipGraph of `graph_steps` iterations per group, replayed).  Results equal those of the same policy and t2d_step
-    calls on one pool holding all the envs (tests/test_gpu_closed_loop.py)."""
-    LAUNCHERS = {"thread": 0, "threads": 1, "graph": 2}
-
-    def __init__(self, groups, launcher="thread", interval_ms=100, graph_steps=64):
-        import torch
-        self.groups, self.launcher = groups, launcher
-        self._lib = _ffi.lib()
-        dev = torch.device("cuda", groups.device_id)
-        # one [n_g, 2] (steering, accel) tensor per group: what a policy network would return for the group's participants
-        self.actions = [torch.zeros((p.n, 2), dtype=torch.float32, device=dev) for p in groups.pools]
-        torch.cuda.synchronize(dev)
-        G = groups.groups
-        vp = C.c_void_p * G
-        self._h = C.c_void_p()
-        rc = self._lib.t2d_debug_closed_loop_create(vp(*[p._h for p in groups.pools]), vp(*[s.cuda_stream for s in groups.streams]),
-                                                    vp(*[a.data_ptr() for a in self.actions]), G, int(interval_ms),
-                                                    self.LAUNCHERS[launcher], int(graph_steps), C.byref(self._h))
-        if rc:
-            for p in groups.pools:
-                if self._lib.t2d_last_error(p._h):
-                    _ffi.check(rc, p._h)
-            _ffi.check(rc, None)
-
-    def run(self, n_steps):
-        """enqueue n_steps iterations of (policy, step) on every group; returns when everything is enqueued"""
-        rc = self._lib.t2d_debug_closed_loop_run(self._h, int(n_steps))
-        if rc:
-            for p in self.groups.pools:
-                if self._lib.t2d_last_error(p._h):
-                    _ffi.check(rc, p._h)
-            _ffi.check(rc, None)
-
-    def close(self):
-        if self._h:
-            self.groups.sync()
-            self._lib.t2d_debug_closed_loop_destroy(self._h)
-            self._h = None

@@ -73,7 +73,10 @@ class HostFrame:
         return self
 
     def _refs(self):
-        return [sys.getrefcount(v) for v in self._tracked]
+        # the object itself counts too: a caller that keeps the HostFrame (`frames.append(mgr.step_host(a))`) holds no array
+        # reference, and must pin the frame all the same.  (calibrate() and in_use() are both called through one local name
+        # beside whatever container owns the frame -- ParticipantPool._frame / _pick_frame keep it that way.)
+        return [sys.getrefcount(self)] + [sys.getrefcount(v) for v in self._tracked]
 
     def in_use(self):
         return self._idle_refs is None or self._refs() != self._idle_refs
@@ -87,13 +90,15 @@ class HostFrame:
 class ParticipantPool:
     """n_env environments x max_agents participants resident on one MI355X."""
 
-    def __init__(self, n_env, max_agents=1, device_id=0):
-        self._lib = _ffi.lib()
+    def __init__(self, n_env, max_agents=1, device_id=0, library=None):
+        """library: the loaded C library the pool lives in -- libt2d_hip.so unless a test / measurement asks for the hooks of
+        libt2d_hip_debug.so (tactics2d_amd.debug.pool)."""
+        self._lib = library if library is not None else _ffi.lib()
         self._h = C.c_void_p()
         self.n_env, self.max_agents = int(n_env), int(max_agents)
         self.n = self.n_env * self.max_agents
         self.device_id = int(device_id)
-        _ffi.check(self._lib.t2d_create(self.n_env, self.max_agents, self.device_id, C.byref(self._h)))
+        _ffi.check(self._lib.t2d_create(self.n_env, self.max_agents, self.device_id, C.byref(self._h)), None, self._lib)
 
     # ---------------------------------------------------------------- lifetime
     def close(self):
@@ -108,7 +113,7 @@ class ParticipantPool:
             pass
 
     def _ck(self, rc):
-        _ffi.check(rc, self._h)
+        _ffi.check(rc, self._h, self._lib)
 
     # ---------------------------------------------------------------- configuration
     def set_param_table(self, rows):
@@ -291,7 +296,8 @@ class ParticipantPool:
             arr = np.frombuffer(buf, np.uint8)
             fr = HostFrame(arr, self.frame_layout)
             del arr, buf
-            self._frames[k] = fr.calibrate()
+            self._frames[k] = fr   # (first: the idle reference counts include the list's reference and the local name's,
+            fr.calibrate()         #  exactly what _pick_frame's `fr.in_use()` sees when nobody else holds the frame)
         return fr
 
     def step_host(self, actions, interval_ms=100, stream=None, action_box=None, fresh=False):
@@ -477,30 +483,16 @@ class ParticipantPool:
         """Steps taken so far (t2d_step_count): what t2d_gather's fragment length must divide."""
         return int(self._lib.t2d_step_count(self._h))
 
-    def set_step_placement(self, wgmap=None):
-        """Which logical workgroup (and wave rotation << 16) each physical workgroup of the step launch steps; None = identity.
-        Never changes a result (t2d.h: t2d_debug_set_step_placement)."""
-        if wgmap is None:
-            self._ck(self._lib.t2d_debug_set_step_placement(self._h, None, 0))
-            return
-        m = np.ascontiguousarray(wgmap, np.uint32)
-        self._ck(self._lib.t2d_debug_set_step_placement(self._h, m.ctypes.data_as(C.POINTER(C.c_uint32)), int(m.size)))
-
-    def debug_chain_fault(self, kind):
-        """Test hook (t2d_debug_chain_fault): the CHAIN launches of step_n break one hand-off on purpose -- 1: a foreign XCC
-        id in the word, 2: a word that never comes; 0: off."""
-        self._ck(self._lib.t2d_debug_chain_fault(self._h, int(kind)))
-
     def step_occupancy(self):
         """(resident workgroups per CU, LDS bytes per workgroup) of the fused step kernel with this pool's geometry."""
         b, l, g = C.c_int32(), C.c_int64(), C.c_int64()
-        self._ck(self._lib.t2d_debug_step_occupancy(self._h, C.byref(b), C.byref(l), C.byref(g)))
+        self._ck(self._lib.t2d_step_occupancy(self._h, C.byref(b), C.byref(l), C.byref(g)))
         return b.value, l.value
 
     def geometry_bytes_per_launch(self):
         """bytes of packed geometry records (polygons, boxes, lane-union boundary pieces) one step launch stages into LDS"""
         b, l, g = C.c_int32(), C.c_int64(), C.c_int64()
-        self._ck(self._lib.t2d_debug_step_occupancy(self._h, C.byref(b), C.byref(l), C.byref(g)))
+        self._ck(self._lib.t2d_step_occupancy(self._h, C.byref(b), C.byref(l), C.byref(g)))
         return g.value
 
     # ---------------------------------------------------------------- profiling

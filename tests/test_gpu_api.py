@@ -262,10 +262,10 @@ def test_bound_action_memory_is_read_only_and_uploads_end_a_binding():
 
 @pytest.mark.gpu
 def test_step_placement_never_changes_a_result():
-    """t2d_debug_set_step_placement: any permutation of the step launch's workgroups, with any wave rotations, gives the
+    """t2d_debug_set_step_placement (a hook of libt2d_hip_debug.so, include/t2d_debug.h): any permutation of the step launch's workgroups, with any wave rotations, gives the
     same state, flags, status and rewards step after step (auto-reset on); malformed maps are rejected."""
     from tactics2d_amd import scenarios as S, layout as L
-    from tactics2d_amd.pool import ParticipantPool
+    from tactics2d_amd import debug as D
     from tactics2d_amd._ffi import T2DError
     rng = np.random.default_rng(3)
     # 1060 envs: 265 workgroups of 4 envs (four waves each: rotations apply); 96 envs: fewer workgroups than compute units at
@@ -275,9 +275,9 @@ def test_step_placement_never_changes_a_result():
         acts = [sc.sample_actions(rng) for _ in range(6)]
 
         def rollout(wgmap):
-            pool = ParticipantPool(sc.n_env, sc.A); sc.load(pool); pool.set_auto_reset(True)
+            pool = D.pool(sc.n_env, sc.A); sc.load(pool); pool.set_auto_reset(True)
             if wgmap is not None:
-                pool.set_step_placement(wgmap)
+                D.set_step_placement(pool, wgmap)
             out = []
             for a0, a1 in acts:
                 pool.set_actions(a0, a1); pool.step(100)
@@ -291,12 +291,12 @@ def test_step_placement_never_changes_a_result():
         for w, g in zip(want, got):
             for a, b in zip(w, g):
                 assert np.array_equal(a, b, equal_nan=True)
-        pool = ParticipantPool(sc.n_env, sc.A); sc.load(pool)
+        pool = D.pool(sc.n_env, sc.A); sc.load(pool)
         bad = perm.copy(); bad[0] = bad[1]
         for m in (bad, perm[:-1], perm | np.uint32(4 << 16)):
             with pytest.raises(T2DError):
-                pool.set_step_placement(m)
-        pool.set_step_placement(None)
+                D.set_step_placement(pool, m)
+        D.set_step_placement(pool, None)
         pool.close()
 
 

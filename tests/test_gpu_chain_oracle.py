@@ -223,8 +223,10 @@ def test_a_broken_hand_off_is_reported_once_rolled_back_and_survived(kind, code)
     a0 = torch.from_numpy(r0).to(dev).contiguous(); a1 = torch.from_numpy(r1).to(dev).contiguous()
     fields = (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_VX, L.F_VY, L.F_IDS, L.F_CNT_STEP, L.F_FRAME_MS)
 
+    from tactics2d_amd import debug as D      # (fault injection is a hook of libt2d_hip_debug.so: include/t2d_debug.h)
+
     def fresh():
-        p = ParticipantPool(sc.n_env, sc.A)
+        p = D.pool(sc.n_env, sc.A)
         sc.load(p)
         p.set_integrator_variant("exact")
         p.set_auto_reset(True)
@@ -252,9 +254,9 @@ def test_a_broken_hand_off_is_reported_once_rolled_back_and_survived(kind, code)
         pool.step_n(n, sc.interval_ms, sc.n)
 
     frag(0, 6)
-    pool.debug_chain_fault(kind)
+    D.chain_fault(pool, kind)
     frag(6, 6)
-    pool.debug_chain_fault(0)
+    D.chain_fault(pool, 0)
     frag(12, 6)                         # enqueued behind the failed fragment: must not disturb its checkpoint
     assert pool.step_count() == 18
     with pytest.raises(_ffi.T2DError) as ei:
@@ -354,7 +356,8 @@ def test_a_failure_during_the_first_step_leaves_a_complete_checkpoint():
     r0, r1 = _ring(sc, 12, seed=3)
     a0 = torch.from_numpy(r0).to(dev).contiguous(); a1 = torch.from_numpy(r1).to(dev).contiguous()
     fields = (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_IDS, L.F_CNT_STEP, L.F_FRAME_MS)
-    pool = ParticipantPool(sc.n_env, sc.A)
+    from tactics2d_amd import debug as D
+    pool = D.pool(sc.n_env, sc.A)
     sc.load(pool)
     pool.set_auto_reset(True)
     pool.set_step_chaining(2)
@@ -370,9 +373,9 @@ def test_a_failure_during_the_first_step_leaves_a_complete_checkpoint():
     after6 = [pool.download(f) for f in fields]
     for rep in range(3):
         pool.set_step_chaining(2)
-        pool.debug_chain_fault(3)
+        D.chain_fault(pool, 3)
         frag(6, 6)
-        pool.debug_chain_fault(0)
+        D.chain_fault(pool, 0)
         with pytest.raises(_ffi.T2DError) as ei:
             pool.sync()
         assert ei.value.code == _ffi.ERR_STATE and "rolled back to step 6" in str(ei.value), str(ei.value)

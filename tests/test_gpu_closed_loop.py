@@ -20,9 +20,9 @@ def _fields():
 def _reference(sc, steps):
     """one pool, one stream, the host calling the policy and the step in turn"""
     torch = pytest.importorskip("torch")
-    from tactics2d_amd.pool import ParticipantPool
+    from tactics2d_amd import debug as D
     dev = torch.device("cuda", 0)
-    pool = ParticipantPool(sc.n_env, sc.A)
+    pool = D.pool(sc.n_env, sc.A)           # (the stand-in policy is a hook of libt2d_hip_debug.so: include/t2d_debug.h)
     sc.load(pool)
     pool.set_integrator_variant("exact")
     pool.set_auto_reset(True)
@@ -30,7 +30,7 @@ def _reference(sc, steps):
     torch.cuda.synchronize()
     pool.bind_actions(act.data_ptr() + 4, act.data_ptr(), 2)
     for _ in range(steps):
-        pool._ck(pool._lib.t2d_debug_feedback_policy(pool._h, act.data_ptr(), 12.0, 0.5, 0.04, None))
+        D.feedback_policy(pool, act.data_ptr(), 12.0, 0.5, 0.04)
         pool.step(sc.interval_ms)
     out = [pool.download(f) for f in _fields()]
     pool.close()
@@ -40,10 +40,10 @@ def _reference(sc, steps):
 @pytest.mark.parametrize("groups,launcher", [(1, "thread"), (2, "thread"), (4, "threads"), (8, "threads"), (4, "graph"), (1, "graph")])
 def test_closed_loop_of_env_groups_equals_one_pool_stepped_by_the_host(groups, launcher):
     from tactics2d_amd import scenarios as S
-    from tactics2d_amd.pipeline import ClosedLoop, EnvGroups
+    from tactics2d_amd.debug import ClosedLoop, env_groups
     sc = S.mixed(96, 64, seed=23)
     want = _reference(sc, STEPS)
-    eg = EnvGroups(sc, groups)
+    eg = env_groups(sc, groups)
     eg.configure(lambda p: (p.set_integrator_variant("exact"), p.set_auto_reset(True)))
     loop = ClosedLoop(eg, launcher, sc.interval_ms, graph_steps=16)
     loop.run(STEPS // 2)
@@ -62,9 +62,9 @@ def test_closed_loop_of_env_groups_equals_one_pool_stepped_by_the_host(groups, l
 def test_closed_loop_at_the_metric_size_runs_and_matches_a_single_pool_sample():
     """4096 x 64 in 4 groups on 4 host threads, 24 steps: the first group's envs against a single pool holding just them"""
     from tactics2d_amd import scenarios as S
-    from tactics2d_amd.pipeline import ClosedLoop, EnvGroups
+    from tactics2d_amd.debug import ClosedLoop, env_groups
     sc = S.mixed(4096, 64, seed=3)
-    eg = EnvGroups(sc, 4)
+    eg = env_groups(sc, 4)
     eg.configure(lambda p: (p.set_integrator_variant("exact"), p.set_auto_reset(True)))
     loop = ClosedLoop(eg, "threads", sc.interval_ms)
     loop.run(24)

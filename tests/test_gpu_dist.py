@@ -142,7 +142,8 @@ def test_a_step_waits_for_the_gather_that_still_reads_its_record_slot():
     acts = _actions(sc)
     want = _single_pool_records(sc, acts)
     a0, a1 = _device_action_ring(sc, acts)
-    pool = ParticipantPool(sc.n_env, sc.A)
+    from tactics2d_amd import debug as D     # (the gather delay is a hook of libt2d_hip_debug.so: include/t2d_debug.h)
+    pool = D.pool(sc.n_env, sc.A)
     sc.load(pool)
     pool.set_auto_reset(True)
     pool.comm_init(pool.comm_unique_id(), 0, 1)
@@ -155,7 +156,7 @@ def test_a_step_waits_for_the_gather_that_still_reads_its_record_slot():
             pool.step(100, st.cuda_stream)
     torch.cuda.synchronize()
     steps(0, EVERY)
-    pool._ck(pool._lib.t2d_debug_delay_gather(pool._h, 30000))
+    D.delay_gather(pool, 30000)
     k = g.launch(stream=st.cuda_stream)
     from tactics2d_amd import layout as L
     steps(EVERY, L.RECORD_RING + EVERY)                       # wraps the ring onto slots 0..15 -- must wait inside t2d_step

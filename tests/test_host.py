@@ -267,3 +267,48 @@ def test_host_frame_views_and_in_use_tracking():
     assert own.lidar is None and own.obs.base is not fr.base and np.array_equal(own.status, fr.status)
     x = float(fr.obs[0, 0])            # scalars do not hold the frame
     assert not fr.in_use() and x == 0.0
+    kept = [fr]                        # the HostFrame object itself, kept by a caller: no array reference, the frame is held
+    assert fr.in_use()
+    del kept
+    assert not fr.in_use()
+
+
+def test_a_kept_host_frame_object_is_not_handed_out_again():
+    """ParticipantPool._pick_frame / _frame (no device needed: the frames are stood in by host arrays): a caller that keeps the
+    HostFrame OBJECTS of several steps -- not views of their arrays -- never sees one of them filled again (round-5 advice)."""
+    from tactics2d_amd._ffi import FrameLayout
+    from tactics2d_amd.pool import HostFrame, ParticipantPool
+    n = 3
+    lay = FrameLayout()
+    off = 256
+    for name in ("off_rel", "off_obs", "off_reward", "off_status", "off_iou", "off_frame_ms", "off_cnt_step", "off_episode"):
+        setattr(lay, name, off)
+        off += 256
+    lay.off_target = lay.off_target_heading = lay.off_lidar = -1
+    lay.bytes, lay.n_env, lay.n_beams = off, n, 0
+    pool = ParticipantPool.__new__(ParticipantPool)      # the bookkeeping alone
+    pool.frame_layout, pool.n_frames, pool._frames, pool._frame_turn = lay, 4, [None] * 4, 0
+    mem = [np.zeros(off, np.uint8) for _ in range(4)]
+
+    def step_host(fresh=True):                           # what ParticipantPool.step_host does around the library call
+        k, must_copy = pool._pick_frame(fresh)
+        if pool._frames[k] is None:
+            fr = HostFrame(mem[k], lay)
+            pool._frames[k] = fr
+            fr.calibrate()
+        fr = pool._frames[k]
+        fr.reward[:] += 1.0                              # "the library filled frame k"
+        return (fr.copy() if must_copy else fr), k
+
+    a, ka = step_host()
+    b, kb = step_host()
+    assert a is not b and ka != kb                       # `a` is held as an OBJECT: its frame is not picked again
+    c, kc = step_host()
+    d, kd = step_host()                                  # every frame but the last is held: the last one is filled and copied out
+    assert len({ka, kb, kc}) == 3 and kd == 3 and d.base is not mem[3]
+    e, ke = step_host()
+    assert ke == 3 and e is not d and d.reward[0] == 1.0 and e.reward[0] == 2.0
+    del a
+    f, kf = step_host()
+    assert kf == ka                                      # released: handed out again without a copy
+    del pool._frames, pool

@@ -59,14 +59,28 @@ def test_golden_generator_uses_the_same_columns():
     assert g.P_DELTA_T == L.P_DELTA_T_MS and g.NCOL == L.PARAM_COLS
 
 
-def _declared_functions():
-    text = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+DEBUG_HEADER = open(os.path.join(ROOT, "include", "t2d_debug.h")).read()
+
+
+def _declared_functions(header=HEADER):
+    text = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     return sorted(set(re.findall(r"\b(t2d_[a-z_0-9]+)\s*\(", text)) - {"t2d_pool", "t2d_status_config"})
 
 
+def _exported(path):
+    """dynamic symbols a shared library defines (nm -D --defined-only)"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+
+
 def test_ffi_table_covers_the_header():
-    from tactics2d_amd import _ffi
+    from tactics2d_amd import _ffi, debug
     assert sorted(_ffi.SYMBOLS) == _declared_functions()
+    assert sorted(debug.DEBUG_SYMBOLS) == _declared_functions(DEBUG_HEADER)
+    # the product header declares no test hook, and the two tables do not overlap
+    assert not [n for n in _ffi.SYMBOLS if n.startswith("t2d_debug_")] and not set(_ffi.SYMBOLS) & set(debug.DEBUG_SYMBOLS)
+    assert all(n.startswith("t2d_debug_") for n in debug.DEBUG_SYMBOLS)
 
 
 def test_shared_library_exports_every_declared_symbol():
@@ -77,6 +91,29 @@ def test_shared_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} not exported by {_ffi.LIB_PATH}"
     lib.t2d_abi_version.restype = ctypes.c_int
     assert lib.t2d_abi_version() == _enum_values()["T2D_ABI_VERSION"]
+
+
+def test_the_product_library_exports_no_test_hook_and_the_debug_library_exports_both_headers():
+    """include/t2d_debug.h (fault injection, a gather delay, the stand-in policy and its closed-loop runner, placement maps)
+    exists only in libt2d_hip_debug.so; libt2d_hip.so -- what the reference-side binding of INTEGRATION.md loads -- exports
+    exactly the product ABI."""
+    from tactics2d_amd import build, _ffi, debug
+    build.build()
+    build.build_debug_lib()
+    prod = {n for n in _exported(_ffi.LIB_PATH) if n.startswith("t2d_")}
+    assert not [n for n in prod if "debug" in n], sorted(n for n in prod if "debug" in n)
+    assert prod == set(_declared_functions()), sorted(prod ^ set(_declared_functions()))
+    dbg = {n for n in _exported(debug.DEBUG_LIB_PATH) if n.startswith("t2d_")}
+    assert dbg == set(_declared_functions()) | set(_declared_functions(DEBUG_HEADER))
+
+
+def test_no_product_module_imports_the_debug_module():
+    pkg = os.path.join(ROOT, "tactics2d_amd")
+    for f in sorted(os.listdir(pkg)):
+        if f.endswith(".py") and f != "debug.py":
+            src = open(os.path.join(pkg, f)).read()
+            assert not re.search(r"^\s*(from\s+\.\s+import\s+.*\bdebug\b|from\s+\.debug\b|import\s+tactics2d_amd\.debug|from\s+tactics2d_amd\s+import\s+.*\bdebug\b|from\s+tactics2d_amd\.debug)", src, re.M), f
+            assert "t2d_debug_" not in src.replace("t2d_debug.h", ""), f"{f} names a test hook"
 
 
 def test_status_config_struct_matches_oracle_mirror():
@@ -143,5 +180,5 @@ def test_the_build_tracks_every_kernel_source_and_header():
     import os
     from tactics2d_amd import build as B
     on_disk = set(os.listdir(B.CSRC))
-    assert {f for f in on_disk if f.endswith(".hip")} == set(B.SOURCES)
+    assert {f for f in on_disk if f.endswith(".hip")} == set(B.SOURCES) | set(B.DEBUG_SOURCES)
     assert {f for f in on_disk if f.endswith(".h")} == {h for h in B.HEADERS if os.sep not in h and "/" not in h}

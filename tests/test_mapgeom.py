@@ -121,13 +121,47 @@ def test_ring_to_convex_on_non_convex_areas():
             assert all(_convex_ccw(q) and len(q) <= mv for q in pieces)
             assert abs(sum(_area2(q) for q in pieces) - abs(_area2(np.float32(ring)))) < 1e-4
         assert len(MG.ring_to_convex(ring, 8)) <= len(MG.ring_to_convex(ring, 3))
-    sq = MG.ring_to_convex([(0, 0), (2, 0), (4, 0), (4, 3), (0, 3)], 8)   # a collinear vertex adds nothing
-    assert len(sq) == 1 and abs(_area2(sq[0]) - 24.0) < 1e-6
+    sq = MG.ring_to_convex([(0, 0), (2, 0), (4, 0), (4, 3), (0, 3)], 8)   # a collinear vertex adds no area; it stays a (straight) corner
+    assert len(sq) == 1 and abs(_area2(sq[0]) - 24.0) < 1e-6 and len(sq[0]) == 5
     with pytest.raises(ValueError):
         MG.ring_to_convex([(0, 0), (4, 4), (4, 0), (0, 4)], 8)             # a bow tie is not a simple ring
     with pytest.raises(ValueError):
         MG.ring_to_convex([(0, 0), (1, 1), (2, 2)], 8)
     assert len(MG.areas_to_convex([ell, comb], 8)) == len(MG.ring_to_convex(ell, 8)) + len(MG.ring_to_convex(comb, 8))
+
+
+def test_rings_that_share_a_straight_side_with_collinear_points_keep_those_points(oracle):
+    """two lanes given as RINGS only, side by side along a straight, densely sampled rail (the common case): the collinear
+    points of the shared rail stay corners of the pieces on both sides (no T-junction: every piece edge on the rail is matched by
+    the neighbour's reversed edge), straight corners are accepted as convex, and the union rule sees no seam"""
+    xs = np.linspace(0.0, 40.0, 11)                                    # exactly representable collinear points
+    rail = np.stack([xs, np.full_like(xs, 3.75)], 1)
+    low = np.concatenate([np.stack([xs, np.zeros_like(xs)], 1), rail[::-1]])          # ring of the lower lane (CCW)
+    up = np.concatenate([rail, np.stack([xs[::-1], np.full_like(xs, 7.5)], 1)])        # ring of the upper lane (CCW)
+    pl, pu = MG.ring_to_convex(low, 8), MG.ring_to_convex(up, 8)
+    rail_pts = {tuple(np.float32(p)) for p in rail}
+    for pieces in (pl, pu):
+        assert all(_convex_ccw(q) and 3 <= len(q) <= 8 for q in pieces)
+        assert rail_pts <= {tuple(v) for q in pieces for v in q}       # none of the rail's points was dropped
+    assert abs(sum(_area2(q) for q in pl + pu) - 2 * 40.0 * 7.5) < 1e-6
+    on_rail = lambda e: e[0] in rail_pts and e[1] in rail_pts and e[0][1] == e[1][1] == np.float32(3.75)
+    el = {(tuple(q[k]), tuple(q[(k + 1) % len(q)])) for q in pl for k in range(len(q))}
+    eu = {(tuple(q[k]), tuple(q[(k + 1) % len(q)])) for q in pu for k in range(len(q))}
+    rl, ru = {e for e in el if on_rail(e)}, {e for e in eu if on_rail(e)}
+    assert len(rl) == len(ru) == 10 and {(b, a) for a, b in rl} == ru  # the seam: ten edges, each shared exactly
+    # a body across the seam is on the lanes, wherever it sits along the rail; one over the outer edge is not
+    for x in np.linspace(3.0, 37.0, 35):
+        for h in (0.0, 0.3, np.pi / 2):
+            pose = oracle.pose_obb(float(x), 3.75, float(h), 4.5, 1.8, trig=0)
+            assert oracle.pose_in_lane_union(pose, (float(x), 3.75), pl + pu)
+        pose = oracle.pose_obb(float(x), 7.0, 0.0, 4.5, 1.8, trig=0)
+        assert not oracle.pose_in_lane_union(pose, (float(x), 7.0), pl + pu)
+    # a ring with MORE straight corners on one ear than a piece may have: cut down, nothing dropped
+    many = np.concatenate([np.stack([np.linspace(0, 30, 31), np.zeros(31)], 1), [(30.0, 5.0), (0.0, 5.0)]])
+    for mv in (4, 8):
+        pm = MG.ring_to_convex(many, mv)
+        assert all(_convex_ccw(q) and 3 <= len(q) <= mv for q in pm) and abs(sum(_area2(q) for q in pm) - 300.0) < 1e-6
+        assert {tuple(np.float32(p)) for p in many} <= {tuple(v) for q in pm for v in q}
 
 
 def test_map_boundary_and_the_duck_typed_map_adapter():

@@ -355,7 +355,7 @@ def test_lane_boundary_of_abutting_lanes_is_their_outline(oracle):
 # ---------------------------------------------------------------------------------------------------------------------
 # Certificates of the step kernel (round 3): short cuts that must never contradict the oracle's predicate.
 def _safe_rects(lanes):
-    """t2d_debug_lane_safe_rects for one env (host-only entry point of libt2d_hip.so: no device is touched)."""
+    """t2d_lane_safe_rects for one env (host-only entry point of libt2d_hip.so: no device is touched)."""
     import ctypes as C
     from tactics2d_amd import _ffi, layout as L
     lib = _ffi.lib()
@@ -364,7 +364,7 @@ def _safe_rects(lanes):
     xy = np.ascontiguousarray(np.concatenate([np.float32(q).reshape(-1, 2) for q in lanes]), np.float32)
     eo = np.array([0, len(lanes)], np.int32)
     out = np.zeros((L.SAFE_RECTS, 4), np.float32)
-    rc = lib.t2d_debug_lane_safe_rects(1, eo.ctypes.data_as(C.c_void_p), vo.ctypes.data_as(C.c_void_p),
+    rc = lib.t2d_lane_safe_rects(1, eo.ctypes.data_as(C.c_void_p), vo.ctypes.data_as(C.c_void_p),
                                        xy.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     assert rc == 0
     return out
