@@ -44,6 +44,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MI
 # VALU issue roof: a SIMD issues one wave64 VALU instruction (fp64 included: full rate on CDNA4) per 4 cycles;
 # 256 CUs x 4 SIMDs at the 2.4 GHz peak clock of the same guide
 VALU_ISSUE_PEAK_GINST = 256 * 4 * 2.4 / 4.0
+EFFECTIVE_CLOCK_GHZ = 2.26     # shader clock inside the chained step kernel (s_memtime / s_memrealtime; profiles/r06_chain_timing_frag20.json)
 SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9   # SIMD-cycles per second at the 2.4 GHz peak clock
 INTEGRATOR_BYTES = 44          # algorithmic bytes per participant-step
 COLLIDE_BYTES = 20             # + per-env geometry (computed from the scene)
@@ -233,6 +234,131 @@ class Runner:
         self.pool.close()
 
 
+def power_clock_under_load(run, mode, frag, seconds=0.6):
+    """Socket power and shader clock the SMU reports WHILE the headline launches run (amdsmi's metrics table, sampled by a
+    thread; outside `value`): whether the step's time is set by a power budget.  None when amdsmi is not importable."""
+    import threading
+    import torch
+    try:
+        import amdsmi
+        amdsmi.amdsmi_init()
+        h = amdsmi.amdsmi_get_processor_handles()[torch.cuda.current_device()]
+        cap = amdsmi.amdsmi_get_power_cap_info(h).get("power_cap")
+    except Exception as exc:   # noqa: BLE001
+        return dict(error=f"amdsmi unavailable: {exc}")
+    rows, stop = [], [False]
+
+    def loop():
+        while not stop[0]:
+            try:
+                m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+                clk = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and 0 < c < 60000]
+                rows.append((m.get("current_socket_power"), float(np.mean(clk)) if clk else None, m.get("ppt_residency_acc")))
+            except Exception:   # noqa: BLE001
+                break
+    th = threading.Thread(target=loop, daemon=True)
+    t0 = time.perf_counter()
+    run.run(mode, 64, frag)
+    torch.cuda.synchronize()
+    th.start()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        run.run(mode, 10 * frag, frag)
+        n += 1
+        if n % 4 == 0:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    stop[0] = True
+    th.join()
+    tail = rows[len(rows) // 3:]
+    pw = [r[0] for r in tail if isinstance(r[0], (int, float)) and r[0] < 60000]
+    ck = [r[1] for r in tail if r[1]]
+    ppt = [r[2] for r in rows if isinstance(r[2], (int, float))]
+    if not pw or not ck:
+        return dict(error="the SMU's metrics table held no power / clock sample", samples=len(rows))
+    return dict(power_w=float(np.mean(pw)), power_cap_w=(cap / 1e6 if isinstance(cap, (int, float)) and cap > 1e5 else cap),
+                clock_mhz_under_load=float(np.mean(ck)), ppt_residency_delta=(ppt[-1] - ppt[0] if len(ppt) > 1 else None),
+                samples=len(tail), seconds=seconds,
+                note="SMU metrics table (amdsmi) sampled while the headline launches run, outside `value`; current_gfxclks averaged "
+                     "over the XCDs.  The EFFECTIVE shader clock (s_memtime ticks per 100 MHz tick inside the kernel, = GRBM_GUI_ACTIVE "
+                     "/ duration) is ~5 % below what the SMU reports: profiles/r06_chain_timing_frag20.json")
+
+
+STRONG_CASES = (("metric", 4096, 64), ("cfg4", 2048, 32), ("cfg5", 8192, 64))   # BASELINE.json: the TOTALS its metric / configs name
+
+
+def strong_scaling(rank, world, dev, args, backend, native_gather, every, clock_warm):
+    """The FIXED-TOTAL reading of BASELINE.json's metric ("at 4096 envs x 64 agents, 1/2/4/8 GPU") and of its sharded configs
+    (cfg4 = 2048 x 32 over 4 GPUs, cfg5 = 8192 x 64 over 8): the total is cut into `world` contiguous env blocks, each rank steps
+    its block, the per-env records travel in the same all-gather as in the weak run and are INSIDE the timed region.  Same
+    protocol as `value`: barrier + synchronise on both sides, max over ranks.  Returns {case: {...}} on every rank.
+    What it will show: a 512-env shard is a one-wave-per-SIMD pool -- a latency chain per step that more GPUs do
+    not shorten -- so the fixed-total curve flattens near 2-3x at 8 GPUs while the weak curve stays linear."""
+    import torch
+    from tactics2d_amd import dist as D, layout as L
+    out = {}
+    for name, total, agents in STRONG_CASES:
+        if total % world:
+            out[f"{name}_{total}x{agents}"] = dict(skipped=f"{total} envs do not divide over {world} ranks")
+            continue
+        per = total // world
+        scene = build_scene(name, total, agents, seed=0).shard(rank * per, (rank + 1) * per)
+        run = Runner(scene, dev, args.variant, auto_reset=not args.no_reset, outputs=args.outputs, seed=2000 + rank)
+        chained = args.mode == "chain"
+        ev = max(e for e in (1, 2, 4, 8, 16, 32) if e <= max(1, min(every, args.steps, L.RECORD_RING // 2)))
+        frag = ev if world > 1 or os.environ.get("T2D_FORCE_GATHER") else max(1, min(args.fragment, L.RECORD_RING, ACTION_SETS))
+        gather = None
+        if world > 1 or os.environ.get("T2D_FORCE_GATHER"):
+            if native_gather:
+                D.NativeGather.bootstrap(run.pool, rank, world)
+                gather = D.NativeGather(run.pool, world, every=ev, device=dev)
+            else:
+                rec = torch.as_tensor(run.pool.device_array(L.F_RECORD), device=dev).view(torch.int32)
+                gather = D.ResultGather(rec, world, every=ev)
+        run.align = gather is not None
+
+        def hook(gather=gather, run=run):
+            if gather is None:
+                return
+            if native_gather:
+                gather.launch(None, run.stream.cuda_stream)
+            else:
+                with torch.cuda.stream(run.stream):
+                    gather.launch(run.k - 1)
+
+        def barrier():
+            torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+                torch.cuda.synchronize()
+
+        mode = "chain" if chained else "step"
+        clock_warm()
+        run.run(mode, args.warmup, frag, hook)
+        if gather is not None:
+            with torch.cuda.stream(run.stream):
+                gather.wait()
+        barrier()
+        t0 = time.perf_counter()
+        run.run(mode, args.steps, frag, hook)
+        if gather is not None:
+            with torch.cuda.stream(run.stream):
+                gather.wait()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            torch.distributed.all_gather(allt, t)
+            elapsed = max(float(x.item()) for x in allt)
+        out[f"{name}_{total}x{agents}"] = dict(
+            value=total * agents * args.steps / elapsed, unit="participant-steps/s", total_envs=total, envs_per_gpu=per,
+            participants_per_env=agents, us_per_step=1e6 * elapsed / args.steps, step_form=run.pool.step_form(frag) if chained else "step",
+            fragment=frag, gather_every=(ev if gather is not None else None), gather_native=(bool(native_gather) if gather is not None else None))
+        run.close()
+    return out
+
+
 def timed(runner, mode, steps, warmup, frag, clock_warm=None, reps=1):
     """wall time and HIP-event span of `steps` steps after `warmup` untimed ones: (us per step, event-span us per step)"""
     import torch
@@ -403,6 +529,7 @@ def next_rows(dev, clock_warm, metric_scene):
 
     for key, kw in (("vec_parking_env_step_numpy_us", dict(info_lidar=False)),
                     ("vec_parking_env_step_numpy_us_with_lidar_in_info", dict()),
+                    ("vec_parking_env_step_numpy_us_with_120_beams_in_info", dict(lidar_beams=120)),
                     ("vec_parking_env_step_numpy_us_generator_scenes", dict(info_lidar=False, scene_source="generator"))):
         env = VecParkingEnv(4096, max_step=200, auto_reset=True, seed=1, **kw)
         env.reset()
@@ -464,7 +591,9 @@ def next_rows(dev, clock_warm, metric_scene):
                                     "synchronisation per step -- the PCIe-inclusive rate of the path (never `value`)")
     out["host_path_note"] = ("VecParkingEnv.step at 4096 envs, host to host: numpy actions in (Box.contains checked while they are staged), "
                              "(obs, reward, terminated, truncated, infos) out as views of a pinned frame nobody holds any more -- one "
-                             "library call, no per-field copies; '_with_lidar_in_info' adds the 360-beam scan to the frame (5.9 MB per "
+                             "library call, no per-field copies; '_with_120_beams_in_info' = VecParkingEnv(lidar_beams=120): the every-third-beam scan the "
+                             "tutorial policy consumes (docs/tutorial/train_parking_demo.ipynb), bit-identical to [::3] of the 360-beam one; "
+                             "'_with_lidar_in_info' adds the 360-beam scan to the frame (5.9 MB per "
                              "step over PCIe).  parking_env_single_*: BASELINE config 1, one ParkingEnv stepped through the reference's "
                              "5-tuple API (lidar in info), resets included; compare cpu_baseline.python_loop_value (physics only)")
     return out
@@ -493,6 +622,7 @@ def main():
     ap.add_argument("--no-next-rows", action="store_true", help="skip the IDM / lidar / ParkingEnv timings")
     ap.add_argument("--no-alternates", action="store_true", help="skip timing the other step mode and the all-outputs form")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip timing the closed loop (policy kernel -> t2d_step per env group)")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the fixed-total (strong-scaling) cases")
     ap.add_argument("--no-reset", action="store_true", help="skip the device-side auto-reset")
     ap.add_argument("--idm", action="store_true", help="non-ego vehicles driven by on-device IDM controllers (row f3); "
                     "adds the idm kernel to every step (not the metric configuration)")
@@ -663,6 +793,10 @@ def main():
         run.pool.set_fused_step(True)
         run.pool.profile_enable(False)
 
+    pclk = None
+    if world == 1 and gather is None and not args.no_profile:
+        pclk = power_clock_under_load(run, mode, frag)
+
     # ---- the other ways of running the same steps, driver-timed like `value` -----------------------------------------
     alternates = None
     if world == 1 and gather is None and not args.no_alternates:
@@ -713,6 +847,15 @@ def main():
     cloop = None
     if world == 1 and rank == 0 and not args.no_closed_loop and not args.idm:
         cloop = closed_loop(scene, dev, args.variant, args.steps, args.warmup, clock_warm, args.outputs)
+    # ---- N > 1: the fixed-total (strong-scaling) reading of the same metric and of the sharded configs, every rank takes part --
+    strong = None
+    if (world > 1 or os.environ.get("T2D_FORCE_STRONG")) and args.config == "metric" and not args.idm and not args.no_strong:
+        try:
+            strong = strong_scaling(rank, world, dev, args, backend, native_gather, every, clock_warm)
+            strong["note"] = ("fixed TOTAL sizes cut into contiguous env blocks over the ranks (weak `value` above: 4096 envs PER rank); the "
+                              "all-gather of the records is inside the timed region; value = total participant-steps / max-over-ranks time")
+        except Exception as exc:   # noqa: BLE001 -- reported in the line; `value` (the contract) is already measured
+            strong = dict(error=f"rank {rank}: {exc}")
     if warm is not None:
         warm.close()
 
@@ -738,8 +881,19 @@ def main():
         dom = "step_kernel_chained" if mode == "chain" else "step_kernel"
         sq = tj.get("sq_counters_per_step", {}).get(dom) if same_cfg else None
         traffic = tj.get("hbm_bytes_per_step", {}).get(dom) if same_cfg and not stale else None
-        roof = dict(bound="valu_fp64_issue", kernel=dom, peak=VALU_ISSUE_PEAK_GINST, unit="G wave-instructions/s",
-                    peak_is="256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (fp64 is full rate)",
+        # What bounds the chained step, as MEASURED in round 6 (profiles/r06_chain_timing_frag20.json, r06_power_clock.json,
+        # r06_sq_wait_chain.json): VALU issue -- but of a SIMD that holds four wave slots of which, on average, only 2.8 are in a
+        # phase that issues: per slot and step 7 % is the dispatch gap between two workgroups, 5 % the hand-off wait, 12 % the
+        # start-up (tables + geometry record -> LDS) and 6 % the store drain.  Not power: 947 W of a 1400 W cap, no PPT residency.
+        roof = dict(bound="valu_issue_at_2.8_of_4_wave_slots_issuing", kernel=dom, peak=VALU_ISSUE_PEAK_GINST, unit="G wave-instructions/s",
+                    peak_is="256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (every class but plain 32-bit runs: "
+                            "profiles/valu_issue_cycles.json); at the EFFECTIVE clock measured inside the kernel (2.26 GHz: s_memtime per "
+                            "100 MHz tick) the peak is peak_at_measured_clock",
+                    peak_at_measured_clock=VALU_ISSUE_PEAK_GINST * EFFECTIVE_CLOCK_GHZ / 2.4, measured_clock_ghz=EFFECTIVE_CLOCK_GHZ,
+                    attribution="profiles/r06_chain_timing_frag20.json: per wave slot and step -- dispatch gap 1.2 us, hand-off wait 0.8, "
+                                "start-up 2.1, integrator 4.2, event phases 7.5, store drain + word 1.1 (sums to the step); "
+                                "profiles/r06_sq_wait_chain.json: a wave is parked 43 % of its life, issue-stalled 21 %, issuing 36 %",
+                    power_clock=pclk,
                     step_us=step_us, counters_source=src, counters_stale=bool(stale) if tj else None,
                     traffic=traffic, hbm=hbm, timed_region_event_span_ms=span_ms,
                     how="step_us (what `achieved` divides by) = HIP-event span of the timed region on the launch stream / its steps "
@@ -753,6 +907,7 @@ def main():
                         valu_insts_per_wave=insts / sq["SQ_WAVES"], insts_per_wave=sq.get("SQ_INSTS", 0) / sq["SQ_WAVES"])
             roof["frac_at_4_cycles_per_instruction"] = roof["achieved"] / VALU_ISSUE_PEAK_GINST
             roof["frac"] = roof["frac_at_4_cycles_per_instruction"]
+            roof["frac_at_measured_clock"] = roof["achieved"] / roof["peak_at_measured_clock"]
             # class-resolved: what the step's VALU instructions cost a SIMD by the MEASURED issue cost of their class
             # (profiles/valu_issue_cycles.json <- scripts/valu_roof.hip on this GPU) over the SIMD-cycles of the step
             cyc_f = os.path.join(ROOT, "profiles", "valu_issue_cycles.json")
@@ -833,6 +988,7 @@ def main():
                                parallelism=(f"env-sharded x{world}, one async all-gather of the 8 B/env result records per {every} steps"
                                             if world > 1 else "single GPU")),
                    roofline=roof, closed_loop=cloop, value_without_clock_ramp=no_ramp, alternates=alternates, gather=gather_obj,
+                   strong=strong,
                    configs=configs, next_rows=nrows,
                    check=dict(state_finite=finite,
                               flag_rates=[float((flags & b).astype(bool).mean()) for b in (1, 2, 4, 8)],

@@ -87,6 +87,10 @@ extern "C" {
 #define T2D_MODEL_KINEMATICS 0   /* SingleTrackKinematics */
 #define T2D_MODEL_DYNAMICS   1   /* SingleTrackDynamics   */
 #define T2D_MODEL_POINTMASS  2   /* PointMass, newton back-end */
+#define T2D_MODEL_POINTMASS_EULER 4   /* PointMass, euler back-end (point_mass.py:177-207, backend="euler"): vx, vy AND heading are state
+                                       * (the clipped speed is re-projected onto the previous sub-step's heading).  A rare,
+                                       * selectable second back-end: integrated by the side kernel that also takes
+                                       * T2D_MODEL_DRIFT (one launch ahead of the step launch; such pools are not chained) */
 #define T2D_MODEL_DRIFT      3   /* SingleTrackDrift (Pacejka tyres, default Tire constants); extra state
                                   * T2D_F_OMEGA_F / T2D_F_OMEGA_R; integrated by its own kernel */
 

@@ -352,12 +352,12 @@ void t2do_pointmass_euler(const double* p, double* x, double* y, double* heading
         double speed = sqrt(*vx * *vx + *vy * *vy);
         double sc = (flags & T2D_RANGE_SPEED) ? clip(speed, p[T2D_P_SPEED_LO], p[T2D_P_SPEED_HI]) : speed;
         if (fabs(speed - sc) > 1e-12) { /* :195 */
-            *vx = sc * cos(*heading);
-            *vy = sc * sin(*heading);
+            *vx = sc * T_cos(*heading);
+            *vy = sc * T_sin(*heading);
         }
         *x += *vx * dt; /* :199 */
         *y += *vy * dt;
-        *heading = atan2(*vy, *vx);
+        *heading = T_atan2(*vy, *vx);
     }
 }
 
@@ -383,7 +383,12 @@ void t2do_integrate(const double* rows, int row_stride, int n, const float* x, c
             t2do_kinematics(p, x[i], y[i], heading[i], speed[i], act0[i], act1[i], interval_ms, o);
         else if (model == T2D_MODEL_DYNAMICS)
             t2do_dynamics(p, x[i], y[i], heading[i], speed[i], act0[i], act1[i], interval_ms, o);
-        else
+        else if (model == T2D_MODEL_POINTMASS_EULER) { /* PointMass(backend="euler").step: point_mass.py:228-229 */
+            double ex = x[i], ey = y[i], eh = heading[i], evx = vx[i], evy = vy[i];
+            t2do_pointmass_euler(p, &ex, &ey, &eh, &evx, &evy, act0[i], act1[i], interval_ms);
+            o[0] = ex; o[1] = ey; o[2] = eh; o[3] = sqrt(evx * evx + evy * evy);
+            o[4] = evx; o[5] = evy; o[6] = act0[i]; o[7] = act1[i];
+        } else
             t2do_pointmass(p, x[i], y[i], vx[i], vy[i], act0[i], act1[i], interval_ms, o);
     }
 }

@@ -41,7 +41,8 @@ def child():
             best = min(best, 1e6 * (time.perf_counter() - t) / steps)
         return best
 
-    for name in ("cfg3", "cfg4", "cfg5") if os.environ.get("T2D_AB_SMALL") else ("metric", "cfg3", "cfg4", "cfg5"):
+    only = os.environ.get("T2D_AB_ONLY")   # e.g. "metric": one scene
+    for name in (only,) if only else ("cfg3", "cfg4", "cfg5") if os.environ.get("T2D_AB_SMALL") else ("metric", "cfg3", "cfg4", "cfg5"):
         sc = scene(name)
         rng = np.random.default_rng(5)
         K = 4
@@ -88,6 +89,12 @@ def child():
                 pool.set_step_chaining(True, rule)
                 for frag in (20, 100) if name == "metric" else (20,):
                     r[f"chain{frag}_rule{rule}"] = timed(chained(frag), steps)
+                if name == "metric" and rule == 1:   # what the driver's `--steps 20` sees: ONE fragment between two synchronisations
+                    def one_by_one(n, run=chained(20)):
+                        for _ in range(n // 20):
+                            run(20)
+                            torch.cuda.synchronize()
+                    r["chain20_synced_each"] = timed(one_by_one, steps)
                 if name != "metric" and os.environ.get("T2D_AB_SMALL"):   # the looping forms one by one
                     for mode, key in ((4, "pipe1"), (3, "loop")):
                         pool.set_step_chaining(mode, rule)

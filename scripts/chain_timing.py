@@ -103,6 +103,14 @@ stall_cyc = cyc[..., 18] + cyc[..., 0] + cyc[..., 19]
 frac_compute = float(1.0 - stall_cyc[S].sum() / (c1 - c0)[S].sum())
 # spread between SIMDs: a SIMD's time per step over the window
 per_simd_busy = np.bincount(np.unique(key[S], return_inverse=True)[1].ravel(), weights=life_ticks[S].ravel()) / 100.0 / steady_steps / 4.0
+# the fragment's timeline: when the waves of step k start and end, relative to the fragment's first instruction
+t00 = rt0.min()
+timeline = [dict(step=k, start_p1=float((np.quantile(rt0[k], 0.01) - t00) / 100), start_p50=float((np.median(rt0[k]) - t00) / 100),
+                 start_p99=float((np.quantile(rt0[k], 0.99) - t00) / 100), end_p50=float((np.median(rt1[k]) - t00) / 100),
+                 end_p99=float((np.quantile(rt1[k], 0.99) - t00) / 100), end_max=float((rt1[k].max() - t00) / 100),
+                 life_mean=float(life_ticks[k].mean() / 100), wait_mean=float(cyc[k][..., 18].mean() * to_us),
+                 startup_mean=float(cyc[k][..., 0].mean() * to_us))
+            for k in range(frag)]
 res = dict(
     what="chained step (collide_kernel<true,1,false,CHAIN>), metric scene %d x %d, one fragment of %d steps, steady window = steps %d..%d" % (n_env, A, frag, lo, hi - 1),
     us_per_step_hip_events_10_fragments=us_per_step_events,
@@ -119,6 +127,7 @@ res = dict(
                                     std=float(per_simd_busy.std())),
     attribution_per_slot_and_step=table, attribution_sum_us=total,
     by_env_kind=by_kind,
+    timeline_us=timeline,
     note="timing build: the stamps cost ~ +10 % wave cycles (MI355X_MICROARCH.md); read shares, not absolutes, against the product's time",
 )
 print(json.dumps(res, indent=1))

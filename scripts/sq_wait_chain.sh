@@ -15,12 +15,15 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQ_WAVES SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LEVEL_WAVES SQ_WAVE_CYCLES" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
+  if [ -n "$PASSES" ] && [ $i -gt $PASSES ]; then break; fi
   timeout 300 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d $OUT/p$i -o run -- $CMD > $OUT/p$i.log 2>&1 || echo "pass $i failed: $SET" >> $OUT/failed.txt
 done
 python - <<PY
 import csv, glob, collections, json, os
 frag = 32 if "$MODE" == "chain" else 1
-want = 'collide_kernel<true, 1, false, true' if "$MODE" == "chain" else 'collide_kernel<true, 1, false, false'
+import os
+want = os.environ.get("T2D_SQ_FILTER") or ('collide_kernel<true, 1, false, true' if "$MODE" == "chain" else 'collide_kernel<true, 1, false, false')
+steps_per_wave = int(os.environ.get("T2D_SQ_STEPS_PER_WAVE", "1"))   # (a LOOP launch: one wave walks through the fragment's steps)
 res = {"mode": "$MODE", "kernel_filter": want, "steps_per_launch": frag, "per_wave_and_step": {}, "passes": {}}
 for f in sorted(glob.glob('$OUT/p*/run_counter_collection.csv')):
     acc = collections.defaultdict(list)
@@ -36,7 +39,7 @@ for f in sorted(glob.glob('$OUT/p*/run_counter_collection.csv')):
     p = os.path.basename(os.path.dirname(f))
     res["passes"][p] = {"kernel": sorted(names), "launches": len(next(iter(acc.values()))), "per_launch": avg}
     for k, v in avg.items():
-        if k != 'SQ_WAVES' and w: res["per_wave_and_step"][k] = v / w   # (a chained launch's SQ_WAVES counts every step's waves)
+        if k != 'SQ_WAVES' and w: res["per_wave_and_step"][k] = v / w / steps_per_wave   # (a chained launch's SQ_WAVES counts every step's waves)
     # kernel durations of this pass (for the slow-down the counters cause)
     kt = glob.glob(os.path.dirname(f) + '/run_kernel_trace.csv')
     if kt:

@@ -893,6 +893,13 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
     // ParkingEnv defaults: envs/parking.py:106 (max_step 2e4), :151-163 (reward table)
     p->status_cfg = t2d_status_config{20000, 0, 0, 0, -5.0f, -1.0f, -5.0f, 5.0f, 0.001f,
                                       0, 0, 100, 0, 0.95f, 0.999f, 0.1f};
+#ifndef T2D_CHAIN_DEPTH_DEFAULT
+#define T2D_CHAIN_DEPTH_DEFAULT 1
+#endif
+    p->chain_depth = T2D_CHAIN_DEPTH_DEFAULT;
+#ifdef T2D_EXPERIMENTS   // (builds with -DT2D_EXPERIMENTS carry the instantiation; the product's depth is 1)
+    if (const char* e = getenv("T2D_CHAIN_DEPTH")) p->chain_depth = std::max(1, std::min(16, atoi(e)));
+#endif
     *out_pool = p;
     return T2D_OK;
 }
@@ -940,8 +947,9 @@ int t2d_set_param_table(t2d_pool* p, const double* rows, int32_t n_types, int32_
     for (int ty = 0; ty < n_types; ++ty) {
         const double* r = rows + (size_t)ty * row_stride;
         const int model = (int)r[T2D_P_MODEL];
-        if (model < 0 || model > T2D_MODEL_DRIFT)
+        if (model < 0 || model > T2D_MODEL_POINTMASS_EULER)
             return fail(p, T2D_ERR_INVALID, "row " + std::to_string(ty) + ": unknown model id");
+        if (model == T2D_MODEL_POINTMASS_EULER) has_drift = true;   // (integrated by the side kernel, like the drift model)
         if (model == T2D_MODEL_DRIFT) {
             has_drift = true;
             if (!(r[T2D_P_MASS] > 0.0) || !(r[T2D_P_IZ] > 0.0) || !(r[T2D_P_DRIFT_RADIUS] > 0.0) ||
@@ -951,7 +959,7 @@ int t2d_set_param_table(t2d_pool* p, const double* rows, int32_t n_types, int32_
         }
         const int dt = (int)r[T2D_P_DELTA_T_MS];
         if (dt < 1) return fail(p, T2D_ERR_INVALID, "row " + std::to_string(ty) + ": delta_t must be >= 1 ms");
-        if (model != T2D_MODEL_POINTMASS && !(r[T2D_P_WB] != 0.0))
+        if (model != T2D_MODEL_POINTMASS && model != T2D_MODEL_POINTMASS_EULER && !(r[T2D_P_WB] != 0.0))
             return fail(p, T2D_ERR_INVALID, "row " + std::to_string(ty) + ": zero wheel base");
         for (int c = 0; c < T2D_PARAM_COLS; ++c) {
             p->host_params[ty][c] = r[c];
@@ -1529,7 +1537,12 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
     if ((rc = prepare_interval(p, interval_ms, s))) return rc;
     for (int done = 0; done < n_steps && rc == T2D_OK;) {
         // one launch covers at most a ring of record slots (and a gather that still reads any of them is waited for first)
-        const int n = std::min(n_steps - done, (int)T2D_RECORD_RING);
+        int n = std::min(n_steps - done, (int)T2D_RECORD_RING);
+        // the chained form of large pools: chain_depth steps per workgroup (launches of a multiple of it; what is left over
+        // at the end of a call goes out one step per workgroup)
+        const int depth = p->chain_loop && !ego && !p->idm_on && p->chain_depth > 1 && n >= p->chain_depth && log2_pad(p->v.A) <= 6
+                              ? p->chain_depth : 1;
+        n -= n % depth;
         const int slot0 = (int)(p->step_count % T2D_RECORD_RING);
         for (int k = 0; k < n; ++k) {
             if ((rc = claim_record_slot(p, s))) return rc;
@@ -1583,6 +1596,11 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
         // t2d_set_split_step, t2d_set_step_chaining) starts them afresh, on the stream -- and every fragment carries the
         // checkpoint a failed hand-off is rolled back to
         const bool chain_form = !ego && v.loop_steps == 0;
+        v.chain_k = 0;
+        if (chain_form && !v.split_step && depth > 1) {
+            v.chain_k = depth;
+            v.loop_steps = depth;
+        }
         if (chain_form) {
             const uint32_t sig = ((uint32_t)v.chain_real_wgs << 1) | (v.split_step ? 1u : 0u) | 0x80000000u;
             if (sig != p->chain_sig) {

@@ -86,6 +86,18 @@ using namespace geom;
 #ifndef T2D_LOOP_RESUM
 #define T2D_LOOP_RESUM 0
 #endif
+#ifndef T2D_LOOP_STAGGER
+#define T2D_LOOP_STAGGER 0
+#endif
+#ifndef T2D_LOOP_PRIO
+#define T2D_LOOP_PRIO 0
+#endif
+#ifndef T2D_CHAIN_PREFETCH
+#define T2D_CHAIN_PREFETCH 0   // (measured, same box, ABAB: 16.95 / 16.42 us per step with it, 16.83 / 16.30 without -- not kept on)
+#endif
+#ifndef T2D_CHAIN_LATE_SPINS
+#define T2D_CHAIN_LATE_SPINS 1   // a chained workgroup that had to poll at least this often for its hand-off is LATE: priority 3 throughout (0 = off)
+#endif
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
 constexpr int kQueueCap = 288;  // queue entries per wave per round (also holds the broad phase's 3 x 96 staging floats)
@@ -302,7 +314,7 @@ T2D_DEV void compact_and_process(unsigned long long mask, int id_base, int own_i
 #define T2D_MARK(k)                                                                     \
     do {                                                                                \
         const unsigned long long now_ = __builtin_readcyclecounter();                   \
-        if (lane == 0) { if (LOOP) pv.dbg[wave_slot_ + k] += now_ - t_prev_; else pv.dbg[wave_slot_ + k] = now_ - t_prev_; } \
+        if (lane == 0) { if (LOOP && !(CHAIN && step_k == step_first)) pv.dbg[wave_slot_ + k] += now_ - t_prev_; else pv.dbg[wave_slot_ + k] = now_ - t_prev_; } \
         t_prev_ = now_;                                                                 \
     } while (0)
 #else
@@ -390,9 +402,10 @@ constexpr int kPipeSpinLimit = 1 << 17;   // polls (s_sleep 1 between them) befo
 // (t2d_idm_dev.h: the kernel's own functions), its acceleration goes to the pool's action field and into the integrator; a
 // lane whose env was reset does it again on the restored positions.  Same leaders, same accelerations, same states.
 template <bool WITH_STATUS, int FUSE, bool IOU = true, bool CHAIN = false, bool LOOP = false, bool SPLIT = false, int PIPE = 0, bool IDMF = false>
-__global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOOP_WAVES : T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv_arg, t2d_status_config cfg_arg,
+__global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : (LOOP && !CHAIN) ? T2D_LOOP_WAVES : T2D_COLLIDE_WAVES) void collide_kernel(PoolView pv_arg, t2d_status_config cfg_arg,
                                                                                                                    int interval_ms, int log2A) {
-    static_assert(!(CHAIN && LOOP) && (!LOOP || (FUSE >= 0 && WITH_STATUS)), "LOOP = the fused step, not combined with CHAIN");
+    static_assert(!LOOP || (FUSE >= 0 && WITH_STATUS), "LOOP = the fused step");
+    static_assert(!(CHAIN && LOOP) || (!PIPE && !SPLIT && !IDMF && !IOU), "CHAIN + LOOP = the plain chained form whose workgroups take several steps each");
     static_assert(!PIPE || (LOOP && !IOU && !SPLIT), "PIPE = a LOOP launch with integrator waves");
     static_assert(!IDMF || PIPE == 1 || (PIPE == 0 && !LOOP && !SPLIT && FUSE >= 0), "IDMF = the controller inside a PIPE = 1 launch, or ahead of the integrator of a chained one");
     static_assert(!SPLIT || (!LOOP && FUSE >= 0 && WITH_STATUS && !IOU), "SPLIT = the fused step of a plain pool, one launch or chained");
@@ -444,6 +457,8 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
     // IDMF: the integrator waves' table of their envs' positions (NaN = inactive slot) and speeds, as in idm_kernel
     __shared__ double2 s_ixy[IDMF && PIPE ? kBlock : 1];
     __shared__ float s_iv[IDMF && PIPE ? kBlock : 1];
+    // CHAIN: the workgroup found its predecessor unfinished -- its env set is on the fragment's critical path (see chain_wait)
+    __shared__ int s_late[1];
     extern __shared__ __attribute__((aligned(16))) uint32_t s_geo[];  // packed geometry record
 
     // Every kernel argument the start-up phase needs, requested in ONE scalar round trip.  Left to itself the compiler
@@ -470,10 +485,15 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
     // what this workgroup stands for: a set of EPB envs = one geometry record -- or (SPLIT) ONE env, whose record it shares
     const int unit = blockIdx.x;
     int wg = SPLIT ? unit / a_epb : unit, wave_rot = 0;
-    int step_k = CHAIN ? (int)blockIdx.y : 0;
+    // CHAIN + LOOP: workgroup (x, y) takes the steps [y k, (y + 1) k) of its envs, k = pv.loop_steps -- the dispatch gap, the
+    // hand-off, the start-up (tables and record staged once per workgroup) and the store drain are paid once per k steps
+    const int steps_here = (CHAIN && LOOP) ? pv.loop_steps : 1;
+    int step_k = CHAIN ? (int)blockIdx.y * steps_here : 0;
+    [[maybe_unused]] const int step_first = step_k;
+    [[maybe_unused]] const int step_end = CHAIN ? step_k + steps_here : (LOOP ? pv.loop_steps : 1);
     if (CHAIN && unit >= pv.chain_real_wgs) {   // padding of the grid's x extent to a multiple of 8 (see launch_step_chain)
         if (threadIdx.x == 0)
-            __hip_atomic_store(&pv.chain_done[unit], chain_word(pv.chain_base + (uint32_t)step_k + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&pv.chain_done[unit], chain_word(pv.chain_base + (uint32_t)(step_k + steps_here)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
 #ifdef T2D_DEBUG_HOOKS   // (libt2d_hip_debug.so: t2d_debug_set_step_placement)
@@ -529,10 +549,16 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
     // When the launches of several env groups overlap (pv.overlapped, t2d_step_groups) the opposite holds: a workgroup
     // that retires makes room for the next launch's, so waves past the integrator go first (0, then 2) -- 4 groups:
     // 20.0 us per step of all envs with that rule, 20.3 without priorities, 23.4 with the single-launch rule.
-    constexpr bool pipe_prio = PIPE != 0 && T2D_PIPE_PRIO >= 0;
-    const bool behind_first = pv.overlapped == 0 && !pipe_prio;
+    // LOOP without integrator waves on pools of more than two workgroups per CU (T2D_LOOP_PRIO = 1): a SIMD's four waves never
+    // retire, so "priority, then age" would let its oldest wave run ahead of the others for the whole fragment and leave the
+    // youngest to finish alone.  The priority ROTATES instead -- (step + dispatch round of the workgroup) mod 4: whenever the
+    // four are in the same step their priorities are a permutation, and over four steps each has held every level
+    // (T2D_LOOP_PRIO = 2: the single launch's phase rule, re-armed on every trip)
+    constexpr bool loop_rot = LOOP && !PIPE && T2D_LOOP_PRIO == 1;
+    constexpr bool pipe_prio = (PIPE != 0 && T2D_PIPE_PRIO >= 0) || loop_rot;
+    const bool behind_first = (pv.overlapped == 0 || (LOOP && !PIPE && T2D_LOOP_PRIO == 2)) && !pipe_prio;
     if (behind_first) __builtin_amdgcn_s_setprio(3);
-    if constexpr (pipe_prio) {
+    if constexpr (pipe_prio && !loop_rot) {
         if ((int)threadIdx.x >= PIPE * (a_epb << log2A)) __builtin_amdgcn_s_setprio(T2D_PIPE_PRIO >= 0 ? T2D_PIPE_PRIO % 10 : 0);
         else if (role_b) __builtin_amdgcn_s_setprio(T2D_PIPE_PRIO >= 0 ? (T2D_PIPE_PRIO / 10) % 10 : 0);
         else __builtin_amdgcn_s_setprio(T2D_PIPE_PRIO >= 0 ? (T2D_PIPE_PRIO / 100) % 10 : 0);
@@ -548,6 +574,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
                                                    (unsigned long long)code | ((unsigned long long)pv.ckpt_tag << 32),
                                                    __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    [[maybe_unused]] bool chain_late = false;
     auto chain_wait = [&]() {
         if (ptid == 0) {
             const uint32_t want = pv.chain_base + (uint32_t)step_k;
@@ -568,9 +595,25 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
             }
             // the previous step's stores sit in ITS XCD's L2: the sc1 loads below see them only from the same XCD
             if ((uint32_t)(w >> 32) != (uint32_t)__builtin_amdgcn_s_getreg(63508)) chain_fail(2u);
+            s_late[0] = T2D_CHAIN_LATE_SPINS > 0 && spins >= T2D_CHAIN_LATE_SPINS;
         }
         __syncthreads();
+        // A fragment lasts as long as its SLOWEST chain of workgroups (scripts/chain_timing.py, timeline: the last env set ends
+        // 28 us after the median one in a 20-step fragment): a workgroup that had to wait for its predecessor belongs to such a
+        // chain -- its waves take priority 3 for the whole step, ahead of the waves of env sets that are on time.
+        if (T2D_CHAIN_LATE_SPINS > 0 && s_late[0]) {
+            chain_late = true;
+            __builtin_amdgcn_s_setprio(3);
+        }
     };
+#if T2D_LOOP_STAGGER > 0   // (experiment: start the workgroups of dispatch round k -- the k-th on their CU -- k x T2D_LOOP_STAGGER ticks of
+    // the 100 MHz clock late, so that a SIMD's resident waves sit in different phases of the step)
+    if constexpr (LOOP && !PIPE) {
+        const long long wait = (long long)(blockIdx.x >> 8) * T2D_LOOP_STAGGER;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     if constexpr (LOOP) {
         // tables and the workgroup's geometry record: staged once, ahead of the loop, in the plainest form (kept inside
         // the loop behind a first-trip test, the staging code's lane masks were hoisted out of it and held in scalar
@@ -710,7 +753,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
                             wave_sync();   // (the table is rewritten by the next round / step)
                         }
                     }
-                    if (todo && i_valid && ((ids >> kIdsActiveShift) & 0xffu) && model != T2D_MODEL_DRIFT) {
+                    if (todo && i_valid && ((ids >> kIdsActiveShift) & 0xffu) && model < T2D_MODEL_DRIFT) {
                         auto P = [&](int col) -> double { return s_partab[col * T2D_MAX_TYPES + type]; };
                         const bool pm = model == T2D_MODEL_POINTMASS;
                         const integ::StepOut o = integ::step_participant<(FUSE > 0 ? 1 : 0)>(
@@ -798,6 +841,16 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
     // LOOP: the lane's coordinates are derived again on every trip from a laundered thread id -- as loop invariants every
     // lane mask built from them (agent == 0, agent < n_off, valid && ..., one per use) is hoisted and held in a scalar
     // register pair across the whole body (170 spilled scalars)
+    if constexpr (loop_rot) {
+        switch ((step_k + ((int)blockIdx.x >> 8)) & 3) {   // (s_setprio takes an immediate)
+            case 0: __builtin_amdgcn_s_setprio(3); break;
+            case 1: __builtin_amdgcn_s_setprio(2); break;
+            case 2: __builtin_amdgcn_s_setprio(1); break;
+            default: __builtin_amdgcn_s_setprio(0); break;
+        }
+    } else if constexpr (LOOP && !PIPE && T2D_LOOP_PRIO == 2) {
+        if (behind_first) __builtin_amdgcn_s_setprio(3);
+    }
     int tid_l = tid_outer;
     if constexpr (LOOP) asm volatile("" : "+v"(tid_l));
     const int tid = tid_l;
@@ -825,9 +878,34 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
     // the status epilogue's inputs, fetched now by the lane that will run it (agent 0): their latency
     // would otherwise sit, unhidden, at the very end of the wave
     int pre_cnt = 0, pre_frame = 0;
-    if (CHAIN && step_k > 0) chain_wait();
+    const bool carried = LOOP && step_k > step_first;   // (LOOP: the second and later trips take their inputs from registers)
+    // The plain chained form: what does not depend on the step before -- the type table, the workgroup's geometry record, this
+    // step's actions -- is requested BEFORE the wait for the hand-off, so that the poll's round trip to the L2 and theirs overlap
+    // (scripts/chain_timing.py: hand-off wait 0.8 us + start-up 2.1 us of a slot's 16.8 us were two memory round trips in a row)
+    constexpr bool PREF = CHAIN && !LOOP && !SPLIT && !IDMF && FUSE >= 0 && T2D_CHAIN_PREFETCH;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a struct: no assignment across address spaces)
+    const int n_vec = a_geo ? a_stride >> 2 : 0;
+    const T2D_GLOBAL u32x4* gsrc = (const T2D_GLOBAL u32x4*)(a_geo + (size_t)wg * a_stride);
+    [[maybe_unused]] double pf_t0 = 0.0, pf_t1 = 0.0, pf_t2 = 0.0;
+    [[maybe_unused]] float pf_a0 = 0.0f, pf_a1 = 0.0f;
+    [[maybe_unused]] u32x4 pf_geo = {0u, 0u, 0u, 0u};
+    [[maybe_unused]] const bool pref = PREF && nthreads == kBlock && n_vec <= nthreads;
+    if constexpr (PREF) {
+        if (pref) {
+            constexpr int kTabP = kTabCols * T2D_MAX_TYPES;
+            pf_t0 = a_params[ptid];
+            pf_t1 = a_params[ptid + kBlock];
+            if (ptid + 2 * kBlock < kTabP) pf_t2 = a_params[ptid + 2 * kBlock];
+            if (tid < n_vec) pf_geo = gsrc[tid];
+            if (valid) {
+                const size_t ai = (size_t)idx * a_act_stride + (size_t)step_k * (size_t)pv.chain_act_step;
+                pf_a0 = a_act0[ai];
+                pf_a1 = a_act1[ai];
+            }
+        }
+    }
+    if (CHAIN && step_k > 0 && !carried) chain_wait();
     if constexpr (CHAIN) { T2D_MARK(18); }
-    const bool carried = LOOP && step_k > 0;   // (LOOP: the second and later trips take their inputs from registers)
     if (valid && !PIPE && (!SPLIT || role == 0)) {   // (SPLIT: wave 0 loads and integrates; the others get the new state through LDS)
         if (carried) {
             ids = c_ids; fx = c_x; fy = c_y; fh = c_h; fv = c_v; fa0 = n_a0; fa1 = n_a1;
@@ -841,10 +919,15 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
             const size_t ai = (size_t)idx * a_act_stride + (MULTI ? (size_t)step_k * (size_t)pv.chain_act_step : 0);
             if (!carried) {
                 fv = ld_state<MULTI>(a_v + idx);
-                fa0 = a_act0[ai];
-                fa1 = a_act1[ai];
+                if (PREF && pref) {
+                    fa0 = pf_a0;
+                    fa1 = pf_a1;
+                } else {
+                    fa0 = a_act0[ai];
+                    fa1 = a_act1[ai];
+                }
             }
-            if (LOOP && step_k + 1 < pv.loop_steps) {   // the next trip's actions: their latency overlaps this trip
+            if (LOOP && step_k + 1 < step_end) {   // the next trip's actions: their latency overlaps this trip
                 n_a0 = a_act0[ai + (size_t)pv.chain_act_step];
                 n_a1 = a_act1[ai + (size_t)pv.chain_act_step];
             }
@@ -865,8 +948,13 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
         constexpr int kTab = kTabCols * T2D_MAX_TYPES;
         if (nthreads == kBlock) {   // the usual launch shape: 3 x 8 B per thread, no per-load bounds logic
             static_assert(kTab <= 3 * kBlock && kTab > 2 * kBlock, "staging below assumes 2 full rounds + a (possibly full) third one");
-            const double t0 = a_params[ptid], t1 = a_params[ptid + kBlock];
-            const double t2 = ptid + 2 * kBlock < kTab ? a_params[ptid + 2 * kBlock] : 0.0;
+            double t0, t1, t2;
+            if (PREF && pref) {
+                t0 = pf_t0; t1 = pf_t1; t2 = pf_t2;
+            } else {
+                t0 = a_params[ptid]; t1 = a_params[ptid + kBlock];
+                t2 = ptid + 2 * kBlock < kTab ? a_params[ptid + 2 * kBlock] : 0.0;
+            }
             s_partab[ptid] = t0;
             s_partab[ptid + kBlock] = t1;
             if (ptid + 2 * kBlock < kTab) s_partab[ptid + 2 * kBlock] = t2;
@@ -892,9 +980,6 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
         }
     }
     // geometry record -> LDS, 16-B loads
-    const int n_vec = a_geo ? a_stride >> 2 : 0;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a struct: no assignment across address spaces)
-    const T2D_GLOBAL u32x4* gsrc = (const T2D_GLOBAL u32x4*)(a_geo + (size_t)wg * a_stride);
     {
         // rounds of 16-B loads this record needs (wave-uniform): 1 for the metric scenes (<= 4 KiB per workgroup) --
         // the unrolled generic form spends more on its per-load bounds logic than on the loads
@@ -902,7 +987,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
         u32x4 geo_stage0 = {0u, 0u, 0u, 0u};
         const int gtid = SPLIT ? ptid : tid;   // (the thread's own number: SPLIT's `tid` is the participant slot)
         if (rounds <= 1) {
-            if (gtid < n_vec && rounds == 1) geo_stage0 = gsrc[gtid];
+            if (gtid < n_vec && rounds == 1) geo_stage0 = (PREF && pref) ? pf_geo : gsrc[gtid];
         } else {
             // big records (many envs or many polygons per workgroup, e.g. 32 parking lots = 30 KiB for 32 threads):
             // global_load_lds -- 16 B per lane straight into LDS at M0 + lane * 16, no staging registers -- so ALL
@@ -1005,8 +1090,8 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
         if (valid) as_global(pv.idm_leader)[idx] = lead;
         if (log2A <= 6) wave_sync(); else __syncthreads();   // (the planes are the pose phase's from here on)
     }
-    // (SingleTrackDrift lanes were integrated by drift_kernel, launched before this one)
-    if (!PIPE && FUSE >= 0 && active && ((ids >> kIdsModelShift) & 0xff) != T2D_MODEL_DRIFT && (!SPLIT || role == 0) && !(T2D_PROBE_SKIP & 64)) {
+    // (SingleTrackDrift and euler point-mass lanes were integrated by drift_kernel, launched before this one)
+    if (!PIPE && FUSE >= 0 && active && ((ids >> kIdsModelShift) & 0xff) < T2D_MODEL_DRIFT && (!SPLIT || role == 0) && !(T2D_PROBE_SKIP & 64)) {
         // ---------------- fused physics: one PhysicsModelBase.step in registers ----------------
         const int model = (ids >> kIdsModelShift) & 0xff;
         auto P = [&](int col) -> double { return s_partab[col * T2D_MAX_TYPES + type]; };
@@ -1032,7 +1117,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
                 }
             }
         }
-        const integ::StepOut o = integ::step_participant<(FUSE > 0 ? 1 : 0), (!LOOP || T2D_LOOP_RESUM)>(
+        const integ::StepOut o = integ::step_participant<(FUSE > 0 ? 1 : 0), (!LOOP || CHAIN || T2D_LOOP_RESUM)>(
             model, P, (double)fx, (double)fy, (double)fh, (double)fv, pvx, pvy, (double)fa0, (double)fa1, interval_ms, pv.interval_s);
         fx = (float)o.x;
         fy = (float)o.y;
@@ -1310,7 +1395,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
     }
     // (SPLIT: one pass -- wave 0 takes the pair stage, the others the polygon stages, each its part: see below)
     for (int stage_it = 0; stage_it < (SPLIT ? 1 : 2); ++stage_it) {
-    if (!pipe_prio) {
+    if (!pipe_prio && !(CHAIN && chain_late)) {
         if (behind_first && stage_it == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
     }
     if (SPLIT ? role == 0 : ((stage_it == 0) != polys_first && !role_b)) {
@@ -1501,7 +1586,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
 
     }
     }
-    if (behind_first) __builtin_amdgcn_s_setprio(0);
+    if (behind_first && !(CHAIN && chain_late)) __builtin_amdgcn_s_setprio(0);
     // ---------------- phase 3: reduce + status epilogue ------------------------------------
     // every kernel argument the epilogue touches, requested together (see the start-up phase): the status lane's chain
     // and the restore of a finished env are the last thing a wave does, with nothing behind them to hide a scalar round
@@ -1867,7 +1952,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
     if constexpr (PIPE != 0) {
         if (!role_b) pipe_post(&s_seq_e[tid >> 6], (uint32_t)step_k + 1u);   // this step's verdicts are in s_dec
     }
-    if (++step_k >= pv.loop_steps) break;
+    if (++step_k >= step_end) break;
     }
     if (CHAIN) {   // this step of these envs is complete: every store above is in the L2 before the word moves
 #ifdef T2D_TIMING
@@ -1876,7 +1961,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : LOOP ? T2D_LOO
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (ptid == 0) {
-            unsigned long long w = chain_word(pv.chain_base + (uint32_t)step_k + 1u);
+            unsigned long long w = chain_word(pv.chain_base + (uint32_t)step_k + (LOOP ? 0u : 1u));   // (LOOP: step_k = one past its last step)
             // test hook (t2d_debug_chain_fault): workgroup 1 hands its step 1 over with a foreign XCC id (1) / not at all (2);
             // 3: it hands its step 0 over with a foreign XCC id -- the failure is then posted while the fragment's first
             // step is still being dispatched on a grid larger than the device holds
@@ -1942,6 +2027,17 @@ hipError_t launch_step_chain(const PoolView& v, const t2d_status_config& cfg, in
         else hipLaunchKernelGGL((collide_kernel<true, 1, false, true, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
         return hipGetLastError();
     }
+#ifdef T2D_EXPERIMENTS   // (measured in round 6 and not shipped: profiles/r06_ab_chain_depth.txt)
+    if (v.chain_k > 1) {   // the chained form, chain_k steps per workgroup: grid (env sets, n_steps / chain_k)
+        if (log2A > 6 || v.idm_rows || n_steps % v.chain_k) return hipErrorInvalidValue;
+        const int real = (v.n_env + EPB - 1) / EPB, padded = (real + 7) & ~7;
+        const dim3 grid(padded, n_steps / v.chain_k), block(EPB << log2A);
+        const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
+        if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, true, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        else hipLaunchKernelGGL((collide_kernel<true, 1, false, true, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        return hipGetLastError();
+    }
+#endif
     if (v.loop_steps > 0 && v.pipe_step) {   // ... with a second set of waves that integrates a step ahead
         const dim3 grid((v.n_env + EPB - 1) / EPB), block(2 * (EPB << log2A));
         const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;

@@ -79,9 +79,55 @@ __global__ __launch_bounds__(kDriftBlock) void drift_kernel(PoolView pv, int int
     const int i = blockIdx.x * kDriftBlock + threadIdx.x;
     if (i >= pv.N) return;
     const uint32_t ids = pv.ids[i];
-    if (!((ids >> kIdsActiveShift) & 0xffu) || ((ids >> kIdsModelShift) & 0xff) != T2D_MODEL_DRIFT) return;
+    const int model = (ids >> kIdsModelShift) & 0xff;
+    if (!((ids >> kIdsActiveShift) & 0xffu) || model < T2D_MODEL_DRIFT) return;
     const int type = (ids >> kIdsTypeShift) & 0xff;
     auto P = [&](int col) -> double { return pv.params[col * T2D_MAX_TYPES + type]; };
+    if (model == T2D_MODEL_POINTMASS_EULER) {
+        // PointMass._step_euler (physics/point_mass.py:177-207): per sub-step v += a h; speed clipped -- and, when the clip
+        // moved it by more than 1e-12, the velocity re-projected onto the heading of the PREVIOUS sub-step (:195-197) --;
+        // position += v h; heading = atan2(vy, vx).  interval // delta_t sub-steps of delta_t and one of the remainder.
+        const bool idm = pv.idm_ctrl && pv.idm_ctrl[i] != T2D_IDM_NONE;
+        const double ax = (double)(idm ? pv.own_act0[i] : pv.act0[(size_t)i * pv.act_stride]),
+                     ay = (double)(idm ? pv.own_act1[i] : pv.act1[(size_t)i * pv.act_stride]);
+        double x = (double)pv.x[i], y = (double)pv.y[i], heading = (double)pv.heading[i];
+        double vx = (double)pv.vx[i], vy = (double)pv.vy[i];
+        const bool clip_s = (int)P(T2D_P_RANGE_FLAGS) & T2D_RANGE_SPEED;
+        const double lo = P(T2D_P_SPEED_LO), hi = P(T2D_P_SPEED_HI);
+        const int delta_t = (int)P(T2D_P_DELTA_T_MS);
+        const int n_sub = interval_ms / delta_t, rem = interval_ms % delta_t;
+        for (int k = 0; k <= n_sub; ++k) {
+            double h = (double)delta_t / 1000;
+            if (k == n_sub) {
+                if (rem <= 0) break;
+                h = (double)rem / 1000;
+            }
+            vx += ax * h;
+            vy += ay * h;
+            const double speed = __builtin_sqrt(vx * vx + vy * vy);   // np.linalg.norm([vx, vy])
+            const double sc = clip_s ? clipd(speed, lo, hi) : speed;
+            if (__builtin_fabs(speed - sc) > 1e-12) {
+                double sn, cs;
+                sincos_det(heading, sn, cs);
+                vx = sc * cs;
+                vy = sc * sn;
+            }
+            x += vx * h;
+            y += vy * h;
+            heading = atan2_det(vy, vx);
+        }
+        pv.x[i] = (float)x;
+        pv.y[i] = (float)y;
+        pv.heading[i] = (float)heading;
+        pv.speed[i] = (float)__builtin_sqrt(vx * vx + vy * vy);   // State.speed, lazily ||(vx, vy)|| (state.py:135-150)
+        pv.vx[i] = (float)vx;
+        pv.vy[i] = (float)vy;
+        if (pv.out_mask & T2D_OUT_APPLIED) {
+            pv.applied0[i] = (float)ax;
+            pv.applied1[i] = (float)ay;
+        }
+        return;
+    }
     double x = (double)pv.x[i], y = (double)pv.y[i], phi = (double)pv.heading[i], v = (double)pv.speed[i];
     double omega_wf = (double)pv.omega_f[i], omega_wr = (double)pv.omega_r[i];
     const bool idm_lane = pv.idm_ctrl && pv.idm_ctrl[i] != T2D_IDM_NONE;   // IDM lane while caller actions are bound

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(PIPE ? 2 * kEgoBlock : kEgoBlock, 2) void ego_step_
                         nx = x; ny = y; nh = h; nv = v; nvx = vx; nvy = vy;
                         moved = false; has_vel = false;
                     }
-                    if (todo && live && ((ids >> kIdsActiveShift) & 0xffu) && model != T2D_MODEL_DRIFT) {
+                    if (todo && live && ((ids >> kIdsActiveShift) & 0xffu) && model < T2D_MODEL_DRIFT) {
                         auto P = [&](int col) -> double { return ia->params[col * T2D_MAX_TYPES + type]; };
                         const bool pm = model == T2D_MODEL_POINTMASS;
                         const integ::StepOut o = integ::step_participant<VARIANT>(model, P, (double)x, (double)y, (double)h, (double)v,
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(PIPE ? 2 * kEgoBlock : kEgoBlock, 2) void ego_step_
     auto P = [&](int col) -> double { return pv.params[col * T2D_MAX_TYPES + type]; };
 
     // ---------------- physics: one PhysicsModelBase.step, the group's lanes all the same --------------------------
-    if (!PIPE && active && model != T2D_MODEL_DRIFT) {   // (SingleTrackDrift participants are integrated by drift_kernel)
+    if (!PIPE && active && model < T2D_MODEL_DRIFT) {   // (SingleTrackDrift participants are integrated by drift_kernel)
         double pvx = 0.0, pvy = 0.0;
         if (model == T2D_MODEL_POINTMASS) {
             pvx = (double)ld_state<LOOP>(G(pv.vx) + idx);

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(PoolView pv, int inte
     if (!active) return;
     const int type = (ids >> kIdsTypeShift) & 0xff;
     const int model = (ids >> kIdsModelShift) & 0xff;
-    if (model == T2D_MODEL_DRIFT) return;  // integrated by drift_kernel (t2d_drift.hip)
+    if (model >= T2D_MODEL_DRIFT) return;  // SingleTrackDrift, PointMass(backend="euler"): integrated by drift_kernel (t2d_drift.hip)
     auto P = [&](int col) -> double { return s_par[col * T2D_MAX_TYPES + type]; };
 
     StepOut o;

@@ -112,6 +112,7 @@ struct PoolView {
     int32_t split_step;         // the step launch gives every env a workgroup of its own (SPLIT form, small pools of 64-agent envs)
     int32_t loop_steps;         // > 0: the LOOP form -- every workgroup walks through this many steps itself (small pools)
     int32_t pipe_step;          // LOOP form with integrator waves running a step ahead of the event waves (PIPE)
+    int32_t chain_k;            // > 1: the chained form with workgroups that take chain_k (= loop_steps) consecutive steps each
     int64_t chain_act_step;     // elements between the action sets of consecutive steps (0: the same actions every step)
     uint2* record_ring;         // the whole ring of per-env result records; step k writes slot (record_slot0 + k) % ring
     int32_t record_slot0;
@@ -314,6 +315,7 @@ struct t2d_pool {
     bool ckpt_armed = false;       // every multi-step launch since the last quiesce was a CHAIN launch with a checkpoint
     uint32_t chain_sig = 0;        // shape (workgroups, split) of the last CHAIN launch whose counters d_chain holds; 0 = none
     uint32_t chain_fault = 0;      // t2d_debug_chain_fault
+    int chain_depth = 1;           // steps per workgroup of the chained form of large pools (T2D_CHAIN_DEPTH in the environment)
     int device_cus = 0;            // compute units of the pool's device (read once)
     // result gather (the one collective of the path): RCCL communicator + a stream of its own, so that the steps that
     // follow a fragment do not wait for its all-gather; slot_event[k] != null = a gather that reads record slot k was

@@ -56,7 +56,7 @@ class VecParkingEnv:
     _discrete_actions = {1: (0, 0), 2: (-0.5, 0), 3: (0.5, 0), 4: (0, 1), 5: (0, -1)}  # parking.py:95
 
     def __init__(self, n_envs, max_step=int(2e4), continuous=True, auto_reset=False, seed=0, device_id=0,
-                 scene_source="layout", type_proportion=0.5, info_lidar=True, copy=True, zero_copy=None):
+                 scene_source="layout", type_proportion=0.5, info_lidar=True, copy=True, zero_copy=None, lidar_beams=360):
         """scene_source: "generator" = the device-side ParkingLotGenerator (tactics2d_amd.generator; bay and
         parallel scenes with the reference's rejection sampler, `type_proportion` as in envs/parking.py:331-333),
         "layout" = the fixed bay layout of scenarios.parking (BASELINE config 2).
@@ -65,7 +65,11 @@ class VecParkingEnv:
         envs the 360 floats per env are 5.9 MB per step over PCIe).  The arrays handed out are views of pinned host frames:
         copy=True (default) fills a frame nobody holds a view of any more -- as good as fresh arrays, without a memcpy (a
         caller that keeps many steps' results by reference gets real copies once the four frames are held); copy=False
-        takes the frames in turn (valid for three further steps).  zero_copy: the kernels read the actions from / write
+        takes the frames in turn (valid for three further steps); copy="always" hands out arrays that OWN their memory (one
+        memcpy of the frame per step: nothing the caller holds is ever touched again, whatever it keeps and however).
+        lidar_beams: beams of the scan in info["lidar"] / step_torch()["lidar"], a divisor of the reference's 360
+        (envs/parking.py:303-304): the scan is then exactly `full_scan[:, ::360 // lidar_beams]` -- the tutorial policy keeps
+        every third beam (docs/tutorial/train_parking_demo.ipynb), i.e. lidar_beams=120 moves a third of the bytes.  zero_copy: the kernels read the actions from / write
         the frame to mapped host memory instead of copy commands (None = for pools of at most 16384 envs; beyond, the
         8 B per env of the actions would cross PCIe inside the step kernel)."""
         if scene_source not in ("layout", "generator"):
@@ -78,7 +82,13 @@ class VecParkingEnv:
         self.continuous = continuous
         self.auto_reset = auto_reset
         self.info_lidar = bool(info_lidar)
-        self.copy = bool(copy)
+        if copy not in (True, False, "always"):
+            raise ValueError('copy must be True, False or "always"')
+        self.copy = copy is True
+        self.copy_always = copy == "always"
+        self.lidar_beams = int(lidar_beams)
+        if self.lidar_beams < 1 or 360 % self.lidar_beams:
+            raise ValueError("lidar_beams must divide 360 (a regular subset of the reference's scan)")
         self.zero_copy = self.n_envs <= 16384 if zero_copy is None else bool(zero_copy)
         self.observation_space = Box(np.full(6, -np.inf), np.full(6, np.inf))
         self.action_space = Box([-self._max_steer, -self._max_accel], [self._max_steer, self._max_accel])
@@ -125,12 +135,13 @@ class VecParkingEnv:
         m.pool.bind_actions(None, None)   # a step_torch binding does not outlive the episode set-up
         m.pool.set_auto_reset(self.auto_reset)
         # SingleLineLidar(perception_range=20, freq_detect=360 * 10)  envs/parking.py:303-304,422-431
-        m.pool.lidar_config(360, 20.0, include_participants=False)
+        m.pool.lidar_config(self.lidar_beams, 20.0, include_participants=False, subsample_of=360)
         # the target area changes under the caller only when scenes are regenerated on the device: the frame carries it then
         self._moving_targets = self.scene_source == "generator" and self.auto_reset
         m.pool.frame_config(lidar=self.info_lidar, target=self._moving_targets, zero_copy=self.zero_copy)
         self._target_area, self._target_heading = self._scene.target, self._scene.target_heading
-        fr = self._last = m.pool.frame_fetch(fresh=self.copy)
+        fr = m.pool.frame_fetch(fresh=self.copy)
+        fr = self._last = fr.copy() if self.copy_always else fr
         return fr.obs, self._infos(fr)
 
     @property
@@ -161,7 +172,8 @@ class VecParkingEnv:
             raise RuntimeError("call reset() first")
         a = self._to_continuous(actions)
         try:
-            fr = self._last = self.scenario_manager.pool.step_host(a, 100, action_box=self._action_box, fresh=self.copy)
+            fr = self.scenario_manager.pool.step_host(a, 100, action_box=self._action_box, fresh=self.copy)
+            fr = self._last = fr.copy() if self.copy_always else fr
         except T2DError as exc:
             if exc.code == ERR_ACTION:
                 raise InvalidAction(f"Action {actions} is not in the action space.") from None
@@ -174,7 +186,7 @@ class VecParkingEnv:
         accel); nothing is copied to the host and nothing synchronises.  Returns a dict of torch tensors that are
         ZERO-COPY VIEWS of the pool (valid until the next step): state [6 x n_envs] columns (vx, vy as written by the ego's
         SingleTrackKinematics -- a dynamics / drift ego leaves those two fields alone, include/t2d.h), reward, status (u8 [n, 4]:
-        scenario, traffic, terminated, truncated), iou, and `lidar` [n_envs, 360] written by the scan kernel straight
+        scenario, traffic, terminated, truncated), iou, and `lidar` [n_envs, lidar_beams] written by the scan kernel straight
         into a tensor owned by this env -- the observation buffer handed back to the policy.  Out-of-range actions are
         the caller's responsibility here (the numpy `step` raises InvalidAction like the reference)."""
         import torch
@@ -196,7 +208,7 @@ class VecParkingEnv:
             pool.bind_actions(base + 4, base, stride=2)
             pool.step(100, st.cuda_stream)
             if getattr(self, "_t_lidar", None) is None or self._t_lidar.device != dev:
-                self._t_lidar = torch.empty((self.n_envs, 360), dtype=torch.float32, device=dev)
+                self._t_lidar = torch.empty((self.n_envs, self.lidar_beams), dtype=torch.float32, device=dev)
                 view = lambda f: torch.as_tensor(pool.device_array(f), device=dev)
                 self._t_views = dict(x=view(L.F_X), y=view(L.F_Y), heading=view(L.F_HEADING), speed=view(L.F_SPEED),
                                      vx=view(L.F_VX), vy=view(L.F_VY), reward=view(L.F_REWARD), status=view(L.F_STATUS),

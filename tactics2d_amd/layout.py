@@ -9,7 +9,7 @@ P_DELTA_T_MS, P_SHAPE, P_LENGTH, P_WIDTH = 17, 18, 19, 20
 PARAM_COLS = 24
 MAX_TYPES = 32
 RANGE_STEER, RANGE_SPEED, RANGE_ACCEL = 1, 2, 4
-MODEL_KINEMATICS, MODEL_DYNAMICS, MODEL_POINTMASS, MODEL_DRIFT = 0, 1, 2, 3
+MODEL_KINEMATICS, MODEL_DYNAMICS, MODEL_POINTMASS, MODEL_DRIFT, MODEL_POINTMASS_EULER = 0, 1, 2, 3, 4
 P_DRIFT_TSB, P_DRIFT_TSE, P_DRIFT_RADIUS, P_DRIFT_IYW = 15, 16, 22, 23   # SingleTrackDrift rows only
 P_DT_S, P_SUBSTEPS = 22, 23   # rows of the other models: derived by the library (sub-step in s, sub-step counts of the launch)
 MAX_INTERVAL_MS = 32767

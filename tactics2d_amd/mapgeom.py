@@ -128,8 +128,17 @@ def _split_large(P, poly, max_verts):
     return _split_large(P, best[1], max_verts) + _split_large(P, best[2], max_verts)
 
 
-def _merge(P, polys, max_verts):
-    """Hertel-Mehlhorn style: join two pieces across a shared edge while the result stays convex and small enough"""
+def _strict_corners(P, idx):
+    """the vertices of the convex index polygon that are real corners (a turn), in order"""
+    n = len(idx)
+    return [idx[i] for i in range(n) if _orient(P[idx[i - 1]], P[idx[i]], P[idx[(i + 1) % n]]) != 0.0]
+
+
+def _merge(P, polys, max_verts, strict=False):
+    """Hertel-Mehlhorn style: join two pieces across a shared edge while the result stays convex and small enough.
+    strict=True counts only the REAL corners of the joined piece against max_verts (its straight corners -- vertices lying
+    exactly on an edge -- are kept while merging, so that further neighbours still find their shared edges, and dropped by
+    the caller at the end): consecutive quads of a straight strip become one quad."""
     polys = [list(p) for p in polys]
     changed = True
     while changed:
@@ -143,13 +152,13 @@ def _merge(P, polys, max_verts):
             if other is None:
                 continue
             pj, kb = other
-            if pi == pj or len(polys[pi]) + len(polys[pj]) - 2 > max_verts:
+            if pi == pj or (not strict and len(polys[pi]) + len(polys[pj]) - 2 > max_verts):
                 continue
             p, q = polys[pi], polys[pj]
             # p runs ... a, b ...; q runs ... b, a ...: walk p from b round to a, then q from a round to b (ends dropped)
             m = [p[(ka + 1 + t) % len(p)] for t in range(len(p))] + [q[(kb + 2 + t) % len(q)] for t in range(len(q) - 2)]
             # straight corners at the two joints are kept (shared vertices stay shared); the piece must be convex
-            if _is_convex(P, m):
+            if _is_convex(P, m) and (not strict or len(_strict_corners(P, m)) <= max_verts):
                 polys[pi] = m
                 polys.pop(pj)
                 changed = True
@@ -186,12 +195,57 @@ def areas_to_convex(polys, max_verts=8):
 
 
 # ---------------------------------------------------------------------------------------------------------------- lanes
-def lanes_from_sides(left_xy, right_xy, max_verts=4):
+def simplify_polyline(xy, tol):
+    """Douglas-Peucker on a side polyline: drops points that lie within `tol` metres of the chord of the points kept (end points
+    always stay).  Direction-independent -- the polyline is walked from its lexicographically smaller end -- so two lanes that
+    share a rail (map/element/lane.py:117-130: the left side of one is the right side of the other) keep the SAME points and
+    still abut exactly.  tol = 0 drops only points that are exactly collinear in fp32 coordinates."""
+    P = _dedup(_f32(xy))
+    if len(P) <= 2:
+        return np.float32(P)
+    flip = tuple(P[0]) > tuple(P[-1])
+    if flip:
+        P = P[::-1]
+    keep = np.zeros(len(P), bool)
+    keep[0] = keep[-1] = True
+    stack = [(0, len(P) - 1)]
+    while stack:
+        a, b = stack.pop()
+        if b - a < 2:
+            continue
+        d = P[b] - P[a]
+        L = float(np.hypot(d[0], d[1]))
+        q = P[a + 1:b] - P[a]
+        # distance to the chord's line inside its span, to the nearer end point beyond it
+        t = np.clip((q @ d) / (L * L), 0.0, 1.0) if L > 0.0 else np.zeros(len(q))
+        dist = np.hypot(q[:, 0] - t * d[0], q[:, 1] - t * d[1])
+        k = int(np.argmax(dist))
+        exact0 = tol == 0.0 and all(_orient(P[a], P[a + 1 + j], P[b]) == 0.0 and 0.0 < t[j] < 1.0 for j in range(len(q)))
+        if (tol > 0.0 and dist[k] <= tol) or exact0:
+            continue
+        if tol == 0.0:      # split at the first point that is not exactly on the chord
+            k = next(j for j in range(len(q)) if not (_orient(P[a], P[a + 1 + j], P[b]) == 0.0 and 0.0 < t[j] < 1.0))
+        keep[a + 1 + k] = True
+        stack += [(a, a + 1 + k), (a + 1 + k, b)]
+    out = P[keep]
+    return np.float32(out[::-1] if flip else out)
+
+
+def lanes_from_sides(left_xy, right_xy, max_verts=4, simplify_tol=None):
     """One lane of the reference -- its two side polylines, same direction of travel (Lane.left_side / right_side,
     map/element/lane.py:117-130) -- as a strip of exactly-abutting convex polygons (quads where the sides allow, triangles where
     one side has more points than the other): consecutive cross cuts L[i] - R[j] advance along whichever side keeps the cut
     short, so the pieces follow the lane instead of fanning out from one corner.  Falls back to ear clipping of the ring
-    left + reversed(right) when a cut would leave the lane (sides that fold back).  Returns float32 arrays (n, 2), CCW."""
+    left + reversed(right) when a cut would leave the lane (sides that fold back).  Returns float32 arrays (n, 2), CCW.
+    Consecutive pieces of a STRAIGHT stretch -- cut points exactly collinear on both sides, in the fp32 coordinates the pool
+    stores -- are joined and lose their straight corners: an axis-aligned 40-point lanelet is one quad, not 39 (the union, hence
+    every off-lane verdict, is unchanged; a neighbour that keeps a point on such an edge meets it in an exact T-junction,
+    which the lane-union boundary walk of t2d_set_lane_geometry covers by construction: collinear, opposite direction).
+    simplify_tol (metres, None = off): first drop the side points within that distance of the chord of their neighbours
+    (simplify_polyline: the same result for both lanes of a shared rail) -- a straight lanelet in any direction becomes one quad,
+    a 60-m curve keeps a point every ~0.7 m at 1 mm; the lane's outline moves by at most that much."""
+    if simplify_tol is not None:
+        left_xy, right_xy = simplify_polyline(left_xy, simplify_tol), simplify_polyline(right_xy, simplify_tol)
     Lp, Rp = _dedup(_f32(left_xy)), _dedup(_f32(right_xy))
     if len(Lp) < 2 or len(Rp) < 2:
         raise ValueError("each side needs at least 2 distinct points")
@@ -222,7 +276,8 @@ def lanes_from_sides(left_xy, right_xy, max_verts=4):
         ok = abs(total - abs(_area2(ring))) <= 1e-9 * abs(_area2(ring))
     if not ok or not tris:
         return ring_to_convex(ring, max(max_verts, 3))
-    return [np.float32(P[list(p)]) for p in _merge(P, tris, max_verts)]
+    pieces = _merge(P, _merge(P, tris, max_verts), max_verts, strict=True)
+    return [np.float32(P[_strict_corners(P, p)]) for p in pieces]
 
 
 # ---------------------------------------------------------------------------------------------------------------- boundary
@@ -245,7 +300,7 @@ def _coords(geom):
     return a[:, :2] if a.size else None
 
 
-def from_reference_map(map_, origin=(0.0, 0.0), obstacle_subtypes=("obstacle",), max_lane_verts=4, max_area_verts=8):
+def from_reference_map(map_, origin=(0.0, 0.0), obstacle_subtypes=("obstacle",), max_lane_verts=4, max_area_verts=8, simplify_tol=None):
     """Flatten a tactics2d `Map` (duck-typed: `.lanes`, `.areas`, optionally `.nodes` / `.roadlines`, dicts of elements with the
     reference's attributes) for ONE env: returns dict(lanes=[convex polys], static=[convex polys], boundary=(xmin, xmax, ymin,
     ymax)).  `origin` is subtracted first: the pool stores env-local fp32 coordinates and wants |x|, |y| < 256 m.
@@ -256,7 +311,7 @@ def from_reference_map(map_, origin=(0.0, 0.0), obstacle_subtypes=("obstacle",),
     for lane in getattr(map_, "lanes", {}).values():
         left, right = _coords(getattr(lane, "left_side", None)), _coords(getattr(lane, "right_side", None))
         if left is not None and right is not None:
-            lanes.extend(lanes_from_sides(left - o, right - o, max_lane_verts))
+            lanes.extend(lanes_from_sides(left - o, right - o, max_lane_verts, simplify_tol))
             pts += [left - o, right - o]
         else:
             ring = _coords(getattr(lane, "geometry", None))

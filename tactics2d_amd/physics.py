@@ -315,11 +315,13 @@ class PointMass(_BatchedModel):
         self.accel_range = _pointmass_range(accel_range)
         self.interval = interval
         self.delta_t = _resolve_delta_t(delta_t, interval)
-        if backend != "newton":
-            # the euler back-end only exists as a test cross-check in the reference
-            # (point_mass.py:18-19, tests/test_physics.py:224); the kernels implement newton.
-            logging.warning(f"Backend {backend} is not accelerated. Using `newton` instead.")
-        self.backend = "newton"
+        if backend not in self.backends:   # point_mass.py:77-81
+            logging.warning(f"Unsupported backend {backend}. Using `newton` instead.")
+            backend = "newton"
+        self.backend = backend
+        # (the euler back-end -- point_mass.py:177-207 -- is T2D_MODEL_POINTMASS_EULER on the device: integrated by the side
+        # kernel that also takes the drift model, a launch ahead of the step launch)
+        self.model_id = L.MODEL_POINTMASS_EULER if backend == "euler" else L.MODEL_POINTMASS
 
     def param_row(self, shape=L.SHAPE_CIRCLE, length=0.0, width=0.0):
         r = np.zeros(L.PARAM_COLS)
@@ -343,7 +345,9 @@ class PointMass(_BatchedModel):
         pool = self._pool(n)
         vx, vy = state.velocity
         z = np.zeros(n, np.float32)
-        pool.reset(state.x, state.y, z, z, np.zeros(n, np.uint8), vx=vx, vy=vy)
+        # (the euler back-end re-projects a clipped speed onto state.heading, point_mass.py:195-197: heading is state there)
+        h = np.asarray(state.heading, np.float32) if self.backend == "euler" else z
+        pool.reset(state.x, state.y, h, z, np.zeros(n, np.uint8), vx=vx, vy=vy)
         ax, ay = accel
         pool.set_actions(np.broadcast_to(np.asarray(ax, np.float32), (n,)),
                          np.broadcast_to(np.asarray(ay, np.float32), (n,)))

@@ -164,9 +164,16 @@ class ParticipantPool:
         c = _arr(centroid, np.float32, 2 * self.n_env, "centroid")
         self._ck(self._lib.t2d_set_target_areas(self._h, _p(t), _p(c)))
 
-    def lidar_config(self, n_beams=360, max_range=20.0, include_participants=False):
-        """SingleLineLidar of every ego; beam tables come from numpy like the reference's linspace/sin/cos."""
-        th = np.linspace(0, 2 * np.pi, int(n_beams), endpoint=False)
+    def lidar_config(self, n_beams=360, max_range=20.0, include_participants=False, subsample_of=None):
+        """SingleLineLidar of every ego; beam tables come from numpy like the reference's linspace/sin/cos.
+        subsample_of = N: the n_beams beams are every (N / n_beams)-th beam of the N-beam scan -- the SAME angles, so the scan
+        equals `full_scan[:, ::N // n_beams]` bit for bit (what the tutorial policy keeps of ParkingEnv's 360 beams)."""
+        if subsample_of is None:
+            th = np.linspace(0, 2 * np.pi, int(n_beams), endpoint=False)
+        else:
+            if int(subsample_of) % int(n_beams):
+                raise ValueError(f"{n_beams} beams are not a regular subset of {subsample_of}")
+            th = np.linspace(0, 2 * np.pi, int(subsample_of), endpoint=False)[::int(subsample_of) // int(n_beams)]
         bs, bc = np.ascontiguousarray(np.sin(th)), np.ascontiguousarray(np.cos(th))
         self._ck(self._lib.t2d_lidar_config(self._h, int(n_beams), float(max_range), int(bool(include_participants)),
                                             _p(bs), _p(bc)))

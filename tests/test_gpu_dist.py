@@ -270,6 +270,30 @@ def test_bench_line_holds_a_gather_inside_the_timed_region_whatever_the_step_cou
         assert g["every"] == want_every and g["gathers_in_timed_region"] >= want_gathers, g
 
 
+def test_two_rank_bench_line_carries_the_weak_value_and_the_fixed_total_cases():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on ONE device with
+    gloo (T2D_DIST_BACKEND / T2D_FORCE_DEVICE: the records travel through torch.distributed, everything else is the N > 1 code
+    path): the line keeps the weak-scaling contract (`scaling: "weak"`, value over all ranks) and carries, under `strong`, the
+    fixed-total cases BASELINE.json names -- the metric at 4096 x 64 in total, cfg4 2048 x 32, cfg5 8192 x 64 -- each with the
+    gather inside its timed region."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, T2D_DIST_BACKEND="gloo", T2D_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--envs", "1024", "--no-profile", "--clock-warm", "0"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2500:]
+    line = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == "weak" and line["n_gpus"] == 2 and line["gather"]["gathers_in_timed_region"] >= 1
+    st = line["strong"]
+    assert set(st) >= {"metric_4096x64", "cfg4_2048x32", "cfg5_8192x64", "note"}, st
+    for key, per in (("metric_4096x64", 2048), ("cfg4_2048x32", 1024), ("cfg5_8192x64", 4096)):
+        c = st[key]
+        assert c["envs_per_gpu"] == per and c["value"] > 1e7 and c["gather_every"] == 16 and c["gather_native"] is False, c
+        assert abs(c["value"] - c["total_envs"] * c["participants_per_env"] / (c["us_per_step"] * 1e-6)) < 1e-3 * c["value"]
+
+
 def _rank_native(rank, world, port, out_dir):
     """one process per GPU: the library's own RCCL communicator (t2d_comm_init with a real unique id), steps and gathers on
     one stream with no host wait in between -- what `bench.py --gpus N` runs"""

@@ -311,6 +311,94 @@ def test_default_step_results_are_never_overwritten():
     env.close()
 
 
+def test_lidar_beams_is_a_regular_subset_of_the_reference_scan_and_copy_always_owns_its_memory():
+    """VecParkingEnv(lidar_beams=120): the scan in info["lidar"] (host path) and in step_torch() equals every third beam of the
+    360-beam scan bit for bit -- what docs/tutorial/train_parking_demo.ipynb keeps of envs/parking.py:422-431's observation --;
+    copy="always": the arrays handed out own their memory (nothing of the pinned frames is aliased)."""
+    torch = pytest.importorskip("torch")
+    from tactics2d_amd.envs import VecParkingEnv
+    n = 96
+    full = VecParkingEnv(n, max_step=40, seed=11, auto_reset=True)
+    third = VecParkingEnv(n, max_step=40, seed=11, auto_reset=True, lidar_beams=120, copy="always")
+    tenth = VecParkingEnv(n, max_step=40, seed=11, auto_reset=True, lidar_beams=36)
+    _, i0 = full.reset(); _, i1 = third.reset(); _, i2 = tenth.reset()
+    assert i1["lidar"].shape == (n, 120) and i2["lidar"].shape == (n, 36)
+    assert np.array_equal(i0["lidar"][:, ::3].view(np.uint32), i1["lidar"].view(np.uint32))
+    assert np.array_equal(i0["lidar"][:, ::10].view(np.uint32), i2["lidar"].view(np.uint32))
+    rng = np.random.default_rng(4)
+    pool = third.scenario_manager.pool
+    frames = lambda: {fr.base.__array_interface__["data"][0] for fr in pool._frames if fr is not None}
+    kept = []
+    hits = 0
+    for t in range(10):
+        act = full.action_space.sample(rng, n)
+        o0, r0, _, _, f0 = full.step(act)
+        o1, r1, _, _, f1 = third.step(act)
+        _, _, _, _, f2 = tenth.step(act)
+        assert np.array_equal(o0, o1) and np.array_equal(r0, r1)
+        assert np.array_equal(f0["lidar"][:, ::3].view(np.uint32), f1["lidar"].view(np.uint32)), t
+        assert np.array_equal(f0["lidar"][:, ::10].view(np.uint32), f2["lidar"].view(np.uint32)), t
+        hits += int(np.isfinite(f1["lidar"]).sum())
+        base = o1.base if o1.base is not None else o1
+        while getattr(base, "base", None) is not None:
+            base = base.base
+        assert base.__array_interface__["data"][0] not in frames()          # a real copy: not one of the pinned frames
+        kept.append((o1, f1["lidar"], o1.copy(), f1["lidar"].copy()))
+    assert hits > 1000
+    for o, l, oc, lc in kept:                                                   # ... and never touched again
+        assert np.array_equal(o, oc) and np.array_equal(l, lc, equal_nan=True)
+    dev = torch.device("cuda", 0)
+    a = torch.from_numpy(full.action_space.sample(rng, n)).to(dev)
+    t0, t1 = full.step_torch(a), third.step_torch(a)
+    torch.cuda.synchronize()
+    assert t1["lidar"].shape == (n, 120)
+    assert np.array_equal(t0["lidar"].cpu().numpy()[:, ::3].view(np.uint32), t1["lidar"].cpu().numpy().view(np.uint32))
+    with pytest.raises(ValueError):
+        VecParkingEnv(4, lidar_beams=100)
+    with pytest.raises(ValueError):
+        VecParkingEnv(4, copy="sometimes")
+    full.close(); third.close(); tenth.close()
+
+
+def test_a_new_frame_configuration_never_leaves_the_pool_reading_freed_action_buffers():
+    """t2d_step_host binds the pool's actions to its staging buffers; t2d_frame_config with ANOTHER configuration frees them.
+    The pool falls back to its own action fields (round-5 advice: it kept reading the freed device / mapped memory)."""
+    from tactics2d_amd import layout as L, scenarios as S
+    from tactics2d_amd.pool import ParticipantPool
+    for zero_copy in (False, True):
+        sc = S.parking(32, seed0=3)
+        pool = ParticipantPool(sc.n_env, 1)
+        sc.load(pool)
+        pool.lidar_config(360, 20.0)
+        a0, a1 = sc.sample_actions(np.random.default_rng(1))
+        pool.set_actions(a0, a1)                                 # the pool's own action fields hold THESE
+        pool.snapshot()
+        pool.step(100)
+        want = [pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED)]
+        pool.restore(False)
+        pool.frame_config(lidar=False, zero_copy=zero_copy)
+        other = np.ascontiguousarray(np.stack([-a1, -a0], 1), np.float32)   # (steering, accel): different actions
+        pool.step_host(other, 100)
+        pool.restore(False)
+        pool.frame_config(lidar=True, zero_copy=zero_copy, n_frames=3)       # another configuration: staging buffers freed
+        pool.step(100)                                            # must read the pool's own fields, not freed memory
+        got = [pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED)]
+        assert all(np.array_equal(g, w) for g, w in zip(got, want)), zero_copy
+        # ... and a rejected action row is not staged: a plain step afterwards uses the last ACCEPTED actions
+        pool.restore(False)
+        ok = np.ascontiguousarray(np.stack([a1, a0], 1), np.float32)
+        box = np.float32([-0.524, 0.524, -2.0, 2.0])
+        pool.step_host(ok, 100, action_box=box)
+        first = [pool.download(f) for f in (L.F_X, L.F_Y)]
+        pool.restore(False)
+        bad = ok.copy(); bad[5, 0] = np.nan
+        with pytest.raises(Exception):
+            pool.step_host(bad, 100, action_box=box)
+        pool.step_host(None, 100)                                 # the actions already in place: the accepted ones
+        assert all(np.array_equal(g, w) for g, w in zip([pool.download(f) for f in (L.F_X, L.F_Y)], first)), zero_copy
+        pool.close()
+
+
 def test_nan_actions_are_invalid_actions_and_step_nothing():
     """`action_space.contains(nan)` is False in the reference (envs/parking.py:235-236): the host path raises InvalidAction
     from the staging pass of t2d_step_host and nothing is stepped -- vector env and single env alike."""

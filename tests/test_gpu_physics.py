@@ -64,6 +64,92 @@ def test_pointmass_within_1e5_of_reference(variant):
     assert worst.max() <= TOL, worst
 
 
+def _pm_euler_gpu(d, m, iv, variant, through_step=False):
+    """every case of the mask as its own one-agent env: t2d_integrate, or the whole t2d_step (the side kernel runs ahead of it)"""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    st = np.float32(d["state"][m])
+    pool = ParticipantPool(int(m.sum()), 1)
+    try:
+        pool.set_param_table(d["rows"])
+        pool.set_integrator_variant(variant)
+        pool.reset(st[:, 0], st[:, 1], st[:, 2], np.zeros(len(st), np.float32), np.uint8(d["type_id"][m]), vx=st[:, 3], vy=st[:, 4])
+        pool.set_actions(np.float32(d["action"][m, 0]), np.float32(d["action"][m, 1]))
+        (pool.step if through_step else pool.integrate)(int(iv))
+        return np.stack([pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_VX, L.F_VY, L.F_APPLIED0, L.F_APPLIED1)], 1)
+    finally:
+        pool.close()
+
+
+@pytest.mark.parametrize("variant", ["fast", "exact"])
+def test_pointmass_euler_backend_within_1e5_of_reference_and_bit_equal_to_the_oracle(variant, oracle):
+    """PointMass(backend="euler") (point_mass.py:177-207; T2D_MODEL_POINTMASS_EULER): fixtures by import within 1e-5, the fp32
+    state bit-equal to the oracle in deterministic-trig mode, the same through t2d_step (the side kernel ahead of the fused one)."""
+    d = H.load_npz("pm_euler.npz")
+    st = np.float32(d["state"])
+    worst = np.zeros(6)
+    for iv in np.unique(d["timing"][:, 0]):
+        m = d["timing"][:, 0] == iv
+        got = _pm_euler_gpu(d, m, iv, variant)
+        worst = np.maximum(worst, H.state_err(got, d["out"][m], cols=6).max(0))
+        oracle.set_trig(1)
+        o = oracle.integrate(d["rows"], st[m, 0], st[m, 1], st[m, 2], None, st[m, 3], st[m, 4], np.float32(d["action"][m, 0]),
+                             np.float32(d["action"][m, 1]), d["type_id"][m], None, int(iv))
+        oracle.set_trig(0)
+        assert np.array_equal(np.float32(o[:, :6]), got[:, :6]), np.abs(np.float32(o[:, :6]) - got[:, :6]).max(0)
+        assert np.array_equal(got[:, 6:8], np.float32(d["action"][m]))
+        assert np.array_equal(_pm_euler_gpu(d, m, iv, variant, through_step=True)[:, :6], got[:, :6])
+    assert worst.max() <= TOL, worst
+
+
+def test_pointmass_euler_mirror_and_pools_that_hold_both_backends(oracle):
+    """physics.PointMass(backend="euler").step (the mirror of point_mass.py:209-232) and a pool whose table holds newton AND euler
+    rows: each participant takes its own back-end; t2d_step_n on such a pool falls back to plain launches (form 'unfused')."""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.physics import BatchedState, PointMass
+    from tactics2d_amd.pool import ParticipantPool
+    d = H.load_npz("pm_euler.npz")
+    m = d["type_id"] == 1                                   # speed_range (0.5, 1.2), interval 100, delta_t 5
+    st = np.float32(d["state"][m])
+    model = PointMass(speed_range=(0.5, 1.2), interval=100, delta_t=5, backend="euler")
+    assert model.backend == "euler" and model.model_id == L.MODEL_POINTMASS_EULER
+    assert PointMass(backend="rk4").backend == "newton"     # point_mass.py:77-81
+    nxt = model.step(BatchedState(0, st[:, 0], st[:, 1], st[:, 2], vx=st[:, 3], vy=st[:, 4]),
+                     (np.float32(d["action"][m, 0]), np.float32(d["action"][m, 1])), 100)
+    got = np.stack([nxt.x, nxt.y, nxt.heading, nxt.vx, nxt.vy], 1)
+    assert np.abs(got - d["out"][m][:, [0, 1, 2, 4, 5]]).max() <= TOL
+    assert nxt.frame == 100
+    # newton and euler rows side by side
+    newton = PointMass(speed_range=(0.5, 1.2), interval=100, delta_t=5)
+    rows = np.stack([newton.param_row(), model.param_row()])
+    n = int(m.sum())
+    pool = ParticipantPool(n, 2)
+    pool.set_param_table(rows)
+    rep = lambda a: np.repeat(np.float32(a), 2)
+    tid = np.tile(np.uint8([0, 1]), n)
+    pool.reset(rep(st[:, 0]), rep(st[:, 1]), rep(st[:, 2]), np.zeros(2 * n, np.float32), tid, vx=rep(st[:, 3]), vy=rep(st[:, 4]))
+    pool.set_actions(rep(d["action"][m, 0]), rep(d["action"][m, 1]))
+    assert pool.step_form(4) == "unfused"
+    pool.snapshot()
+    pool.step_n(3, 100)
+    three = [pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_VX, L.F_VY)]
+    pool.restore(False)
+    for _ in range(3):
+        pool.step(100)
+    assert all(np.array_equal(a, pool.download(f)) for a, f in zip(three, (L.F_X, L.F_Y, L.F_HEADING, L.F_VX, L.F_VY)))
+    pool.restore(False)
+    pool.step(100)
+    gx, gy, gh, gvx, gvy = (pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_VX, L.F_VY))
+    pool.close()
+    oracle.set_trig(1)
+    o = oracle.integrate(rows, rep(st[:, 0]), rep(st[:, 1]), rep(st[:, 2]), None, rep(st[:, 3]), rep(st[:, 4]),
+                         rep(d["action"][m, 0]), rep(d["action"][m, 1]), tid, None, 100)
+    oracle.set_trig(0)
+    for g, c in ((gx, 0), (gy, 1), (gh, 2), (gvx, 4), (gvy, 5)):
+        assert np.array_equal(np.float32(o[:, c]), g), c
+    assert (gx[0::2] != gx[1::2]).any()                      # the two back-ends do differ where the speed is clipped
+
+
 @pytest.mark.parametrize("variant", ["fast", "exact"])
 def test_dynamics_within_1e5_of_reference_wherever_it_is_conditioned(variant):
     """Every dyn_random case against the reference's own result, with the tolerance its conditioning allows

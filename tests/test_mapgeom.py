@@ -164,6 +164,79 @@ def test_rings_that_share_a_straight_side_with_collinear_points_keep_those_point
         assert {tuple(np.float32(p)) for p in many} <= {tuple(v) for q in pm for v in q}
 
 
+def test_straight_stretches_collapse_to_single_quads_without_changing_a_verdict(oracle):
+    """lanes_from_sides joins the pieces of a straight stretch (cut points exactly collinear on both sides): an axis-aligned
+    40-point lanelet is ONE quad.  A neighbour that keeps a point on the long edge meets it in an exact T-junction; the union --
+    and every off-lane verdict -- is what the unmerged pieces give."""
+    xs = np.linspace(0.0, 78.0, 40)                                    # exactly representable, exactly collinear
+    rail = lambda y: np.stack([xs, np.full_like(xs, y)], 1)
+    a = MG.lanes_from_sides(rail(3.75), rail(0.0))                      # (left = +y side for travel along +x)
+    b = MG.lanes_from_sides(rail(7.5), rail(3.75))
+    assert len(a) == 1 and len(b) == 1 and len(a[0]) == 4 and abs(_area2(a[0]) - 2 * 78.0 * 3.75) < 1e-6
+    # a branch that abuts on part of lane b's outer edge, with rail points of its own on it (a T-junction on a merged edge)
+    bx = np.array([20.0, 24.0, 30.0])
+    branch = MG.lanes_from_sides(np.stack([bx, np.full(3, 11.25)], 1), np.stack([bx, np.full(3, 7.5)], 1))
+    assert len(branch) == 1
+    merged = a + b + branch
+    # the same roads cut at every rail point (what round 5 produced): 39 + 39 + 2 pieces
+    fine = []
+    for lo, hi in ((0.0, 3.75), (3.75, 7.5)):
+        fine += [np.float32([(xs[i], lo), (xs[i + 1], lo), (xs[i + 1], hi), (xs[i], hi)]) for i in range(39)]
+    fine += [np.float32([(bx[i], 7.5), (bx[i + 1], 7.5), (bx[i + 1], 11.25), (bx[i], 11.25)]) for i in range(2)]
+    rng = np.random.default_rng(8)
+    n_in = 0
+    for _ in range(400):
+        x, y, h = np.float32(rng.uniform(-3, 81)), np.float32(rng.uniform(-2, 13)), np.float32(rng.uniform(0, 2 * np.pi))
+        pose = oracle.pose_obb(float(x), float(y), float(h), 4.5, 1.8, trig=0)
+        got = oracle.pose_in_lane_union(pose, (float(x), float(y)), merged)
+        assert got == oracle.pose_in_lane_union(pose, (float(x), float(y)), fine), (x, y, h)
+        n_in += got
+    for x in (20.0, 22.0, 24.0, 27.0, 30.0):                           # bodies across the T-junction seam, on every rail point
+        pose = oracle.pose_obb(float(x), 7.5, np.pi / 2, 4.5, 1.2, trig=0)
+        assert oracle.pose_in_lane_union(pose, (float(x), 7.5), merged) == (21.0 <= x <= 29.0 or x in (20.0, 30.0) and False)
+    assert 60 < n_in < 340
+    assert MG.geometry_budget(4, 64, lanes=[merged] * 4)["dwords_needed"] < MG.geometry_budget(4, 64, lanes=[fine] * 4)["dwords_needed"] / 8
+
+
+def test_rail_simplification_is_shared_by_both_lanes_of_a_rail_and_bounded_by_its_tolerance(oracle):
+    """simplify_tol: Douglas-Peucker on each side polyline, direction-independent -- the two lanes of a shared rail keep the same
+    points and still abut edge for edge; a straight lanelet in ANY direction (fp32-rounded points are not exactly collinear)
+    becomes one quad; a curved road keeps what its curvature needs; the outline moves by at most the tolerance."""
+    t = np.linspace(0.0, 1.0, 40)[:, None]
+    d = np.array([np.cos(0.37), np.sin(0.37)])
+    nrm = np.array([-d[1], d[0]])
+    mid, left, right = 5.0 + 80.0 * t * d, 5.0 + 80.0 * t * d + 3.75 * nrm, 5.0 + 80.0 * t * d - 3.75 * nrm
+    assert len(MG.lanes_from_sides(left, mid)) > 20                     # fp32 rounding: not exactly collinear, nothing merges
+    l0, l1 = MG.lanes_from_sides(left, mid, simplify_tol=1e-4), MG.lanes_from_sides(mid, right, simplify_tol=1e-4)
+    assert len(l0) == 1 and len(l1) == 1 and len(l0[0]) == 4
+    shared = {tuple(v) for v in l0[0]} & {tuple(v) for v in l1[0]}
+    assert len(shared) == 2                                             # the rail's two end points, bit for bit
+    assert np.array_equal(MG.simplify_polyline(mid, 1e-4), MG.simplify_polyline(mid[::-1], 1e-4)[::-1])
+    # curved two-lane road (tests above): fewer pieces, still abutting exactly, outline within the tolerance
+    for tol in (5e-3, 2e-2):
+        road = _curved_road(n_pts=160, seed=4)                          # a point every 0.5 m: what a recorded map looks like
+        fine = [q for l, r in road for q in MG.lanes_from_sides(l, r)]
+        coarse = [q for l, r in road for q in MG.lanes_from_sides(l, r, simplify_tol=tol)]
+        assert len(coarse) < 0.6 * len(fine) and all(_convex_ccw(q) and 3 <= len(q) <= 4 for q in coarse)
+        edges = {}
+        for q in coarse:
+            for k in range(len(q)):
+                e = (tuple(q[k]), tuple(q[(k + 1) % len(q)]))
+                edges[e] = edges.get(e, 0) + 1
+        assert all(v == 1 for v in edges.values())
+        inner = [e for e in edges if (e[1], e[0]) in edges]
+        assert len(inner) >= 2 * (len(coarse) - 2)                      # every cut and the whole middle rail are shared edges
+        a_f, a_c = sum(_area2(q) for q in fine), sum(_area2(q) for q in coarse)
+        perimeter = 2 * (60.0 * 1.3 + 7.5)
+        assert abs(a_f - a_c) <= 2 * tol * perimeter
+        rng = np.random.default_rng(3)
+        for _ in range(120):                                            # verdicts agree away from the outline
+            ang = rng.uniform(0.05, 1.25); rr = 60.0 + rng.uniform(-1.5, 1.5)
+            x, y = np.float32(rr * np.cos(ang)), np.float32(rr * np.sin(ang))
+            pose = oracle.pose_obb(float(x), float(y), float(ang + np.pi / 2), 4.0, 1.8, trig=0)
+            assert oracle.pose_in_lane_union(pose, (float(x), float(y)), coarse) == oracle.pose_in_lane_union(pose, (float(x), float(y)), fine)
+
+
 def test_map_boundary_and_the_duck_typed_map_adapter():
     assert MG.map_boundary() == (0.0, 0.0, 0.0, 0.0)
     assert MG.map_boundary([(0.2, -1.5), (3.7, 2.01)], [(-0.1, 0.0)]) == (-1.0, 4.0, -2.0, 3.0)   # floor / ceil, map.py:149-160

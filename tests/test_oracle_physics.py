@@ -29,6 +29,28 @@ def test_pointmass_matches_reference(oracle):
     assert e.max() < 1e-12, e.max(0)
 
 
+def test_pointmass_euler_backend_matches_reference(oracle):
+    """PointMass(backend="euler") -- point_mass.py:177-207, a selectable back-end of the reference -- against fixtures made by
+    importing it (oracle/gen_golden_pm_euler.py): sub-steps + remainder, both speed bounds, the re-projection onto the previous
+    sub-step's heading, delta_t clamped to the interval."""
+    d = H.load_npz("pm_euler.npz")
+    assert (d["rows"][:, 0] == 4).all()
+    st = np.float32(d["state"])
+    worst = 0.0
+    for iv in np.unique(d["timing"][:, 0]):
+        m = d["timing"][:, 0] == iv
+        oracle.set_trig(0)
+        o = oracle.integrate(d["rows"], st[m, 0], st[m, 1], st[m, 2], None, st[m, 3], st[m, 4], np.float32(d["action"][m, 0]),
+                             np.float32(d["action"][m, 1]), d["type_id"][m], None, int(iv))
+        worst = max(worst, H.state_err(o, d["out"][m], cols=6).max())
+        assert np.array_equal(o[:, 6:8], np.float64(np.float32(d["action"][m])))
+    assert worst < 1e-12, worst
+    # the cases exercise what they were drawn for: clipped and unclipped steps, moving and resting starts
+    sp_in = np.hypot(st[:, 3], st[:, 4])
+    assert (sp_in == 0).sum() > 10 and (np.abs(d["out"][:, 3] - np.hypot(st[:, 3] + d["action"][:, 0] * d["timing"][:, 0] / 1000,
+                                                                        st[:, 4] + d["action"][:, 1] * d["timing"][:, 0] / 1000)) > 1e-3).sum() > 50
+
+
 def test_dynamics_matches_reference_wherever_it_is_conditioned(oracle):
     """libm-mode oracle vs the reference's own fp64 results, tolerance set by the fixture's conditioning column
     (helpers.dyn_tolerance): rounding noise where the reference is conditioned, nothing asserted only where one ulp
