@@ -249,7 +249,14 @@ int t2d_set_param_table(t2d_pool* pool, const double* rows, int32_t n_types, int
  *   boundary_valid    [n_env]      0 = "boundary is None" -> never out of bound; NULL = all valid
  * Polygons must be convex with 3..T2D_MAX_POLY_VERTS vertices; either winding accepted.  A polygon of
  * 5..8 vertices is evaluated as its fan of quads (v0 v1 v2 v3), (v0 v3 v4 v5), (v0 v5 v6 v7): the union is the
- * polygon, `intersects` is the OR over the parts; the lidar scans the undivided ring.             */
+ * polygon, `intersects` is the OR over the parts; the lidar scans the undivided ring.
+ * Size: the step kernels keep the static + lane parts of one workgroup's envs in ONE packed LDS record of at most 32 KiB
+ * (t2d_geometry_budget says what a scene needs).  A scene beyond that -- a reference map of hundreds of lanelets,
+ * map/element/map.py:242-329 answers its proximity queries with an STRtree -- is NOT refused: t2d_set_static_geometry /
+ * t2d_set_lane_geometry keep its parts in global memory behind one uniform grid per env (the HBM grid tier,
+ * tactics2d_amd/csrc/t2d_mapgrid.hip), and t2d_step / t2d_step_n run as t2d_integrate -> a map-events launch -> the event + status
+ * launch (t2d_step_form: T2D_FORM_UNFUSED): the same flags, statuses and rewards at any map size, about three launches per step
+ * instead of one.  (Not for generated parking scenes: their capacity layout is fixed.)              */
 int t2d_set_static_geometry(t2d_pool* pool, const int32_t* env_poly_offsets,
                             const int32_t* poly_vert_offsets, const float* verts_xy,
                             const float* boundary, const uint8_t* boundary_valid);
@@ -656,7 +663,7 @@ int t2d_lane_safe_rects(int32_t n_env, const int32_t* env_lane_offsets, const in
 
 /* Host-only (no device is touched): the LDS budget of a scene before it is installed.  The step kernels keep the static and
  * lane geometry of one workgroup's envs in ONE packed record of at most 32 KiB; t2d_set_static_geometry / t2d_set_lane_geometry
- * narrow the workgroup down to one wave (64 / padded max_agents envs) before they give up with T2D_ERR_GEOMETRY.  This call runs
+ * narrow the workgroup down to one wave (64 / padded max_agents envs) before they move the scene to the HBM grid tier.  This call runs
  * the same preparation (convexity checks, fans of quads for 5..8-gons, the boundary pieces of each env's lane union) on host
  * CSR arrays (as in t2d_set_*_geometry; either pair may be NULL) and reports the dwords the fullest such workgroup needs and
  * the budget (8192): what tactics2d_amd/mapgeom.py uses to say how many lane / obstacle polygons of a reference map

@@ -35,6 +35,12 @@ int t2d_debug_chain_fault(t2d_pool* pool, int32_t kind);
  * overwrite a record slot really waits for the gather that still has to read it.                                       */
 int t2d_debug_delay_gather(t2d_pool* pool, int32_t microseconds);
 
+/* Which instantiation of the step / event kernel the LAST launch of this process took: its template arguments as written at the
+ * launch site in tactics2d_amd/csrc/t2d_collide.hip, e.g. "(true, 1, false, true)" = the chained fused step, fast integrator.
+ * tests/test_gpu_forms.py drives one recipe per launch site and holds the set it sees against the list in the source file
+ * (DESIGN.md 4.2c).  Not thread-safe; a static string.                                                                    */
+const char* t2d_debug_last_step_kernel(void);
+
 /* ---- the closed loop (measurement / test helpers; tactics2d_amd/csrc/t2d_loop.hip) -----------------------------------------
  * The reference's callers run  action = policy(obs); obs, reward, ... = env.step(action)  (envs/parking.py:219-256 inside the
  * tutorial's training loop).  On the device that is: a policy kernel that reads the state the previous step left behind and

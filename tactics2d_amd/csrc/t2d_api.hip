@@ -478,6 +478,96 @@ int envs_per_workgroup(t2d_pool* p, int log2A) {
     return epb;
 }
 
+// The HBM grid tier (t2d_mapgrid.hip): the env's parts -- static and lane, the same fans of 3- / 4-gons and the same boundary
+// pieces the LDS record would hold -- stay in global memory, indexed by one uniform grid per env.  Cell edge: the square root of
+// the env's extent over its number of parts (about one part per cell), between 4 m and 64 m, at most 4096 cells per env.
+int build_map_grid(t2d_pool* p) {
+    const int E = p->v.n_env;
+    std::vector<t2d::MapGridEnv> env((size_t)E);
+    std::vector<int32_t> cell_start(1, 0);
+    std::vector<uint32_t> items;
+    std::vector<std::vector<uint32_t>> cells;
+    const float m = t2d::kGridMargin;
+    for (int e = 0; e < E; ++e) {
+        float x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        int n_parts = 0;
+        for (int k = 0; k < 2; ++k) {
+            const auto& g = p->hgeo[k];
+            if (!g.present) continue;
+            for (int q = g.env_off[e]; q < g.env_off[e + 1]; ++q, ++n_parts) {
+                const float* b = &g.aabb[4 * (size_t)q];   // xmin, xmax, ymin, ymax
+                if (n_parts == 0) { x0 = b[0]; x1 = b[1]; y0 = b[2]; y1 = b[3]; }
+                x0 = std::min(x0, b[0]); x1 = std::max(x1, b[1]); y0 = std::min(y0, b[2]); y1 = std::max(y1, b[3]);
+            }
+        }
+        t2d::MapGridEnv& h = env[(size_t)e];
+        x0 -= 2 * m; y0 -= 2 * m; x1 += 2 * m; y1 += 2 * m;
+        const double w = (double)x1 - x0, ht = (double)y1 - y0;
+        double cell = n_parts > 0 ? sqrt(w * ht / n_parts) : 64.0;
+        cell = std::min(64.0, std::max(4.0, cell));
+        while ((floor(w / cell) + 1) * (floor(ht / cell) + 1) > 4096.0) cell *= 1.25;
+        h.x0 = x0; h.y0 = y0; h.inv_cell = (float)(1.0 / cell);
+        h.nx = (int)floor(w * (double)h.inv_cell) + 1;
+        h.ny = (int)floor(ht * (double)h.inv_cell) + 1;
+        h.cell_off = (int32_t)cell_start.size() - 1;
+        h.has_lanes = p->hgeo[1].present && p->hgeo[1].env_off[e + 1] > p->hgeo[1].env_off[e];
+        h.pad = 0;
+        cells.assign((size_t)h.nx * h.ny, {});
+        auto cell_of = [&](float v, float o, int n) {   // the kernel's expression: floor((v - o) * inv_cell) in fp64, clamped
+            int c = (int)floor(((double)v - (double)o) * (double)h.inv_cell);
+            return c < 0 ? 0 : (c >= n ? n - 1 : c);
+        };
+        for (int k = 0; k < 2; ++k) {
+            const auto& g = p->hgeo[k];
+            if (!g.present) continue;
+            for (int q = g.env_off[e]; q < g.env_off[e + 1]; ++q) {
+                const float* b = &g.aabb[4 * (size_t)q];
+                const int ix0 = cell_of(b[0] - m, h.x0, h.nx), ix1 = cell_of(b[1] + m, h.x0, h.nx);
+                const int iy0 = cell_of(b[2] - m, h.y0, h.ny), iy1 = cell_of(b[3] + m, h.y0, h.ny);
+                for (int iy = iy0; iy <= iy1; ++iy)
+                    for (int ix = ix0; ix <= ix1; ++ix) cells[(size_t)iy * h.nx + ix].push_back((uint32_t)q | ((uint32_t)k << 31));
+            }
+        }
+        for (const auto& c : cells) {
+            items.insert(items.end(), c.begin(), c.end());
+            cell_start.push_back((int32_t)items.size());
+        }
+    }
+    int rc;
+    if ((rc = dev_replace(p, &p->d_grid_env, env.data(), env.size()))) return rc;
+    if ((rc = dev_replace(p, &p->d_grid_cell_start, cell_start.data(), cell_start.size()))) return rc;
+    if (items.empty()) items.push_back(0u);
+    if ((rc = dev_replace(p, &p->d_grid_items, items.data(), items.size()))) return rc;
+    t2d::MapGridView mg{};
+    mg.env = p->d_grid_env; mg.cell_start = p->d_grid_cell_start; mg.cell_items = p->d_grid_items;
+    for (int k = 0; k < 2; ++k) {
+        const auto& g = p->hgeo[k];
+        std::vector<int32_t> vo = g.present ? g.vert_off : std::vector<int32_t>(1, 0);
+        std::vector<float> xy = g.present && !g.xy.empty() ? g.xy : std::vector<float>(2, 0.f);
+        if ((rc = dev_replace(p, &p->d_grid_vert_off[k], vo.data(), vo.size()))) return rc;
+        if ((rc = dev_replace(p, &p->d_grid_xy[k], xy.data(), xy.size()))) return rc;
+        mg.vert_off[k] = p->d_grid_vert_off[k];
+        mg.xy[k] = p->d_grid_xy[k];
+    }
+    {
+        const auto& g = p->hgeo[1];
+        std::vector<int32_t> bo = g.present && !g.bnd_off.empty() ? g.bnd_off : std::vector<int32_t>(1, 0);
+        std::vector<double> bd = g.present && !g.bnd.empty() ? g.bnd : std::vector<double>(4, 0.0);
+        if ((rc = dev_replace(p, &p->d_grid_bnd_off, bo.data(), bo.size()))) return rc;
+        if ((rc = dev_replace(p, &p->d_grid_bnd, bd.data(), bd.size()))) return rc;
+        mg.bnd_off = p->d_grid_bnd_off;
+        mg.bnd = p->d_grid_bnd;
+    }
+    if (!p->d_map_flags) {
+        T2D_HIP(p, hipMalloc((void**)&p->d_map_flags, sizeof(uint32_t) * (size_t)p->v.N));
+        T2D_HIP(p, hipMemset(p->d_map_flags, 0, sizeof(uint32_t) * (size_t)p->v.N));
+    }
+    p->mapgrid = mg;
+    p->grid_tier = true;
+    p->v.map_flags = p->d_map_flags;
+    return T2D_OK;
+}
+
 // (Re)build the packed per-workgroup geometry records from the host CSR copies and upload them.
 int rebuild_geo(t2d_pool* p) {
     const int E = p->v.n_env;
@@ -486,6 +576,8 @@ int rebuild_geo(t2d_pool* p) {
     constexpr int kBudgetDwords = 8192;  // 32 KiB of dynamic LDS for the record
     t2d::GeoLayout gl{};
     gl.epb = epb_max;
+    p->grid_tier = false;
+    p->v.map_flags = nullptr;
     if (!p->hgeo[0].present && !p->hgeo[1].present) {
         int rc = dev_replace<uint32_t>(p, &p->d_geo, nullptr, 0);
         p->v.geo = nullptr;
@@ -512,8 +604,20 @@ int rebuild_geo(t2d_pool* p) {
         }
         fill_layout(gl, epb, mp, mv, mb);
         if (gl.stride <= kBudgetDwords) break;
-        if ((epb << log2A) <= 64 || epb == 1)
-            return fail(p, T2D_ERR_GEOMETRY, "static + lane geometry of one workgroup exceeds the 32 KiB LDS record");
+        if ((epb << log2A) <= 64 || epb == 1) {
+            // Too large for the LDS record even at one wave per workgroup: the map goes to the HBM grid tier (t2d_mapgrid.hip).
+            // The event kernel then carries no static / lane record at all; the step runs as integrate -> map events -> events +
+            // status (t2d_step_form: "unfused"), same results, any map size.
+            if (p->scene_mode) return fail(p, T2D_ERR_GEOMETRY, "static + lane geometry of one workgroup exceeds the 32 KiB LDS record");
+            int rc = dev_replace<uint32_t>(p, &p->d_geo, nullptr, 0);
+            if (rc != T2D_OK) return rc;
+            t2d::GeoLayout none{};
+            none.epb = epb_max;
+            p->v.geo = nullptr;
+            p->v.geo_layout = none;
+            p->v.wgmap = nullptr;
+            return build_map_grid(p);
+        }
     }
     for (int k = 0; k < 2; ++k) gl.has[k] = p->hgeo[k].present && mp[k] > 0;
     const int nb = (E + epb - 1) / epb;
@@ -873,6 +977,7 @@ int t2d_create(int32_t n_env, int32_t max_agents, int32_t device_id, t2d_pool** 
     v.cell = 1.0;
     v.inv_cell = 1.0;
     v.dbg = nullptr;
+    v.map_flags = nullptr;
     for (int k = 0; k < 6; ++k) v.snap[k] = nullptr;
     v.snap_ids = nullptr;
     v.auto_reset = 0;
@@ -915,7 +1020,9 @@ int t2d_destroy(t2d_pool* p) {
                     p->d_lidar_env_off, p->d_lidar_next, p->d_lidar_meta, p->d_lidar_xy, p->d_beam_sin, p->d_beam_cos,
                     p->d_snap[0], p->d_snap[1], p->d_snap[2],
                     p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_wgmap, p->d_idm_rows, p->d_idm_ctrl, p->d_snap_omega[0], p->d_snap_omega[1], p->d_time_penalty,
-                    p->d_scene_arrays, p->d_lidar_cnt, p->d_chain, p->d_ckpt, p->d_scene_view};
+                    p->d_scene_arrays, p->d_lidar_cnt, p->d_chain, p->d_ckpt, p->d_scene_view,
+                    p->d_grid_env, p->d_grid_cell_start, p->d_grid_items, p->d_map_flags, p->d_grid_vert_off[0], p->d_grid_vert_off[1],
+                    p->d_grid_xy[0], p->d_grid_xy[1], p->d_grid_bnd_off, p->d_grid_bnd};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     frame_release(p);
@@ -1168,6 +1275,7 @@ int t2d_reset(t2d_pool* p, const uint8_t* env_mask, const float* x, const float*
         T2D_HIP(p, hipMemcpy(hstat.data(), p->v.status, 4 * (size_t)E, hipMemcpyDeviceToHost));
         T2D_HIP(p, hipMemcpy(hrew.data(), p->v.reward, 4 * (size_t)E, hipMemcpyDeviceToHost));
     }
+    uint32_t types_used = partial ? p->types_used : 0u;   // (T2D_MAX_TYPES = 32 rows: one bit each)
     for (int e = 0; e < E; ++e) {
         if (partial && !env_mask[e]) continue;
         for (int a = 0; a < A; ++a) {
@@ -1183,6 +1291,7 @@ int t2d_reset(t2d_pool* p, const uint8_t* env_mask, const float* x, const float*
                 hvy[i] = (float)((double)speed[i] * sin((double)heading[i]));
             }
             const int model = active[i] ? (int)p->host_params[ty][T2D_P_MODEL] : 0;
+            if (active[i]) types_used |= 1u << ty;
             hids[i] = ((uint32_t)model << t2d::kIdsModelShift) | ((uint32_t)ty << t2d::kIdsTypeShift) |
                       ((uint32_t)(active[i] ? 1 : 0) << t2d::kIdsActiveShift);
             hflags[i] = 0;
@@ -1219,6 +1328,7 @@ int t2d_reset(t2d_pool* p, const uint8_t* env_mask, const float* x, const float*
         int rc2 = init_iou_state(p, env_mask, hx.data(), hy.data());
         if (rc2 != T2D_OK) return rc2;
     }
+    p->types_used = types_used;
     p->have_reset = true;
     return T2D_OK;
 }
@@ -1346,7 +1456,13 @@ int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     if (p->idm_on && (rc = idm_impl(p, s))) return rc;
     if (p->has_drift && (rc = drift_impl(p, interval_ms, s))) return rc;
     if ((rc = record_event(p, 0, s, true))) return rc;
-    T2D_HIP(p, t2d::launch_integrate(p->v, interval_ms, p->integrator_variant, s));
+    // (four participants per lane pay where the model is cheap enough for the kernel to be memory-bound: measured at 4 M
+    // participants 72.4 -> 63.5 us for point masses, 74.6 -> 73.7 for the kinematic bicycle, 167.7 -> 170.3 for the dynamics
+    // model -- pools whose table holds a dynamics row keep one participant per lane)
+    bool wide = true;
+    for (int t = 0; t < p->v.n_types; ++t)   // (of the types some active participant HAS: t2d_reset keeps the set)
+        wide = wide && !((p->types_used >> t & 1u) && (int)p->host_params[t][T2D_P_MODEL] == T2D_MODEL_DYNAMICS);
+    T2D_HIP(p, t2d::launch_integrate(p->v, interval_ms, p->integrator_variant, wide, s));
     return record_event(p, 0, s, false);
 }
 
@@ -1358,7 +1474,7 @@ int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
 static bool idm_in_step(t2d_pool* p) {
     // (not pools with SingleTrackDrift participants: drift_kernel runs between the controllers and the step launch and reads
     // the accelerations the controllers wrote -- t2d_step's order is IDM, drift, step -- so there idm_kernel stays a launch)
-    return p->idm_on && p->chain_steps && p->fused_step && !p->has_drift && p->v.A >= 2 && p->v.A <= 64 &&
+    return p->idm_on && p->chain_steps && p->fused_step && !p->grid_tier && !p->has_drift && p->v.A >= 2 && p->v.A <= 64 &&
            !(p->status_cfg.check_no_action || p->status_cfg.check_arrival);
 }
 static void fill_idm(t2d::PoolView& v, t2d_pool* p) {
@@ -1394,6 +1510,10 @@ static int collide_impl(t2d_pool* p, bool with_status, int interval_ms, hipStrea
     // (t2d_ego.hip) instead of one lane per participant; same arithmetic, same results (t2d_set_ego_kernel(pool, 0)
     // keeps such a pool on the general kernel: the two are held against each other in tests/test_gpu_ego.py)
     p->scene_committed_in_step = false;
+    if (p->grid_tier) {   // the map's verdicts for the poses as they are now, ahead of the event kernel that ORs them in
+        if (fuse_variant >= 0) return fail(p, T2D_ERR_STATE, "internal: a grid-tier pool took the fused step");
+        T2D_HIP(p, t2d::launch_map_events(p->v, p->mapgrid, p->d_map_flags, s));
+    }
     if (fuse_variant >= 0 && p->ego_kernel && p->v.A == 1 && p->all_boxes && !p->has_drift && !p->hgeo[1].present) {
         t2d::PoolView v = p->v;
         // staged scene regeneration: the step's own epilogue moves finished envs into their next lot (no launch behind it)
@@ -1485,7 +1605,7 @@ int t2d_check_status(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
 
 int t2d_step(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     if (!p) return T2D_ERR_INVALID;
-    if (!p->fused_step) {
+    if (!p->fused_step || p->grid_tier) {
         int rc = t2d_integrate(p, interval_ms, hip_stream);
         if (rc != T2D_OK) return rc;
         return t2d_check_status(p, interval_ms, hip_stream);
@@ -1519,7 +1639,7 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
     const bool ego = p->ego_kernel && p->v.A == 1 && p->all_boxes && !p->has_drift && !p->hgeo[1].present;
     const bool iou = p->status_cfg.check_no_action || p->status_cfg.check_arrival;   // per-env history read by the epilogue
     // (the single-ego kernel has a LOOP form of its own, which reads the history with sc1 loads: IoU events are fine there)
-    const bool chain = p->chain_steps && n_steps >= 2 && p->fused_step && (!p->idm_on || idm_in_step(p)) && !p->has_drift &&
+    const bool chain = p->chain_steps && n_steps >= 2 && p->fused_step && !p->grid_tier && (!p->idm_on || idm_in_step(p)) && !p->has_drift &&
                        !p->scene_regen && (ego ? p->chain_loop : !iou);
     const float *a0 = p->v.act0, *a1 = p->v.act1;
     int rc = T2D_OK;
@@ -1646,7 +1766,7 @@ int t2d_step_form(t2d_pool* p, int32_t n_steps) {
     if (!p) return -1;
     const bool ego = p->ego_kernel && p->v.A == 1 && p->all_boxes && !p->has_drift && !p->hgeo[1].present;
     const bool iou = p->status_cfg.check_no_action || p->status_cfg.check_arrival;
-    if (!p->fused_step || p->has_drift || p->scene_regen) return T2D_FORM_UNFUSED;
+    if (!p->fused_step || p->grid_tier || p->has_drift || p->scene_regen) return T2D_FORM_UNFUSED;
     const bool chain = p->chain_steps && n_steps >= 2 && (ego ? p->chain_loop : !iou);
     if (p->idm_on) {
         if (ego || !idm_in_step(p)) return T2D_FORM_UNFUSED;
@@ -2058,6 +2178,9 @@ int t2d_gather_wait(t2d_pool* p, void* hip_stream, int32_t block_host) {
 }
 
 // test hook: the next CHAIN launches of the pool break one hand-off on purpose (include/t2d.h)
+#ifdef T2D_DEBUG_HOOKS   // include/t2d_debug.h: libt2d_hip_debug.so only
+const char* t2d_debug_last_step_kernel(void) { return t2d::last_collide_form(); }
+#endif
 #ifdef T2D_DEBUG_HOOKS   // include/t2d_debug.h: libt2d_hip_debug.so only
 int t2d_debug_chain_fault(t2d_pool* p, int32_t kind) {
     if (!p) return T2D_ERR_INVALID;

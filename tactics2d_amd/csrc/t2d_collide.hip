@@ -96,7 +96,9 @@ using namespace geom;
 #define T2D_CHAIN_PREFETCH 0   // (measured, same box, ABAB: 16.95 / 16.42 us per step with it, 16.83 / 16.30 without -- not kept on)
 #endif
 #ifndef T2D_CHAIN_LATE_SPINS
-#define T2D_CHAIN_LATE_SPINS 1   // a chained workgroup that had to poll at least this often for its hand-off is LATE: priority 3 throughout (0 = off)
+#define T2D_CHAIN_LATE_SPINS 6   // a chained workgroup that had to poll at least this often for its hand-off is LATE: priority 3 throughout (0 = off;
+                                 // same box, us per step as fragments of 20 / 100 / single synchronised fragments: off 16.73 / 16.21 / 17.36, 1: 16.63 / 16.21 / 17.23,
+                                 // 3: 16.47 / 16.05 / 17.07, 5: 16.41 / 15.99 / 17.01, 8: 16.41 / 15.99 / 17.02 -- profiles/r06_ab_late2.txt)
 #endif
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / 64;
@@ -147,19 +149,6 @@ T2D_DEV bool point_in_generic(const PolyRef B, double x, double y) {
     return in;
 }
 
-T2D_DEV double seg_dist2(double px, double py, double qx, double qy, double cx, double cy) {
-    double dx = qx - px, dy = qy - py;
-    double wx = cx - px, wy = cy - py;
-    double dd = dx * dx + dy * dy;
-    double t = 0.0;
-    if (dd > 0.0) {
-        t = (wx * dx + wy * dy) / dd;
-        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
-    }
-    double ex = wx - t * dx, ey = wy - t * dy;
-    return ex * ex + ey * ey;
-}
-
 // oracle t2do_circle_convex_intersects
 __device__ __noinline__ bool circle_vs_generic(double cx, double cy, double R, const PolyRef B) {
     if (point_in_generic(B, cx, cy)) return true;
@@ -175,26 +164,6 @@ __device__ __noinline__ bool circle_vs_generic(double cx, double cy, double R, c
         py = qy;
     }
     return hit;
-}
-
-// ---- off-lane = not union(lanes).contains(pose): boundary pieces of the union vs the pose --------------------------
-// oracle t2do_piece_meets_quad_interior: the piece A -> B misses the open CCW quad P when some edge of P has A and B
-// on its outer side or on it, or all four vertices of P lie on one closed side of the line AB
-T2D_DEV bool piece_meets_quad_interior(const Quad& P, double ax, double ay, double bx, double by) {
-    bool sep = false;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = (i + 1) & 3;
-        sep |= (int)(orient(P.x[i], P.y[i], P.x[k], P.y[k], ax, ay) <= 0.0) & (int)(orient(P.x[i], P.y[i], P.x[k], P.y[k], bx, by) <= 0.0);
-    }
-    bool all_ge = true, all_le = true;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double o = orient(ax, ay, bx, by, P.x[k], P.y[k]);
-        all_ge &= o >= 0.0;
-        all_le &= o <= 0.0;
-    }
-    return !(sep | all_ge | all_le);
 }
 
 // a_planes: the pose in the LDS coordinate planes (&s_v[0][lane]); b_aos: 4 x (x, y) doubles in global memory
@@ -1669,6 +1638,9 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : (LOOP && !CHAI
     if (active) {
         const uint32_t sf = s_flags[tid];
         f = f_own | (sf & ((1u << kLaneShift) - 1u));
+        if constexpr (FUSE < 0) {   // maps in the HBM grid tier: map_events_kernel's verdicts for this participant (t2d_mapgrid.hip)
+            if (pv.map_flags) f |= pv.map_flags[idx];
+        }
         if (n_lane_polys > 0) {  // build-defined off-lane: not union(lanes).contains(pose)
             const uint32_t b = sf >> kLaneShift;   // see process_lane
             const bool in = lane_safe || ((b & 1u) && !(b & 2u));
@@ -1989,6 +1961,22 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : (LOOP && !CHAI
 
 }  // namespace
 
+// Every launch of collide_kernel goes through this macro: the debug library (-DT2D_DEBUG_HOOKS) notes WHICH instantiation the
+// last launch took (t2d_debug_last_step_kernel), so that tests/test_gpu_forms.py can hold the list of instantiations in this
+// file against what the test suite's recipes actually reach (the table of forms).
+#ifdef T2D_DEBUG_HOOKS
+const char* g_last_collide_form = "";
+#define T2D_NOTE_FORM(str) (g_last_collide_form = str)
+#else
+#define T2D_NOTE_FORM(str) ((void)0)
+#endif
+#define T2D_UNPAREN(...) __VA_ARGS__
+#define T2D_LAUNCH_COLLIDE(ARGS, grid_, block_)                                                                              \
+    do {                                                                                                                     \
+        T2D_NOTE_FORM(#ARGS);                                                                                                \
+        hipLaunchKernelGGL((collide_kernel<T2D_UNPAREN ARGS>), grid_, block_, dyn, s, v, cfg, interval_ms, log2A);           \
+    } while (0)
+
 // resident workgroups per CU of the fused step kernel with this pool's geometry record (the metric scenes are sized
 // for 4: one wave-round of 1024 workgroups on 256 CUs) and the LDS bytes per workgroup
 hipError_t step_occupancy(const PoolView& v, int* blocks_per_cu, size_t* lds_bytes) {
@@ -2023,8 +2011,8 @@ hipError_t launch_step_chain(const PoolView& v, const t2d_status_config& cfg, in
         const int padded = (v.n_env + 7) & ~7;
         const dim3 grid(padded, n_steps), block(kBlock);
         const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
-        if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, true, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
-        else hipLaunchKernelGGL((collide_kernel<true, 1, false, true, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        if (variant == 0) T2D_LAUNCH_COLLIDE((true, 0, false, true, false, true), grid, block);
+        else T2D_LAUNCH_COLLIDE((true, 1, false, true, false, true), grid, block);
         return hipGetLastError();
     }
 #ifdef T2D_EXPERIMENTS   // (measured in round 6 and not shipped: profiles/r06_ab_chain_depth.txt)
@@ -2033,8 +2021,8 @@ hipError_t launch_step_chain(const PoolView& v, const t2d_status_config& cfg, in
         const int real = (v.n_env + EPB - 1) / EPB, padded = (real + 7) & ~7;
         const dim3 grid(padded, n_steps / v.chain_k), block(EPB << log2A);
         const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
-        if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, true, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
-        else hipLaunchKernelGGL((collide_kernel<true, 1, false, true, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        if (variant == 0) T2D_LAUNCH_COLLIDE((true, 0, false, true, true), grid, block);
+        else T2D_LAUNCH_COLLIDE((true, 1, false, true, true), grid, block);
         return hipGetLastError();
     }
 #endif
@@ -2045,24 +2033,24 @@ hipError_t launch_step_chain(const PoolView& v, const t2d_status_config& cfg, in
         if (v.pipe_step == 2) {   // ... and a third set that takes the lane stage
             const dim3 block3(3 * (EPB << log2A));
             if (block3.x > 1024) return hipErrorInvalidValue;
-            if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, true, false, 2>), grid, block3, dyn, s, v, cfg, interval_ms, log2A);
-            else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, true, false, 2>), grid, block3, dyn, s, v, cfg, interval_ms, log2A);
+            if (variant == 0) T2D_LAUNCH_COLLIDE((true, 0, false, false, true, false, 2), grid, block3);
+            else T2D_LAUNCH_COLLIDE((true, 1, false, false, true, false, 2), grid, block3);
             return hipGetLastError();
         }
         if (v.idm_rows) {   // installed IDM controllers: run by the integrator waves
-            if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, true, false, 1, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
-            else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, true, false, 1, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+            if (variant == 0) T2D_LAUNCH_COLLIDE((true, 0, false, false, true, false, 1, true), grid, block);
+            else T2D_LAUNCH_COLLIDE((true, 1, false, false, true, false, 1, true), grid, block);
             return hipGetLastError();
         }
-        if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, true, false, 1>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
-        else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, true, false, 1>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        if (variant == 0) T2D_LAUNCH_COLLIDE((true, 0, false, false, true, false, 1), grid, block);
+        else T2D_LAUNCH_COLLIDE((true, 1, false, false, true, false, 1), grid, block);
         return hipGetLastError();
     }
     if (v.loop_steps > 0) {   // small pool: every workgroup resident, each walks through the steps itself
         const dim3 grid((v.n_env + EPB - 1) / EPB), block(EPB << log2A);
         const size_t dyn = v.geo ? (size_t)v.geo_layout.stride * 4 : 0;
-        if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
-        else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        if (variant == 0) T2D_LAUNCH_COLLIDE((true, 0, false, false, true), grid, block);
+        else T2D_LAUNCH_COLLIDE((true, 1, false, false, true), grid, block);
         return hipGetLastError();
     }
     // x extent rounded up to a multiple of 8: workgroup ids go round the 8 XCDs, so step k + 1 of a set of envs then runs on
@@ -2074,12 +2062,12 @@ hipError_t launch_step_chain(const PoolView& v, const t2d_status_config& cfg, in
     // the caller steps those one launch at a time)
     if (cfg.check_no_action || cfg.check_arrival) return hipErrorInvalidValue;
     if (v.idm_rows) {   // installed IDM controllers: run by every workgroup ahead of its integrator
-        if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, true, false, false, 0, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
-        else hipLaunchKernelGGL((collide_kernel<true, 1, false, true, false, false, 0, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        if (variant == 0) T2D_LAUNCH_COLLIDE((true, 0, false, true, false, false, 0, true), grid, block);
+        else T2D_LAUNCH_COLLIDE((true, 1, false, true, false, false, 0, true), grid, block);
         return hipGetLastError();
     }
-    if (variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
-    else hipLaunchKernelGGL((collide_kernel<true, 1, false, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+    if (variant == 0) T2D_LAUNCH_COLLIDE((true, 0, false, true), grid, block);
+    else T2D_LAUNCH_COLLIDE((true, 1, false, true), grid, block);
     return hipGetLastError();
 }
 
@@ -2093,30 +2081,34 @@ hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool 
     const bool iou = cfg.check_no_action || cfg.check_arrival;
     if (fuse_variant >= 0 && v.split_step) {
         const dim3 sgrid(v.n_env), sblock(kBlock);
-        if (fuse_variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, false, true>), sgrid, sblock, dyn, s, v, cfg, interval_ms, log2A);
-        else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, false, true>), sgrid, sblock, dyn, s, v, cfg, interval_ms, log2A);
+        if (fuse_variant == 0) T2D_LAUNCH_COLLIDE((true, 0, false, false, false, true), sgrid, sblock);
+        else T2D_LAUNCH_COLLIDE((true, 1, false, false, false, true), sgrid, sblock);
         return hipGetLastError();
     }
     if (fuse_variant >= 0 && v.idm_rows && !iou) {   // installed IDM controllers, run ahead of the integrator
-        if (fuse_variant == 0) hipLaunchKernelGGL((collide_kernel<true, 0, false, false, false, false, 0, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
-        else hipLaunchKernelGGL((collide_kernel<true, 1, false, false, false, false, 0, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        if (fuse_variant == 0) T2D_LAUNCH_COLLIDE((true, 0, false, false, false, false, 0, true), grid, block);
+        else T2D_LAUNCH_COLLIDE((true, 1, false, false, false, false, 0, true), grid, block);
         return hipGetLastError();
     }
     if (fuse_variant >= 0) {  // the fused step always runs the status epilogue
         if (fuse_variant == 0) {
-            if (iou) hipLaunchKernelGGL((collide_kernel<true, 0, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
-            else hipLaunchKernelGGL((collide_kernel<true, 0, false>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+            if (iou) T2D_LAUNCH_COLLIDE((true, 0, true), grid, block);
+            else T2D_LAUNCH_COLLIDE((true, 0, false), grid, block);
         } else {
-            if (iou) hipLaunchKernelGGL((collide_kernel<true, 1, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
-            else hipLaunchKernelGGL((collide_kernel<true, 1, false>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+            if (iou) T2D_LAUNCH_COLLIDE((true, 1, true), grid, block);
+            else T2D_LAUNCH_COLLIDE((true, 1, false), grid, block);
         }
     } else if (with_status) {
-        if (iou) hipLaunchKernelGGL((collide_kernel<true, -1, true>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
-        else hipLaunchKernelGGL((collide_kernel<true, -1, false>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        if (iou) T2D_LAUNCH_COLLIDE((true, -1, true), grid, block);
+        else T2D_LAUNCH_COLLIDE((true, -1, false), grid, block);
     } else {
-        hipLaunchKernelGGL((collide_kernel<false, -1, false>), grid, block, dyn, s, v, cfg, interval_ms, log2A);
+        T2D_LAUNCH_COLLIDE((false, -1, false), grid, block);
     }
     return hipGetLastError();
 }
+
+#ifdef T2D_DEBUG_HOOKS
+const char* last_collide_form() { return g_last_collide_form; }
+#endif
 
 }  // namespace t2d

@@ -119,6 +119,42 @@ T2D_DEV bool point_in_quad(const Quad& B, double x, double y) {
     return in;
 }
 
+// squared distance of the point (cx, cy) from the segment P -> Q (oracle t2do_seg_dist2)
+T2D_DEV double seg_dist2(double px, double py, double qx, double qy, double cx, double cy) {
+    double dx = qx - px, dy = qy - py;
+    double wx = cx - px, wy = cy - py;
+    double dd = dx * dx + dy * dy;
+    double t = 0.0;
+    if (dd > 0.0) {
+        t = (wx * dx + wy * dy) / dd;
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+    }
+    double ex = wx - t * dx, ey = wy - t * dy;
+    return ex * ex + ey * ey;
+}
+
+
+// ---- off-lane = not union(lanes).contains(pose): boundary pieces of the union vs the pose --------------------------
+// oracle t2do_piece_meets_quad_interior: the piece A -> B misses the open CCW quad P when some edge of P has A and B
+// on its outer side or on it, or all four vertices of P lie on one closed side of the line AB
+T2D_DEV bool piece_meets_quad_interior(const Quad& P, double ax, double ay, double bx, double by) {
+    bool sep = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = (i + 1) & 3;
+        sep |= (int)(orient(P.x[i], P.y[i], P.x[k], P.y[k], ax, ay) <= 0.0) & (int)(orient(P.x[i], P.y[i], P.x[k], P.y[k], bx, by) <= 0.0);
+    }
+    bool all_ge = true, all_le = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double o = orient(ax, ay, bx, by, P.x[k], P.y[k]);
+        all_ge &= o >= 0.0;
+        all_le &= o <= 0.0;
+    }
+    return !(sep | all_ge | all_le);
+}
+
+
 // ---- IoU of two convex quads (Arrival / NoAction), oracle t2do_quad_iou: the boundary of A n B is
 // integrated directly -- every edge of A clipped to closed B, every edge of B clipped to A with
 // coincident (parallel, on-the-line) pieces dropped -- and the 8 partial sums are combined in a

@@ -30,6 +30,7 @@ namespace t2d {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kWideMinParticipants = 8 * 64 * 4 * 256 * 4;   // four per lane and still eight waves' worth of lanes per SIMD
 using namespace integ;
 
 template <int VARIANT>
@@ -92,6 +93,107 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(PoolView pv, int inte
     if (pv.out_mask & T2D_OUT_APPLIED) {
         pv.applied0[i] = (float)o.app0;
         pv.applied1[i] = (float)o.app1;
+    }
+}
+
+// The same step, FOUR consecutive participants per lane: pools large enough to stay wide afterwards (launch_integrate) take
+// their state through 16-byte loads and stores -- a quarter of the memory instructions, four times the bytes in flight per
+// wave.  At 4 M point masses the one-per-lane kernel moved 3.5 TB/s of its ~60 B per participant (72 us, 0.32 of the 8 TB/s
+// peak on the 44-B figure); the model's arithmetic is the same per participant, the results are the same bits
+// (tests/test_gpu_physics.py holds this kernel against the fused step's one-per-lane integrator).
+template <int VARIANT>
+__global__ __launch_bounds__(kBlock) void integrate_wide_kernel(PoolView pv, int interval_ms) {
+    __shared__ double s_par[T2D_PARAM_COLS * T2D_MAX_TYPES];
+    const int tid = threadIdx.x;
+    const int i4 = blockIdx.x * kBlock + tid;          // index of the lane's group of four
+    const bool in_range = 4 * (size_t)i4 < (size_t)pv.N;   // (N is a multiple of 4: launch_integrate)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ids = {0u, 0u, 0u, 0u};
+    f32x4 fx = {0, 0, 0, 0}, fy = fx, fh = fx, fv = fx, fa0 = fx, fa1 = fx, fvx = fx, fvy = fx;
+    if (in_range) {
+        ids = reinterpret_cast<const u32x4*>(pv.ids)[i4];
+        fx = reinterpret_cast<const f32x4*>(pv.x)[i4];
+        fy = reinterpret_cast<const f32x4*>(pv.y)[i4];
+        fh = reinterpret_cast<const f32x4*>(pv.heading)[i4];
+        fv = reinterpret_cast<const f32x4*>(pv.speed)[i4];
+        fa0 = reinterpret_cast<const f32x4*>(pv.act0)[i4];
+        fa1 = reinterpret_cast<const f32x4*>(pv.act1)[i4];
+    }
+    static_assert(T2D_PARAM_COLS * T2D_MAX_TYPES == 3 * kBlock, "staging assumes 3 loads per thread");
+    const double t0 = pv.params[tid], t1 = pv.params[tid + kBlock], t2 = pv.params[tid + 2 * kBlock];
+    s_par[tid] = t0;
+    s_par[tid + kBlock] = t1;
+    s_par[tid + 2 * kBlock] = t2;
+    __syncthreads();
+    if (!in_range) return;
+    // a point mass's velocity is state: fetched when any of the four is one (wave-uniform in pools sorted by kind)
+    bool any_pm = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int model = (ids[k] >> kIdsModelShift) & 0xff;
+        any_pm |= ((ids[k] >> kIdsActiveShift) & 0xffu) && model == T2D_MODEL_POINTMASS;
+    }
+    if (any_pm) {
+        fvx = reinterpret_cast<const f32x4*>(pv.vx)[i4];
+        fvy = reinterpret_cast<const f32x4*>(pv.vy)[i4];
+    }
+    f32x4 ovx = fvx, ovy = fvy, oa0 = {0, 0, 0, 0}, oa1 = oa0;
+    uint32_t done = 0u, has_vel = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool active = (ids[k] >> kIdsActiveShift) & 0xffu;
+        const int type = (ids[k] >> kIdsTypeShift) & 0xff;
+        const int model = (ids[k] >> kIdsModelShift) & 0xff;
+        if (!active || model >= T2D_MODEL_DRIFT) continue;
+        auto P = [&](int col) -> double { return s_par[col * T2D_MAX_TYPES + type]; };
+        StepOut o;
+        if (model == T2D_MODEL_KINEMATICS) {
+            o = step_kinematics<VARIANT, true>(P, (double)fx[k], (double)fy[k], (double)fh[k], (double)fv[k], (double)fa0[k],
+                                               (double)fa1[k], interval_ms);
+        } else if (model == T2D_MODEL_DYNAMICS) {
+            o = step_dynamics<VARIANT>(P, (double)fx[k], (double)fy[k], (double)fh[k], (double)fv[k], (double)fa0[k],
+                                       (double)fa1[k], interval_ms);
+        } else {
+            o = step_pointmass(P, (double)fx[k], (double)fy[k], (double)fvx[k], (double)fvy[k], (double)fa0[k], (double)fa1[k],
+                               pv.interval_s);
+        }
+        fx[k] = (float)o.x;
+        fy[k] = (float)o.y;
+        fh[k] = (float)o.heading;
+        fv[k] = (float)o.speed;
+        oa0[k] = (float)o.app0;
+        oa1[k] = (float)o.app1;
+        done |= 1u << k;
+        if (o.has_velocity && (model == T2D_MODEL_POINTMASS || (pv.out_mask & T2D_OUT_VELOCITY))) {
+            ovx[k] = (float)o.vx;
+            ovy[k] = (float)o.vy;
+            has_vel |= 1u << k;
+        }
+    }
+    if (done == 0u) return;
+    // whole-vector stores where all four were stepped (the usual case); element stores otherwise -- a slot that was not
+    // stepped (inactive, drift model) keeps every byte it had
+    auto put = [&](float* col, const f32x4& v, uint32_t mask) {
+        if (mask == 15u) {
+            reinterpret_cast<f32x4*>(col)[i4] = v;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (mask >> k & 1u) col[4 * (size_t)i4 + k] = v[k];
+        }
+    };
+    put(pv.x, fx, done);
+    put(pv.y, fy, done);
+    put(pv.heading, fh, done);
+    put(pv.speed, fv, done);
+    if (has_vel) {
+        put(pv.vx, ovx, has_vel);
+        put(pv.vy, ovy, has_vel);
+    }
+    if (pv.out_mask & T2D_OUT_APPLIED) {
+        put(pv.applied0, oa0, done);
+        put(pv.applied1, oa1, done);
     }
 }
 
@@ -179,7 +281,21 @@ hipError_t launch_derive(double* params, int n_types, int interval_ms, hipStream
     return hipGetLastError();
 }
 
-hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hipStream_t s) {
+hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, bool allow_wide, hipStream_t s) {
+    // pools that still put eight waves' worth of lanes on every SIMD with four participants per lane (>= 2 M on an MI355X:
+    // at 1 M the wide kernel's 158 registers -- three waves per SIMD -- made every model slower, 21.8 -> 24.0 us), contiguous
+    // actions, no IDM lanes reading the pool's own fields beside caller-owned ones, every column 16-byte aligned
+    auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    if (allow_wide && v.N >= kWideMinParticipants && (v.N & 3) == 0 && v.act_stride == 1 && !v.idm_ctrl && aligned(v.act0) && aligned(v.act1) &&
+        aligned(v.x) && aligned(v.y) && aligned(v.heading) && aligned(v.speed) && aligned(v.vx) && aligned(v.vy) &&
+        aligned(v.applied0) && aligned(v.applied1) && aligned(v.ids)) {
+        const int grid4 = (v.N / 4 + kBlock - 1) / kBlock;
+        if (variant == 0)
+            hipLaunchKernelGGL(integrate_wide_kernel<0>, dim3(grid4), dim3(kBlock), 0, s, v, interval_ms);
+        else
+            hipLaunchKernelGGL(integrate_wide_kernel<1>, dim3(grid4), dim3(kBlock), 0, s, v, interval_ms);
+        return hipGetLastError();
+    }
     const int grid = (v.N + kBlock - 1) / kBlock;
     if (variant == 0)
         hipLaunchKernelGGL(integrate_kernel<0>, dim3(grid), dim3(kBlock), 0, s, v, interval_ms);

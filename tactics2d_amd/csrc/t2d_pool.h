@@ -48,6 +48,23 @@ constexpr int kSafeRects = 4;   // per env
 constexpr int kKinDegree = 4;   // resummed kinematics: polynomials of degree 4 in a^2 (truncation < 2e-10 m at |a| <= 0.5)
 enum { KIN_Q0 = 0, KIN_Q4, KIN_Q2, KIN_Q6, KIN_R4, KIN_R8, KIN_R2, KIN_R6 };
 
+// Maps beyond the step kernel's LDS record: one uniform grid per env in HBM (t2d_mapgrid.hip)
+constexpr float kGridMargin = 1e-2f;   // parts are registered, and poses looked up, with boxes widened by this much (m)
+struct MapGridEnv {
+    float x0, y0, inv_cell;   // cell (ix, iy) covers [x0 + ix / inv_cell, ...) x [y0 + iy / inv_cell, ...)
+    int32_t nx, ny, cell_off; // the env's cells are cell_start[cell_off + iy * nx + ix]
+    int32_t has_lanes, pad;
+};
+struct MapGridView {
+    const MapGridEnv* env;        // [E]
+    const int32_t* cell_start;    // CSR over all cells of all envs (+ 1)
+    const uint32_t* cell_items;   // part index (global, as in vert_off) | kind << 31 (0 static, 1 lane)
+    const int32_t* vert_off[2];   // the parts of t2d_set_static_geometry / t2d_set_lane_geometry (fans of 3- / 4-gons)
+    const float* xy[2];
+    const int32_t* bnd_off;       // lane parts: boundary pieces of the env's lane union, 4 doubles each
+    const double* bnd;
+};
+
 // What kernels receive by value.
 struct LidarView;
 struct SceneView;
@@ -140,6 +157,9 @@ struct PoolView {
     // the host (long double) whenever the interval changes; read by the kernels as scalar loads from their argument block.
     double kin_coef[kKinDegree + 1][8];
     double kin_geo[8];
+    // pools whose static + lane geometry lives in the HBM grid tier (t2d_mapgrid.hip): the per-participant verdicts
+    // (T2D_FLAG_COLLISION_STATIC | T2D_FLAG_OFF_LANE) of map_events_kernel, OR-ed into the flags by the event kernel; else null
+    const uint32_t* map_flags;
     unsigned long long* dbg;  // phase cycle accumulators (profiling builds with -DT2D_TIMING only)
     double cell;      // spatial-hash cell edge (m) >= max circum-diameter * 1.001
     double inv_cell;
@@ -235,6 +255,14 @@ struct t2d_pool {
     size_t field_bytes[T2D_F_COUNT]{};
     double* d_params = nullptr;
     uint32_t* d_geo = nullptr;
+    // the HBM grid tier of maps too large for the LDS record (rebuild_geo): device copies of the parts + the grid
+    bool grid_tier = false;
+    t2d::MapGridView mapgrid{};
+    t2d::MapGridEnv* d_grid_env = nullptr;
+    int32_t *d_grid_cell_start = nullptr, *d_grid_vert_off[2] = {nullptr, nullptr}, *d_grid_bnd_off = nullptr;
+    uint32_t *d_grid_items = nullptr, *d_map_flags = nullptr;
+    float* d_grid_xy[2] = {nullptr, nullptr};
+    double* d_grid_bnd = nullptr;
     float* d_boundary = nullptr;
     uint8_t* d_boundary_valid = nullptr;
     // host copies of the CCW-normalised CSR geometry, kind 0 static / 1 lanes
@@ -315,6 +343,7 @@ struct t2d_pool {
     bool ckpt_armed = false;       // every multi-step launch since the last quiesce was a CHAIN launch with a checkpoint
     uint32_t chain_sig = 0;        // shape (workgroups, split) of the last CHAIN launch whose counters d_chain holds; 0 = none
     uint32_t chain_fault = 0;      // t2d_debug_chain_fault
+    uint32_t types_used = 0;       // bit t: some active participant has type t (t2d_reset)
     int chain_depth = 1;           // steps per workgroup of the chained form of large pools (T2D_CHAIN_DEPTH in the environment)
     int device_cus = 0;            // compute units of the pool's device (read once)
     // result gather (the one collective of the path): RCCL communicator + a stream of its own, so that the steps that
@@ -352,7 +381,7 @@ struct t2d_pool {
 
 // kernel launchers (defined in t2d_integrate.hip / t2d_collide.hip)
 namespace t2d {
-hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, hipStream_t s);
+hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, bool allow_wide, hipStream_t s);
 // column T2D_P_SUBSTEPS of the device table for `interval_ms` (rows of the drift model keep their own column 23)
 hipError_t launch_derive(double* params, int n_types, int interval_ms, hipStream_t s);
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,
@@ -371,6 +400,10 @@ hipError_t launch_idm(const PoolView& v, const IdmView& iv, const int32_t* force
 hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
                           hipStream_t s);
 hipError_t launch_spin(long long ticks_100mhz, hipStream_t s);
+hipError_t launch_map_events(const PoolView& v, const MapGridView& mg, uint32_t* out, hipStream_t s);
+#ifdef T2D_DEBUG_HOOKS
+const char* last_collide_form();   // template arguments of the collide_kernel instantiation the last launch took (t2d_collide.hip)
+#endif
 hipError_t launch_frame_pack(const PoolView& v, const FrameView& fv, hipStream_t s);
 // note that work of this pool was enqueued on `s` by code outside t2d_api.hip (a replayed graph): t2d_sync waits for it
 void pool_touch(t2d_pool* p, hipStream_t s);

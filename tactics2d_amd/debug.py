@@ -34,6 +34,7 @@ DEBUG_SYMBOLS = {
     "t2d_debug_closed_loop_create": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_vp)]),
     "t2d_debug_closed_loop_run": (C.c_int, [_vp, C.c_int32]),
     "t2d_debug_closed_loop_destroy": (C.c_int, [_vp]),
+    "t2d_debug_last_step_kernel": (C.c_char_p, []),
 }
 
 _debug_lib = None
@@ -83,6 +84,11 @@ def delay_gather(p, microseconds):
     """t2d_debug_delay_gather: one idle wave holds the pool's gather stream for that long"""
     _need(p)
     p._ck(p._lib.t2d_debug_delay_gather(p._h, int(microseconds)))
+
+
+def last_step_kernel():
+    """template arguments of the collide_kernel instantiation the last launch took, e.g. "(true, 1, false, true)\""""
+    return lib().t2d_debug_last_step_kernel().decode()
 
 
 def feedback_policy(p, act_out_ptr, v_target, k_speed, k_steer, stream=None):

@@ -338,7 +338,7 @@ def from_reference_map(map_, origin=(0.0, 0.0), obstacle_subtypes=("obstacle",),
 def geometry_budget(n_env, max_agents, static=None, lanes=None):
     """What t2d_set_static_geometry + t2d_set_lane_geometry would need of the 32 KiB per-workgroup record for these scenes
     (per-env lists of convex polygons, or CSR triples), WITHOUT a device: dict(dwords_needed, dwords_budget, envs_per_workgroup,
-    fits).  Raises GeometryError for polygons the library rejects (not convex, degenerate, > 8 vertices)."""
+    fits, tier).  Raises GeometryError for polygons the library rejects (not convex, degenerate, > 8 vertices)."""
     from . import _ffi
     from .traffic import polygons_to_csr
 
@@ -353,4 +353,8 @@ def geometry_budget(n_env, max_agents, static=None, lanes=None):
     need, budget, epb = C.c_int32(), C.c_int32(), C.c_int32()
     _ffi.check(_ffi.lib().t2d_geometry_budget(int(n_env), int(max_agents), p(s[0]), p(s[1]), p(s[2]), p(l[0]), p(l[1]), p(l[2]),
                                                    C.byref(need), C.byref(budget), C.byref(epb)))
-    return dict(dwords_needed=need.value, dwords_budget=budget.value, envs_per_workgroup=epb.value, fits=need.value <= budget.value)
+    fits = need.value <= budget.value
+    # (a scene that does not fit the LDS record is not refused: t2d_set_*_geometry keeps it in the HBM grid tier -- one uniform
+    # grid per env, tactics2d_amd/csrc/t2d_mapgrid.hip -- and the pool steps as integrate -> map events -> events + status)
+    return dict(dwords_needed=need.value, dwords_budget=budget.value, envs_per_workgroup=epb.value, fits=fits,
+                tier="lds_record" if fits else "hbm_grid")

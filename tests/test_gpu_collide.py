@@ -246,9 +246,13 @@ def test_reference_lane_rings_through_the_map_adapter(oracle):
         assert bool(got[i] & L.FLAG_OFF_LANE) == (not inside), i
         n_in += inside
     assert 20 < n_in < n // 3 - 20
-    # a scene that does not fit: the budget query says so, and so does the library
+    # a scene that does not fit the LDS record: the budget query says so, and the library keeps it in the HBM grid tier
+    # (tests/test_gpu_mapgrid.py) instead of refusing it
     too_many = [pieces * 8] * n_env
-    assert not MG.geometry_budget(n_env, A, lanes=too_many)["fits"]
-    with pytest.raises(_ffi.GeometryError):
-        pool.set_lane_geometry(polygons_to_csr(too_many))
+    bud = MG.geometry_budget(n_env, A, lanes=too_many)
+    assert not bud["fits"] and bud["tier"] == "hbm_grid"
+    pool.set_lane_geometry(polygons_to_csr(too_many))
+    assert pool.step_form(1) == "unfused"
+    pool.collide()
+    assert np.array_equal(pool.download(L.F_FLAGS), got)          # the same lanes eight times over: the same verdicts
     pool.close()

@@ -151,6 +151,49 @@ def test_pointmass_euler_mirror_and_pools_that_hold_both_backends(oracle):
 
 
 @pytest.mark.parametrize("variant", ["fast", "exact"])
+def test_four_per_lane_integrator_of_large_pools_equals_the_one_per_lane_step(variant):
+    """Pools of >= 2 M participants without a dynamics row take t2d_integrate with four consecutive participants per lane
+    (16-byte loads and stores: integrate_wide_kernel).  Same arithmetic per participant: every state column equals, bit for
+    bit, what the fused step's one-per-lane integrator leaves behind -- kinematic bicycles and point masses in one pool,
+    inactive slots untouched."""
+    from tactics2d_amd import layout as L, scenarios as S
+    from tactics2d_amd.pool import ParticipantPool
+    rows, _ = S.full_type_table()
+    rows = rows[(rows[:, L.P_MODEL] == L.MODEL_KINEMATICS) | (rows[:, L.P_MODEL] == L.MODEL_POINTMASS)]
+    models = rows[:, L.P_MODEL].astype(int)
+    usable = np.arange(len(rows))
+    n_env, A = 32768, 64
+    n = n_env * A
+    rng = np.random.default_rng(12)
+    tid = usable[rng.integers(0, usable.size, n)].astype(np.uint8)
+    active = (rng.random(n) > 0.03).astype(np.uint8)
+    pm = models[tid] == L.MODEL_POINTMASS
+    x, y = np.float32(rng.uniform(-100, 100, n)), np.float32(rng.uniform(-100, 100, n))
+    h = np.float32(rng.uniform(0, 6.28, n))
+    v = np.float32(np.where(pm, rng.uniform(0.5, 1.4, n), rng.uniform(0.0, 9.0, n)))
+    vx, vy = np.float32(v * np.cos(h)), np.float32(v * np.sin(h))
+    a0, a1 = np.float32(rng.uniform(-2.0, 2.0, n)), np.float32(rng.uniform(-0.3, 0.3, n))
+    fields = (L.F_X, L.F_Y, L.F_HEADING, L.F_SPEED, L.F_VX, L.F_VY, L.F_APPLIED0, L.F_APPLIED1)
+
+    def run(fused):
+        pool = ParticipantPool(n_env, A)
+        pool.set_param_table(rows)
+        pool.set_integrator_variant(variant)
+        pool.reset(x, y, h, v, tid, active, vx=vx, vy=vy)
+        pool.set_actions(a0, a1)
+        (pool.step if fused else pool.integrate)(100)
+        out = [pool.download(f) for f in fields]
+        pool.close()
+        return out
+    wide, narrow = run(False), run(True)
+    for f, w, nr in zip(fields, wide, narrow):
+        assert np.array_equal(w.view(np.uint32), nr.view(np.uint32)), (f, int((w.view(np.uint32) != nr.view(np.uint32)).sum()))
+    off = active == 0
+    assert np.array_equal(wide[0][off], x[off]) and np.array_equal(wide[3][off], v[off])
+    assert (wide[0][~off] != x[~off]).mean() > 0.9
+
+
+@pytest.mark.parametrize("variant", ["fast", "exact"])
 def test_dynamics_within_1e5_of_reference_wherever_it_is_conditioned(variant):
     """Every dyn_random case against the reference's own result, with the tolerance its conditioning allows
     (helpers.dyn_tolerance): 1e-5 where 100 ulp-sensitivities stay under 1e-6 (5731 of 6000 cases), 1e-5 + 1000 x
