@@ -12,4 +12,8 @@ cp gpurun_out/prof_$TAG/*.log gpurun_out/${TAG}_logs/ 2>/dev/null; rm -rf gpurun
 cp gpurun_out/${TAG}_traffic_latest.json profiles/traffic_latest.json
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_like.json 2> gpurun_out/${TAG}_logs/bench_driver_like.err; echo "bench (20 steps) rc $?"
 timeout 900 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline > gpurun_out/${TAG}_bench_1000.json 2> gpurun_out/${TAG}_logs/bench_1000.err; echo "bench (1000 steps) rc $?"
+# round 6: the chained form's attribution on the final binary (timing build), the wait-side counters, power + clock
+T2D_LIB_NAME=libt2d_hip_timing.so timeout 300 python scripts/chain_timing.py 20 gpurun_out/${TAG}_chain_timing_frag20.json > gpurun_out/${TAG}_logs/chain_timing.log 2>&1; echo "chain timing rc $?"
+MODE=chain PASSES=3 bash scripts/sq_wait_chain.sh $TAG > gpurun_out/${TAG}_logs/sq_wait_chain.log 2>&1; echo "sq wait rc $?"
+T2D_PC_SECONDS=2.5 timeout 300 python scripts/power_clock.py gpurun_out/${TAG}_power_clock.json > gpurun_out/${TAG}_logs/power_clock.log 2>&1; echo "power clock rc $?"
 du -sh gpurun_out

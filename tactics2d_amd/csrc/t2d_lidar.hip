@@ -25,6 +25,11 @@ namespace t2d {
 namespace {
 
 constexpr int kLidarBlock = 128;
+#ifndef T2D_LIDAR_ONE_WAVE
+#define T2D_LIDAR_ONE_WAVE 0   // (round 6, measured and left off: one wave per env scans 4096 lots in 21.7 us against 20.0 with two --
+                               // HIP events around each launch, same box, ABAB; the vector step 29.7 against 27.4 -- bit-identical)
+#endif
+constexpr int kOneWaveMinEnvs = 2048;   // one wave per env must still put >= 2 waves on every SIMD
 constexpr int kLidarQueue = 256;  // (beam, edge) candidates per wave per round (LidarView::queue_len: 128 where that buys a workgroup per CU)
 // An edge's beam span in LDS, one word: first beam (12 bits, < n_beams <= 4096) | length + 1 (13 bits, -1 .. n_beams) |
 // "16 + ring" of a front edge with a core (5 bits, else 0: see the occlusion culling below).  0 = nothing to scatter.
@@ -148,12 +153,19 @@ T2D_DEV int2 edge_span(double x1, double y1, double x2, double y2, double R, int
 // WAVES = waves per SIMD the register allocation is held to: short edge lists (ParkingEnv: ~32 edges) are bound by
 // the chain of dependent latencies per workgroup, so twice the resident workgroups beat the 22 spilled registers
 // (39 vs 47 us at 4096 envs); long lists (participants scanned: 250+ edges) are issue-bound and keep all 98 registers.
-template <int WAVES, bool PARTS>
-__global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, LidarView lv, float* out) {
+// BLOCK = threads per env: 128 (two waves).  BLOCK = 64 -- one wave per env, six beams per lane, no workgroup barrier that means
+// anything, half the waves -- was the review's proposal for the ParkingEnv scan (32 static edges need 32 lanes in phase 1 and 64 in
+// the scatter: the second wave only helps in the evaluation and pays its own ego transform for it).  Built in round 6
+// (-DT2D_LIDAR_ONE_WAVE=1), bit-identical, SLOWER: the evaluation is 57 % of a wave's cycles (scripts/lidar_phases.py) and its
+// compaction rounds are chains of LDS round trips that eight waves per SIMD hide and four do not.
+template <int WAVES, bool PARTS, int BLOCK = kLidarBlock, bool PRE = (WAVES == 8)>
+__global__ __launch_bounds__(BLOCK, WAVES) void lidar_kernel(PoolView pv, LidarView lv, float* out) {
+    constexpr int kLidarBlock = BLOCK;          // (shadows the namespace constant: everything below is per instantiation)
+    constexpr int kChunk = BLOCK / 2;           // edges per scatter chunk: two lanes per edge
     // short edge lists (the 8-waves-per-SIMD instantiation, ParkingEnv) keep the precomputed EdgePre per edge (64 B);
     // long lists keep the four end-point coordinates (32 B) and derive it per candidate: twice the LDS per slot would
     // cost them resident workgroups (47 -> 61 us on the 252-edge scene)
-    constexpr bool kPre = WAVES == 8;
+    constexpr bool kPre = PRE;
     constexpr int kSlotDoubles = kPre ? 8 : 4;
     extern __shared__ __attribute__((aligned(16))) double s_edge_raw[];  // [slots][kSlotDoubles] (sensor frame)
     auto put_edge = [&](int slot, double x1, double y1, double x2, double y2) {
@@ -253,7 +265,8 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     T2D_LMARK(0);
 
     // ---- phase 1a: static polygon edges (vertex v -> next vertex of its ring) ------------------------
-    const bool cull_on = kCull && lv.edge_meta != nullptr && n_static <= kCullEdges;   // (workgroup-uniform)
+    // (the culling's bit layout wants every edge in ONE scatter chunk)
+    const bool cull_on = kCull && lv.edge_meta != nullptr && n_static <= (kCullEdges < kChunk ? kCullEdges : kChunk);   // (workgroup-uniform)
     if (kCull && tid < 16) s_back[tid] = 0u;
     if (kCull && tid < 8) s_back_hi[tid] = 0u;
     for (int q = tid; q < n_static; q += kLidarBlock) {
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
     };
     const bool scan = ego_active && n_slots > 0;
     const int n_iter = (lv.n_beams + kLidarBlock - 1) / kLidarBlock;
-    for (int c0 = 0; c0 < n_slots && scan; c0 += 64) {
+    for (int c0 = 0; c0 < n_slots && scan; c0 += kChunk) {
         // pass 1, edge-major: every edge of the chunk ORs its bit into the masks of the beams of its span (two
         // lanes per edge, alternate beams) -- sum of span lengths instead of beams x edges comparisons
         if (c0 > 0) {
@@ -435,7 +448,7 @@ __global__ __launch_bounds__(kLidarBlock, WAVES) void lidar_kernel(PoolView pv, 
             }
         }
         T2D_LMARK(3);
-        if (c0 + 64 < n_slots) __syncthreads();  // the next chunk clears s_mask
+        if (c0 + kChunk < n_slots) __syncthreads();  // the next chunk clears s_mask
     }
     wave_sync();
     __builtin_amdgcn_s_setprio(0);
@@ -469,6 +482,14 @@ hipError_t launch_lidar(const PoolView& v, const LidarView& lv_in, float* out, h
     const size_t dyn = lds(lv.queue_len);
     // (the scan of static obstacles only -- ParkingEnv -- is compiled without the participants' phase: at the 64
     // registers of 8 waves / SIMD that code cost the whole kernel 27 spilled registers, reloaded in the evaluation loop)
+    // ParkingEnv's laid-out lots (<= 32 static edges) in pools that fill the GPU with one wave per env: see BLOCK above
+    if (short_list && !lv.include_participants && lv.max_slots <= 32 && v.n_env >= kOneWaveMinEnvs && T2D_LIDAR_ONE_WAVE) {
+        lv.queue_len = kLidarQueue;
+        const size_t dyn1 = (sizeof(EdgePre)) * (size_t)lv.max_slots + 4 * (size_t)((lv.max_slots + 1) & ~1) +
+                            16 * (size_t)lv.n_beams + 4 * (size_t)lv.queue_len;
+        hipLaunchKernelGGL((lidar_kernel<4, false, 64, true>), dim3(v.n_env), dim3(64), dyn1, s, v, lv, out);
+        return hipGetLastError();
+    }
     if (short_list && !lv.include_participants)
         hipLaunchKernelGGL((lidar_kernel<8, false>), dim3(v.n_env), dim3(kLidarBlock), dyn, s, v, lv, out);
     else if (short_list)
