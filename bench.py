@@ -234,6 +234,43 @@ class Runner:
         self.pool.close()
 
 
+def integrator_per_model(variant, n_env=65536, A=64):
+    """north_star's roofline kernel at a size where it STREAMS (4 M participants; the metric's 262 144 are one wave round: launch
+    ramp, not bandwidth): t2d_integrate per physics model, us per launch and the fraction of the 8 TB/s peak on SURVEY 8(d)'s 44-B
+    figure.  Pools of >= 2 M participants without a dynamics participant take four participants per lane."""
+    from tactics2d_amd import layout as L, scenarios as S
+    from tactics2d_amd.pool import ParticipantPool
+    rows, _ = S.full_type_table()
+    models = rows[:, L.P_MODEL].astype(int)
+    n = n_env * A
+    out = {}
+    for label, model in (("kinematics", L.MODEL_KINEMATICS), ("dynamics", L.MODEL_DYNAMICS), ("pointmass", L.MODEL_POINTMASS)):
+        ids = np.nonzero(models == model)[0]
+        rng = np.random.default_rng(1)
+        tid = ids[rng.integers(0, ids.size, n)].astype(np.uint8)
+        pool = ParticipantPool(n_env, A)
+        pool.set_param_table(rows)
+        pool.set_integrator_variant(variant)
+        pool.reset(np.float32(rng.uniform(-100, 100, n)), np.float32(rng.uniform(-100, 100, n)), np.float32(rng.uniform(0, 6.28, n)),
+                   np.float32(rng.uniform(0.5, 1.4, n) if model == L.MODEL_POINTMASS else rng.uniform(2.0, 7.5, n)), tid)
+        pool.set_actions(np.float32(rng.uniform(-1.0, 1.0, n)), np.float32(rng.uniform(-0.08, 0.08, n)))
+        pool.snapshot()
+        for _ in range(3):
+            pool.integrate(100)
+        pool.profile_enable(True)
+        for _ in range(12):
+            pool.restore()
+            pool.integrate(100)
+        ms, launches = pool.profile_read(0)
+        us = 1e3 * ms / launches
+        out[label] = dict(participants=n, avg_us=us, achieved_gbs=INTEGRATOR_BYTES * n / (us * 1e-6) / 1e9,
+                          frac=INTEGRATOR_BYTES * n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS)
+        pool.close()
+    out["note"] = ("stand-alone t2d_integrate on pools of one model, every launch from the same snapshot, HIP events around each launch "
+                   "(~2 us of the pair included); 44 algorithmic bytes per participant -- the kernel really moves 56-60")
+    return out
+
+
 def power_clock_under_load(run, mode, frag, seconds=0.6):
     """Socket power and shader clock the SMU reports WHILE the headline launches run (amdsmi's metrics table, sampled by a
     thread; outside `value`): whether the step's time is set by a power budget.  None when amdsmi is not importable."""
@@ -796,6 +833,12 @@ def main():
     pclk = None
     if world == 1 and gather is None and not args.no_profile:
         pclk = power_clock_under_load(run, mode, frag)
+    integ_models = None
+    if world == 1 and gather is None and not args.no_profile and args.config == "metric" and not args.no_next_rows:
+        try:
+            integ_models = integrator_per_model(args.variant)
+        except Exception as exc:   # noqa: BLE001 -- a reported side measurement, never fatal for the line
+            integ_models = dict(error=str(exc))
 
     # ---- the other ways of running the same steps, driver-timed like `value` -----------------------------------------
     alternates = None
@@ -958,6 +1001,8 @@ def main():
             if isq and isq.get("SQ_WAVES"):
                 integ.update(valu_insts_per_wave=isq["SQ_INSTS_VALU"] / isq["SQ_WAVES"],
                              valu_busy_frac=isq.get("_valu_busy_frac"), rocprofv3_avg_us=tj.get("kernel_trace_avg_us_per_step", {}).get("step", {}).get("integrate_kernel"))
+        if integ is not None and integ_models is not None:
+            integ["per_model_at_4M_participants"] = integ_models
         roof["integrator"] = integ
         gather_obj = None
         if gather is not None:

@@ -16,4 +16,6 @@ timeout 900 python bench.py --steps 1000 --warmup 100 --no-cpu-baseline > gpurun
 T2D_LIB_NAME=libt2d_hip_timing.so timeout 300 python scripts/chain_timing.py 20 gpurun_out/${TAG}_chain_timing_frag20.json > gpurun_out/${TAG}_logs/chain_timing.log 2>&1; echo "chain timing rc $?"
 MODE=chain PASSES=3 bash scripts/sq_wait_chain.sh $TAG > gpurun_out/${TAG}_logs/sq_wait_chain.log 2>&1; echo "sq wait rc $?"
 T2D_PC_SECONDS=2.5 timeout 300 python scripts/power_clock.py gpurun_out/${TAG}_power_clock.json > gpurun_out/${TAG}_logs/power_clock.log 2>&1; echo "power clock rc $?"
+timeout 600 python tests/soak/soak.py 60 > gpurun_out/${TAG}_logs/soak.log 2>&1; echo "soak rc $?"; tail -2 gpurun_out/${TAG}_logs/soak.log
+timeout 600 python tests/soak/soak_lidar.py 150 > gpurun_out/${TAG}_logs/soak_lidar.log 2>&1; echo "soak lidar rc $?"; tail -2 gpurun_out/${TAG}_logs/soak_lidar.log
 du -sh gpurun_out

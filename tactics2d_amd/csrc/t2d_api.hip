@@ -24,6 +24,8 @@ typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3 } nccl
 #include <limits>
 #include <memory>
 #include <new>
+#include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "t2d_pool.h"
@@ -331,8 +333,34 @@ void build_lane_boundary(int E, t2d_pool::HostGeo& g) {
     g.bnd_off.assign((size_t)P + 1, 0);
     g.bnd.clear();
     std::vector<std::pair<double, double>> iv;
+    // Envs that hold the SAME lanes -- every env of a pool on one reference map -- share the result: the walk is edge x polygon
+    // per env (seconds for the thousands of parts of a real map), done once per distinct geometry and copied.
+    struct Done { std::vector<int32_t> count; std::vector<double> pieces; };
+    std::unordered_map<std::string, Done> cache;
     for (int e = 0; e < E; ++e) {
         const int l0 = g.env_off[e], l1 = g.env_off[e + 1];
+        std::string key;
+        {
+            const int v0 = g.vert_off[l0], v1 = g.vert_off[l1];
+            key.assign(reinterpret_cast<const char*>(&g.xy[2 * (size_t)v0]), sizeof(float) * 2 * (size_t)(v1 - v0));
+            for (int li = l0; li <= l1; ++li) {
+                const int32_t rel = g.vert_off[li] - v0;
+                key.append(reinterpret_cast<const char*>(&rel), sizeof rel);
+            }
+        }
+        auto hit = cache.find(key);
+        if (hit != cache.end()) {
+            const Done& d = hit->second;
+            g.bnd.insert(g.bnd.end(), d.pieces.begin(), d.pieces.end());
+            int32_t at = g.bnd_off[(size_t)l0];
+            for (int li = l0; li < l1; ++li) {
+                at += d.count[(size_t)(li - l0)];
+                g.bnd_off[(size_t)li + 1] = at;
+            }
+            continue;
+        }
+        Done d;
+        const size_t bnd_before = g.bnd.size();
         for (int li = l0; li < l1; ++li) {
             const int v0 = g.vert_off[li], n = g.vert_off[li + 1] - v0;
             double L[2 * T2D_MAX_POLY_VERTS];
@@ -345,6 +373,12 @@ void build_lane_boundary(int E, t2d_pool::HostGeo& g) {
                 iv.clear();
                 for (int mi = l0; mi < l1; ++mi) {
                     if (mi == li) continue;
+                    // (a polygon whose box does not reach this edge's cannot cover any of it: the clip below would say so,
+                    // 4 comparisons say it first -- what keeps a 1000-part map at seconds, not minutes)
+                    const float* bb = &g.aabb[4 * (size_t)mi];
+                    const double ex0 = q0[0] < q1[0] ? q0[0] : q1[0], ex1 = q0[0] < q1[0] ? q1[0] : q0[0];
+                    const double ey0 = q0[1] < q1[1] ? q0[1] : q1[1], ey1 = q0[1] < q1[1] ? q1[1] : q0[1];
+                    if ((double)bb[0] > ex1 || (double)bb[1] < ex0 || (double)bb[2] > ey1 || (double)bb[3] < ey0) continue;
                     const int w0 = g.vert_off[mi], m = g.vert_off[mi + 1] - w0;
                     double M[2 * T2D_MAX_POLY_VERTS];
                     for (int k = 0; k < 2 * m; ++k) M[k] = (double)g.xy[2 * (size_t)w0 + k];
@@ -366,7 +400,10 @@ void build_lane_boundary(int E, t2d_pool::HostGeo& g) {
                 }
             }
             g.bnd_off[(size_t)li + 1] = (int32_t)(g.bnd.size() / 4);
+            d.count.push_back(g.bnd_off[(size_t)li + 1] - g.bnd_off[(size_t)li]);
         }
+        d.pieces.assign(g.bnd.begin() + (long)bnd_before, g.bnd.end());
+        cache.emplace(std::move(key), std::move(d));
     }
 }
 
