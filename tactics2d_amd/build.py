@@ -13,10 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, os.environ.get("T2D_LIB_NAME", "libt2d_hip.so"))
 SOURCES = ["t2d_api.hip", "t2d_integrate.hip", "t2d_collide.hip", "t2d_lidar.hip", "t2d_idm.hip", "t2d_drift.hip",
-           "t2d_generate.hip", "t2d_ego.hip", "t2d_frame.hip", "t2d_mapgrid.hip"]
+           "t2d_generate.hip", "t2d_ego.hip", "t2d_frame.hip", "t2d_mapgrid.hip", "t2d_geometry_host.hip"]
 # test / measurement hooks (include/t2d_debug.h): compiled into libt2d_hip_debug.so only
 DEBUG_SOURCES = ["t2d_loop.hip"]
-HEADERS = ["t2d_math.h", "t2d_pool.h", "t2d_integrate_dev.h", "t2d_geom_dev.h", "t2d_idm_dev.h", "t2d_scene_dev.h",
+HEADERS = ["t2d_math.h", "t2d_pool.h", "t2d_host.h", "t2d_integrate_dev.h", "t2d_geom_dev.h", "t2d_idm_dev.h", "t2d_scene_dev.h",
            os.path.join("..", "..", "include", "t2d.h")]
 DEBUG_HEADERS = [os.path.join("..", "..", "include", "t2d_debug.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
