@@ -990,7 +990,13 @@ int t2d_integrate(t2d_pool* p, int32_t interval_ms, void* hip_stream) {
     bool wide = true;
     for (int t = 0; t < p->v.n_types; ++t)   // (of the types some active participant HAS: t2d_reset keeps the set)
         wide = wide && !((p->types_used >> t & 1u) && (int)p->host_params[t][T2D_P_MODEL] == T2D_MODEL_DYNAMICS);
-    T2D_HIP(p, t2d::launch_integrate(p->v, interval_ms, p->integrator_variant, wide, s));
+    int only_model = -1;   // the one model every active participant has, if there is one: an instantiation that carries it alone
+    for (int t = 0; t < p->v.n_types; ++t)
+        if (p->types_used >> t & 1u) {
+            const int m = (int)p->host_params[t][T2D_P_MODEL];
+            only_model = only_model == -1 || only_model == m ? m : -2;
+        }
+    T2D_HIP(p, t2d::launch_integrate(p->v, interval_ms, p->integrator_variant, wide, only_model, s));
     return record_event(p, 0, s, false);
 }
 

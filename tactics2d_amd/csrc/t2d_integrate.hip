@@ -29,6 +29,9 @@ namespace t2d {
 
 namespace {
 
+#ifndef T2D_WIDE_ONLY_KIN
+#define T2D_WIDE_ONLY_KIN 1
+#endif
 constexpr int kBlock = 256;
 constexpr int kWideMinParticipants = 8 * 64 * 4 * 256 * 4;   // four per lane and still eight waves' worth of lanes per SIMD
 using namespace integ;
@@ -101,8 +104,13 @@ __global__ __launch_bounds__(kBlock) void integrate_kernel(PoolView pv, int inte
 // wave.  At 4 M point masses the one-per-lane kernel moved 3.5 TB/s of its ~60 B per participant (72 us, 0.32 of the 8 TB/s
 // peak on the 44-B figure); the model's arithmetic is the same per participant, the results are the same bits
 // (tests/test_gpu_physics.py holds this kernel against the fused step's one-per-lane integrator).
-template <int VARIANT>
+// ONLY = T2D_MODEL_POINTMASS: every active participant of the pool is a (newton) point mass (the host knows: t2d_reset keeps the set of types in
+// use) -- the instantiation carries that model alone: ~50 registers instead of the 158 of the three bodies unrolled four times,
+// i.e. eight waves per SIMD instead of three, and every load is issued before the first one returns (nothing waits for the ids
+// word to learn the model).  The point mass is the one model whose step is cheap enough to be memory-bound.
+template <int VARIANT, int ONLY = -1>   // ONLY: the one model every active participant has (T2D_MODEL_*), or -1 = any
 __global__ __launch_bounds__(kBlock) void integrate_wide_kernel(PoolView pv, int interval_ms) {
+    constexpr bool ONLY_PM = ONLY == T2D_MODEL_POINTMASS, ONLY_KIN = ONLY == T2D_MODEL_KINEMATICS;
     __shared__ double s_par[T2D_PARAM_COLS * T2D_MAX_TYPES];
     const int tid = threadIdx.x;
     const int i4 = blockIdx.x * kBlock + tid;          // index of the lane's group of four
@@ -111,14 +119,20 @@ __global__ __launch_bounds__(kBlock) void integrate_wide_kernel(PoolView pv, int
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     u32x4 ids = {0u, 0u, 0u, 0u};
     f32x4 fx = {0, 0, 0, 0}, fy = fx, fh = fx, fv = fx, fa0 = fx, fa1 = fx, fvx = fx, fvy = fx;
-    if (in_range) {
+    if (in_range) {   // what every model reads; heading / speed (single-track models) and vx / vy (point mass) follow the ids word
         ids = reinterpret_cast<const u32x4*>(pv.ids)[i4];
         fx = reinterpret_cast<const f32x4*>(pv.x)[i4];
         fy = reinterpret_cast<const f32x4*>(pv.y)[i4];
-        fh = reinterpret_cast<const f32x4*>(pv.heading)[i4];
-        fv = reinterpret_cast<const f32x4*>(pv.speed)[i4];
         fa0 = reinterpret_cast<const f32x4*>(pv.act0)[i4];
         fa1 = reinterpret_cast<const f32x4*>(pv.act1)[i4];
+        if constexpr (ONLY_PM) {
+            fvx = reinterpret_cast<const f32x4*>(pv.vx)[i4];
+            fvy = reinterpret_cast<const f32x4*>(pv.vy)[i4];
+        }
+        if constexpr (ONLY_KIN) {
+            fh = reinterpret_cast<const f32x4*>(pv.heading)[i4];
+            fv = reinterpret_cast<const f32x4*>(pv.speed)[i4];
+        }
     }
     static_assert(T2D_PARAM_COLS * T2D_MAX_TYPES == 3 * kBlock, "staging assumes 3 loads per thread");
     const double t0 = pv.params[tid], t1 = pv.params[tid + kBlock], t2 = pv.params[tid + 2 * kBlock];
@@ -127,16 +141,26 @@ __global__ __launch_bounds__(kBlock) void integrate_wide_kernel(PoolView pv, int
     s_par[tid + 2 * kBlock] = t2;
     __syncthreads();
     if (!in_range) return;
-    // a point mass's velocity is state: fetched when any of the four is one (wave-uniform in pools sorted by kind)
-    bool any_pm = false;
+    // a point mass's state is (x, y, vx, vy) -- it reads neither heading nor speed --, a single-track model's (x, y, heading,
+    // speed): each pair is fetched only where one of the lane's four needs it (wave-uniform in pools sorted by kind).  For a
+    // point-mass pool that is 8 of 36 bytes read per participant not read: 61 -> 5x us at 4 M.
+    bool any_pm = false, any_st = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int model = (ids[k] >> kIdsModelShift) & 0xff;
-        any_pm |= ((ids[k] >> kIdsActiveShift) & 0xffu) && model == T2D_MODEL_POINTMASS;
+        const bool act = (ids[k] >> kIdsActiveShift) & 0xffu;
+        any_pm |= act && model == T2D_MODEL_POINTMASS;
+        any_st |= act && model < T2D_MODEL_POINTMASS;
     }
-    if (any_pm) {
-        fvx = reinterpret_cast<const f32x4*>(pv.vx)[i4];
-        fvy = reinterpret_cast<const f32x4*>(pv.vy)[i4];
+    if constexpr (ONLY < 0) {
+        if (any_st) {
+            fh = reinterpret_cast<const f32x4*>(pv.heading)[i4];
+            fv = reinterpret_cast<const f32x4*>(pv.speed)[i4];
+        }
+        if (any_pm) {
+            fvx = reinterpret_cast<const f32x4*>(pv.vx)[i4];
+            fvy = reinterpret_cast<const f32x4*>(pv.vy)[i4];
+        }
     }
     f32x4 ovx = fvx, ovy = fvy, oa0 = {0, 0, 0, 0}, oa1 = oa0;
     uint32_t done = 0u, has_vel = 0u;
@@ -148,10 +172,10 @@ __global__ __launch_bounds__(kBlock) void integrate_wide_kernel(PoolView pv, int
         if (!active || model >= T2D_MODEL_DRIFT) continue;
         auto P = [&](int col) -> double { return s_par[col * T2D_MAX_TYPES + type]; };
         StepOut o;
-        if (model == T2D_MODEL_KINEMATICS) {
+        if (ONLY_KIN || (ONLY < 0 && model == T2D_MODEL_KINEMATICS)) {
             o = step_kinematics<VARIANT, true>(P, (double)fx[k], (double)fy[k], (double)fh[k], (double)fv[k], (double)fa0[k],
                                                (double)fa1[k], interval_ms);
-        } else if (model == T2D_MODEL_DYNAMICS) {
+        } else if (ONLY < 0 && model == T2D_MODEL_DYNAMICS) {
             o = step_dynamics<VARIANT>(P, (double)fx[k], (double)fy[k], (double)fh[k], (double)fv[k], (double)fa0[k],
                                        (double)fa1[k], interval_ms);
         } else {
@@ -281,7 +305,7 @@ hipError_t launch_derive(double* params, int n_types, int interval_ms, hipStream
     return hipGetLastError();
 }
 
-hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, bool allow_wide, hipStream_t s) {
+hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, bool allow_wide, int only_model, hipStream_t s) {
     // pools that still put eight waves' worth of lanes on every SIMD with four participants per lane (>= 2 M on an MI355X:
     // at 1 M the wide kernel's 158 registers -- three waves per SIMD -- made every model slower, 21.8 -> 24.0 us), contiguous
     // actions, no IDM lanes reading the pool's own fields beside caller-owned ones, every column 16-byte aligned
@@ -290,6 +314,15 @@ hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, boo
         aligned(v.x) && aligned(v.y) && aligned(v.heading) && aligned(v.speed) && aligned(v.vx) && aligned(v.vy) &&
         aligned(v.applied0) && aligned(v.applied1) && aligned(v.ids)) {
         const int grid4 = (v.N / 4 + kBlock - 1) / kBlock;
+        if (only_model == T2D_MODEL_POINTMASS) {   // (one arithmetic for both variants: the point mass has no trig recurrence to approximate)
+            hipLaunchKernelGGL((integrate_wide_kernel<1, T2D_MODEL_POINTMASS>), dim3(grid4), dim3(kBlock), 0, s, v, interval_ms);
+            return hipGetLastError();
+        }
+        if (only_model == T2D_MODEL_KINEMATICS && T2D_WIDE_ONLY_KIN) {
+            if (variant == 0) hipLaunchKernelGGL((integrate_wide_kernel<0, T2D_MODEL_KINEMATICS>), dim3(grid4), dim3(kBlock), 0, s, v, interval_ms);
+            else hipLaunchKernelGGL((integrate_wide_kernel<1, T2D_MODEL_KINEMATICS>), dim3(grid4), dim3(kBlock), 0, s, v, interval_ms);
+            return hipGetLastError();
+        }
         if (variant == 0)
             hipLaunchKernelGGL(integrate_wide_kernel<0>, dim3(grid4), dim3(kBlock), 0, s, v, interval_ms);
         else

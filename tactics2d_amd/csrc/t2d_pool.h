@@ -381,7 +381,7 @@ struct t2d_pool {
 
 // kernel launchers (defined in t2d_integrate.hip / t2d_collide.hip)
 namespace t2d {
-hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, bool allow_wide, hipStream_t s);
+hipError_t launch_integrate(const PoolView& v, int interval_ms, int variant, bool allow_wide, int only_model, hipStream_t s);
 // column T2D_P_SUBSTEPS of the device table for `interval_ms` (rows of the drift model keep their own column 23)
 hipError_t launch_derive(double* params, int n_types, int interval_ms, hipStream_t s);
 hipError_t launch_collide(const PoolView& v, const t2d_status_config& cfg, bool with_status,

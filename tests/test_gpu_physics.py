@@ -150,8 +150,8 @@ def test_pointmass_euler_mirror_and_pools_that_hold_both_backends(oracle):
     assert (gx[0::2] != gx[1::2]).any()                      # the two back-ends do differ where the speed is clipped
 
 
-@pytest.mark.parametrize("variant", ["fast", "exact"])
-def test_four_per_lane_integrator_of_large_pools_equals_the_one_per_lane_step(variant):
+@pytest.mark.parametrize("variant,only", [("fast", None), ("exact", None), ("fast", "pm"), ("exact", "pm"), ("fast", "kin"), ("exact", "kin")])
+def test_four_per_lane_integrator_of_large_pools_equals_the_one_per_lane_step(variant, only):
     """Pools of >= 2 M participants without a dynamics row take t2d_integrate with four consecutive participants per lane
     (16-byte loads and stores: integrate_wide_kernel).  Same arithmetic per participant: every state column equals, bit for
     bit, what the fused step's one-per-lane integrator leaves behind -- kinematic bicycles and point masses in one pool,
@@ -159,7 +159,8 @@ def test_four_per_lane_integrator_of_large_pools_equals_the_one_per_lane_step(va
     from tactics2d_amd import layout as L, scenarios as S
     from tactics2d_amd.pool import ParticipantPool
     rows, _ = S.full_type_table()
-    rows = rows[(rows[:, L.P_MODEL] == L.MODEL_KINEMATICS) | (rows[:, L.P_MODEL] == L.MODEL_POINTMASS)]
+    # (only = "pm" / "kin": every active participant has that one model -- the instantiation that carries it alone)
+    rows = rows[((rows[:, L.P_MODEL] == L.MODEL_KINEMATICS) & (only != "pm")) | ((rows[:, L.P_MODEL] == L.MODEL_POINTMASS) & (only != "kin"))]
     models = rows[:, L.P_MODEL].astype(int)
     usable = np.arange(len(rows))
     n_env, A = 32768, 64
