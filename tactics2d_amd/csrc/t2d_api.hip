@@ -1813,6 +1813,9 @@ int t2d_upload(t2d_pool* p, int32_t f, const void* host_src, size_t nbytes) {
     T2D_HIP(p, hipSetDevice(p->device));
     T2D_HIP(p, quiesce(p));
     T2D_HIP(p, hipMemcpy(p->field_ptr[f], host_src, nbytes, hipMemcpyHostToDevice));
+    // an ids column written by the caller: which types are in use is no longer known -- every row of the table counts (the
+    // integrator's single-model / four-per-lane instantiations are chosen from this set: t2d_integrate)
+    if (f == T2D_F_IDS) p->types_used = ~0u;
     // actions uploaded into the pool's own fields are the actions from now on: a binding to caller-owned device memory
     // (t2d_bind_actions) ends here, or the kernels would keep reading the caller's stale tensors
     if (f == T2D_F_ACT0 || f == T2D_F_ACT1) {
