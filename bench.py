@@ -212,7 +212,7 @@ class Runner:
 
     def steps_chain(self, n, frag, after_fragment=None):
         """n steps as t2d_step_n fragments of `frag` steps; step j of a fragment reads action set j of the ring"""
-        self.pool.bind_actions(self.a0.data_ptr(), self.a1.data_ptr())
+        self.pool.bind_actions(self.a0.data_ptr(), self.a1.data_ptr(), extent=self.a0.numel())
         done = 0
         while done < n:
             f = min(frag, n - done)

@@ -72,7 +72,7 @@
 extern "C" {
 #endif
 
-#define T2D_ABI_VERSION 11
+#define T2D_ABI_VERSION 12
 
 /* ---- status codes --------------------------------------------------------------- */
 #define T2D_OK            0
@@ -298,6 +298,13 @@ int t2d_bind_actions(t2d_pool* pool, const float* act0_dev, const float* act1_de
  * elements, >= 1).  A policy's [N, 2] output in the reference's (steering, accel) layout (envs/parking.py:130-139)
  * binds as act0 = out + 1, act1 = out, stride = 2 -- no copy kernels between the policy and the step.              */
 int t2d_bind_actions_strided(t2d_pool* pool, const float* act0_dev, const float* act1_dev, int32_t stride);
+/* Optional guard for bound memory: n_elements = how many float elements may be read from act0_dev and from act1_dev (0 = not
+ * declared, the default after every t2d_bind_actions[_strided]; the library cannot see the size of caller-owned memory).  With a
+ * declared extent, t2d_step_n refuses (T2D_ERR_INVALID) a fragment whose last step would read beyond it -- participant N - 1 of
+ * step n_steps - 1 reads element (N - 1) * stride + (n_steps - 1) * act_step_stride -- instead of faulting on the device.
+ * T2D_ERR_STATE while the pool reads its own ACT0 / ACT1 fields; T2D_ERR_INVALID if one action set does not fit.
+ * (The reference has no counterpart: its actions are Python tuples, envs/parking.py:239.)                                      */
+int t2d_set_action_extent(t2d_pool* pool, int64_t n_elements);
 
 /* Physics only: one PhysicsModelBase.step(interval_ms) for every active participant,
  * actions taken from fields ACT0/ACT1.                                                  */

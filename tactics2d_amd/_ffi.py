@@ -60,6 +60,7 @@ SYMBOLS = {
     "t2d_reset": (C.c_int, [_vp] * 10),
     "t2d_bind_actions": (C.c_int, [_vp, _vp, _vp]),
     "t2d_bind_actions_strided": (C.c_int, [_vp, _vp, _vp, C.c_int32]),
+    "t2d_set_action_extent": (C.c_int, [_vp, C.c_int64]),
     "t2d_integrate": (C.c_int, [_vp, C.c_int32, _vp]),
     "t2d_collide": (C.c_int, [_vp, _vp]),
     "t2d_check_status": (C.c_int, [_vp, C.c_int32, _vp]),

@@ -880,7 +880,19 @@ int t2d_bind_actions_strided(t2d_pool* p, const float* act0_dev, const float* ac
     p->v.act1 = act1_dev ? act1_dev : (const float*)p->field_ptr[T2D_F_ACT1];
     p->v.act_stride = act0_dev ? stride : 1;
     p->act_in_frame = false;
+    p->act_extent = 0;   // how far the new memory reaches is not known until the caller says (t2d_set_action_extent)
     refresh_idm_view(p);
+    return T2D_OK;
+}
+
+int t2d_set_action_extent(t2d_pool* p, int64_t n_elements) {
+    if (!p) return T2D_ERR_INVALID;
+    if (n_elements < 0) return fail(p, T2D_ERR_INVALID, "the action extent is a number of elements (0 = not declared)");
+    if (n_elements && p->v.act0 == (const float*)p->field_ptr[T2D_F_ACT0])
+        return fail(p, T2D_ERR_STATE, "t2d_set_action_extent describes memory bound with t2d_bind_actions[_strided]");
+    if (n_elements && (int64_t)(p->v.N - 1) * p->v.act_stride >= n_elements)
+        return fail(p, T2D_ERR_INVALID, "the declared extent does not hold one action per participant at the bound stride");
+    p->act_extent = n_elements;
     return T2D_OK;
 }
 
@@ -1165,6 +1177,10 @@ int t2d_step_n(t2d_pool* p, int32_t interval_ms, int32_t n_steps, int64_t act_st
     // (the pool's own action fields hold ONE action set: a ring needs bound memory of n_steps * act_step_stride elements)
     if (act_step_stride != 0 && p->v.act0 == (const float*)p->field_ptr[T2D_F_ACT0])
         return fail(p, T2D_ERR_INVALID, "act_step_stride > 0 needs an action ring bound with t2d_bind_actions (the pool's own ACT0 / ACT1 hold one set)");
+    // a declared extent (t2d_set_action_extent) is held against the furthest element step n_steps - 1 reads
+    if (p->act_extent && (int64_t)(p->v.N - 1) * p->v.act_stride + (int64_t)(n_steps - 1) * act_step_stride >= p->act_extent)
+        return fail(p, T2D_ERR_INVALID, "step " + std::to_string(n_steps - 1) + " of the fragment would read past the declared extent of the bound actions (" +
+                                         std::to_string((long long)p->act_extent) + " elements)");
     if (p->chain_failed || p->scene_commit_failed) return report_chain_failure(p);   // (once; the call after it goes ahead with plain launches)
     if (!p->have_params || !p->have_reset)
         return fail(p, T2D_ERR_STATE, "t2d_set_param_table and t2d_reset must precede t2d_step_n");
@@ -1822,6 +1838,7 @@ int t2d_upload(t2d_pool* p, int32_t f, const void* host_src, size_t nbytes) {
         p->v.act0 = (const float*)p->field_ptr[T2D_F_ACT0];
         p->v.act1 = (const float*)p->field_ptr[T2D_F_ACT1];
         p->v.act_stride = 1;
+        p->act_extent = 0;
         p->act_in_frame = false;
         refresh_idm_view(p);
     }
@@ -1844,6 +1861,7 @@ static void frame_release(t2d_pool* p) {
         p->v.act0 = (const float*)p->field_ptr[T2D_F_ACT0];
         p->v.act1 = (const float*)p->field_ptr[T2D_F_ACT1];
         p->v.act_stride = 1;
+        p->act_extent = 0;
         p->act_in_frame = false;
         refresh_idm_view(p);
     }
@@ -2024,6 +2042,7 @@ int t2d_step_host(t2d_pool* p, const float* actions_host, const float* action_bo
         p->v.act0 = dev_act + 1;
         p->v.act1 = dev_act;
         p->v.act_stride = 2;
+        p->act_extent = 0;
         p->act_in_frame = true;
         refresh_idm_view(p);
     }

@@ -370,6 +370,7 @@ struct t2d_pool {
     float* h_actions = nullptr;       // pinned (and mapped) staging of the host actions, [N][2]
     float* d_actions = nullptr;       // device copy of them (copy mode)
     bool act_in_frame = false;        // v.act0 / v.act1 point into d_actions / the mapped h_actions (set by t2d_step_host)
+    int64_t act_extent = 0;       // elements readable behind each bound action pointer (t2d_set_action_extent; 0 = not declared)
     double* d_target_heading = nullptr;
     // profiling
     bool profiling = false;

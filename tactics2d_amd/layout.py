@@ -1,6 +1,6 @@
 """Numeric constants of the C ABI (include/t2d.h), mirrored for the Python host side.
 tests/test_layout.py parses the header and checks that the two agree."""
-ABI_VERSION = 11   # T2D_ABI_VERSION: _ffi.lib() refuses a libt2d_hip.so built from another header
+ABI_VERSION = 12   # T2D_ABI_VERSION: _ffi.lib() refuses a libt2d_hip.so built from another header
 # parameter-row columns
 P_MODEL, P_LF, P_LR, P_WB = 0, 1, 2, 3
 P_STEER_LO, P_STEER_HI, P_SPEED_LO, P_SPEED_HI, P_ACCEL_LO, P_ACCEL_HI = 4, 5, 6, 7, 8, 9

@@ -376,13 +376,17 @@ class ParticipantPool:
         self.upload(L.F_ACT0, act0)
         self.upload(L.F_ACT1, act1)
 
-    def bind_actions(self, act0_ptr=None, act1_ptr=None, stride=1):
+    def bind_actions(self, act0_ptr=None, act1_ptr=None, stride=1, extent=None):
         """Zero-copy actions from caller-owned device memory (raw pointers, e.g. tensor.data_ptr()); participant i reads
-        element i * stride of each (a policy's [N, 2] (steering, accel) tensor: act0 = ptr + 4, act1 = ptr, stride = 2)."""
+        element i * stride of each (a policy's [N, 2] (steering, accel) tensor: act0 = ptr + 4, act1 = ptr, stride = 2).
+        extent = elements readable behind each pointer (an action ring of K sets: K * N * stride): `step_n` then refuses a
+        fragment that would read past it instead of faulting on the device (t2d_set_action_extent)."""
         if stride == 1:
             self._ck(self._lib.t2d_bind_actions(self._h, act0_ptr, act1_ptr))
         else:
             self._ck(self._lib.t2d_bind_actions_strided(self._h, act0_ptr, act1_ptr, int(stride)))
+        if extent is not None and act0_ptr is not None:
+            self._ck(self._lib.t2d_set_action_extent(self._h, int(extent)))
 
     def field_ptr(self, field):
         ptr, nb = C.c_void_p(), C.c_size_t()

@@ -21,7 +21,7 @@ class FakePool:
     def step_count(self):
         return self.steps
 
-    def bind_actions(self, a0, a1, stride=1):
+    def bind_actions(self, a0, a1, stride=1, extent=None):
         pass
 
     def step_n(self, n, interval_ms, act_step_stride=0, stream=None):
@@ -43,7 +43,7 @@ class FakePool:
 
 def _runner(pool, n_participants=640):
     import bench
-    a = types.SimpleNamespace(data_ptr=lambda: 4096)
+    a = types.SimpleNamespace(data_ptr=lambda: 4096, numel=lambda: 32 * n_participants)
     r = types.SimpleNamespace(pool=pool, a0=a, a1=a, k=0, align=True, stream=types.SimpleNamespace(cuda_stream=None),
                               scene=types.SimpleNamespace(interval_ms=100, n=n_participants))
     r.steps_chain = types.MethodType(bench.Runner.steps_chain, r)

@@ -343,3 +343,35 @@ def test_idm_pool_of_more_workgroups_than_cus_chains_with_its_controllers():
         pool.close()
     for f, g, w in zip(fields, outs[1], outs[0]):
         assert np.array_equal(g, w, equal_nan=True), (f, int((g != w).sum()))
+
+
+def test_a_declared_action_extent_stops_a_fragment_that_would_read_past_the_ring():
+    """t2d_set_action_extent: the library cannot see how large caller-owned action memory is; told, t2d_step_n refuses the fragment
+    whose last step would read beyond it (T2D_ERR_INVALID, nothing launched) instead of faulting on the device; a rebind forgets
+    the extent; the pool's own action fields take none"""
+    torch = pytest.importorskip("torch")
+    from tactics2d_amd import layout as L, scenarios as S
+    from tactics2d_amd._ffi import T2DError
+    dev = torch.device("cuda", 0)
+    sc = S.highway(8, 64, seed=3)
+    n, K = sc.n, 4
+    rng = np.random.default_rng(1)
+    sets = [sc.sample_actions(rng) for _ in range(K)]
+    a0 = torch.from_numpy(np.stack([s[0] for s in sets])).to(dev).contiguous()
+    a1 = torch.from_numpy(np.stack([s[1] for s in sets])).to(dev).contiguous()
+    pool = _pool(sc, "exact")
+    with pytest.raises(T2DError):                       # nothing bound: the pool reads its own fields
+        pool._ck(pool._lib.t2d_set_action_extent(pool._h, K * n))
+    pool.bind_actions(a0.data_ptr(), a1.data_ptr(), extent=K * n)
+    pool.step_n(K, sc.interval_ms, n)                   # the whole ring: fine
+    count = pool.step_count()
+    before = pool.download(L.F_X).copy()
+    with pytest.raises(T2DError, match="extent"):
+        pool.step_n(K + 1, sc.interval_ms, n)           # one set too many
+    assert pool.step_count() == count and np.array_equal(pool.download(L.F_X), before)   # refused before anything ran
+    pool.step_n(K + 1, sc.interval_ms, 0)               # one set repeated reads the first set only
+    with pytest.raises(T2DError):                       # an extent that does not hold one set
+        pool._ck(pool._lib.t2d_set_action_extent(pool._h, n - 1))
+    pool.bind_actions(a0.data_ptr(), a1.data_ptr())    # a rebind: the extent is unknown again, the caller is on their own
+    pool.step_n(K, sc.interval_ms, n)
+    pool.close()
