@@ -199,12 +199,14 @@ class Runner:
         self.stream = torch.cuda.Stream(device=dev)
         self.k = 0
         self.align = False
+        self.ring_bound = False    # the whole action ring is what the pool reads (steps_chain binds it once, steps_single rebinds per step)
 
     def steps_single(self, n, after_step=None):
         N = self.scene.n
         for _ in range(n):
             s = self.k % ACTION_SETS
             self.pool.bind_actions(self.a0.data_ptr() + 4 * N * s, self.a1.data_ptr() + 4 * N * s)
+            self.ring_bound = False
             self.pool.step(self.scene.interval_ms, self.stream.cuda_stream)
             self.k += 1
             if after_step:
@@ -212,7 +214,9 @@ class Runner:
 
     def steps_chain(self, n, frag, after_fragment=None):
         """n steps as t2d_step_n fragments of `frag` steps; step j of a fragment reads action set j of the ring"""
-        self.pool.bind_actions(self.a0.data_ptr(), self.a1.data_ptr(), extent=self.a0.numel())
+        if not self.ring_bound:   # (bound once, like a caller with a resident action ring would: not a call per fragment)
+            self.pool.bind_actions(self.a0.data_ptr(), self.a1.data_ptr(), extent=self.a0.numel())
+            self.ring_bound = True
         done = 0
         while done < n:
             f = min(frag, n - done)

@@ -44,7 +44,7 @@ class FakePool:
 def _runner(pool, n_participants=640):
     import bench
     a = types.SimpleNamespace(data_ptr=lambda: 4096, numel=lambda: 32 * n_participants)
-    r = types.SimpleNamespace(pool=pool, a0=a, a1=a, k=0, align=True, stream=types.SimpleNamespace(cuda_stream=None),
+    r = types.SimpleNamespace(pool=pool, a0=a, a1=a, k=0, align=True, ring_bound=False, stream=types.SimpleNamespace(cuda_stream=None),
                               scene=types.SimpleNamespace(interval_ms=100, n=n_participants))
     r.steps_chain = types.MethodType(bench.Runner.steps_chain, r)
     r.steps_single = types.MethodType(bench.Runner.steps_single, r)
