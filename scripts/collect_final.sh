@@ -4,7 +4,7 @@
 TAG=$1
 cd "$(dirname "$0")/.."
 for f in summary.json kernel_stats.csv configs.json next_rows.json traffic_latest.json host_path.json bench_driver_like.json \
-         bench_1000.json chain_timing_frag20.json sq_wait_chain.json power_clock.json; do
+         bench_1000.json chain_timing_frag20.json sq_wait_chain.json power_clock.json mapgrid_timing.txt; do
     [ -f gpurun_out/${TAG}_$f ] && cp gpurun_out/${TAG}_$f profiles/${TAG}_$f
 done
 cp gpurun_out/${TAG}_traffic_latest.json profiles/traffic_latest.json

@@ -549,8 +549,7 @@ int t2d_destroy(t2d_pool* p) {
                     p->d_snap[0], p->d_snap[1], p->d_snap[2],
                     p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_wgmap, p->d_idm_rows, p->d_idm_ctrl, p->d_snap_omega[0], p->d_snap_omega[1], p->d_time_penalty,
                     p->d_scene_arrays, p->d_lidar_cnt, p->d_chain, p->d_ckpt, p->d_scene_view,
-                    p->d_grid_env, p->d_grid_cell_start, p->d_grid_items, p->d_map_flags, p->d_grid_vert_off[0], p->d_grid_vert_off[1],
-                    p->d_grid_xy[0], p->d_grid_xy[1], p->d_grid_bnd_off, p->d_grid_bnd};
+                    p->d_grid_env, p->d_grid_cell_start, p->d_grid_items, p->d_map_flags, p->d_grid_bnd};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     frame_release(p);

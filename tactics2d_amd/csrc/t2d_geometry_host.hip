@@ -335,8 +335,8 @@ int build_map_grid(t2d_pool* p) {
     const int E = p->v.n_env;
     std::vector<t2d::MapGridEnv> env((size_t)E);
     std::vector<int32_t> cell_start(1, 0);
-    std::vector<uint32_t> items;
-    std::vector<std::vector<uint32_t>> cells;
+    std::vector<t2d::MapItem> items;
+    std::vector<std::vector<t2d::MapItem>> cells;
     const float m = t2d::kGridMargin;
     for (int e = 0; e < E; ++e) {
         float x0 = 0, x1 = 0, y0 = 0, y1 = 0;
@@ -374,8 +374,19 @@ int build_map_grid(t2d_pool* p) {
                 const float* b = &g.aabb[4 * (size_t)q];
                 const int ix0 = cell_of(b[0] - m, h.x0, h.nx), ix1 = cell_of(b[1] + m, h.x0, h.nx);
                 const int iy0 = cell_of(b[2] - m, h.y0, h.ny), iy1 = cell_of(b[3] + m, h.y0, h.ny);
+                t2d::MapItem it{};
+                const int v0 = g.vert_off[q], n = g.vert_off[q + 1] - v0;
+                for (int j = 0; j < 4; ++j) {   // (load_quad_f32's padding: a triangle repeats its first vertex)
+                    const int jj = j < n ? j : 0;
+                    it.xy[2 * j] = g.xy[2 * (size_t)(v0 + jj)];
+                    it.xy[2 * j + 1] = g.xy[2 * (size_t)(v0 + jj) + 1];
+                }
+                it.bnd0 = k == 1 && !g.bnd_off.empty() ? g.bnd_off[q] : 0;
+                it.bnd1 = k == 1 && !g.bnd_off.empty() ? g.bnd_off[q + 1] : 0;
+                it.cell_lo = (uint32_t)ix0 | ((uint32_t)iy0 << 16);
+                it.kind = (uint32_t)k;
                 for (int iy = iy0; iy <= iy1; ++iy)
-                    for (int ix = ix0; ix <= ix1; ++ix) cells[(size_t)iy * h.nx + ix].push_back((uint32_t)q | ((uint32_t)k << 31));
+                    for (int ix = ix0; ix <= ix1; ++ix) cells[(size_t)iy * h.nx + ix].push_back(it);
             }
         }
         for (const auto& c : cells) {
@@ -386,26 +397,17 @@ int build_map_grid(t2d_pool* p) {
     int rc;
     if ((rc = dev_replace(p, &p->d_grid_env, env.data(), env.size()))) return rc;
     if ((rc = dev_replace(p, &p->d_grid_cell_start, cell_start.data(), cell_start.size()))) return rc;
-    if (items.empty()) items.push_back(0u);
+    // (a queue entry of the kernel names an item or a boundary piece in 27 bits)
+    if (items.size() >= (size_t(1) << 27) || p->hgeo[1].bnd.size() / 4 >= (size_t(1) << 27))
+        return fail(p, T2D_ERR_GEOMETRY, "the map's grid holds more than 2^27 part registrations or boundary pieces");
+    if (items.empty()) items.push_back(t2d::MapItem{});
     if ((rc = dev_replace(p, &p->d_grid_items, items.data(), items.size()))) return rc;
     t2d::MapGridView mg{};
-    mg.env = p->d_grid_env; mg.cell_start = p->d_grid_cell_start; mg.cell_items = p->d_grid_items;
-    for (int k = 0; k < 2; ++k) {
-        const auto& g = p->hgeo[k];
-        std::vector<int32_t> vo = g.present ? g.vert_off : std::vector<int32_t>(1, 0);
-        std::vector<float> xy = g.present && !g.xy.empty() ? g.xy : std::vector<float>(2, 0.f);
-        if ((rc = dev_replace(p, &p->d_grid_vert_off[k], vo.data(), vo.size()))) return rc;
-        if ((rc = dev_replace(p, &p->d_grid_xy[k], xy.data(), xy.size()))) return rc;
-        mg.vert_off[k] = p->d_grid_vert_off[k];
-        mg.xy[k] = p->d_grid_xy[k];
-    }
+    mg.env = p->d_grid_env; mg.cell_start = p->d_grid_cell_start; mg.items = p->d_grid_items;
     {
         const auto& g = p->hgeo[1];
-        std::vector<int32_t> bo = g.present && !g.bnd_off.empty() ? g.bnd_off : std::vector<int32_t>(1, 0);
         std::vector<double> bd = g.present && !g.bnd.empty() ? g.bnd : std::vector<double>(4, 0.0);
-        if ((rc = dev_replace(p, &p->d_grid_bnd_off, bo.data(), bo.size()))) return rc;
         if ((rc = dev_replace(p, &p->d_grid_bnd, bd.data(), bd.size()))) return rc;
-        mg.bnd_off = p->d_grid_bnd_off;
         mg.bnd = p->d_grid_bnd;
     }
     if (!p->d_map_flags) {

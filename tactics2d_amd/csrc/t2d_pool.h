@@ -55,14 +55,21 @@ struct MapGridEnv {
     int32_t nx, ny, cell_off; // the env's cells are cell_start[cell_off + iy * nx + ix]
     int32_t has_lanes, pad;
 };
+// One registration of a part in a cell: the part's vertices INLINE (padded to four the way load_quad_f32 pads: a triangle repeats its
+// first vertex), its boundary pieces' range and the first cell of the part's own cell range -- so a pose that meets the part through
+// several cells evaluates it once (in the first cell both ranges share) and the walk is cell -> record, one dependent load.
+struct MapItem {
+    float xy[8];
+    int32_t bnd0, bnd1;       // lane parts: pieces [bnd0, bnd1) of MapGridView::bnd (static parts: 0, 0)
+    uint32_t cell_lo;         // ix0 | iy0 << 16 of the cells the part is registered in
+    uint32_t kind;            // 0 static, 1 lane
+};
+static_assert(sizeof(MapItem) == 48, "three 16-byte loads per record");
 struct MapGridView {
     const MapGridEnv* env;        // [E]
     const int32_t* cell_start;    // CSR over all cells of all envs (+ 1)
-    const uint32_t* cell_items;   // part index (global, as in vert_off) | kind << 31 (0 static, 1 lane)
-    const int32_t* vert_off[2];   // the parts of t2d_set_static_geometry / t2d_set_lane_geometry (fans of 3- / 4-gons)
-    const float* xy[2];
-    const int32_t* bnd_off;       // lane parts: boundary pieces of the env's lane union, 4 doubles each
-    const double* bnd;
+    const MapItem* items;         // per cell: the parts whose (widened) box overlaps it
+    const double* bnd;            // boundary pieces of the envs' lane unions, 4 doubles each
 };
 
 // What kernels receive by value.
@@ -259,9 +266,9 @@ struct t2d_pool {
     bool grid_tier = false;
     t2d::MapGridView mapgrid{};
     t2d::MapGridEnv* d_grid_env = nullptr;
-    int32_t *d_grid_cell_start = nullptr, *d_grid_vert_off[2] = {nullptr, nullptr}, *d_grid_bnd_off = nullptr;
-    uint32_t *d_grid_items = nullptr, *d_map_flags = nullptr;
-    float* d_grid_xy[2] = {nullptr, nullptr};
+    int32_t* d_grid_cell_start = nullptr;
+    t2d::MapItem* d_grid_items = nullptr;
+    uint32_t* d_map_flags = nullptr;
     double* d_grid_bnd = nullptr;
     float* d_boundary = nullptr;
     uint8_t* d_boundary_valid = nullptr;

@@ -169,3 +169,60 @@ def test_grid_tier_and_lds_record_give_the_same_flags_statuses_and_rewards():
     flags = np.concatenate([r[3] for r in outs[0]])
     env_flags = np.concatenate([r[4] for r in outs[0]])
     assert (flags & L.FLAG_OFF_LANE).any() and (env_flags & (L.FLAG_OFF_LANE | L.FLAG_COLLISION_STATIC | L.FLAG_COLLISION_DYNAMIC)).any()
+
+
+@pytest.mark.parametrize("case", ["crowded_statics", "long_vehicles_small_cells"])
+def test_grid_tier_edge_cases_agree_with_the_oracle(oracle, case):
+    """crowded_statics: hundreds of overlapping boxes around the poses of one workgroup -- more (participant, part) pairs than
+    the kernel's queue holds, the rest is decided by the lanes that found them; long_vehicles_small_cells: a dense map (cells at
+    the 4-m floor) under 18-m vehicles -- a pose's box spans dozens of cells and meets every part through several of them
+    (taken once, in the first cell both ranges share).  Flags == oracle, bit for bit, either way."""
+    from tactics2d_amd import layout as L, mapgeom as MG
+    from tactics2d_amd.pool import ParticipantPool
+    n_env, A = 3, 64
+    rails = _road(n_pts=220)
+    sc = _scene(n_env, A, 23, rails, n_static=0)
+    rng = np.random.default_rng(11)
+    if case == "crowded_statics":
+        # 400 boxes per env, 300 of them piled on the first 16 participants of the env (one workgroup's poses)
+        for e in range(n_env):
+            polys = []
+            for j in range(400):
+                i = e * A + (rng.integers(0, 16) if j < 300 else rng.integers(0, A))
+                cx, cy = sc["x"][i] + rng.uniform(-4, 4), sc["y"][i] + rng.uniform(-4, 4)
+                a = rng.uniform(0, np.pi); hl, hw = rng.uniform(0.3, 2.5), rng.uniform(0.3, 1.2)
+                c, s = np.cos(a), np.sin(a)
+                polys.append(np.float32([(cx + c * lx - s * ly, cy + s * lx + c * ly) for lx, ly in ((hl, -hw), (hl, hw), (-hl, hw), (-hl, -hw))]))
+            sc["statics"][e] = polys
+    else:
+        rows = sc["rows"].copy()
+        box = rows[:, L.P_SHAPE] == L.SHAPE_OBB
+        rows[box, L.P_LENGTH] = 18.0                         # every vehicle a road train
+        rows[box, L.P_WIDTH] = 2.6
+        sc["rows"] = rows
+        # a denser map: every lane quad of the road cut in two along its length (1752 pieces): the cell size falls to its floor
+        lanes = []
+        for q in sc["lanes"]:
+            q = np.float32(q)
+            if len(q) == 4:
+                m01, m23 = (q[0] + q[1]) / 2, (q[2] + q[3]) / 2
+                lanes += [np.float32([q[0], m01, m23, q[3]]), np.float32([m01, q[1], q[2], m23])]
+            else:
+                lanes.append(q)
+        sc["lanes"] = lanes
+    assert MG.geometry_budget(n_env, A, static=sc["statics"], lanes=[sc["lanes"]] * n_env)["tier"] == "hbm_grid"
+    pool = ParticipantPool(n_env, A)
+    static, lanes = _load(pool, sc, n_env, [sc["lanes"]] * n_env)
+    assert pool.step_form(1) == "unfused"
+    seen = 0
+    for step in range(3):
+        pool.set_actions(np.float32(rng.uniform(-2.0, 2.0, n_env * A)), np.float32(rng.uniform(-0.3, 0.3, n_env * A)))
+        pool.step(100)
+        x, y, h = (pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING))
+        got, got_env = pool.download(L.F_FLAGS), pool.download(L.F_ENV_FLAGS)
+        want, want_env = oracle.collide(sc["rows"], n_env, A, x, y, h, sc["tid"], sc["active"], static, None, None, lanes, 0)
+        assert np.array_equal(got, want), (case, step, int((got != want).sum()), np.nonzero(got != want)[0][:8])
+        assert np.array_equal(got_env, want_env), (case, step)
+        seen += int((got & (L.FLAG_COLLISION_STATIC if case == "crowded_statics" else L.FLAG_OFF_LANE)).astype(bool).sum())
+    assert seen > 60, seen
+    pool.close()
