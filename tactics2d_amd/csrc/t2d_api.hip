@@ -549,7 +549,7 @@ int t2d_destroy(t2d_pool* p) {
                     p->d_snap[0], p->d_snap[1], p->d_snap[2],
                     p->d_snap[3], p->d_snap[4], p->d_snap[5], p->d_snap_ids, p->d_wgmap, p->d_idm_rows, p->d_idm_ctrl, p->d_snap_omega[0], p->d_snap_omega[1], p->d_time_penalty,
                     p->d_scene_arrays, p->d_lidar_cnt, p->d_chain, p->d_ckpt, p->d_scene_view,
-                    p->d_grid_env, p->d_grid_cell_start, p->d_grid_items, p->d_map_flags, p->d_grid_bnd};
+                    p->d_grid_env, p->d_grid_cell_start, p->d_grid_items, p->d_map_flags, p->d_grid_bnd, p->d_grid_seg};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     frame_release(p);
@@ -1057,7 +1057,7 @@ static int collide_impl(t2d_pool* p, bool with_status, int interval_ms, hipStrea
     p->scene_committed_in_step = false;
     if (p->grid_tier) {   // the map's verdicts for the poses as they are now, ahead of the event kernel that ORs them in
         if (fuse_variant >= 0) return fail(p, T2D_ERR_STATE, "internal: a grid-tier pool took the fused step");
-        T2D_HIP(p, t2d::launch_map_events(p->v, p->mapgrid, p->d_map_flags, s));
+        T2D_HIP(p, t2d::launch_map_events(p->v, p->mapgrid, p->d_grid_seg, p->d_map_flags, s));
     }
     if (fuse_variant >= 0 && p->ego_kernel && p->v.A == 1 && p->all_boxes && !p->has_drift && !p->hgeo[1].present) {
         t2d::PoolView v = p->v;

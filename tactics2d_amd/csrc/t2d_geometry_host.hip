@@ -397,9 +397,9 @@ int build_map_grid(t2d_pool* p) {
     int rc;
     if ((rc = dev_replace(p, &p->d_grid_env, env.data(), env.size()))) return rc;
     if ((rc = dev_replace(p, &p->d_grid_cell_start, cell_start.data(), cell_start.size()))) return rc;
-    // (a queue entry of the kernel names an item or a boundary piece in 27 bits)
-    if (items.size() >= (size_t(1) << 27) || p->hgeo[1].bnd.size() / 4 >= (size_t(1) << 27))
-        return fail(p, T2D_ERR_GEOMETRY, "the map's grid holds more than 2^27 part registrations or boundary pieces");
+    // (a queue entry of the kernels names a registration or a boundary piece in 25 bits)
+    if (items.size() >= (size_t(1) << 25) || p->hgeo[1].bnd.size() / 4 >= (size_t(1) << 25))
+        return fail(p, T2D_ERR_GEOMETRY, "the map's grid holds more than 2^25 part registrations or boundary pieces");
     if (items.empty()) items.push_back(t2d::MapItem{});
     if ((rc = dev_replace(p, &p->d_grid_items, items.data(), items.size()))) return rc;
     t2d::MapGridView mg{};
@@ -413,6 +413,11 @@ int build_map_grid(t2d_pool* p) {
     if (!p->d_map_flags) {
         T2D_HIP(p, hipMalloc((void**)&p->d_map_flags, sizeof(uint32_t) * (size_t)p->v.N));
         T2D_HIP(p, hipMemset(p->d_map_flags, 0, sizeof(uint32_t) * (size_t)p->v.N));
+    }
+    if (!p->d_grid_seg) {
+        const size_t bytes = t2d::map_segment_bytes(p->v.N);
+        T2D_HIP(p, hipMalloc(&p->d_grid_seg, bytes));
+        T2D_HIP(p, hipMemset(p->d_grid_seg, 0, bytes));
     }
     p->mapgrid = mg;
     p->grid_tier = true;

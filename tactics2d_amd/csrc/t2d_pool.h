@@ -269,6 +269,7 @@ struct t2d_pool {
     int32_t* d_grid_cell_start = nullptr;
     t2d::MapItem* d_grid_items = nullptr;
     uint32_t* d_map_flags = nullptr;
+    void* d_grid_seg = nullptr;   // t2d_mapgrid.hip: one segment per sixteen participants (poses, verdict bits, the queue of pairs to decide)
     double* d_grid_bnd = nullptr;
     float* d_boundary = nullptr;
     uint8_t* d_boundary_valid = nullptr;
@@ -408,7 +409,8 @@ hipError_t launch_idm(const PoolView& v, const IdmView& iv, const int32_t* force
 hipError_t launch_restore(const PoolView& v, float* const* snap, const uint32_t* snap_ids, int mode,
                           hipStream_t s);
 hipError_t launch_spin(long long ticks_100mhz, hipStream_t s);
-hipError_t launch_map_events(const PoolView& v, const MapGridView& mg, uint32_t* out, hipStream_t s);
+size_t map_segment_bytes(int n_participants);   // the walk -> decisions hand-over buffer of launch_map_events
+hipError_t launch_map_events(const PoolView& v, const MapGridView& mg, void* segments, uint32_t* out, hipStream_t s);
 #ifdef T2D_DEBUG_HOOKS
 const char* last_collide_form();   // template arguments of the collide_kernel instantiation the last launch took (t2d_collide.hip)
 #endif

@@ -173,8 +173,8 @@ def test_grid_tier_and_lds_record_give_the_same_flags_statuses_and_rewards():
 
 @pytest.mark.parametrize("case", ["crowded_statics", "long_vehicles_small_cells"])
 def test_grid_tier_edge_cases_agree_with_the_oracle(oracle, case):
-    """crowded_statics: hundreds of overlapping boxes around the poses of one workgroup -- more (participant, part) pairs than
-    the kernel's queue holds, the rest is decided by the lanes that found them; long_vehicles_small_cells: a dense map (cells at
+    """crowded_statics: thousands of overlapping boxes around eight poses of each env -- more (participant, part) pairs than a
+    workgroup's queue holds: the decisions' launch then decides that workgroup's poses from scratch; long_vehicles_small_cells: a dense map (cells at
     the 4-m floor) under 18-m vehicles -- a pose's box spans dozens of cells and meets every part through several of them
     (taken once, in the first cell both ranges share).  Flags == oracle, bit for bit, either way."""
     from tactics2d_amd import layout as L, mapgeom as MG
@@ -184,12 +184,12 @@ def test_grid_tier_edge_cases_agree_with_the_oracle(oracle, case):
     sc = _scene(n_env, A, 23, rails, n_static=0)
     rng = np.random.default_rng(11)
     if case == "crowded_statics":
-        # 400 boxes per env, 300 of them piled on the first 16 participants of the env (one workgroup's poses)
+        # 2600 boxes per env, 2400 of them piled on eight participants of the env: more pairs than any workgroup's queue holds
         for e in range(n_env):
             polys = []
-            for j in range(400):
-                i = e * A + (rng.integers(0, 16) if j < 300 else rng.integers(0, A))
-                cx, cy = sc["x"][i] + rng.uniform(-4, 4), sc["y"][i] + rng.uniform(-4, 4)
+            for j in range(2600):
+                i = e * A + (rng.integers(0, 8) if j < 2400 else rng.integers(0, A))
+                cx, cy = sc["x"][i] + rng.uniform(-1.5, 1.5), sc["y"][i] + rng.uniform(-1.5, 1.5)
                 a = rng.uniform(0, np.pi); hl, hw = rng.uniform(0.3, 2.5), rng.uniform(0.3, 1.2)
                 c, s = np.cos(a), np.sin(a)
                 polys.append(np.float32([(cx + c * lx - s * ly, cy + s * lx + c * ly) for lx, ly in ((hl, -hw), (hl, hw), (-hl, hw), (-hl, -hw))]))
