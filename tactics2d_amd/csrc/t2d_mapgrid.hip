@@ -131,8 +131,9 @@ T2D_DEV uint32_t flags_of(uint32_t v) {
 // registers it never used.  Variants of the one-kernel form measured on the way: the pose derived by ONE lane per participant and
 // read from LDS behind a barrier -- 29 % fewer VALU instructions, 52 us (a chain of latencies per workgroup, not of instructions);
 // 5 / 6 / 8 waves per SIMD by spilling 50-70 registers: 65 / 60 / 100 us; the in-place decisions of a full queue out of line: 49 us.
-// Of this kernel: 6 / 8 waves per SIMD (21 / 32 registers spilled) 54 / 65 us against 37 at 5; 16 / 8 / 4 lanes per participant
-// 37 / 31 / 30 us (walk + decisions + the event launch behind them).
+// Of this kernel, at sixteen lanes per participant: 6 / 8 waves per SIMD (21 / 32 registers spilled) 54 / 65 us against 37 at 5;
+// 16 / 8 / 4 lanes per participant 37 / 31 / 30 us (walk + decisions + the event launch behind them).  At four lanes the launch
+// is four waves per SIMD, and the allocation is held to that (104 registers, none spilled).
 #ifndef T2D_MAP_WALK_WAVES
 #define T2D_MAP_WALK_WAVES 4
 #endif
