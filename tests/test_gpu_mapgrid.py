@@ -136,11 +136,15 @@ def test_a_one_kilometre_four_lane_road_loads_steps_and_agrees_with_the_oracle_a
     pool.close()
 
 
-def test_grid_tier_and_lds_record_give_the_same_flags_statuses_and_rewards():
+@pytest.mark.parametrize("idm", [False, True])
+def test_grid_tier_and_lds_record_give_the_same_flags_statuses_and_rewards(idm):
     """the SAME short road through both tiers: a pool that fits the LDS record, and one whose lanes are padded with far-away
-    pieces until the record overflows (the extra pieces lie 300 m from every participant: they change no verdict)"""
+    pieces until the record overflows (the extra pieces lie 300 m from every participant: they change no verdict).  idm: every
+    vehicle but the first of each env driven by an on-device IDM controller (a launch of its own ahead of the step on both tiers'
+    unfused / fused paths) -- the controllers' actions, and everything behind them, agree too"""
     from tactics2d_amd import layout as L, mapgeom as MG
     from tactics2d_amd.pool import ParticipantPool
+    from tactics2d_amd.controller import IDMController, install
     n_env, A = 4, 64
     rails = _road(n_pts=12, arc=0.2)                                           # 100 m of road: 4 x 11 pieces
     sc = _scene(n_env, A, 5, rails, n_static=6)
@@ -151,15 +155,21 @@ def test_grid_tier_and_lds_record_give_the_same_flags_statuses_and_rewards():
     for extra in ([], far):
         pool = ParticipantPool(n_env, A)
         _load(pool, sc, n_env, [sc["lanes"] + extra] * n_env)
+        if idm:
+            veh = (sc["rows"][sc["tid"], L.P_MODEL] != L.MODEL_POINTMASS).reshape(n_env, A)
+            cid = np.full((n_env, A), L.IDM_NONE, np.uint8)
+            cid[:, 1:] = np.where(veh[:, 1:], 0, L.IDM_NONE)
+            install(pool, [IDMController(desired_speed=12.0, horizon=60.0)], cid.reshape(-1))
         pool.snapshot()
         pool.set_auto_reset(True)
-        assert (pool.step_form(1) == "unfused") == bool(extra)
+        if extra:
+            assert pool.step_form(1) == "unfused"
         rng = np.random.default_rng(9)
         rec = []
         for _ in range(12):
             pool.set_actions(np.float32(rng.uniform(-2, 2, n_env * A)), np.float32(rng.uniform(-0.3, 0.3, n_env * A)))
             pool.step(100)
-            rec.append([pool.download(f).copy() for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_FLAGS, L.F_ENV_FLAGS, L.F_STATUS, L.F_REWARD, L.F_CNT_STEP)])
+            rec.append([pool.download(f).copy() for f in (L.F_X, L.F_Y, L.F_HEADING, L.F_FLAGS, L.F_ENV_FLAGS, L.F_STATUS, L.F_REWARD, L.F_CNT_STEP, L.F_APPLIED0)])
         outs.append(rec)
         pool.close()
     assert not MG.geometry_budget(n_env, A, lanes=[sc["lanes"] + far] * n_env)["fits"]
