@@ -1638,7 +1638,7 @@ __global__ __launch_bounds__((1 + PIPE) * kBlock, PIPE == 2 ? 3 : (LOOP && !CHAI
     if (active) {
         const uint32_t sf = s_flags[tid];
         f = f_own | (sf & ((1u << kLaneShift) - 1u));
-        if constexpr (FUSE < 0) {   // maps in the HBM grid tier: map_events_kernel's verdicts for this participant (t2d_mapgrid.hip)
+        if constexpr (FUSE < 0) {   // maps in the HBM grid tier: the map events' verdicts for this participant (t2d_mapgrid.hip)
             if (pv.map_flags) f |= pv.map_flags[idx];
         }
         if (n_lane_polys > 0) {  // build-defined off-lane: not union(lanes).contains(pose)

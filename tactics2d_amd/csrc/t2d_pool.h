@@ -165,7 +165,7 @@ struct PoolView {
     double kin_coef[kKinDegree + 1][8];
     double kin_geo[8];
     // pools whose static + lane geometry lives in the HBM grid tier (t2d_mapgrid.hip): the per-participant verdicts
-    // (T2D_FLAG_COLLISION_STATIC | T2D_FLAG_OFF_LANE) of map_events_kernel, OR-ed into the flags by the event kernel; else null
+    // (T2D_FLAG_COLLISION_STATIC | T2D_FLAG_OFF_LANE) of t2d_mapgrid.hip's two launches, OR-ed into the flags by the event kernel; else null
     const uint32_t* map_flags;
     unsigned long long* dbg;  // phase cycle accumulators (profiling builds with -DT2D_TIMING only)
     double cell;      // spatial-hash cell edge (m) >= max circum-diameter * 1.001
