@@ -9,7 +9,7 @@ for f in summary.json kernel_stats.csv configs.json next_rows.json traffic_lates
 done
 cp gpurun_out/${TAG}_traffic_latest.json profiles/traffic_latest.json
 tail -n 3 gpurun_out/${TAG}_logs/pytest_gpu.log > profiles/${TAG}_pytest_gpu_tail.txt
-(tail -n 2 gpurun_out/${TAG}_logs/soak.log; tail -n 1 gpurun_out/${TAG}_logs/soak_lidar.log) > profiles/${TAG}_soak_tail.txt
+(tail -n 2 gpurun_out/${TAG}_logs/soak.log; tail -n 1 gpurun_out/${TAG}_logs/soak_lidar.log; tail -n 1 gpurun_out/${TAG}_logs/soak_mapgrid.log 2>/dev/null) > profiles/${TAG}_soak_tail.txt
 python - "$TAG" <<'PY'
 import json, sys
 tag = sys.argv[1]

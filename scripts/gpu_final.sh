@@ -18,5 +18,6 @@ MODE=chain PASSES=3 bash scripts/sq_wait_chain.sh $TAG > gpurun_out/${TAG}_logs/
 T2D_PC_SECONDS=2.5 timeout 300 python scripts/power_clock.py gpurun_out/${TAG}_power_clock.json > gpurun_out/${TAG}_logs/power_clock.log 2>&1; echo "power clock rc $?"
 timeout 600 python tests/soak/soak.py 60 > gpurun_out/${TAG}_logs/soak.log 2>&1; echo "soak rc $?"; tail -2 gpurun_out/${TAG}_logs/soak.log
 timeout 600 python tests/soak/soak_lidar.py 150 > gpurun_out/${TAG}_logs/soak_lidar.log 2>&1; echo "soak lidar rc $?"; tail -2 gpurun_out/${TAG}_logs/soak_lidar.log
+timeout 600 python tests/soak/soak_mapgrid.py 24 > gpurun_out/${TAG}_logs/soak_mapgrid.log 2>&1; echo "soak mapgrid rc $?"; tail -1 gpurun_out/${TAG}_logs/soak_mapgrid.log
 timeout 300 python scripts/mapgrid_timing.py 1024 > gpurun_out/${TAG}_logs/mapgrid_timing.log 2>&1; echo "mapgrid timing rc $?"; grep '^grid_tier\|^lds_record' gpurun_out/${TAG}_logs/mapgrid_timing.log > gpurun_out/${TAG}_mapgrid_timing.txt
 du -sh gpurun_out
