@@ -38,11 +38,14 @@ def loop(fn, n=200, warm=40):
 
 
 res = {}
-cases = (("grid_tier_876_pieces", T._road(n_pts=220)), ("lds_record_44_pieces", T._road(n_pts=12, arc=0.2)))
+cases = (("grid_tier_876_pieces", T._road(n_pts=220)), ("grid_tier_876_pieces_one_map_for_all_envs", T._road(n_pts=220)),
+         ("lds_record_44_pieces", T._road(n_pts=12, arc=0.2)))
 if os.environ.get("T2D_MG_ONLY"):   # (profiling runs: the grid tier alone)
-    cases = cases[:1]
+    cases = cases[:2]
 for name, rails in cases:
     sc = T._scene(n_env, A, 17, rails, n_static=24 if name.startswith("grid") else 6)
+    if name.endswith("one_map_for_all_envs"):   # every env on the SAME map, obstacles included (what a pool on one reference map is):
+        sc["statics"] = [sc["statics"][0]] * n_env   # the library then keeps one grid and one set of registrations for all of them
     if not name.startswith("grid"):   # participants on the short road only
         keep = np.abs(np.arctan2(sc["x"], 500.0)) < 0.09
         sc["active"] = (sc["active"].astype(bool) & keep).astype(np.uint8)

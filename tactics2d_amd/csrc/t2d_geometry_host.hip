@@ -338,7 +338,33 @@ int build_map_grid(t2d_pool* p) {
     std::vector<t2d::MapItem> items;
     std::vector<std::vector<t2d::MapItem>> cells;
     const float m = t2d::kGridMargin;
+    // Envs that hold the SAME static and lane polygons -- every env of a pool on one reference map -- share ONE grid and one set of
+    // registrations (their boundary pieces are equal too: build_lane_boundary copies them): the walk's records then stay in the L2
+    // instead of being each env's own 70 KB of a 70 MB array.
+    std::unordered_map<std::string, int> first_env;
     for (int e = 0; e < E; ++e) {
+        {
+            std::string key;
+            for (int k = 0; k < 2; ++k) {
+                const auto& g = p->hgeo[k];
+                const int32_t present = g.present ? 1 : 0;
+                key.append(reinterpret_cast<const char*>(&present), sizeof present);
+                if (!g.present) continue;
+                const int l0 = g.env_off[e], l1 = g.env_off[e + 1];
+                const int v0 = g.vert_off[l0], v1 = g.vert_off[l1];
+                if (v1 > v0) key.append(reinterpret_cast<const char*>(&g.xy[2 * (size_t)v0]), sizeof(float) * 2 * (size_t)(v1 - v0));
+                for (int li = l0; li <= l1; ++li) {
+                    const int32_t rel = g.vert_off[li] - v0;
+                    key.append(reinterpret_cast<const char*>(&rel), sizeof rel);
+                }
+            }
+            const auto hit = first_env.find(key);
+            if (hit != first_env.end()) {
+                env[(size_t)e] = env[(size_t)hit->second];
+                continue;
+            }
+            first_env.emplace(std::move(key), e);
+        }
         float x0 = 0, x1 = 0, y0 = 0, y1 = 0;
         int n_parts = 0;
         for (int k = 0; k < 2; ++k) {

@@ -236,3 +236,29 @@ def test_grid_tier_edge_cases_agree_with_the_oracle(oracle, case):
         seen += int((got & (L.FLAG_COLLISION_STATIC if case == "crowded_statics" else L.FLAG_OFF_LANE)).astype(bool).sum())
     assert seen > 60, seen
     pool.close()
+
+
+def test_envs_on_the_same_map_share_one_grid_and_envs_on_another_do_not_mix_with_them(oracle):
+    """every env of a pool on one reference map holds the SAME polygons: the library keeps one grid and one set of registrations
+    for them (build_map_grid).  Five envs on one map and one env on a map of its own (other obstacles): flags == oracle for all"""
+    from tactics2d_amd import layout as L
+    from tactics2d_amd.pool import ParticipantPool
+    n_env, A = 6, 64
+    sc = _scene(n_env, A, 31, _road(n_pts=220), n_static=40)
+    sc["statics"] = [sc["statics"][0]] * 3 + [sc["statics"][4]] + [sc["statics"][0]] * 2      # env 3 has obstacles of its own
+    pool = ParticipantPool(n_env, A)
+    static, lanes = _load(pool, sc, n_env, [sc["lanes"]] * n_env)
+    assert pool.step_form(1) == "unfused"
+    rng = np.random.default_rng(2)
+    seen = 0
+    for step in range(3):
+        pool.set_actions(np.float32(rng.uniform(-2.0, 2.0, n_env * A)), np.float32(rng.uniform(-0.3, 0.3, n_env * A)))
+        pool.step(100)
+        x, y, h = (pool.download(f) for f in (L.F_X, L.F_Y, L.F_HEADING))
+        got, got_env = pool.download(L.F_FLAGS), pool.download(L.F_ENV_FLAGS)
+        want, want_env = oracle.collide(sc["rows"], n_env, A, x, y, h, sc["tid"], sc["active"], static, None, None, lanes, 0)
+        assert np.array_equal(got, want), (step, int((got != want).sum()), np.nonzero(got != want)[0][:8])
+        assert np.array_equal(got_env, want_env), step
+        seen += int((got & L.FLAG_COLLISION_STATIC).astype(bool).sum())
+    assert seen > 5, seen
+    pool.close()
