@@ -6,6 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export PYTHONUNBUFFERED=1
 mkdir -p gpurun_out/${TAG}_logs
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_logs/pytest_gpu.log 2>&1; echo "gpu tests rc $?"; tail -3 gpurun_out/${TAG}_logs/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_logs/smoke.log 2>&1; echo "smoke rc $?"; tail -1 gpurun_out/${TAG}_logs/smoke.log
 bash scripts/profile_round.sh $TAG > gpurun_out/${TAG}_logs/profile_round.log 2>&1; echo "profile round rc $?"
 cp gpurun_out/prof_$TAG/*.log gpurun_out/${TAG}_logs/ 2>/dev/null; rm -rf gpurun_out/prof_$TAG
 # (the bench reads profiles/traffic_latest.json: the fresh one is put in place for the two lines below)
