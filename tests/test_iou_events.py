@@ -245,3 +245,59 @@ def test_iou_against_exact_rational_arithmetic(oracle):
         want = _exact_iou(A, B)
         worst = max(worst, abs(got - want))
     assert worst <= 5e-13, worst     # 1e-4 below the tightest decision threshold in use (NoAction: IoU > 0.999)
+
+
+def test_status_epilogue_reproduces_the_reference_executed_step_by_step(oracle):
+    """tests/golden/status_epilogue.npz holds what the reference's OWN definitions -- ParkingEnv.step / _get_reward /
+    _get_relative_pose, _ParkingScenarioManager.check_status, the TimeExceed / NoAction / Arrival classes and the status enums,
+    executed where they lie by oracle/gen_golden_status.py -- make of 48 scripted episodes (reaching the target, standing still,
+    running out of steps, colliding, leaving the boundary, wandering): 2241 steps.  Geometry is not what it pins: the IoUs the
+    reference's detectors saw are the ones the C oracle computes for the same quads (stored in the fixture and re-checked here),
+    collision / out-of-bound verdicts are scripted flags.  Everything behind them is held against the reference: the detectors'
+    counters and thresholds, the order of the checks, the status values (the NO_ACTION-in-traffic_status quirk included),
+    terminated / truncated, every term of the reward."""
+    import os
+    from tactics2d_amd import layout as L
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "status_epilogue.npz"))
+    from tactics2d_amd.participant import full_type_table
+    rows, _ = full_type_table()
+    tid = np.uint8([int(g["type_id"])])
+    Lg, Wd = float(rows[tid[0], L.P_LENGTH]), float(rows[tid[0], L.P_WIDTH])
+    ep_ids = g["episode"]
+    seen = set(); worst = 0.0; steps = 0
+    for e in np.unique(ep_ids):
+        idx = np.nonzero(ep_ids == e)[0]
+        k0 = idx[0]
+        cfg = oracle.make_config(max_step=int(g["max_step"][k0]), check_arrival=1, check_no_action=1, no_action_max_step=100, shaped_reward=1)
+        ep = oracle.EpisodeState(1, np.float32([g["target"][k0]]), None, np.float32([[g["x"][k0], g["y"][k0]]]))
+        cnt = np.zeros(1, np.int32); frame = np.zeros(1, np.int32)
+        prev = None
+        for k in idx:
+            x, y, h = np.float32([g["x"][k]]), np.float32([g["y"][k]]), np.float32([g["heading"][k]])
+            # the scripted IoUs ARE the oracle's for these quads (the fixture was made with the same functions)
+            q = oracle.ccw(oracle.pose_obb(float(x[0]), float(y[0]), float(h[0]), Lg, Wd, trig=0))
+            assert oracle.quad_iou(q, oracle.ccw(np.float32(g["target"][k]))) == g["iou_target"][k]
+            if prev is not None:
+                assert oracle.quad_iou(q, prev) == g["iou_last"][k]
+            prev = q
+            st, rw, iou = oracle.status_ex(cfg, 1, np.uint32([g["flags"][k]]), 100, cnt, frame, rows, x, y, h, tid, ep)
+            want = [int(g["scenario"][k]), int(g["traffic"][k]), int(g["terminated"][k]), int(g["truncated"][k])]
+            assert st[0].tolist() == want, (int(e), int(k - k0), st[0].tolist(), want)
+            if np.isnan(g["iou"][k]):
+                assert np.isnan(iou[0]), (int(e), int(k - k0))
+            else:
+                assert iou[0] == np.float32(g["iou"][k]), (int(e), int(k - k0), float(iou[0]), float(g["iou"][k]))
+            # (the oracle's scales 0.001 / 0.1 are fp32 fields of t2d_status_config: 5e-8 relative on those terms)
+            err = abs(float(rw[0]) - float(g["reward"][k]))
+            assert err <= 2e-7 * max(1.0, abs(float(g["reward"][k]))), (int(e), int(k - k0), float(rw[0]), float(g["reward"][k]))
+            worst = max(worst, err); steps += 1
+            seen.add((want[0], want[1]))
+            # _get_relative_pose (:192-204): the formulas tests/test_gpu_envs.py holds the packed frame against, bit for bit
+            tcx, tcy = ep.target_c[0]
+            fx, fy, fh, th = float(x[0]), float(y[0]), float(h[0]), float(g["target_heading"][k])
+            assert g["diff_position"][k] == np.linalg.norm(np.array([tcx, tcy]) - np.array((fx, fy)))
+            assert g["diff_angle"][k] == np.arctan2(tcy - fy, tcx - fx) - fh and g["diff_heading"][k] == th - fh
+        assert cnt[0] == len(idx)
+    # every branch of check_status was walked: normal, completed, time exceeded, out of bound, failed + static collision, no action
+    assert {(1, 1), (2, 1), (3, 1), (4, 1), (6, 3), (1, 5)} <= seen, seen
+    assert steps > 2000
