@@ -328,3 +328,16 @@ def test_random_lanes_tile_exactly_and_agree_with_the_undivided_ring(oracle):
             assert oracle.pose_in_lane_union(pose, (float(x), float(y)), pieces) == want, (case, float(x), float(y), float(h))
             n_pose += 1; inside += want
     assert n_pose == 240 and 0.1 < inside / n_pose < 0.9, (n_pose, inside)
+
+
+def test_map_boundary_equals_the_reference_property_executed():
+    """tests/golden/map_boundary.json: Map.boundary (map/element/map.py:92-167) EXECUTED by oracle/gen_golden_tables.py on 40
+    maps of plain data holders (nodes, lane and road-line polylines, area exteriors; coordinates of 1e1 .. 5e3 m, rounded to 0-5
+    decimals; the empty map; integer coordinates) -- mapgeom.map_boundary and the duck-typed adapter give the same four numbers"""
+    import json, os, types
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "map_boundary.json")))
+    assert len(cases) == 40
+    for c in cases:
+        sets = [c["nodes"]] + c["lanes"] + c["areas"] + c["roadlines"]
+        assert list(MG.map_boundary(*[s for s in sets if len(s)])) == c["boundary"], c
+    assert cases[0]["boundary"] == [0.0, 0.0, 0.0, 0.0] and cases[1]["boundary"] == [2.0, 2.0, -3.0, -3.0]
