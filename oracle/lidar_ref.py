@@ -8,11 +8,11 @@ shapely at import time):
 The obstacle-level range filter of _rotate_and_filter_obstacles (`distance(origin) <
 max_perception_distance`) cannot change a result -- an obstacle entirely beyond the range only yields
 intersections the per-ray range filter removes anyway -- and is not restated.
-PARITY: the scan proper -- lidar.py:160-221, the determinant solve, its eight filters, the parallel-line rule,
-min / clip / inf -- is PINNED: oracle/gen_golden_lidar.py executes those statements of the reference where they lie
-(no import of the module, nothing of shapely stood in for) and tests/test_lidar.py holds this restatement against
-the result bit for bit (tests/golden/lidar.npz, 167 scenes).  What stays restated here is the two-line affine
-transform into the sensor frame, which the reference hands to shapely.affinity.affine_transform.
+PARITY: PINNED.  oracle/gen_golden_lidar.py executes the reference's statements where they lie -- _rotate_and_filter_obstacles
+(lidar.py:97-126: the matrix, the range filter) whole and _scan_obstacles from the beam table to the end (:160-221: the
+determinant solve, its eight filters, the parallel-line rule, min / clip / inf) -- with stand-ins for exactly two shapely
+calls, each its documented rule (affine_transform with a 6-element matrix; distance from a ring to a point), and
+tests/test_lidar.py holds this restatement against the result bit for bit (tests/golden/lidar.npz, 167 scenes).
 """
 import numpy as np
 

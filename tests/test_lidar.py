@@ -149,8 +149,9 @@ def test_numpy_restatement_equals_the_reference_block_bit_for_bit():
     oracle/gen_golden_lidar.py -- make of 167 scenes (random quads around the sensor, 7 .. 1000 beams, ranges 10 .. 35 m; an edge
     along a beam, through the sensor, exactly at the range, the sensor inside a ring, triangles and hexagons, no obstacle).
     oracle/lidar_ref.py, the restatement every other lidar test is held against, must give the same fp64 values bit for bit:
-    with this the scan's determinant solve, its eight filters and the parallel-line rule are PINNED by the reference; what is
-    left restated is the two-line affine transform the reference hands to shapely (see the generator's header)."""
+    with this the sensor-frame matrix, the scan's determinant solve, its eight filters and the parallel-line rule are PINNED by
+    the reference; what is stood in for is shapely's affine_transform and ring-to-point distance, each by its documented rule
+    (see the generator's header)."""
     from oracle import lidar_ref
     n_beams = hits = 0
     for c, ego, rings, R, dens, want in _lidar_golden():
