@@ -23,8 +23,17 @@
  *   ParkingLotGenerator : PARITY UNPINNED (numpy global MT19937 stream + shapely predicates; no reference test
  *              of its output).  t2do_generate_parking restates distributions, draw order, control flow and
  *              predicate semantics on a counter stream of its own; pinned by property tests (tests/test_generator.py).
- *   lidar    : the reference module imports shapely (cannot run here): oracle/lidar_ref.py restates its
- *              numpy expression sequence; PARITY UNPINNED against the reference itself.
+ *   lidar    : PINNED (round 6).  The reference module imports shapely (cannot be imported here), but its numeric code needs
+ *              none of it: oracle/gen_golden_lidar.py executes _rotate_and_filter_obstacles (lidar.py:97-126) and the
+ *              statements of _scan_obstacles from the beam table on (:160-221) where they lie -> tests/golden/lidar.npz;
+ *              oracle/lidar_ref.py equals them bit for bit, t2do_lidar to fp32 rounding with the same hits (tests/test_lidar.py).
+ *   status / reward epilogue : PINNED (round 6).  oracle/gen_golden_status.py executes ParkingEnv.step, _get_reward,
+ *              _get_relative_pose, _ParkingScenarioManager.check_status and the TimeExceed / NoAction / Arrival classes
+ *              where they lie on 48 scripted episodes (the IoUs their detectors see are t2do_quad_iou's for the same
+ *              quads: geometry stays unpinned) -> tests/golden/status_epilogue.npz; t2do_status_ex reproduces every
+ *              status, flag and reward (tests/test_iou_events.py).
+ *   parameter tables, Vehicle.load_from_template / get_pose, Map.boundary : PINNED (round 6) by loading / executing the
+ *              reference's definitions (oracle/gen_golden_tables.py; tests/test_host.py, tests/test_mapgeom.py).
  *
  * Every function cites the reference file:line it follows (paths relative to the
  * tactics2d repo root).  Arithmetic is IEEE fp64, evaluated left-to-right exactly as the
