@@ -71,6 +71,9 @@ class BatchedTrajectory:
             raise ValueError("add_state expects a BatchedState")
         frame = state.frame
         if frame in self._by_frame:
+            # (the reference overwrites BEFORE it checks the order, :131-135: a repeated frame that also lies before the last one
+            # replaces the stored state and THEN raises -- found by replaying the reference: tests/golden/trajectory_kats.json)
+            self._by_frame[frame] = state
             _log.warning("trajectory %s: state at time stamp %s overwritten", self.id_, frame)
         if self._stamps and frame < self._stamps[-1]:
             raise KeyError(f"trajectory {self.id_}: time stamp {frame} lies before the last one ({self._stamps[-1]})")

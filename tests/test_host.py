@@ -364,3 +364,61 @@ def test_vehicle_rows_and_poses_equal_the_reference_methods_executed(oracle):
             assert np.abs(got - np.asarray(p["pose"])).max() <= 2e-13, (name, got, p["pose"])
             n_pose += 1
     assert n_pose == 48
+
+
+def test_batched_trajectory_replays_the_reference_operation_by_operation():
+    """tests/golden/trajectory_kats.json: 33 scripted sequences (457 operations, 61 of them raising) run on the reference's own
+    `Trajectory` by oracle/gen_golden_trajectory.py -- add_state (duplicates, earlier stamps, uneven intervals, a non-State),
+    get_state, has_state, get_trace, the three reset modes -- with what the reference answered after EVERY operation: the value or
+    the exception's type, frames, len, stable_freq, first / last / current / initial frame, average_speed.  BatchedTrajectory (a
+    batch of two: the second participant carries the same numbers shifted) answers the same."""
+    import warnings
+    from tactics2d_amd.physics import BatchedState
+    from tactics2d_amd.history import BatchedTrajectory
+    seqs = H.load_json("trajectory_kats.json")
+    n_ops = 0
+    mk = lambda frame, x, y, speed: BatchedState(frame=frame, x=[x, x + 1.0], y=[y, y - 1.0], heading=[0.0, 0.0], speed=[speed, 2.0 * speed])
+    for si, seq in enumerate(seqs):
+        t = BatchedTrajectory(id_=3)
+        for oi, rec in enumerate(seq):
+            op = rec["op"]; kind = op[0]; got = None; raised = None
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    if kind == "add":
+                        t.add_state(mk(*op[1:]))
+                    elif kind == "add_bad":
+                        t.add_state("not a state")
+                    elif kind == "get":
+                        s = t.get_state(op[1])
+                        got = None if s is None else dict(frame=s.frame, speed=float(s.speed[0]), x=float(s.x[0]))
+                    elif kind == "has":
+                        got = bool(t.has_state(op[1]))
+                    elif kind == "trace":
+                        tr = t.get_trace(None if op[1] is None else tuple(op[1]))
+                        got = [[float(p[0][0]), float(p[1][0])] for p in tr]     # (a location is (x[batch], y[batch]))
+                    elif kind == "reset":
+                        t.reset(None if op[1] is None else mk(*op[1]), keep_history=op[2])
+            except Exception as exc:   # noqa: BLE001 -- compared by type below
+                raised = type(exc).__name__
+            where = (si, oi, op)
+            assert raised == rec.get("raises"), (where, raised, rec.get("raises"))
+            if raised is None and kind in ("get", "has", "trace"):
+                want = rec["result"]
+                if kind == "get" and want is not None:
+                    assert got["frame"] == want["frame"] and got["speed"] == np.float32(want["speed"]) and got["x"] == np.float32(want["x"]), (where, got, want)
+                elif kind == "trace":
+                    assert np.allclose(got, want, rtol=1e-6, atol=0) if want else got == [], (where, got, want)
+                else:
+                    assert got == want, (where, got, want)
+            a = rec["after"]
+            cur = t.get_state()
+            assert list(t.frames) == a["frames"] and len(t) == a["n"] and bool(t.stable_freq) == a["stable_freq"], (where, list(t.frames), a)
+            assert t.first_frame == a["first_frame"] and t.last_frame == a["last_frame"], where
+            assert (None if cur is None else cur.frame) == a["current_frame"], (where, a)
+            assert (None if t.initial_state is None else t.initial_state.frame) == a["initial_frame"], where
+            assert (None if t.last_state is None else t.last_state.frame) == a["last_state_frame"], where
+            if a["average_speed"] is not None and len(t):
+                assert np.allclose(np.asarray(t.average_speed)[0], a["average_speed"], rtol=1e-6), (where, t.average_speed, a["average_speed"])
+            n_ops += 1
+    assert n_ops == 457
