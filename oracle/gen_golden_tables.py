@@ -9,6 +9,9 @@ TEST INFRASTRUCTURE (build container only; the reference tree is mounted read-on
     file and EXECUTED on a blank attribute holder, with recorders where they hand their results to shapely (`LinearRing`: the
     bounding box and its vertex order; `affine_transform`: the matrix) -> tests/golden/vehicle_templates_loaded.json: max_accel
     (the rounded 0-100 rule), speed / accel ranges, bbox, and six poses per template.
+  * the literal constants of `tactics2d/envs/parking.py` (module level, `ParkingEnv`, `_ParkingScenarioManager`, the defaults of
+    `ParkingEnv.__init__`: read from the parsed file -- the module needs gymnasium) and the enums of `tactics2d/traffic/status.py`
+    (loaded as a file) -> tests/golden/parking_constants.json.
   * `Map.boundary` (`tactics2d/map/element/map.py:92-167`) reads `.nodes` / `.lanes` / `.areas` / `.roadlines` of the map and,
     of every element, `.x` / `.y` or `.geometry(.exterior).coords`: the property's getter is taken from the parsed file and
     EXECUTED, unmodified, on maps made of plain data holders with seeded coordinates (the module itself cannot be imported:
@@ -125,6 +128,39 @@ def main():
                               accel_range=[float(v) for v in holder.accel_range], bbox=holder._bbox, poses=poses)
     json.dump(vehicles, open(os.path.join(OUT, "vehicle_templates_loaded.json"), "w"))
     print(f"{len(vehicles)} vehicles x 6 poses -> tests/golden/vehicle_templates_loaded.json")
+    # ---- the literal constants of envs/parking.py and traffic/status.py (the module cannot be imported: gymnasium, shapely) -------
+    ep = os.path.join(args.ref, "tactics2d", "envs", "parking.py")
+    etree = ast.parse(open(ep).read(), filename=ep)
+    consts = {}
+
+    def literal_assigns(body, prefix, env):
+        for st in body:
+            if isinstance(st, ast.Assign) and len(st.targets) == 1 and isinstance(st.targets[0], ast.Name):
+                try:
+                    val = eval(compile(ast.Expression(st.value), ep, "eval"), {"__builtins__": {"int": int}}, dict(env))
+                except Exception:      # noqa: BLE001 -- not a literal (a call into gymnasium ...): not a constant
+                    continue
+                env[st.targets[0].id] = val
+                consts[prefix + st.targets[0].id] = val
+    module_env = {}
+    literal_assigns(etree.body, "", module_env)
+    pcls = next(n for n in etree.body if isinstance(n, ast.ClassDef) and n.name == "ParkingEnv")
+    literal_assigns(pcls.body, "ParkingEnv.", dict(module_env))
+    mcls = next(n for n in pcls.body if isinstance(n, ast.ClassDef) and n.name == "_ParkingScenarioManager")
+    literal_assigns(mcls.body, "ParkingEnv._ParkingScenarioManager.", dict(module_env))
+    init = next(n for n in pcls.body if isinstance(n, ast.FunctionDef) and n.name == "__init__")
+    defaults = dict(zip([a.arg for a in init.args.args][-len(init.args.defaults):],
+                        [eval(compile(ast.Expression(dv), ep, "eval"), {"__builtins__": {"int": int}}) for dv in init.args.defaults]))
+    consts["ParkingEnv.__init__.defaults"] = defaults
+    sp = os.path.join(args.ref, "tactics2d", "traffic", "status.py")
+    sspec = importlib.util.spec_from_file_location("t2d_ref_status", sp)
+    sm = importlib.util.module_from_spec(sspec)
+    sspec.loader.exec_module(sm)
+    consts["ScenarioStatus"] = {e.name: int(e) for e in sm.ScenarioStatus}
+    consts["TrafficStatus"] = {e.name: int(e) for e in sm.TrafficStatus}
+    jsonable = lambda v: {str(k): jsonable(x) for k, x in v.items()} if isinstance(v, dict) else ([jsonable(x) for x in v] if isinstance(v, (list, tuple)) else v)
+    json.dump(jsonable(consts), open(os.path.join(OUT, "parking_constants.json"), "w"), indent=1, sort_keys=True)
+    print("constants:", sorted(consts))
 
 
 if __name__ == "__main__":

@@ -422,3 +422,30 @@ def test_batched_trajectory_replays_the_reference_operation_by_operation():
                 assert np.allclose(np.asarray(t.average_speed)[0], a["average_speed"], rtol=1e-6), (where, t.average_speed, a["average_speed"])
             n_ops += 1
     assert n_ops == 457
+
+
+def test_env_constants_and_status_enums_equal_the_reference_literals():
+    """tests/golden/parking_constants.json: the literal constants of envs/parking.py (read from the parsed file: the module needs
+    gymnasium) and the two enums of traffic/status.py (loaded as a file) -- the mirror's action limits, discrete actions, default
+    step limit, lidar beams / range and every status name and value are the reference's"""
+    import inspect
+    from tactics2d_amd import envs as E, traffic as T, layout as L
+    c = H.load_json("parking_constants.json")
+    assert (E.MAX_STEER, E.MAX_ACCEL) == (c["MAX_STEER"], c["MAX_ACCEL"])
+    assert (E.VecParkingEnv._max_steer, E.VecParkingEnv._max_accel) == (c["ParkingEnv._max_steer"], c["ParkingEnv._max_accel"])
+    assert {str(k): list(v) for k, v in E.VecParkingEnv._discrete_actions.items()} == c["ParkingEnv._discrete_actions"]
+    sig = inspect.signature(E.VecParkingEnv.__init__).parameters
+    d = c["ParkingEnv.__init__.defaults"]
+    assert sig["max_step"].default == d["max_step"] and sig["continuous"].default == d["continuous"] and sig["type_proportion"].default == d["type_proportion"]
+    assert sig["lidar_beams"].default == c["ParkingEnv._ParkingScenarioManager._lidar_line"]
+    assert {e.name: int(e) for e in T.ScenarioStatus} == c["ScenarioStatus"]
+    assert {e.name: int(e) for e in T.TrafficStatus} == c["TrafficStatus"]
+    # the C ABI's status codes are the same numbers (include/t2d.h)
+    import os, re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "t2d.h")).read()
+    abi = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define T2D_((?:SCENARIO|TRAFFIC)_[A-Z_]+)\s+(\d+)", hdr)}
+    for name, val in c["ScenarioStatus"].items():
+        assert abi["SCENARIO_" + name] == val, name
+    for name in ("NORMAL", "COLLISION_STATIC", "COLLISION_DYNAMIC", "OFF_LANE"):
+        assert abi["TRAFFIC_" + name] == c["TrafficStatus"][name], name
+    assert abi["TRAFFIC_NO_ACTION_QUIRK"] == c["ScenarioStatus"]["NO_ACTION"]      # parking.py:373
