@@ -428,7 +428,7 @@ GEN_START_FLIPPED, GEN_TARGET_FLIPPED = 32, 64
 
 
 def generate_parking(seed, n_env, type_proportion=0.5, vehicle_size=(5.3, 2.5), first_env=0, trig=1):
-    """ParkingLotGenerator.generate restated for n_env scenes (row f4; parity unpinned, see t2d_oracle.c).
+    """ParkingLotGenerator.generate restated for n_env scenes (row f4; pinned by replay, see t2d_oracle.c).
     Returns a dict of arrays: quads (n, 12, 4, 2) f32, quad_id (n, 12), n_quads (n,), start (n, 3) f64,
     target (n, 4, 2) f32, target_heading (n,) f64, boundary (n, 4) f32, info (n,) u32."""
     out = dict(quads=np.zeros((n_env, GEN_MAX_QUADS, 4, 2), np.float32), quad_id=np.zeros((n_env, GEN_MAX_QUADS), np.int32),
@@ -447,3 +447,27 @@ def generate_parking(seed, n_env, type_proportion=0.5, vehicle_size=(5.3, 2.5), 
     finally:
         lib().t2do_set_trig(0)
     return out
+
+
+def generate_parking_replay(tape_kind, tape_val, type_proportion=0.5, vehicle_size=(5.3, 2.5), trig=1):
+    """ONE scene of the restated generator on a tape of recorded draws (oracle/gen_golden_generator.py: the values numpy handed
+    the reference's own generate()).  Returns (scene dict as generate_parking, draws consumed, index of the first draw whose kind
+    did not match the tape's -- or that ran past its end --, -1 = none)."""
+    out = dict(quads=np.zeros((1, GEN_MAX_QUADS, 4, 2), np.float32), quad_id=np.zeros((1, GEN_MAX_QUADS), np.int32),
+               n_quads=np.zeros(1, np.int32), start=np.zeros((1, 3)), target=np.zeros((1, 4, 2), np.float32),
+               target_heading=np.zeros(1), boundary=np.zeros((1, 4), np.float32), info=np.zeros(1, np.uint32))
+    kind = np.ascontiguousarray(tape_kind, np.int32); val = np.ascontiguousarray(tape_val, np.float64)
+    desync = np.zeros(1, np.int32)
+    f = lib().t2do_generate_parking_replay
+    f.restype = C.c_int
+    f.argtypes = [_f64p, np.ctypeslib.ndpointer(np.int32, flags="C"), C.c_int, C.c_double, C.c_double, C.c_double, _f32p,
+                  np.ctypeslib.ndpointer(np.int32, flags="C"), np.ctypeslib.ndpointer(np.int32, flags="C"), _f64p, _f32p,
+                  _f64p, _f32p, np.ctypeslib.ndpointer(np.uint32, flags="C"), np.ctypeslib.ndpointer(np.int32, flags="C")]
+    lib().t2do_set_trig(trig)
+    try:
+        used = f(val, kind, int(kind.size), float(type_proportion), float(vehicle_size[0]), float(vehicle_size[1]),
+                 out["quads"], out["quad_id"], out["n_quads"], out["start"], out["target"], out["target_heading"],
+                 out["boundary"], out["info"], desync)
+    finally:
+        lib().t2do_set_trig(0)
+    return out, int(used), int(desync[0])

@@ -20,9 +20,11 @@
  *              tests/test_iou_events.py) -- the mathematical values GEOS evaluates robustly.
  *   IDM controller, verify_state, SingleTrackDrift : PINNED by golden vectors produced by running the
  *              reference (oracle/gen_golden_idm.py, gen_golden_verify.py, gen_golden_drift.py).
- *   ParkingLotGenerator : PARITY UNPINNED (numpy global MT19937 stream + shapely predicates; no reference test
- *              of its output).  t2do_generate_parking restates distributions, draw order, control flow and
- *              predicate semantics on a counter stream of its own; pinned by property tests (tests/test_generator.py).
+ *   ParkingLotGenerator : the restatement is PINNED by replay (round 6).  t2do_generate_parking restates distributions, draw
+ *              order, control flow and predicate semantics on a counter stream of its own, so its scenes are not numpy's;
+ *              oracle/gen_golden_generator.py executes the reference's own class on 240 seeds of numpy's stream with every
+ *              draw recorded (exact stand-ins for its shapely calls), and t2do_generate_parking_replay, fed the same draws,
+ *              consumes them in the same order and yields the same scenes (tests/test_generator.py).  Property tests beside it.
  *   lidar    : PINNED (round 6).  The reference module imports shapely (cannot be imported here), but its numeric code needs
  *              none of it: oracle/gen_golden_lidar.py executes _rotate_and_filter_obstacles (lidar.py:97-126) and the
  *              statements of _scan_obstacles from the beam table on (:160-221) where they lie -> tests/golden/lidar.npz;
@@ -1519,8 +1521,8 @@ void t2do_drift_batch(const double* rows, int row_stride, int n, const float* x,
 
 /* ------------------------------------------------------------------------------------------------
  * Row f4: ParkingLotGenerator.generate (map/generator/generate_parking_lot.py:239-444) restated per
- * env.  PARITY UNPINNED: the reference draws from numpy's global MT19937 stream and evaluates its
- * predicates in shapely/GEOS (neither can run here), so this follows the reference's sampling
+ * env.  The reference draws from numpy's global MT19937 stream and evaluates its predicates in shapely/GEOS
+ * (PINNED by replay on recorded draws: see the header), so this follows the reference's sampling
  * distributions, draw ORDER, geometric predicates and control flow -- including the two behaviours
  * that follow from its bookkeeping: side vehicles appended during rejected attempts stay in the
  * `obstacles` list (:283-285, :320-322), and Map.add_area keys areas by id so a later obstacle with
@@ -1534,15 +1536,42 @@ void t2do_drift_batch(const double* rows, int row_stride, int n, const float* x,
 #define PI_D 3.141592653589793
 #define M_PI_2_D (PI_D / 2)
 typedef struct { uint64_t s; } gen_rng;
+/* REPLAY (tests only: t2do_generate_parking_replay): the draws come from a tape of the VALUES numpy handed the reference when
+ * its own generate() ran (oracle/gen_golden_generator.py records every np.random call): kind 0 = a uniform in [0, 1)
+ * (np.random.rand() / uniform()), 1 = np.random.uniform(a, b), 2 = np.random.normal(mean, std).  A draw of another kind than the
+ * tape's next entry, or a draw past its end, is a desynchronisation: the restatement asked for its random numbers in another
+ * ORDER than the reference.  Not thread safe: one env at a time. */
+static const double* g_tape_val = NULL;
+static const int32_t* g_tape_kind = NULL;
+static int g_tape_n = 0, g_tape_pos = 0, g_tape_bad = -1;
+static int tape_take(int kind, double* out) {
+    if (!g_tape_val) return 0;
+    if (g_tape_pos >= g_tape_n || g_tape_kind[g_tape_pos] != kind) {
+        if (g_tape_bad < 0) g_tape_bad = g_tape_pos;
+        *out = kind == 2 ? 0.0 : 0.5;
+        if (g_tape_pos < g_tape_n) ++g_tape_pos;
+        return 1;
+    }
+    *out = g_tape_val[g_tape_pos++];
+    return 1;
+}
 static double gen_u(gen_rng* r) {
+    double t;
+    if (tape_take(0, &t)) return t;
     uint64_t z = (r->s += 0x9E3779B97F4A7C15ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z ^= z >> 31;
     return (double)(z >> 11) * (1.0 / 9007199254740992.0);
 }
-static double gen_uniform(gen_rng* r, double a, double b) { return a + (b - a) * gen_u(r); }
+static double gen_uniform(gen_rng* r, double a, double b) {
+    double t;
+    if (tape_take(1, &t)) return t;
+    return a + (b - a) * gen_u(r);
+}
 static double gen_normal(gen_rng* r, double mean, double std) {
+    double t;
+    if (tape_take(2, &t)) return t;
     double u1 = 1.0 - gen_u(r), u2 = gen_u(r);
     double rad = sqrt(-2.0 * (g_trig ? t2do_log(u1) : log(u1)));
     return mean + std * (rad * T_cos(TWO_PI * u2));
@@ -1780,6 +1809,22 @@ void t2do_generate_parking(uint64_t seed, int64_t env0, int n_env, double type_p
         info[e] = flags | (bay ? T2D_GEN_BAY : 0u) | ((uint32_t)(attempts > 255 ? 255 : attempts) << 8) |
                   ((uint32_t)(s_attempts > 255 ? 255 : s_attempts) << 16);
     }
+}
+
+/* One scene from a tape of recorded draws (see g_tape_val above).  Returns the number of draws consumed; *desync = index of the
+ * first draw that did not match the tape's kind or ran past its end, -1 = none. */
+int t2do_generate_parking_replay(const double* tape_val, const int32_t* tape_kind, int n_tape, double type_proportion, double len,
+                                 double wid, float* quads, int32_t* quad_id, int32_t* n_quads, double* start, float* target,
+                                 double* target_heading, float* boundary, uint32_t* info, int32_t* desync) {
+    const int threads = g_threads;
+    g_threads = 1;
+    g_tape_val = tape_val; g_tape_kind = tape_kind; g_tape_n = n_tape; g_tape_pos = 0; g_tape_bad = -1;
+    t2do_generate_parking(0, 0, 1, type_proportion, len, wid, quads, quad_id, n_quads, start, target, target_heading, boundary, info);
+    const int used = g_tape_pos;
+    if (desync) *desync = g_tape_bad;
+    g_tape_val = NULL; g_tape_kind = NULL; g_tape_n = 0;
+    g_threads = threads;
+    return used;
 }
 
 int t2do_abi_version(void) { return T2D_ABI_VERSION; }

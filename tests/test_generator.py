@@ -525,3 +525,36 @@ def test_layout_relations_of_the_reference_construction(oracle, scenes):
             top = max(q[e, k, :, 1].max() for k in early)
             assert scenes["start"][e, 1] >= top + 1.8 - 1e-6
     assert min(checked.values()) > 0.8 * len(range(0, N, 5))          # the 5 % drop removes a few
+
+
+def test_restated_generator_replays_the_reference_draw_for_draw(oracle):
+    """tests/golden/generator_replay.npz: the reference's OWN ParkingLotGenerator class (map/generator/generate_parking_lot.py:19-444,
+    executed where it lies by oracle/gen_golden_generator.py, with exact stand-ins for the shapely calls it makes) run on 240 seeds
+    of numpy's global stream, every value np.random handed it recorded.  Fed the same draws, the build's restatement
+    (t2do_generate_parking -- what the device generator is bit-identical to) must ask for them in the same ORDER and of the same
+    kind, consume all of them, and produce the same scene: bay / parallel, every obstacle of Map.areas in order with its id (the
+    stale side vehicles of rejected attempts, the "0003" id collision, the 5 % drops included), the target, its heading, the start
+    pose (flipped or not) and the boundary."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "generator_replay.npz"))
+    n = len(g["seed"])
+    assert n == 240
+    n_draws = n_areas = 0
+    worst_q = worst_s = 0.0
+    for c in range(n):
+        t0, t1 = g["tape_off"][c], g["tape_off"][c + 1]
+        sc, used, desync = oracle.generate_parking_replay(g["tape_kind"][t0:t1], g["tape_val"][t0:t1], float(g["type_proportion"][c]))
+        assert desync == -1 and used == t1 - t0, (c, desync, used, int(t1 - t0))
+        a0, a1 = g["area_off"][c], g["area_off"][c + 1]
+        k = int(sc["n_quads"][0])
+        assert k == a1 - a0 and sc["quad_id"][0, :k].tolist() == g["area_id"][a0:a1].tolist(), (c, sc["quad_id"][0, :k].tolist(), g["area_id"][a0:a1].tolist())
+        assert bool(sc["info"][0] & oracle.GEN_BAY) == bool(g["bay"][c]), c
+        if k:
+            worst_q = max(worst_q, float(np.abs(sc["quads"][0, :k].astype(np.float64) - g["area_quad"][a0:a1]).max()))
+        worst_q = max(worst_q, float(np.abs(sc["target"][0].astype(np.float64) - g["target"][c]).max()))
+        worst_s = max(worst_s, float(np.abs(sc["start"][0] - g["start"][c]).max()), abs(float(sc["target_heading"][0]) - float(g["target_heading"][c])))
+        assert np.array_equal(sc["boundary"][0], np.float32(g["boundary"][c])), (c, sc["boundary"][0], g["boundary"][c])
+        n_draws += int(t1 - t0); n_areas += k
+    assert worst_q < 4e-6 and worst_s < 1e-9, (worst_q, worst_s)      # (the scene's quads are fp32)
+    assert n_draws > 10000 and n_areas > 1500
+    assert 0.3 < g["bay"].mean() < 0.8 and set(np.unique(g["type_proportion"]).tolist()) == {0.0, 0.5, 0.8, 1.0}
