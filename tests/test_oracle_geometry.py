@@ -585,3 +585,38 @@ def test_piece_clear_of_the_pose_support_is_a_miss(oracle):
         clear_n += clear; meets_n += meets
         assert not (clear and meets), (piece, P)
     assert clear_n > 1500 and meets_n > 1000, (clear_n, meets_n)
+
+
+@pytest.mark.parametrize("trig", [1, 0])
+def test_static_collision_and_out_bound_equal_the_reference_detectors_executed(oracle, trig):
+    """tests/golden/events_static_outbound.npz: the reference's StaticCollision and OutBound classes and Vehicle.get_pose, EXECUTED
+    by oracle/gen_golden_events.py on 1500 scenes (an ego box of template or random size, 0-6 convex obstacles of 3-6 vertices
+    around it, a boundary that sometimes cuts it, sometimes None) with exact stand-ins for the shapely calls they make.  The
+    oracle's event step gives the same two verdicts for every scene: the pose's vertices, which predicate is asked of which
+    object, `any` over the obstacles, the boundary tuple's order and the negation are the reference's.  (trig = 0: the
+    deterministic sincos every kernel uses moves a vertex by <= 1 ulp -- a verdict could only differ on an exact touch.)"""
+    import os
+    from tactics2d_amd import layout as L
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "events_static_outbound.npz"))
+    n = len(g["ego"])
+    assert n == 1500
+    # one env per scene, one participant; a parameter row per scene carries the box size
+    rows = np.zeros((32, 24)); rows[:, L.P_SHAPE] = L.SHAPE_OBB; rows[:, L.P_MODEL] = L.MODEL_KINEMATICS
+    mism = 0
+    for c0 in range(0, n, 32):          # 32 type rows at a time (the table's capacity)
+        c1 = min(n, c0 + 32)
+        k = c1 - c0
+        rows[:k, L.P_LENGTH] = g["size"][c0:c1, 0]; rows[:k, L.P_WIDTH] = g["size"][c0:c1, 1]
+        eo = (g["obs_off"][c0:c1 + 1] - g["obs_off"][c0]).astype(np.int32)
+        p0, p1 = g["obs_off"][c0], g["obs_off"][c1]
+        vo = (g["obs_vert_off"][p0:p1 + 1] - g["obs_vert_off"][p0]).astype(np.int32)
+        xy = g["obs_xy"][g["obs_vert_off"][p0]:g["obs_vert_off"][p1]]
+        b = g["boundary"][c0:c1]
+        valid = (~np.isnan(b[:, 0])).astype(np.uint8)
+        flags, _ = oracle.collide(rows, k, 1, g["ego"][c0:c1, 0], g["ego"][c0:c1, 1], g["ego"][c0:c1, 2], np.arange(k, dtype=np.uint8),
+                                  np.ones(k, np.uint8), (eo, vo, xy) if p1 > p0 else None, np.float32(np.nan_to_num(b)), valid, None, trig)
+        got_static = (flags & L.FLAG_COLLISION_STATIC) != 0
+        got_out = (flags & L.FLAG_OUT_BOUND) != 0
+        mism += int((got_static != (g["static"][c0:c1] != 0)).sum()) + int((got_out != (g["out"][c0:c1] != 0)).sum())
+    assert mism == 0, mism
+    assert 300 < int(g["static"].sum()) < 800 and 200 < int(g["out"].sum()) < 800
